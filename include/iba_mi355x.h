@@ -1,0 +1,227 @@
+/*
+ * iba_mi355x.h — C ABI of the MI355X-native IBA cross-modality evaluation path.
+ *
+ * This is the drop-in boundary for ONE hot path of
+ * gitouni/Spatial-Temporal-LiDAR-camera-Calibration: the per-candidate-extrinsic
+ * evaluation that the reference runs on the CPU in
+ *   BAError()            src/examples/iba_global.cpp:169-344  (= iba_func.cpp:179-354)
+ *   BALoss::eval_x()     src/examples/iba_global.cpp:377-396
+ *   BuildProblem()       src/examples/iba_local.cpp:145-323   (association for the Jacobian path)
+ *   IBA_PlaneFactor / Point2Point_Factor / Point2Plane_Factor
+ *                        include/IBACalib2.hpp:152-184, 570-584, 611-625 (g2o twin: IBACalib.hpp:103-140)
+ *
+ * Only PODs cross the boundary: no Eigen / OpenCV / ORB_SLAM2 / torch types.
+ * All pointers in iba_problem_desc are HOST pointers borrowed for the duration
+ * of iba_create() only. Errors are return codes (the reference throws or
+ * returns DBL_MAX sentinels; the sentinels are kept, see iba_cost_out).
+ * A handle is thread-compatible: one evaluation at a time per handle
+ * (BALoss::eval_x is called from NOMAD's single worker thread, iba_global.cpp:385).
+ */
+#ifndef IBA_MI355X_H
+#define IBA_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IBA_ABI_VERSION 1
+#define IBA_MAX_BATCH 64 /* candidates per call */
+
+typedef enum iba_status {
+    IBA_OK = 0,
+    IBA_ERR_INVALID_ARG = 1,
+    IBA_ERR_NO_DEVICE = 2,   /* no gfx950 device / HIP runtime unusable: there is NO CPU fallback */
+    IBA_ERR_HIP = 3,
+    IBA_ERR_UNSUPPORTED = 4, /* problem shape outside what the kernels handle */
+    IBA_ERR_STATE = 5        /* e.g. iba_eval_factors before iba_build_problem */
+} iba_status;
+
+typedef struct iba_handle iba_handle;
+
+/*
+ * Flat description of what the reference holds in
+ *   std::vector<VecVector3d> PointClouds, std::vector<Eigen::Isometry3d> vTwl,
+ *   std::vector<ORB_SLAM2::KeyFrame*> KeyFrames          (iba_global.cpp:169-173)
+ * Frames are the keyframes sorted by mnId (iba_global.cpp:507). CSR offsets are
+ * element counts (not bytes).
+ */
+typedef struct iba_problem_desc {
+    int32_t n_frames; /* F */
+
+    /* PointClouds[Fi] — raw scan in the LiDAR frame, float32 as in KITTI .bin (io_tools.h:170-187). */
+    const uint64_t* pt_offset; /* [F+1] */
+    const float* pts_xyz;      /* [N*3] AoS x,y,z */
+
+    /* pKF->fx, fy, cx, cy, mnMaxX (W), mnMaxY (H)  (iba_global.cpp:64-65) */
+    const double* intrinsics; /* [F*6] */
+
+    /* pKF->mvKeysUn[i].pt (cv::Point2f) */
+    const uint64_t* kp_offset; /* [F+1] */
+    const float* kp_uv;        /* [K*2] */
+
+    /* mapKpt2Mpt (inverse of pKF->mmapMpt2Kpt, iba_global.cpp:210-213):
+     * MapPoint::GetWorldPos() (CV_32F 3x1) of the MapPoint owned by keypoint i. */
+    const uint8_t* kp_has_mappoint; /* [K] 0/1 */
+    const float* kp_mappoint_w;     /* [K*3] world position, ignored where kp_has_mappoint==0 */
+
+    /* pKF->GetPoseSafe() (CV_32F 4x4, top 3 rows, row-major) */
+    const float* Tcw; /* [F*12] */
+
+    /* pKF->GetBestCovisibilityKeyFramesSafe(num_best_covis) (or ByWeight), iba_global.cpp:254-258.
+     * One "slot" per (reference KF, covisible KF) pair. */
+    const uint64_t* covis_offset; /* [F+1] slots of frame f are covis_offset[f]..covis_offset[f+1] */
+    const int32_t* covis_frame;   /* [S] frame index of the covisible KF */
+    /* pKFConv->GetPose() * InvRefCVPose evaluated in CV_32F (iba_global.cpp:280), top 3 rows
+     * row-major, translation NOT multiplied by scale. */
+    const float* covis_relpose; /* [S*12] */
+    /* pKF->GetUordMatchedKptIds(pKFConv): keypoint id in the reference KF -> keypoint id in
+     * the covisible KF (KeyFrame.cc:528-538 semantics). */
+    const uint64_t* match_offset;  /* [S+1] */
+    const int32_t* match_kp_ref;   /* [M] */
+    const int32_t* match_kp_covis; /* [M] */
+
+    /* Hand-eye term inputs (iba_global.cpp:264-276), one per frame, ignored for the last frame:
+     *   Tc_next[f] = KeyFrames[f+1]->GetPose() * InvRefCVPose   in CV_32F, unscaled (:267)
+     *   Tl_next[f] = vTwl[f+1].inverse() * vTwl[f]              double            (:269) */
+    const float* Tc_next;  /* [F*12] */
+    const double* Tl_next; /* [F*12] */
+} iba_problem_desc;
+
+/*
+ * Thresholds. Field names follow IBAGlobalParams (iba_global.cpp:26-52) for the cost path
+ * and IBALocalParams (IBACalib2.hpp:108-137) for the Jacobian path ("local_" prefix where the
+ * two structs share a name but are configured independently).
+ */
+typedef struct iba_params {
+    /* shared association (FindProjectCorrespondences) */
+    double max_pixel_dist; /* 1.5 */
+
+    /* cost path: BAError */
+    int32_t num_min_corr_cost;   /* 30, hard-coded at iba_global.cpp:203 */
+    double corr_3d_2d_threshold; /* 40 */
+    double corr_3d_3d_threshold; /* 5 (yml: 10) */
+    int32_t norm_max_pts;        /* 30 (<= 32 supported) */
+    int32_t norm_min_pts;        /* 5 */
+    double norm_radius;          /* 0.6 */
+    double norm_reg_threshold;   /* 0.04 (yml: 0.02) */
+    double min_diff_dist;        /* 0.01 (yml: 0.2) */
+    double err_weight[2];        /* {1,1} */
+    int32_t use_plane;           /* 1 */
+
+    /* Jacobian path: BuildProblem + Ceres losses */
+    int32_t num_min_corr;             /* 30 */
+    double max_3d_dist;               /* 1.0 */
+    double neigh_radius;              /* 0.6 */
+    int32_t neigh_max_pts;            /* 30 (<= 32 supported) */
+    int32_t neigh_min_pts;            /* 5 */
+    double local_min_diff_dist;       /* 0.2 */
+    double local_norm_reg_threshold;  /* 0.001 */
+    double robust_kernel_delta;       /* 2.98 */
+    double robust_kernel_3ddelta;     /* 1.0 */
+
+    /* engine knob (no reference counterpart): 1 = memoise the x-independent local-plane fit per
+     * scan point (bit-identical results); 0 = refit inside every evaluation as the reference does. */
+    int32_t plane_cache;
+} iba_params;
+
+/* Output of one BAError() call. The first five fields are the reference's returned tuple
+ * (iba_global.cpp:343); the rest are the counters it prints with verborse (:341-342). */
+typedef struct iba_cost_out {
+    double f1;               /* mean 3d-2d distance over valid edges, DBL_MAX sentinel (:330-333) */
+    double f2;               /* mean 3d-3d distance over valid edges, DBL_MAX sentinel (:334-337) */
+    double C;                /* mean hand-eye constraint value, NaN if no frame was processed (:338) */
+    int32_t valid_cnt_3d_2d;
+    int32_t cnt_3d_2d;
+    int32_t cnt_3d_3d;
+    int32_t valid_cnt_3d_3d;
+    int32_t valid_pl_3d_3d;
+    int32_t valid_pt_3d_3d;
+    int32_t frames_used;     /* frames that passed the >= num_min_corr_cost test */
+    int32_t n_corr;          /* sum of corrset.size() over used frames */
+} iba_cost_out;
+
+/* Gauss-Newton normal equations of the iba_local problem at x:
+ *   H = sum_blocks w J^T J,  b = sum_blocks w J^T r,  cost = 1/2 sum_blocks rho(|r|^2)
+ * with Huber IRLS weights per residual block as Ceres applies them (corrector with rho''<=0). */
+typedef struct iba_normal_out {
+    double H[49]; /* row-major symmetric 7x7 */
+    double b[7];
+    double cost;          /* Ceres convention: 1/2 sum rho(s) */
+    double chi2;          /* sum |r|^2 (un-robustified) */
+    int32_t n_factor_3d2d; /* IBA_PlaneFactor blocks */
+    int32_t n_factor_p2pl; /* Point2Plane_Factor blocks */
+    int32_t n_factor_p2pt; /* Point2Point_Factor blocks */
+    int32_t n_residuals;   /* total scalar residuals */
+    int32_t frames_used;
+    int32_t n_corr;
+} iba_normal_out;
+
+/* NOMAD black-box outputs of BALoss::eval_x (iba_global.cpp:386-392). */
+typedef struct iba_bbo {
+    double f, c1, c2, c3;
+} iba_bbo;
+
+iba_status iba_default_params(iba_params* p); /* IBAGlobalParams / IBALocalParams defaults */
+
+/* Uploads the frames [frame_begin, frame_end) of the problem to HIP device `device`, builds the
+ * static per-scan 3-D indices (reference: KDTree3D per scan, iba_global.cpp:361-367) and the
+ * per-frame keypoint grids. The full descriptor must be given on every rank (covisible keypoints
+ * are resolved at creation time); only owned frames are uploaded and evaluated. */
+iba_status iba_create(const iba_problem_desc* desc, const iba_params* params, int device,
+                      int32_t frame_begin, int32_t frame_end, iba_handle** out);
+void iba_destroy(iba_handle* h);
+iba_status iba_set_params(iba_handle* h, const iba_params* params);
+const char* iba_last_error(const iba_handle* h); /* never NULL; h may be NULL for creation errors */
+
+/* BAError() for B candidate x = [omega(3), upsilon(3), s] (row-major B x 7). */
+iba_status iba_eval_cost(iba_handle* h, const double* x, int32_t B, iba_cost_out* out);
+/* BALoss::eval_x packing on top of iba_eval_cost. */
+iba_status iba_eval_bbo(iba_handle* h, const double* x, int32_t B, double he_threshold, double valid_rate,
+                        iba_bbo* out);
+
+/* BuildProblem() at x_assoc followed by one evaluation of every residual block at the same x:
+ * association + residuals + Jacobians + normal equations, B candidates per call. */
+iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal_out* out);
+
+/* The two halves separately, as Ceres uses them (iba_local.cpp:443-445): freeze the association
+ * at x_assoc, then evaluate the frozen residual blocks at B other x. */
+iba_status iba_build_problem(iba_handle* h, const double* x_assoc);
+iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out);
+/* Per-residual values and Jacobians of the frozen problem (for Ceres / g2o adaptors and tests).
+ * Call with r == NULL to query *n_rows. J is n_rows x 7 row-major, block_id[n_rows] identifies the
+ * residual block, block_kind: 0 = IBA_PlaneFactor, 1 = Point2Plane, 2 = Point2Point. */
+iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double* J, int32_t* block_id,
+                              int32_t* block_kind, int64_t* n_rows);
+
+/* 2d-3d correspondences (corrset of FindProjectCorrespondences, iba_global.cpp:55-96) of one owned
+ * frame at x: pairs (keypoint id, scan point id) sorted by keypoint id. cap = capacity in pairs. */
+iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame, uint32_t* kp_idx,
+                                   uint32_t* pt_idx, int32_t cap, int32_t* n_out);
+
+/*
+ * Multi-GPU building blocks (frames shard across ranks; one sum all-reduce per evaluation).
+ * iba_eval_*_partial writes this rank's partial sums for B candidates into DEVICE memory
+ * `d_partials` (B * iba_partial_stride() doubles, counters carried as doubles) on HIP stream
+ * `stream` (a hipStream_t passed as void*; NULL = the handle's own stream) without synchronising.
+ * After the caller has summed the partial blocks over ranks (ncclAllReduce, sum, f64),
+ * iba_finalize_* turns HOST copies of the summed blocks into the outputs above.
+ */
+int32_t iba_partial_stride(void);
+iba_status iba_eval_cost_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream);
+iba_status iba_eval_normal_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream);
+iba_status iba_finalize_cost(const iba_params* params, const double* partials, int32_t B, iba_cost_out* out);
+iba_status iba_finalize_normal(const iba_params* params, const double* partials, int32_t B, iba_normal_out* out);
+
+/* Introspection for benchmarks: device-side duration of the last evaluation's dominant kernel
+ * measured with HIP events on the launch stream (ms), and the frame-kernel launch shape. */
+iba_status iba_last_kernel_ms(iba_handle* h, float* frame_kernel_ms, float* total_ms);
+iba_status iba_set_timing(iba_handle* h, int32_t enable);
+int64_t iba_num_points(const iba_handle* h);
+int64_t iba_num_keypoints(const iba_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBA_MI355X_H */

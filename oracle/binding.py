@@ -1,0 +1,213 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes binding of oracle/liboracle.so (the CPU restatement of the
+reference path) and oracle/_ref/libref_nanoflann.so (the reference's own nanoflann).
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi")
+IbaCostOut, IbaNormalOut, IbaBbo, IbaParams = _abi.IbaCostOut, _abi.IbaNormalOut, _abi.IbaBbo, _abi.IbaParams
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("iba_oracle.cpp", "oracle_math.hpp", "oracle_kdtree.hpp")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return so
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_create.restype = C.c_void_p
+        _lib.oracle_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _lib.oracle_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+def ref_lib():
+    """The reference's nanoflann (None when oracle/_ref was never built: no /root/reference)."""
+    global _ref
+    if _ref is None:
+        p = os.path.join(_HERE, "_ref", "libref_nanoflann.so")
+        if not os.path.exists(p):
+            return None
+        _ref = C.CDLL(p)
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def knn(which, dim, pts, leaf, queries, k):
+    """which: 'oracle' | 'ref'. Returns (idx[nq,k] u32, d2[nq,k] f64, cnt[nq] i32)."""
+    L = lib() if which == "oracle" else ref_lib()
+    fn = L.oracle_knn if which == "oracle" else L.ref_nanoflann_knn
+    pts = np.ascontiguousarray(pts, np.float64)
+    queries = np.ascontiguousarray(queries, np.float64)
+    nq = len(queries)
+    idx = np.zeros((nq, k), np.uint32)
+    d2 = np.zeros((nq, k), np.float64)
+    cnt = np.zeros(nq, np.int32)
+    rc = fn(C.c_int(dim), _p(pts), C.c_uint64(len(pts)), C.c_int(leaf), _p(queries), C.c_uint64(nq), C.c_int(k), _p(idx), _p(d2), _p(cnt))
+    assert rc == 0
+    return idx, d2, cnt
+
+
+class Oracle:
+    def __init__(self, problem, leaf2d=10, leaf3d=30):
+        self.problem = problem
+        self._desc = problem.desc()
+        self.h = lib().oracle_create(C.byref(self._desc), leaf2d, leaf3d)
+
+    def close(self):
+        if self.h:
+            lib().oracle_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval_cost(self, params, x, nthreads=1):
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
+        B = len(x)
+        out = (IbaCostOut * B)()
+        lib().oracle_eval_cost(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out, C.c_int(nthreads))
+        return list(out)
+
+    def eval_bbo(self, params, x, he_threshold, valid_rate):
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
+        B = len(x)
+        out = (IbaBbo * B)()
+        lib().oracle_eval_bbo(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), C.c_double(he_threshold), C.c_double(valid_rate), out, C.c_int(1))
+        return list(out)
+
+    def correspondences(self, params, x, frame):
+        K = int(self.problem.arrays["kp_offset"][frame + 1] - self.problem.arrays["kp_offset"][frame])
+        kp = np.zeros(K, np.uint32)
+        pt = np.zeros(K, np.uint32)
+        n = C.c_int(0)
+        x = np.ascontiguousarray(x, np.float64)
+        lib().oracle_get_correspondences(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(frame), _p(kp), _p(pt), C.c_int(K), C.byref(n))
+        return kp[: n.value].copy(), pt[: n.value].copy()
+
+    def build_problem(self, params, x):
+        x = np.ascontiguousarray(x, np.float64)
+        lib().oracle_build_problem(C.c_void_p(self.h), C.byref(params), _p(x))
+        return lib().oracle_num_factors(C.c_void_p(self.h))
+
+    def eval_factors(self, params, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
+        B = len(x)
+        out = (IbaNormalOut * B)()
+        lib().oracle_eval_factors(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out)
+        return list(out)
+
+    def eval_normal(self, params, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
+        B = len(x)
+        out = (IbaNormalOut * B)()
+        lib().oracle_eval_normal(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out)
+        return list(out)
+
+    def eval_residuals(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        n = C.c_int64(0)
+        lib().oracle_eval_residuals(C.c_void_p(self.h), _p(x), None, None, None, None, None, C.byref(n))
+        m = n.value
+        r = np.zeros(m)
+        J = np.zeros((m, 7))
+        bid = np.zeros(m, np.int32)
+        kind = np.zeros(m, np.int32)
+        fk = np.zeros((m, 2), np.int32)
+        if m:
+            lib().oracle_eval_residuals(C.c_void_p(self.h), _p(x), _p(r), _p(J), _p(bid), _p(kind), _p(fk), C.byref(n))
+        return r, J, bid, kind, fk
+
+    def plane_at(self, frame, pt_idx, radius, max_pts):
+        k = C.c_int32(0)
+        far = C.c_double(0)
+        nrm = np.zeros(3)
+        reg = C.c_double(0)
+        lib().oracle_plane_at(C.c_void_p(self.h), C.c_int(frame), C.c_uint32(pt_idx), C.c_double(radius), C.c_int(max_pts), C.byref(k), C.byref(far), _p(nrm), C.byref(reg))
+        return k.value, far.value, nrm, reg.value
+
+
+# ---- unit-level helpers for the known-answer tests ----
+def sim3exp(x):
+    x = np.ascontiguousarray(x, np.float64)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    s = C.c_double(0)
+    lib().oracle_sim3exp(_p(x), _p(R), _p(t), C.byref(s))
+    return R.reshape(3, 3), t, s.value
+
+
+def sim3exp_jet(x):
+    x = np.ascontiguousarray(x, np.float64)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    dR = np.zeros((9, 7))
+    dt = np.zeros((3, 7))
+    lib().oracle_sim3exp_jet(_p(x), _p(R), _p(t), _p(dR), _p(dt))
+    return R.reshape(3, 3), t, dR, dt
+
+
+def se3exp(x):
+    x = np.ascontiguousarray(x, np.float64)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    lib().oracle_se3exp(_p(x), _p(R), _p(t))
+    return R.reshape(3, 3), t
+
+
+def se3log(R, t):
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    t = np.ascontiguousarray(t, np.float64)
+    out = np.zeros(6)
+    lib().oracle_se3log(_p(R), _p(t), _p(out))
+    return out
+
+
+def covariance(pts, idx):
+    pts = np.ascontiguousarray(pts, np.float64)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    cov = np.zeros(9)
+    lib().oracle_covariance(_p(pts), _p(idx), C.c_uint64(len(idx)), _p(cov))
+    return cov.reshape(3, 3)
+
+
+def fast_eigen(cov):
+    cov = np.ascontiguousarray(cov, np.float64).reshape(9)
+    v = np.zeros(3)
+    ev = np.zeros(3)
+    lib().oracle_fast_eigen(_p(cov), _p(v), _p(ev))
+    return v, ev
+
+
+def huber(a, s):
+    r0 = C.c_double(0)
+    r1 = C.c_double(0)
+    lib().oracle_huber(C.c_double(a), C.c_double(s), C.byref(r0), C.byref(r1))
+    return r0.value, r1.value
+
+
+def max_threads():
+    return lib().oracle_max_threads()

@@ -1,0 +1,567 @@
+// TEST INFRASTRUCTURE ONLY — CPU oracle: a restatement of the reference's IBA evaluation path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+// and only as the checker / the timed CPU baseline — never from the product path.
+//
+// Follows, step for step:
+//   FindProjectCorrespondences   src/examples/iba_global.cpp:55-96  (= iba_local.cpp:17-58)
+//   ComputeAlignmentDist         src/examples/iba_global.cpp:111-156
+//   BAError                      src/examples/iba_global.cpp:169-344 (= iba_func.cpp:179-354)
+//   BALoss::eval_x packing       src/examples/iba_global.cpp:386-392
+//   BuildProblem                 src/examples/iba_local.cpp:145-323
+//   ComputeLocalNeighbor / ComputeLocalNormalSingleThre   include/pointcloud.h:733-760, 651-666, 699-717
+//   IBA_PlaneFactor / Point2Point_Factor / Point2Plane_Factor  include/IBACalib2.hpp:152-184, 570-584, 611-625
+//   IBAPlaneEdge (g2o twin, 20-d zero padded)                  include/IBACalib.hpp:103-140
+//   ceres::HuberLoss + Corrector (third-party; iba_local.cpp:263, 291)
+// including the per-evaluation 2-D kd-tree rebuild (iba_global.cpp:84).
+//
+// PARITY PIN STATUS (see oracle_math.hpp): kd-tree/kNN pinned to the reference's nanoflann; the
+// closed-form math pinned by known-answer tests; the remainder "parity unpinned" because the
+// reference has no tests and its third-party dependencies (Eigen, OpenCV, g2o, Ceres) are absent.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <unordered_map>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/iba_mi355x.h"
+#include "oracle_kdtree.hpp"
+#include "oracle_math.hpp"
+
+using namespace oracle;
+
+namespace {
+
+using KDTree2D = KDTree<2>;
+using KDTree3D = KDTree<3>;
+
+struct Covis {
+    int frame;
+    Iso3 rel;                           // widened CV_32F product, translation unscaled
+    std::unordered_map<int, int> kptmap;  // GetUordMatchedKptIds
+};
+
+struct Frame {
+    std::vector<double> pts;  // VecVector3d (P x 3 doubles), LiDAR frame
+    std::unique_ptr<KDTree3D> tree;
+    double fx, fy, cx, cy, W, H;
+    std::vector<float> kp_uv;      // K x 2
+    std::vector<uint8_t> has_mp;   // K
+    std::vector<float> mp_w;       // K x 3
+    Iso3 Tcw;                      // widened float pose
+    std::vector<Covis> covis;
+    Iso3 Tc_next;                  // widened, unscaled
+    Iso3 Tl_next;
+    size_t P() const { return pts.size() / 3; }
+    size_t K() const { return kp_uv.size() / 2; }
+};
+
+struct Factor {
+    int kind;  // 0 IBA_PlaneFactor, 1 Point2Plane_Factor, 2 Point2Point_Factor
+    int frame, kp;
+    double fx, fy, cx, cy, u0, v0;
+    std::vector<double> u1, v1;
+    std::vector<M3d> R;
+    std::vector<V3d> t;
+    V3d p0, n0;          // plane factor
+    V3d MapPoint, Q, n;  // 3d-3d factors
+    int rows() const { return kind == 0 ? 2 * (int)u1.size() : (kind == 1 ? 1 : 3); }
+};
+
+struct Oracle {
+    std::vector<Frame> frames;
+    int leaf2d = 10, leaf3d = 30;
+    std::vector<Factor> factors;  // frozen problem
+    int bp_frames_used = 0, bp_n_corr = 0;
+};
+
+Iso3 iso_from_f32(const float* m) {
+    Iso3 T;
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T.R(r, c) = (double)m[r * 4 + c]; T.t[r] = (double)m[r * 4 + 3]; }
+    return T;
+}
+Iso3 iso_from_f64(const double* m) {
+    Iso3 T;
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T.R(r, c) = m[r * 4 + c]; T.t[r] = m[r * 4 + 3]; }
+    return T;
+}
+
+using CorrSet = std::vector<std::pair<uint32_t, uint32_t>>;
+
+// iba_global.cpp:55-96. `PC` = scan already transformed into the camera frame.
+void FindProjectCorrespondences(const std::vector<double>& PC, const Frame& kf, int leaf_size, double max_corr_dist, CorrSet& corrset) {
+    const size_t K = kf.K();
+    std::vector<double> vKeyUn(2 * K);
+    for (size_t i = 0; i < K; ++i) { vKeyUn[2 * i] = (double)kf.kp_uv[2 * i]; vKeyUn[2 * i + 1] = (double)kf.kp_uv[2 * i + 1]; }
+    const double fx = kf.fx, cx = kf.cx, cy = kf.cy;
+    const double H = kf.H, W = kf.W;
+    std::vector<double> ProjectPC; std::vector<uint32_t> ProjectIndex;
+    const size_t n = PC.size() / 3;
+    for (size_t i = 0; i < n; ++i) {
+        const double px = PC[3 * i], py = PC[3 * i + 1], pz = PC[3 * i + 2];
+        if (pz > 0) {
+            double u = (fx * px + cx * pz) / pz;
+            double v = (fx * py + cy * pz) / pz;  // fx, not fy: iba_global.cpp:73
+            if (0 <= u && u < W && 0 <= v && v < H) { ProjectPC.push_back(u); ProjectPC.push_back(v); ProjectIndex.push_back((uint32_t)i); }
+        }
+    }
+    if (ProjectIndex.empty()) return;
+    KDTree2D kdtree(ProjectPC.data(), ProjectIndex.size(), (size_t)leaf_size);
+    for (uint32_t i = 0; i < K; ++i) {
+        uint32_t index; double sq_dist = std::numeric_limits<double>::max();
+        KNNResultSet rs(1); rs.init(&index, &sq_dist);
+        kdtree.findNeighbors(rs, &vKeyUn[2 * i]);
+        if (rs.size() > 0 && sq_dist <= max_corr_dist * max_corr_dist) corrset.emplace_back(i, ProjectIndex[index]);
+    }
+}
+
+struct PlaneFit { size_t k; double far_d2; V3d normal; double reg_err; std::vector<uint32_t> idx; };
+// Shared by ComputeAlignmentDist (:125-147), ComputeLocalNeighbor (pointcloud.h:733-760) and
+// ComputeLocalNormalSingleThre (pointcloud.h:699-717): kNN(max_pts) around `center`, clip to d^2 < r^2.
+void knn_clip(const Frame& f, const double* center, int max_pts, double radius, std::vector<uint32_t>& indices, std::vector<double>& sq_dist, size_t& k) {
+    indices.assign(max_pts, 0); sq_dist.assign(max_pts, 0.0);
+    KNNResultSet rs((size_t)max_pts); rs.init(indices.data(), sq_dist.data());
+    f.tree->findNeighbors(rs, center);
+    k = rs.size();
+    k = std::distance(sq_dist.begin(), std::lower_bound(sq_dist.begin(), sq_dist.begin() + k, radius * radius));
+    indices.resize(k); sq_dist.resize(k);
+}
+void normal_and_reg(const Frame& f, const std::vector<uint32_t>& indices, const V3d& ref_pt, V3d& normal, double& reg_err) {
+    M3d cov = ComputeCovariance(f.pts.data(), indices.data(), indices.size());
+    double ev[3]; normal = normalized(FastEigen3x3_EV(cov, ev));
+    reg_err = 0;
+    for (uint32_t idx : indices) {
+        V3d p{f.pts[3 * idx], f.pts[3 * idx + 1], f.pts[3 * idx + 2]};
+        reg_err += std::abs(dot(p - ref_pt, normal));
+    }
+}
+
+// iba_global.cpp:111-156
+void ComputeAlignmentDist(const Frame& f, const V3d& query_pt, const iba_params& p, bool& is_plane, double& dist) {
+    uint32_t nn_idx; double nn_sq;
+    KNNResultSet nn(1); nn.init(&nn_idx, &nn_sq);
+    const double q[3] = {query_pt.x, query_pt.y, query_pt.z};
+    f.tree->findNeighbors(nn, q);
+    const V3d nn_pt{f.pts[3 * nn_idx], f.pts[3 * nn_idx + 1], f.pts[3 * nn_idx + 2]};
+    double pt2pt_dist = norm(nn_pt - query_pt);
+    is_plane = false; dist = pt2pt_dist;
+    if (!p.use_plane) return;
+    std::vector<uint32_t> indices; std::vector<double> sq_dist; size_t k;
+    const double c[3] = {nn_pt.x, nn_pt.y, nn_pt.z};
+    knn_clip(f, c, p.norm_max_pts, p.norm_radius, indices, sq_dist, k);
+    if (sq_dist[k - 1] < p.min_diff_dist * p.min_diff_dist) return;
+    if (k < (size_t)p.norm_min_pts) return;
+    V3d normal; double reg_err; normal_and_reg(f, indices, nn_pt, normal, reg_err);
+    if (reg_err / (k - 1) > p.norm_reg_threshold) return;
+    is_plane = true; dist = std::abs(dot(nn_pt - query_pt, normal));
+}
+
+void transform_cloud(const Frame& f, const Iso3& T, std::vector<double>& PC) {  // pointcloud.h:82-86
+    const size_t n = f.P(); PC.resize(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        V3d q = apply(T, V3d{f.pts[3 * i], f.pts[3 * i + 1], f.pts[3 * i + 2]});
+        PC[3 * i] = q.x; PC[3 * i + 1] = q.y; PC[3 * i + 2] = q.z;
+    }
+}
+
+// iba_global.cpp:169-344
+void BAError(const Oracle& O, const iba_params& prm, const double* xvec, bool multiprocessing, iba_cost_out& out) {
+    double corr_3d_2d_err = 0, corr_3d_3d_err = 0, Cval = 0, Ccnt = 0;
+    int cnt_3d_2d = 0, valid_cnt_3d_2d = 0, valid_pl_3d_3d = 0, valid_pt_3d_3d = 0, cnt_3d_3d = 0, valid_cnt_3d_3d = 0;
+    int frames_used = 0, n_corr = 0;
+    M3d rotation; V3d translation; double scale;
+    Sim3Exp<double>(xvec, rotation, translation, scale);
+    Iso3 Tcl{rotation, translation};
+    const Iso3 Tlc = inverse(Tcl);
+    const int F = (int)O.frames.size();
+    (void)multiprocessing;
+#pragma omp parallel for if (multiprocessing)
+    for (int Fi = 0; Fi < F; ++Fi) {
+        const Frame& kf = O.frames[Fi];
+        std::vector<double> PC;
+        transform_cloud(kf, Tcl, PC);
+        CorrSet corrset;
+        FindProjectCorrespondences(PC, kf, O.leaf2d, prm.max_pixel_dist, corrset);
+        if ((int)corrset.size() < prm.num_min_corr_cost) continue;  // hard-coded 30 at :203
+        Iso3 TcwRS = kf.Tcw;
+        TcwRS.t = {TcwRS.t.x * scale, TcwRS.t.y * scale, TcwRS.t.z * scale};
+#pragma omp critical
+        { frames_used++; n_corr += (int)corrset.size(); }
+        if (prm.err_weight[1] <= 1e-10) {
+#pragma omp critical
+            { corr_3d_3d_err = 0; cnt_3d_3d++; valid_cnt_3d_3d++; }
+        } else {
+            const float s32 = (float)scale;  // cv::Mat(CV_32F) * double: OpenCV convertTo scales in float
+            for (auto const& [point2d_idx, point3d_idx] : corrset) {
+                (void)point3d_idx;
+                if (!kf.has_mp[point2d_idx]) continue;
+                const float* pw = &kf.mp_w[3 * point2d_idx];
+                const float m0 = pw[0] * s32, m1 = pw[1] * s32, m2 = pw[2] * s32;
+                V3d MapRefPose{(double)m0, (double)m1, (double)m2};
+                MapRefPose = apply(TcwRS, MapRefPose);
+                MapRefPose = apply(Tlc, MapRefPose);
+                bool is_planefit; double dist;
+                ComputeAlignmentDist(kf, MapRefPose, prm, is_planefit, dist);
+#pragma omp critical
+                {
+                    if (dist < prm.corr_3d_3d_threshold) {
+                        corr_3d_3d_err += dist; valid_cnt_3d_3d++;
+                        if (is_planefit) valid_pl_3d_3d++; else valid_pt_3d_3d++;
+                    }
+                    cnt_3d_3d++;
+                }
+            }
+        }
+        if (Fi < F - 1) {
+            Iso3 Tc = kf.Tc_next;
+            Tc.t = {Tc.t.x * scale, Tc.t.y * scale, Tc.t.z * scale};
+            const Iso3 C1 = compose(Tcl, kf.Tl_next);
+            const Iso3 C2 = compose(Tc, Tcl);
+            double l1[6], l2[6]; SE3Log(C1.R, C1.t, l1); SE3Log(C2.R, C2.t, l2);
+            double ss = 0; for (int i = 0; i < 6; ++i) ss += (l1[i] - l2[i]) * (l1[i] - l2[i]);
+#pragma omp critical
+            { Cval += std::sqrt(ss); Ccnt++; }
+        }
+        std::vector<Iso3> relCVPoseList; relCVPoseList.reserve(kf.covis.size());
+        for (auto const& cv : kf.covis) {
+            Iso3 rel = cv.rel; rel.t = {rel.t.x * scale, rel.t.y * scale, rel.t.z * scale};
+            relCVPoseList.push_back(rel);
+        }
+        for (auto& corr : corrset) {
+            const int point2d_idx = corr.first, point3d_idx = corr.second;
+            V3d p0{PC[3 * point3d_idx], PC[3 * point3d_idx + 1], PC[3 * point3d_idx + 2]};
+            const double fx = kf.fx, fy = kf.fy, cx = kf.cx, cy = kf.cy, H = kf.H, W = kf.W;
+            for (size_t ci = 0; ci < kf.covis.size(); ++ci) {
+                auto it = kf.covis[ci].kptmap.find(point2d_idx);
+                if (it == kf.covis[ci].kptmap.end()) continue;
+                const int covis_idx = it->second;
+                const Frame& ckf = O.frames[kf.covis[ci].frame];
+                double u1 = ckf.kp_uv[2 * covis_idx], v1 = ckf.kp_uv[2 * covis_idx + 1];
+                V3d p1 = apply(relCVPoseList[ci], p0);
+                double obs_u1 = fx * p1.x / p1.z + cx;
+                double obs_v1 = fy * p1.y / p1.z + cy;
+                if (!(obs_u1 >= 0 && obs_u1 < W && obs_v1 >= 0 && obs_v1 < H)) continue;
+                double err = (obs_u1 - u1) * (obs_u1 - u1) + (obs_v1 - v1) * (obs_v1 - v1);
+                double dist = std::sqrt(err);
+#pragma omp critical
+                {
+                    if (dist < prm.corr_3d_2d_threshold) { corr_3d_2d_err += dist; valid_cnt_3d_2d++; }
+                    cnt_3d_2d++;
+                }
+            }
+        }
+    }
+    if (valid_cnt_3d_2d == 0 && prm.err_weight[0] > 1e-10) corr_3d_2d_err = std::numeric_limits<double>::max();
+    else corr_3d_2d_err /= valid_cnt_3d_2d;
+    if (valid_cnt_3d_3d == 0 && prm.err_weight[1] > 1e-10) corr_3d_3d_err = std::numeric_limits<double>::max();
+    else corr_3d_3d_err /= valid_cnt_3d_3d;
+    Cval /= Ccnt;
+    out.f1 = corr_3d_2d_err; out.f2 = corr_3d_3d_err; out.C = Cval;
+    out.valid_cnt_3d_2d = valid_cnt_3d_2d; out.cnt_3d_2d = cnt_3d_2d; out.cnt_3d_3d = cnt_3d_3d; out.valid_cnt_3d_3d = valid_cnt_3d_3d;
+    out.valid_pl_3d_3d = valid_pl_3d_3d; out.valid_pt_3d_3d = valid_pt_3d_3d; out.frames_used = frames_used; out.n_corr = n_corr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Residual functors (templated on double / Dual<7>)
+// ------------------------------------------------------------------------------------------------
+template <class T> V3<T> castv(const V3d& v) { return {T(v.x), T(v.y), T(v.z)}; }
+template <class T> M3<T> castm(const M3d& m) { M3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = T(m.m[i]); return r; }
+
+template <class T>
+void eval_plane_factor(const Factor& f, const T* x, T* error) {  // IBACalib2.hpp:152-184
+    M3<T> Rcl; V3<T> tcl; T s;
+    Sim3Exp<T>(x, Rcl, tcl, s);
+    T fx(f.fx), fy(f.fy), cx(f.cx), cy(f.cy), u0(f.u0), v0(f.v0);
+    V3<T> p0 = castv<T>(f.p0), n0 = castv<T>(f.n0);
+    V3<T> p0c = mul(Rcl, p0) + tcl;
+    V3<T> n0c = mul(Rcl, n0);
+    T Cxz = (u0 - cx) / fx;
+    T Cyz = (v0 - cy) / fy;
+    T Z0 = dot(n0c, p0c) / (Cxz * n0c.x + Cyz * n0c.y + n0c.z);
+    T X0 = Cxz * Z0, Y0 = Cyz * Z0;
+    V3<T> P0{X0, Y0, Z0};
+    for (size_t i = 0; i < f.u1.size(); ++i) {
+        M3<T> R = castm<T>(f.R[i]);
+        V3<T> t = castv<T>(f.t[i]);
+        t = t * s;
+        T u1(f.u1[i]), v1(f.v1[i]);
+        V3<T> P1 = mul(R, P0) + t;
+        T u1_obs = fx * P1.x / P1.z + cx;
+        T v1_obs = fy * P1.y / P1.z + cy;
+        error[2 * i] = u1_obs - u1;
+        error[2 * i + 1] = v1_obs - v1;
+    }
+}
+template <class T>
+void eval_p2x_factor(const Factor& f, const T* x, T* error) {  // IBACalib2.hpp:570-584, 611-625
+    T inv[6] = {-x[0], -x[1], -x[2], -x[3], -x[4], -x[5]};
+    M3<T> Rlc; V3<T> tlc; T s = x[6];
+    SE3Exp<T>(inv, Rlc, tlc);
+    V3<T> M = mul(Rlc, castv<T>(f.MapPoint) * s) + tlc;
+    V3<T> Q = castv<T>(f.Q);
+    if (f.kind == 2) { error[0] = M.x - Q.x; error[1] = M.y - Q.y; error[2] = M.z - Q.z; }
+    else { error[0] = dot(M - Q, castv<T>(f.n)); }
+}
+void eval_factor(const Factor& f, const double* x, double* r, double* J /*rows x 7, may be null*/) {
+    using D7 = Dual<7>;
+    const int rows = f.rows();
+    if (!J) {
+        if (f.kind == 0) eval_plane_factor<double>(f, x, r); else eval_p2x_factor<double>(f, x, r);
+        return;
+    }
+    D7 xd[7]; for (int i = 0; i < 7; ++i) xd[i] = D7(x[i], i);
+    std::vector<D7> e(rows);
+    if (f.kind == 0) eval_plane_factor<D7>(f, xd, e.data()); else eval_p2x_factor<D7>(f, xd, e.data());
+    for (int i = 0; i < rows; ++i) { r[i] = e[i].a; for (int c = 0; c < 7; ++c) J[i * 7 + c] = e[i].v[c]; }
+}
+
+// iba_local.cpp:145-323 (association only; the factors are appended in frame order, the reference's
+// insertion order under `omp critical` is nondeterministic)
+void BuildProblem(Oracle& O, const iba_params& prm, const double* params) {
+    O.factors.clear(); O.bp_frames_used = 0; O.bp_n_corr = 0;
+    const double max_3d_dist2 = prm.max_3d_dist * prm.max_3d_dist;
+    M3d init_rotation; V3d init_translation; double init_scale;
+    Sim3Exp<double>(params, init_rotation, init_translation, init_scale);
+    Iso3 initSE3{init_rotation, init_translation};
+    const Iso3 initSE3inv = inverse(initSE3);
+    for (size_t Fi = 0; Fi < O.frames.size(); ++Fi) {
+        const Frame& kf = O.frames[Fi];
+        std::vector<double> points; transform_cloud(kf, initSE3, points);
+        CorrSet pt2d3d_map;
+        FindProjectCorrespondences(points, kf, O.leaf2d, prm.max_pixel_dist, pt2d3d_map);
+        if ((int)pt2d3d_map.size() < prm.num_min_corr) continue;
+        O.bp_frames_used++; O.bp_n_corr += (int)pt2d3d_map.size();
+        for (size_t ci = 0; ci < pt2d3d_map.size(); ++ci) {
+            const uint32_t point2d_idx = pt2d3d_map[ci].first, point3d_idx = pt2d3d_map[ci].second;
+            // ComputeLocalNeighbor (pointcloud.h:733-760)
+            std::vector<uint32_t> neigh_idx; std::vector<double> sq_dist; size_t k;
+            const double* c = &kf.pts[3 * (size_t)point3d_idx];
+            knn_clip(kf, c, prm.neigh_max_pts, prm.neigh_radius, neigh_idx, sq_dist, k);
+            if ((int)k < prm.neigh_min_pts || sq_dist[k - 1] < prm.local_min_diff_dist * prm.local_min_diff_dist) continue;
+            if (!kf.has_mp[point2d_idx]) continue;
+            const V3d nn_pt{c[0], c[1], c[2]};
+            V3d normal; double reg_err; normal_and_reg(kf, neigh_idx, nn_pt, normal, reg_err);
+            reg_err /= neigh_idx.size() - 1;
+            const bool bvalid_plane = reg_err < prm.local_norm_reg_threshold;
+            const double u0 = kf.kp_uv[2 * point2d_idx], v0 = kf.kp_uv[2 * point2d_idx + 1];
+            V3d MapPoint{(double)kf.mp_w[3 * point2d_idx], (double)kf.mp_w[3 * point2d_idx + 1], (double)kf.mp_w[3 * point2d_idx + 2]};
+            MapPoint = apply(kf.Tcw, MapPoint);
+            Factor pf; pf.kind = 0; pf.frame = (int)Fi; pf.kp = (int)point2d_idx;
+            pf.fx = kf.fx; pf.fy = kf.fy; pf.cx = kf.cx; pf.cy = kf.cy; pf.u0 = u0; pf.v0 = v0; pf.p0 = nn_pt; pf.n0 = normal;
+            for (auto const& cv : kf.covis) {
+                auto it = cv.kptmap.find((int)point2d_idx);
+                if (it == cv.kptmap.end()) continue;
+                const Frame& ckf = O.frames[cv.frame];
+                pf.u1.push_back(ckf.kp_uv[2 * it->second]); pf.v1.push_back(ckf.kp_uv[2 * it->second + 1]);
+                pf.R.push_back(cv.rel.R); pf.t.push_back(cv.rel.t);  // translation unscaled: iba_local.cpp:184-188
+            }
+            if (pf.u1.empty()) continue;
+            if (bvalid_plane) O.factors.push_back(pf);
+            V3d MapPointInLidar = apply(initSE3inv, MapPoint * init_scale);
+            uint32_t mp_idx; double mp_sq;
+            KNNResultSet rs(1); rs.init(&mp_idx, &mp_sq);
+            const double q[3] = {MapPointInLidar.x, MapPointInLidar.y, MapPointInLidar.z};
+            kf.tree->findNeighbors(rs, q);
+            if (mp_sq > max_3d_dist2) continue;
+            const V3d NN{kf.pts[3 * (size_t)mp_idx], kf.pts[3 * (size_t)mp_idx + 1], kf.pts[3 * (size_t)mp_idx + 2]};
+            // ComputeLocalNormalSingleThre (pointcloud.h:699-717 -> 651-666)
+            std::vector<uint32_t> idx2; std::vector<double> sq2; size_t k2;
+            const double c2[3] = {NN.x, NN.y, NN.z};
+            knn_clip(kf, c2, prm.neigh_max_pts, prm.neigh_radius, idx2, sq2, k2);
+            V3d n2{0, 0, 1}; bool state = false;
+            if (!((int)k2 < prm.neigh_min_pts || sq2[k2 - 1] < prm.local_min_diff_dist * prm.local_min_diff_dist)) {
+                double re; normal_and_reg(kf, idx2, NN, n2, re);
+                re /= idx2.size() - 1;
+                state = re < prm.local_norm_reg_threshold;
+            }
+            Factor g; g.kind = state ? 1 : 2; g.frame = (int)Fi; g.kp = (int)point2d_idx;
+            g.fx = g.fy = g.cx = g.cy = g.u0 = g.v0 = 0; g.MapPoint = MapPoint; g.Q = NN; g.n = n2; g.p0 = {0, 0, 0}; g.n0 = {0, 0, 0};
+            O.factors.push_back(g);
+        }
+    }
+}
+
+// ceres::HuberLoss::Evaluate + Corrector with rho'' <= 0 (third-party, restated)
+inline void huber(double a, double s, double& rho0, double& rho1) {
+    const double b = a * a;
+    if (s > b) { const double r = std::sqrt(s); rho0 = 2.0 * a * r - b; rho1 = std::max(std::numeric_limits<double>::min(), a / r); }
+    else { rho0 = s; rho1 = 1.0; }
+}
+
+void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_normal_out& out) {
+    std::memset(&out, 0, sizeof(out));
+    double r[64], J[64 * 7];
+    for (auto const& f : O.factors) {
+        const int rows = f.rows();
+        if (rows > 64) continue;
+        eval_factor(f, x, r, J);
+        double s = 0; for (int i = 0; i < rows; ++i) s += r[i] * r[i];
+        double rho0, rho1; huber(f.kind == 0 ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, s, rho0, rho1);
+        out.cost += 0.5 * rho0; out.chi2 += s;
+        for (int i = 0; i < rows; ++i)
+            for (int a = 0; a < 7; ++a) {
+                out.b[a] += rho1 * J[i * 7 + a] * r[i];
+                for (int c = 0; c < 7; ++c) out.H[a * 7 + c] += rho1 * J[i * 7 + a] * J[i * 7 + c];
+            }
+        out.n_residuals += rows;
+        if (f.kind == 0) out.n_factor_3d2d++; else if (f.kind == 1) out.n_factor_p2pl++; else out.n_factor_p2pt++;
+    }
+    out.frames_used = O.bp_frames_used; out.n_corr = O.bp_n_corr;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C interface (ctypes from tests / bench cpu_baseline)
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+void* oracle_create(const iba_problem_desc* d, int leaf2d, int leaf3d) {
+    auto* O = new Oracle; O->leaf2d = leaf2d; O->leaf3d = leaf3d;
+    const int F = d->n_frames;
+    O->frames.resize(F);
+    for (int f = 0; f < F; ++f) {
+        Frame& fr = O->frames[f];
+        const uint64_t p0 = d->pt_offset[f], p1 = d->pt_offset[f + 1];
+        fr.pts.resize(3 * (p1 - p0));
+        for (uint64_t i = 0; i < 3 * (p1 - p0); ++i) fr.pts[i] = (double)d->pts_xyz[3 * p0 + i];
+        const double* in = d->intrinsics + 6 * f;
+        fr.fx = in[0]; fr.fy = in[1]; fr.cx = in[2]; fr.cy = in[3]; fr.W = in[4]; fr.H = in[5];
+        const uint64_t k0 = d->kp_offset[f], k1 = d->kp_offset[f + 1];
+        fr.kp_uv.assign(d->kp_uv + 2 * k0, d->kp_uv + 2 * k1);
+        fr.has_mp.assign(d->kp_has_mappoint + k0, d->kp_has_mappoint + k1);
+        fr.mp_w.assign(d->kp_mappoint_w + 3 * k0, d->kp_mappoint_w + 3 * k1);
+        fr.Tcw = iso_from_f32(d->Tcw + 12 * f);
+        fr.Tc_next = iso_from_f32(d->Tc_next + 12 * f);
+        fr.Tl_next = iso_from_f64(d->Tl_next + 12 * f);
+        for (uint64_t s = d->covis_offset[f]; s < d->covis_offset[f + 1]; ++s) {
+            Covis cv; cv.frame = d->covis_frame[s]; cv.rel = iso_from_f32(d->covis_relpose + 12 * s);
+            for (uint64_t m = d->match_offset[s]; m < d->match_offset[s + 1]; ++m) cv.kptmap[d->match_kp_ref[m]] = d->match_kp_covis[m];
+            fr.covis.push_back(std::move(cv));
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int f = 0; f < F; ++f) {  // iba_global.cpp:361-367
+        Frame& fr = O->frames[f];
+        fr.tree.reset(new KDTree3D(fr.pts.data(), fr.P(), (size_t)leaf3d));
+    }
+    return O;
+}
+void oracle_destroy(void* h) { delete (Oracle*)h; }
+
+int oracle_eval_cost(void* h, const iba_params* p, const double* x, int B, iba_cost_out* out, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    for (int b = 0; b < B; ++b) BAError(*(Oracle*)h, *p, x + 7 * b, nthreads > 1, out[b]);
+    return 0;
+}
+int oracle_eval_bbo(void* h, const iba_params* p, const double* x, int B, double he_threshold, double valid_rate, iba_bbo* out, int nthreads) {
+    for (int b = 0; b < B; ++b) {  // iba_global.cpp:385-392
+        iba_cost_out c; oracle_eval_cost(h, p, x + 7 * b, 1, &c, nthreads);
+        out[b].f = c.f1 * p->err_weight[0] + c.f2 * p->err_weight[1];
+        out[b].c1 = c.C - he_threshold; out[b].c2 = -c.C - he_threshold;
+        out[b].c3 = valid_rate - static_cast<double>(c.valid_cnt_3d_2d) / (c.cnt_3d_2d + 1);
+    }
+    return 0;
+}
+int oracle_get_correspondences(void* h, const iba_params* p, const double* x, int frame, uint32_t* kp, uint32_t* pt, int cap, int* n) {
+    Oracle& O = *(Oracle*)h;
+    M3d R; V3d t; double s; Sim3Exp<double>(x, R, t, s);
+    std::vector<double> PC; transform_cloud(O.frames[frame], Iso3{R, t}, PC);
+    CorrSet cs; FindProjectCorrespondences(PC, O.frames[frame], O.leaf2d, p->max_pixel_dist, cs);
+    *n = (int)cs.size();
+    for (int i = 0; i < (int)cs.size() && i < cap; ++i) { kp[i] = cs[i].first; pt[i] = cs[i].second; }
+    return 0;
+}
+int oracle_build_problem(void* h, const iba_params* p, const double* x) { BuildProblem(*(Oracle*)h, *p, x); return 0; }
+int oracle_eval_factors(void* h, const iba_params* p, const double* x, int B, iba_normal_out* out) {
+    for (int b = 0; b < B; ++b) EvalFactors(*(Oracle*)h, *p, x + 7 * b, out[b]);
+    return 0;
+}
+int oracle_eval_normal(void* h, const iba_params* p, const double* x, int B, iba_normal_out* out) {
+    for (int b = 0; b < B; ++b) { BuildProblem(*(Oracle*)h, *p, x + 7 * b); EvalFactors(*(Oracle*)h, *p, x + 7 * b, out[b]); }
+    return 0;
+}
+int oracle_eval_residuals(void* h, const double* x, double* r, double* J, int32_t* block_id, int32_t* block_kind, int32_t* block_frame_kp, int64_t* n_rows) {
+    Oracle& O = *(Oracle*)h;
+    int64_t rows = 0; for (auto const& f : O.factors) rows += f.rows();
+    *n_rows = rows;
+    if (!r) return 0;
+    int64_t at = 0; int32_t bid = 0;
+    for (auto const& f : O.factors) {
+        eval_factor(f, x, r + at, J ? J + 7 * at : nullptr);
+        for (int i = 0; i < f.rows(); ++i) {
+            if (block_id) block_id[at + i] = bid;
+            if (block_kind) block_kind[at + i] = f.kind;
+            if (block_frame_kp) { block_frame_kp[2 * (at + i)] = f.frame; block_frame_kp[2 * (at + i) + 1] = f.kp; }
+        }
+        at += f.rows(); ++bid;
+    }
+    return 0;
+}
+// IBAPlaneEdge (g2o twin): same math, error zero-padded to 20 (IBACalib.hpp:133-137). block = index of a
+// kind-0 factor of the frozen problem.
+int oracle_eval_plane_edge20(void* h, int64_t factor_index, const double* x, double* err20, double* J20x7) {
+    Oracle& O = *(Oracle*)h;
+    if (factor_index < 0 || factor_index >= (int64_t)O.factors.size()) return 1;
+    const Factor& f = O.factors[factor_index];
+    if (f.kind != 0 || f.u1.size() > 10) return 1;
+    std::memset(err20, 0, 20 * sizeof(double)); if (J20x7) std::memset(J20x7, 0, 140 * sizeof(double));
+    eval_factor(f, x, err20, J20x7);
+    return 0;
+}
+// x-independent local plane record at one scan point (for the GPU plane-cache parity test)
+int oracle_plane_at(void* h, int frame, uint32_t pt_idx, double radius, int max_pts, int32_t* k_out, double* far_d2, double* normal3, double* reg_err_sum) {
+    Oracle& O = *(Oracle*)h; const Frame& f = O.frames[frame];
+    std::vector<uint32_t> idx; std::vector<double> sq; size_t k;
+    const double* c = &f.pts[3 * (size_t)pt_idx];
+    knn_clip(f, c, max_pts, radius, idx, sq, k);
+    *k_out = (int32_t)k; *far_d2 = k ? sq[k - 1] : 0.0;
+    V3d n; double re; normal_and_reg(f, idx, V3d{c[0], c[1], c[2]}, n, re);
+    normal3[0] = n.x; normal3[1] = n.y; normal3[2] = n.z; *reg_err_sum = re;
+    return 0;
+}
+int oracle_num_factors(void* h) { return (int)((Oracle*)h)->factors.size(); }
+
+// ---- unit-level exports for the known-answer tests ----
+void oracle_sim3exp(const double* x, double* R9, double* t3, double* s) { M3d R; V3d t; Sim3Exp<double>(x, R, t, *s); std::memcpy(R9, R.m, 72); t3[0] = t.x; t3[1] = t.y; t3[2] = t.z; }
+void oracle_se3exp(const double* x, double* R9, double* t3) { M3d R; V3d t; SE3Exp<double>(x, R, t); std::memcpy(R9, R.m, 72); t3[0] = t.x; t3[1] = t.y; t3[2] = t.z; }
+void oracle_sim3exp_jet(const double* x, double* R9, double* t3, double* dR /*9x7*/, double* dt /*3x7*/) {
+    using D7 = Dual<7>; D7 xd[7]; for (int i = 0; i < 7; ++i) xd[i] = D7(x[i], i);
+    M3<D7> R; V3<D7> t; D7 s; Sim3Exp<D7>(xd, R, t, s);
+    for (int i = 0; i < 9; ++i) { R9[i] = R.m[i].a; for (int c = 0; c < 7; ++c) dR[i * 7 + c] = R.m[i].v[c]; }
+    for (int i = 0; i < 3; ++i) { t3[i] = t[i].a; for (int c = 0; c < 7; ++c) dt[i * 7 + c] = t[i].v[c]; }
+}
+void oracle_se3log(const double* R9, const double* t3, double* out6) { M3d R; std::memcpy(R.m, R9, 72); SE3Log(R, V3d{t3[0], t3[1], t3[2]}, out6); }
+void oracle_covariance(const double* pts, const uint32_t* idx, uint64_t n, double* cov9) { M3d c = ComputeCovariance(pts, idx, n); std::memcpy(cov9, c.m, 72); }
+void oracle_fast_eigen(const double* cov9, double* evec3, double* evals3) { M3d c; std::memcpy(c.m, cov9, 72); V3d v = FastEigen3x3_EV(c, evals3); evec3[0] = v.x; evec3[1] = v.y; evec3[2] = v.z; }
+void oracle_huber(double a, double s, double* rho0, double* rho1) { huber(a, s, *rho0, *rho1); }
+int oracle_knn(int dim, const double* pts, uint64_t n, int leaf, const double* queries, uint64_t nq, int k, uint32_t* out_idx, double* out_d2, int32_t* out_cnt) {
+    auto run = [&](auto& tree, int D) {
+        for (uint64_t q = 0; q < nq; ++q) {
+            std::vector<uint32_t> indices(k); std::vector<double> sq(k, std::numeric_limits<double>::max());
+            KNNResultSet rs((size_t)k); rs.init(indices.data(), sq.data());
+            tree.findNeighbors(rs, queries + q * D);
+            const int cnt = (int)rs.size(); out_cnt[q] = cnt;
+            for (int j = 0; j < k; ++j) { out_idx[q * k + j] = j < cnt ? indices[j] : 0xFFFFFFFFu; out_d2[q * k + j] = j < cnt ? sq[j] : -1.0; }
+        }
+    };
+    if (dim == 2) { KDTree<2> t(pts, n, (size_t)leaf); run(t, 2); return 0; }
+    if (dim == 3) { KDTree<3> t(pts, n, (size_t)leaf); run(t, 3); return 0; }
+    return 1;
+}
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

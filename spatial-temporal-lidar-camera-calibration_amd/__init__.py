@@ -1,0 +1,231 @@
+"""MI355X-native IBA cross-modality evaluation path — Python plumbing around the C-ABI library.
+
+The product is csrc/ (hand-written HIP for gfx950 behind include/iba_mi355x.h). This module only
+builds/loads libiba_mi355x.so and wraps the entry points with numpy arrays for tests and bench.py.
+It never computes anything itself and never touches oracle/: if the HIP library (or a GPU) is
+missing, calls fail loudly.
+
+The directory name carries a hyphen; import it with
+    importlib.import_module("spatial-temporal-lidar-camera-calibration_amd")
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .abi import (IBA_MAX_BATCH, IbaBbo, IbaCostOut, IbaNormalOut, IbaParams, IbaProblemDesc, Problem, copy_params,
+                  reference_yaml_params)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiba_mi355x.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "iba_mi355x.h")
+
+STATUS = {0: "IBA_OK", 1: "IBA_ERR_INVALID_ARG", 2: "IBA_ERR_NO_DEVICE", 3: "IBA_ERR_HIP", 4: "IBA_ERR_UNSUPPORTED", 5: "IBA_ERR_STATE"}
+
+
+class IbaError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS.get(status, status)}: {msg}")
+        self.status = status
+
+
+def build_extension(force=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). Returns the .so path."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp"))] + [HEADER_PATH]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IbaError(2, f"{LIB_PATH} is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.iba_last_error.restype = C.c_char_p
+        L.iba_last_error.argtypes = [C.c_void_p]
+        L.iba_create.argtypes = [C.POINTER(IbaProblemDesc), C.POINTER(IbaParams), C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.iba_destroy.argtypes = [C.c_void_p]
+        L.iba_num_points.restype = C.c_int64
+        L.iba_num_points.argtypes = [C.c_void_p]
+        L.iba_num_keypoints.restype = C.c_int64
+        L.iba_num_keypoints.argtypes = [C.c_void_p]
+        L.iba_eval_cost_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.iba_eval_normal_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params():
+    p = IbaParams()
+    load_library().iba_default_params(C.byref(p))
+    return p
+
+
+def partial_stride():
+    return int(load_library().iba_partial_stride())
+
+
+def finalize_cost(params, partials):
+    partials = np.ascontiguousarray(partials, np.float64).reshape(-1, partial_stride())
+    B = len(partials)
+    out = (IbaCostOut * B)()
+    st = load_library().iba_finalize_cost(C.byref(params), _p(partials), C.c_int32(B), out)
+    if st != 0:
+        raise IbaError(st, "iba_finalize_cost")
+    return list(out)
+
+
+def finalize_normal(params, partials):
+    partials = np.ascontiguousarray(partials, np.float64).reshape(-1, partial_stride())
+    B = len(partials)
+    out = (IbaNormalOut * B)()
+    st = load_library().iba_finalize_normal(C.byref(params), _p(partials), C.c_int32(B), out)
+    if st != 0:
+        raise IbaError(st, "iba_finalize_normal")
+    return list(out)
+
+
+class IbaHandle:
+    """iba_handle wrapper. One evaluation at a time per handle (as BALoss::eval_x)."""
+
+    def __init__(self, problem, params=None, device=0, frame_begin=0, frame_end=None):
+        self.lib = load_library()
+        self.problem = problem
+        self.params = copy_params(params) if params is not None else default_params()
+        self._desc = problem.desc()
+        self.h = C.c_void_p(None)
+        fe = problem.n_frames if frame_end is None else frame_end
+        self.frame_begin, self.frame_end = frame_begin, fe
+        st = self.lib.iba_create(C.byref(self._desc), C.byref(self.params), C.c_int(device), C.c_int32(frame_begin), C.c_int32(fe), C.byref(self.h))
+        if st != 0:
+            raise IbaError(st, self.lib.iba_last_error(None).decode())
+
+    def _chk(self, st):
+        if st != 0:
+            raise IbaError(st, self.lib.iba_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.iba_destroy(self.h)
+            self.h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params):
+        self.params = copy_params(params)
+        self._chk(self.lib.iba_set_params(self.h, C.byref(self.params)))
+
+    @staticmethod
+    def _x(x):
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
+        assert x.shape[1] == 7
+        return x
+
+    def eval_cost(self, x):
+        x = self._x(x)
+        B = len(x)
+        out = (IbaCostOut * B)()
+        self._chk(self.lib.iba_eval_cost(self.h, _p(x), C.c_int32(B), out))
+        return list(out)
+
+    def eval_bbo(self, x, he_threshold, valid_rate):
+        x = self._x(x)
+        B = len(x)
+        out = (IbaBbo * B)()
+        self._chk(self.lib.iba_eval_bbo(self.h, _p(x), C.c_int32(B), C.c_double(he_threshold), C.c_double(valid_rate), out))
+        return list(out)
+
+    def eval_normal(self, x):
+        x = self._x(x)
+        B = len(x)
+        out = (IbaNormalOut * B)()
+        self._chk(self.lib.iba_eval_normal(self.h, _p(x), C.c_int32(B), out))
+        return list(out)
+
+    def build_problem(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        self._chk(self.lib.iba_build_problem(self.h, _p(x)))
+
+    def eval_factors(self, x):
+        x = self._x(x)
+        B = len(x)
+        out = (IbaNormalOut * B)()
+        self._chk(self.lib.iba_eval_factors(self.h, _p(x), C.c_int32(B), out))
+        return list(out)
+
+    def eval_residuals(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        n = C.c_int64(0)
+        self._chk(self.lib.iba_eval_residuals(self.h, _p(x), None, None, None, None, C.byref(n)))
+        m = n.value
+        r = np.zeros(m)
+        J = np.zeros((m, 7))
+        bid = np.zeros(m, np.int32)
+        kind = np.zeros(m, np.int32)
+        if m:
+            self._chk(self.lib.iba_eval_residuals(self.h, _p(x), _p(r), _p(J), _p(bid), _p(kind), C.byref(n)))
+        return r, J, bid, kind
+
+    def correspondences(self, x, frame):
+        o = self.problem.arrays["kp_offset"]
+        K = int(o[frame + 1] - o[frame])
+        kp = np.zeros(max(K, 1), np.uint32)
+        pt = np.zeros(max(K, 1), np.uint32)
+        n = C.c_int32(0)
+        x = np.ascontiguousarray(x, np.float64)
+        self._chk(self.lib.iba_get_correspondences(self.h, _p(x), C.c_int32(frame), _p(kp), _p(pt), C.c_int32(K), C.byref(n)))
+        return kp[: n.value].copy(), pt[: n.value].copy()
+
+    # --- multi-GPU building blocks: partial sums into caller-owned device memory ---
+    def eval_cost_partial(self, x, d_partials_ptr, stream_ptr=None):
+        x = self._x(x)
+        self._chk(self.lib.iba_eval_cost_partial(self.h, _p(x), C.c_int32(len(x)), C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
+
+    def eval_normal_partial(self, x, d_partials_ptr, stream_ptr=None):
+        x = self._x(x)
+        self._chk(self.lib.iba_eval_normal_partial(self.h, _p(x), C.c_int32(len(x)), C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
+
+    def set_timing(self, on=True):
+        self._chk(self.lib.iba_set_timing(self.h, C.c_int32(1 if on else 0)))
+
+    def last_kernel_ms(self):
+        a = C.c_float(0)
+        b = C.c_float(0)
+        self._chk(self.lib.iba_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @property
+    def n_points(self):
+        return int(self.lib.iba_num_points(self.h))
+
+    @property
+    def n_keypoints(self):
+        return int(self.lib.iba_num_keypoints(self.h))
+
+
+def shard_frames(n_frames, world_size, rank, weights=None):
+    """Contiguous frame range of `rank`, balanced by `weights` (points per frame; uniform if None)."""
+    w = np.ones(n_frames) if weights is None else np.asarray(weights, np.float64)
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    tot = c[-1]
+    cuts = [int(np.searchsorted(c, tot * r / world_size, side="left")) for r in range(world_size + 1)]
+    cuts[0], cuts[-1] = 0, n_frames
+    for i in range(1, world_size + 1):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]

@@ -1,0 +1,490 @@
+// C-ABI of the MI355X IBA evaluation path (include/iba_mi355x.h). Host side: flat-problem packing,
+// static index builds, kernel launches, host finalisation. There is NO CPU compute fallback: every
+// entry point that evaluates anything needs a HIP device and fails with IBA_ERR_NO_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/iba_mi355x.h"
+#include "iba_build.hpp"
+#include "iba_host_math.hpp"
+#include "iba_kernels.hpp"
+#include "iba_types.hpp"
+
+using namespace iba;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+constexpr uint32_t kLdsBytes = 160u * 1024u;
+constexpr int kRing = 4;
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) { n = count; return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size()); if (e != hipSuccess) return e;
+        if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct iba_handle {
+    int device = 0;
+    int n_frames = 0;          // owned frames
+    int global_frames = 0;
+    int frame_begin = 0;
+    iba_params params{};
+    DevParams dprm{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    bool timing = false;
+    float last_frame_ms = 0.f, last_total_ms = 0.f;
+    int64_t n_points = 0, n_keypoints = 0;
+    uint32_t maxP = 0, maxPpad = 0, maxK = 0, maxNodes = 0, maxBitmapWords = 0;
+    bool scan_lds = false;
+    LdsLayout lay{};
+
+    DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
+    DevBuf<float> xs, ys, zs; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
+    DevBuf<float2> kp_uv; DevBuf<float4> kp_mp;
+    DevBuf<uint32_t> cell_start, cell_kp, bitmap; DevBuf<float2> cell_uv;
+    DevBuf<float2> match_uv;
+    DevBuf<PlaneRec> plane_cost, plane_local;
+    bool plane_local_aliases_cost = false;
+    double plane_cost_r2 = -1, plane_local_r2 = -1; int plane_cost_max = -1, plane_local_max = -1;
+    DevBuf<Cand> d_cands;                 // kRing * IBA_MAX_BATCH
+    DevBuf<double> d_frame_partials;      // IBA_MAX_BATCH * n_frames * kPartialStride
+    DevBuf<double> d_partials;            // IBA_MAX_BATCH * kPartialStride
+    DevBuf<uint32_t> d_corr;              // n_keypoints
+    Cand* h_cands = nullptr;              // pinned, kRing * IBA_MAX_BATCH
+    double* h_partials = nullptr;         // pinned
+    hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    bool ring_used[kRing] = {false, false, false, false};
+    int ring_next = 0;
+    std::vector<FrameHdr> h_frames;
+    std::vector<uint64_t> h_kp_off;       // local frame -> kp offset (K+1)
+
+    DevProblem dev_problem() const {
+        DevProblem dp{};
+        dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p;
+        dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.cell_start = cell_start.p; dp.cell_kp = cell_kp.p; dp.cell_uv = cell_uv.p;
+        dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
+        dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames;
+        return dp;
+    }
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                  \
+            return (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? IBA_ERR_NO_DEVICE : IBA_ERR_HIP; \
+        }                                                                                                  \
+    } while (0)
+
+iba_status fail(iba_handle* h, iba_status s, const std::string& msg) { if (h) h->err = msg; else g_create_error = msg; return s; }
+
+void to_dev_params(const iba_params& p, DevParams& d) {
+    d.gate2 = p.max_pixel_dist * p.max_pixel_dist;
+    d.grid_margin = p.max_pixel_dist + 0.01;
+    d.num_min_corr_cost = p.num_min_corr_cost;
+    d.corr_3d_2d_threshold = p.corr_3d_2d_threshold; d.corr_3d_3d_threshold = p.corr_3d_3d_threshold;
+    d.norm_max_pts = p.norm_max_pts; d.norm_min_pts = p.norm_min_pts;
+    d.norm_radius2 = p.norm_radius * p.norm_radius; d.norm_reg_threshold = p.norm_reg_threshold; d.min_diff_dist2 = p.min_diff_dist * p.min_diff_dist;
+    d.use_plane = p.use_plane; d.use_3d3d = p.err_weight[1] > 1e-10 ? 1 : 0;
+    d.num_min_corr = p.num_min_corr; d.max_3d_dist2 = p.max_3d_dist * p.max_3d_dist; d.neigh_radius2 = p.neigh_radius * p.neigh_radius;
+    d.neigh_max_pts = p.neigh_max_pts; d.neigh_min_pts = p.neigh_min_pts;
+    d.local_min_diff_dist2 = p.local_min_diff_dist * p.local_min_diff_dist; d.local_norm_reg_threshold = p.local_norm_reg_threshold;
+    d.robust_kernel_delta = p.robust_kernel_delta; d.robust_kernel_3ddelta = p.robust_kernel_3ddelta; d.plane_cache = p.plane_cache;
+}
+
+iba_status check_params(iba_handle* h, const iba_params& p) {
+    if (!(p.max_pixel_dist > 0) || 2.0 * (p.max_pixel_dist + 0.01) > (double)kGridCell)
+        return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist must be in (0, 1.99] px for the 4 px keypoint grid");
+    if (p.norm_max_pts < 1 || p.norm_max_pts > 32 || p.neigh_max_pts < 1 || p.neigh_max_pts > 32)
+        return fail(h, IBA_ERR_UNSUPPORTED, "norm_max_pts / neigh_max_pts must be in [1, 32]");
+    if (!p.plane_cache) return fail(h, IBA_ERR_UNSUPPORTED, "plane_cache = 0 (per-evaluation plane refit) is not implemented yet");
+    return IBA_OK;
+}
+
+template <class F>
+void parallel_for(int n, F fn) {
+    const int nt = std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), n));
+    if (nt <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& t : th) t.join();
+}
+
+uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
+    const uint32_t red_bytes = 8u * (kWaves + 1) * kRedSlots + 4u * kWaves;
+    L.scan_stride = with_scan ? h->maxPpad : 0;
+    uint32_t off = with_scan ? 12u * h->maxPpad : 0u;
+    off = align_up(off, 16); L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
+    L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
+    off = align_up(off, 8); L.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
+    L.off_bitmap = off; off += 4u * std::max(h->maxBitmapWords, 1u);
+    off = align_up(off, 8); L.off_red = off; off += red_bytes;
+    L.total = align_up(off, 16);
+    return L.total <= kLdsBytes;
+}
+
+iba_status compute_plane_cache(iba_handle* h) {
+    const iba_params& p = h->params;
+    const DevProblem dp = h->dev_problem();
+    auto run = [&](double r2, int max_pts, PlaneRec* out) -> hipError_t {
+        dim3 grid((h->maxP + 3) / 4, h->n_frames);
+        if (h->maxP == 0 || h->n_frames == 0) return hipSuccess;
+        hipLaunchKernelGGL(iba_plane_kernel, grid, dim3(256), 0, h->stream, dp, r2, max_pts, out);
+        hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
+        return hipStreamSynchronize(h->stream);
+    };
+    const double r2c = p.norm_radius * p.norm_radius, r2l = p.neigh_radius * p.neigh_radius;
+    if (h->plane_cost_r2 != r2c || h->plane_cost_max != p.norm_max_pts) {
+        HIP_TRY(h, run(r2c, p.norm_max_pts, h->plane_cost.p));
+        h->plane_cost_r2 = r2c; h->plane_cost_max = p.norm_max_pts;
+    }
+    h->plane_local_aliases_cost = (r2l == r2c && p.neigh_max_pts == p.norm_max_pts);
+    if (!h->plane_local_aliases_cost && (h->plane_local_r2 != r2l || h->plane_local_max != p.neigh_max_pts)) {
+        if (!h->plane_local.p) HIP_TRY(h, h->plane_local.alloc(h->plane_cost.n));
+        HIP_TRY(h, run(r2l, p.neigh_max_pts, h->plane_local.p));
+        h->plane_local_r2 = r2l; h->plane_local_max = p.neigh_max_pts;
+    }
+    return IBA_OK;
+}
+
+template <int MODE>
+iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, hipStream_t st) {
+    const DevProblem dp = h->dev_problem();
+    const int per_xcd = (h->n_frames + 7) / 8;
+    const dim3 grid(8 * per_xcd * B), block(kThreads);
+    if (h->n_frames == 0) return IBA_OK;
+    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr);
+    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr);
+    HIP_TRY(h, hipGetLastError());
+    return IBA_OK;
+}
+
+// stages B candidates into a pinned ring slot and enqueues the H2D copy; returns the device pointer
+iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out) {
+    const int slot = h->ring_next; h->ring_next = (h->ring_next + 1) % kRing;
+    if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
+    Cand* hc = h->h_cands + (size_t)slot * IBA_MAX_BATCH;
+    for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
+    Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
+    HIP_TRY(h, hipMemcpyAsync(dc, hc, sizeof(Cand) * B, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipEventRecord(h->ring_ev[slot], st));
+    h->ring_used[slot] = true;
+    *d_out = dc;
+    return IBA_OK;
+}
+
+iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
+    if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Cand* dc = nullptr;
+    iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    s = launch_frame<MODE_COST>(h, dc, B, h->d_frame_partials.p, nullptr, st); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->n_frames, d_partials);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev2, st));
+    return IBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+iba_status iba_default_params(iba_params* p) {
+    if (!p) return IBA_ERR_INVALID_ARG;
+    std::memset(p, 0, sizeof(*p));
+    p->max_pixel_dist = 1.5; p->num_min_corr_cost = 30; p->corr_3d_2d_threshold = 40.; p->corr_3d_3d_threshold = 5.;
+    p->norm_max_pts = 30; p->norm_min_pts = 5; p->norm_radius = 0.6; p->norm_reg_threshold = 0.04; p->min_diff_dist = 0.01;
+    p->err_weight[0] = 1.0; p->err_weight[1] = 1.0; p->use_plane = 1;
+    p->num_min_corr = 30; p->max_3d_dist = 1.0; p->neigh_radius = 0.6; p->neigh_max_pts = 30; p->neigh_min_pts = 5;
+    p->local_min_diff_dist = 0.2; p->local_norm_reg_threshold = 0.001; p->robust_kernel_delta = 2.98; p->robust_kernel_3ddelta = 1.0;
+    p->plane_cache = 1;
+    return IBA_OK;
+}
+
+const char* iba_last_error(const iba_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+int32_t iba_partial_stride(void) { return kPartialStride; }
+int64_t iba_num_points(const iba_handle* h) { return h ? h->n_points : 0; }
+int64_t iba_num_keypoints(const iba_handle* h) { return h ? h->n_keypoints : 0; }
+
+void iba_destroy(iba_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release();
+    h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->cell_start.release(); h->cell_kp.release(); h->bitmap.release(); h->cell_uv.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release();
+    if (h->h_cands) (void)hipHostFree(h->h_cands);
+    if (h->h_partials) (void)hipHostFree(h->h_partials);
+    for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int device, int32_t frame_begin, int32_t frame_end, iba_handle** out) {
+    g_create_error.clear();
+    if (!d || !params || !out) return fail(nullptr, IBA_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    const int F = d->n_frames;
+    if (F < 0 || frame_begin < 0 || frame_end < frame_begin || frame_end > F) return fail(nullptr, IBA_ERR_INVALID_ARG, "bad frame range");
+    {
+        iba_status ps = check_params(nullptr, *params);
+        if (ps != IBA_OK) return ps;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, IBA_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, IBA_ERR_NO_DEVICE, "device index out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, IBA_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+    iba_handle* h = new iba_handle;
+    h->device = device; h->params = *params; to_dev_params(*params, h->dprm);
+    h->global_frames = F; h->frame_begin = frame_begin; h->n_frames = frame_end - frame_begin;
+    const int nf = h->n_frames;
+
+    // ---- validation of the owned slice ----
+    for (int f = frame_begin; f < frame_end; ++f) {
+        const uint64_t P = d->pt_offset[f + 1] - d->pt_offset[f], K = d->kp_offset[f + 1] - d->kp_offset[f];
+        if (P >= (1ull << 24) || K >= (1ull << 20)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan or keypoint count too large"); }
+        const uint64_t ns = d->covis_offset[f + 1] - d->covis_offset[f];
+        if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 10 covisible keyframes per frame"); }
+    }
+
+    // ---- per-frame host build (parallel over frames; reference: omp parallel for at iba_global.cpp:363) ----
+    struct FrameBuild { std::vector<uint32_t> idx; std::vector<TreeNode> nodes; KpGrid grid; uint32_t D = 0; };
+    std::vector<FrameBuild> fb(nf);
+    const double margin = h->dprm.grid_margin;
+    parallel_for(nf, [&](int lf) {
+        const int f = frame_begin + lf;
+        const uint32_t P = (uint32_t)(d->pt_offset[f + 1] - d->pt_offset[f]);
+        const uint32_t K = (uint32_t)(d->kp_offset[f + 1] - d->kp_offset[f]);
+        FrameBuild& b = fb[lf];
+        b.D = tree_depth_for(P);
+        build_tree(d->pts_xyz + 3 * d->pt_offset[f], P, b.D, b.idx, b.nodes);
+        const double* in = d->intrinsics + 6 * f;
+        build_kp_grid(d->kp_uv + 2 * d->kp_offset[f], K, in[4], in[5], margin, b.grid);
+    });
+
+    // ---- flatten ----
+    std::vector<FrameHdr>& hdr = h->h_frames; hdr.resize(nf);
+    uint64_t pt_base = 0, kp_base = 0, cell_base = 0, bm_base = 0, match_base = 0; uint32_t node_base = 0, slot_base = 0;
+    for (int lf = 0; lf < nf; ++lf) {
+        const int f = frame_begin + lf;
+        FrameHdr& x = hdr[lf]; std::memset(&x, 0, sizeof(x));
+        x.P = (uint32_t)(d->pt_offset[f + 1] - d->pt_offset[f]); x.Ppad = (x.P + 3u) & ~3u; x.pt_base = pt_base; pt_base += x.Ppad;
+        x.depth = fb[lf].D; x.node_base = node_base; node_base += (uint32_t)fb[lf].nodes.size();
+        x.K = (uint32_t)(d->kp_offset[f + 1] - d->kp_offset[f]); x.kp_base = kp_base; kp_base += x.K;
+        x.gw = fb[lf].grid.gw; x.gh = fb[lf].grid.gh; x.cell_base = cell_base; cell_base += (uint64_t)x.gw * x.gh + 1;
+        x.bitmap_base = bm_base; bm_base += fb[lf].grid.bitmap.size();
+        x.n_slots = (uint32_t)(d->covis_offset[f + 1] - d->covis_offset[f]); x.slot_base = slot_base; slot_base += x.n_slots;
+        x.match_base = match_base; match_base += (uint64_t)x.n_slots * x.K;
+        const double* in = d->intrinsics + 6 * f;
+        x.fx = in[0]; x.fy = in[1]; x.cx = in[2]; x.cy = in[3]; x.W = in[4]; x.H = in[5];
+        for (int i = 0; i < 12; ++i) { x.Tcw[i] = (double)d->Tcw[12 * f + i]; x.Tc_next[i] = (double)d->Tc_next[12 * f + i]; x.Tl_next[i] = d->Tl_next[12 * f + i]; }
+        x.he_valid = f < F - 1 ? 1 : 0; x.global_frame = f;
+        h->maxP = std::max(h->maxP, x.P); h->maxPpad = std::max(h->maxPpad, x.Ppad); h->maxK = std::max(h->maxK, x.K);
+        h->maxNodes = std::max<uint32_t>(h->maxNodes, (uint32_t)fb[lf].nodes.size());
+        h->maxBitmapWords = std::max<uint32_t>(h->maxBitmapWords, (uint32_t)fb[lf].grid.bitmap.size());
+    }
+    h->n_points = 0; for (auto& x : hdr) h->n_points += x.P;
+    h->n_keypoints = (int64_t)kp_base;
+    h->h_kp_off.resize(nf + 1); for (int lf = 0; lf < nf; ++lf) h->h_kp_off[lf] = hdr[lf].kp_base; h->h_kp_off[nf] = kp_base;
+
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    std::vector<float> xs(pt_base, qnan), ys(pt_base, qnan), zs(pt_base, qnan);
+    std::vector<uint32_t> perm(pt_base, 0u), inv_perm(pt_base, 0u);
+    std::vector<TreeNode> nodes(node_base);
+    std::vector<float2> kp_uv(kp_base), cell_uv(kp_base); std::vector<float4> kp_mp(kp_base);
+    std::vector<uint32_t> cell_start(cell_base), cell_kp(kp_base), bitmap(bm_base);
+    std::vector<float2> match_uv(match_base, float2{qnan, qnan});
+    std::vector<SlotHdr> slots(slot_base);
+    std::atomic<bool> bad_match(false);
+    parallel_for(nf, [&](int lf) {
+        const int f = frame_begin + lf; const FrameHdr& x = hdr[lf]; const FrameBuild& b = fb[lf];
+        const float* src = d->pts_xyz + 3 * d->pt_offset[f];
+        for (uint32_t i = 0; i < x.P; ++i) {
+            const uint32_t o = b.idx[i];
+            xs[x.pt_base + i] = src[3 * (size_t)o]; ys[x.pt_base + i] = src[3 * (size_t)o + 1]; zs[x.pt_base + i] = src[3 * (size_t)o + 2];
+            perm[x.pt_base + i] = o; inv_perm[x.pt_base + o] = i;
+        }
+        std::copy(b.nodes.begin(), b.nodes.end(), nodes.begin() + x.node_base);
+        const uint64_t k0 = d->kp_offset[f];
+        for (uint32_t k = 0; k < x.K; ++k) {
+            kp_uv[x.kp_base + k] = float2{d->kp_uv[2 * (k0 + k)], d->kp_uv[2 * (k0 + k) + 1]};
+            const bool has = d->kp_has_mappoint[k0 + k] != 0;
+            kp_mp[x.kp_base + k] = has ? float4{d->kp_mappoint_w[3 * (k0 + k)], d->kp_mappoint_w[3 * (k0 + k) + 1], d->kp_mappoint_w[3 * (k0 + k) + 2], 1.0f} : float4{0.f, 0.f, 0.f, 0.f};
+            cell_kp[x.kp_base + k] = b.grid.cell_kp[k];
+            cell_uv[x.kp_base + k] = float2{b.grid.cell_uv[2 * k], b.grid.cell_uv[2 * k + 1]};
+        }
+        std::copy(b.grid.cell_start.begin(), b.grid.cell_start.end(), cell_start.begin() + x.cell_base);
+        std::copy(b.grid.bitmap.begin(), b.grid.bitmap.end(), bitmap.begin() + x.bitmap_base);
+        for (uint32_t sl = 0; sl < x.n_slots; ++sl) {
+            const uint64_t gs = d->covis_offset[f] + sl;
+            for (int i = 0; i < 12; ++i) slots[x.slot_base + sl].rel[i] = (double)d->covis_relpose[12 * gs + i];
+            const int cf = d->covis_frame[gs];
+            if (cf < 0 || cf >= F) { bad_match = true; continue; }
+            const uint64_t ck0 = d->kp_offset[cf], cK = d->kp_offset[cf + 1] - ck0;
+            for (uint64_t m = d->match_offset[gs]; m < d->match_offset[gs + 1]; ++m) {
+                const int kr = d->match_kp_ref[m], kc = d->match_kp_covis[m];
+                if (kr < 0 || (uint32_t)kr >= x.K || kc < 0 || (uint64_t)kc >= cK) { bad_match = true; continue; }
+                match_uv[x.match_base + (uint64_t)sl * x.K + kr] = float2{d->kp_uv[2 * (ck0 + kc)], d->kp_uv[2 * (ck0 + kc) + 1]};
+            }
+        }
+    });
+    fb.clear(); fb.shrink_to_fit();
+    if (bad_match) { delete h; return fail(nullptr, IBA_ERR_INVALID_ARG, "covisibility / match index out of range"); }
+
+    // ---- LDS plan: stage the scan in LDS when it fits (<= ~10.9k points with 2000 keypoints) ----
+    h->scan_lds = layout(h, true, h->lay);
+    if (!h->scan_lds && !layout(h, false, h->lay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
+
+    auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
+#define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
+    UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes);
+    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(cell_start, cell_start); UP(cell_kp, cell_kp); UP(cell_uv, cell_uv); UP(bitmap, bitmap); UP(match_uv, match_uv);
+#undef UP
+    hipError_t er;
+    if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);
+    if ((er = h->d_cands.alloc((size_t)kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("alloc cands", er);
+    if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
+    if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
+    if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
+    if ((er = hipHostMalloc((void**)&h->h_cands, sizeof(Cand) * kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("hipHostMalloc", er);
+    if ((er = hipHostMalloc((void**)&h->h_partials, sizeof(double) * IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("hipHostMalloc", er);
+    if ((er = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
+    if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
+    for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
+    // > 64 KB of dynamic LDS must be opted into per kernel
+    const void* fns[4] = {(const void*)iba_frame_kernel<MODE_COST, true>, (const void*)iba_frame_kernel<MODE_COST, false>,
+                          (const void*)iba_frame_kernel<MODE_CORR, true>, (const void*)iba_frame_kernel<MODE_CORR, false>};
+    for (const void* fn : fns)
+        if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+
+    iba_status ps = compute_plane_cache(h);
+    if (ps != IBA_OK) { g_create_error = h->err; iba_destroy(h); return ps; }
+    *out = h;
+    return IBA_OK;
+}
+
+iba_status iba_set_params(iba_handle* h, const iba_params* p) {
+    if (!h || !p) return IBA_ERR_INVALID_ARG;
+    iba_status s = check_params(h, *p); if (s != IBA_OK) return s;
+    if (p->max_pixel_dist != h->params.max_pixel_dist) return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist is baked into the keypoint grid: recreate the handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->params = *p; to_dev_params(*p, h->dprm);
+    return compute_plane_cache(h);
+}
+
+iba_status iba_set_timing(iba_handle* h, int32_t enable) { if (!h) return IBA_ERR_INVALID_ARG; h->timing = enable != 0; return IBA_OK; }
+iba_status iba_last_kernel_ms(iba_handle* h, float* frame_kernel_ms, float* total_ms) {
+    if (!h) return IBA_ERR_INVALID_ARG;
+    if (frame_kernel_ms) *frame_kernel_ms = h->last_frame_ms;
+    if (total_ms) *total_ms = h->last_total_ms;
+    return IBA_OK;
+}
+
+iba_status iba_finalize_cost(const iba_params* p, const double* part, int32_t B, iba_cost_out* out) {
+    if (!p || !part || !out || B < 1) return IBA_ERR_INVALID_ARG;
+    for (int b = 0; b < B; ++b) {
+        const double* q = part + (size_t)b * kPartialStride; iba_cost_out& o = out[b];
+        o.valid_cnt_3d_2d = (int32_t)q[P_VALID_3D2D]; o.cnt_3d_2d = (int32_t)q[P_CNT_3D2D];
+        o.cnt_3d_3d = (int32_t)q[P_CNT_3D3D]; o.valid_cnt_3d_3d = (int32_t)q[P_VALID_3D3D];
+        o.valid_pl_3d_3d = (int32_t)q[P_VALID_PL]; o.valid_pt_3d_3d = (int32_t)q[P_VALID_PT];
+        o.frames_used = (int32_t)q[P_FRAMES]; o.n_corr = (int32_t)q[P_NCORR];
+        // iba_global.cpp:330-338
+        if (o.valid_cnt_3d_2d == 0 && p->err_weight[0] > 1e-10) o.f1 = std::numeric_limits<double>::max();
+        else o.f1 = q[P_SUM_3D2D] / (double)o.valid_cnt_3d_2d;
+        if (o.valid_cnt_3d_3d == 0 && p->err_weight[1] > 1e-10) o.f2 = std::numeric_limits<double>::max();
+        else o.f2 = (p->err_weight[1] <= 1e-10 ? 0.0 : q[P_SUM_3D3D]) / (double)o.valid_cnt_3d_3d;
+        o.C = q[P_HE_SUM] / q[P_HE_CNT];
+    }
+    return IBA_OK;
+}
+
+iba_status iba_eval_cost_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
+    if (!h || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return eval_cost_partial_impl(h, x, B, (double*)d_partials, stream ? (hipStream_t)stream : h->stream);
+}
+
+iba_status iba_eval_cost(iba_handle* h, const double* x, int32_t B, iba_cost_out* out) {
+    if (!h || !out) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    iba_status s = eval_cost_partial_impl(h, x, B, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
+    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
+    return iba_finalize_cost(&h->params, h->h_partials, B, out);
+}
+
+iba_status iba_eval_bbo(iba_handle* h, const double* x, int32_t B, double he_threshold, double valid_rate, iba_bbo* out) {
+    if (!h || !out || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    iba_cost_out c[IBA_MAX_BATCH];
+    iba_status s = iba_eval_cost(h, x, B, c); if (s != IBA_OK) return s;
+    for (int b = 0; b < B; ++b) {   // iba_global.cpp:386-392
+        out[b].f = c[b].f1 * h->params.err_weight[0] + c[b].f2 * h->params.err_weight[1];
+        out[b].c1 = c[b].C - he_threshold; out[b].c2 = -c[b].C - he_threshold;
+        out[b].c3 = valid_rate - static_cast<double>(c[b].valid_cnt_3d_2d) / (c[b].cnt_3d_2d + 1);
+    }
+    return IBA_OK;
+}
+
+iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame, uint32_t* kp_idx, uint32_t* pt_idx, int32_t cap, int32_t* n_out) {
+    if (!h || !x || !n_out) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    const int lf = frame - h->frame_begin;
+    if (lf < 0 || lf >= h->n_frames) return fail(h, IBA_ERR_INVALID_ARG, "frame not owned by this handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Cand* dc = nullptr;
+    iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
+    s = launch_frame<MODE_CORR>(h, dc, 1, h->d_frame_partials.p, h->d_corr.p, h->stream); if (s != IBA_OK) return s;
+    const uint64_t k0 = h->h_kp_off[lf], K = h->h_kp_off[lf + 1] - k0;
+    std::vector<uint32_t> tmp(K);
+    HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_corr.p + k0, sizeof(uint32_t) * K, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int n = 0;
+    for (uint64_t k = 0; k < K; ++k)
+        if (tmp[k] != kNone) { if (n < cap && kp_idx && pt_idx) { kp_idx[n] = (uint32_t)k; pt_idx[n] = tmp[k]; } ++n; }
+    *n_out = n;
+    return IBA_OK;
+}
+
+// ---- Jacobian path: implemented in the next milestone ----
+iba_status iba_eval_normal(iba_handle* h, const double*, int32_t, iba_normal_out*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_normal: not implemented yet"); }
+iba_status iba_build_problem(iba_handle* h, const double*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_build_problem: not implemented yet"); }
+iba_status iba_eval_factors(iba_handle* h, const double*, int32_t, iba_normal_out*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_factors: not implemented yet"); }
+iba_status iba_eval_residuals(iba_handle* h, const double*, double*, double*, int32_t*, int32_t*, int64_t*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_residuals: not implemented yet"); }
+iba_status iba_eval_normal_partial(iba_handle* h, const double*, int32_t, void*, void*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_normal_partial: not implemented yet"); }
+iba_status iba_finalize_normal(const iba_params*, const double*, int32_t, iba_normal_out*) { return IBA_ERR_UNSUPPORTED; }
+
+}  // extern "C"

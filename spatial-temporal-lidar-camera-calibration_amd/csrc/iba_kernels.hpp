@@ -1,0 +1,620 @@
+// CDNA4 (gfx950) kernels of the IBA cross-modality evaluation path. Written for wave64 / 160 KB LDS.
+//
+// iba_frame_kernel: ONE workgroup (16 waves) evaluates ONE keyframe for ONE candidate extrinsic,
+// start to finish, with the whole scan (<= ~10.9k points as float32 SoA), the scan's kd-tree nodes,
+// the keypoint reject-bitmap and the per-keypoint 1-NN slots resident in LDS:
+//   phase 1  K1+K2+K3: stream the scan (16 B/lane coalesced), Tcl*p, pinhole project, FOV cull,
+//            look the pixel up in the static keypoint grid, ds_min_u64 on the keypoint's best d^2
+//            (replaces TransformPointCloud + the per-evaluation KDTree2D rebuild + 1-NN queries,
+//            pointcloud.h:82-86, iba_global.cpp:55-96)
+//   phase 2  exact tie resolution (lowest original point index) for the few points that hit
+//   phase 3  corrset size test (iba_global.cpp:203)
+//   phase 4  K6: covisible reprojection residuals (iba_global.cpp:291-328);
+//            K4+K5: MapPoint -> LiDAR frame, stackless 1-NN in the LDS-resident tree, local plane
+//            (memoised per scan point, or refitted per evaluation) (iba_global.cpp:223-252, 111-156);
+//            K7: hand-eye term (iba_global.cpp:264-276)
+//   phase 5  K8: fixed-order wave/block reduction -> one partial record per (candidate, frame)
+// iba_reduce_kernel sums the records over frames in a fixed order (bitwise reproducible).
+// iba_plane_kernel: wave-per-query kNN(<=32)+covariance+closed-form eigen = the x-independent part of
+// ComputeAlignmentDist / ComputeLocalNeighbor / ComputeLocalNormalSingleThre.
+//
+// All arithmetic that decides an index or a gate is IEEE double in the reference's expression order;
+// the library is compiled with -ffp-contract=off so no mul+add is fused on either side.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "iba_build.hpp"
+#include "iba_types.hpp"
+
+namespace iba {
+
+struct DevProblem {
+    const FrameHdr* frames;
+    const SlotHdr* slots;
+    const float* xs; const float* ys; const float* zs;
+    const uint32_t* perm;      // tree position -> original point index
+    const uint32_t* inv_perm;  // original point index -> tree position
+    const TreeNode* nodes;
+    const float2* kp_uv;
+    const float4* kp_mp;       // MapPoint world position (x,y,z), w = 1 if the keypoint owns one
+    const uint32_t* cell_start; const uint32_t* cell_kp; const float2* cell_uv; const uint32_t* bitmap;
+    const float2* match_uv;    // [slot][K] matched covisible keypoint, NaN = no match
+    const PlaneRec* plane_cost;   // x-independent plane records (norm_radius / norm_max_pts)
+    const PlaneRec* plane_local;  // (neigh_radius / neigh_max_pts)
+    int32_t n_frames;
+};
+
+struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
+    uint32_t scan_stride;   // floats per coordinate array (0 = scan not staged in LDS)
+    uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_red, total;
+};
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kWaves = kThreads / 64;
+constexpr int kRedSlots = 64;   // doubles per wave in the reduction slab
+
+__device__ __forceinline__ unsigned long long d2bits(double d) { return (unsigned long long)__double_as_longlong(d); }
+
+// ---- SE3Log on device: g2o::SE3Quat(R,t).log() restated (see oracle/oracle_math.hpp) ----
+__device__ inline void dev_se3log(const double* R, const double* t, double* out) {
+    double q[4];
+    double tr = R[0] + R[4] + R[8];
+    if (tr > 0.0) {
+        double s = sqrt(tr + 1.0); q[3] = 0.5 * s; s = 0.5 / s;
+        q[0] = (R[7] - R[5]) * s; q[1] = (R[2] - R[6]) * s; q[2] = (R[3] - R[1]) * s;
+    } else {
+        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[i * 4]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        q[i] = 0.5 * s; s = 0.5 / s;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * s; q[j] = (R[j * 3 + i] + R[i * 3 + j]) * s; q[k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
+    }
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    double r[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+    const double d = 0.5 * (r[0] + r[4] + r[8] - 1);
+    const double dRx = r[7] - r[5], dRy = r[2] - r[6], dRz = r[3] - r[1];
+    double ox, oy, oz, c2;
+    if (fabs(d) > 0.99999) {
+        ox = 0.5 * dRx; oy = 0.5 * dRy; oz = 0.5 * dRz; c2 = 1. / 12.;
+    } else {
+        const double theta = acos(d);
+        const double k = theta / (2 * sqrt(1 - d * d));
+        ox = k * dRx; oy = k * dRy; oz = k * dRz;
+        c2 = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+    }
+    const double Om[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+    double Vi[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const double o2 = Om[a * 3 + 0] * Om[0 * 3 + b] + Om[a * 3 + 1] * Om[1 * 3 + b] + Om[a * 3 + 2] * Om[2 * 3 + b];
+            Vi[a * 3 + b] = ((a == b ? 1.0 : 0.0) - 0.5 * Om[a * 3 + b]) + c2 * o2;
+        }
+    out[0] = ox; out[1] = oy; out[2] = oz;
+    for (int a = 0; a < 3; ++a) out[3 + a] = Vi[a * 3 + 0] * t[0] + Vi[a * 3 + 1] * t[1] + Vi[a * 3 + 2] * t[2];
+}
+
+// ---- closed-form symmetric 3x3 eigen solver: pointcloud.h:194-288, 378-463 restated for device ----
+__device__ inline void dev_evec0(const double* A, double ev, double* o) {
+    const double r0[3] = {A[0] - ev, A[1], A[2]}, r1[3] = {A[1], A[4] - ev, A[5]}, r2[3] = {A[2], A[5], A[8] - ev};
+    const double a[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    const double b[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+    const double c[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    const double d0 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], d1 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2], d2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    double dmax = d0; int imax = 0;
+    if (d1 > dmax) { dmax = d1; imax = 1; }
+    if (d2 > dmax) { imax = 2; }
+    if (imax == 0) { const double s = sqrt(d0); o[0] = a[0] / s; o[1] = a[1] / s; o[2] = a[2] / s; }
+    else if (imax == 1) { const double s = sqrt(d1); o[0] = b[0] / s; o[1] = b[1] / s; o[2] = b[2] / s; }
+    else { const double s = sqrt(d2); o[0] = c[0] / s; o[1] = c[1] / s; o[2] = c[2] / s; }
+}
+__device__ inline void dev_evec1(const double* A, const double* e0, double ev1, double* o) {
+    double U[3], V[3];
+    if (fabs(e0[0]) > fabs(e0[1])) { const double il = 1 / sqrt(e0[0] * e0[0] + e0[2] * e0[2]); U[0] = -e0[2] * il; U[1] = 0; U[2] = e0[0] * il; }
+    else { const double il = 1 / sqrt(e0[1] * e0[1] + e0[2] * e0[2]); U[0] = 0; U[1] = e0[2] * il; U[2] = -e0[1] * il; }
+    V[0] = e0[1] * U[2] - e0[2] * U[1]; V[1] = e0[2] * U[0] - e0[0] * U[2]; V[2] = e0[0] * U[1] - e0[1] * U[0];
+    const double AU[3] = {A[0] * U[0] + A[1] * U[1] + A[2] * U[2], A[1] * U[0] + A[4] * U[1] + A[5] * U[2], A[2] * U[0] + A[5] * U[1] + A[8] * U[2]};
+    const double AV[3] = {A[0] * V[0] + A[1] * V[1] + A[2] * V[2], A[1] * V[0] + A[4] * V[1] + A[5] * V[2], A[2] * V[0] + A[5] * V[1] + A[8] * V[2]};
+    double m00 = U[0] * AU[0] + U[1] * AU[1] + U[2] * AU[2] - ev1;
+    double m01 = U[0] * AV[0] + U[1] * AV[1] + U[2] * AV[2];
+    double m11 = V[0] * AV[0] + V[1] * AV[1] + V[2] * AV[2] - ev1;
+    const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    if (a00 >= a11) {
+        if (fmax(a00, a01) > 0) {
+            if (a00 >= a01) { m01 /= m00; m00 = 1 / sqrt(1 + m01 * m01); m01 *= m00; }
+            else { m00 /= m01; m01 = 1 / sqrt(1 + m00 * m00); m00 *= m01; }
+            o[0] = m01 * U[0] - m00 * V[0]; o[1] = m01 * U[1] - m00 * V[1]; o[2] = m01 * U[2] - m00 * V[2];
+        } else { o[0] = U[0]; o[1] = U[1]; o[2] = U[2]; }
+    } else {
+        if (fmax(a11, a01) > 0) {
+            if (a11 >= a01) { m01 /= m11; m11 = 1 / sqrt(1 + m01 * m01); m01 *= m11; }
+            else { m11 /= m01; m01 = 1 / sqrt(1 + m11 * m11); m11 *= m01; }
+            o[0] = m11 * U[0] - m01 * V[0]; o[1] = m11 * U[1] - m01 * V[1]; o[2] = m11 * U[2] - m01 * V[2];
+        } else { o[0] = U[0]; o[1] = U[1]; o[2] = U[2]; }
+    }
+}
+// eigenvector of the smallest eigenvalue of symmetric `cov` (row-major 9), then Eigen-style normalize()
+__device__ inline void dev_smallest_evec(const double* cov, double* nrm) {
+    double A[9];
+    double mc = cov[0];
+    for (int i = 1; i < 9; ++i) mc = cov[i] > mc ? cov[i] : mc;
+    double v[3] = {0, 0, 0};
+    if (mc != 0) {
+        for (int i = 0; i < 9; ++i) A[i] = cov[i] / mc;
+        const double nn = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (nn > 0) {
+            const double q = (A[0] + A[4] + A[8]) / 3;
+            const double b00 = A[0] - q, b11 = A[4] - q, b22 = A[8] - q;
+            const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + nn * 2) / 6);
+            const double c00 = b11 * b22 - A[5] * A[5];
+            const double c01 = A[1] * b22 - A[5] * A[2];
+            const double c02 = A[1] * A[5] - b11 * A[2];
+            const double det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+            double hd = det * 0.5;
+            hd = fmin(fmax(hd, -1.0), 1.0);
+            const double angle = acos(hd) / 3.0;
+            const double beta2 = cos(angle) * 2;
+            const double beta0 = cos(angle + 2.09439510239319549) * 2;
+            const double beta1 = -(beta0 + beta2);
+            const double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+            if (hd >= 0) {
+                double v2[3]; dev_evec0(A, e2, v2);
+                if (e2 < e0 && e2 < e1) { v[0] = v2[0]; v[1] = v2[1]; v[2] = v2[2]; }
+                else {
+                    double v1[3]; dev_evec1(A, v2, e1, v1);
+                    if (e1 < e0 && e1 < e2) { v[0] = v1[0]; v[1] = v1[1]; v[2] = v1[2]; }
+                    else { v[0] = v1[1] * v2[2] - v1[2] * v2[1]; v[1] = v1[2] * v2[0] - v1[0] * v2[2]; v[2] = v1[0] * v2[1] - v1[1] * v2[0]; }
+                }
+            } else {
+                double v0[3]; dev_evec0(A, e0, v0);
+                if (e0 < e1 && e0 < e2) { v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; }
+                else {
+                    double v1[3]; dev_evec1(A, v0, e1, v1);
+                    if (e1 < e0 && e1 < e2) { v[0] = v1[0]; v[1] = v1[1]; v[2] = v1[2]; }
+                    else { v[0] = v0[1] * v1[2] - v0[2] * v1[1]; v[1] = v0[2] * v1[0] - v0[0] * v1[2]; v[2] = v0[0] * v1[1] - v0[1] * v1[0]; }
+                }
+            }
+        } else {
+            if (cov[0] < cov[4] && cov[0] < cov[8]) v[0] = 1;
+            else if (cov[4] < cov[0] && cov[4] < cov[8]) v[1] = 1;
+            else v[2] = 1;
+        }
+    }
+    const double z = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    if (z > 0) { const double n = sqrt(z); nrm[0] = v[0] / n; nrm[1] = v[1] / n; nrm[2] = v[2] / n; }
+    else { nrm[0] = v[0]; nrm[1] = v[1]; nrm[2] = v[2]; }
+}
+
+// ---- stackless exact 1-NN in the implicit balanced kd-tree (one query per lane) ----
+__device__ __forceinline__ void nn_search(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+                                          const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
+                                          double qx, double qy, double qz, double& best, uint32_t& bpos) {
+    best = INFINITY; bpos = kNone;
+    uint32_t node = 0, depth = 0;
+    const uint32_t first_leaf = (1u << D) - 1u;
+    bool descend = true;
+    for (;;) {
+        if (descend) {
+            while (depth < D) {
+                const TreeNode n = nodes[node];
+                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+                node = 2u * node + 1u + ((qd - (double)n.split) >= 0.0 ? 1u : 0u);
+                ++depth;
+            }
+            const uint32_t j = node - first_leaf;
+            const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+            for (uint32_t i = lo; i < hi; ++i) {
+                const double dx = qx - (double)xs[i], dy = qy - (double)ys[i], dz = qz - (double)zs[i];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 < best) { best = d2; bpos = i; }
+                else if (d2 == best && bpos != kNone) { if (perm_g[i] < perm_g[bpos]) bpos = i; }
+            }
+            descend = false;
+        }
+        if (depth == 0) break;
+        const uint32_t parent = (node - 1u) >> 1;
+        const bool was_right = (node & 1u) == 0u;
+        const TreeNode n = nodes[parent];
+        const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+        const double diff = qd - (double)n.split;
+        const bool near_right = diff >= 0.0;
+        if (was_right == near_right && diff * diff <= best) { node = 2u * parent + 1u + (near_right ? 0u : 1u); descend = true; }
+        else { node = parent; --depth; }
+    }
+}
+
+// ---- wave-cooperative kNN(max_pts <= 32, d^2 < r2) + plane fit around scan point `cpos` ----
+// All 64 lanes must be active; traversal state is wave-uniform; leaf points are tested one per lane and
+// inserted into the sorted list held one entry per lane (lane i = i-th nearest).
+__device__ inline PlaneRec plane_fit_wave(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+                                          const TreeNode* __restrict__ nodes, uint32_t P, uint32_t D, uint32_t cpos, double r2, int max_pts) {
+    const int lane = threadIdx.x & 63;
+    const double qx = (double)xs[cpos], qy = (double)ys[cpos], qz = (double)zs[cpos];
+    double my_d = INFINITY; uint32_t my_pos = kNone;
+    int count = 0; double bound = r2;
+    uint32_t node = 0, depth = 0;
+    const uint32_t first_leaf = (1u << D) - 1u;
+    bool descend = true;
+    for (;;) {
+        if (descend) {
+            while (depth < D) {
+                const TreeNode n = nodes[node];
+                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+                node = 2u * node + 1u + ((qd - (double)n.split) >= 0.0 ? 1u : 0u);
+                ++depth;
+            }
+            const uint32_t j = node - first_leaf;
+            const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+            for (uint32_t base = lo; base < hi; base += 64) {
+                const uint32_t i = base + lane;
+                double d2 = INFINITY;
+                if (i < hi) {
+                    const double dx = qx - (double)xs[i], dy = qy - (double)ys[i], dz = qz - (double)zs[i];
+                    d2 = (dx * dx + dy * dy) + dz * dz;
+                }
+                unsigned long long mask = __ballot(d2 < bound);
+                while (mask) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const double cd = __shfl(d2, l);
+                    if (cd < bound) {
+                        const int ins = __popcll(__ballot(lane < count && my_d <= cd));
+                        const double up_d = __shfl_up(my_d, 1); const uint32_t up_p = __shfl_up(my_pos, 1);
+                        if (lane > ins) { my_d = up_d; my_pos = up_p; }
+                        else if (lane == ins) { my_d = cd; my_pos = base + l; }
+                        if (count < max_pts) ++count;
+                        if (count == max_pts) bound = fmin(r2, __shfl(my_d, max_pts - 1));
+                    }
+                }
+            }
+            descend = false;
+        }
+        if (depth == 0) break;
+        const uint32_t parent = (node - 1u) >> 1;
+        const bool was_right = (node & 1u) == 0u;
+        const TreeNode n = nodes[parent];
+        const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+        const double diff = qd - (double)n.split;
+        const bool near_right = diff >= 0.0;
+        if (was_right == near_right && diff * diff < bound) { node = 2u * parent + 1u + (near_right ? 0u : 1u); descend = true; }
+        else { node = parent; --depth; }
+    }
+    PlaneRec rec;
+    rec.k = count; rec.pad = 0;
+    rec.far_d2 = count > 0 ? __shfl(my_d, count - 1) : 0.0;
+    // ComputeCovariance: one-pass raw moments in list order (pointcloud.h:126-158)
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < count; ++j) {
+        const uint32_t pj = __shfl(my_pos, j);
+        const double px = (double)xs[pj], py = (double)ys[pj], pz = (double)zs[pj];
+        c[0] += px; c[1] += py; c[2] += pz;
+        c[3] += px * px; c[4] += px * py; c[5] += px * pz; c[6] += py * py; c[7] += py * pz; c[8] += pz * pz;
+    }
+    const double inv_n = (double)count;
+    for (int i = 0; i < 9; ++i) c[i] /= inv_n;
+    double cov[9];
+    cov[0] = c[3] - c[0] * c[0]; cov[4] = c[6] - c[1] * c[1]; cov[8] = c[8] - c[2] * c[2];
+    cov[1] = cov[3] = c[4] - c[0] * c[1]; cov[2] = cov[6] = c[5] - c[0] * c[2]; cov[5] = cov[7] = c[7] - c[1] * c[2];
+    double nrm[3]; dev_smallest_evec(cov, nrm);
+    double reg = 0;
+    for (int j = 0; j < count; ++j) {
+        const uint32_t pj = __shfl(my_pos, j);
+        const double ax = (double)xs[pj] - qx, ay = (double)ys[pj] - qy, az = (double)zs[pj] - qz;
+        reg += fabs(ax * nrm[0] + ay * nrm[1] + az * nrm[2]);
+    }
+    rec.nx = nrm[0]; rec.ny = nrm[1]; rec.nz = nrm[2]; rec.reg_sum = reg;
+    return rec;
+}
+
+// grid: (ceil(maxP / waves_per_block), n_frames); one wave per scan point
+__global__ __launch_bounds__(256) void iba_plane_kernel(DevProblem dp, double r2, int max_pts, PlaneRec* out) {
+    const FrameHdr& h = dp.frames[blockIdx.y];
+    const uint32_t pos = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (pos >= h.P) return;
+    const PlaneRec rec = plane_fit_wave(dp.xs + h.pt_base, dp.ys + h.pt_base, dp.zs + h.pt_base, dp.nodes + h.node_base, h.P, h.depth, pos, r2, max_pts);
+    if ((threadIdx.x & 63) == 0) out[h.pt_base + pos] = rec;
+}
+
+// ---- fixed-order block reduction of NV doubles per thread; result valid in s_red[0..NV) for all threads after return ----
+template <int NV>
+__device__ inline void block_reduce(double* v, double* s_red /* kWaves*kRedSlots doubles */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double x = v[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        v[i] = x;
+    }
+    __syncthreads();
+    if (lane == 0)
+        for (int i = 0; i < NV; ++i) s_red[wave * kRedSlots + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double x = 0;
+        for (int w = 0; w < kWaves; ++w) x += s_red[w * kRedSlots + threadIdx.x];
+        s_red[kWaves * kRedSlots + threadIdx.x] = x;
+    }
+    __syncthreads();
+    for (int i = 0; i < NV; ++i) v[i] = s_red[kWaves * kRedSlots + i];
+    __syncthreads();
+}
+
+struct FrameCtx {   // wave-uniform per-block context
+    const float* xs; const float* ys; const float* zs;   // LDS or HBM
+    const TreeNode* nodes;                               // LDS
+    const uint32_t* bitmap;                              // LDS
+    unsigned long long* best_d2; uint32_t* best_idx;     // LDS
+    const uint32_t* cell_start; const uint32_t* cell_kp; const float2* cell_uv;   // HBM, frame-relative
+    const uint32_t* perm;                                // HBM, frame-relative
+    int gw, gh;
+    float margin;
+    double gate2;
+    double fx, cx, cy, W, H;
+    double R[9], t[3];
+};
+
+// K1+K2+K3 for one scan point. PASS 1: ds_min on best d^2. PASS 2: resolve exact ties by original index.
+template <int PASS>
+__device__ __forceinline__ bool project_match(const FrameCtx& c, float xf, float yf, float zf, uint32_t pos) {
+    const double x = (double)xf, y = (double)yf, z = (double)zf;
+    const double pcx = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
+    const double pcy = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
+    const double pcz = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
+    if (!(pcz > 0)) return false;
+    const double u = (c.fx * pcx + c.cx * pcz) / pcz;
+    const double v = (c.fx * pcy + c.cy * pcz) / pcz;   // fx on purpose: iba_global.cpp:73
+    if (!(0 <= u && u < c.W && 0 <= v && v < c.H)) return false;
+    const float uf = (float)u, vf = (float)v;
+    const uint32_t cell = (uint32_t)grid_cell(vf, c.gh) * (uint32_t)c.gw + (uint32_t)grid_cell(uf, c.gw);
+    if (!((c.bitmap[cell >> 5] >> (cell & 31)) & 1u)) return false;
+    const int x0 = grid_cell(uf - c.margin, c.gw), x1 = grid_cell(uf + c.margin, c.gw);
+    const int y0 = grid_cell(vf - c.margin, c.gh), y1 = grid_cell(vf + c.margin, c.gh);
+    bool hit = false;
+    for (int yy = y0; yy <= y1; ++yy) {
+        const uint32_t e0 = c.cell_start[yy * c.gw + x0], e1 = c.cell_start[yy * c.gw + x1 + 1];
+        for (uint32_t e = e0; e < e1; ++e) {
+            const float2 kuv = c.cell_uv[e];
+            const double du = (double)kuv.x - u, dv = (double)kuv.y - v;
+            const double d2 = du * du + dv * dv;
+            if (d2 <= c.gate2) {
+                const uint32_t k = c.cell_kp[e];
+                if (PASS == 1) { atomicMin(&c.best_d2[k], d2bits(d2)); hit = true; }
+                else if (c.best_d2[k] == d2bits(d2)) atomicMin(&c.best_idx[k], c.perm[pos]);
+            }
+        }
+    }
+    return hit;
+}
+
+enum FrameMode { MODE_COST = 0, MODE_CORR = 1 };
+
+// grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so
+// all candidates of one frame share that XCD's L2 copy of the scan.
+template <int MODE, bool SCAN_LDS>
+__global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
+                                                             double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nf = dp.n_frames;
+    const int per_xcd = (nf + 7) / 8;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int f = xcd + 8 * (jj / B), b = jj % B;
+    if (f >= nf || jj / B >= per_xcd) return;
+    const FrameHdr& h = dp.frames[f];
+    const Cand& cd = cands[b];
+    double* part = frame_partials + ((size_t)b * nf + f) * kPartialStride;
+
+    float* s_xs = (float*)smem; float* s_ys = s_xs + lay.scan_stride; float* s_zs = s_ys + lay.scan_stride;
+    unsigned long long* s_best_d2 = (unsigned long long*)(smem + lay.off_best_d2);
+    uint32_t* s_best_idx = (uint32_t*)(smem + lay.off_best_idx);
+    TreeNode* s_nodes = (TreeNode*)(smem + lay.off_nodes);
+    uint32_t* s_bitmap = (uint32_t*)(smem + lay.off_bitmap);
+    double* s_red = (double*)(smem + lay.off_red);
+    uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 after phase 2
+    uint32_t* s_wcnt = (uint32_t*)(s_red + (kWaves + 1) * kRedSlots);
+
+    const uint32_t P = h.P, Ppad = h.Ppad, K = h.K, D = h.depth;
+    const float* gxs = dp.xs + h.pt_base; const float* gys = dp.ys + h.pt_base; const float* gzs = dp.zs + h.pt_base;
+
+    // ---- phase 0: LDS init ----
+    for (uint32_t i = tid; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; }
+    const uint32_t nnodes = (1u << D) - 1u;
+    for (uint32_t i = tid; i < nnodes; i += kThreads) s_nodes[i] = dp.nodes[h.node_base + i];
+    const uint32_t nbw = (h.gw * h.gh + 31u) >> 5;
+    for (uint32_t i = tid; i < nbw; i += kThreads) s_bitmap[i] = dp.bitmap[h.bitmap_base + i];
+    __syncthreads();
+
+    FrameCtx c;
+    c.xs = SCAN_LDS ? s_xs : gxs; c.ys = SCAN_LDS ? s_ys : gys; c.zs = SCAN_LDS ? s_zs : gzs;
+    c.nodes = s_nodes; c.bitmap = s_bitmap; c.best_d2 = s_best_d2; c.best_idx = s_best_idx;
+    c.cell_start = dp.cell_start + h.cell_base; c.cell_kp = dp.cell_kp + h.kp_base; c.cell_uv = dp.cell_uv + h.kp_base;
+    c.perm = dp.perm + h.pt_base;
+    c.gw = (int)h.gw; c.gh = (int)h.gh; c.margin = (float)prm.grid_margin; c.gate2 = prm.gate2;
+    c.fx = h.fx; c.cx = h.cx; c.cy = h.cy; c.W = h.W; c.H = h.H;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = cd.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.t[i] = cd.t[i];
+
+    // ---- phase 1: stream + project + match ----
+    unsigned long long hitmask = 0ull;
+    bool overflow = false;
+    {
+        int slot = 0;
+        for (uint32_t base = (uint32_t)tid * 4u; base < Ppad; base += kThreads * 4u, ++slot) {
+            const float4 X = *(const float4*)(gxs + base), Y = *(const float4*)(gys + base), Z = *(const float4*)(gzs + base);
+            if (SCAN_LDS) { *(float4*)(s_xs + base) = X; *(float4*)(s_ys + base) = Y; *(float4*)(s_zs + base) = Z; }
+            const float px[4] = {X.x, X.y, X.z, X.w}, py[4] = {Y.x, Y.y, Y.z, Y.w}, pz[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (project_match<1>(c, px[j], py[j], pz[j], base + j)) {
+                    const int bit = slot * 4 + j;
+                    if (bit < 64) hitmask |= 1ull << bit; else overflow = true;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: tie resolution for the points that hit ----
+    {
+        unsigned long long m = hitmask;
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1; m &= m - 1;
+            const uint32_t pos = (uint32_t)tid * 4u + (uint32_t)(bit >> 2) * (kThreads * 4u) + (uint32_t)(bit & 3);
+            project_match<2>(c, c.xs[pos], c.ys[pos], c.zs[pos], pos);
+        }
+        if (overflow) {
+            for (uint32_t base = (uint32_t)tid * 4u + 16u * kThreads * 4u; base < Ppad; base += kThreads * 4u)
+                for (int j = 0; j < 4; ++j) project_match<2>(c, c.xs[base + j], c.ys[base + j], c.zs[base + j], base + j);
+        }
+    }
+    __syncthreads();
+
+    if (MODE == MODE_CORR) {   // dense dump: corr_out[b][kp_base + k] = original point index or kNone
+        for (uint32_t k = tid; k < K; k += kThreads) corr_out[h.kp_base + k] = s_best_idx[k];
+        return;
+    }
+
+    // ---- phase 3: corrset.size() ----
+    double acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0;
+    {
+        double cnt[1] = {0};
+        for (uint32_t k = tid; k < K; k += kThreads) cnt[0] += (s_best_idx[k] != kNone) ? 1.0 : 0.0;
+        block_reduce<1>(cnt, s_red);
+        if (cnt[0] < (double)prm.num_min_corr_cost) {   // iba_global.cpp:203: frame skipped entirely
+            if (tid < kPartialStride) part[tid] = 0.0;
+            return;
+        }
+        if (tid == 0) { acc[P_FRAMES] = 1.0; acc[P_NCORR] = cnt[0]; }
+    }
+
+    // ---- phase 4a: 3d-2d residuals + ordered compaction of the 3d-3d work list ----
+    const float2* kp_uv = dp.kp_uv + h.kp_base;
+    const float4* kp_mp = dp.kp_mp + h.kp_base;
+    const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
+    const double s = cd.s;
+    uint32_t n3 = 0;   // wave-uniform running length of s_list
+    const uint32_t Kceil = (K + kThreads - 1) / kThreads * kThreads;
+    for (uint32_t k = tid; k < Kceil; k += kThreads) {
+        bool want3 = false;
+        if (k < K) {
+            const uint32_t orig = s_best_idx[k];
+            if (orig != kNone) {
+                const uint32_t pos = inv_perm[orig];
+                const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
+                const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
+                const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
+                const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
+                for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
+                    const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k];
+                    if (m.x != m.x) continue;   // NaN: keypoint not in GetUordMatchedKptIds(pKFConv)
+                    const double* rel = dp.slots[h.slot_base + sl].rel;
+                    const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
+                    const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
+                    const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
+                    const double ou = h.fx * p1x / p1z + h.cx;
+                    const double ov = h.fy * p1y / p1z + h.cy;
+                    if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
+                    const double eu = ou - (double)m.x, ev = ov - (double)m.y;
+                    const double dist = sqrt(eu * eu + ev * ev);
+                    if (dist < prm.corr_3d_2d_threshold) { acc[P_SUM_3D2D] += dist; acc[P_VALID_3D2D] += 1.0; }
+                    acc[P_CNT_3D2D] += 1.0;
+                }
+                want3 = prm.use_3d3d && kp_mp[k].w != 0.0f;
+            }
+        }
+        // ordered (by keypoint id) compaction, so the summation order below is run-to-run stable
+        const unsigned long long bal = __ballot(want3);
+        if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < kWaves; ++w) { const uint32_t cw = s_wcnt[w]; total += cw; if (w < wave) before += cw; }
+        if (want3) s_list[n3 + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = k;
+        n3 += total;
+        __syncthreads();
+    }
+
+    // ---- phase 4b: 3d-3d (MapPoint -> LiDAR frame, 1-NN, local plane) ----
+    if (prm.use_3d3d) {
+        const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
+        for (uint32_t i = tid; i < n3; i += kThreads) {
+            const uint32_t k = s_list[i];
+            const float4 mp = kp_mp[k];
+            const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;   // CV_32F product (:232)
+            const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
+            const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
+            const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
+            const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
+            const double qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
+            const double qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
+            const double qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+            double best; uint32_t bpos;
+            nn_search(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
+            double dist = sqrt(best);   // (nn_pt - query_pt).norm()  (:122)
+            bool is_plane = false;
+            if (prm.use_plane) {
+                const PlaneRec rec = dp.plane_cost[h.pt_base + bpos];
+                if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
+                    !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
+                    const double ax = (double)c.xs[bpos] - qx, ay = (double)c.ys[bpos] - qy, az = (double)c.zs[bpos] - qz;
+                    dist = fabs(ax * rec.nx + ay * rec.ny + az * rec.nz);
+                    is_plane = true;
+                }
+            }
+            if (dist < prm.corr_3d_3d_threshold) {
+                acc[P_SUM_3D3D] += dist; acc[P_VALID_3D3D] += 1.0;
+                if (is_plane) acc[P_VALID_PL] += 1.0; else acc[P_VALID_PT] += 1.0;
+            }
+            acc[P_CNT_3D3D] += 1.0;
+        }
+    } else if (tid == 0) {   // iba_global.cpp:214-220
+        acc[P_CNT_3D3D] = 1.0; acc[P_VALID_3D3D] = 1.0;
+    }
+
+    // ---- phase 4c: hand-eye term (iba_global.cpp:264-276) ----
+    if (tid == kThreads - 1 && h.he_valid) {
+        double C1R[9], C1t[3], C2R[9], C2t[3];
+        const double* Tl = h.Tl_next; const double* Tc = h.Tc_next;
+        for (int r = 0; r < 3; ++r) {
+            for (int cc = 0; cc < 3; ++cc) {
+                C1R[r * 3 + cc] = (cd.R[r * 3 + 0] * Tl[0 * 4 + cc] + cd.R[r * 3 + 1] * Tl[1 * 4 + cc]) + cd.R[r * 3 + 2] * Tl[2 * 4 + cc];
+                C2R[r * 3 + cc] = (Tc[r * 4 + 0] * cd.R[0 * 3 + cc] + Tc[r * 4 + 1] * cd.R[1 * 3 + cc]) + Tc[r * 4 + 2] * cd.R[2 * 3 + cc];
+            }
+            C1t[r] = ((cd.R[r * 3 + 0] * Tl[3] + cd.R[r * 3 + 1] * Tl[7]) + cd.R[r * 3 + 2] * Tl[11]) + cd.t[r];
+            C2t[r] = ((Tc[r * 4 + 0] * cd.t[0] + Tc[r * 4 + 1] * cd.t[1]) + Tc[r * 4 + 2] * cd.t[2]) + Tc[r * 4 + 3] * s;
+        }
+        double l1[6], l2[6];
+        dev_se3log(C1R, C1t, l1); dev_se3log(C2R, C2t, l2);
+        double ss = 0;
+        for (int i = 0; i < 6; ++i) ss += (l1[i] - l2[i]) * (l1[i] - l2[i]);
+        acc[P_HE_SUM] = sqrt(ss); acc[P_HE_CNT] = 1.0;
+    }
+
+    // ---- phase 5: reduction -> partial record ----
+    block_reduce<12>(acc, s_red);
+    if (tid < kPartialStride) part[tid] = tid < 12 ? acc[tid] : 0.0;
+}
+
+// sums the per-frame records of each candidate in a fixed order. grid: B blocks of 256 threads
+__global__ __launch_bounds__(256) void iba_reduce_kernel(const double* __restrict__ frame_partials, int nf, double* __restrict__ out) {
+    __shared__ double s[4][kPartialStride];
+    const int b = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const double* src = frame_partials + (size_t)b * nf * kPartialStride;
+    const int per = (nf + 3) / 4, f0 = g * per, f1 = min(nf, f0 + per);
+    double x = 0;
+    for (int f = f0; f < f1; ++f) x += src[(size_t)f * kPartialStride + i];
+    s[g][i] = x;
+    __syncthreads();
+    if (g == 0) out[(size_t)b * kPartialStride + i] = ((s[0][i] + s[1][i]) + s[2][i]) + s[3][i];
+}
+
+}  // namespace iba
