@@ -218,6 +218,8 @@ iba_status iba_finalize_normal(const iba_params* params, const double* partials,
  * measured with HIP events on the launch stream (ms), and the frame-kernel launch shape. */
 iba_status iba_last_kernel_ms(iba_handle* h, float* frame_kernel_ms, float* total_ms);
 iba_status iba_set_timing(iba_handle* h, int32_t enable);
+/* debug: host copy of the summed partial blocks of the last iba_eval_* call */
+iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
 int64_t iba_num_points(const iba_handle* h);
 int64_t iba_num_keypoints(const iba_handle* h);
 

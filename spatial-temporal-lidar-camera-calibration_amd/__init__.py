@@ -18,7 +18,7 @@ from .abi import (IBA_MAX_BATCH, IbaBbo, IbaCostOut, IbaNormalOut, IbaParams, Ib
                   reference_yaml_params)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiba_mi355x.so")
+LIB_PATH = os.environ.get("IBA_LIB", os.path.join(_HERE, "libiba_mi355x.so"))  # IBA_LIB: diagnostic builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "iba_mi355x.h")
 
 STATUS = {0: "IBA_OK", 1: "IBA_ERR_INVALID_ARG", 2: "IBA_ERR_NO_DEVICE", 3: "IBA_ERR_HIP", 4: "IBA_ERR_UNSUPPORTED", 5: "IBA_ERR_STATE"}
@@ -200,6 +200,11 @@ class IbaHandle:
     def eval_normal_partial(self, x, d_partials_ptr, stream_ptr=None):
         x = self._x(x)
         self._chk(self.lib.iba_eval_normal_partial(self.h, _p(x), C.c_int32(len(x)), C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
+
+    def debug_last_partials(self, B):
+        out = np.zeros((B, partial_stride()))
+        self._chk(self.lib.iba_debug_last_partials(self.h, _p(out), C.c_int32(B)))
+        return out
 
     def set_timing(self, on=True):
         self._chk(self.lib.iba_set_timing(self.h, C.c_int32(1 if on else 0)))

@@ -72,6 +72,12 @@ struct iba_handle {
     DevBuf<double> d_frame_partials;      // IBA_MAX_BATCH * n_frames * kPartialStride
     DevBuf<double> d_partials;            // IBA_MAX_BATCH * kPartialStride
     DevBuf<uint32_t> d_corr;              // n_keypoints
+    DevBuf<uint2> d_assoc;                // assoc_cap * n_keypoints (per-candidate association of iba_eval_normal)
+    int assoc_cap = 0;
+    DevBuf<uint2> d_assoc_frozen;         // n_keypoints (iba_build_problem)
+    bool frozen_valid = false; int32_t frozen_frames = 0, frozen_ncorr = 0;
+    int nfb = 0;                          // factor-kernel blocks per candidate = n_frames * ceil(maxK/256)
+    int nrec = 0;                         // partial records per candidate = n_frames + nfb
     Cand* h_cands = nullptr;              // pinned, kRing * IBA_MAX_BATCH
     double* h_partials = nullptr;         // pinned
     hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -85,7 +91,7 @@ struct iba_handle {
         dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p;
         dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.cell_start = cell_start.p; dp.cell_kp = cell_kp.p; dp.cell_uv = cell_uv.p;
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
-        dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames;
+        dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         return dp;
     }
 };
@@ -176,13 +182,13 @@ iba_status compute_plane_cache(iba_handle* h) {
 }
 
 template <int MODE>
-iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, hipStream_t st) {
+iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, uint2* d_assoc, int nrec, hipStream_t st) {
     const DevProblem dp = h->dev_problem();
     const int per_xcd = (h->n_frames + 7) / 8;
     const dim3 grid(8 * per_xcd * B), block(kThreads);
     if (h->n_frames == 0) return IBA_OK;
-    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr);
-    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr);
+    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec);
+    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }
@@ -207,7 +213,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    s = launch_frame<MODE_COST>(h, dc, B, h->d_frame_partials.p, nullptr, st); if (s != IBA_OK) return s;
+    s = launch_frame<MODE_COST>(h, dc, B, h->d_frame_partials.p, nullptr, nullptr, h->n_frames, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->n_frames, d_partials);
     HIP_TRY(h, hipGetLastError());
@@ -242,7 +248,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->cell_start.release(); h->cell_kp.release(); h->bitmap.release(); h->cell_uv.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release();
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
@@ -379,7 +385,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     hipError_t er;
     if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);
     if ((er = h->d_cands.alloc((size_t)kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("alloc cands", er);
-    if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
+    h->nfb = nf * (int)((h->maxK + kFactorThreads - 1) / kFactorThreads); h->nrec = nf + h->nfb;
+    if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(h->nrec, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
+    if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
     if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
     if ((er = hipHostMalloc((void**)&h->h_cands, sizeof(Cand) * kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("hipHostMalloc", er);
@@ -388,8 +396,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel
-    const void* fns[4] = {(const void*)iba_frame_kernel<MODE_COST, true>, (const void*)iba_frame_kernel<MODE_COST, false>,
-                          (const void*)iba_frame_kernel<MODE_CORR, true>, (const void*)iba_frame_kernel<MODE_CORR, false>};
+    const void* fns[6] = {(const void*)iba_frame_kernel<MODE_COST, true>, (const void*)iba_frame_kernel<MODE_COST, false>,
+                          (const void*)iba_frame_kernel<MODE_CORR, true>, (const void*)iba_frame_kernel<MODE_CORR, false>,
+                          (const void*)iba_frame_kernel<MODE_ASSOC, true>, (const void*)iba_frame_kernel<MODE_ASSOC, false>};
     for (const void* fn : fns)
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
 
@@ -404,7 +413,7 @@ iba_status iba_set_params(iba_handle* h, const iba_params* p) {
     iba_status s = check_params(h, *p); if (s != IBA_OK) return s;
     if (p->max_pixel_dist != h->params.max_pixel_dist) return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist is baked into the keypoint grid: recreate the handle");
     HIP_TRY(h, hipSetDevice(h->device));
-    h->params = *p; to_dev_params(*p, h->dprm);
+    h->params = *p; to_dev_params(*p, h->dprm); h->frozen_valid = false;
     return compute_plane_cache(h);
 }
 
@@ -467,7 +476,7 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
-    s = launch_frame<MODE_CORR>(h, dc, 1, h->d_frame_partials.p, h->d_corr.p, h->stream); if (s != IBA_OK) return s;
+    s = launch_frame<MODE_CORR>(h, dc, 1, h->d_frame_partials.p, h->d_corr.p, nullptr, h->n_frames, h->stream); if (s != IBA_OK) return s;
     const uint64_t k0 = h->h_kp_off[lf], K = h->h_kp_off[lf + 1] - k0;
     std::vector<uint32_t> tmp(K);
     HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_corr.p + k0, sizeof(uint32_t) * K, hipMemcpyDeviceToHost, h->stream));
@@ -479,12 +488,105 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     return IBA_OK;
 }
 
-// ---- Jacobian path: implemented in the next milestone ----
-iba_status iba_eval_normal(iba_handle* h, const double*, int32_t, iba_normal_out*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_normal: not implemented yet"); }
-iba_status iba_build_problem(iba_handle* h, const double*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_build_problem: not implemented yet"); }
-iba_status iba_eval_factors(iba_handle* h, const double*, int32_t, iba_normal_out*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_factors: not implemented yet"); }
+// debug: host copy of the last summed partial blocks (B x iba_partial_stride() doubles)
+iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
+    if (!h || !out || B < 1 || B > IBA_MAX_BATCH) return IBA_ERR_INVALID_ARG;
+    std::memcpy(out, h->h_partials, sizeof(double) * B * kPartialStride);
+    return IBA_OK;
+}
+
+// ---- Jacobian path ----
+iba_status iba_finalize_normal(const iba_params* p, const double* part, int32_t B, iba_normal_out* out) {
+    if (!p || !part || !out || B < 1) return IBA_ERR_INVALID_ARG;
+    for (int b = 0; b < B; ++b) {
+        const double* q = part + (size_t)b * kPartialStride; iba_normal_out& o = out[b];
+        int at = 0;
+        for (int i = 0; i < 7; ++i)
+            for (int j = i; j < 7; ++j) { o.H[i * 7 + j] = q[P_H0 + at]; o.H[j * 7 + i] = q[P_H0 + at]; ++at; }
+        for (int i = 0; i < 7; ++i) o.b[i] = q[P_B0 + i];
+        o.cost = q[P_COST]; o.chi2 = q[P_CHI2];
+        o.n_factor_3d2d = (int32_t)q[P_NF_3D2D]; o.n_factor_p2pl = (int32_t)q[P_NF_P2PL]; o.n_factor_p2pt = (int32_t)q[P_NF_P2PT];
+        o.n_residuals = (int32_t)q[P_NRES]; o.frames_used = (int32_t)q[P_FRAMES_N]; o.n_corr = (int32_t)q[P_NCORR_N];
+    }
+    return IBA_OK;
+}
+
+static iba_status launch_factors(iba_handle* h, const Cand* dc, int B, const uint2* assoc, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
+    if (h->n_frames == 0 || h->maxK == 0) return IBA_OK;
+    const dim3 grid((h->maxK + kFactorThreads - 1) / kFactorThreads, h->n_frames, B);
+    hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, assoc, per_cand, partials, nrec, rec_base);
+    HIP_TRY(h, hipGetLastError());
+    return IBA_OK;
+}
+
+static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
+    if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->assoc_cap < B) {
+        HIP_TRY(h, hipStreamSynchronize(st));
+        h->d_assoc.release();
+        HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
+        h->assoc_cap = B;
+    }
+    Cand* dc = nullptr;
+    iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    s = launch_frame<MODE_ASSOC>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
+    s = launch_factors(h, dc, B, h->d_assoc.p, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev2, st));
+    return IBA_OK;
+}
+
+iba_status iba_eval_normal_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
+    if (!h || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return eval_normal_partial_impl(h, x, B, (double*)d_partials, stream ? (hipStream_t)stream : h->stream);
+}
+
+iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
+    if (!h || !out) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    iba_status s = eval_normal_partial_impl(h, x, B, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
+    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
+    return iba_finalize_normal(&h->params, h->h_partials, B, out);
+}
+
+iba_status iba_build_problem(iba_handle* h, const double* x) {
+    if (!h || !x) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Cand* dc = nullptr;
+    iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
+    s = launch_frame<MODE_ASSOC>(h, dc, 1, h->d_frame_partials.p, nullptr, h->d_assoc_frozen.p, h->n_frames, h->stream); if (s != IBA_OK) return s;
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_frame_partials.p, h->n_frames, h->d_partials.p);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->frozen_frames = (int32_t)h->h_partials[P_FRAMES_N]; h->frozen_ncorr = (int32_t)h->h_partials[P_NCORR_N]; h->frozen_valid = true;
+    return IBA_OK;
+}
+
+iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
+    if (!h || !x || !out || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    if (!h->frozen_valid) return fail(h, IBA_ERR_STATE, "iba_eval_factors called before iba_build_problem");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Cand* dc = nullptr;
+    iba_status s = stage_cands(h, x, B, h->stream, &dc); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    s = launch_factors(h, dc, B, h->d_assoc_frozen.p, 0, h->d_frame_partials.p, h->nfb, 0, h->stream); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, h->stream, h->d_frame_partials.p, h->nfb, h->d_partials.p);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev2, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
+    for (int b = 0; b < B; ++b) { h->h_partials[(size_t)b * kPartialStride + P_FRAMES_N] = h->frozen_frames; h->h_partials[(size_t)b * kPartialStride + P_NCORR_N] = h->frozen_ncorr; }
+    return iba_finalize_normal(&h->params, h->h_partials, B, out);
+}
+
 iba_status iba_eval_residuals(iba_handle* h, const double*, double*, double*, int32_t*, int32_t*, int64_t*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_residuals: not implemented yet"); }
-iba_status iba_eval_normal_partial(iba_handle* h, const double*, int32_t, void*, void*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_normal_partial: not implemented yet"); }
-iba_status iba_finalize_normal(const iba_params*, const double*, int32_t, iba_normal_out*) { return IBA_ERR_UNSUPPORTED; }
 
 }  // extern "C"

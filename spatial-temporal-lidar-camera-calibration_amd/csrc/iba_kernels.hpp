@@ -45,6 +45,7 @@ struct DevProblem {
     const PlaneRec* plane_cost;   // x-independent plane records (norm_radius / norm_max_pts)
     const PlaneRec* plane_local;  // (neigh_radius / neigh_max_pts)
     int32_t n_frames;
+    int64_t n_kp_total;
 };
 
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
@@ -393,13 +394,20 @@ __device__ __forceinline__ bool project_match(const FrameCtx& c, float xf, float
     return hit;
 }
 
-enum FrameMode { MODE_COST = 0, MODE_CORR = 1 };
+enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2 };
+
+#ifdef IBA_STAMPS   // diagnostic build only: per-phase shader-clock deltas of thread 0 into partial slots 56..63
+#define IBA_STAMP(i) do { if (threadIdx.x == 0) { stamp_t[i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define IBA_STAMP(i) do { } while (0)
+#endif
 
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so
 // all candidates of one frame share that XCD's L2 copy of the scan.
 template <int MODE, bool SCAN_LDS>
 __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
-                                                             double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out) {
+                                                             double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out,
+                                                             uint2* __restrict__ assoc_out, int nrec) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = dp.n_frames;
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     if (f >= nf || jj / B >= per_xcd) return;
     const FrameHdr& h = dp.frames[f];
     const Cand& cd = cands[b];
-    double* part = frame_partials + ((size_t)b * nf + f) * kPartialStride;
+    double* part = frame_partials + ((size_t)b * nrec + f) * kPartialStride;
 
     float* s_xs = (float*)smem; float* s_ys = s_xs + lay.scan_stride; float* s_zs = s_ys + lay.scan_stride;
     unsigned long long* s_best_d2 = (unsigned long long*)(smem + lay.off_best_d2);
@@ -423,6 +431,10 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     const uint32_t P = h.P, Ppad = h.Ppad, K = h.K, D = h.depth;
     const float* gxs = dp.xs + h.pt_base; const float* gys = dp.ys + h.pt_base; const float* gzs = dp.zs + h.pt_base;
 
+#ifdef IBA_STAMPS
+    unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    IBA_STAMP(0);
     // ---- phase 0: LDS init ----
     for (uint32_t i = tid; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; }
     const uint32_t nnodes = (1u << D) - 1u;
@@ -443,6 +455,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
 #pragma unroll
     for (int i = 0; i < 3; ++i) c.t[i] = cd.t[i];
 
+    IBA_STAMP(1);
     // ---- phase 1: stream + project + match ----
     unsigned long long hitmask = 0ull;
     bool overflow = false;
@@ -462,6 +475,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         }
     }
     __syncthreads();
+    IBA_STAMP(2);
     // ---- phase 2: tie resolution for the points that hit ----
     {
         unsigned long long m = hitmask;
@@ -482,6 +496,55 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         return;
     }
 
+    IBA_STAMP(3);
+    if (MODE == MODE_ASSOC) {
+        // ---- BuildProblem association (iba_local.cpp:145-323): which residual blocks exist at this x ----
+        uint2* arow = assoc_out + (size_t)b * dp.n_kp_total + h.kp_base;
+        double cnt[1] = {0};
+        for (uint32_t k = tid; k < K; k += kThreads) cnt[0] += (s_best_idx[k] != kNone) ? 1.0 : 0.0;
+        block_reduce<1>(cnt, s_red);
+        const bool used = !(cnt[0] < (double)prm.num_min_corr);   // iba_local.cpp:192
+        if (tid < kPartialStride) part[tid] = (used && tid == P_FRAMES_N) ? 1.0 : ((used && tid == P_NCORR_N) ? cnt[0] : 0.0);
+        const float4* kp_mp = dp.kp_mp + h.kp_base;
+        const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
+        const PlaneRec* planes = dp.plane_local + h.pt_base;
+        for (uint32_t k = tid; k < K; k += kThreads) {
+            uint2 a = make_uint2(kNone, kNone);
+            const uint32_t orig = s_best_idx[k];
+            if (used && orig != kNone) {
+                const uint32_t pos = inv_perm[orig];
+                const PlaneRec rec = planes[pos];
+                // ComputeLocalNeighbor validity (pointcloud.h:752), then MapPoint ownership (iba_local.cpp:213)
+                const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
+                const float4 mp = kp_mp[k];
+                bool any_covis = false;
+                for (uint32_t sl = 0; sl < h.n_slots; ++sl) { const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k]; any_covis |= (m.x == m.x); }
+                if (neigh_ok && mp.w != 0.0f && any_covis) {   // :259-260
+                    if (rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) a.x = pos;   // bvalid_plane (:231)
+                    // MapPoint in the reference camera frame, scale-free (:238-239), then into the LiDAR frame (:282)
+                    const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+                    const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
+                    const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
+                    const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
+                    const double sx = mx * cd.s, sy = my * cd.s, sz = mz * cd.s;
+                    const double qx = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
+                    const double qy = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
+                    const double qz = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
+                    double best; uint32_t bpos;
+                    nn_search(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
+                    if (!(best > prm.max_3d_dist2)) {   // :289
+                        const PlaneRec r2 = planes[bpos];   // ComputeLocalNormalSingleThre (pointcloud.h:699-717)
+                        const bool state = !(r2.k < prm.neigh_min_pts || r2.far_d2 < prm.local_min_diff_dist2) &&
+                                           (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);
+                        a.y = bpos | (state ? 0x80000000u : 0u);
+                    }
+                }
+            }
+            arow[k] = a;
+        }
+        return;
+    }
+
     // ---- phase 3: corrset.size() ----
     double acc[12];
 #pragma unroll
@@ -497,6 +560,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         if (tid == 0) { acc[P_FRAMES] = 1.0; acc[P_NCORR] = cnt[0]; }
     }
 
+    IBA_STAMP(4);
     // ---- phase 4a: 3d-2d residuals + ordered compaction of the 3d-3d work list ----
     const float2* kp_uv = dp.kp_uv + h.kp_base;
     const float4* kp_mp = dp.kp_mp + h.kp_base;
@@ -543,6 +607,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         __syncthreads();
     }
 
+    IBA_STAMP(5);
     // ---- phase 4b: 3d-3d (MapPoint -> LiDAR frame, 1-NN, local plane) ----
     if (prm.use_3d3d) {
         const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
@@ -580,6 +645,10 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         acc[P_CNT_3D3D] = 1.0; acc[P_VALID_3D3D] = 1.0;
     }
 
+#ifdef IBA_STAMPS
+    __syncthreads();
+#endif
+    IBA_STAMP(6);
     // ---- phase 4c: hand-eye term (iba_global.cpp:264-276) ----
     if (tid == kThreads - 1 && h.he_valid) {
         double C1R[9], C1t[3], C2R[9], C2t[3];
@@ -602,6 +671,171 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     // ---- phase 5: reduction -> partial record ----
     block_reduce<12>(acc, s_red);
     if (tid < kPartialStride) part[tid] = tid < 12 ? acc[tid] : 0.0;
+#ifdef IBA_STAMPS
+    __syncthreads();
+    if (tid == 0) { const unsigned long long te = __builtin_readcyclecounter(); for (int i = 0; i < 7; ++i) part[56 + i] = (double)((i < 6 ? stamp_t[i + 1] : te) - stamp_t[i]); }
+#endif
+}
+
+// ---- Jacobian path: residual blocks of the frozen association, evaluated at candidate x ----
+// IBA_PlaneFactor (IBACalib2.hpp:152-184), Point2Plane/Point2Point_Factor (:570-584, 611-625), Huber
+// IRLS weights as Ceres' Corrector applies them (rho'' <= 0), accumulated as the upper triangle of
+// H = sum w J^T J, b = sum w J^T r. Derivatives are analytic: the chain rule through the same
+// expressions the reference's Jets differentiate, with dR/dx, dt/dx from the host duals (Cand).
+struct NAcc { double H[28], b[7], chi2, cost, nf2d, nfpl, nfpt, nres; };
+
+__device__ __forceinline__ void huber_w(double a, double s, double& rho0, double& w) {
+    const double bb = a * a;
+    if (s > bb) { const double r = sqrt(s); rho0 = 2.0 * a * r - bb; w = fmax(2.2250738585072014e-308, a / r); }
+    else { rho0 = s; w = 1.0; }
+}
+// H (upper, row-major i<=j) index
+__device__ __forceinline__ int hidx(int i, int j) { return i * 7 - (i * (i - 1)) / 2 + (j - i); }
+
+__device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
+                                          double u0, double v0, const double* p0, const double* n0, NAcc& A) {
+    // p0c, n0c and their derivatives
+    double p0c[3], n0c[3];
+    for (int r = 0; r < 3; ++r) {
+        p0c[r] = ((c.R[r * 3] * p0[0] + c.R[r * 3 + 1] * p0[1]) + c.R[r * 3 + 2] * p0[2]) + c.t[r];
+        n0c[r] = (c.R[r * 3] * n0[0] + c.R[r * 3 + 1] * n0[1]) + c.R[r * 3 + 2] * n0[2];
+    }
+    const double Cxz = (u0 - h.cx) / h.fx, Cyz = (v0 - h.cy) / h.fy;
+    const double num = (n0c[0] * p0c[0] + n0c[1] * p0c[1]) + n0c[2] * p0c[2];
+    const double den = (Cxz * n0c[0] + Cyz * n0c[1]) + n0c[2];
+    const double Z0 = num / den;
+    double z6[6];
+    for (int kk = 0; kk < 6; ++kk) {
+        double dpv[3], dnv[3] = {0, 0, 0};
+        for (int r = 0; r < 3; ++r) {
+            dpv[r] = c.dt[kk][r];
+            if (kk < 3) {
+                dpv[r] += (c.dR[kk][r * 3] * p0[0] + c.dR[kk][r * 3 + 1] * p0[1]) + c.dR[kk][r * 3 + 2] * p0[2];
+                dnv[r] = (c.dR[kk][r * 3] * n0[0] + c.dR[kk][r * 3 + 1] * n0[1]) + c.dR[kk][r * 3 + 2] * n0[2];
+            }
+        }
+        const double dnum = ((dnv[0] * p0c[0] + dnv[1] * p0c[1]) + dnv[2] * p0c[2]) + ((n0c[0] * dpv[0] + n0c[1] * dpv[1]) + n0c[2] * dpv[2]);
+        const double dden = (Cxz * dnv[0] + Cyz * dnv[1]) + dnv[2];
+        z6[kk] = (dnum - Z0 * dden) / den;
+    }
+    const double P0x = Cxz * Z0, P0y = Cyz * Z0, P0z = Z0;
+    double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0; int nconv = 0;
+    for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
+        const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k];
+        if (m.x != m.x) continue;
+        const double* rel = dp.slots[h.slot_base + sl].rel;
+        const double tx = rel[3] * c.s, ty = rel[7] * c.s, tz = rel[11] * c.s;   // _t *= _s (IBACalib2.hpp:175)
+        const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx;
+        const double P1y = ((rel[4] * P0x + rel[5] * P0y) + rel[6] * P0z) + ty;
+        const double P1z = ((rel[8] * P0x + rel[9] * P0y) + rel[10] * P0z) + tz;
+        const double ru = (h.fx * P1x / P1z + h.cx) - (double)m.x;
+        const double rv = (h.fy * P1y / P1z + h.cy) - (double)m.y;
+        const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[4] * Cxz + rel[5] * Cyz) + rel[6], az = (rel[8] * Cxz + rel[9] * Cyz) + rel[10];
+        const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
+        const double gu = h.fx * iz * (ax - xz * az), gv = h.fy * iz * (ay - yz * az);
+        const double hu = h.fx * iz * (rel[3] - xz * rel[11]), hv = h.fy * iz * (rel[7] - yz * rel[11]);
+        ssq += ru * ru + rv * rv;
+        G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
+        Gr += gu * ru + gv * rv; Hr += hu * ru + hv * rv;
+        ++nconv;
+    }
+    if (nconv == 0) return;
+    double rho0, w; huber_w(prm.robust_kernel_delta, ssq, rho0, w);
+    A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0 * nconv;
+    for (int i = 0; i < 6; ++i) {
+        const double wz = w * z6[i];
+        for (int j = i; j < 6; ++j) A.H[hidx(i, j)] += wz * G * z6[j];
+        A.H[hidx(i, 6)] += wz * GH;
+        A.b[i] += wz * Gr;
+    }
+    A.H[27] += w * HH; A.b[6] += w * Hr;
+}
+
+__device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const DevParams& prm, const float4 mp, const double* Q, const double* n, bool is_plane, NAcc& A) {
+    const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+    const double m[3] = {((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3], ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7],
+                         ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11]};
+    const double sm[3] = {m[0] * c.s, m[1] * c.s, m[2] * c.s};
+    double M[3], dM[7][3];
+    for (int r = 0; r < 3; ++r) {
+        M[r] = ((c.Rlc[r * 3] * sm[0] + c.Rlc[r * 3 + 1] * sm[1]) + c.Rlc[r * 3 + 2] * sm[2]) + c.tlc[r];
+        for (int kk = 0; kk < 6; ++kk) {
+            double v = c.dtlc[kk][r];
+            if (kk < 3) v += (c.dRlc[kk][r * 3] * sm[0] + c.dRlc[kk][r * 3 + 1] * sm[1]) + c.dRlc[kk][r * 3 + 2] * sm[2];
+            dM[kk][r] = v;
+        }
+        dM[6][r] = (c.Rlc[r * 3] * m[0] + c.Rlc[r * 3 + 1] * m[1]) + c.Rlc[r * 3 + 2] * m[2];
+    }
+    const double e[3] = {M[0] - Q[0], M[1] - Q[1], M[2] - Q[2]};
+    if (is_plane) {
+        const double r = (e[0] * n[0] + e[1] * n[1]) + e[2] * n[2];
+        double J[7];
+        for (int kk = 0; kk < 7; ++kk) J[kk] = (dM[kk][0] * n[0] + dM[kk][1] * n[1]) + dM[kk][2] * n[2];
+        double rho0, w; huber_w(prm.robust_kernel_3ddelta, r * r, rho0, w);
+        A.cost += 0.5 * rho0; A.chi2 += r * r; A.nfpl += 1.0; A.nres += 1.0;
+        for (int i = 0; i < 7; ++i) { const double wj = w * J[i]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * J[j]; A.b[i] += wj * r; }
+    } else {
+        const double ssq = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
+        double rho0, w; huber_w(prm.robust_kernel_3ddelta, ssq, rho0, w);
+        A.cost += 0.5 * rho0; A.chi2 += ssq; A.nfpt += 1.0; A.nres += 3.0;
+        for (int r = 0; r < 3; ++r)
+            for (int i = 0; i < 7; ++i) { const double wj = w * dM[i][r]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * dM[j][r]; A.b[i] += wj * e[r]; }
+    }
+}
+
+constexpr int kFactorThreads = 256;
+// grid: (ceil(maxK/256), n_frames, B). assoc row = assoc + (assoc_per_cand ? b : 0) * n_kp_total.
+// record (b, rec_base + blockIdx.y * gridDim.x + blockIdx.x) of `partials` receives this block's sums.
+__global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint2* __restrict__ assoc,
+                                                                    int assoc_per_cand, double* __restrict__ partials, int nrec, int rec_base) {
+    __shared__ double s_part[kFactorThreads / 64][kPartialStride];
+    const int f = blockIdx.y, b = blockIdx.z;
+    const FrameHdr& h = dp.frames[f];
+    const Cand& c = cands[b];
+    const uint32_t k = blockIdx.x * kFactorThreads + threadIdx.x;
+    NAcc A;
+    for (int i = 0; i < 28; ++i) A.H[i] = 0;
+    for (int i = 0; i < 7; ++i) A.b[i] = 0;
+    A.chi2 = A.cost = A.nf2d = A.nfpl = A.nfpt = A.nres = 0;
+    if (k < h.K) {
+        const uint2 a = assoc[(size_t)(assoc_per_cand ? b : 0) * dp.n_kp_total + h.kp_base + k];
+        const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
+        if (a.x != kNone) {
+            const PlaneRec rec = dp.plane_local[h.pt_base + a.x];
+            const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]}, n0[3] = {rec.nx, rec.ny, rec.nz};
+            const float2 uv = dp.kp_uv[h.kp_base + k];
+            plane_factor_accum(c, h, dp, prm, k, h.K, (double)uv.x, (double)uv.y, p0, n0, A);
+        }
+        if (a.y != kNone) {
+            const uint32_t pos = a.y & 0x7FFFFFFFu; const bool is_plane = (a.y >> 31) != 0;
+            const PlaneRec rec = dp.plane_local[h.pt_base + pos];
+            const double Q[3] = {(double)xs[pos], (double)ys[pos], (double)zs[pos]}, n[3] = {rec.nx, rec.ny, rec.nz};
+            p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, n, is_plane, A);
+        }
+    }
+    // fixed-order reduction: wave shuffle, then the 4 waves in order
+    double* v = (double*)&A;   // 41 contiguous doubles
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 41; ++i) {
+        double x = v[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (lane == 0) s_part[wave][i] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartialStride) {
+        const int i = threadIdx.x;
+        double out = 0;
+        // map NAcc slot -> partial slot
+        int src = -1;
+        if (i >= P_H0 && i < P_H0 + 28) src = i - P_H0;
+        else if (i >= P_B0 && i < P_B0 + 7) src = 28 + (i - P_B0);
+        else if (i == P_CHI2) src = 35; else if (i == P_COST) src = 36; else if (i == P_NF_3D2D) src = 37;
+        else if (i == P_NF_P2PL) src = 38; else if (i == P_NF_P2PT) src = 39; else if (i == P_NRES) src = 40;
+        if (src >= 0) out = ((s_part[0][src] + s_part[1][src]) + s_part[2][src]) + s_part[3][src];
+        partials[((size_t)b * nrec + rec_base + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * kPartialStride + i] = out;
+    }
 }
 
 // sums the per-frame records of each candidate in a fixed order. grid: B blocks of 256 threads

@@ -1,0 +1,49 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PKG = "spatial-temporal-lidar-camera-calibration_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module(PKG)
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module(PKG + ".synth")
+
+
+@pytest.fixture(scope="session")
+def abi():
+    return importlib.import_module(PKG + ".abi")
+
+
+@pytest.fixture(scope="session")
+def ob():
+    """oracle binding (test infrastructure)"""
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+_scene_cache = {}
+
+
+@pytest.fixture(scope="session")
+def scene_small(synth):
+    """12 keyframes x 4000 points, 2000 keypoints each (seed 1)."""
+    if "small" not in _scene_cache:
+        _scene_cache["small"] = synth.make_scene(n_frames=12, pts_per_frame=4000, seed=1)
+    return _scene_cache["small"]
