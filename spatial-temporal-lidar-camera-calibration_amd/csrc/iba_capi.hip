@@ -53,7 +53,7 @@ struct iba_handle {
     std::string err;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    bool timing = false;
+    bool timing = false, timing_recorded = false;
     float last_frame_ms = 0.f, last_total_ms = 0.f;
     int64_t n_points = 0, n_keypoints = 0;
     uint32_t maxP = 0, maxPpad = 0, maxK = 0, maxNodes = 0, maxBitmapWords = 0;
@@ -217,7 +217,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->n_frames, d_partials);
     HIP_TRY(h, hipGetLastError());
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev2, st));
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
     return IBA_OK;
 }
 
@@ -420,6 +420,11 @@ iba_status iba_set_params(iba_handle* h, const iba_params* p) {
 iba_status iba_set_timing(iba_handle* h, int32_t enable) { if (!h) return IBA_ERR_INVALID_ARG; h->timing = enable != 0; return IBA_OK; }
 iba_status iba_last_kernel_ms(iba_handle* h, float* frame_kernel_ms, float* total_ms) {
     if (!h) return IBA_ERR_INVALID_ARG;
+    if (h->timing && h->timing_recorded) {   // events of the last launch (any stream): wait for them, then read
+        HIP_TRY(h, hipEventSynchronize(h->ev2));
+        HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1));
+        HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2));
+    }
     if (frame_kernel_ms) *frame_kernel_ms = h->last_frame_ms;
     if (total_ms) *total_ms = h->last_total_ms;
     return IBA_OK;
@@ -536,7 +541,7 @@ static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B
     s = launch_factors(h, dc, B, h->d_assoc.p, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
     HIP_TRY(h, hipGetLastError());
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev2, st));
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
     return IBA_OK;
 }
 
@@ -579,7 +584,7 @@ iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_norma
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, h->stream, h->d_frame_partials.p, h->nfb, h->d_partials.p);
     HIP_TRY(h, hipGetLastError());
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev2, h->stream));
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, h->stream)); h->timing_recorded = true; }
     HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
