@@ -163,19 +163,22 @@ def main():
         # ---- CPU baseline: the oracle (a port of the reference algorithm) on this box's host cores ----
         from oracle import binding as ob
         o = ob.Oracle(base)
-        nc = 2
+        nthreads = min(ob.max_threads(), args.frames)
+        nc1 = 2
         t0 = time.perf_counter()
-        o.eval_cost(params, xs[:nc], nthreads=1)
-        o.eval_normal(params, xs[:nc])
-        t1 = time.perf_counter() - t0
-        nthreads = ob.max_threads()
+        o.eval_cost(params, xs[:nc1], nthreads=1)
+        o.eval_normal(params, xs[:nc1], nthreads=1)
+        t1 = (time.perf_counter() - t0) / nc1
+        nco = 8 if nthreads >= 8 else 2
         t0 = time.perf_counter()
-        o.eval_cost(params, xs[:2 * nc], nthreads=nthreads)
-        t_omp = (time.perf_counter() - t0) / (2 * nc)
+        o.eval_cost(params, xs[:nco], nthreads=nthreads)
+        o.eval_normal(params, xs[:nco], nthreads=nthreads)
+        to = (time.perf_counter() - t0) / nco
         res["cpu_baseline"] = {
-            "value": nc / t1, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": "%d of the %d candidates of one step, cost tuple + normal equations each, 1 thread (what the NOMAD loop runs, iba_global.cpp:385)" % (nc, B),
-            "cost_path_all_cores_evals_per_s": 1.0 / t_omp, "all_cores": nthreads,
+            "value": 1.0 / to, "unit": "evals/s", "cores": nthreads, "kind": "port",
+            "sample": "%d of the %d candidates of one step (cost tuple + normal equations each), OpenMP over keyframes as iba_func.cpp:203 / iba_local.cpp:162" % (nco, B),
+            "single_thread_evals_per_s": 1.0 / t1,
+            "single_thread_note": "%d candidates, 1 thread = what the reference's NOMAD loop runs (iba_global.cpp:385)" % nc1,
         }
     if rank == 0:
         print(json.dumps(res))

@@ -92,6 +92,13 @@ class Oracle:
         lib().oracle_eval_cost(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out, C.c_int(nthreads))
         return list(out)
 
+    def eval_cost_raw(self, params, x, f_begin, f_end):
+        """un-normalised sums over frames [f_begin, f_end) in the order of the product's partial block"""
+        x = np.ascontiguousarray(x, np.float64)
+        raw = np.zeros(12)
+        lib().oracle_eval_cost_raw(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(f_begin), C.c_int(f_end), _p(raw))
+        return raw
+
     def eval_bbo(self, params, x, he_threshold, valid_rate):
         x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
         B = len(x)
@@ -120,11 +127,11 @@ class Oracle:
         lib().oracle_eval_factors(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out)
         return list(out)
 
-    def eval_normal(self, params, x):
+    def eval_normal(self, params, x, nthreads=1):
         x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
         B = len(x)
         out = (IbaNormalOut * B)()
-        lib().oracle_eval_normal(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out)
+        lib().oracle_eval_normal(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out, C.c_int(nthreads))
         return list(out)
 
     def eval_residuals(self, x):
@@ -210,4 +217,9 @@ def huber(a, s):
 
 
 def max_threads():
-    return lib().oracle_max_threads()
+    """host cores usable by this process (OMP_NUM_THREADS may be pinned to 1 by the launcher)"""
+    import os
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1

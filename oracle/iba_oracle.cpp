@@ -170,7 +170,7 @@ void transform_cloud(const Frame& f, const Iso3& T, std::vector<double>& PC) {  
 }
 
 // iba_global.cpp:169-344
-void BAError(const Oracle& O, const iba_params& prm, const double* xvec, bool multiprocessing, iba_cost_out& out) {
+void BAError(const Oracle& O, const iba_params& prm, const double* xvec, bool multiprocessing, iba_cost_out& out, int f_begin = 0, int f_end = -1, double* raw = nullptr) {
     double corr_3d_2d_err = 0, corr_3d_3d_err = 0, Cval = 0, Ccnt = 0;
     int cnt_3d_2d = 0, valid_cnt_3d_2d = 0, valid_pl_3d_3d = 0, valid_pt_3d_3d = 0, cnt_3d_3d = 0, valid_cnt_3d_3d = 0;
     int frames_used = 0, n_corr = 0;
@@ -180,8 +180,9 @@ void BAError(const Oracle& O, const iba_params& prm, const double* xvec, bool mu
     const Iso3 Tlc = inverse(Tcl);
     const int F = (int)O.frames.size();
     (void)multiprocessing;
+    const int Fb = f_begin, Fe = f_end < 0 ? F : f_end;
 #pragma omp parallel for if (multiprocessing)
-    for (int Fi = 0; Fi < F; ++Fi) {
+    for (int Fi = Fb; Fi < Fe; ++Fi) {
         const Frame& kf = O.frames[Fi];
         std::vector<double> PC;
         transform_cloud(kf, Tcl, PC);
@@ -256,6 +257,10 @@ void BAError(const Oracle& O, const iba_params& prm, const double* xvec, bool mu
             }
         }
     }
+    if (raw) {   // un-normalised sums in the order of the product's partial block (for the sharding tests)
+        raw[0] = corr_3d_2d_err; raw[1] = corr_3d_3d_err; raw[2] = Cval; raw[3] = Ccnt; raw[4] = cnt_3d_2d; raw[5] = valid_cnt_3d_2d; raw[6] = cnt_3d_3d;
+        raw[7] = valid_cnt_3d_3d; raw[8] = valid_pl_3d_3d; raw[9] = valid_pt_3d_3d; raw[10] = frames_used; raw[11] = n_corr;
+    }
     if (valid_cnt_3d_2d == 0 && prm.err_weight[0] > 1e-10) corr_3d_2d_err = std::numeric_limits<double>::max();
     else corr_3d_2d_err /= valid_cnt_3d_2d;
     if (valid_cnt_3d_3d == 0 && prm.err_weight[1] > 1e-10) corr_3d_3d_err = std::numeric_limits<double>::max();
@@ -322,20 +327,26 @@ void eval_factor(const Factor& f, const double* x, double* r, double* J /*rows x
 
 // iba_local.cpp:145-323 (association only; the factors are appended in frame order, the reference's
 // insertion order under `omp critical` is nondeterministic)
-void BuildProblem(Oracle& O, const iba_params& prm, const double* params) {
+void BuildProblem(Oracle& O, const iba_params& prm, const double* params, bool multithread = false) {
     O.factors.clear(); O.bp_frames_used = 0; O.bp_n_corr = 0;
+    std::vector<std::vector<Factor>> per_frame(O.frames.size());
+    int frames_used = 0, n_corr = 0;
     const double max_3d_dist2 = prm.max_3d_dist * prm.max_3d_dist;
     M3d init_rotation; V3d init_translation; double init_scale;
     Sim3Exp<double>(params, init_rotation, init_translation, init_scale);
     Iso3 initSE3{init_rotation, init_translation};
     const Iso3 initSE3inv = inverse(initSE3);
+    (void)multithread;
+#pragma omp parallel for schedule(static) if (multithread)   // iba_local.cpp:162
     for (size_t Fi = 0; Fi < O.frames.size(); ++Fi) {
         const Frame& kf = O.frames[Fi];
+        std::vector<Factor>& out_factors = per_frame[Fi];
         std::vector<double> points; transform_cloud(kf, initSE3, points);
         CorrSet pt2d3d_map;
         FindProjectCorrespondences(points, kf, O.leaf2d, prm.max_pixel_dist, pt2d3d_map);
         if ((int)pt2d3d_map.size() < prm.num_min_corr) continue;
-        O.bp_frames_used++; O.bp_n_corr += (int)pt2d3d_map.size();
+#pragma omp critical
+        { frames_used++; n_corr += (int)pt2d3d_map.size(); }
         for (size_t ci = 0; ci < pt2d3d_map.size(); ++ci) {
             const uint32_t point2d_idx = pt2d3d_map[ci].first, point3d_idx = pt2d3d_map[ci].second;
             // ComputeLocalNeighbor (pointcloud.h:733-760)
@@ -361,7 +372,7 @@ void BuildProblem(Oracle& O, const iba_params& prm, const double* params) {
                 pf.R.push_back(cv.rel.R); pf.t.push_back(cv.rel.t);  // translation unscaled: iba_local.cpp:184-188
             }
             if (pf.u1.empty()) continue;
-            if (bvalid_plane) O.factors.push_back(pf);
+            if (bvalid_plane) out_factors.push_back(pf);
             V3d MapPointInLidar = apply(initSE3inv, MapPoint * init_scale);
             uint32_t mp_idx; double mp_sq;
             KNNResultSet rs(1); rs.init(&mp_idx, &mp_sq);
@@ -381,9 +392,11 @@ void BuildProblem(Oracle& O, const iba_params& prm, const double* params) {
             }
             Factor g; g.kind = state ? 1 : 2; g.frame = (int)Fi; g.kp = (int)point2d_idx;
             g.fx = g.fy = g.cx = g.cy = g.u0 = g.v0 = 0; g.MapPoint = MapPoint; g.Q = NN; g.n = n2; g.p0 = {0, 0, 0}; g.n0 = {0, 0, 0};
-            O.factors.push_back(g);
+            out_factors.push_back(g);
         }
     }
+    O.bp_frames_used = frames_used; O.bp_n_corr = n_corr;
+    for (auto& v : per_frame) for (auto& f : v) O.factors.push_back(std::move(f));   // frame order (the reference's order under omp critical is nondeterministic)
 }
 
 // ceres::HuberLoss::Evaluate + Corrector with rho'' <= 0 (third-party, restated)
@@ -393,23 +406,38 @@ inline void huber(double a, double s, double& rho0, double& rho1) {
     else { rho0 = s; rho1 = 1.0; }
 }
 
-void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_normal_out& out) {
+void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_normal_out& out, bool multithread = false) {
     std::memset(&out, 0, sizeof(out));
-    double r[64], J[64 * 7];
-    for (auto const& f : O.factors) {
-        const int rows = f.rows();
-        if (rows > 64) continue;
-        eval_factor(f, x, r, J);
-        double s = 0; for (int i = 0; i < rows; ++i) s += r[i] * r[i];
-        double rho0, rho1; huber(f.kind == 0 ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, s, rho0, rho1);
-        out.cost += 0.5 * rho0; out.chi2 += s;
-        for (int i = 0; i < rows; ++i)
-            for (int a = 0; a < 7; ++a) {
-                out.b[a] += rho1 * J[i * 7 + a] * r[i];
-                for (int c = 0; c < 7; ++c) out.H[a * 7 + c] += rho1 * J[i * 7 + a] * J[i * 7 + c];
-            }
-        out.n_residuals += rows;
-        if (f.kind == 0) out.n_factor_3d2d++; else if (f.kind == 1) out.n_factor_p2pl++; else out.n_factor_p2pt++;
+    const long n = (long)O.factors.size();
+    (void)multithread;
+#pragma omp parallel if (multithread)
+    {
+        iba_normal_out loc; std::memset(&loc, 0, sizeof(loc));
+        double r[64], J[64 * 7];
+#pragma omp for schedule(static)
+        for (long fi = 0; fi < n; ++fi) {
+            const Factor& f = O.factors[fi];
+            const int rows = f.rows();
+            if (rows > 64) continue;
+            eval_factor(f, x, r, J);
+            double s = 0; for (int i = 0; i < rows; ++i) s += r[i] * r[i];
+            double rho0, rho1; huber(f.kind == 0 ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, s, rho0, rho1);
+            loc.cost += 0.5 * rho0; loc.chi2 += s;
+            for (int i = 0; i < rows; ++i)
+                for (int a = 0; a < 7; ++a) {
+                    loc.b[a] += rho1 * J[i * 7 + a] * r[i];
+                    for (int c = 0; c < 7; ++c) loc.H[a * 7 + c] += rho1 * J[i * 7 + a] * J[i * 7 + c];
+                }
+            loc.n_residuals += rows;
+            if (f.kind == 0) loc.n_factor_3d2d++; else if (f.kind == 1) loc.n_factor_p2pl++; else loc.n_factor_p2pt++;
+        }
+#pragma omp critical
+        {
+            for (int i = 0; i < 49; ++i) out.H[i] += loc.H[i];
+            for (int i = 0; i < 7; ++i) out.b[i] += loc.b[i];
+            out.cost += loc.cost; out.chi2 += loc.chi2; out.n_residuals += loc.n_residuals;
+            out.n_factor_3d2d += loc.n_factor_3d2d; out.n_factor_p2pl += loc.n_factor_p2pl; out.n_factor_p2pt += loc.n_factor_p2pt;
+        }
     }
     out.frames_used = O.bp_frames_used; out.n_corr = O.bp_n_corr;
 }
@@ -461,6 +489,9 @@ int oracle_eval_cost(void* h, const iba_params* p, const double* x, int B, iba_c
     for (int b = 0; b < B; ++b) BAError(*(Oracle*)h, *p, x + 7 * b, nthreads > 1, out[b]);
     return 0;
 }
+int oracle_eval_cost_raw(void* h, const iba_params* p, const double* x, int f_begin, int f_end, double* raw12) {
+    iba_cost_out tmp; BAError(*(Oracle*)h, *p, x, false, tmp, f_begin, f_end, raw12); return 0;
+}
 int oracle_eval_bbo(void* h, const iba_params* p, const double* x, int B, double he_threshold, double valid_rate, iba_bbo* out, int nthreads) {
     for (int b = 0; b < B; ++b) {  // iba_global.cpp:385-392
         iba_cost_out c; oracle_eval_cost(h, p, x + 7 * b, 1, &c, nthreads);
@@ -484,8 +515,11 @@ int oracle_eval_factors(void* h, const iba_params* p, const double* x, int B, ib
     for (int b = 0; b < B; ++b) EvalFactors(*(Oracle*)h, *p, x + 7 * b, out[b]);
     return 0;
 }
-int oracle_eval_normal(void* h, const iba_params* p, const double* x, int B, iba_normal_out* out) {
-    for (int b = 0; b < B; ++b) { BuildProblem(*(Oracle*)h, *p, x + 7 * b); EvalFactors(*(Oracle*)h, *p, x + 7 * b, out[b]); }
+int oracle_eval_normal(void* h, const iba_params* p, const double* x, int B, iba_normal_out* out, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    for (int b = 0; b < B; ++b) { BuildProblem(*(Oracle*)h, *p, x + 7 * b, nthreads > 1); EvalFactors(*(Oracle*)h, *p, x + 7 * b, out[b], nthreads > 1); }
     return 0;
 }
 int oracle_eval_residuals(void* h, const double* x, double* r, double* J, int32_t* block_id, int32_t* block_kind, int32_t* block_frame_kp, int64_t* n_rows) {

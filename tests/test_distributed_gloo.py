@@ -1,0 +1,59 @@
+"""N>1 path on CPU: frames shard across ranks with no data-path collective; each rank's partial block is
+summed with ONE all-reduce (gloo here, RCCL on the GPU box) and finalised by the product's host code.
+The per-shard partial blocks come from the oracle (no GPU in this container); what is under test is
+shard_frames + the partial-block layout + iba_finalize_cost over a real torch.distributed world of 2."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    import importlib
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd")
+    synth = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.synth")
+    abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi")
+    from oracle import binding as ob
+    prob, meta = synth.make_scene(n_frames=7, pts_per_frame=1200, n_keypoints=500, seed=9, new_mappoints=70, scan_kp=100)
+    p = abi.reference_yaml_params()
+    o = ob.Oracle(prob)
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(0), n=3)
+    f0, f1 = pkg.shard_frames(prob.n_frames, world, rank, np.diff(prob.arrays["pt_offset"].astype(np.int64)))
+    S = pkg.partial_stride()
+    part = np.zeros((len(xs), S))
+    for b, x in enumerate(xs):
+        part[b, :12] = o.eval_cost_raw(p, x, f0, f1)
+    t = torch.from_numpy(part)
+    dist.all_reduce(t)           # the single exchange step of the path
+    got = pkg.finalize_cost(p, t.numpy())
+    ref = o.eval_cost(p, xs)
+    ok = all((g.cnt_3d_2d, g.valid_cnt_3d_2d, g.cnt_3d_3d, g.valid_cnt_3d_3d, g.frames_used, g.n_corr) ==
+             (r.cnt_3d_2d, r.valid_cnt_3d_2d, r.cnt_3d_3d, r.valid_cnt_3d_3d, r.frames_used, r.n_corr) and
+             abs(g.f1 - r.f1) <= 1e-12 * abs(r.f1) and abs(g.f2 - r.f2) <= 1e-12 * abs(r.f2) and abs(g.C - r.C) <= 1e-12 for g, r in zip(got, ref))
+    q.put((rank, ok, (f0, f1)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_cost_allreduce():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for pr in procs:
+        pr.join(60)
+    assert all(ok for _, ok, _ in res), res
+    ranges = sorted(r for _, _, r in res)
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 7

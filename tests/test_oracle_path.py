@@ -1,0 +1,131 @@
+"""The oracle's restated evaluation path: committed golden outputs (regression pin), independent
+brute-force cross-checks of the association, Jacobians against central differences, and properties."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "path_small_scene.npz")
+
+
+@pytest.fixture(scope="module")
+def gold(abi):
+    z = np.load(GOLD)
+    prob = abi.Problem(**{k[6:]: z[k] for k in z.files if k.startswith("scene_")})
+    return z, prob
+
+
+def test_golden_cost_and_normal(ob, abi, gold):
+    z, prob = gold
+    p = abi.reference_yaml_params()
+    o = ob.Oracle(prob)
+    cost = o.eval_cost(p, z["xs"])
+    ci = np.array([[c.valid_cnt_3d_2d, c.cnt_3d_2d, c.cnt_3d_3d, c.valid_cnt_3d_3d, c.valid_pl_3d_3d, c.valid_pt_3d_3d, c.frames_used, c.n_corr] for c in cost])
+    assert np.array_equal(ci, z["cost_i"])
+    cf = np.array([[c.f1, c.f2, c.C] for c in cost])
+    assert np.allclose(cf, z["cost_f"], rtol=1e-12, atol=0, equal_nan=True)
+    nrm = o.eval_normal(p, z["xs"])
+    ni = np.array([[n.n_factor_3d2d, n.n_factor_p2pl, n.n_factor_p2pt, n.n_residuals, n.frames_used, n.n_corr] for n in nrm])
+    assert np.array_equal(ni, z["normal_i"])
+    for n, H, b, s in zip(nrm, z["normal_H"], z["normal_b"], z["normal_s"]):
+        assert np.allclose(n.H_np(), H, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(H).max()))
+        assert np.allclose(n.b_np(), b, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(b).max()))
+        assert np.allclose([n.cost, n.chi2], s, rtol=1e-12)
+    kp, pt = o.correspondences(p, z["xs"][0], 2)
+    assert np.array_equal(kp, z["corr_f2_kp"]) and np.array_equal(pt, z["corr_f2_pt"])
+    # last candidate is far off: every frame skipped -> DBL_MAX sentinels, NaN C (iba_global.cpp:330-338)
+    assert cost[-1].frames_used == 0 and cost[-1].f1 == np.finfo(np.float64).max and cost[-1].f2 == np.finfo(np.float64).max and np.isnan(cost[-1].C)
+
+
+def test_correspondences_vs_numpy_brute_force(ob, abi, synth, gold):
+    """FindProjectCorrespondences (iba_global.cpp:55-96) restated independently in numpy."""
+    z, prob = gold
+    p = abi.reference_yaml_params()
+    o = ob.Oracle(prob)
+    x = z["xs"][1]
+    R, t, _ = ob.sim3exp(x)
+    fx, fy, cx, cy, W, H = prob.arrays["intrinsics"][:6]
+    for f in range(prob.n_frames):
+        P = prob.frame_points(f).astype(np.float64)
+        pc = P @ R.T + t
+        zc = pc[:, 2]
+        with np.errstate(all="ignore"):
+            u = (fx * pc[:, 0] + cx * zc) / zc
+            v = (fx * pc[:, 1] + cy * zc) / zc
+        ok = (zc > 0) & (u >= 0) & (u < W) & (v >= 0) & (v < H)
+        ids = np.flatnonzero(ok)
+        kps = prob.frame_keypoints(f).astype(np.float64)
+        d2 = (kps[:, None, 0] - u[ids][None, :]) ** 2 + (kps[:, None, 1] - v[ids][None, :]) ** 2
+        j = np.argmin(d2, 1)
+        best = d2[np.arange(len(kps)), j]
+        sel = best <= p.max_pixel_dist ** 2
+        kp, pt = o.correspondences(p, x, f)
+        assert np.array_equal(kp, np.flatnonzero(sel).astype(np.uint32))
+        assert np.array_equal(pt, ids[j[sel]].astype(np.uint32))
+
+
+def test_residual_jacobians_vs_central_differences(ob, abi, gold):
+    """The dual-number Jacobians of IBA_PlaneFactor / Point2Plane / Point2Point (what Ceres' autodiff yields)."""
+    z, prob = gold
+    p = abi.reference_yaml_params()
+    o = ob.Oracle(prob)
+    x = z["xs"][1]
+    assert o.build_problem(p, x) > 50
+    r, J, bid, kind, fk = o.eval_residuals(x)
+    assert set(np.unique(kind)) <= {0, 1, 2} and len(r) == len(J)
+    Jn = np.zeros_like(J)
+    for k in range(7):
+        h = 1e-6 * max(1.0, abs(x[k]))
+        xp, xm = x.copy(), x.copy()
+        xp[k] += h
+        xm[k] -= h
+        Jn[:, k] = (o.eval_residuals(xp)[0] - o.eval_residuals(xm)[0]) / (2 * h)
+    assert np.allclose(J, Jn, rtol=2e-5, atol=2e-5 * np.abs(J).max())
+    # normal equations are consistent with the per-residual output: H = sum w J^T J, b = sum w J^T r
+    no = o.eval_factors(p, x)[0]
+    H = np.zeros((7, 7))
+    b = np.zeros(7)
+    cost = 0.0
+    for blk in np.unique(bid):
+        m = bid == blk
+        s = float(r[m] @ r[m])
+        a = p.robust_kernel_delta if kind[m][0] == 0 else p.robust_kernel_3ddelta
+        rho0, w = ob.huber(a, s)
+        H += w * J[m].T @ J[m]
+        b += w * J[m].T @ r[m]
+        cost += 0.5 * rho0
+    assert np.allclose(no.H_np(), H, rtol=1e-10, atol=1e-10 * np.abs(H).max()) and np.allclose(no.b_np(), b, rtol=1e-9, atol=1e-9 * np.abs(b).max())
+    assert np.isclose(no.cost, cost, rtol=1e-12)
+
+
+def test_cost_variants_and_bbo(ob, abi, gold):
+    z, prob = gold
+    o = ob.Oracle(prob)
+    x = z["xs"][0]
+    p = abi.reference_yaml_params()
+    base = o.eval_cost(p, x)[0]
+    p0 = abi.reference_yaml_params()
+    p0.err_weight[1] = 0.0      # 3d-3d disabled: counters bumped once per processed frame (iba_global.cpp:214-220)
+    c = o.eval_cost(p0, x)[0]
+    assert c.cnt_3d_3d == c.frames_used == c.valid_cnt_3d_3d and c.f2 == 0.0 and c.f1 == base.f1
+    pn = abi.reference_yaml_params()
+    pn.use_plane = 0
+    c = o.eval_cost(pn, x)[0]
+    assert c.valid_pl_3d_3d == 0 and c.valid_pt_3d_3d == c.valid_cnt_3d_3d and c.f2 >= base.f2
+    bb = o.eval_bbo(p, x, 0.094, 0.95)[0]
+    assert np.isclose(bb.f, base.f1 + base.f2) and np.isclose(bb.c1, base.C - 0.094) and np.isclose(bb.c2, -base.C - 0.094)
+    assert np.isclose(bb.c3, 0.95 - base.valid_cnt_3d_2d / (base.cnt_3d_2d + 1))
+    # OpenMP over frames (iba_func.cpp:203) gives the same counters and the same sums up to rounding
+    c8 = o.eval_cost(p, x, nthreads=4)[0]
+    assert (c8.cnt_3d_2d, c8.cnt_3d_3d, c8.n_corr) == (base.cnt_3d_2d, base.cnt_3d_3d, base.n_corr) and np.isclose(c8.f1, base.f1, rtol=1e-12)
+
+
+def test_frame_ranges_sum_to_whole(ob, abi, gold):
+    z, prob = gold
+    p = abi.reference_yaml_params()
+    o = ob.Oracle(prob)
+    x = z["xs"][0]
+    whole = o.eval_cost_raw(p, x, 0, prob.n_frames)
+    parts = o.eval_cost_raw(p, x, 0, 2) + o.eval_cost_raw(p, x, 2, prob.n_frames)
+    assert np.allclose(whole, parts, rtol=1e-13)
+    assert whole[3] == whole[10] - 1    # HE term exists for every processed frame but the last (iba_global.cpp:264)
