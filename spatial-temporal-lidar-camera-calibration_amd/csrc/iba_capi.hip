@@ -72,6 +72,7 @@ struct iba_handle {
     DevBuf<double> d_frame_partials;      // IBA_MAX_BATCH * n_frames * kPartialStride
     DevBuf<double> d_partials;            // IBA_MAX_BATCH * kPartialStride
     DevBuf<uint32_t> d_corr;              // n_keypoints
+    DevBuf<double> d_he;                  // IBA_MAX_BATCH * n_frames hand-eye values
     DevBuf<uint2> d_assoc;                // assoc_cap * n_keypoints (per-candidate association of iba_eval_normal)
     int assoc_cap = 0;
     DevBuf<uint2> d_assoc_frozen;         // n_keypoints (iba_build_problem)
@@ -145,7 +146,7 @@ void parallel_for(int n, F fn) {
 uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
 bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
-    const uint32_t red_bytes = 8u * (kWaves + 1) * kRedSlots + 4u * kWaves;
+    const uint32_t red_bytes = 8u * (kWaves + 1) * kRedSlots + 4u * kWaves + 16u;   // reduction slab + wave counts + misc
     L.scan_stride = with_scan ? h->maxPpad : 0;
     uint32_t off = with_scan ? 12u * h->maxPpad : 0u;
     off = align_up(off, 16); L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
@@ -153,7 +154,16 @@ bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
     off = align_up(off, 8); L.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
     L.off_bitmap = off; off += 4u * std::max(h->maxBitmapWords, 1u);
     off = align_up(off, 8); L.off_red = off; off += red_bytes;
-    L.total = align_up(off, 16);
+    off = align_up(off, 16); L.off_cand = off;
+    if (off + 1024u > kLdsBytes) return false;
+    // candidate queue takes what is left (u16 entries when the scan is in LDS, u32 otherwise); a full queue only
+    // costs speed (inline matching + rescan), never correctness
+    const uint32_t entry = with_scan ? 2u : 4u;
+    const uint32_t want = std::max<uint32_t>(h->maxPpad / 2u, 512u) * entry;
+    const uint32_t avail = (kLdsBytes - off) & ~15u;
+    const uint32_t bytes = std::min(want, avail);
+    L.cand_cap = bytes / entry;
+    L.total = off + bytes;
     return L.total <= kLdsBytes;
 }
 
@@ -184,11 +194,15 @@ iba_status compute_plane_cache(iba_handle* h) {
 template <int MODE>
 iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, uint2* d_assoc, int nrec, hipStream_t st) {
     const DevProblem dp = h->dev_problem();
+    if (MODE == MODE_COST && h->n_frames > 0) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
+        hipLaunchKernelGGL(iba_he_kernel, dim3((B * h->n_frames + 63) / 64), dim3(64), 0, st, dp, d_cands, B, h->d_he.p);
+        HIP_TRY(h, hipGetLastError());
+    }
     const int per_xcd = (h->n_frames + 7) / 8;
     const dim3 grid(8 * per_xcd * B), block(kThreads);
     if (h->n_frames == 0) return IBA_OK;
-    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec);
-    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec);
+    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p);
+    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }
@@ -248,7 +262,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->cell_start.release(); h->cell_kp.release(); h->bitmap.release(); h->cell_uv.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
@@ -389,6 +403,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(h->nrec, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
     if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
+    if ((er = h->d_he.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1))) != hipSuccess) return bail("alloc he", er);
     if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
     if ((er = hipHostMalloc((void**)&h->h_cands, sizeof(Cand) * kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("hipHostMalloc", er);
     if ((er = hipHostMalloc((void**)&h->h_partials, sizeof(double) * IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("hipHostMalloc", er);

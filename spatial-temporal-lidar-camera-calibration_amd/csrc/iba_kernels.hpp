@@ -25,6 +25,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #include "iba_build.hpp"
 #include "iba_types.hpp"
@@ -50,12 +51,12 @@ struct DevProblem {
 
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
     uint32_t scan_stride;   // floats per coordinate array (0 = scan not staged in LDS)
-    uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_red, total;
+    uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_red, off_cand, cand_cap, total;
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kWaves = kThreads / 64;
-constexpr int kRedSlots = 64;   // doubles per wave in the reduction slab
+constexpr int kRedSlots = 16;   // doubles per wave in the reduction slab
 
 __device__ __forceinline__ unsigned long long d2bits(double d) { return (unsigned long long)__double_as_longlong(d); }
 
@@ -322,9 +323,9 @@ __global__ __launch_bounds__(256) void iba_plane_kernel(DevProblem dp, double r2
     if ((threadIdx.x & 63) == 0) out[h.pt_base + pos] = rec;
 }
 
-// ---- fixed-order block reduction of NV doubles per thread; result valid in s_red[0..NV) for all threads after return ----
+// ---- fixed-order block reduction of NV doubles per thread; the totals are returned in v[] on every thread ----
 template <int NV>
-__device__ inline void block_reduce(double* v, double* s_red /* kWaves*kRedSlots doubles */) {
+__device__ inline void block_reduce(double* v, double* s_red /* (kWaves+1)*kRedSlots doubles */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -361,20 +362,28 @@ struct FrameCtx {   // wave-uniform per-block context
     double R[9], t[3];
 };
 
-// K1+K2+K3 for one scan point. PASS 1: ds_min on best d^2. PASS 2: resolve exact ties by original index.
-template <int PASS>
-__device__ __forceinline__ bool project_match(const FrameCtx& c, float xf, float yf, float zf, uint32_t pos) {
+// K1+K2: Tcl*p (pointcloud.h:82-86), pinhole projection and FOV cull (iba_global.cpp:68-81) for one scan point
+__device__ __forceinline__ bool project_uv(const FrameCtx& c, float xf, float yf, float zf, double& u, double& v) {
     const double x = (double)xf, y = (double)yf, z = (double)zf;
     const double pcx = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
     const double pcy = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
     const double pcz = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
     if (!(pcz > 0)) return false;
-    const double u = (c.fx * pcx + c.cx * pcz) / pcz;
-    const double v = (c.fx * pcy + c.cy * pcz) / pcz;   // fx on purpose: iba_global.cpp:73
-    if (!(0 <= u && u < c.W && 0 <= v && v < c.H)) return false;
+    u = (c.fx * pcx + c.cx * pcz) / pcz;
+    v = (c.fx * pcy + c.cy * pcz) / pcz;   // fx on purpose: iba_global.cpp:73
+    return 0 <= u && u < c.W && 0 <= v && v < c.H;
+}
+// one LDS bit: can any keypoint be within max_pixel_dist of this pixel?
+__device__ __forceinline__ bool near_keypoint(const FrameCtx& c, double u, double v) {
+    const uint32_t cell = (uint32_t)grid_cell((float)v, c.gh) * (uint32_t)c.gw + (uint32_t)grid_cell((float)u, c.gw);
+    return (c.bitmap[cell >> 5] >> (cell & 31)) & 1u;
+}
+// K3: exact 1-NN of every keypoint among the projected points, inverted: the projected point visits the
+// keypoints of the <= 2x2 grid cells around it. PASS 1: ds_min_u64 on the keypoint's best d^2.
+// PASS 2: resolve exact ties by the lowest original point index.
+template <int PASS>
+__device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v, uint32_t pos) {
     const float uf = (float)u, vf = (float)v;
-    const uint32_t cell = (uint32_t)grid_cell(vf, c.gh) * (uint32_t)c.gw + (uint32_t)grid_cell(uf, c.gw);
-    if (!((c.bitmap[cell >> 5] >> (cell & 31)) & 1u)) return false;
     const int x0 = grid_cell(uf - c.margin, c.gw), x1 = grid_cell(uf + c.margin, c.gw);
     const int y0 = grid_cell(vf - c.margin, c.gh), y1 = grid_cell(vf + c.margin, c.gh);
     bool hit = false;
@@ -394,6 +403,53 @@ __device__ __forceinline__ bool project_match(const FrameCtx& c, float xf, float
     return hit;
 }
 
+// ---- exact 1-NN with G lanes per query (G = 1,2,4,8): the G lanes walk the tree in lockstep and split each leaf ----
+template <int G>
+__device__ __forceinline__ void nn_search_group(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+                                                const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
+                                                double qx, double qy, double qz, double& best, uint32_t& bpos) {
+    if (G == 1) { nn_search(xs, ys, zs, nodes, perm_g, P, D, qx, qy, qz, best, bpos); return; }
+    const uint32_t sub = threadIdx.x & (G - 1);
+    best = INFINITY; bpos = kNone;
+    uint32_t node = 0, depth = 0;
+    const uint32_t first_leaf = (1u << D) - 1u;
+    bool descend = true;
+    for (;;) {
+        if (descend) {
+            while (depth < D) {
+                const TreeNode n = nodes[node];
+                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+                node = 2u * node + 1u + ((qd - (double)n.split) >= 0.0 ? 1u : 0u);
+                ++depth;
+            }
+            const uint32_t j = node - first_leaf;
+            const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+            for (uint32_t i = lo + sub; i < hi; i += G) {
+                const double dx = qx - (double)xs[i], dy = qy - (double)ys[i], dz = qz - (double)zs[i];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 < best) { best = d2; bpos = i; }
+                else if (d2 == best && bpos != kNone) { if (perm_g[i] < perm_g[bpos]) bpos = i; }
+            }
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) {
+                const double od = __shfl_xor(best, off); const uint32_t op = __shfl_xor(bpos, off);
+                if (od < best) { best = od; bpos = op; }
+                else if (od == best && op != kNone && op != bpos) { if (bpos == kNone || perm_g[op] < perm_g[bpos]) bpos = op; }
+            }
+            descend = false;
+        }
+        if (depth == 0) break;
+        const uint32_t parent = (node - 1u) >> 1;
+        const bool was_right = (node & 1u) == 0u;
+        const TreeNode n = nodes[parent];
+        const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+        const double diff = qd - (double)n.split;
+        const bool near_right = diff >= 0.0;
+        if (was_right == near_right && diff * diff <= best) { node = 2u * parent + 1u + (near_right ? 0u : 1u); descend = true; }
+        else { node = parent; --depth; }
+    }
+}
+
 enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2 };
 
 #ifdef IBA_STAMPS   // diagnostic build only: per-phase shader-clock deltas of thread 0 into partial slots 56..63
@@ -402,14 +458,57 @@ enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2 };
 #define IBA_STAMP(i) do { } while (0)
 #endif
 
+// K7: hand-eye consistency term of every (candidate, frame) pair (iba_global.cpp:264-276); one lane each.
+// The frame kernel adds he[b][f] only for frames that pass the corrset test.
+__global__ __launch_bounds__(64) void iba_he_kernel(DevProblem dp, const Cand* __restrict__ cands, int B, double* __restrict__ he) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= B * dp.n_frames) return;
+    const int b = i / dp.n_frames, f = i % dp.n_frames;
+    const FrameHdr& h = dp.frames[f];
+    const Cand& cd = cands[b];
+    double val = 0.0;
+    if (h.he_valid) {
+        double C1R[9], C1t[3], C2R[9], C2t[3];
+        const double* Tl = h.Tl_next; const double* Tc = h.Tc_next;
+        for (int r = 0; r < 3; ++r) {
+            for (int cc = 0; cc < 3; ++cc) {
+                C1R[r * 3 + cc] = (cd.R[r * 3 + 0] * Tl[0 * 4 + cc] + cd.R[r * 3 + 1] * Tl[1 * 4 + cc]) + cd.R[r * 3 + 2] * Tl[2 * 4 + cc];
+                C2R[r * 3 + cc] = (Tc[r * 4 + 0] * cd.R[0 * 3 + cc] + Tc[r * 4 + 1] * cd.R[1 * 3 + cc]) + Tc[r * 4 + 2] * cd.R[2 * 3 + cc];
+            }
+            C1t[r] = ((cd.R[r * 3 + 0] * Tl[3] + cd.R[r * 3 + 1] * Tl[7]) + cd.R[r * 3 + 2] * Tl[11]) + cd.t[r];
+            C2t[r] = ((Tc[r * 4 + 0] * cd.t[0] + Tc[r * 4 + 1] * cd.t[1]) + Tc[r * 4 + 2] * cd.t[2]) + Tc[r * 4 + 3] * cd.s;
+        }
+        double l1[6], l2[6];
+        dev_se3log(C1R, C1t, l1); dev_se3log(C2R, C2t, l2);
+        double ss = 0;
+        for (int k = 0; k < 6; ++k) ss += (l1[k] - l2[k]) * (l1[k] - l2[k]);
+        val = sqrt(ss);
+    }
+    he[i] = val;
+}
+
+// ordered (by keypoint id) append of the keypoints with `want` set to s_list; two barriers; n3 stays wave-uniform
+__device__ __forceinline__ void ordered_append(bool want, uint32_t k, uint32_t& n3, uint32_t* s_list, uint32_t* s_wcnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(want);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < kWaves; ++w) { const uint32_t cw = s_wcnt[w]; total += cw; if (w < wave) before += cw; }
+    if (want) s_list[n3 + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = k;
+    n3 += total;
+    __syncthreads();
+}
+
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so
 // all candidates of one frame share that XCD's L2 copy of the scan.
 template <int MODE, bool SCAN_LDS>
 __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
                                                              double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out,
-                                                             uint2* __restrict__ assoc_out, int nrec) {
+                                                             uint2* __restrict__ assoc_out, int nrec, const double* __restrict__ he) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    typedef typename std::conditional<SCAN_LDS, uint16_t, uint32_t>::type CandT;   // LDS mode implies P < 65536
+    const int tid = threadIdx.x, lane = tid & 63;
     const int nf = dp.n_frames;
     const int per_xcd = (nf + 7) / 8;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -425,8 +524,10 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     TreeNode* s_nodes = (TreeNode*)(smem + lay.off_nodes);
     uint32_t* s_bitmap = (uint32_t*)(smem + lay.off_bitmap);
     double* s_red = (double*)(smem + lay.off_red);
-    uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 after phase 2
     uint32_t* s_wcnt = (uint32_t*)(s_red + (kWaves + 1) * kRedSlots);
+    uint32_t* s_misc = s_wcnt + kWaves;                       // [0] candidate count, [1] overflow flag
+    CandT* s_cand = (CandT*)(smem + lay.off_cand);
+    uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 after phase 2
 
     const uint32_t P = h.P, Ppad = h.Ppad, K = h.K, D = h.depth;
     const float* gxs = dp.xs + h.pt_base; const float* gys = dp.ys + h.pt_base; const float* gzs = dp.zs + h.pt_base;
@@ -441,6 +542,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     for (uint32_t i = tid; i < nnodes; i += kThreads) s_nodes[i] = dp.nodes[h.node_base + i];
     const uint32_t nbw = (h.gw * h.gh + 31u) >> 5;
     for (uint32_t i = tid; i < nbw; i += kThreads) s_bitmap[i] = dp.bitmap[h.bitmap_base + i];
+    if (tid < 2) s_misc[tid] = 0u;
     __syncthreads();
 
     FrameCtx c;
@@ -456,47 +558,85 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     for (int i = 0; i < 3; ++i) c.t[i] = cd.t[i];
 
     IBA_STAMP(1);
-    // ---- phase 1: stream + project + match ----
-    unsigned long long hitmask = 0ull;
-    bool overflow = false;
+    // ---- phase 1a: stream the scan once (16 B/lane), keep it in LDS, project, cull, 1-bit keypoint test.
+    //      Survivors (~1 in 5) are queued in LDS so that the grid lookups below run with dense lanes.
+    const uint32_t cand_cap = lay.cand_cap;
     {
-        int slot = 0;
-        for (uint32_t base = (uint32_t)tid * 4u; base < Ppad; base += kThreads * 4u, ++slot) {
-            const float4 X = *(const float4*)(gxs + base), Y = *(const float4*)(gys + base), Z = *(const float4*)(gzs + base);
-            if (SCAN_LDS) { *(float4*)(s_xs + base) = X; *(float4*)(s_ys + base) = Y; *(float4*)(s_zs + base) = Z; }
-            const float px[4] = {X.x, X.y, X.z, X.w}, py[4] = {Y.x, Y.y, Y.z, Y.w}, pz[4] = {Z.x, Z.y, Z.z, Z.w};
+        const uint32_t n_iter = (Ppad + kThreads * 4u - 1u) / (kThreads * 4u);
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            const uint32_t base = (uint32_t)tid * 4u + it * (kThreads * 4u);
+            float px[4] = {0.f, 0.f, 0.f, 0.f}, py[4] = {0.f, 0.f, 0.f, 0.f}, pz[4] = {-1.f, -1.f, -1.f, -1.f};
+            if (base < Ppad) {
+                const float4 X = *(const float4*)(gxs + base), Y = *(const float4*)(gys + base), Z = *(const float4*)(gzs + base);
+                if (SCAN_LDS) { *(float4*)(s_xs + base) = X; *(float4*)(s_ys + base) = Y; *(float4*)(s_zs + base) = Z; }
+                px[0] = X.x; px[1] = X.y; px[2] = X.z; px[3] = X.w; py[0] = Y.x; py[1] = Y.y; py[2] = Y.z; py[3] = Y.w;
+                pz[0] = Z.x; pz[1] = Z.y; pz[2] = Z.z; pz[3] = Z.w;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (project_match<1>(c, px[j], py[j], pz[j], base + j)) {
-                    const int bit = slot * 4 + j;
-                    if (bit < 64) hitmask |= 1ull << bit; else overflow = true;
+                double u = 0, v = 0;
+                const bool pass = base < Ppad && project_uv(c, px[j], py[j], pz[j], u, v) && near_keypoint(c, u, v);
+                const unsigned long long bal = __ballot(pass);
+                if (bal) {
+                    uint32_t wb = 0;
+                    if (lane == 0) wb = atomicAdd(&s_misc[0], (uint32_t)__popcll(bal));
+                    wb = __shfl(wb, 0);
+                    if (pass) {
+                        const uint32_t idx = wb + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                        if (idx < cand_cap) s_cand[idx] = (CandT)(base + j);
+                        else { grid_match<1>(c, u, v, base + j); s_misc[1] = 1u; }   // queue full: match inline, rescan in phase 2
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    IBA_STAMP(2);
-    // ---- phase 2: tie resolution for the points that hit ----
+    // ---- phase 1b: queued points visit the keypoint grid; ds_min_u64 on the keypoint's best d^2 ----
+    const uint32_t ncand = min(s_misc[0], cand_cap);
+    const bool overflow = s_misc[1] != 0u;
+    uint32_t hitbits = 0u;
     {
-        unsigned long long m = hitmask;
-        while (m) {
-            const int bit = __ffsll((long long)m) - 1; m &= m - 1;
-            const uint32_t pos = (uint32_t)tid * 4u + (uint32_t)(bit >> 2) * (kThreads * 4u) + (uint32_t)(bit & 3);
-            project_match<2>(c, c.xs[pos], c.ys[pos], c.zs[pos], pos);
+        int it = 0;
+        for (uint32_t i = tid; i < ncand; i += kThreads, ++it) {
+            const uint32_t pos = (uint32_t)s_cand[i];
+            double u, v;
+            project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v);
+            if (grid_match<1>(c, u, v, pos)) hitbits |= 1u << (it & 31);
+        }
+    }
+    __syncthreads();
+    IBA_STAMP(2);
+    // ---- phase 2: exact tie resolution (lowest original index) for the points that hit ----
+    {
+        int it = 0;
+        for (uint32_t i = tid; i < ncand; i += kThreads, ++it) {
+            if (!((hitbits >> (it & 31)) & 1u) && it < 32) continue;
+            const uint32_t pos = (uint32_t)s_cand[i];
+            double u, v;
+            project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v);
+            grid_match<2>(c, u, v, pos);
         }
         if (overflow) {
-            for (uint32_t base = (uint32_t)tid * 4u + 16u * kThreads * 4u; base < Ppad; base += kThreads * 4u)
-                for (int j = 0; j < 4; ++j) project_match<2>(c, c.xs[base + j], c.ys[base + j], c.zs[base + j], base + j);
+            for (uint32_t pos = tid; pos < P; pos += kThreads) {
+                double u, v;
+                if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v) && near_keypoint(c, u, v)) grid_match<2>(c, u, v, pos);
+            }
         }
     }
     __syncthreads();
 
-    if (MODE == MODE_CORR) {   // dense dump: corr_out[b][kp_base + k] = original point index or kNone
+    if (MODE == MODE_CORR) {   // dense dump: corr_out[kp_base + k] = original point index or kNone
         for (uint32_t k = tid; k < K; k += kThreads) corr_out[h.kp_base + k] = s_best_idx[k];
         return;
     }
 
     IBA_STAMP(3);
+    const float4* kp_mp = dp.kp_mp + h.kp_base;
+    const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
+    const uint32_t Kceil = (K + kThreads - 1) / kThreads * kThreads;
+    const double s = cd.s;
+    uint32_t n3 = 0;   // wave-uniform running length of s_list
+
     if (MODE == MODE_ASSOC) {
         // ---- BuildProblem association (iba_local.cpp:145-323): which residual blocks exist at this x ----
         uint2* arow = assoc_out + (size_t)b * dp.n_kp_total + h.kp_base;
@@ -505,43 +645,56 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         block_reduce<1>(cnt, s_red);
         const bool used = !(cnt[0] < (double)prm.num_min_corr);   // iba_local.cpp:192
         if (tid < kPartialStride) part[tid] = (used && tid == P_FRAMES_N) ? 1.0 : ((used && tid == P_NCORR_N) ? cnt[0] : 0.0);
-        const float4* kp_mp = dp.kp_mp + h.kp_base;
-        const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
         const PlaneRec* planes = dp.plane_local + h.pt_base;
-        for (uint32_t k = tid; k < K; k += kThreads) {
-            uint2 a = make_uint2(kNone, kNone);
-            const uint32_t orig = s_best_idx[k];
-            if (used && orig != kNone) {
-                const uint32_t pos = inv_perm[orig];
-                const PlaneRec rec = planes[pos];
-                // ComputeLocalNeighbor validity (pointcloud.h:752), then MapPoint ownership (iba_local.cpp:213)
-                const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
-                const float4 mp = kp_mp[k];
-                bool any_covis = false;
-                for (uint32_t sl = 0; sl < h.n_slots; ++sl) { const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k]; any_covis |= (m.x == m.x); }
-                if (neigh_ok && mp.w != 0.0f && any_covis) {   // :259-260
-                    if (rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) a.x = pos;   // bvalid_plane (:231)
-                    // MapPoint in the reference camera frame, scale-free (:238-239), then into the LiDAR frame (:282)
-                    const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
-                    const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
-                    const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
-                    const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
-                    const double sx = mx * cd.s, sy = my * cd.s, sz = mz * cd.s;
-                    const double qx = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
-                    const double qy = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
-                    const double qz = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
-                    double best; uint32_t bpos;
-                    nn_search(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
-                    if (!(best > prm.max_3d_dist2)) {   // :289
-                        const PlaneRec r2 = planes[bpos];   // ComputeLocalNormalSingleThre (pointcloud.h:699-717)
-                        const bool state = !(r2.k < prm.neigh_min_pts || r2.far_d2 < prm.local_min_diff_dist2) &&
-                                           (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);
-                        a.y = bpos | (state ? 0x80000000u : 0u);
+        for (uint32_t k = tid; k < Kceil; k += kThreads) {
+            bool want3 = false;
+            if (k < K) {
+                uint2 a = make_uint2(kNone, kNone);
+                const uint32_t orig = s_best_idx[k];
+                if (used && orig != kNone) {
+                    const uint32_t pos = inv_perm[orig];
+                    const PlaneRec rec = planes[pos];
+                    // ComputeLocalNeighbor validity (pointcloud.h:752), then MapPoint ownership (iba_local.cpp:213)
+                    const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
+                    bool any_covis = false;
+                    for (uint32_t sl = 0; sl < h.n_slots; ++sl) { const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k]; any_covis |= (m.x == m.x); }
+                    if (neigh_ok && kp_mp[k].w != 0.0f && any_covis) {   // :259-260
+                        if (rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) a.x = pos;   // bvalid_plane (:231)
+                        want3 = true;
                     }
                 }
+                arow[k] = a;
             }
-            arow[k] = a;
+            ordered_append(want3, k, n3, s_list, s_wcnt);
         }
+        // MapPoint -> LiDAR frame (iba_local.cpp:238-239, 282), 1-NN, local plane at the NN (pointcloud.h:699-717)
+        auto assoc_3d3d = [&](auto GT) {
+            constexpr int G = decltype(GT)::value;
+            for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
+                const uint32_t k = s_list[i];
+                const float4 mp = kp_mp[k];
+                const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+                const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
+                const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
+                const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
+                const double sx = mx * s, sy = my * s, sz = mz * s;
+                const double qx = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
+                const double qy = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
+                const double qz = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
+                double best; uint32_t bpos;
+                nn_search_group<G>(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
+                if ((tid & (G - 1)) == 0 && !(best > prm.max_3d_dist2)) {   // :289
+                    const PlaneRec r2 = planes[bpos];
+                    const bool state = !(r2.k < prm.neigh_min_pts || r2.far_d2 < prm.local_min_diff_dist2) &&
+                                       (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);
+                    arow[k].y = bpos | (state ? 0x80000000u : 0u);
+                }
+            }
+        };
+        if (n3 * 8u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 8>());
+        else if (n3 * 4u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 4>());
+        else if (n3 * 2u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 2>());
+        else assoc_3d3d(std::integral_constant<int, 1>());
         return;
     }
 
@@ -557,90 +710,89 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             if (tid < kPartialStride) part[tid] = 0.0;
             return;
         }
-        if (tid == 0) { acc[P_FRAMES] = 1.0; acc[P_NCORR] = cnt[0]; }
+        if (tid == 0) {
+            acc[P_FRAMES] = 1.0; acc[P_NCORR] = cnt[0];
+            if (h.he_valid) { acc[P_HE_SUM] = he[(size_t)b * nf + f]; acc[P_HE_CNT] = 1.0; }   // K7 (iba_he_kernel)
+        }
     }
 
     IBA_STAMP(4);
-    // ---- phase 4a: 3d-2d residuals + ordered compaction of the 3d-3d work list ----
-    const float2* kp_uv = dp.kp_uv + h.kp_base;
-    const float4* kp_mp = dp.kp_mp + h.kp_base;
-    const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
-    const double s = cd.s;
-    uint32_t n3 = 0;   // wave-uniform running length of s_list
-    const uint32_t Kceil = (K + kThreads - 1) / kThreads * kThreads;
+    // ---- phase 4a: 3d-2d residuals (iba_global.cpp:291-328) + ordered compaction of the 3d-3d work list ----
     for (uint32_t k = tid; k < Kceil; k += kThreads) {
         bool want3 = false;
-        if (k < K) {
-            const uint32_t orig = s_best_idx[k];
-            if (orig != kNone) {
-                const uint32_t pos = inv_perm[orig];
-                const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
-                const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
-                const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
-                const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
-                for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
-                    const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k];
-                    if (m.x != m.x) continue;   // NaN: keypoint not in GetUordMatchedKptIds(pKFConv)
-                    const double* rel = dp.slots[h.slot_base + sl].rel;
-                    const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
-                    const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
-                    const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
-                    const double ou = h.fx * p1x / p1z + h.cx;
-                    const double ov = h.fy * p1y / p1z + h.cy;
-                    if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
-                    const double eu = ou - (double)m.x, ev = ov - (double)m.y;
-                    const double dist = sqrt(eu * eu + ev * ev);
-                    if (dist < prm.corr_3d_2d_threshold) { acc[P_SUM_3D2D] += dist; acc[P_VALID_3D2D] += 1.0; }
-                    acc[P_CNT_3D2D] += 1.0;
-                }
-                want3 = prm.use_3d3d && kp_mp[k].w != 0.0f;
+        const uint32_t orig = k < K ? s_best_idx[k] : kNone;
+        if (orig != kNone) {
+            const uint32_t pos = inv_perm[orig];
+            const float has_mp = kp_mp[k].w;
+            float2 m[4];
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) m[sl] = (uint32_t)sl < h.n_slots ? dp.match_uv[h.match_base + (size_t)sl * K + k] : make_float2(__builtin_nanf(""), 0.f);
+            const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
+            const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
+            const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
+            const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
+            for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
+                const float2 mm = sl < 4 ? m[sl & 3] : dp.match_uv[h.match_base + (size_t)sl * K + k];
+                if (mm.x != mm.x) continue;   // NaN: keypoint not in GetUordMatchedKptIds(pKFConv)
+                const double* rel = dp.slots[h.slot_base + sl].rel;
+                const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
+                const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
+                const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
+                const double ou = h.fx * p1x / p1z + h.cx;
+                const double ov = h.fy * p1y / p1z + h.cy;
+                if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
+                const double eu = ou - (double)mm.x, ev = ov - (double)mm.y;
+                const double dist = sqrt(eu * eu + ev * ev);
+                if (dist < prm.corr_3d_2d_threshold) { acc[P_SUM_3D2D] += dist; acc[P_VALID_3D2D] += 1.0; }
+                acc[P_CNT_3D2D] += 1.0;
             }
+            want3 = prm.use_3d3d && has_mp != 0.0f;
         }
-        // ordered (by keypoint id) compaction, so the summation order below is run-to-run stable
-        const unsigned long long bal = __ballot(want3);
-        if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (int w = 0; w < kWaves; ++w) { const uint32_t cw = s_wcnt[w]; total += cw; if (w < wave) before += cw; }
-        if (want3) s_list[n3 + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = k;
-        n3 += total;
-        __syncthreads();
+        ordered_append(want3, k, n3, s_list, s_wcnt);
     }
 
     IBA_STAMP(5);
-    // ---- phase 4b: 3d-3d (MapPoint -> LiDAR frame, 1-NN, local plane) ----
+    // ---- phase 4b: 3d-3d (MapPoint -> LiDAR frame, 1-NN with G lanes per query, memoised local plane) ----
     if (prm.use_3d3d) {
         const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
-        for (uint32_t i = tid; i < n3; i += kThreads) {
-            const uint32_t k = s_list[i];
-            const float4 mp = kp_mp[k];
-            const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;   // CV_32F product (:232)
-            const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
-            const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
-            const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
-            const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
-            const double qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
-            const double qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
-            const double qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
-            double best; uint32_t bpos;
-            nn_search(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
-            double dist = sqrt(best);   // (nn_pt - query_pt).norm()  (:122)
-            bool is_plane = false;
-            if (prm.use_plane) {
-                const PlaneRec rec = dp.plane_cost[h.pt_base + bpos];
-                if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
-                    !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
-                    const double ax = (double)c.xs[bpos] - qx, ay = (double)c.ys[bpos] - qy, az = (double)c.zs[bpos] - qz;
-                    dist = fabs(ax * rec.nx + ay * rec.ny + az * rec.nz);
-                    is_plane = true;
+        auto cost_3d3d = [&](auto GT) {
+            constexpr int G = decltype(GT)::value;
+            for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
+                const uint32_t k = s_list[i];
+                const float4 mp = kp_mp[k];
+                const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;   // CV_32F product (:232)
+                const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
+                const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
+                const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
+                const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
+                const double qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
+                const double qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
+                const double qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+                double best; uint32_t bpos;
+                nn_search_group<G>(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
+                if ((tid & (G - 1)) != 0) continue;
+                double dist = sqrt(best);   // (nn_pt - query_pt).norm()  (:122)
+                bool is_plane = false;
+                if (prm.use_plane) {
+                    const PlaneRec rec = dp.plane_cost[h.pt_base + bpos];
+                    if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
+                        !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
+                        const double ax = (double)c.xs[bpos] - qx, ay = (double)c.ys[bpos] - qy, az = (double)c.zs[bpos] - qz;
+                        dist = fabs(ax * rec.nx + ay * rec.ny + az * rec.nz);
+                        is_plane = true;
+                    }
                 }
+                if (dist < prm.corr_3d_3d_threshold) {
+                    acc[P_SUM_3D3D] += dist; acc[P_VALID_3D3D] += 1.0;
+                    if (is_plane) acc[P_VALID_PL] += 1.0; else acc[P_VALID_PT] += 1.0;
+                }
+                acc[P_CNT_3D3D] += 1.0;
             }
-            if (dist < prm.corr_3d_3d_threshold) {
-                acc[P_SUM_3D3D] += dist; acc[P_VALID_3D3D] += 1.0;
-                if (is_plane) acc[P_VALID_PL] += 1.0; else acc[P_VALID_PT] += 1.0;
-            }
-            acc[P_CNT_3D3D] += 1.0;
-        }
+        };
+        if (n3 * 8u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 8>());
+        else if (n3 * 4u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 4>());
+        else if (n3 * 2u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 2>());
+        else cost_3d3d(std::integral_constant<int, 1>());
     } else if (tid == 0) {   // iba_global.cpp:214-220
         acc[P_CNT_3D3D] = 1.0; acc[P_VALID_3D3D] = 1.0;
     }
@@ -649,26 +801,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     __syncthreads();
 #endif
     IBA_STAMP(6);
-    // ---- phase 4c: hand-eye term (iba_global.cpp:264-276) ----
-    if (tid == kThreads - 1 && h.he_valid) {
-        double C1R[9], C1t[3], C2R[9], C2t[3];
-        const double* Tl = h.Tl_next; const double* Tc = h.Tc_next;
-        for (int r = 0; r < 3; ++r) {
-            for (int cc = 0; cc < 3; ++cc) {
-                C1R[r * 3 + cc] = (cd.R[r * 3 + 0] * Tl[0 * 4 + cc] + cd.R[r * 3 + 1] * Tl[1 * 4 + cc]) + cd.R[r * 3 + 2] * Tl[2 * 4 + cc];
-                C2R[r * 3 + cc] = (Tc[r * 4 + 0] * cd.R[0 * 3 + cc] + Tc[r * 4 + 1] * cd.R[1 * 3 + cc]) + Tc[r * 4 + 2] * cd.R[2 * 3 + cc];
-            }
-            C1t[r] = ((cd.R[r * 3 + 0] * Tl[3] + cd.R[r * 3 + 1] * Tl[7]) + cd.R[r * 3 + 2] * Tl[11]) + cd.t[r];
-            C2t[r] = ((Tc[r * 4 + 0] * cd.t[0] + Tc[r * 4 + 1] * cd.t[1]) + Tc[r * 4 + 2] * cd.t[2]) + Tc[r * 4 + 3] * s;
-        }
-        double l1[6], l2[6];
-        dev_se3log(C1R, C1t, l1); dev_se3log(C2R, C2t, l2);
-        double ss = 0;
-        for (int i = 0; i < 6; ++i) ss += (l1[i] - l2[i]) * (l1[i] - l2[i]);
-        acc[P_HE_SUM] = sqrt(ss); acc[P_HE_CNT] = 1.0;
-    }
-
-    // ---- phase 5: reduction -> partial record ----
+    // ---- phase 5: fixed-order reduction -> partial record ----
     block_reduce<12>(acc, s_red);
     if (tid < kPartialStride) part[tid] = tid < 12 ? acc[tid] : 0.0;
 #ifdef IBA_STAMPS
