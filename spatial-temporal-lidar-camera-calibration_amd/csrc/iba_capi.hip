@@ -86,6 +86,7 @@ struct iba_handle {
     int ring_next = 0;
     std::vector<FrameHdr> h_frames;
     std::vector<uint64_t> h_kp_off;       // local frame -> kp offset (K+1)
+    std::vector<uint32_t> h_kp_ext;       // internal (Morton) keypoint id -> reference keypoint id
 
     DevProblem dev_problem() const {
         DevProblem dp{};
@@ -113,6 +114,7 @@ iba_status fail(iba_handle* h, iba_status s, const std::string& msg) { if (h) h-
 void to_dev_params(const iba_params& p, DevParams& d) {
     d.gate2 = p.max_pixel_dist * p.max_pixel_dist;
     d.grid_margin = p.max_pixel_dist + 0.01;
+    d.bitmap_margin = p.max_pixel_dist + 0.45;
     d.num_min_corr_cost = p.num_min_corr_cost;
     d.corr_3d_2d_threshold = p.corr_3d_2d_threshold; d.corr_3d_3d_threshold = p.corr_3d_3d_threshold;
     d.norm_max_pts = p.norm_max_pts; d.norm_min_pts = p.norm_min_pts;
@@ -125,8 +127,8 @@ void to_dev_params(const iba_params& p, DevParams& d) {
 }
 
 iba_status check_params(iba_handle* h, const iba_params& p) {
-    if (!(p.max_pixel_dist > 0) || 2.0 * (p.max_pixel_dist + 0.01) > (double)kGridCell)
-        return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist must be in (0, 1.99] px for the 4 px keypoint grid");
+    if (!(p.max_pixel_dist > 0) || p.max_pixel_dist > 64.0)
+        return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist must be in (0, 64] px");
     if (p.norm_max_pts < 1 || p.norm_max_pts > 32 || p.neigh_max_pts < 1 || p.neigh_max_pts > 32)
         return fail(h, IBA_ERR_UNSUPPORTED, "norm_max_pts / neigh_max_pts must be in [1, 32]");
     if (!p.plane_cache) return fail(h, IBA_ERR_UNSUPPORTED, "plane_cache = 0 (per-evaluation plane refit) is not implemented yet");
@@ -146,7 +148,7 @@ void parallel_for(int n, F fn) {
 uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
 bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
-    const uint32_t red_bytes = 8u * (kWaves + 1) * kRedSlots + 4u * kWaves + 16u;   // reduction slab + wave counts + misc
+    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;   // wave sums + covisible poses + wave counts + misc
     L.scan_stride = with_scan ? h->maxPpad : 0;
     uint32_t off = with_scan ? 12u * h->maxPpad : 0u;
     off = align_up(off, 16); L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
@@ -304,9 +306,11 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     }
 
     // ---- per-frame host build (parallel over frames; reference: omp parallel for at iba_global.cpp:363) ----
-    struct FrameBuild { std::vector<uint32_t> idx; std::vector<TreeNode> nodes; KpGrid grid; uint32_t D = 0; };
+    // keypoints are stored in Morton order of their pixel (internal id j -> reference id kp_order[j]): queries that
+    // share a wave then walk neighbouring kd-tree leaves (coherent LDS reads, less lane divergence)
+    struct FrameBuild { std::vector<uint32_t> idx; std::vector<TreeNode> nodes; KpGrid grid; uint32_t D = 0; std::vector<uint32_t> kp_order, kp_inv; std::vector<float> uv; };
     std::vector<FrameBuild> fb(nf);
-    const double margin = h->dprm.grid_margin;
+    const double margin = h->dprm.bitmap_margin;
     parallel_for(nf, [&](int lf) {
         const int f = frame_begin + lf;
         const uint32_t P = (uint32_t)(d->pt_offset[f + 1] - d->pt_offset[f]);
@@ -315,7 +319,17 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         b.D = tree_depth_for(P);
         build_tree(d->pts_xyz + 3 * d->pt_offset[f], P, b.D, b.idx, b.nodes);
         const double* in = d->intrinsics + 6 * f;
-        build_kp_grid(d->kp_uv + 2 * d->kp_offset[f], K, in[4], in[5], margin, b.grid);
+        auto part1by1 = [](uint32_t v) { v &= 0xFFFFu; v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
+        const float* uv0 = d->kp_uv + 2 * d->kp_offset[f];
+        std::vector<std::pair<uint32_t, uint32_t>> key(K);
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t qx = (uint32_t)std::min(65535.f, std::max(0.f, uv0[2 * k] * 8.f)), qy = (uint32_t)std::min(65535.f, std::max(0.f, uv0[2 * k + 1] * 8.f));
+            key[k] = {part1by1(qx) | (part1by1(qy) << 1), k};
+        }
+        std::sort(key.begin(), key.end());
+        b.kp_order.resize(K); b.kp_inv.resize(K); b.uv.resize(2 * (size_t)K);
+        for (uint32_t j = 0; j < K; ++j) { const uint32_t k = key[j].second; b.kp_order[j] = k; b.kp_inv[k] = j; b.uv[2 * j] = uv0[2 * k]; b.uv[2 * j + 1] = uv0[2 * k + 1]; }
+        build_kp_grid(b.uv.data(), K, in[4], in[5], margin, b.grid);
     });
 
     // ---- flatten ----
@@ -348,6 +362,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     std::vector<uint32_t> perm(pt_base, 0u), inv_perm(pt_base, 0u);
     std::vector<TreeNode> nodes(node_base);
     std::vector<float2> kp_uv(kp_base), cell_uv(kp_base); std::vector<float4> kp_mp(kp_base);
+    std::vector<uint32_t>& kp_ext = h->h_kp_ext; kp_ext.resize(kp_base);
     std::vector<uint32_t> cell_start(cell_base), cell_kp(kp_base), bitmap(bm_base);
     std::vector<float2> match_uv(match_base, float2{qnan, qnan});
     std::vector<SlotHdr> slots(slot_base);
@@ -362,10 +377,12 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         }
         std::copy(b.nodes.begin(), b.nodes.end(), nodes.begin() + x.node_base);
         const uint64_t k0 = d->kp_offset[f];
-        for (uint32_t k = 0; k < x.K; ++k) {
-            kp_uv[x.kp_base + k] = float2{d->kp_uv[2 * (k0 + k)], d->kp_uv[2 * (k0 + k) + 1]};
-            const bool has = d->kp_has_mappoint[k0 + k] != 0;
-            kp_mp[x.kp_base + k] = has ? float4{d->kp_mappoint_w[3 * (k0 + k)], d->kp_mappoint_w[3 * (k0 + k) + 1], d->kp_mappoint_w[3 * (k0 + k) + 2], 1.0f} : float4{0.f, 0.f, 0.f, 0.f};
+        for (uint32_t k = 0; k < x.K; ++k) {   // k = internal (Morton) id, e = reference id
+            const uint64_t e = k0 + b.kp_order[k];
+            kp_ext[x.kp_base + k] = b.kp_order[k];
+            kp_uv[x.kp_base + k] = float2{d->kp_uv[2 * e], d->kp_uv[2 * e + 1]};
+            const bool has = d->kp_has_mappoint[e] != 0;
+            kp_mp[x.kp_base + k] = has ? float4{d->kp_mappoint_w[3 * e], d->kp_mappoint_w[3 * e + 1], d->kp_mappoint_w[3 * e + 2], 1.0f} : float4{0.f, 0.f, 0.f, 0.f};
             cell_kp[x.kp_base + k] = b.grid.cell_kp[k];
             cell_uv[x.kp_base + k] = float2{b.grid.cell_uv[2 * k], b.grid.cell_uv[2 * k + 1]};
         }
@@ -380,7 +397,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
             for (uint64_t m = d->match_offset[gs]; m < d->match_offset[gs + 1]; ++m) {
                 const int kr = d->match_kp_ref[m], kc = d->match_kp_covis[m];
                 if (kr < 0 || (uint32_t)kr >= x.K || kc < 0 || (uint64_t)kc >= cK) { bad_match = true; continue; }
-                match_uv[x.match_base + (uint64_t)sl * x.K + kr] = float2{d->kp_uv[2 * (ck0 + kc)], d->kp_uv[2 * (ck0 + kc) + 1]};
+                match_uv[x.match_base + (uint64_t)sl * x.K + b.kp_inv[kr]] = float2{d->kp_uv[2 * (ck0 + kc)], d->kp_uv[2 * (ck0 + kc) + 1]};
             }
         }
     });
@@ -501,13 +518,23 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     std::vector<uint32_t> tmp(K);
     HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_corr.p + k0, sizeof(uint32_t) * K, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    int n = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;
     for (uint64_t k = 0; k < K; ++k)
-        if (tmp[k] != kNone) { if (n < cap && kp_idx && pt_idx) { kp_idx[n] = (uint32_t)k; pt_idx[n] = tmp[k]; } ++n; }
+        if (tmp[k] != kNone) pairs.emplace_back(h->h_kp_ext[k0 + k], tmp[k]);
+    std::sort(pairs.begin(), pairs.end());   // corrset is ordered by keypoint id (iba_global.cpp:85-95)
+    int n = 0;
+    for (auto const& pr : pairs) { if (n < cap && kp_idx && pt_idx) { kp_idx[n] = pr.first; pt_idx[n] = pr.second; } ++n; }
     *n_out = n;
     return IBA_OK;
 }
 
+#ifdef IBA_STAMPS
+extern "C" int iba_debug_counters(unsigned long long* out8, int reset) {
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(iba::g_dbg), 512);
+    if (reset) { unsigned long long z[64] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(iba::g_dbg), z, 512); }
+    return 0;
+}
+#endif
 // debug: host copy of the last summed partial blocks (B x iba_partial_stride() doubles)
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
     if (!h || !out || B < 1 || B > IBA_MAX_BATCH) return IBA_ERR_INVALID_ARG;

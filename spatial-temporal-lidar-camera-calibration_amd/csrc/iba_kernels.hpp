@@ -200,9 +200,8 @@ __device__ __forceinline__ void nn_search(const float* __restrict__ xs, const fl
     best = INFINITY; bpos = kNone;
     uint32_t node = 0, depth = 0;
     const uint32_t first_leaf = (1u << D) - 1u;
-    bool descend = true;
     for (;;) {
-        if (descend) {
+        {
             while (depth < D) {
                 const TreeNode n = nodes[node];
                 const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
@@ -217,17 +216,21 @@ __device__ __forceinline__ void nn_search(const float* __restrict__ xs, const fl
                 if (d2 < best) { best = d2; bpos = i; }
                 else if (d2 == best && bpos != kNone) { if (perm_g[i] < perm_g[bpos]) bpos = i; }
             }
-            descend = false;
         }
-        if (depth == 0) break;
-        const uint32_t parent = (node - 1u) >> 1;
-        const bool was_right = (node & 1u) == 0u;
-        const TreeNode n = nodes[parent];
-        const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
-        const double diff = qd - (double)n.split;
-        const bool near_right = diff >= 0.0;
-        if (was_right == near_right && diff * diff <= best) { node = 2u * parent + 1u + (near_right ? 0u : 1u); descend = true; }
-        else { node = parent; --depth; }
+        // climb in a tight loop until a far child can still hold a closer (or tying) point; lanes of a wave then
+        // re-converge once per leaf visit instead of once per tree level
+        bool go = false;
+        while (depth > 0) {
+            const uint32_t parent = (node - 1u) >> 1;
+            const bool was_right = (node & 1u) == 0u;
+            const TreeNode n = nodes[parent];
+            const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+            const double diff = qd - (double)n.split;
+            const bool near_right = diff >= 0.0;
+            if (was_right == near_right && diff * diff <= best) { node = 2u * parent + 1u + (near_right ? 0u : 1u); go = true; break; }
+            node = parent; --depth;
+        }
+        if (!go) break;
     }
 }
 
@@ -242,9 +245,8 @@ __device__ inline PlaneRec plane_fit_wave(const float* __restrict__ xs, const fl
     int count = 0; double bound = r2;
     uint32_t node = 0, depth = 0;
     const uint32_t first_leaf = (1u << D) - 1u;
-    bool descend = true;
     for (;;) {
-        if (descend) {
+        {
             while (depth < D) {
                 const TreeNode n = nodes[node];
                 const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
@@ -275,17 +277,19 @@ __device__ inline PlaneRec plane_fit_wave(const float* __restrict__ xs, const fl
                     }
                 }
             }
-            descend = false;
         }
-        if (depth == 0) break;
-        const uint32_t parent = (node - 1u) >> 1;
-        const bool was_right = (node & 1u) == 0u;
-        const TreeNode n = nodes[parent];
-        const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
-        const double diff = qd - (double)n.split;
-        const bool near_right = diff >= 0.0;
-        if (was_right == near_right && diff * diff < bound) { node = 2u * parent + 1u + (near_right ? 0u : 1u); descend = true; }
-        else { node = parent; --depth; }
+        bool go = false;
+        while (depth > 0) {
+            const uint32_t parent = (node - 1u) >> 1;
+            const bool was_right = (node & 1u) == 0u;
+            const TreeNode n = nodes[parent];
+            const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+            const double diff = qd - (double)n.split;
+            const bool near_right = diff >= 0.0;
+            if (was_right == near_right && diff * diff < bound) { node = 2u * parent + 1u + (near_right ? 0u : 1u); go = true; break; }
+            node = parent; --depth;
+        }
+        if (!go) break;
     }
     PlaneRec rec;
     rec.k = count; rec.pad = 0;
@@ -403,7 +407,34 @@ __device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v
     return hit;
 }
 
+// PASS-1 variant that also remembers up to two (keypoint, d^2) hits of this point in registers, so that the tie
+// pass needs no second grid walk. Returns the number of hits (a third hit is counted but not stored).
+__device__ __forceinline__ int grid_match_rec(const FrameCtx& c, double u, double v, uint32_t& k0, unsigned long long& d0, uint32_t& k1, unsigned long long& d1) {
+    const float uf = (float)u, vf = (float)v;
+    const int x0 = grid_cell(uf - c.margin, c.gw), x1 = grid_cell(uf + c.margin, c.gw);
+    const int y0 = grid_cell(vf - c.margin, c.gh), y1 = grid_cell(vf + c.margin, c.gh);
+    int nh = 0;
+    for (int yy = y0; yy <= y1; ++yy) {
+        const uint32_t e0 = c.cell_start[yy * c.gw + x0], e1 = c.cell_start[yy * c.gw + x1 + 1];
+        for (uint32_t e = e0; e < e1; ++e) {
+            const float2 kuv = c.cell_uv[e];
+            const double du = (double)kuv.x - u, dv = (double)kuv.y - v;
+            const double d2 = du * du + dv * dv;
+            if (d2 <= c.gate2) {
+                const uint32_t k = c.cell_kp[e];
+                atomicMin(&c.best_d2[k], d2bits(d2));
+                if (nh == 0) { k0 = k; d0 = d2bits(d2); } else if (nh == 1) { k1 = k; d1 = d2bits(d2); }
+                ++nh;
+            }
+        }
+    }
+    return nh;
+}
+
 // ---- exact 1-NN with G lanes per query (G = 1,2,4,8): the G lanes walk the tree in lockstep and split each leaf ----
+#ifdef IBA_STAMPS
+__device__ unsigned long long g_dbg[64];
+#endif
 template <int G>
 __device__ __forceinline__ void nn_search_group(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
                                                 const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
@@ -413,9 +444,8 @@ __device__ __forceinline__ void nn_search_group(const float* __restrict__ xs, co
     best = INFINITY; bpos = kNone;
     uint32_t node = 0, depth = 0;
     const uint32_t first_leaf = (1u << D) - 1u;
-    bool descend = true;
     for (;;) {
-        if (descend) {
+        {
             while (depth < D) {
                 const TreeNode n = nodes[node];
                 const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
@@ -424,6 +454,7 @@ __device__ __forceinline__ void nn_search_group(const float* __restrict__ xs, co
             }
             const uint32_t j = node - first_leaf;
             const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+#pragma unroll 2
             for (uint32_t i = lo + sub; i < hi; i += G) {
                 const double dx = qx - (double)xs[i], dy = qy - (double)ys[i], dz = qz - (double)zs[i];
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
@@ -436,17 +467,21 @@ __device__ __forceinline__ void nn_search_group(const float* __restrict__ xs, co
                 if (od < best) { best = od; bpos = op; }
                 else if (od == best && op != kNone && op != bpos) { if (bpos == kNone || perm_g[op] < perm_g[bpos]) bpos = op; }
             }
-            descend = false;
         }
-        if (depth == 0) break;
-        const uint32_t parent = (node - 1u) >> 1;
-        const bool was_right = (node & 1u) == 0u;
-        const TreeNode n = nodes[parent];
-        const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
-        const double diff = qd - (double)n.split;
-        const bool near_right = diff >= 0.0;
-        if (was_right == near_right && diff * diff <= best) { node = 2u * parent + 1u + (near_right ? 0u : 1u); descend = true; }
-        else { node = parent; --depth; }
+        // climb in a tight loop until a far child can still hold a closer (or tying) point; lanes of a wave then
+        // re-converge once per leaf visit instead of once per tree level
+        bool go = false;
+        while (depth > 0) {
+            const uint32_t parent = (node - 1u) >> 1;
+            const bool was_right = (node & 1u) == 0u;
+            const TreeNode n = nodes[parent];
+            const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+            const double diff = qd - (double)n.split;
+            const bool near_right = diff >= 0.0;
+            if (was_right == near_right && diff * diff <= best) { node = 2u * parent + 1u + (near_right ? 0u : 1u); go = true; break; }
+            node = parent; --depth;
+        }
+        if (!go) break;
     }
 }
 
@@ -500,6 +535,38 @@ __device__ __forceinline__ void ordered_append(bool want, uint32_t k, uint32_t& 
     __syncthreads();
 }
 
+// ---- wave64 sum on the VALU (DPP row shifts + row broadcasts, no LDS traffic); total lands in lane 63 ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long b) {
+    int lo = (int)(unsigned int)b, hi = (int)(unsigned int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x) { return __longlong_as_double((long long)dpp_u64<CTRL, ROW_MASK>((unsigned long long)__double_as_longlong(x))); }
+__device__ __forceinline__ double wave_sum_f64(double x) {   // fixed association order => bitwise reproducible
+    x += dpp_f64<0x111, 0xf>(x); x += dpp_f64<0x112, 0xf>(x); x += dpp_f64<0x114, 0xf>(x); x += dpp_f64<0x118, 0xf>(x);   // row_shr 1,2,4,8
+    x += dpp_f64<0x142, 0xa>(x);   // row_bcast:15 -> rows 1,3
+    x += dpp_f64<0x143, 0xc>(x);   // row_bcast:31 -> rows 2,3
+    return x;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x) {
+    x += dpp_u64<0x111, 0xf>(x); x += dpp_u64<0x112, 0xf>(x); x += dpp_u64<0x114, 0xf>(x); x += dpp_u64<0x118, 0xf>(x);
+    x += dpp_u64<0x142, 0xa>(x); x += dpp_u64<0x143, 0xc>(x);
+    return x;
+}
+// number of set flags in the block, known to every thread (one ballot per wave + 16 LDS words)
+__device__ __forceinline__ uint32_t block_count(uint32_t my_count_wave_uniform, uint32_t* s_wcnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_wcnt[wave] = my_count_wave_uniform;
+    __syncthreads();
+    uint32_t total = 0;
+    for (int w = 0; w < kWaves; ++w) total += s_wcnt[w];
+    __syncthreads();
+    return total;
+}
+
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so
 // all candidates of one frame share that XCD's L2 copy of the scan.
 template <int MODE, bool SCAN_LDS>
@@ -508,7 +575,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                                                              uint2* __restrict__ assoc_out, int nrec, const double* __restrict__ he) {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef typename std::conditional<SCAN_LDS, uint16_t, uint32_t>::type CandT;   // LDS mode implies P < 65536
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = dp.n_frames;
     const int per_xcd = (nf + 7) / 8;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -523,8 +590,9 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     uint32_t* s_best_idx = (uint32_t*)(smem + lay.off_best_idx);
     TreeNode* s_nodes = (TreeNode*)(smem + lay.off_nodes);
     uint32_t* s_bitmap = (uint32_t*)(smem + lay.off_bitmap);
-    double* s_red = (double*)(smem + lay.off_red);
-    uint32_t* s_wcnt = (uint32_t*)(s_red + (kWaves + 1) * kRedSlots);
+    double* s_red = (double*)(smem + lay.off_red);            // kWaves * 4 doubles / u64
+    double* s_rel = s_red + kWaves * 4;                       // kMaxCovis * 12 doubles: relative poses of the covisible KFs
+    uint32_t* s_wcnt = (uint32_t*)(s_rel + kMaxCovis * 12);
     uint32_t* s_misc = s_wcnt + kWaves;                       // [0] candidate count, [1] overflow flag
     CandT* s_cand = (CandT*)(smem + lay.off_cand);
     uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 after phase 2
@@ -542,6 +610,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     for (uint32_t i = tid; i < nnodes; i += kThreads) s_nodes[i] = dp.nodes[h.node_base + i];
     const uint32_t nbw = (h.gw * h.gh + 31u) >> 5;
     for (uint32_t i = tid; i < nbw; i += kThreads) s_bitmap[i] = dp.bitmap[h.bitmap_base + i];
+    if ((uint32_t)tid < h.n_slots * 12u) s_rel[tid] = dp.slots[h.slot_base + tid / 12].rel[tid % 12];
     if (tid < 2) s_misc[tid] = 0u;
     __syncthreads();
 
@@ -558,14 +627,21 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     for (int i = 0; i < 3; ++i) c.t[i] = cd.t[i];
 
     IBA_STAMP(1);
-    // ---- phase 1a: stream the scan once (16 B/lane), keep it in LDS, project, cull, 1-bit keypoint test.
-    //      Survivors (~1 in 5) are queued in LDS so that the grid lookups below run with dense lanes.
+    // ---- phase 1a: stream the scan once (16 B/lane), keep it in LDS, and PRE-CULL in float32:
+    //      a point can only matter if it may project within ~1.5 px of a keypoint. The f32 projection errs by
+    //      < 0.3 px for depth > 0.1 m; the reject bitmap is dilated by max_pixel_dist + 0.45 px, so a clear bit
+    //      proves that the exact (f64) test could not produce a match. Everything that survives (~6 %) — and
+    //      everything the f32 test cannot decide (|depth| <= 0.1 m) — is queued for the exact f64 path below.
     const uint32_t cand_cap = lay.cand_cap;
     {
+        const float r0 = (float)c.R[0], r1 = (float)c.R[1], r2 = (float)c.R[2], r3 = (float)c.R[3], r4 = (float)c.R[4], r5 = (float)c.R[5],
+                    r6 = (float)c.R[6], r7 = (float)c.R[7], r8 = (float)c.R[8], t0 = (float)c.t[0], t1 = (float)c.t[1], t2 = (float)c.t[2];
+        const float fxf = (float)c.fx, cxf = (float)c.cx, cyf = (float)c.cy, Wf = (float)c.W + 1.0f, Hf = (float)c.H + 1.0f;
         const uint32_t n_iter = (Ppad + kThreads * 4u - 1u) / (kThreads * 4u);
         for (uint32_t it = 0; it < n_iter; ++it) {
             const uint32_t base = (uint32_t)tid * 4u + it * (kThreads * 4u);
-            float px[4] = {0.f, 0.f, 0.f, 0.f}, py[4] = {0.f, 0.f, 0.f, 0.f}, pz[4] = {-1.f, -1.f, -1.f, -1.f};
+            const float qn = __builtin_nanf("");
+            float px[4] = {qn, qn, qn, qn}, py[4] = {qn, qn, qn, qn}, pz[4] = {qn, qn, qn, qn};
             if (base < Ppad) {
                 const float4 X = *(const float4*)(gxs + base), Y = *(const float4*)(gys + base), Z = *(const float4*)(gzs + base);
                 if (SCAN_LDS) { *(float4*)(s_xs + base) = X; *(float4*)(s_ys + base) = Y; *(float4*)(s_zs + base) = Z; }
@@ -574,8 +650,18 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                double u = 0, v = 0;
-                const bool pass = base < Ppad && project_uv(c, px[j], py[j], pz[j], u, v) && near_keypoint(c, u, v);
+                const float zc = fmaf(r6, px[j], fmaf(r7, py[j], fmaf(r8, pz[j], t2)));
+                bool pass = false;
+                if (zc > 0.1f) {
+                    const float xc = fmaf(r0, px[j], fmaf(r1, py[j], fmaf(r2, pz[j], t0)));
+                    const float yc = fmaf(r3, px[j], fmaf(r4, py[j], fmaf(r5, pz[j], t1)));
+                    const float rz = __builtin_amdgcn_rcpf(zc);
+                    const float uf = fmaf(fxf * xc, rz, cxf), vf = fmaf(fxf * yc, rz, cyf);
+                    if (uf > -1.0f && uf < Wf && vf > -1.0f && vf < Hf) {
+                        const uint32_t cell = (uint32_t)grid_cell(vf, c.gh) * (uint32_t)c.gw + (uint32_t)grid_cell(uf, c.gw);
+                        pass = (s_bitmap[cell >> 5] >> (cell & 31)) & 1u;
+                    }
+                } else if (zc > -0.1f) pass = true;   // undecidable in f32: let the exact path decide
                 const unsigned long long bal = __ballot(pass);
                 if (bal) {
                     uint32_t wb = 0;
@@ -584,43 +670,70 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                     if (pass) {
                         const uint32_t idx = wb + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                         if (idx < cand_cap) s_cand[idx] = (CandT)(base + j);
-                        else { grid_match<1>(c, u, v, base + j); s_misc[1] = 1u; }   // queue full: match inline, rescan in phase 2
+                        else {   // queue full: exact path inline, full rescan in phase 2 (speed only)
+                            double u, v;
+                            if (project_uv(c, px[j], py[j], pz[j], u, v)) grid_match<1>(c, u, v, base + j);
+                            s_misc[1] = 1u;
+                        }
                     }
                 }
             }
         }
     }
     __syncthreads();
-    // ---- phase 1b: queued points visit the keypoint grid; ds_min_u64 on the keypoint's best d^2 ----
+    // ---- phase 1b: exact f64 projection + FOV test of the queued points, keypoint grid lookup,
+    //      ds_min_u64 on the keypoint's best d^2 ----
     const uint32_t ncand = min(s_misc[0], cand_cap);
+#ifdef IBA_STAMPS
+    if (tid == 0) { atomicAdd(&g_dbg[1], (unsigned long long)s_misc[0]); atomicAdd(&g_dbg[2], 1ull); }
+#endif
     const bool overflow = s_misc[1] != 0u;
-    uint32_t hitbits = 0u;
-    {
-        int it = 0;
-        for (uint32_t i = tid; i < ncand; i += kThreads, ++it) {
+    constexpr int kRec = 4;   // queue iterations whose hits are kept in registers
+    uint32_t hk[kRec][2]; unsigned long long hd[kRec][2]; int hn[kRec];
+    bool redo = false;
+#pragma unroll
+    for (int it = 0; it < kRec; ++it) {
+        hn[it] = 0;
+        const uint32_t i = (uint32_t)tid + (uint32_t)it * kThreads;
+        if (i < ncand) {
             const uint32_t pos = (uint32_t)s_cand[i];
             double u, v;
-            project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v);
-            if (grid_match<1>(c, u, v, pos)) hitbits |= 1u << (it & 31);
+            if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) hn[it] = grid_match_rec(c, u, v, hk[it][0], hd[it][0], hk[it][1], hd[it][1]);
+            redo |= hn[it] > 2;
         }
+    }
+    for (uint32_t i = (uint32_t)tid + kRec * kThreads; i < ncand; i += kThreads) {   // very long queues: no register record
+        const uint32_t pos = (uint32_t)s_cand[i];
+        double u, v;
+        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) redo |= grid_match<1>(c, u, v, pos);
     }
     __syncthreads();
     IBA_STAMP(2);
-    // ---- phase 2: exact tie resolution (lowest original index) for the points that hit ----
-    {
-        int it = 0;
-        for (uint32_t i = tid; i < ncand; i += kThreads, ++it) {
-            if (!((hitbits >> (it & 31)) & 1u) && it < 32) continue;
+    // ---- phase 2: the winner of each keypoint records its original index; exact ties -> lowest index ----
+#pragma unroll
+    for (int it = 0; it < kRec; ++it) {
+        if (hn[it] > 0) {
+            const uint32_t pos = (uint32_t)s_cand[(uint32_t)tid + (uint32_t)it * kThreads];
+            const bool w0 = s_best_d2[hk[it][0]] == hd[it][0];
+            const bool w1 = hn[it] > 1 && s_best_d2[hk[it][1]] == hd[it][1];
+            if (w0 || w1) {
+                const uint32_t orig = c.perm[pos];
+                if (w0) atomicMin(&s_best_idx[hk[it][0]], orig);
+                if (w1) atomicMin(&s_best_idx[hk[it][1]], orig);
+            }
+        }
+    }
+    if (redo) {   // rare: a point within reach of > 2 keypoints, or an over-long queue: walk the grid again
+        for (uint32_t i = tid; i < ncand; i += kThreads) {
             const uint32_t pos = (uint32_t)s_cand[i];
             double u, v;
-            project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v);
-            grid_match<2>(c, u, v, pos);
+            if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) grid_match<2>(c, u, v, pos);
         }
-        if (overflow) {
-            for (uint32_t pos = tid; pos < P; pos += kThreads) {
-                double u, v;
-                if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v) && near_keypoint(c, u, v)) grid_match<2>(c, u, v, pos);
-            }
+    }
+    if (overflow) {
+        for (uint32_t pos = tid; pos < P; pos += kThreads) {
+            double u, v;
+            if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) grid_match<2>(c, u, v, pos);
         }
     }
     __syncthreads();
@@ -637,14 +750,19 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     const double s = cd.s;
     uint32_t n3 = 0;   // wave-uniform running length of s_list
 
+    // ---- phase 3: corrset.size() ----
+    uint32_t n_corr;
+    {
+        uint32_t wc = 0;
+        for (uint32_t k = tid; k < Kceil; k += kThreads) wc += (uint32_t)__popcll(__ballot(k < K && s_best_idx[k] != kNone));
+        n_corr = block_count(wc, s_wcnt);
+    }
+
     if (MODE == MODE_ASSOC) {
         // ---- BuildProblem association (iba_local.cpp:145-323): which residual blocks exist at this x ----
         uint2* arow = assoc_out + (size_t)b * dp.n_kp_total + h.kp_base;
-        double cnt[1] = {0};
-        for (uint32_t k = tid; k < K; k += kThreads) cnt[0] += (s_best_idx[k] != kNone) ? 1.0 : 0.0;
-        block_reduce<1>(cnt, s_red);
-        const bool used = !(cnt[0] < (double)prm.num_min_corr);   // iba_local.cpp:192
-        if (tid < kPartialStride) part[tid] = (used && tid == P_FRAMES_N) ? 1.0 : ((used && tid == P_NCORR_N) ? cnt[0] : 0.0);
+        const bool used = !((int)n_corr < prm.num_min_corr);   // iba_local.cpp:192
+        if (tid < kPartialStride) part[tid] = (used && tid == P_FRAMES_N) ? 1.0 : ((used && tid == P_NCORR_N) ? (double)n_corr : 0.0);
         const PlaneRec* planes = dp.plane_local + h.pt_base;
         for (uint32_t k = tid; k < Kceil; k += kThreads) {
             bool want3 = false;
@@ -698,65 +816,67 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         return;
     }
 
-    // ---- phase 3: corrset.size() ----
-    double acc[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = 0;
-    {
-        double cnt[1] = {0};
-        for (uint32_t k = tid; k < K; k += kThreads) cnt[0] += (s_best_idx[k] != kNone) ? 1.0 : 0.0;
-        block_reduce<1>(cnt, s_red);
-        if (cnt[0] < (double)prm.num_min_corr_cost) {   // iba_global.cpp:203: frame skipped entirely
-            if (tid < kPartialStride) part[tid] = 0.0;
-            return;
-        }
-        if (tid == 0) {
-            acc[P_FRAMES] = 1.0; acc[P_NCORR] = cnt[0];
-            if (h.he_valid) { acc[P_HE_SUM] = he[(size_t)b * nf + f]; acc[P_HE_CNT] = 1.0; }   // K7 (iba_he_kernel)
-        }
+    if ((int)n_corr < prm.num_min_corr_cost) {   // iba_global.cpp:203: frame skipped entirely
+        if (tid < kPartialStride) part[tid] = 0.0;
+        return;
     }
 
     IBA_STAMP(4);
-    // ---- phase 4a: 3d-2d residuals (iba_global.cpp:291-328) + ordered compaction of the 3d-3d work list ----
+    // ---- phase 4: compaction of the 3d-3d work list first (the only barriers), then all the arithmetic ----
     for (uint32_t k = tid; k < Kceil; k += kThreads) {
-        bool want3 = false;
-        const uint32_t orig = k < K ? s_best_idx[k] : kNone;
-        if (orig != kNone) {
-            const uint32_t pos = inv_perm[orig];
-            const float has_mp = kp_mp[k].w;
-            float2 m[4];
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) m[sl] = (uint32_t)sl < h.n_slots ? dp.match_uv[h.match_base + (size_t)sl * K + k] : make_float2(__builtin_nanf(""), 0.f);
-            const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
-            const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
-            const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
-            const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
-            for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
-                const float2 mm = sl < 4 ? m[sl & 3] : dp.match_uv[h.match_base + (size_t)sl * K + k];
-                if (mm.x != mm.x) continue;   // NaN: keypoint not in GetUordMatchedKptIds(pKFConv)
-                const double* rel = dp.slots[h.slot_base + sl].rel;
-                const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
-                const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
-                const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
-                const double ou = h.fx * p1x / p1z + h.cx;
-                const double ov = h.fy * p1y / p1z + h.cy;
-                if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
-                const double eu = ou - (double)mm.x, ev = ov - (double)mm.y;
-                const double dist = sqrt(eu * eu + ev * ev);
-                if (dist < prm.corr_3d_2d_threshold) { acc[P_SUM_3D2D] += dist; acc[P_VALID_3D2D] += 1.0; }
-                acc[P_CNT_3D2D] += 1.0;
-            }
-            want3 = prm.use_3d3d && has_mp != 0.0f;
-        }
+        const bool want3 = prm.use_3d3d && k < K && s_best_idx[k] != kNone && kp_mp[k].w != 0.0f;
         ordered_append(want3, k, n3, s_list, s_wcnt);
     }
+    double sum2d = 0.0, sum3d = 0.0;
+    uint32_t c2 = 0, v2 = 0, c3 = 0, v3 = 0, vpl = 0, vpt = 0;
+    // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328)
+    for (uint32_t k = tid; k < K; k += kThreads) {
+        const uint32_t orig = s_best_idx[k];
+        if (orig == kNone) continue;
+        float2 m[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) m[sl] = (uint32_t)sl < h.n_slots ? dp.match_uv[h.match_base + (size_t)sl * K + k] : make_float2(__builtin_nanf(""), 0.f);
+        bool any = false;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) any |= (m[sl].x == m[sl].x);
+        if (!any && h.n_slots <= 4) continue;
+        const uint32_t pos = inv_perm[orig];
+        const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
+        const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
+        const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
+        const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
+        for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
+            const float2 mm = sl < 4 ? m[sl & 3] : dp.match_uv[h.match_base + (size_t)sl * K + k];
+            if (mm.x != mm.x) continue;   // NaN: keypoint not in GetUordMatchedKptIds(pKFConv)
+            const double* rel = s_rel + sl * 12;
+            const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
+            const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
+            const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
+            const double ou = h.fx * p1x / p1z + h.cx;
+            const double ov = h.fy * p1y / p1z + h.cy;
+            if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
+            const double eu = ou - (double)mm.x, ev = ov - (double)mm.y;
+            const double dist = sqrt(eu * eu + ev * ev);
+            if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
+            ++c2;
+        }
+    }
 
+#ifdef IBA_STAMPS
+    __syncthreads();
+#endif
     IBA_STAMP(5);
-    // ---- phase 4b: 3d-3d (MapPoint -> LiDAR frame, 1-NN with G lanes per query, memoised local plane) ----
+    // K4+K5: 3d-3d (MapPoint -> LiDAR frame, 1-NN with G lanes per query, memoised local plane)
+#ifdef IBA_STAMPS
+    const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
     if (prm.use_3d3d) {
         const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
         auto cost_3d3d = [&](auto GT) {
             constexpr int G = decltype(GT)::value;
+#ifdef IBA_STAMPS
+            unsigned long long tt0 = __builtin_readcyclecounter(), tt1, tpre = 0, tsearch = 0, tpost = 0;
+#endif
             for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
                 const uint32_t k = s_list[i];
                 const float4 mp = kp_mp[k];
@@ -768,12 +888,26 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                 const double qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
                 const double qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
                 const double qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+#ifdef IBA_STAMPS
+                tt1 = __builtin_readcyclecounter(); tpre += tt1 - tt0; tt0 = tt1;
+#endif
                 double best; uint32_t bpos;
+#if defined(IBA_EXP) && IBA_EXP == 1
+                best = qx * qx; bpos = (uint32_t)(fabs(qy) * 10.0) % P;
+#else
                 nn_search_group<G>(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
+#endif
+#ifdef IBA_STAMPS
+                tt1 = __builtin_readcyclecounter(); tsearch += tt1 - tt0; tt0 = tt1;
+#endif
                 if ((tid & (G - 1)) != 0) continue;
                 double dist = sqrt(best);   // (nn_pt - query_pt).norm()  (:122)
                 bool is_plane = false;
+#if defined(IBA_EXP) && IBA_EXP == 2
+                if (false) {
+#else
                 if (prm.use_plane) {
+#endif
                     const PlaneRec rec = dp.plane_cost[h.pt_base + bpos];
                     if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
                         !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
@@ -782,28 +916,56 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                         is_plane = true;
                     }
                 }
-                if (dist < prm.corr_3d_3d_threshold) {
-                    acc[P_SUM_3D3D] += dist; acc[P_VALID_3D3D] += 1.0;
-                    if (is_plane) acc[P_VALID_PL] += 1.0; else acc[P_VALID_PT] += 1.0;
-                }
-                acc[P_CNT_3D3D] += 1.0;
+                if (dist < prm.corr_3d_3d_threshold) { sum3d += dist; ++v3; if (is_plane) ++vpl; else ++vpt; }
+                ++c3;
+#ifdef IBA_STAMPS
+                tt1 = __builtin_readcyclecounter(); tpost += tt1 - tt0; tt0 = tt1;
+#endif
             }
+#ifdef IBA_STAMPS
+            if (lane == 0) { atomicAdd(&g_dbg[8 + wave], tsearch); atomicAdd(&g_dbg[24 + wave], tpre); atomicAdd(&g_dbg[40 + wave], tpost); }
+#endif
         };
+#ifdef IBA_STAMPS
+        if (tid == 0) atomicAdd(&g_dbg[3], (unsigned long long)n3);
+#endif
         if (n3 * 8u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 8>());
         else if (n3 * 4u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 4>());
         else if (n3 * 2u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 2>());
         else cost_3d3d(std::integral_constant<int, 1>());
-    } else if (tid == 0) {   // iba_global.cpp:214-220
-        acc[P_CNT_3D3D] = 1.0; acc[P_VALID_3D3D] = 1.0;
     }
 
 #ifdef IBA_STAMPS
     __syncthreads();
 #endif
     IBA_STAMP(6);
-    // ---- phase 5: fixed-order reduction -> partial record ----
-    block_reduce<12>(acc, s_red);
-    if (tid < kPartialStride) part[tid] = tid < 12 ? acc[tid] : 0.0;
+    // ---- phase 5 (K8): two double sums + six exact integer counters packed 21 bits each; DPP wave sums, then the
+    //      16 waves in fixed order. No atomics => bitwise reproducible.
+    {
+        const double w2d = wave_sum_f64(sum2d), w3d = wave_sum_f64(sum3d);
+        const unsigned long long wa = wave_sum_u64((unsigned long long)c2 | ((unsigned long long)v2 << 21) | ((unsigned long long)c3 << 42));
+        const unsigned long long wb = wave_sum_u64((unsigned long long)v3 | ((unsigned long long)vpl << 21) | ((unsigned long long)vpt << 42));
+        unsigned long long* s_redu = (unsigned long long*)s_red;
+        if (lane == 63) { s_red[wave * 4 + 0] = w2d; s_red[wave * 4 + 1] = w3d; s_redu[wave * 4 + 2] = wa; s_redu[wave * 4 + 3] = wb; }
+        __syncthreads();
+        if (tid < kPartialStride) {
+            double out = 0.0;
+            if (tid == P_SUM_3D2D || tid == P_SUM_3D3D) { for (int w = 0; w < kWaves; ++w) out += s_red[w * 4 + (tid == P_SUM_3D2D ? 0 : 1)]; }
+            else if (tid >= P_CNT_3D2D && tid <= P_VALID_PT) {
+                unsigned long long a = 0, bb = 0;
+                for (int w = 0; w < kWaves; ++w) { a += s_redu[w * 4 + 2]; bb += s_redu[w * 4 + 3]; }
+                const unsigned long long msk = (1ull << 21) - 1ull;
+                const unsigned long long vals[6] = {a & msk, (a >> 21) & msk, (a >> 42) & msk, bb & msk, (bb >> 21) & msk, (bb >> 42) & msk};
+                out = (double)vals[tid - P_CNT_3D2D];
+                if (!prm.use_3d3d && (tid == P_CNT_3D3D || tid == P_VALID_3D3D)) out = 1.0;   // iba_global.cpp:214-220
+            }
+            else if (tid == P_FRAMES) out = 1.0;
+            else if (tid == P_NCORR) out = (double)n_corr;
+            else if (tid == P_HE_SUM) out = h.he_valid ? he[(size_t)b * nf + f] : 0.0;   // K7 (iba_he_kernel)
+            else if (tid == P_HE_CNT) out = h.he_valid ? 1.0 : 0.0;
+            part[tid] = out;
+        }
+    }
 #ifdef IBA_STAMPS
     __syncthreads();
     if (tid == 0) { const unsigned long long te = __builtin_readcyclecounter(); for (int i = 0; i < 7; ++i) part[56 + i] = (double)((i < 6 ? stamp_t[i + 1] : te) - stamp_t[i]); }

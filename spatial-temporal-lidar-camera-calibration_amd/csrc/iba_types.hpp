@@ -81,7 +81,8 @@ struct Cand {
 
 struct DevParams {
     double gate2;                 // max_pixel_dist^2
-    double grid_margin;           // max_pixel_dist + 0.01
+    double grid_margin;           // max_pixel_dist + 0.01  (exact f64 lookups)
+    double bitmap_margin;         // max_pixel_dist + 0.45  (f32 pre-cull bitmap)
     int32_t num_min_corr_cost;
     double corr_3d_2d_threshold, corr_3d_3d_threshold;
     int32_t norm_max_pts, norm_min_pts;
