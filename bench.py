@@ -78,14 +78,11 @@ def main():
     def step(i):
         xs = xs_all[i % len(xs_all)]
         st = torch.cuda.current_stream().cuda_stream
-        h.eval_cost_partial(xs, d_cost.data_ptr(), st)
-        h.eval_normal_partial(xs, d_norm.data_ptr(), st)
-        if world > 1:   # frames shard across ranks: one sum all-reduce of the partial blocks (RCCL over xGMI)
+        h.eval_full_partial(xs, d_cost.data_ptr(), st)   # cost tuple + normal equations from one pass over the scans
+        if world > 1:   # frames shard across ranks: ONE sum all-reduce of the partial blocks (RCCL over xGMI)
             dist.all_reduce(d_cost)
-            dist.all_reduce(d_norm)
         pc = d_cost.cpu().numpy()
-        pn = d_norm.cpu().numpy()
-        return pkg.finalize_cost(params, pc), pkg.finalize_normal(params, pn)
+        return pkg.finalize_cost(params, pc), pkg.finalize_normal(params, pc)
 
     def sync():
         if world > 1:
@@ -106,11 +103,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- dominant kernel (cost-path frame kernel), timed with HIP events on its launch stream ----
+    # ---- dominant kernel (fused frame kernel), timed with HIP events on its launch stream ----
     xs = xs_all[0]
     kms = []
     for _ in range(5):
-        h.eval_cost_partial(xs, d_cost.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        h.eval_full_partial(xs, d_cost.data_ptr(), torch.cuda.current_stream().cuda_stream)
         kms.append(h.last_kernel_ms()[0])
     torch.cuda.synchronize()
     frame_ms = float(np.median(kms))
@@ -147,7 +144,7 @@ def main():
             "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of %d doubles per call" % (world, B * stride),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "iba_frame_kernel<MODE_COST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "iba_frame_kernel<MODE_BOTH>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_eval": per_eval, "evals_per_launch": B, "launch_ms": frame_ms,
         },

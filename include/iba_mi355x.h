@@ -185,6 +185,11 @@ iba_status iba_eval_bbo(iba_handle* h, const double* x, int32_t B, double he_thr
  * association + residuals + Jacobians + normal equations, B candidates per call. */
 iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal_out* out);
 
+/* BAError tuple AND the re-associated normal equations of the same B candidates from one pass over the scans
+ * (the two paths share projection + 2d-3d association). Results are identical to calling iba_eval_cost and
+ * iba_eval_normal separately. */
+iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal);
+
 /* The two halves separately, as Ceres uses them (iba_local.cpp:443-445): freeze the association
  * at x_assoc, then evaluate the frozen residual blocks at B other x. */
 iba_status iba_build_problem(iba_handle* h, const double* x_assoc);
@@ -211,6 +216,8 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
 int32_t iba_partial_stride(void);
 iba_status iba_eval_cost_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream);
 iba_status iba_eval_normal_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream);
+/* cost and normal sums share one block (disjoint slots): finalize the summed block with BOTH iba_finalize_* */
+iba_status iba_eval_full_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream);
 iba_status iba_finalize_cost(const iba_params* params, const double* partials, int32_t B, iba_cost_out* out);
 iba_status iba_finalize_normal(const iba_params* params, const double* partials, int32_t B, iba_normal_out* out);
 

@@ -59,6 +59,7 @@ def load_library():
         L.iba_num_keypoints.argtypes = [C.c_void_p]
         L.iba_eval_cost_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.iba_eval_normal_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.iba_eval_full_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -158,6 +159,14 @@ class IbaHandle:
         self._chk(self.lib.iba_eval_normal(self.h, _p(x), C.c_int32(B), out))
         return list(out)
 
+    def eval_full(self, x):
+        x = self._x(x)
+        B = len(x)
+        cost = (IbaCostOut * B)()
+        nrm = (IbaNormalOut * B)()
+        self._chk(self.lib.iba_eval_full(self.h, _p(x), C.c_int32(B), cost, nrm))
+        return list(cost), list(nrm)
+
     def build_problem(self, x):
         x = np.ascontiguousarray(x, np.float64)
         self._chk(self.lib.iba_build_problem(self.h, _p(x)))
@@ -205,6 +214,10 @@ class IbaHandle:
         out = np.zeros((B, partial_stride()))
         self._chk(self.lib.iba_debug_last_partials(self.h, _p(out), C.c_int32(B)))
         return out
+
+    def eval_full_partial(self, x, d_partials_ptr, stream_ptr=None):
+        x = self._x(x)
+        self._chk(self.lib.iba_eval_full_partial(self.h, _p(x), C.c_int32(len(x)), C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
 
     def set_timing(self, on=True):
         self._chk(self.lib.iba_set_timing(self.h, C.c_int32(1 if on else 0)))

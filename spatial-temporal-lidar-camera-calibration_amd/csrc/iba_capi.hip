@@ -77,7 +77,7 @@ struct iba_handle {
     int assoc_cap = 0;
     DevBuf<uint2> d_assoc_frozen;         // n_keypoints (iba_build_problem)
     bool frozen_valid = false; int32_t frozen_frames = 0, frozen_ncorr = 0;
-    int nfb = 0;                          // factor-kernel blocks per candidate = n_frames * ceil(maxK/256)
+    int nfb = 0;                          // factor-kernel records per candidate (= n_frames)
     int nrec = 0;                         // partial records per candidate = n_frames + nfb
     Cand* h_cands = nullptr;              // pinned, kRing * IBA_MAX_BATCH
     double* h_partials = nullptr;         // pinned
@@ -196,7 +196,7 @@ iba_status compute_plane_cache(iba_handle* h) {
 template <int MODE>
 iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, uint2* d_assoc, int nrec, hipStream_t st) {
     const DevProblem dp = h->dev_problem();
-    if (MODE == MODE_COST && h->n_frames > 0) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
+    if ((MODE == MODE_COST || MODE == MODE_BOTH) && h->n_frames > 0) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
         hipLaunchKernelGGL(iba_he_kernel, dim3((B * h->n_frames + 63) / 64), dim3(64), 0, st, dp, d_cands, B, h->d_he.p);
         HIP_TRY(h, hipGetLastError());
     }
@@ -416,7 +416,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     hipError_t er;
     if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);
     if ((er = h->d_cands.alloc((size_t)kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("alloc cands", er);
-    h->nfb = nf * (int)((h->maxK + kFactorThreads - 1) / kFactorThreads); h->nrec = nf + h->nfb;
+    h->nfb = nf; h->nrec = nf + h->nfb;   // one factor-kernel record per frame
     if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(h->nrec, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
     if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
@@ -428,9 +428,10 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel
-    const void* fns[6] = {(const void*)iba_frame_kernel<MODE_COST, true>, (const void*)iba_frame_kernel<MODE_COST, false>,
+    const void* fns[8] = {(const void*)iba_frame_kernel<MODE_COST, true>, (const void*)iba_frame_kernel<MODE_COST, false>,
                           (const void*)iba_frame_kernel<MODE_CORR, true>, (const void*)iba_frame_kernel<MODE_CORR, false>,
-                          (const void*)iba_frame_kernel<MODE_ASSOC, true>, (const void*)iba_frame_kernel<MODE_ASSOC, false>};
+                          (const void*)iba_frame_kernel<MODE_ASSOC, true>, (const void*)iba_frame_kernel<MODE_ASSOC, false>,
+                          (const void*)iba_frame_kernel<MODE_BOTH, true>, (const void*)iba_frame_kernel<MODE_BOTH, false>};
     for (const void* fn : fns)
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
 
@@ -560,8 +561,8 @@ iba_status iba_finalize_normal(const iba_params* p, const double* part, int32_t 
 
 static iba_status launch_factors(iba_handle* h, const Cand* dc, int B, const uint2* assoc, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
     if (h->n_frames == 0 || h->maxK == 0) return IBA_OK;
-    const dim3 grid((h->maxK + kFactorThreads - 1) / kFactorThreads, h->n_frames, B);
-    hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, assoc, per_cand, partials, nrec, rec_base);
+    const dim3 grid(h->n_frames, B);
+    hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 8u * h->maxK, st, h->dev_problem(), h->dprm, dc, assoc, per_cand, partials, nrec, rec_base, (int)h->maxK);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }
@@ -599,6 +600,43 @@ iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
     return iba_finalize_normal(&h->params, h->h_partials, B, out);
+}
+
+// BAError tuple AND re-associated normal equations of the same candidates from ONE pass over the scans:
+// the two paths share projection + 2d-3d association (iba_global.cpp:55-96 = iba_local.cpp:17-58).
+static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
+    if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->assoc_cap < B) {
+        HIP_TRY(h, hipStreamSynchronize(st));
+        h->d_assoc.release();
+        HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
+        h->assoc_cap = B;
+    }
+    Cand* dc = nullptr;
+    iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    s = launch_frame<MODE_BOTH>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
+    s = launch_factors(h, dc, B, h->d_assoc.p, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
+    return IBA_OK;
+}
+
+iba_status iba_eval_full_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
+    if (!h || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return eval_full_partial_impl(h, x, B, (double*)d_partials, stream ? (hipStream_t)stream : h->stream);
+}
+
+iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal) {
+    if (!h || !cost || !normal) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    iba_status s = eval_full_partial_impl(h, x, B, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
+    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    s = iba_finalize_cost(&h->params, h->h_partials, B, cost); if (s != IBA_OK) return s;
+    return iba_finalize_normal(&h->params, h->h_partials, B, normal);
 }
 
 iba_status iba_build_problem(iba_handle* h, const double* x) {

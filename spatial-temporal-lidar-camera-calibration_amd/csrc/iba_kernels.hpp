@@ -327,6 +327,27 @@ __global__ __launch_bounds__(256) void iba_plane_kernel(DevProblem dp, double r2
     if ((threadIdx.x & 63) == 0) out[h.pt_base + pos] = rec;
 }
 
+// ---- wave64 sum on the VALU (DPP row shifts + row broadcasts, no LDS traffic); total lands in lane 63 ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long b) {
+    int lo = (int)(unsigned int)b, hi = (int)(unsigned int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x) { return __longlong_as_double((long long)dpp_u64<CTRL, ROW_MASK>((unsigned long long)__double_as_longlong(x))); }
+__device__ __forceinline__ double wave_sum_f64(double x) {   // fixed association order => bitwise reproducible
+    x += dpp_f64<0x111, 0xf>(x); x += dpp_f64<0x112, 0xf>(x); x += dpp_f64<0x114, 0xf>(x); x += dpp_f64<0x118, 0xf>(x);   // row_shr 1,2,4,8
+    x += dpp_f64<0x142, 0xa>(x);   // row_bcast:15 -> rows 1,3
+    x += dpp_f64<0x143, 0xc>(x);   // row_bcast:31 -> rows 2,3
+    return x;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x) {
+    x += dpp_u64<0x111, 0xf>(x); x += dpp_u64<0x112, 0xf>(x); x += dpp_u64<0x114, 0xf>(x); x += dpp_u64<0x118, 0xf>(x);
+    x += dpp_u64<0x142, 0xa>(x); x += dpp_u64<0x143, 0xc>(x);
+    return x;
+}
 // ---- fixed-order block reduction of NV doubles per thread; the totals are returned in v[] on every thread ----
 template <int NV>
 __device__ inline void block_reduce(double* v, double* s_red /* (kWaves+1)*kRedSlots doubles */) {
@@ -485,7 +506,7 @@ __device__ __forceinline__ void nn_search_group(const float* __restrict__ xs, co
     }
 }
 
-enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2 };
+enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2, MODE_BOTH = 3 };   // BOTH = BAError + BuildProblem association in one pass
 
 #ifdef IBA_STAMPS   // diagnostic build only: per-phase shader-clock deltas of thread 0 into partial slots 56..63
 #define IBA_STAMP(i) do { if (threadIdx.x == 0) { stamp_t[i] = __builtin_readcyclecounter(); } } while (0)
@@ -535,27 +556,6 @@ __device__ __forceinline__ void ordered_append(bool want, uint32_t k, uint32_t& 
     __syncthreads();
 }
 
-// ---- wave64 sum on the VALU (DPP row shifts + row broadcasts, no LDS traffic); total lands in lane 63 ----
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long b) {
-    int lo = (int)(unsigned int)b, hi = (int)(unsigned int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double x) { return __longlong_as_double((long long)dpp_u64<CTRL, ROW_MASK>((unsigned long long)__double_as_longlong(x))); }
-__device__ __forceinline__ double wave_sum_f64(double x) {   // fixed association order => bitwise reproducible
-    x += dpp_f64<0x111, 0xf>(x); x += dpp_f64<0x112, 0xf>(x); x += dpp_f64<0x114, 0xf>(x); x += dpp_f64<0x118, 0xf>(x);   // row_shr 1,2,4,8
-    x += dpp_f64<0x142, 0xa>(x);   // row_bcast:15 -> rows 1,3
-    x += dpp_f64<0x143, 0xc>(x);   // row_bcast:31 -> rows 2,3
-    return x;
-}
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x) {
-    x += dpp_u64<0x111, 0xf>(x); x += dpp_u64<0x112, 0xf>(x); x += dpp_u64<0x114, 0xf>(x); x += dpp_u64<0x118, 0xf>(x);
-    x += dpp_u64<0x142, 0xa>(x); x += dpp_u64<0x143, 0xc>(x);
-    return x;
-}
 // number of set flags in the block, known to every thread (one ballot per wave + 16 LDS words)
 __device__ __forceinline__ uint32_t block_count(uint32_t my_count_wave_uniform, uint32_t* s_wcnt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -758,11 +758,13 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         n_corr = block_count(wc, s_wcnt);
     }
 
-    if (MODE == MODE_ASSOC) {
+    bool used_assoc = false;
+    if (MODE == MODE_ASSOC || MODE == MODE_BOTH) {
         // ---- BuildProblem association (iba_local.cpp:145-323): which residual blocks exist at this x ----
         uint2* arow = assoc_out + (size_t)b * dp.n_kp_total + h.kp_base;
         const bool used = !((int)n_corr < prm.num_min_corr);   // iba_local.cpp:192
-        if (tid < kPartialStride) part[tid] = (used && tid == P_FRAMES_N) ? 1.0 : ((used && tid == P_NCORR_N) ? (double)n_corr : 0.0);
+        used_assoc = used;
+        if (MODE == MODE_ASSOC && tid < kPartialStride) part[tid] = (used && tid == P_FRAMES_N) ? 1.0 : ((used && tid == P_NCORR_N) ? (double)n_corr : 0.0);
         const PlaneRec* planes = dp.plane_local + h.pt_base;
         for (uint32_t k = tid; k < Kceil; k += kThreads) {
             bool want3 = false;
@@ -813,11 +815,13 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         else if (n3 * 4u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 4>());
         else if (n3 * 2u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 2>());
         else assoc_3d3d(std::integral_constant<int, 1>());
-        return;
+        if (MODE == MODE_ASSOC) return;
+        __syncthreads();   // s_list is reused by the cost path below
+        n3 = 0;
     }
 
     if ((int)n_corr < prm.num_min_corr_cost) {   // iba_global.cpp:203: frame skipped entirely
-        if (tid < kPartialStride) part[tid] = 0.0;
+        if (tid < kPartialStride) part[tid] = (used_assoc && tid == P_FRAMES_N) ? 1.0 : ((used_assoc && tid == P_NCORR_N) ? (double)n_corr : 0.0);
         return;
     }
 
@@ -963,6 +967,8 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             else if (tid == P_NCORR) out = (double)n_corr;
             else if (tid == P_HE_SUM) out = h.he_valid ? he[(size_t)b * nf + f] : 0.0;   // K7 (iba_he_kernel)
             else if (tid == P_HE_CNT) out = h.he_valid ? 1.0 : 0.0;
+            else if (tid == P_FRAMES_N) out = used_assoc ? 1.0 : 0.0;
+            else if (tid == P_NCORR_N) out = used_assoc ? (double)n_corr : 0.0;
             part[tid] = out;
         }
     }
@@ -1079,57 +1085,87 @@ __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const 
 }
 
 constexpr int kFactorThreads = 256;
-// grid: (ceil(maxK/256), n_frames, B). assoc row = assoc + (assoc_per_cand ? b : 0) * n_kp_total.
-// record (b, rec_base + blockIdx.y * gridDim.x + blockIdx.x) of `partials` receives this block's sums.
+// grid: (n_frames, B), 256 threads; dynamic LDS = 8 * maxK bytes. assoc row = assoc + (assoc_per_cand ? b : 0) * n_kp_total.
+// Only ~1 keypoint in 7 owns a residual block, so each wave first compacts ITS quarter of the keypoints into two
+// ordered LDS lists (ballot + prefix, no block barrier), then the block works through the dense lists.
+// record (b, rec_base + frame) of `partials` receives this block's sums.
 __global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint2* __restrict__ assoc,
-                                                                    int assoc_per_cand, double* __restrict__ partials, int nrec, int rec_base) {
-    __shared__ double s_part[kFactorThreads / 64][kPartialStride];
-    const int f = blockIdx.y, b = blockIdx.z;
+                                                                    int assoc_per_cand, double* __restrict__ partials, int nrec, int rec_base, int maxK) {
+    extern __shared__ __align__(16) unsigned char fsm[];
+    __shared__ double s_part[kFactorThreads / 64][48];
+    __shared__ uint32_t s_cnt[2][kFactorThreads / 64];
+    const int f = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kFactorThreads / 64;
     const FrameHdr& h = dp.frames[f];
     const Cand& c = cands[b];
-    const uint32_t k = blockIdx.x * kFactorThreads + threadIdx.x;
+    const uint32_t K = h.K;
+    uint32_t* s_lp = (uint32_t*)fsm;            // plane-factor keypoints, wave segments of `seg` entries
+    uint32_t* s_l3 = s_lp + maxK;               // 3d-3d-factor keypoints
+    const uint2* arow = assoc + (size_t)(assoc_per_cand ? b : 0) * dp.n_kp_total + h.kp_base;
+    const uint32_t seg = (K + NW - 1) / NW;     // keypoints per wave
+    {
+        const uint32_t k0 = wave * seg, k1 = min(K, k0 + seg);
+        uint32_t np = 0, n3 = 0;
+        for (uint32_t kb = k0; kb < k1; kb += 64) {
+            const uint32_t k = kb + lane;
+            uint2 a = make_uint2(kNone, kNone);
+            if (k < k1) a = arow[k];
+            const unsigned long long bp = __ballot(a.x != kNone), b3 = __ballot(a.y != kNone);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (a.x != kNone) s_lp[k0 + np + (uint32_t)__popcll(bp & lt)] = k;
+            if (a.y != kNone) s_l3[k0 + n3 + (uint32_t)__popcll(b3 & lt)] = k;
+            np += (uint32_t)__popcll(bp); n3 += (uint32_t)__popcll(b3);
+        }
+        if (lane == 0) { s_cnt[0][wave] = np; s_cnt[1][wave] = n3; }
+    }
+    __syncthreads();
     NAcc A;
     for (int i = 0; i < 28; ++i) A.H[i] = 0;
     for (int i = 0; i < 7; ++i) A.b[i] = 0;
     A.chi2 = A.cost = A.nf2d = A.nfpl = A.nfpt = A.nres = 0;
-    if (k < h.K) {
-        const uint2 a = assoc[(size_t)(assoc_per_cand ? b : 0) * dp.n_kp_total + h.kp_base + k];
-        const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
-        if (a.x != kNone) {
-            const PlaneRec rec = dp.plane_local[h.pt_base + a.x];
-            const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]}, n0[3] = {rec.nx, rec.ny, rec.nz};
-            const float2 uv = dp.kp_uv[h.kp_base + k];
-            plane_factor_accum(c, h, dp, prm, k, h.K, (double)uv.x, (double)uv.y, p0, n0, A);
-        }
-        if (a.y != kNone) {
-            const uint32_t pos = a.y & 0x7FFFFFFFu; const bool is_plane = (a.y >> 31) != 0;
-            const PlaneRec rec = dp.plane_local[h.pt_base + pos];
-            const double Q[3] = {(double)xs[pos], (double)ys[pos], (double)zs[pos]}, n[3] = {rec.nx, rec.ny, rec.nz};
-            p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, n, is_plane, A);
-        }
+    const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
+    // entry i of the concatenated wave segments
+    auto entry = [&](const uint32_t* list, int which, uint32_t i, uint32_t& k) -> bool {
+        for (int w = 0; w < NW; ++w) { const uint32_t n = s_cnt[which][w]; if (i < n) { k = list[w * seg + i]; return true; } i -= n; }
+        return false;
+    };
+    for (uint32_t i = tid;; i += kFactorThreads) {
+        uint32_t k;
+        if (!entry(s_lp, 0, i, k)) break;
+        const uint2 a = arow[k];
+        const PlaneRec rec = dp.plane_local[h.pt_base + a.x];
+        const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]}, n0[3] = {rec.nx, rec.ny, rec.nz};
+        const float2 uv = dp.kp_uv[h.kp_base + k];
+        plane_factor_accum(c, h, dp, prm, k, K, (double)uv.x, (double)uv.y, p0, n0, A);
     }
-    // fixed-order reduction: wave shuffle, then the 4 waves in order
+    for (uint32_t i = tid;; i += kFactorThreads) {
+        uint32_t k;
+        if (!entry(s_l3, 1, i, k)) break;
+        const uint2 a = arow[k];
+        const uint32_t pos = a.y & 0x7FFFFFFFu; const bool is_plane = (a.y >> 31) != 0;
+        const PlaneRec rec = dp.plane_local[h.pt_base + pos];
+        const double Q[3] = {(double)xs[pos], (double)ys[pos], (double)zs[pos]}, n[3] = {rec.nx, rec.ny, rec.nz};
+        p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, n, is_plane, A);
+    }
+    // fixed-order reduction: DPP wave sums (VALU), then the 4 waves in order
     double* v = (double*)&A;   // 41 contiguous doubles
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 41; ++i) {
-        double x = v[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-        if (lane == 0) s_part[wave][i] = x;
+        const double x = wave_sum_f64(v[i]);
+        if (lane == 63) s_part[wave][i] = x;
     }
     __syncthreads();
-    if (threadIdx.x < kPartialStride) {
-        const int i = threadIdx.x;
+    if (tid < kPartialStride) {
+        const int i = tid;
         double out = 0;
-        // map NAcc slot -> partial slot
-        int src = -1;
+        int src = -1;   // NAcc slot -> partial slot
         if (i >= P_H0 && i < P_H0 + 28) src = i - P_H0;
         else if (i >= P_B0 && i < P_B0 + 7) src = 28 + (i - P_B0);
         else if (i == P_CHI2) src = 35; else if (i == P_COST) src = 36; else if (i == P_NF_3D2D) src = 37;
         else if (i == P_NF_P2PL) src = 38; else if (i == P_NF_P2PT) src = 39; else if (i == P_NRES) src = 40;
         if (src >= 0) out = ((s_part[0][src] + s_part[1][src]) + s_part[2][src]) + s_part[3][src];
-        partials[((size_t)b * nrec + rec_base + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * kPartialStride + i] = out;
+        partials[((size_t)b * nrec + rec_base + f) * kPartialStride + i] = out;
     }
 }
 

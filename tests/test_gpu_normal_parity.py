@@ -66,3 +66,24 @@ def test_local_params_differ_from_cost_params(pkg, synth, abi, ob, scene_small):
     o = ob.Oracle(prob)
     _cmp_normal(h.eval_normal(meta["x_gt"])[0], o.eval_normal(p, meta["x_gt"])[0])
     h.close()
+
+
+def test_eval_full_equals_separate_calls(pkg, synth, abi, scene_small):
+    """iba_eval_full (one fused pass) must reproduce iba_eval_cost + iba_eval_normal: counters and the normal
+    equations bit for bit; f1/f2/C to the last ulps (the frame records are summed in a different grouping)."""
+    prob, meta = scene_small
+    h = pkg.IbaHandle(prob, abi.reference_yaml_params())
+    rng = np.random.default_rng(21)
+    xs = np.vstack([synth.perturb(meta["x_gt"], rng, n=3), synth.perturb(meta["x_gt"], rng, rot=0.03, trans=0.1, scale_rel=0.05, n=2)])
+    cf, nf = h.eval_full(xs)
+    cs, ns = h.eval_cost(xs), h.eval_normal(xs)
+    for a, b in zip(cf, cs):
+        da, db = a.as_dict(), b.as_dict()
+        for k in da:
+            if k in ("f1", "f2", "C"):
+                assert (np.isnan(da[k]) and np.isnan(db[k])) or abs(da[k] - db[k]) <= 1e-14 * abs(db[k]), (k, da[k], db[k])
+            else:
+                assert da[k] == db[k], k
+    for a, b in zip(nf, ns):
+        assert a.counts() == b.counts() and np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.cost == b.cost
+    h.close()
