@@ -194,6 +194,23 @@ iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out
  * at x_assoc, then evaluate the frozen residual blocks at B other x. */
 iba_status iba_build_problem(iba_handle* h, const double* x_assoc);
 iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out);
+/* Caller of the Jacobian path: the outer re-association loop of iba_local
+ * (iba_local.cpp:434-460) around a Ceres-style LM on the device-reduced 7x7 normal equations. */
+typedef struct iba_lm_options {
+    int32_t max_outer_iterations; /* max_iba_iter */
+    int32_t max_inner_iterations; /* 30, iba_local.cpp:437 */
+    double min_diff;              /* iba_min_diff for allClose (iba_local.cpp:454) */
+    double function_tolerance, gradient_tolerance, parameter_tolerance; /* Ceres defaults 1e-6, 1e-10, 1e-8 */
+    double initial_trust_region_radius;                                 /* 1e4 */
+} iba_lm_options;
+typedef struct iba_lm_result {
+    double x[7];
+    int32_t outer_iterations, inner_iterations, evaluations, converged;
+    double initial_cost, final_cost;
+} iba_lm_result;
+iba_status iba_default_lm_options(iba_lm_options* o);
+iba_status iba_calibrate_lm(iba_handle* h, const double* x0, const iba_lm_options* opt, iba_lm_result* res);
+
 /* Per-residual values and Jacobians of the frozen problem (for Ceres / g2o adaptors and tests).
  * Call with r == NULL to query *n_rows. J is n_rows x 7 row-major, block_id[n_rows] identifies the
  * residual block, block_kind: 0 = IBA_PlaneFactor, 1 = Point2Plane, 2 = Point2Point. */

@@ -14,7 +14,7 @@ import subprocess
 
 import numpy as np
 
-from .abi import (IBA_MAX_BATCH, IbaBbo, IbaCostOut, IbaNormalOut, IbaParams, IbaProblemDesc, Problem, copy_params,
+from .abi import (IBA_MAX_BATCH, IbaLmOptions, IbaLmResult, IbaBbo, IbaCostOut, IbaNormalOut, IbaParams, IbaProblemDesc, Problem, copy_params,
                   reference_yaml_params)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -166,6 +166,17 @@ class IbaHandle:
         nrm = (IbaNormalOut * B)()
         self._chk(self.lib.iba_eval_full(self.h, _p(x), C.c_int32(B), cost, nrm))
         return list(cost), list(nrm)
+
+    def calibrate_lm(self, x0, **opts):
+        """iba_local's outer loop (re-associate, LM on the frozen problem, until allClose) on the device path."""
+        o = IbaLmOptions()
+        self.lib.iba_default_lm_options(C.byref(o))
+        for k, v in opts.items():
+            setattr(o, k, v)
+        r = IbaLmResult()
+        x0 = np.ascontiguousarray(x0, np.float64)
+        self._chk(self.lib.iba_calibrate_lm(self.h, _p(x0), C.byref(o), C.byref(r)))
+        return np.array(r.x[:]), r
 
     def build_problem(self, x):
         x = np.ascontiguousarray(x, np.float64)

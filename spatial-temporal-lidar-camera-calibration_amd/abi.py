@@ -100,6 +100,17 @@ class IbaNormalOut(C.Structure):
         return {k: getattr(self, k) for k in ("n_factor_3d2d", "n_factor_p2pl", "n_factor_p2pt", "n_residuals", "frames_used", "n_corr")}
 
 
+class IbaLmOptions(C.Structure):
+    _fields_ = [("max_outer_iterations", C.c_int32), ("max_inner_iterations", C.c_int32), ("min_diff", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("initial_trust_region_radius", C.c_double)]
+
+
+class IbaLmResult(C.Structure):
+    _fields_ = [("x", C.c_double * 7), ("outer_iterations", C.c_int32), ("inner_iterations", C.c_int32), ("evaluations", C.c_int32),
+                ("converged", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+
+
 class IbaBbo(C.Structure):
     _fields_ = [("f", C.c_double), ("c1", C.c_double), ("c2", C.c_double), ("c3", C.c_double)]
 

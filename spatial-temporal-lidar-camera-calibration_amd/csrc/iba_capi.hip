@@ -18,6 +18,7 @@
 #include "iba_build.hpp"
 #include "iba_host_math.hpp"
 #include "iba_kernels.hpp"
+#include "iba_lm.hpp"
 #include "iba_types.hpp"
 
 using namespace iba;
@@ -670,6 +671,40 @@ iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_norma
     if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
     for (int b = 0; b < B; ++b) { h->h_partials[(size_t)b * kPartialStride + P_FRAMES_N] = h->frozen_frames; h->h_partials[(size_t)b * kPartialStride + P_NCORR_N] = h->frozen_ncorr; }
     return iba_finalize_normal(&h->params, h->h_partials, B, out);
+}
+
+iba_status iba_default_lm_options(iba_lm_options* o) {
+    if (!o) return IBA_ERR_INVALID_ARG;
+    const LmOptions d;
+    o->max_outer_iterations = d.max_outer_iterations; o->max_inner_iterations = d.max_inner_iterations; o->min_diff = d.min_diff;
+    o->function_tolerance = d.function_tolerance; o->gradient_tolerance = d.gradient_tolerance; o->parameter_tolerance = d.parameter_tolerance;
+    o->initial_trust_region_radius = d.initial_trust_region_radius;
+    return IBA_OK;
+}
+
+iba_status iba_calibrate_lm(iba_handle* h, const double* x0, const iba_lm_options* opt, iba_lm_result* res) {
+    if (!h || !x0 || !res) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    LmOptions o;
+    if (opt) {
+        o.max_outer_iterations = opt->max_outer_iterations; o.max_inner_iterations = opt->max_inner_iterations; o.min_diff = opt->min_diff;
+        o.function_tolerance = opt->function_tolerance; o.gradient_tolerance = opt->gradient_tolerance; o.parameter_tolerance = opt->parameter_tolerance;
+        o.initial_trust_region_radius = opt->initial_trust_region_radius;
+    }
+    iba_status st = IBA_OK;
+    LmResult r;
+    const bool ok = calibrate_lm(x0, o,
+        [&](const double* x) { st = iba_build_problem(h, x); return st == IBA_OK; },
+        [&](const double* x, double* H, double* g, double& cost) {
+            iba_normal_out n; st = iba_eval_factors(h, x, 1, &n);
+            if (st != IBA_OK) return false;
+            std::memcpy(H, n.H, sizeof(n.H)); std::memcpy(g, n.b, sizeof(n.b)); cost = n.cost;
+            return true;
+        }, r);
+    if (!ok) return st == IBA_OK ? IBA_ERR_STATE : st;
+    std::memcpy(res->x, r.x, sizeof(r.x));
+    res->outer_iterations = r.outer_iterations; res->inner_iterations = r.inner_iterations; res->evaluations = r.evaluations; res->converged = r.converged;
+    res->initial_cost = r.initial_cost; res->final_cost = r.final_cost;
+    return IBA_OK;
 }
 
 iba_status iba_eval_residuals(iba_handle* h, const double*, double*, double*, int32_t*, int32_t*, int64_t*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_residuals: not implemented yet"); }
