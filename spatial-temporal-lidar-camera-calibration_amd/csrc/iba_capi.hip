@@ -707,6 +707,58 @@ iba_status iba_calibrate_lm(iba_handle* h, const double* x0, const iba_lm_option
     return IBA_OK;
 }
 
-iba_status iba_eval_residuals(iba_handle* h, const double*, double*, double*, int32_t*, int32_t*, int64_t*) { return fail(h, IBA_ERR_UNSUPPORTED, "iba_eval_residuals: not implemented yet"); }
+iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double* J, int32_t* block_id, int32_t* block_kind, int64_t* n_rows) {
+    if (!h || !x || !n_rows) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    if (!h->frozen_valid) return fail(h, IBA_ERR_STATE, "iba_eval_residuals called before iba_build_problem");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t KT = (size_t)h->n_keypoints;
+    std::vector<uint2> a(KT);
+    HIP_TRY(h, hipMemcpy(a.data(), h->d_assoc_frozen.p, KT * sizeof(uint2), hipMemcpyDeviceToHost));
+    std::vector<float2> muv; std::vector<float2> dummy;
+    // covisible-match counts per keypoint decide the number of plane-factor rows (2 per matched covisible KF)
+    std::vector<int> nconv(KT, 0);
+    {
+        std::vector<float2> m(h->match_uv.n);
+        if (h->match_uv.n) HIP_TRY(h, hipMemcpy(m.data(), h->match_uv.p, h->match_uv.n * sizeof(float2), hipMemcpyDeviceToHost));
+        for (int lf = 0; lf < h->n_frames; ++lf) {
+            const FrameHdr& fh = h->h_frames[lf];
+            for (uint32_t sl = 0; sl < fh.n_slots; ++sl)
+                for (uint32_t k = 0; k < fh.K; ++k) if (m[fh.match_base + (size_t)sl * fh.K + k].x == m[fh.match_base + (size_t)sl * fh.K + k].x) nconv[fh.kp_base + k]++;
+        }
+    }
+    // rows ordered like the oracle / BuildProblem: frame, then reference keypoint id, plane factor before the 3d-3d factor
+    std::vector<long long> row_off(KT, -1);
+    std::vector<int32_t> bid, bkind;
+    long long rows = 0; int32_t blk = 0;
+    for (int lf = 0; lf < h->n_frames; ++lf) {
+        const FrameHdr& fh = h->h_frames[lf];
+        std::vector<uint32_t> inv(fh.K);
+        for (uint32_t j = 0; j < fh.K; ++j) inv[h->h_kp_ext[fh.kp_base + j]] = j;
+        for (uint32_t e = 0; e < fh.K; ++e) {
+            const size_t g = fh.kp_base + inv[e];
+            if (a[g].x == kNone && a[g].y == kNone) continue;
+            row_off[g] = rows;
+            if (a[g].x != kNone) { const int nr = 2 * nconv[g]; for (int i = 0; i < nr; ++i) { bid.push_back(blk); bkind.push_back(0); } rows += nr; ++blk; }
+            if (a[g].y != kNone) { const bool pl = (a[g].y >> 31) != 0; const int nr = pl ? 1 : 3; for (int i = 0; i < nr; ++i) { bid.push_back(blk); bkind.push_back(pl ? 1 : 2); } rows += nr; ++blk; }
+        }
+    }
+    *n_rows = rows;
+    if (!r || !J) return IBA_OK;
+    if (rows == 0) return IBA_OK;
+    DevBuf<long long> d_off; DevBuf<double> d_r, d_J;
+    std::vector<long long> offv(row_off);
+    HIP_TRY(h, d_off.upload(offv)); HIP_TRY(h, d_r.alloc((size_t)rows)); HIP_TRY(h, d_J.alloc((size_t)rows * 7));
+    Cand* dc = nullptr;
+    iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
+    hipLaunchKernelGGL(iba_residual_kernel, dim3((h->maxK + 63) / 64, h->n_frames), dim3(64), 0, h->stream, h->dev_problem(), h->dprm, dc, h->d_assoc_frozen.p, d_off.p, d_r.p, d_J.p);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(r, d_r.p, sizeof(double) * rows, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(J, d_J.p, sizeof(double) * rows * 7, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    d_off.release(); d_r.release(); d_J.release();
+    if (block_id) std::memcpy(block_id, bid.data(), sizeof(int32_t) * rows);
+    if (block_kind) std::memcpy(block_kind, bkind.data(), sizeof(int32_t) * rows);
+    return IBA_OK;
+}
 
 }  // extern "C"

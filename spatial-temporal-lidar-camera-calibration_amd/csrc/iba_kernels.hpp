@@ -993,9 +993,11 @@ __device__ __forceinline__ void huber_w(double a, double s, double& rho0, double
 // H (upper, row-major i<=j) index
 __device__ __forceinline__ int hidx(int i, int j) { return i * 7 - (i * (i - 1)) / 2 + (j - i); }
 
-__device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
-                                          double u0, double v0, const double* p0, const double* n0, NAcc& A) {
-    // p0c, n0c and their derivatives
+// IBA_PlaneFactor core: calls slot(ru, rv, gu, gv, hu, hv) per matched covisible KF, where the two residual rows are
+// (ru, rv) and their Jacobian rows are [gu * z6, hu], [gv * z6, hv] (z6 = dZ0/dx[0:6], last column d/ds).
+template <class SlotFn>
+__device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K,
+                                                 double u0, double v0, const double* p0, const double* n0, double* z6, SlotFn slot) {
     double p0c[3], n0c[3];
     for (int r = 0; r < 3; ++r) {
         p0c[r] = ((c.R[r * 3] * p0[0] + c.R[r * 3 + 1] * p0[1]) + c.R[r * 3 + 2] * p0[2]) + c.t[r];
@@ -1005,7 +1007,6 @@ __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, cons
     const double num = (n0c[0] * p0c[0] + n0c[1] * p0c[1]) + n0c[2] * p0c[2];
     const double den = (Cxz * n0c[0] + Cyz * n0c[1]) + n0c[2];
     const double Z0 = num / den;
-    double z6[6];
     for (int kk = 0; kk < 6; ++kk) {
         double dpv[3], dnv[3] = {0, 0, 0};
         for (int r = 0; r < 3; ++r) {
@@ -1020,7 +1021,7 @@ __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, cons
         z6[kk] = (dnum - Z0 * dden) / den;
     }
     const double P0x = Cxz * Z0, P0y = Cyz * Z0, P0z = Z0;
-    double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0; int nconv = 0;
+    int nconv = 0;
     for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
         const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k];
         if (m.x != m.x) continue;
@@ -1035,11 +1036,21 @@ __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, cons
         const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
         const double gu = h.fx * iz * (ax - xz * az), gv = h.fy * iz * (ay - yz * az);
         const double hu = h.fx * iz * (rel[3] - xz * rel[11]), hv = h.fy * iz * (rel[7] - yz * rel[11]);
+        slot(ru, rv, gu, gv, hu, hv);
+        ++nconv;
+    }
+    return nconv;
+}
+
+__device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
+                                          double u0, double v0, const double* p0, const double* n0, NAcc& A) {
+    double z6[6];
+    double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0;
+    const int nconv = plane_factor_core(c, h, dp, k, K, u0, v0, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
         ssq += ru * ru + rv * rv;
         G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
         Gr += gu * ru + gv * rv; Hr += hu * ru + hv * rv;
-        ++nconv;
-    }
+    });
     if (nconv == 0) return;
     double rho0, w; huber_w(prm.robust_kernel_delta, ssq, rho0, w);
     A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0 * nconv;
@@ -1052,12 +1063,12 @@ __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, cons
     A.H[27] += w * HH; A.b[6] += w * Hr;
 }
 
-__device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const DevParams& prm, const float4 mp, const double* Q, const double* n, bool is_plane, NAcc& A) {
+// M = Rlc (s m) + tlc and dM/dx for the 3d-3d factors (IBACalib2.hpp:570-584, 611-625)
+__device__ __forceinline__ void p2x_core(const Cand& c, const FrameHdr& h, const float4 mp, double* M, double dM[7][3]) {
     const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
     const double m[3] = {((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3], ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7],
                          ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11]};
     const double sm[3] = {m[0] * c.s, m[1] * c.s, m[2] * c.s};
-    double M[3], dM[7][3];
     for (int r = 0; r < 3; ++r) {
         M[r] = ((c.Rlc[r * 3] * sm[0] + c.Rlc[r * 3 + 1] * sm[1]) + c.Rlc[r * 3 + 2] * sm[2]) + c.tlc[r];
         for (int kk = 0; kk < 6; ++kk) {
@@ -1067,6 +1078,11 @@ __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const 
         }
         dM[6][r] = (c.Rlc[r * 3] * m[0] + c.Rlc[r * 3 + 1] * m[1]) + c.Rlc[r * 3 + 2] * m[2];
     }
+}
+
+__device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const DevParams& prm, const float4 mp, const double* Q, const double* n, bool is_plane, NAcc& A) {
+    double M[3], dM[7][3];
+    p2x_core(c, h, mp, M, dM);
     const double e[3] = {M[0] - Q[0], M[1] - Q[1], M[2] - Q[2]};
     if (is_plane) {
         const double r = (e[0] * n[0] + e[1] * n[1]) + e[2] * n[2];
@@ -1166,6 +1182,48 @@ __global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem d
         else if (i == P_NF_P2PL) src = 38; else if (i == P_NF_P2PT) src = 39; else if (i == P_NRES) src = 40;
         if (src >= 0) out = ((s_part[0][src] + s_part[1][src]) + s_part[2][src]) + s_part[3][src];
         partials[((size_t)b * nrec + rec_base + f) * kPartialStride + i] = out;
+    }
+}
+
+// Per-residual output of the frozen problem (for Ceres/g2o adaptors and tests): one lane per keypoint, rows at
+// row_off[kp] (int64, -1 = keypoint owns no block), plane-factor rows first, then the 3d-3d rows.
+__global__ __launch_bounds__(64) void iba_residual_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint2* __restrict__ assoc,
+                                                          const long long* __restrict__ row_off, double* __restrict__ r_out, double* __restrict__ J_out) {
+    const int f = blockIdx.y;
+    const FrameHdr& h = dp.frames[f];
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= h.K) return;
+    const uint2 a = assoc[h.kp_base + k];
+    long long row = row_off[h.kp_base + k];
+    if (row < 0) return;
+    const Cand& c = cands[0];
+    const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
+    if (a.x != kNone) {
+        const PlaneRec rec = dp.plane_local[h.pt_base + a.x];
+        const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]}, n0[3] = {rec.nx, rec.ny, rec.nz};
+        const float2 uv = dp.kp_uv[h.kp_base + k];
+        double z6[6];
+        // two sweeps: z6 is only known after the core has run, so rows are written on the second one
+        plane_factor_core(c, h, dp, k, h.K, (double)uv.x, (double)uv.y, p0, n0, z6, [&](double, double, double, double, double, double) {});
+        plane_factor_core(c, h, dp, k, h.K, (double)uv.x, (double)uv.y, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
+            r_out[row] = ru; r_out[row + 1] = rv;
+            for (int i = 0; i < 6; ++i) { J_out[row * 7 + i] = gu * z6[i]; J_out[(row + 1) * 7 + i] = gv * z6[i]; }
+            J_out[row * 7 + 6] = hu; J_out[(row + 1) * 7 + 6] = hv;
+            row += 2;
+        });
+    }
+    if (a.y != kNone) {
+        const uint32_t pos = a.y & 0x7FFFFFFFu; const bool is_plane = (a.y >> 31) != 0;
+        const PlaneRec rec = dp.plane_local[h.pt_base + pos];
+        double M[3], dM[7][3];
+        p2x_core(c, h, dp.kp_mp[h.kp_base + k], M, dM);
+        const double e[3] = {M[0] - (double)xs[pos], M[1] - (double)ys[pos], M[2] - (double)zs[pos]};
+        if (is_plane) {
+            r_out[row] = (e[0] * rec.nx + e[1] * rec.ny) + e[2] * rec.nz;
+            for (int i = 0; i < 7; ++i) J_out[row * 7 + i] = (dM[i][0] * rec.nx + dM[i][1] * rec.ny) + dM[i][2] * rec.nz;
+        } else {
+            for (int rr = 0; rr < 3; ++rr) { r_out[row + rr] = e[rr]; for (int i = 0; i < 7; ++i) J_out[(row + rr) * 7 + i] = dM[i][rr]; }
+        }
     }
 }
 

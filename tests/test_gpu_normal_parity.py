@@ -87,3 +87,23 @@ def test_eval_full_equals_separate_calls(pkg, synth, abi, scene_small):
     for a, b in zip(nf, ns):
         assert a.counts() == b.counts() and np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.cost == b.cost
     h.close()
+
+
+def test_per_residual_rows_match_oracle(pkg, synth, abi, ob, scene_small):
+    """iba_eval_residuals: every residual and Jacobian row of the frozen problem (what the Ceres/g2o adaptors
+    consume), in BuildProblem order, against the oracle's dual-number rows."""
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(prob, p)
+    o = ob.Oracle(prob)
+    rng = np.random.default_rng(31)
+    x0 = synth.perturb(meta["x_gt"], rng, n=1)[0]
+    h.build_problem(x0)
+    o.build_problem(p, x0)
+    x = synth.perturb(x0, rng, rot=1e-3, trans=1e-2, scale_rel=2e-3, n=1)[0]
+    rg, Jg, bg, kg = h.eval_residuals(x)
+    ro, Jo, bo, ko, _ = o.eval_residuals(x)
+    assert len(rg) == len(ro) > 1000 and np.array_equal(kg, ko) and np.array_equal(bg, bo)
+    assert np.allclose(rg, ro, rtol=1e-9, atol=1e-9)
+    assert np.allclose(Jg, Jo, rtol=1e-8, atol=1e-8 * np.abs(Jo).max())
+    h.close()
