@@ -67,6 +67,8 @@ struct iba_handle {
     DevBuf<uint32_t> cell_start, cell_kp, bitmap; DevBuf<float2> cell_uv;
     DevBuf<float2> match_uv;
     DevBuf<PlaneRec> plane_cost, plane_local;
+    DevBuf<PlaneRec> scratch_cost, scratch_local;   // plane_cache = 0: (scratch_cap + 1) x n_pt_total records
+    int scratch_cap = -1; bool scratch_local_aliases = false; int64_t n_pt_total = 0;
     bool plane_local_aliases_cost = false;
     double plane_cost_r2 = -1, plane_local_r2 = -1; int plane_cost_max = -1, plane_local_max = -1;
     DevBuf<Cand> d_cands;                 // kRing * IBA_MAX_BATCH
@@ -95,6 +97,7 @@ struct iba_handle {
         dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.cell_start = cell_start.p; dp.cell_kp = cell_kp.p; dp.cell_uv = cell_uv.p;
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
+        dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
         return dp;
     }
 };
@@ -132,7 +135,6 @@ iba_status check_params(iba_handle* h, const iba_params& p) {
         return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist must be in (0, 64] px");
     if (p.norm_max_pts < 1 || p.norm_max_pts > 32 || p.neigh_max_pts < 1 || p.neigh_max_pts > 32)
         return fail(h, IBA_ERR_UNSUPPORTED, "norm_max_pts / neigh_max_pts must be in [1, 32]");
-    if (!p.plane_cache) return fail(h, IBA_ERR_UNSUPPORTED, "plane_cache = 0 (per-evaluation plane refit) is not implemented yet");
     return IBA_OK;
 }
 
@@ -172,6 +174,7 @@ bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
 
 iba_status compute_plane_cache(iba_handle* h) {
     const iba_params& p = h->params;
+    if (!p.plane_cache) return IBA_OK;   // planes are refitted inside every evaluation
     const DevProblem dp = h->dev_problem();
     auto run = [&](double r2, int max_pts, PlaneRec* out) -> hipError_t {
         dim3 grid((h->maxP + 3) / 4, h->n_frames);
@@ -194,9 +197,26 @@ iba_status compute_plane_cache(iba_handle* h) {
     return IBA_OK;
 }
 
+// plane_cache = 0: private plane records for B candidates (+ slot 0 for the frozen problem of iba_build_problem)
+iba_status ensure_scratch(iba_handle* h, int B, hipStream_t st) {
+    if (h->params.plane_cache) return IBA_OK;
+    const bool alias = (h->params.norm_radius == h->params.neigh_radius && h->params.norm_max_pts == h->params.neigh_max_pts);
+    if (h->scratch_cap >= B && h->scratch_local_aliases == alias) return IBA_OK;
+    HIP_TRY(h, hipStreamSynchronize(st)); HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->scratch_cost.release(); h->scratch_local.release();
+    const size_t n = (size_t)(B + 1) * (size_t)std::max<int64_t>(h->n_pt_total, 1);
+    HIP_TRY(h, h->scratch_cost.alloc(n));
+    if (!alias) HIP_TRY(h, h->scratch_local.alloc(n));
+    h->scratch_cap = B; h->scratch_local_aliases = alias;
+    h->frozen_valid = false;   // slot 0 (the frozen problem's planes) went with the old buffer
+    return IBA_OK;
+}
+
 template <int MODE>
-iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, uint2* d_assoc, int nrec, hipStream_t st) {
-    const DevProblem dp = h->dev_problem();
+iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, uint2* d_assoc, int nrec, hipStream_t st, int scratch_slot_base = 1) {
+    if (MODE != MODE_CORR) { iba_status es = ensure_scratch(h, B, st); if (es != IBA_OK) return es; }
+    DevProblem dp = h->dev_problem();
+    dp.scratch_slot_base = scratch_slot_base;
     if ((MODE == MODE_COST || MODE == MODE_BOTH) && h->n_frames > 0) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
         hipLaunchKernelGGL(iba_he_kernel, dim3((B * h->n_frames + 63) / 64), dim3(64), 0, st, dp, d_cands, B, h->d_he.p);
         HIP_TRY(h, hipGetLastError());
@@ -265,7 +285,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->cell_start.release(); h->cell_kp.release(); h->bitmap.release(); h->cell_uv.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
@@ -355,6 +375,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         h->maxBitmapWords = std::max<uint32_t>(h->maxBitmapWords, (uint32_t)fb[lf].grid.bitmap.size());
     }
     h->n_points = 0; for (auto& x : hdr) h->n_points += x.P;
+    h->n_pt_total = (int64_t)pt_base;
     h->n_keypoints = (int64_t)kp_base;
     h->h_kp_off.resize(nf + 1); for (int lf = 0; lf < nf; ++lf) h->h_kp_off[lf] = hdr[lf].kp_base; h->h_kp_off[nf] = kp_base;
 
@@ -645,7 +666,7 @@ iba_status iba_build_problem(iba_handle* h, const double* x) {
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
-    s = launch_frame<MODE_ASSOC>(h, dc, 1, h->d_frame_partials.p, nullptr, h->d_assoc_frozen.p, h->n_frames, h->stream); if (s != IBA_OK) return s;
+    s = launch_frame<MODE_ASSOC>(h, dc, 1, h->d_frame_partials.p, nullptr, h->d_assoc_frozen.p, h->n_frames, h->stream, 0); if (s != IBA_OK) return s;
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_frame_partials.p, h->n_frames, h->d_partials.p);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, h->stream));

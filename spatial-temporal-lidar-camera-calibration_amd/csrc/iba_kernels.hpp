@@ -47,6 +47,10 @@ struct DevProblem {
     const PlaneRec* plane_local;  // (neigh_radius / neigh_max_pts)
     int32_t n_frames;
     int64_t n_kp_total;
+    // plane_cache = 0: per-candidate plane records refitted inside every evaluation (slot 0 = frozen problem)
+    PlaneRec* scratch_cost; PlaneRec* scratch_local;
+    int64_t n_pt_total;
+    int32_t scratch_slot_base;
 };
 
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
@@ -758,6 +762,23 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         n_corr = block_count(wc, s_wcnt);
     }
 
+    // local-plane records: memoised per scan point (plane_cache = 1) or refitted for exactly the points this
+    // evaluation needs, as the reference does (plane_cache = 0), into this candidate's private scratch
+    const bool cached = prm.plane_cache != 0;
+    const size_t scr_off = (size_t)(dp.scratch_slot_base + b) * (size_t)dp.n_pt_total + h.pt_base;
+    const PlaneRec* planes_cost = cached ? dp.plane_cost + h.pt_base : dp.scratch_cost + scr_off;
+    const PlaneRec* planes_local = cached ? dp.plane_local + h.pt_base : dp.scratch_local + scr_off;
+    uint32_t* s_bpos = s_list + K;   // NN results of the 3d-3d work list (second half of the aliased region)
+    auto fit_points = [&](const uint32_t* list, uint32_t count, double r2, int max_pts, PlaneRec* dst) {
+        for (uint32_t i = (uint32_t)wave; i < count; i += kWaves) {   // one wave per point: kNN + covariance + eigen
+            const uint32_t pos = list[i];
+            if (pos == kNone) continue;
+            const PlaneRec rec = plane_fit_wave(c.xs, c.ys, c.zs, s_nodes, P, D, pos, r2, max_pts);
+            if (lane == 0) dst[pos] = rec;
+        }
+        __syncthreads();
+    };
+
     bool used_assoc = false;
     if (MODE == MODE_ASSOC || MODE == MODE_BOTH) {
         // ---- BuildProblem association (iba_local.cpp:145-323): which residual blocks exist at this x ----
@@ -765,7 +786,15 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         const bool used = !((int)n_corr < prm.num_min_corr);   // iba_local.cpp:192
         used_assoc = used;
         if (MODE == MODE_ASSOC && tid < kPartialStride) part[tid] = (used && tid == P_FRAMES_N) ? 1.0 : ((used && tid == P_NCORR_N) ? (double)n_corr : 0.0);
-        const PlaneRec* planes = dp.plane_local + h.pt_base;
+        const PlaneRec* planes = planes_local;
+        if (!cached && used) {   // ComputeLocalNeighbor at every matched scan point (iba_local.cpp:207)
+            uint32_t n0 = 0;
+            for (uint32_t k = tid; k < Kceil; k += kThreads) {
+                const uint32_t orig = k < K ? s_best_idx[k] : kNone;
+                ordered_append(orig != kNone, orig != kNone ? inv_perm[orig] : kNone, n0, s_list, s_wcnt);
+            }
+            fit_points(s_list, n0, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
+        }
         for (uint32_t k = tid; k < Kceil; k += kThreads) {
             bool want3 = false;
             if (k < K) {
@@ -788,33 +817,40 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             ordered_append(want3, k, n3, s_list, s_wcnt);
         }
         // MapPoint -> LiDAR frame (iba_local.cpp:238-239, 282), 1-NN, local plane at the NN (pointcloud.h:699-717)
+        auto q_assoc = [&](uint32_t k, double& qx, double& qy, double& qz) {
+            const float4 mp = kp_mp[k];
+            const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+            const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
+            const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
+            const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
+            const double sx = mx * s, sy = my * s, sz = mz * s;
+            qx = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
+            qy = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
+            qz = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
+        };
         auto assoc_3d3d = [&](auto GT) {
             constexpr int G = decltype(GT)::value;
             for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
-                const uint32_t k = s_list[i];
-                const float4 mp = kp_mp[k];
-                const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
-                const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
-                const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
-                const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
-                const double sx = mx * s, sy = my * s, sz = mz * s;
-                const double qx = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
-                const double qy = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
-                const double qz = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
+                double qx, qy, qz; q_assoc(s_list[i], qx, qy, qz);
                 double best; uint32_t bpos;
                 nn_search_group<G>(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
-                if ((tid & (G - 1)) == 0 && !(best > prm.max_3d_dist2)) {   // :289
-                    const PlaneRec r2 = planes[bpos];
-                    const bool state = !(r2.k < prm.neigh_min_pts || r2.far_d2 < prm.local_min_diff_dist2) &&
-                                       (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);
-                    arow[k].y = bpos | (state ? 0x80000000u : 0u);
-                }
+                if ((tid & (G - 1)) == 0) s_bpos[i] = (best > prm.max_3d_dist2) ? kNone : bpos;   // :289
             }
         };
         if (n3 * 8u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 8>());
         else if (n3 * 4u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 4>());
         else if (n3 * 2u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 2>());
         else assoc_3d3d(std::integral_constant<int, 1>());
+        __syncthreads();
+        if (!cached) fit_points(s_bpos, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
+        for (uint32_t i = tid; i < n3; i += kThreads) {
+            const uint32_t bpos = s_bpos[i];
+            if (bpos == kNone) continue;
+            const PlaneRec r2 = planes[bpos];
+            const bool state = !(r2.k < prm.neigh_min_pts || r2.far_d2 < prm.local_min_diff_dist2) &&
+                               (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);
+            arow[s_list[i]].y = bpos | (state ? 0x80000000u : 0u);
+        }
         if (MODE == MODE_ASSOC) return;
         __syncthreads();   // s_list is reused by the cost path below
         n3 = 0;
@@ -876,67 +912,49 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
 #endif
     if (prm.use_3d3d) {
         const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
+        auto q_cost = [&](uint32_t k, double& qx, double& qy, double& qz) {
+            const float4 mp = kp_mp[k];
+            const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;   // CV_32F product (:232)
+            const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
+            const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
+            const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
+            const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
+            qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
+            qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
+            qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+        };
         auto cost_3d3d = [&](auto GT) {
             constexpr int G = decltype(GT)::value;
-#ifdef IBA_STAMPS
-            unsigned long long tt0 = __builtin_readcyclecounter(), tt1, tpre = 0, tsearch = 0, tpost = 0;
-#endif
             for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
-                const uint32_t k = s_list[i];
-                const float4 mp = kp_mp[k];
-                const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;   // CV_32F product (:232)
-                const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
-                const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
-                const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
-                const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
-                const double qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
-                const double qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
-                const double qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
-#ifdef IBA_STAMPS
-                tt1 = __builtin_readcyclecounter(); tpre += tt1 - tt0; tt0 = tt1;
-#endif
+                double qx, qy, qz; q_cost(s_list[i], qx, qy, qz);
                 double best; uint32_t bpos;
-#if defined(IBA_EXP) && IBA_EXP == 1
-                best = qx * qx; bpos = (uint32_t)(fabs(qy) * 10.0) % P;
-#else
                 nn_search_group<G>(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
-#endif
-#ifdef IBA_STAMPS
-                tt1 = __builtin_readcyclecounter(); tsearch += tt1 - tt0; tt0 = tt1;
-#endif
-                if ((tid & (G - 1)) != 0) continue;
-                double dist = sqrt(best);   // (nn_pt - query_pt).norm()  (:122)
-                bool is_plane = false;
-#if defined(IBA_EXP) && IBA_EXP == 2
-                if (false) {
-#else
-                if (prm.use_plane) {
-#endif
-                    const PlaneRec rec = dp.plane_cost[h.pt_base + bpos];
-                    if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
-                        !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
-                        const double ax = (double)c.xs[bpos] - qx, ay = (double)c.ys[bpos] - qy, az = (double)c.zs[bpos] - qz;
-                        dist = fabs(ax * rec.nx + ay * rec.ny + az * rec.nz);
-                        is_plane = true;
-                    }
-                }
-                if (dist < prm.corr_3d_3d_threshold) { sum3d += dist; ++v3; if (is_plane) ++vpl; else ++vpt; }
-                ++c3;
-#ifdef IBA_STAMPS
-                tt1 = __builtin_readcyclecounter(); tpost += tt1 - tt0; tt0 = tt1;
-#endif
+                if ((tid & (G - 1)) == 0) s_bpos[i] = bpos;
             }
-#ifdef IBA_STAMPS
-            if (lane == 0) { atomicAdd(&g_dbg[8 + wave], tsearch); atomicAdd(&g_dbg[24 + wave], tpre); atomicAdd(&g_dbg[40 + wave], tpost); }
-#endif
         };
-#ifdef IBA_STAMPS
-        if (tid == 0) atomicAdd(&g_dbg[3], (unsigned long long)n3);
-#endif
         if (n3 * 8u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 8>());
         else if (n3 * 4u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 4>());
         else if (n3 * 2u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 2>());
         else cost_3d3d(std::integral_constant<int, 1>());
+        __syncthreads();
+        if (!cached && prm.use_plane) fit_points(s_bpos, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);   // iba_global.cpp:125-147
+        for (uint32_t i = tid; i < n3; i += kThreads) {
+            const uint32_t bpos = s_bpos[i];
+            double qx, qy, qz; q_cost(s_list[i], qx, qy, qz);
+            const double ax = (double)c.xs[bpos] - qx, ay = (double)c.ys[bpos] - qy, az = (double)c.zs[bpos] - qz;
+            double dist = sqrt((ax * ax + ay * ay) + az * az);   // (nn_pt - query_pt).norm()  (:122)
+            bool is_plane = false;
+            if (prm.use_plane) {
+                const PlaneRec rec = planes_cost[bpos];
+                if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
+                    !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
+                    dist = fabs(ax * rec.nx + ay * rec.ny + az * rec.nz);
+                    is_plane = true;
+                }
+            }
+            if (dist < prm.corr_3d_3d_threshold) { sum3d += dist; ++v3; if (is_plane) ++vpl; else ++vpt; }
+            ++c3;
+        }
     }
 
 #ifdef IBA_STAMPS
@@ -1141,6 +1159,8 @@ __global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem d
     for (int i = 0; i < 7; ++i) A.b[i] = 0;
     A.chi2 = A.cost = A.nf2d = A.nfpl = A.nfpt = A.nres = 0;
     const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
+    const PlaneRec* planes = prm.plane_cache ? dp.plane_local + h.pt_base
+                                             : dp.scratch_local + (size_t)(assoc_per_cand ? dp.scratch_slot_base + b : 0) * (size_t)dp.n_pt_total + h.pt_base;
     // entry i of the concatenated wave segments
     auto entry = [&](const uint32_t* list, int which, uint32_t i, uint32_t& k) -> bool {
         for (int w = 0; w < NW; ++w) { const uint32_t n = s_cnt[which][w]; if (i < n) { k = list[w * seg + i]; return true; } i -= n; }
@@ -1150,7 +1170,7 @@ __global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem d
         uint32_t k;
         if (!entry(s_lp, 0, i, k)) break;
         const uint2 a = arow[k];
-        const PlaneRec rec = dp.plane_local[h.pt_base + a.x];
+        const PlaneRec rec = planes[a.x];
         const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]}, n0[3] = {rec.nx, rec.ny, rec.nz};
         const float2 uv = dp.kp_uv[h.kp_base + k];
         plane_factor_accum(c, h, dp, prm, k, K, (double)uv.x, (double)uv.y, p0, n0, A);
@@ -1160,7 +1180,7 @@ __global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem d
         if (!entry(s_l3, 1, i, k)) break;
         const uint2 a = arow[k];
         const uint32_t pos = a.y & 0x7FFFFFFFu; const bool is_plane = (a.y >> 31) != 0;
-        const PlaneRec rec = dp.plane_local[h.pt_base + pos];
+        const PlaneRec rec = planes[pos];
         const double Q[3] = {(double)xs[pos], (double)ys[pos], (double)zs[pos]}, n[3] = {rec.nx, rec.ny, rec.nz};
         p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, n, is_plane, A);
     }
@@ -1198,8 +1218,9 @@ __global__ __launch_bounds__(64) void iba_residual_kernel(DevProblem dp, DevPara
     if (row < 0) return;
     const Cand& c = cands[0];
     const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
+    const PlaneRec* planes = prm.plane_cache ? dp.plane_local + h.pt_base : dp.scratch_local + h.pt_base;   // slot 0 = frozen problem
     if (a.x != kNone) {
-        const PlaneRec rec = dp.plane_local[h.pt_base + a.x];
+        const PlaneRec rec = planes[a.x];
         const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]}, n0[3] = {rec.nx, rec.ny, rec.nz};
         const float2 uv = dp.kp_uv[h.kp_base + k];
         double z6[6];
@@ -1214,7 +1235,7 @@ __global__ __launch_bounds__(64) void iba_residual_kernel(DevProblem dp, DevPara
     }
     if (a.y != kNone) {
         const uint32_t pos = a.y & 0x7FFFFFFFu; const bool is_plane = (a.y >> 31) != 0;
-        const PlaneRec rec = dp.plane_local[h.pt_base + pos];
+        const PlaneRec rec = planes[pos];
         double M[3], dM[7][3];
         p2x_core(c, h, dp.kp_mp[h.kp_base + k], M, dM);
         const double e[3] = {M[0] - (double)xs[pos], M[1] - (double)ys[pos], M[2] - (double)zs[pos]};
