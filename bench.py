@@ -47,15 +47,27 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the plane-refit throughput and the LM calibration (profiling runs)")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
+
+    def stage(msg):
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("[bench %7.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
     import torch
     import torch.distributed as dist
+    stage("torch imported")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("IBA_FORCE_DIST"))   # IBA_FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    stage("process group ready" if use_dist else "single process")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -69,6 +81,7 @@ def main():
     params = abi.reference_yaml_params(plane_cache=args.plane_cache)
     f0, f1 = rank * args.frames, (rank + 1) * args.frames
     h = pkg.IbaHandle(prob, params, device=local_rank, frame_begin=f0, frame_end=f1)
+    stage("scene generated, handle created (static indices + plane memo)")
     h.set_timing(True)
     stride = pkg.partial_stride()
     B = args.batch
@@ -81,30 +94,32 @@ def main():
         xs = xs_all[i % len(xs_all)]
         st = torch.cuda.current_stream().cuda_stream
         h.eval_full_partial(xs, d_cost.data_ptr(), st)   # cost tuple + normal equations from one pass over the scans
-        if world > 1:   # frames shard across ranks: ONE sum all-reduce of the partial blocks (RCCL over xGMI)
+        if use_dist:   # frames shard across ranks: ONE sum all-reduce of the partial blocks (RCCL over xGMI)
             dist.all_reduce(d_cost)
         pc = d_cost.cpu().numpy()
         return pkg.finalize_cost(params, pc), pkg.finalize_normal(params, pc)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         out = step(i)
     sync()
+    stage("warmup done")
     t0 = time.perf_counter()
     kms = []
     for i in range(args.steps):
         out = step(i)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    stage("timed steps done")
     # ---- dominant kernel (fused frame kernel), timed with HIP events on its launch stream ----
     xs = xs_all[0]
     kms = []
@@ -162,12 +177,12 @@ def main():
         nrep = 5
         for i in range(nrep):
             h.eval_full_partial(xs_all[i % len(xs_all)], d_cost.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(d_cost)
             d_cost.cpu()
         sync()
         t_other = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([t_other], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_other = float(t.item())
@@ -192,6 +207,7 @@ def main():
         except Exception:
             pass
 
+    stage("extras done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (a port of the reference algorithm) on this box's host cores ----
         from oracle import binding as ob
@@ -218,7 +234,7 @@ def main():
     if rank == 0:
         print(json.dumps(res))
     h.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
