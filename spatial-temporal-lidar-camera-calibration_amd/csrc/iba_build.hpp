@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -70,10 +71,11 @@ inline void build_tree(const float* xyz, uint32_t P, uint32_t D, std::vector<uin
 
 struct KpGrid {
     uint32_t gw = 0, gh = 0;
-    std::vector<uint32_t> cell_start;   // gw*gh + 1
-    std::vector<uint32_t> cell_kp;      // K keypoint ids, sorted by (cell, id)
-    std::vector<float> cell_uv;         // K x 2, same order
-    std::vector<uint32_t> bitmap;       // 1 bit per cell: some keypoint within `margin` (L-inf) of the cell
+    std::vector<uint32_t> bitmap;       // 1 bit per 4-px cell: some keypoint within `margin` (L-inf) of the cell
+    // coarse CSR (16-px cells = 4x4 fine cells): small enough (~4 KB as u16) to live in LDS during the lookups
+    uint32_t gwc = 0, ghc = 0;
+    std::vector<uint32_t> coarse_start; // gwc*ghc + 1
+    std::vector<float> crec;            // K x 4: u, v, bit pattern of the keypoint id, 0 — sorted by (coarse cell, id)
 };
 
 // cell coordinate of a pixel coordinate: one cell of padding on the low side, clamped
@@ -86,19 +88,22 @@ inline void build_kp_grid(const float* uv, uint32_t K, double W, double H, doubl
     g.gw = (uint32_t)std::ceil(W / kGridCell) + 3;
     g.gh = (uint32_t)std::ceil(H / kGridCell) + 3;
     const size_t nc = (size_t)g.gw * g.gh;
-    g.cell_start.assign(nc + 1, 0);
+    g.gwc = (g.gw + 3) >> 2; g.ghc = (g.gh + 3) >> 2;
+    const size_t ncc = (size_t)g.gwc * g.ghc;
+    g.coarse_start.assign(ncc + 1, 0);
     std::vector<uint32_t> cell_of(K);
     for (uint32_t k = 0; k < K; ++k) {
-        const int cxi = grid_cell(uv[2 * k], (int)g.gw), cyi = grid_cell(uv[2 * k + 1], (int)g.gh);
-        cell_of[k] = (uint32_t)cyi * g.gw + (uint32_t)cxi;
-        g.cell_start[cell_of[k] + 1]++;
+        const int cxi = grid_cell(uv[2 * k], (int)g.gw) >> 2, cyi = grid_cell(uv[2 * k + 1], (int)g.gh) >> 2;
+        cell_of[k] = (uint32_t)cyi * g.gwc + (uint32_t)cxi;
+        g.coarse_start[cell_of[k] + 1]++;
     }
-    for (size_t c = 0; c < nc; ++c) g.cell_start[c + 1] += g.cell_start[c];
-    g.cell_kp.resize(K); g.cell_uv.resize(2 * (size_t)K);
-    std::vector<uint32_t> fill(g.cell_start.begin(), g.cell_start.end() - 1);
+    for (size_t c = 0; c < ncc; ++c) g.coarse_start[c + 1] += g.coarse_start[c];
+    g.crec.assign(4 * (size_t)K, 0.f);
+    std::vector<uint32_t> fill(g.coarse_start.begin(), g.coarse_start.end() - 1);
     for (uint32_t k = 0; k < K; ++k) {   // ascending k => ids sorted inside each cell
         const uint32_t e = fill[cell_of[k]]++;
-        g.cell_kp[e] = k; g.cell_uv[2 * e] = uv[2 * k]; g.cell_uv[2 * e + 1] = uv[2 * k + 1];
+        float idf; std::memcpy(&idf, &k, 4);
+        g.crec[4 * (size_t)e] = uv[2 * k]; g.crec[4 * (size_t)e + 1] = uv[2 * k + 1]; g.crec[4 * (size_t)e + 2] = idf;
     }
     g.bitmap.assign((nc + 31) / 32, 0u);
     const float m = (float)margin;

@@ -57,14 +57,14 @@ struct iba_handle {
     bool timing = false, timing_recorded = false;
     float last_frame_ms = 0.f, last_total_ms = 0.f;
     int64_t n_points = 0, n_keypoints = 0;
-    uint32_t maxP = 0, maxPpad = 0, maxK = 0, maxNodes = 0, maxBitmapWords = 0;
+    uint32_t maxP = 0, maxPpad = 0, maxK = 0, maxNodes = 0, maxBitmapWords = 0, maxCoarse = 0;
     bool scan_lds = false;
     LdsLayout lay{};
 
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
     DevBuf<float> xs, ys, zs; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
     DevBuf<float2> kp_uv; DevBuf<float4> kp_mp;
-    DevBuf<uint32_t> cell_start, cell_kp, bitmap; DevBuf<float2> cell_uv;
+    DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
     DevBuf<PlaneRec> plane_cost, plane_local;
     DevBuf<PlaneRec> scratch_cost, scratch_local;   // plane_cache = 0: (scratch_cap + 1) x n_pt_total records
@@ -94,7 +94,7 @@ struct iba_handle {
     DevProblem dev_problem() const {
         DevProblem dp{};
         dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p;
-        dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.cell_start = cell_start.p; dp.cell_kp = cell_kp.p; dp.cell_uv = cell_uv.p;
+        dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.coarse_start = coarse_start.p; dp.crec = crec.p;
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
@@ -158,6 +158,7 @@ bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
     L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
     off = align_up(off, 8); L.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
     L.off_bitmap = off; off += 4u * std::max(h->maxBitmapWords, 1u);
+    L.off_cstart = off; off += 2u * std::max(h->maxCoarse, 1u);
     off = align_up(off, 8); L.off_red = off; off += red_bytes;
     off = align_up(off, 16); L.off_cand = off;
     if (off + 1024u > kLdsBytes) return false;
@@ -284,7 +285,7 @@ void iba_destroy(iba_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release();
-    h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->cell_start.release(); h->cell_kp.release(); h->bitmap.release(); h->cell_uv.release();
+    h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
     h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -321,7 +322,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     // ---- validation of the owned slice ----
     for (int f = frame_begin; f < frame_end; ++f) {
         const uint64_t P = d->pt_offset[f + 1] - d->pt_offset[f], K = d->kp_offset[f + 1] - d->kp_offset[f];
-        if (P >= (1ull << 24) || K >= (1ull << 20)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan or keypoint count too large"); }
+        if (P >= (1ull << 24) || K >= 65535ull) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan (>= 2^24 points) or keypoint count (>= 65535) too large"); }
         const uint64_t ns = d->covis_offset[f + 1] - d->covis_offset[f];
         if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 10 covisible keyframes per frame"); }
     }
@@ -355,14 +356,16 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
 
     // ---- flatten ----
     std::vector<FrameHdr>& hdr = h->h_frames; hdr.resize(nf);
-    uint64_t pt_base = 0, kp_base = 0, cell_base = 0, bm_base = 0, match_base = 0; uint32_t node_base = 0, slot_base = 0;
+    uint64_t pt_base = 0, kp_base = 0, coarse_base = 0, bm_base = 0, match_base = 0; uint32_t node_base = 0, slot_base = 0;
     for (int lf = 0; lf < nf; ++lf) {
         const int f = frame_begin + lf;
         FrameHdr& x = hdr[lf]; std::memset(&x, 0, sizeof(x));
         x.P = (uint32_t)(d->pt_offset[f + 1] - d->pt_offset[f]); x.Ppad = (x.P + 3u) & ~3u; x.pt_base = pt_base; pt_base += x.Ppad;
         x.depth = fb[lf].D; x.node_base = node_base; node_base += (uint32_t)fb[lf].nodes.size();
         x.K = (uint32_t)(d->kp_offset[f + 1] - d->kp_offset[f]); x.kp_base = kp_base; kp_base += x.K;
-        x.gw = fb[lf].grid.gw; x.gh = fb[lf].grid.gh; x.cell_base = cell_base; cell_base += (uint64_t)x.gw * x.gh + 1;
+        x.gw = fb[lf].grid.gw; x.gh = fb[lf].grid.gh; x.gwc = fb[lf].grid.gwc; x.ghc = fb[lf].grid.ghc;
+        x.coarse_base = coarse_base; coarse_base += (uint64_t)x.gwc * x.ghc + 1;
+        h->maxCoarse = std::max<uint32_t>(h->maxCoarse, x.gwc * x.ghc + 1);
         x.bitmap_base = bm_base; bm_base += fb[lf].grid.bitmap.size();
         x.n_slots = (uint32_t)(d->covis_offset[f + 1] - d->covis_offset[f]); x.slot_base = slot_base; slot_base += x.n_slots;
         x.match_base = match_base; match_base += (uint64_t)x.n_slots * x.K;
@@ -383,9 +386,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     std::vector<float> xs(pt_base, qnan), ys(pt_base, qnan), zs(pt_base, qnan);
     std::vector<uint32_t> perm(pt_base, 0u), inv_perm(pt_base, 0u);
     std::vector<TreeNode> nodes(node_base);
-    std::vector<float2> kp_uv(kp_base), cell_uv(kp_base); std::vector<float4> kp_mp(kp_base);
+    std::vector<float2> kp_uv(kp_base); std::vector<float4> kp_mp(kp_base), crec(kp_base);
     std::vector<uint32_t>& kp_ext = h->h_kp_ext; kp_ext.resize(kp_base);
-    std::vector<uint32_t> cell_start(cell_base), cell_kp(kp_base), bitmap(bm_base);
+    std::vector<uint32_t> coarse_start(coarse_base), bitmap(bm_base);
     std::vector<float2> match_uv(match_base, float2{qnan, qnan});
     std::vector<SlotHdr> slots(slot_base);
     std::atomic<bool> bad_match(false);
@@ -405,10 +408,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
             kp_uv[x.kp_base + k] = float2{d->kp_uv[2 * e], d->kp_uv[2 * e + 1]};
             const bool has = d->kp_has_mappoint[e] != 0;
             kp_mp[x.kp_base + k] = has ? float4{d->kp_mappoint_w[3 * e], d->kp_mappoint_w[3 * e + 1], d->kp_mappoint_w[3 * e + 2], 1.0f} : float4{0.f, 0.f, 0.f, 0.f};
-            cell_kp[x.kp_base + k] = b.grid.cell_kp[k];
-            cell_uv[x.kp_base + k] = float2{b.grid.cell_uv[2 * k], b.grid.cell_uv[2 * k + 1]};
+            crec[x.kp_base + k] = float4{b.grid.crec[4 * (size_t)k], b.grid.crec[4 * (size_t)k + 1], b.grid.crec[4 * (size_t)k + 2], 0.f};
         }
-        std::copy(b.grid.cell_start.begin(), b.grid.cell_start.end(), cell_start.begin() + x.cell_base);
+        std::copy(b.grid.coarse_start.begin(), b.grid.coarse_start.end(), coarse_start.begin() + x.coarse_base);
         std::copy(b.grid.bitmap.begin(), b.grid.bitmap.end(), bitmap.begin() + x.bitmap_base);
         for (uint32_t sl = 0; sl < x.n_slots; ++sl) {
             const uint64_t gs = d->covis_offset[f] + sl;
@@ -433,7 +435,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
 #define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
     UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes);
-    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(cell_start, cell_start); UP(cell_kp, cell_kp); UP(cell_uv, cell_uv); UP(bitmap, bitmap); UP(match_uv, match_uv);
+    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv);
 #undef UP
     hipError_t er;
     if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);

@@ -41,7 +41,7 @@ struct DevProblem {
     const TreeNode* nodes;
     const float2* kp_uv;
     const float4* kp_mp;       // MapPoint world position (x,y,z), w = 1 if the keypoint owns one
-    const uint32_t* cell_start; const uint32_t* cell_kp; const float2* cell_uv; const uint32_t* bitmap;
+    const uint32_t* coarse_start; const float4* crec; const uint32_t* bitmap;   // keypoint grid (see iba_build.hpp)
     const float2* match_uv;    // [slot][K] matched covisible keypoint, NaN = no match
     const PlaneRec* plane_cost;   // x-independent plane records (norm_radius / norm_max_pts)
     const PlaneRec* plane_local;  // (neigh_radius / neigh_max_pts)
@@ -55,7 +55,7 @@ struct DevProblem {
 
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
     uint32_t scan_stride;   // floats per coordinate array (0 = scan not staged in LDS)
-    uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_red, off_cand, cand_cap, total;
+    uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_cstart, off_red, off_cand, cand_cap, total;
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -382,7 +382,8 @@ struct FrameCtx {   // wave-uniform per-block context
     const TreeNode* nodes;                               // LDS
     const uint32_t* bitmap;                              // LDS
     unsigned long long* best_d2; uint32_t* best_idx;     // LDS
-    const uint32_t* cell_start; const uint32_t* cell_kp; const float2* cell_uv;   // HBM, frame-relative
+    const uint16_t* cstart; int gwc;     // coarse CSR starts (LDS)
+    const float4* crec;                  // HBM, frame-relative: (u, v, id bits, 0) sorted by coarse cell
     const uint32_t* perm;                                // HBM, frame-relative
     int gw, gh;
     float margin;
@@ -413,17 +414,18 @@ __device__ __forceinline__ bool near_keypoint(const FrameCtx& c, double u, doubl
 template <int PASS>
 __device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v, uint32_t pos) {
     const float uf = (float)u, vf = (float)v;
-    const int x0 = grid_cell(uf - c.margin, c.gw), x1 = grid_cell(uf + c.margin, c.gw);
-    const int y0 = grid_cell(vf - c.margin, c.gh), y1 = grid_cell(vf + c.margin, c.gh);
+    const int x0 = grid_cell(uf - c.margin, c.gw) >> 2, x1 = grid_cell(uf + c.margin, c.gw) >> 2;
+    const int y0 = grid_cell(vf - c.margin, c.gh) >> 2, y1 = grid_cell(vf + c.margin, c.gh) >> 2;
     bool hit = false;
     for (int yy = y0; yy <= y1; ++yy) {
-        const uint32_t e0 = c.cell_start[yy * c.gw + x0], e1 = c.cell_start[yy * c.gw + x1 + 1];
+        const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
         for (uint32_t e = e0; e < e1; ++e) {
-            const float2 kuv = c.cell_uv[e];
-            const double du = (double)kuv.x - u, dv = (double)kuv.y - v;
+            const float4 rec = c.crec[e];
+            if (fabsf(rec.x - uf) > c.margin || fabsf(rec.y - vf) > c.margin) continue;   // cheap f32 reject (margin has 0.01 px slack)
+            const double du = (double)rec.x - u, dv = (double)rec.y - v;
             const double d2 = du * du + dv * dv;
             if (d2 <= c.gate2) {
-                const uint32_t k = c.cell_kp[e];
+                const uint32_t k = __float_as_uint(rec.z);
                 if (PASS == 1) { atomicMin(&c.best_d2[k], d2bits(d2)); hit = true; }
                 else if (c.best_d2[k] == d2bits(d2)) atomicMin(&c.best_idx[k], c.perm[pos]);
             }
@@ -436,17 +438,18 @@ __device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v
 // pass needs no second grid walk. Returns the number of hits (a third hit is counted but not stored).
 __device__ __forceinline__ int grid_match_rec(const FrameCtx& c, double u, double v, uint32_t& k0, unsigned long long& d0, uint32_t& k1, unsigned long long& d1) {
     const float uf = (float)u, vf = (float)v;
-    const int x0 = grid_cell(uf - c.margin, c.gw), x1 = grid_cell(uf + c.margin, c.gw);
-    const int y0 = grid_cell(vf - c.margin, c.gh), y1 = grid_cell(vf + c.margin, c.gh);
+    const int x0 = grid_cell(uf - c.margin, c.gw) >> 2, x1 = grid_cell(uf + c.margin, c.gw) >> 2;
+    const int y0 = grid_cell(vf - c.margin, c.gh) >> 2, y1 = grid_cell(vf + c.margin, c.gh) >> 2;
     int nh = 0;
     for (int yy = y0; yy <= y1; ++yy) {
-        const uint32_t e0 = c.cell_start[yy * c.gw + x0], e1 = c.cell_start[yy * c.gw + x1 + 1];
+        const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
         for (uint32_t e = e0; e < e1; ++e) {
-            const float2 kuv = c.cell_uv[e];
-            const double du = (double)kuv.x - u, dv = (double)kuv.y - v;
+            const float4 rec = c.crec[e];
+            if (fabsf(rec.x - uf) > c.margin || fabsf(rec.y - vf) > c.margin) continue;
+            const double du = (double)rec.x - u, dv = (double)rec.y - v;
             const double d2 = du * du + dv * dv;
             if (d2 <= c.gate2) {
-                const uint32_t k = c.cell_kp[e];
+                const uint32_t k = __float_as_uint(rec.z);
                 atomicMin(&c.best_d2[k], d2bits(d2));
                 if (nh == 0) { k0 = k; d0 = d2bits(d2); } else if (nh == 1) { k1 = k; d1 = d2bits(d2); }
                 ++nh;
@@ -460,53 +463,94 @@ __device__ __forceinline__ int grid_match_rec(const FrameCtx& c, double u, doubl
 #ifdef IBA_STAMPS
 __device__ unsigned long long g_dbg[64];
 #endif
-template <int G>
-__device__ __forceinline__ void nn_search_group(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+// ---- exact 1-NN with G lanes per query (G = 1,2,4,8; run-time so that ONE copy of the traversal exists) ----
+// The G lanes walk the tree in lockstep and split each leaf. The descent keeps the visited path in registers
+// (split value per level, 2-bit dim, side and done bits), so backtracking — otherwise a chain of dependent LDS
+// reads, one per tree level — is pure VALU: the deepest unfinished level whose split plane is within the current
+// best distance is found with an unrolled scan, its far child is entered, and only the levels below are fetched.
+constexpr int kPathMax = 16;   // deeper trees (> 1.5 M points per scan) use the generic LDS-walking branch
+__device__ __forceinline__ void nn_search_group(int G, const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
                                                 const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
                                                 double qx, double qy, double qz, double& best, uint32_t& bpos) {
-    if (G == 1) { nn_search(xs, ys, zs, nodes, perm_g, P, D, qx, qy, qz, best, bpos); return; }
-    const uint32_t sub = threadIdx.x & (G - 1);
+    const uint32_t sub = threadIdx.x & (uint32_t)(G - 1);
     best = INFINITY; bpos = kNone;
-    uint32_t node = 0, depth = 0;
     const uint32_t first_leaf = (1u << D) - 1u;
-    for (;;) {
-        {
+    auto scan_leaf = [&](uint32_t node) {
+        const uint32_t j = node - first_leaf;
+        const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+#pragma unroll 2
+        for (uint32_t i = lo + sub; i < hi; i += G) {
+            const double dx = qx - (double)xs[i], dy = qy - (double)ys[i], dz = qz - (double)zs[i];
+            const double d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < best) { best = d2; bpos = i; }
+            else if (d2 == best && bpos != kNone) { if (perm_g[i] < perm_g[bpos]) bpos = i; }
+        }
+        for (int off = 1; off < G; off <<= 1) {
+            const double od = __shfl_xor(best, off); const uint32_t op = __shfl_xor(bpos, off);
+            if (od < best) { best = od; bpos = op; }
+            else if (od == best && op != kNone && op != bpos) { if (bpos == kNone || perm_g[op] < perm_g[bpos]) bpos = op; }
+        }
+    };
+    if (D > (uint32_t)kPathMax) {   // generic branch: ancestors are re-read from the node array on the way up
+        uint32_t node = 0, depth = 0;
+        for (;;) {
             while (depth < D) {
                 const TreeNode n = nodes[node];
                 const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
                 node = 2u * node + 1u + ((qd - (double)n.split) >= 0.0 ? 1u : 0u);
                 ++depth;
             }
-            const uint32_t j = node - first_leaf;
-            const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
-#pragma unroll 2
-            for (uint32_t i = lo + sub; i < hi; i += G) {
-                const double dx = qx - (double)xs[i], dy = qy - (double)ys[i], dz = qz - (double)zs[i];
-                const double d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 < best) { best = d2; bpos = i; }
-                else if (d2 == best && bpos != kNone) { if (perm_g[i] < perm_g[bpos]) bpos = i; }
+            scan_leaf(node);
+            bool go = false;
+            while (depth > 0) {
+                const uint32_t parent = (node - 1u) >> 1;
+                const bool was_right = (node & 1u) == 0u;
+                const TreeNode n = nodes[parent];
+                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+                const double diff = qd - (double)n.split;
+                const bool near_right = diff >= 0.0;
+                if (was_right == near_right && diff * diff <= best) { node = 2u * parent + 1u + (near_right ? 0u : 1u); go = true; break; }
+                node = parent; --depth;
             }
+            if (!go) break;
+        }
+        return;
+    }
+    float ps[kPathMax];
 #pragma unroll
-            for (int off = 1; off < G; off <<= 1) {
-                const double od = __shfl_xor(best, off); const uint32_t op = __shfl_xor(bpos, off);
-                if (od < best) { best = od; bpos = op; }
-                else if (od == best && op != kNone && op != bpos) { if (bpos == kNone || perm_g[op] < perm_g[bpos]) bpos = op; }
+    for (int L = 0; L < kPathMax; ++L) ps[L] = 0.f;
+    uint32_t dims = 0u, side = 0u, done = 0u;   // per level: 2-bit split dim; 1 = currently in the right child; 1 = far child handled
+    uint32_t node = 0u; int start = 0;
+    for (;;) {
+#pragma unroll
+        for (int L = 0; L < kPathMax; ++L) {
+            if (L >= start && L < (int)D) {
+                const TreeNode n = nodes[node];
+                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+                const uint32_t r = (qd - (double)n.split) >= 0.0 ? 1u : 0u;
+                ps[L] = n.split;
+                dims = (dims & ~(3u << (2 * L))) | (n.dim << (2 * L));
+                side = (side & ~(1u << L)) | (r << L);
+                done &= ~(1u << L);
+                node = 2u * node + 1u + r;
             }
         }
-        // climb in a tight loop until a far child can still hold a closer (or tying) point; lanes of a wave then
-        // re-converge once per leaf visit instead of once per tree level
-        bool go = false;
-        while (depth > 0) {
-            const uint32_t parent = (node - 1u) >> 1;
-            const bool was_right = (node & 1u) == 0u;
-            const TreeNode n = nodes[parent];
-            const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
-            const double diff = qd - (double)n.split;
-            const bool near_right = diff >= 0.0;
-            if (was_right == near_right && diff * diff <= best) { node = 2u * parent + 1u + (near_right ? 0u : 1u); go = true; break; }
-            node = parent; --depth;
+        scan_leaf(node);
+        int go = -1;
+#pragma unroll
+        for (int L = kPathMax - 1; L >= 0; --L) {
+            if (go < 0 && L < (int)D && !((done >> L) & 1u)) {
+                const uint32_t dm = (dims >> (2 * L)) & 3u;
+                const double qd = dm == 0 ? qx : (dm == 1 ? qy : qz);
+                const double diff = qd - (double)ps[L];
+                if (diff * diff <= best) go = L; else done |= 1u << L;   // best only shrinks: a failed level stays failed
+            }
         }
-        if (!go) break;
+        if (go < 0) break;
+        done |= 1u << go; side ^= 1u << go;
+        const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;   // ancestor of the current leaf at level `go`
+        node = 2u * anc + 1u + ((side >> go) & 1u);
+        start = go + 1;
     }
 }
 
@@ -594,6 +638,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     uint32_t* s_best_idx = (uint32_t*)(smem + lay.off_best_idx);
     TreeNode* s_nodes = (TreeNode*)(smem + lay.off_nodes);
     uint32_t* s_bitmap = (uint32_t*)(smem + lay.off_bitmap);
+    uint16_t* s_cstart = (uint16_t*)(smem + lay.off_cstart);
     double* s_red = (double*)(smem + lay.off_red);            // kWaves * 4 doubles / u64
     double* s_rel = s_red + kWaves * 4;                       // kMaxCovis * 12 doubles: relative poses of the covisible KFs
     uint32_t* s_wcnt = (uint32_t*)(s_rel + kMaxCovis * 12);
@@ -614,6 +659,8 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     for (uint32_t i = tid; i < nnodes; i += kThreads) s_nodes[i] = dp.nodes[h.node_base + i];
     const uint32_t nbw = (h.gw * h.gh + 31u) >> 5;
     for (uint32_t i = tid; i < nbw; i += kThreads) s_bitmap[i] = dp.bitmap[h.bitmap_base + i];
+    const uint32_t ncs = h.gwc * h.ghc + 1u;
+    for (uint32_t i = tid; i < ncs; i += kThreads) s_cstart[i] = (uint16_t)dp.coarse_start[h.coarse_base + i];
     if ((uint32_t)tid < h.n_slots * 12u) s_rel[tid] = dp.slots[h.slot_base + tid / 12].rel[tid % 12];
     if (tid < 2) s_misc[tid] = 0u;
     __syncthreads();
@@ -621,7 +668,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     FrameCtx c;
     c.xs = SCAN_LDS ? s_xs : gxs; c.ys = SCAN_LDS ? s_ys : gys; c.zs = SCAN_LDS ? s_zs : gzs;
     c.nodes = s_nodes; c.bitmap = s_bitmap; c.best_d2 = s_best_d2; c.best_idx = s_best_idx;
-    c.cell_start = dp.cell_start + h.cell_base; c.cell_kp = dp.cell_kp + h.kp_base; c.cell_uv = dp.cell_uv + h.kp_base;
+    c.cstart = s_cstart; c.gwc = (int)h.gwc; c.crec = dp.crec + h.kp_base;
     c.perm = dp.perm + h.pt_base;
     c.gw = (int)h.gw; c.gh = (int)h.gh; c.margin = (float)prm.grid_margin; c.gate2 = prm.gate2;
     c.fx = h.fx; c.cx = h.cx; c.cy = h.cy; c.W = h.W; c.H = h.H;
@@ -642,20 +689,22 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                     r6 = (float)c.R[6], r7 = (float)c.R[7], r8 = (float)c.R[8], t0 = (float)c.t[0], t1 = (float)c.t[1], t2 = (float)c.t[2];
         const float fxf = (float)c.fx, cxf = (float)c.cx, cyf = (float)c.cy, Wf = (float)c.W + 1.0f, Hf = (float)c.H + 1.0f;
         const uint32_t n_iter = (Ppad + kThreads * 4u - 1u) / (kThreads * 4u);
+        const float qn = __builtin_nanf("");
+        const float4 nan4 = make_float4(qn, qn, qn, qn);
+        float4 X = nan4, Y = nan4, Z = nan4;   // software pipeline: the next 16-byte loads are in flight while 4 points are tested
+        if ((uint32_t)tid * 4u < Ppad) { X = *(const float4*)(gxs + tid * 4); Y = *(const float4*)(gys + tid * 4); Z = *(const float4*)(gzs + tid * 4); }
         for (uint32_t it = 0; it < n_iter; ++it) {
             const uint32_t base = (uint32_t)tid * 4u + it * (kThreads * 4u);
-            const float qn = __builtin_nanf("");
-            float px[4] = {qn, qn, qn, qn}, py[4] = {qn, qn, qn, qn}, pz[4] = {qn, qn, qn, qn};
-            if (base < Ppad) {
-                const float4 X = *(const float4*)(gxs + base), Y = *(const float4*)(gys + base), Z = *(const float4*)(gzs + base);
-                if (SCAN_LDS) { *(float4*)(s_xs + base) = X; *(float4*)(s_ys + base) = Y; *(float4*)(s_zs + base) = Z; }
-                px[0] = X.x; px[1] = X.y; px[2] = X.z; px[3] = X.w; py[0] = Y.x; py[1] = Y.y; py[2] = Y.z; py[3] = Y.w;
-                pz[0] = Z.x; pz[1] = Z.y; pz[2] = Z.z; pz[3] = Z.w;
-            }
+            const uint32_t nbase = base + kThreads * 4u;
+            float4 Xn = nan4, Yn = nan4, Zn = nan4;
+            if (nbase < Ppad) { Xn = *(const float4*)(gxs + nbase); Yn = *(const float4*)(gys + nbase); Zn = *(const float4*)(gzs + nbase); }
+            if (SCAN_LDS && base < Ppad) { *(float4*)(s_xs + base) = X; *(float4*)(s_ys + base) = Y; *(float4*)(s_zs + base) = Z; }
+            const float px[4] = {X.x, X.y, X.z, X.w}, py[4] = {Y.x, Y.y, Y.z, Y.w}, pz[4] = {Z.x, Z.y, Z.z, Z.w};
+            bool pass[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float zc = fmaf(r6, px[j], fmaf(r7, py[j], fmaf(r8, pz[j], t2)));
-                bool pass = false;
+                pass[j] = false;
                 if (zc > 0.1f) {
                     const float xc = fmaf(r0, px[j], fmaf(r1, py[j], fmaf(r2, pz[j], t0)));
                     const float yc = fmaf(r3, px[j], fmaf(r4, py[j], fmaf(r5, pz[j], t1)));
@@ -663,28 +712,36 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                     const float uf = fmaf(fxf * xc, rz, cxf), vf = fmaf(fxf * yc, rz, cyf);
                     if (uf > -1.0f && uf < Wf && vf > -1.0f && vf < Hf) {
                         const uint32_t cell = (uint32_t)grid_cell(vf, c.gh) * (uint32_t)c.gw + (uint32_t)grid_cell(uf, c.gw);
-                        pass = (s_bitmap[cell >> 5] >> (cell & 31)) & 1u;
+                        pass[j] = (s_bitmap[cell >> 5] >> (cell & 31)) & 1u;
                     }
-                } else if (zc > -0.1f) pass = true;   // undecidable in f32: let the exact path decide
-                const unsigned long long bal = __ballot(pass);
-                if (bal) {
-                    uint32_t wb = 0;
-                    if (lane == 0) wb = atomicAdd(&s_misc[0], (uint32_t)__popcll(bal));
-                    wb = __shfl(wb, 0);
-                    if (pass) {
-                        const uint32_t idx = wb + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                        if (idx < cand_cap) s_cand[idx] = (CandT)(base + j);
-                        else {   // queue full: exact path inline, full rescan in phase 2 (speed only)
-                            double u, v;
-                            if (project_uv(c, px[j], py[j], pz[j], u, v)) grid_match<1>(c, u, v, base + j);
-                            s_misc[1] = 1u;
-                        }
+                } else if (zc > -0.1f) pass[j] = true;   // undecidable in f32 (NaN padding fails both tests): exact path decides
+            }
+            // one LDS atomic per wave per iteration reserves queue slots for all four points
+            const unsigned long long b0 = __ballot(pass[0]), b1 = __ballot(pass[1]), b2 = __ballot(pass[2]), b3 = __ballot(pass[3]);
+            const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3q = (uint32_t)__popcll(b3);
+            if (n0 + n1 + n2 + n3q) {
+                uint32_t wb = 0;
+                if (lane == 0) wb = atomicAdd(&s_misc[0], n0 + n1 + n2 + n3q);
+                wb = __shfl(wb, 0);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const uint32_t off[4] = {wb + (uint32_t)__popcll(b0 & lt), wb + n0 + (uint32_t)__popcll(b1 & lt), wb + n0 + n1 + (uint32_t)__popcll(b2 & lt),
+                                         wb + n0 + n1 + n2 + (uint32_t)__popcll(b3 & lt)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!pass[j]) continue;
+                    if (off[j] < cand_cap) s_cand[off[j]] = (CandT)(base + j);
+                    else {   // queue full: exact path inline, full rescan in phase 2 (speed only)
+                        double u, v;
+                        if (project_uv(c, px[j], py[j], pz[j], u, v)) grid_match<1>(c, u, v, base + j);
+                        s_misc[1] = 1u;
                     }
                 }
             }
+            X = Xn; Y = Yn; Z = Zn;
         }
     }
     __syncthreads();
+    IBA_STAMP(7);
     // ---- phase 1b: exact f64 projection + FOV test of the queued points, keypoint grid lookup,
     //      ds_min_u64 on the keypoint's best d^2 ----
     const uint32_t ncand = min(s_misc[0], cand_cap);
@@ -692,21 +749,22 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     if (tid == 0) { atomicAdd(&g_dbg[1], (unsigned long long)s_misc[0]); atomicAdd(&g_dbg[2], 1ull); }
 #endif
     const bool overflow = s_misc[1] != 0u;
-    constexpr int kRec = 4;   // queue iterations whose hits are kept in registers
-    uint32_t hk[kRec][2]; unsigned long long hd[kRec][2]; int hn[kRec];
+    // the first two queue entries of each lane keep their (<= 2) hits in registers, so the tie pass needs no second
+    // grid walk; later entries (queue longer than two blocks) take the re-walk path
+    uint32_t hk0 = 0, hk1 = 0, gk0 = 0, gk1 = 0; unsigned long long hd0 = 0, hd1 = 0, gd0 = 0, gd1 = 0; int hn = 0, gn = 0;
     bool redo = false;
-#pragma unroll
-    for (int it = 0; it < kRec; ++it) {
-        hn[it] = 0;
-        const uint32_t i = (uint32_t)tid + (uint32_t)it * kThreads;
-        if (i < ncand) {
-            const uint32_t pos = (uint32_t)s_cand[i];
-            double u, v;
-            if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) hn[it] = grid_match_rec(c, u, v, hk[it][0], hd[it][0], hk[it][1], hd[it][1]);
-            redo |= hn[it] > 2;
-        }
+    if ((uint32_t)tid < ncand) {
+        const uint32_t pos = (uint32_t)s_cand[tid];
+        double u, v;
+        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) hn = grid_match_rec(c, u, v, hk0, hd0, hk1, hd1);
     }
-    for (uint32_t i = (uint32_t)tid + kRec * kThreads; i < ncand; i += kThreads) {   // very long queues: no register record
+    if ((uint32_t)tid + kThreads < ncand) {
+        const uint32_t pos = (uint32_t)s_cand[tid + kThreads];
+        double u, v;
+        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) gn = grid_match_rec(c, u, v, gk0, gd0, gk1, gd1);
+    }
+    redo = hn > 2 || gn > 2;
+    for (uint32_t i = (uint32_t)tid + 2u * kThreads; i < ncand; i += kThreads) {
         const uint32_t pos = (uint32_t)s_cand[i];
         double u, v;
         if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) redo |= grid_match<1>(c, u, v, pos);
@@ -714,20 +772,25 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     __syncthreads();
     IBA_STAMP(2);
     // ---- phase 2: the winner of each keypoint records its original index; exact ties -> lowest index ----
-#pragma unroll
-    for (int it = 0; it < kRec; ++it) {
-        if (hn[it] > 0) {
-            const uint32_t pos = (uint32_t)s_cand[(uint32_t)tid + (uint32_t)it * kThreads];
-            const bool w0 = s_best_d2[hk[it][0]] == hd[it][0];
-            const bool w1 = hn[it] > 1 && s_best_d2[hk[it][1]] == hd[it][1];
-            if (w0 || w1) {
-                const uint32_t orig = c.perm[pos];
-                if (w0) atomicMin(&s_best_idx[hk[it][0]], orig);
-                if (w1) atomicMin(&s_best_idx[hk[it][1]], orig);
-            }
+    if (hn > 0) {
+        const bool w0 = s_best_d2[hk0] == hd0;
+        const bool w1 = hn > 1 && s_best_d2[hk1] == hd1;
+        if (w0 || w1) {
+            const uint32_t orig = c.perm[(uint32_t)s_cand[tid]];
+            if (w0) atomicMin(&s_best_idx[hk0], orig);
+            if (w1) atomicMin(&s_best_idx[hk1], orig);
         }
     }
-    if (redo) {   // rare: a point within reach of > 2 keypoints, or an over-long queue: walk the grid again
+    if (gn > 0) {
+        const bool w0 = s_best_d2[gk0] == gd0;
+        const bool w1 = gn > 1 && s_best_d2[gk1] == gd1;
+        if (w0 || w1) {
+            const uint32_t orig = c.perm[(uint32_t)s_cand[tid + kThreads]];
+            if (w0) atomicMin(&s_best_idx[gk0], orig);
+            if (w1) atomicMin(&s_best_idx[gk1], orig);
+        }
+    }
+    if (redo) {   // rare: a point within reach of > 2 keypoints, or a queue longer than two blocks: walk the grid again
         for (uint32_t i = tid; i < ncand; i += kThreads) {
             const uint32_t pos = (uint32_t)s_cand[i];
             double u, v;
@@ -828,19 +891,15 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             qy = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
             qz = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
         };
-        auto assoc_3d3d = [&](auto GT) {
-            constexpr int G = decltype(GT)::value;
+        {
+            const int G = n3 * 8u <= (uint32_t)kThreads ? 8 : (n3 * 4u <= (uint32_t)kThreads ? 4 : (n3 * 2u <= (uint32_t)kThreads ? 2 : 1));
             for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
                 double qx, qy, qz; q_assoc(s_list[i], qx, qy, qz);
                 double best; uint32_t bpos;
-                nn_search_group<G>(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
+                nn_search_group(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
                 if ((tid & (G - 1)) == 0) s_bpos[i] = (best > prm.max_3d_dist2) ? kNone : bpos;   // :289
             }
-        };
-        if (n3 * 8u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 8>());
-        else if (n3 * 4u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 4>());
-        else if (n3 * 2u <= (uint32_t)kThreads) assoc_3d3d(std::integral_constant<int, 2>());
-        else assoc_3d3d(std::integral_constant<int, 1>());
+        }
         __syncthreads();
         if (!cached) fit_points(s_bpos, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
         for (uint32_t i = tid; i < n3; i += kThreads) {
@@ -876,11 +935,11 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         float2 m[4];
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) m[sl] = (uint32_t)sl < h.n_slots ? dp.match_uv[h.match_base + (size_t)sl * K + k] : make_float2(__builtin_nanf(""), 0.f);
+        const uint32_t pos = inv_perm[orig];   // issued together with the match loads
         bool any = false;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) any |= (m[sl].x == m[sl].x);
         if (!any && h.n_slots <= 4) continue;
-        const uint32_t pos = inv_perm[orig];
         const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
         const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
         const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
@@ -923,19 +982,15 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
             qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
         };
-        auto cost_3d3d = [&](auto GT) {
-            constexpr int G = decltype(GT)::value;
+        {
+            const int G = n3 * 8u <= (uint32_t)kThreads ? 8 : (n3 * 4u <= (uint32_t)kThreads ? 4 : (n3 * 2u <= (uint32_t)kThreads ? 2 : 1));
             for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
                 double qx, qy, qz; q_cost(s_list[i], qx, qy, qz);
                 double best; uint32_t bpos;
-                nn_search_group<G>(c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
+                nn_search_group(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
                 if ((tid & (G - 1)) == 0) s_bpos[i] = bpos;
             }
-        };
-        if (n3 * 8u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 8>());
-        else if (n3 * 4u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 4>());
-        else if (n3 * 2u <= (uint32_t)kThreads) cost_3d3d(std::integral_constant<int, 2>());
-        else cost_3d3d(std::integral_constant<int, 1>());
+        }
         __syncthreads();
         if (!cached && prm.use_plane) fit_points(s_bpos, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);   // iba_global.cpp:125-147
         for (uint32_t i = tid; i < n3; i += kThreads) {
@@ -992,7 +1047,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     }
 #ifdef IBA_STAMPS
     __syncthreads();
-    if (tid == 0) { const unsigned long long te = __builtin_readcyclecounter(); for (int i = 0; i < 7; ++i) part[56 + i] = (double)((i < 6 ? stamp_t[i + 1] : te) - stamp_t[i]); }
+    if (tid == 0) { const unsigned long long te = __builtin_readcyclecounter(); for (int i = 0; i < 7; ++i) part[56 + i] = (double)((i < 6 ? stamp_t[i + 1] : te) - stamp_t[i]); part[63] = (double)(stamp_t[7] - stamp_t[1]); }
 #endif
 }
 

@@ -37,7 +37,8 @@ struct FrameHdr {
     uint32_t K;
     // keypoint grid
     uint32_t gw, gh;      // cells
-    uint64_t cell_base;   // offset into cell_start[] (gw*gh+1 entries)
+    uint32_t gwc, ghc;    // coarse (16 px) cells
+    uint64_t coarse_base; // offset into coarse_start[] (gwc*ghc+1 entries)
     uint64_t bitmap_base; // offset into bitmap[] (ceil(gw*gh/32) words)
     // covisibility
     uint32_t slot_base, n_slots;   // slots [slot_base, slot_base+n_slots)

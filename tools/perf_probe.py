@@ -28,7 +28,7 @@ if os.environ.get("IBA_LIB", "").endswith("stamps.so"):
         pp = h.debug_last_partials(B)
         st = pp[:, 56:63].mean(0) / F
         names = ["p0 init", "p1 project", "p2 ties", "p3 count", "p4a 3d2d", "p4b 3d3d", "p4c HE+reduce"]
-        print(f"B={B} mean cycles per block:", ", ".join(f"{n} {v:.0f}" for n, v in zip(names, st)), " total", st.sum())
+        print(f"B={B} mean cycles per block:", ", ".join(f"{n} {v:.0f}" for n, v in zip(names, st)), " total", st.sum(), " [1a only:", int(pp[:, 63].mean() / F), "]")
     import ctypes
     L = pkg.load_library()
     z = (ctypes.c_ulonglong * 64)()
