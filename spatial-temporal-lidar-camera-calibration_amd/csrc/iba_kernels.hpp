@@ -434,13 +434,14 @@ __device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v
     return hit;
 }
 
-// PASS-1 variant that also remembers up to two (keypoint, d^2) hits of this point in registers, so that the tie
-// pass needs no second grid walk. Returns the number of hits (a third hit is counted but not stored).
-__device__ __forceinline__ int grid_match_rec(const FrameCtx& c, double u, double v, uint32_t& k0, unsigned long long& d0, uint32_t& k1, unsigned long long& d1) {
+// PASS-1 variant that also remembers up to two (keypoint, d^2) hits of this point (returned BY VALUE so they stay
+// in registers), so that the tie pass needs no second grid walk. n counts all hits (a third is counted, not stored).
+struct Hits { uint32_t k0, k1; unsigned long long d0, d1; int n; };
+__device__ __forceinline__ Hits grid_match_rec(const FrameCtx& c, double u, double v) {
     const float uf = (float)u, vf = (float)v;
     const int x0 = grid_cell(uf - c.margin, c.gw) >> 2, x1 = grid_cell(uf + c.margin, c.gw) >> 2;
     const int y0 = grid_cell(vf - c.margin, c.gh) >> 2, y1 = grid_cell(vf + c.margin, c.gh) >> 2;
-    int nh = 0;
+    Hits hh; hh.k0 = hh.k1 = 0u; hh.d0 = hh.d1 = 0ull; hh.n = 0;
     for (int yy = y0; yy <= y1; ++yy) {
         const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
         for (uint32_t e = e0; e < e1; ++e) {
@@ -451,12 +452,14 @@ __device__ __forceinline__ int grid_match_rec(const FrameCtx& c, double u, doubl
             if (d2 <= c.gate2) {
                 const uint32_t k = __float_as_uint(rec.z);
                 atomicMin(&c.best_d2[k], d2bits(d2));
-                if (nh == 0) { k0 = k; d0 = d2bits(d2); } else if (nh == 1) { k1 = k; d1 = d2bits(d2); }
-                ++nh;
+                const bool first = hh.n == 0, second = hh.n == 1;
+                hh.k0 = first ? k : hh.k0; hh.d0 = first ? d2bits(d2) : hh.d0;
+                hh.k1 = second ? k : hh.k1; hh.d1 = second ? d2bits(d2) : hh.d1;
+                ++hh.n;
             }
         }
     }
-    return nh;
+    return hh;
 }
 
 // ---- exact 1-NN with G lanes per query (G = 1,2,4,8): the G lanes walk the tree in lockstep and split each leaf ----
@@ -751,19 +754,19 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     const bool overflow = s_misc[1] != 0u;
     // the first two queue entries of each lane keep their (<= 2) hits in registers, so the tie pass needs no second
     // grid walk; later entries (queue longer than two blocks) take the re-walk path
-    uint32_t hk0 = 0, hk1 = 0, gk0 = 0, gk1 = 0; unsigned long long hd0 = 0, hd1 = 0, gd0 = 0, gd1 = 0; int hn = 0, gn = 0;
+    Hits h0, h1; h0.n = 0; h1.n = 0; h0.k0 = h0.k1 = h1.k0 = h1.k1 = 0u; h0.d0 = h0.d1 = h1.d0 = h1.d1 = 0ull;
     bool redo = false;
     if ((uint32_t)tid < ncand) {
         const uint32_t pos = (uint32_t)s_cand[tid];
         double u, v;
-        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) hn = grid_match_rec(c, u, v, hk0, hd0, hk1, hd1);
+        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) h0 = grid_match_rec(c, u, v);
     }
     if ((uint32_t)tid + kThreads < ncand) {
         const uint32_t pos = (uint32_t)s_cand[tid + kThreads];
         double u, v;
-        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) gn = grid_match_rec(c, u, v, gk0, gd0, gk1, gd1);
+        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) h1 = grid_match_rec(c, u, v);
     }
-    redo = hn > 2 || gn > 2;
+    redo = h0.n > 2 || h1.n > 2;
     for (uint32_t i = (uint32_t)tid + 2u * kThreads; i < ncand; i += kThreads) {
         const uint32_t pos = (uint32_t)s_cand[i];
         double u, v;
@@ -772,22 +775,22 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     __syncthreads();
     IBA_STAMP(2);
     // ---- phase 2: the winner of each keypoint records its original index; exact ties -> lowest index ----
-    if (hn > 0) {
-        const bool w0 = s_best_d2[hk0] == hd0;
-        const bool w1 = hn > 1 && s_best_d2[hk1] == hd1;
+    if (h0.n > 0) {
+        const bool w0 = s_best_d2[h0.k0] == h0.d0;
+        const bool w1 = h0.n > 1 && s_best_d2[h0.k1] == h0.d1;
         if (w0 || w1) {
             const uint32_t orig = c.perm[(uint32_t)s_cand[tid]];
-            if (w0) atomicMin(&s_best_idx[hk0], orig);
-            if (w1) atomicMin(&s_best_idx[hk1], orig);
+            if (w0) atomicMin(&s_best_idx[h0.k0], orig);
+            if (w1) atomicMin(&s_best_idx[h0.k1], orig);
         }
     }
-    if (gn > 0) {
-        const bool w0 = s_best_d2[gk0] == gd0;
-        const bool w1 = gn > 1 && s_best_d2[gk1] == gd1;
+    if (h1.n > 0) {
+        const bool w0 = s_best_d2[h1.k0] == h1.d0;
+        const bool w1 = h1.n > 1 && s_best_d2[h1.k1] == h1.d1;
         if (w0 || w1) {
             const uint32_t orig = c.perm[(uint32_t)s_cand[tid + kThreads]];
-            if (w0) atomicMin(&s_best_idx[gk0], orig);
-            if (w1) atomicMin(&s_best_idx[gk1], orig);
+            if (w0) atomicMin(&s_best_idx[h1.k0], orig);
+            if (w1) atomicMin(&s_best_idx[h1.k1], orig);
         }
     }
     if (redo) {   // rare: a point within reach of > 2 keypoints, or a queue longer than two blocks: walk the grid again

@@ -32,7 +32,7 @@ if len(sys.argv) > 4:
     for k, v in traffic.items():
         f = v.get("FETCH_SIZE", (0, 0)); w = v.get("WRITE_SIZE", (0, 0))
         lines.append("| %s | %d | %.2f | %.2f | %.2f |" % (k, f[1], f[0] * 1024 / 1e6, 2 * f[0] * 1024 / 1e6, w[0] * 1024 / 1e6))
-    key = [k for k in traffic if k.startswith("iba_frame_kernel<0")]
+    key = [k for k in traffic if k.startswith("iba_frame_kernel<3")] or [k for k in traffic if k.startswith("iba_frame_kernel<0")]
     if key:
         v = traffic[key[0]]
         json.dump({"round": tag, "kernel": key[0], "fetch_bytes_raw": v["FETCH_SIZE"][0] * 1024, "write_bytes": v["WRITE_SIZE"][0] * 1024,
