@@ -519,10 +519,13 @@ __device__ __forceinline__ void nn_search_group(int G, const float* __restrict__
         }
         return;
     }
-    float ps[kPathMax];
+    // per level: float LOWER bound of (q[dim] - split)^2 (rounded down). Backtracking first builds, with one f32 compare
+    // per level and no memory access, the set of levels whose plane may still be within the best distance; only the
+    // deepest such level is then confirmed exactly (one node re-read) before its far child is entered.
+    float pd2[kPathMax];
 #pragma unroll
-    for (int L = 0; L < kPathMax; ++L) ps[L] = 0.f;
-    uint32_t dims = 0u, side = 0u, done = 0u;   // per level: 2-bit split dim; 1 = currently in the right child; 1 = far child handled
+    for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
+    uint32_t side = 0u, done = 0u;   // per level: 1 = currently in the right child; 1 = far child handled / out of reach
     uint32_t node = 0u; int start = 0;
     for (;;) {
 #pragma unroll
@@ -530,9 +533,9 @@ __device__ __forceinline__ void nn_search_group(int G, const float* __restrict__
             if (L >= start && L < (int)D) {
                 const TreeNode n = nodes[node];
                 const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
-                const uint32_t r = (qd - (double)n.split) >= 0.0 ? 1u : 0u;
-                ps[L] = n.split;
-                dims = (dims & ~(3u << (2 * L))) | (n.dim << (2 * L));
+                const double diff = qd - (double)n.split;
+                const uint32_t r = diff >= 0.0 ? 1u : 0u;
+                pd2[L] = __double2float_rd(diff * diff);
                 side = (side & ~(1u << L)) | (r << L);
                 done &= ~(1u << L);
                 node = 2u * node + 1u + r;
@@ -540,19 +543,23 @@ __device__ __forceinline__ void nn_search_group(int G, const float* __restrict__
         }
         scan_leaf(node);
         int go = -1;
+        for (;;) {
+            const float bestf = __double2float_ru(best);
+            uint32_t cand = 0u;
 #pragma unroll
-        for (int L = kPathMax - 1; L >= 0; --L) {
-            if (go < 0 && L < (int)D && !((done >> L) & 1u)) {
-                const uint32_t dm = (dims >> (2 * L)) & 3u;
-                const double qd = dm == 0 ? qx : (dm == 1 ? qy : qz);
-                const double diff = qd - (double)ps[L];
-                if (diff * diff <= best) go = L; else done |= 1u << L;   // best only shrinks: a failed level stays failed
-            }
+            for (int L = 0; L < kPathMax; ++L) cand |= (pd2[L] <= bestf ? 1u : 0u) << L;
+            cand &= ~done & ((1u << D) - 1u);
+            done |= ~cand;                               // best only shrinks: a level out of reach stays out of reach
+            if (cand == 0u) break;
+            const int L = 31 - __clz((int)cand);         // deepest candidate level
+            const uint32_t anc = ((node + 1u) >> (D - (uint32_t)L)) - 1u;   // ancestor of the current leaf at level L
+            const TreeNode n = nodes[anc];
+            const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+            const double diff = qd - (double)n.split;
+            done |= 1u << L;
+            if (diff * diff <= best) { go = L; side ^= 1u << L; node = 2u * anc + 1u + ((side >> L) & 1u); break; }
         }
         if (go < 0) break;
-        done |= 1u << go; side ^= 1u << go;
-        const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;   // ancestor of the current leaf at level `go`
-        node = 2u * anc + 1u + ((side >> go) & 1u);
         start = go + 1;
     }
 }

@@ -40,6 +40,8 @@ if os.environ.get("IBA_LIB", "").endswith("stamps.so"):
     print("per-wave search:", [int(z[8+w]/nb) for w in range(16)])
     print("per-wave pre   :", [int(z[24+w]/nb) for w in range(16)])
     print("per-wave post  :", [int(z[40+w]/nb) for w in range(16)])
+    print("leaf-visit histogram [1,2,3,4,5-8,9-16,17-32,33+]:", [int(z[48+i]) for i in range(8)], "mean", z[56]/max(1,sum(z[48+i] for i in range(8))), "max", z[57])
+    print(f"SEG wave0 per search call: descent {z[4]/max(1,z[7]):.0f}  leaf+reduce {z[5]/max(1,z[7]):.0f}  ascent-scan {z[6]/max(1,z[7]):.0f}  calls {z[7]}")
     print(f"wave0 cycles per block in nn_search: descent {z[4]/nb:.0f} leaf {z[5]/nb:.0f} reduce {z[6]/nb:.0f} ascent {z[7]/nb:.0f}")
     print(f"OLD per query: desc {z[4]/max(1,z[3]):.1f} asc {z[5]/max(1,z[3]):.1f} leaves {z[0]/max(1,z[3]):.2f}; per wave-call: max leaves {z[6]/(nb*16):.1f} max desc {z[7]/(nb*16):.1f}")
     print(f"per block: leaf visits {z[0]/nb:.0f}, queue candidates {z[1]/nb:.0f}, 3d-3d queries {z[3]/nb:.0f} -> leaf visits per query {z[0]/max(1,z[3]):.1f}")
