@@ -40,7 +40,7 @@ struct DevProblem {
     const uint32_t* inv_perm;  // original point index -> tree position
     const TreeNode* nodes;
     const float2* kp_uv;
-    const float4* kp_mp;       // MapPoint world position (x,y,z), w = 1 if the keypoint owns one
+    const float4* kp_mp;       // MapPoint world position (x,y,z); w = 1*(owns a MapPoint) + 2*(matched in >= 1 covisible KF)
     const uint32_t* coarse_start; const float4* crec; const uint32_t* bitmap;   // keypoint grid (see iba_build.hpp)
     const float2* match_uv;    // [slot][K] matched covisible keypoint, NaN = no match
     const PlaneRec* plane_cost;   // x-independent plane records (norm_radius / norm_max_pts)
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                     const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
                     bool any_covis = false;
                     for (uint32_t sl = 0; sl < h.n_slots; ++sl) { const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k]; any_covis |= (m.x == m.x); }
-                    if (neigh_ok && kp_mp[k].w != 0.0f && any_covis) {   // :259-260
+                    if (neigh_ok && (((int)kp_mp[k].w) & 1) && any_covis) {   // :259-260
                         if (rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) a.x = pos;   // bvalid_plane (:231)
                         want3 = true;
                     }
@@ -931,25 +931,22 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     }
 
     IBA_STAMP(4);
-    // ---- phase 4: compaction of the 3d-3d work list first (the only barriers), then all the arithmetic ----
+    // ---- phase 4: ONE dense work list (keypoints with a correspondence that own a MapPoint and/or a covisible match:
+    //      ~1 keypoint in 8), built in keypoint order with the only barriers of the phase; then all the arithmetic
+    //      runs on full waves instead of dragging every wave through code most of its lanes skip ----
     for (uint32_t k = tid; k < Kceil; k += kThreads) {
-        const bool want3 = prm.use_3d3d && k < K && s_best_idx[k] != kNone && kp_mp[k].w != 0.0f;
-        ordered_append(want3, k, n3, s_list, s_wcnt);
+        const bool want = k < K && s_best_idx[k] != kNone && kp_mp[k].w != 0.0f;
+        ordered_append(want, k, n3, s_list, s_wcnt);
     }
     double sum2d = 0.0, sum3d = 0.0;
     uint32_t c2 = 0, v2 = 0, c3 = 0, v3 = 0, vpl = 0, vpt = 0;
     // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328)
-    for (uint32_t k = tid; k < K; k += kThreads) {
-        const uint32_t orig = s_best_idx[k];
-        if (orig == kNone) continue;
+    for (uint32_t i = tid; i < n3; i += kThreads) {
+        const uint32_t k = s_list[i];
         float2 m[4];
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) m[sl] = (uint32_t)sl < h.n_slots ? dp.match_uv[h.match_base + (size_t)sl * K + k] : make_float2(__builtin_nanf(""), 0.f);
-        const uint32_t pos = inv_perm[orig];   // issued together with the match loads
-        bool any = false;
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) any |= (m[sl].x == m[sl].x);
-        if (!any && h.n_slots <= 4) continue;
+        const uint32_t pos = inv_perm[s_best_idx[k]];   // issued together with the match loads
         const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
         const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
         const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
@@ -995,7 +992,9 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         {
             const int G = n3 * 8u <= (uint32_t)kThreads ? 8 : (n3 * 4u <= (uint32_t)kThreads ? 4 : (n3 * 2u <= (uint32_t)kThreads ? 2 : 1));
             for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
-                double qx, qy, qz; q_cost(s_list[i], qx, qy, qz);
+                const uint32_t k = s_list[i];
+                if (!(((int)kp_mp[k].w) & 1)) { if ((tid & (G - 1)) == 0) s_bpos[i] = kNone; continue; }   // covisible match but no MapPoint
+                double qx, qy, qz; q_cost(k, qx, qy, qz);
                 double best; uint32_t bpos;
                 nn_search_group(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
                 if ((tid & (G - 1)) == 0) s_bpos[i] = bpos;
@@ -1005,6 +1004,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         if (!cached && prm.use_plane) fit_points(s_bpos, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);   // iba_global.cpp:125-147
         for (uint32_t i = tid; i < n3; i += kThreads) {
             const uint32_t bpos = s_bpos[i];
+            if (bpos == kNone) continue;
             double qx, qy, qz; q_cost(s_list[i], qx, qy, qz);
             const double ax = (double)c.xs[bpos] - qx, ay = (double)c.ys[bpos] - qy, az = (double)c.zs[bpos] - qz;
             double dist = sqrt((ax * ax + ay * ay) + az * az);   // (nn_pt - query_pt).norm()  (:122)
