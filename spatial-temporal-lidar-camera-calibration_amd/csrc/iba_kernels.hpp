@@ -860,35 +860,30 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         used_assoc = used;
         if (MODE == MODE_ASSOC && tid < kPartialStride) part[tid] = (used && tid == P_FRAMES_N) ? 1.0 : ((used && tid == P_NCORR_N) ? (double)n_corr : 0.0);
         const PlaneRec* planes = planes_local;
-        if (!cached && used) {   // ComputeLocalNeighbor at every matched scan point (iba_local.cpp:207)
-            uint32_t n0 = 0;
-            for (uint32_t k = tid; k < Kceil; k += kThreads) {
-                const uint32_t orig = k < K ? s_best_idx[k] : kNone;
-                ordered_append(orig != kNone, orig != kNone ? inv_perm[orig] : kNone, n0, s_list, s_wcnt);
-            }
-            fit_points(s_list, n0, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
-        }
+        // dense list of the keypoints that can own residual blocks: a correspondence, a MapPoint (iba_local.cpp:213)
+        // AND a covisible match (:259-260). Everything else gets an empty association row right here.
         for (uint32_t k = tid; k < Kceil; k += kThreads) {
-            bool want3 = false;
-            if (k < K) {
-                uint2 a = make_uint2(kNone, kNone);
-                const uint32_t orig = s_best_idx[k];
-                if (used && orig != kNone) {
-                    const uint32_t pos = inv_perm[orig];
-                    const PlaneRec rec = planes[pos];
-                    // ComputeLocalNeighbor validity (pointcloud.h:752), then MapPoint ownership (iba_local.cpp:213)
-                    const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
-                    bool any_covis = false;
-                    for (uint32_t sl = 0; sl < h.n_slots; ++sl) { const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k]; any_covis |= (m.x == m.x); }
-                    if (neigh_ok && (((int)kp_mp[k].w) & 1) && any_covis) {   // :259-260
-                        if (rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) a.x = pos;   // bvalid_plane (:231)
-                        want3 = true;
-                    }
-                }
-                arow[k] = a;
-            }
-            ordered_append(want3, k, n3, s_list, s_wcnt);
+            const bool want = used && k < K && s_best_idx[k] != kNone && ((int)kp_mp[k].w) == 3;
+            if (k < K && !want) arow[k] = make_uint2(kNone, kNone);
+            ordered_append(want, k, n3, s_list, s_wcnt);
         }
+        if (!cached) {   // ComputeLocalNeighbor at the matched scan point of every listed keypoint (iba_local.cpp:207)
+            for (uint32_t i = tid; i < n3; i += kThreads) s_bpos[i] = inv_perm[s_best_idx[s_list[i]]];
+            __syncthreads();
+            fit_points(s_bpos, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
+        }
+        for (uint32_t i = tid; i < n3; i += kThreads) {
+            const uint32_t k = s_list[i];
+            const uint32_t pos = inv_perm[s_best_idx[k]];
+            const PlaneRec rec = planes[pos];
+            uint2 a = make_uint2(kNone, kNone);
+            // ComputeLocalNeighbor validity (pointcloud.h:752)
+            const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
+            if (neigh_ok && rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) a.x = pos;   // bvalid_plane (:231)
+            arow[k] = a;
+            s_bpos[i] = neigh_ok ? 0u : kNone;   // kNone: no 3d-3d block either (the `continue` at :209-211)
+        }
+        __syncthreads();
         // MapPoint -> LiDAR frame (iba_local.cpp:238-239, 282), 1-NN, local plane at the NN (pointcloud.h:699-717)
         auto q_assoc = [&](uint32_t k, double& qx, double& qy, double& qz) {
             const float4 mp = kp_mp[k];
@@ -904,6 +899,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         {
             const int G = n3 * 8u <= (uint32_t)kThreads ? 8 : (n3 * 4u <= (uint32_t)kThreads ? 4 : (n3 * 2u <= (uint32_t)kThreads ? 2 : 1));
             for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
+                if (s_bpos[i] == kNone) continue;   // uniform within the lane group
                 double qx, qy, qz; q_assoc(s_list[i], qx, qy, qz);
                 double best; uint32_t bpos;
                 nn_search_group(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
