@@ -79,6 +79,8 @@ struct iba_handle {
     DevBuf<uint2> d_assoc;                // assoc_cap * n_keypoints (per-candidate association of iba_eval_normal)
     int assoc_cap = 0;
     DevBuf<uint2> d_assoc_frozen;         // n_keypoints (iba_build_problem)
+    DevBuf<uint4> d_flist, d_flist_frozen;       // dense residual-block lists: [cand][frame][maxK] / [frame][maxK]
+    DevBuf<uint32_t> d_fcount, d_fcount_frozen;  // entries per (cand, frame)
     bool frozen_valid = false; int32_t frozen_frames = 0, frozen_ncorr = 0;
     int nfb = 0;                          // factor-kernel records per candidate (= n_frames)
     int nrec = 0;                         // partial records per candidate = n_frames + nfb
@@ -215,6 +217,8 @@ iba_status ensure_scratch(iba_handle* h, int B, hipStream_t st) {
 
 template <int MODE>
 iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, uint2* d_assoc, int nrec, hipStream_t st, int scratch_slot_base = 1) {
+    const bool frozen = (d_assoc == h->d_assoc_frozen.p);
+    uint4* fl = frozen ? h->d_flist_frozen.p : h->d_flist.p; uint32_t* fc = frozen ? h->d_fcount_frozen.p : h->d_fcount.p;
     if (MODE != MODE_CORR) { iba_status es = ensure_scratch(h, B, st); if (es != IBA_OK) return es; }
     DevProblem dp = h->dev_problem();
     dp.scratch_slot_base = scratch_slot_base;
@@ -225,8 +229,8 @@ iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_fra
     const int per_xcd = (h->n_frames + 7) / 8;
     const dim3 grid(8 * per_xcd * B), block(kThreads);
     if (h->n_frames == 0) return IBA_OK;
-    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p);
-    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p);
+    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->maxK);
+    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->maxK);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }
@@ -286,7 +290,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
@@ -444,6 +448,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     h->nfb = nf; h->nrec = nf + h->nfb;   // one factor-kernel record per frame
     if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(h->nrec, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
     if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
+    if ((er = h->d_flist_frozen.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u))) != hipSuccess) return bail("alloc flist", er);
+    if ((er = h->d_fcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc fcount", er);
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
     if ((er = h->d_he.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1))) != hipSuccess) return bail("alloc he", er);
     if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
@@ -584,10 +590,11 @@ iba_status iba_finalize_normal(const iba_params* p, const double* part, int32_t 
     return IBA_OK;
 }
 
-static iba_status launch_factors(iba_handle* h, const Cand* dc, int B, const uint2* assoc, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
+static iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
     if (h->n_frames == 0 || h->maxK == 0) return IBA_OK;
     const dim3 grid(h->n_frames, B);
-    hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 8u * h->maxK, st, h->dev_problem(), h->dprm, dc, assoc, per_cand, partials, nrec, rec_base, (int)h->maxK);
+    const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
+    hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->maxK, per_cand, partials, nrec, rec_base);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }
@@ -597,8 +604,10 @@ static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->assoc_cap < B) {
         HIP_TRY(h, hipStreamSynchronize(st));
-        h->d_assoc.release();
+        h->d_assoc.release(); h->d_flist.release(); h->d_fcount.release();
         HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
+        HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * std::max(h->maxK, 1u)));
+        HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
         h->assoc_cap = B;
     }
     Cand* dc = nullptr;
@@ -606,7 +615,7 @@ static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
     s = launch_frame<MODE_ASSOC>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    s = launch_factors(h, dc, B, h->d_assoc.p, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
+    s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
@@ -634,8 +643,10 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->assoc_cap < B) {
         HIP_TRY(h, hipStreamSynchronize(st));
-        h->d_assoc.release();
+        h->d_assoc.release(); h->d_flist.release(); h->d_fcount.release();
         HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
+        HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * std::max(h->maxK, 1u)));
+        HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
         h->assoc_cap = B;
     }
     Cand* dc = nullptr;
@@ -643,7 +654,7 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
     s = launch_frame<MODE_BOTH>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    s = launch_factors(h, dc, B, h->d_assoc.p, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
+    s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
@@ -685,7 +696,7 @@ iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_norma
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, h->stream, &dc); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    s = launch_factors(h, dc, B, h->d_assoc_frozen.p, 0, h->d_frame_partials.p, h->nfb, 0, h->stream); if (s != IBA_OK) return s;
+    s = launch_factors(h, dc, B, 0, h->d_frame_partials.p, h->nfb, 0, h->stream); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, h->stream, h->d_frame_partials.p, h->nfb, h->d_partials.p);
     HIP_TRY(h, hipGetLastError());

@@ -630,7 +630,8 @@ __device__ __forceinline__ uint32_t block_count(uint32_t my_count_wave_uniform, 
 template <int MODE, bool SCAN_LDS>
 __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
                                                              double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out,
-                                                             uint2* __restrict__ assoc_out, int nrec, const double* __restrict__ he) {
+                                                             uint2* __restrict__ assoc_out, int nrec, const double* __restrict__ he,
+                                                             uint4* __restrict__ flist, uint32_t* __restrict__ fcount, int flist_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef typename std::conditional<SCAN_LDS, uint16_t, uint32_t>::type CandT;   // LDS mode implies P < 65536
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -916,6 +917,16 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                                (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);
             arow[s_list[i]].y = bpos | (state ? 0x80000000u : 0u);
         }
+        // dense residual-block list of this (candidate, frame) for the factor kernel: {keypoint, plane point, 3d-3d point|kind}
+        {
+            uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
+            for (uint32_t i = tid; i < n3; i += kThreads) {
+                const uint32_t k = s_list[i];
+                const uint2 a = arow[k];   // both halves were written by this same thread
+                fl[i] = make_uint4(k, a.x, a.y, 0u);
+            }
+            if (tid == 0) fcount[(size_t)b * nf + f] = n3;
+        }
         if (MODE == MODE_ASSOC) return;
         __syncthreads();   // s_list is reused by the cost path below
         n3 = 0;
@@ -1180,70 +1191,42 @@ __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const 
 }
 
 constexpr int kFactorThreads = 256;
-// grid: (n_frames, B), 256 threads; dynamic LDS = 8 * maxK bytes. assoc row = assoc + (assoc_per_cand ? b : 0) * n_kp_total.
-// Only ~1 keypoint in 7 owns a residual block, so each wave first compacts ITS quarter of the keypoints into two
-// ordered LDS lists (ballot + prefix, no block barrier), then the block works through the dense lists.
+// grid: (n_frames, B), 256 threads. Works through the dense residual-block list the association pass left for this
+// (candidate, frame): every lane owns a keypoint that has at least one block. list row = (per_cand ? b : 0).
 // record (b, rec_base + frame) of `partials` receives this block's sums.
-__global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint2* __restrict__ assoc,
-                                                                    int assoc_per_cand, double* __restrict__ partials, int nrec, int rec_base, int maxK) {
-    extern __shared__ __align__(16) unsigned char fsm[];
+__global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist,
+                                                                    const uint32_t* __restrict__ fcount, int flist_stride, int per_cand,
+                                                                    double* __restrict__ partials, int nrec, int rec_base) {
     __shared__ double s_part[kFactorThreads / 64][48];
-    __shared__ uint32_t s_cnt[2][kFactorThreads / 64];
     const int f = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = kFactorThreads / 64;
     const FrameHdr& h = dp.frames[f];
     const Cand& c = cands[b];
-    const uint32_t K = h.K;
-    uint32_t* s_lp = (uint32_t*)fsm;            // plane-factor keypoints, wave segments of `seg` entries
-    uint32_t* s_l3 = s_lp + maxK;               // 3d-3d-factor keypoints
-    const uint2* arow = assoc + (size_t)(assoc_per_cand ? b : 0) * dp.n_kp_total + h.kp_base;
-    const uint32_t seg = (K + NW - 1) / NW;     // keypoints per wave
-    {
-        const uint32_t k0 = wave * seg, k1 = min(K, k0 + seg);
-        uint32_t np = 0, n3 = 0;
-        for (uint32_t kb = k0; kb < k1; kb += 64) {
-            const uint32_t k = kb + lane;
-            uint2 a = make_uint2(kNone, kNone);
-            if (k < k1) a = arow[k];
-            const unsigned long long bp = __ballot(a.x != kNone), b3 = __ballot(a.y != kNone);
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            if (a.x != kNone) s_lp[k0 + np + (uint32_t)__popcll(bp & lt)] = k;
-            if (a.y != kNone) s_l3[k0 + n3 + (uint32_t)__popcll(b3 & lt)] = k;
-            np += (uint32_t)__popcll(bp); n3 += (uint32_t)__popcll(b3);
-        }
-        if (lane == 0) { s_cnt[0][wave] = np; s_cnt[1][wave] = n3; }
-    }
-    __syncthreads();
+    const size_t row = (size_t)(per_cand ? b : 0) * dp.n_frames + f;
+    const uint4* fl = flist + row * (size_t)flist_stride;
+    const uint32_t n = fcount[row];
     NAcc A;
     for (int i = 0; i < 28; ++i) A.H[i] = 0;
     for (int i = 0; i < 7; ++i) A.b[i] = 0;
     A.chi2 = A.cost = A.nf2d = A.nfpl = A.nfpt = A.nres = 0;
     const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
     const PlaneRec* planes = prm.plane_cache ? dp.plane_local + h.pt_base
-                                             : dp.scratch_local + (size_t)(assoc_per_cand ? dp.scratch_slot_base + b : 0) * (size_t)dp.n_pt_total + h.pt_base;
-    // entry i of the concatenated wave segments
-    auto entry = [&](const uint32_t* list, int which, uint32_t i, uint32_t& k) -> bool {
-        for (int w = 0; w < NW; ++w) { const uint32_t n = s_cnt[which][w]; if (i < n) { k = list[w * seg + i]; return true; } i -= n; }
-        return false;
-    };
-    for (uint32_t i = tid;; i += kFactorThreads) {
-        uint32_t k;
-        if (!entry(s_lp, 0, i, k)) break;
-        const uint2 a = arow[k];
-        const PlaneRec rec = planes[a.x];
-        const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]}, n0[3] = {rec.nx, rec.ny, rec.nz};
-        const float2 uv = dp.kp_uv[h.kp_base + k];
-        plane_factor_accum(c, h, dp, prm, k, K, (double)uv.x, (double)uv.y, p0, n0, A);
-    }
-    for (uint32_t i = tid;; i += kFactorThreads) {
-        uint32_t k;
-        if (!entry(s_l3, 1, i, k)) break;
-        const uint2 a = arow[k];
-        const uint32_t pos = a.y & 0x7FFFFFFFu; const bool is_plane = (a.y >> 31) != 0;
-        const PlaneRec rec = planes[pos];
-        const double Q[3] = {(double)xs[pos], (double)ys[pos], (double)zs[pos]}, n[3] = {rec.nx, rec.ny, rec.nz};
-        p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, n, is_plane, A);
+                                             : dp.scratch_local + (size_t)(per_cand ? dp.scratch_slot_base + b : 0) * (size_t)dp.n_pt_total + h.pt_base;
+    for (uint32_t i = tid; i < n; i += kFactorThreads) {
+        const uint4 e = fl[i];
+        const uint32_t k = e.x;
+        if (e.y != kNone) {
+            const PlaneRec rec = planes[e.y];
+            const double p0[3] = {(double)xs[e.y], (double)ys[e.y], (double)zs[e.y]}, n0[3] = {rec.nx, rec.ny, rec.nz};
+            const float2 uv = dp.kp_uv[h.kp_base + k];
+            plane_factor_accum(c, h, dp, prm, k, h.K, (double)uv.x, (double)uv.y, p0, n0, A);
+        }
+        if (e.z != kNone) {
+            const uint32_t pos = e.z & 0x7FFFFFFFu; const bool is_plane = (e.z >> 31) != 0;
+            const PlaneRec rec = planes[pos];
+            const double Q[3] = {(double)xs[pos], (double)ys[pos], (double)zs[pos]}, nn[3] = {rec.nx, rec.ny, rec.nz};
+            p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, nn, is_plane, A);
+        }
     }
     // fixed-order reduction: DPP wave sums (VALU), then the 4 waves in order
     double* v = (double*)&A;   // 41 contiguous doubles
