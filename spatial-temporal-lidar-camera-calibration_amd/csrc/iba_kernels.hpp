@@ -564,6 +564,101 @@ __device__ __forceinline__ void nn_search_group(int G, const float* __restrict__
     }
 }
 
+// ---- two exact 1-NN searches in ONE traversal (fused mode): the association-path query qa and the cost-path query
+// qc of the same MapPoint differ by ~1e-7 relative (different float/double islands in the reference), so they visit
+// the same leaves. Pruning is the union of what either query still needs: per level the smaller of the two plane
+// distances (rounded down) against the larger of the two current bests (rounded up), confirmed exactly per query.
+// An inactive query has best = -inf for pruning purposes. Results are identical to two separate searches.
+__device__ __forceinline__ void nn_search_dual(int G, const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+                                               const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
+                                               bool actA, double ax, double ay, double az, bool actC, double cx, double cy, double cz,
+                                               double& bestA, uint32_t& bposA, double& bestC, uint32_t& bposC) {
+    bestA = INFINITY; bposA = kNone; bestC = INFINITY; bposC = kNone;
+    if (D > (uint32_t)kPathMax) {   // very deep trees: two plain searches
+        if (actA) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, ax, ay, az, bestA, bposA);
+        if (actC) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, cx, cy, cz, bestC, bposC);
+        return;
+    }
+    const uint32_t sub = threadIdx.x & (uint32_t)(G - 1);
+    const uint32_t first_leaf = (1u << D) - 1u;
+    const double px = actC ? cx : ax, py = actC ? cy : ay, pz = actC ? cz : az;   // query that steers the descent
+    float pd2[kPathMax];
+#pragma unroll
+    for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
+    uint32_t side = 0u, done = 0u;
+    uint32_t node = 0u; int start = 0;
+    for (;;) {
+#pragma unroll
+        for (int L = 0; L < kPathMax; ++L) {
+            if (L >= start && L < (int)D) {
+                const TreeNode n = nodes[node];
+                const double sp = (double)n.split;
+                const double dA = (n.dim == 0 ? ax : (n.dim == 1 ? ay : az)) - sp;
+                const double dC = (n.dim == 0 ? cx : (n.dim == 1 ? cy : cz)) - sp;
+                const double dP = (n.dim == 0 ? px : (n.dim == 1 ? py : pz)) - sp;
+                const uint32_t r = dP >= 0.0 ? 1u : 0u;
+                const double m = fmin(actA ? dA * dA : INFINITY, actC ? dC * dC : INFINITY);
+                pd2[L] = __double2float_rd(m);
+                side = (side & ~(1u << L)) | (r << L);
+                done &= ~(1u << L);
+                node = 2u * node + 1u + r;
+            }
+        }
+        {
+            const uint32_t j = node - first_leaf;
+            const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+#pragma unroll 2
+            for (uint32_t i = lo + sub; i < hi; i += G) {
+                const double x = (double)xs[i], y = (double)ys[i], z = (double)zs[i];
+                if (actA) {
+                    const double dx = ax - x, dy = ay - y, dz = az - z;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 < bestA) { bestA = d2; bposA = i; }
+                    else if (d2 == bestA && bposA != kNone) { if (perm_g[i] < perm_g[bposA]) bposA = i; }
+                }
+                if (actC) {
+                    const double dx = cx - x, dy = cy - y, dz = cz - z;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 < bestC) { bestC = d2; bposC = i; }
+                    else if (d2 == bestC && bposC != kNone) { if (perm_g[i] < perm_g[bposC]) bposC = i; }
+                }
+            }
+            for (int off = 1; off < G; off <<= 1) {
+                {
+                    const double od = __shfl_xor(bestA, off); const uint32_t op = __shfl_xor(bposA, off);
+                    if (od < bestA) { bestA = od; bposA = op; }
+                    else if (od == bestA && op != kNone && op != bposA) { if (bposA == kNone || perm_g[op] < perm_g[bposA]) bposA = op; }
+                }
+                {
+                    const double od = __shfl_xor(bestC, off); const uint32_t op = __shfl_xor(bposC, off);
+                    if (od < bestC) { bestC = od; bposC = op; }
+                    else if (od == bestC && op != kNone && op != bposC) { if (bposC == kNone || perm_g[op] < perm_g[bposC]) bposC = op; }
+                }
+            }
+        }
+        int go = -1;
+        for (;;) {
+            const float bestf = __double2float_ru(fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY));
+            uint32_t cand = 0u;
+#pragma unroll
+            for (int L = 0; L < kPathMax; ++L) cand |= (pd2[L] <= bestf ? 1u : 0u) << L;
+            cand &= ~done & ((1u << D) - 1u);
+            done |= ~cand;
+            if (cand == 0u) break;
+            const int L = 31 - __clz((int)cand);
+            const uint32_t anc = ((node + 1u) >> (D - (uint32_t)L)) - 1u;
+            const TreeNode n = nodes[anc];
+            const double sp = (double)n.split;
+            const double dA = (n.dim == 0 ? ax : (n.dim == 1 ? ay : az)) - sp;
+            const double dC = (n.dim == 0 ? cx : (n.dim == 1 ? cy : cz)) - sp;
+            done |= 1u << L;
+            if ((actA && dA * dA <= bestA) || (actC && dC * dC <= bestC)) { go = L; side ^= 1u << L; node = 2u * anc + 1u + ((side >> L) & 1u); break; }
+        }
+        if (go < 0) break;
+        start = go + 1;
+    }
+}
+
 enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2, MODE_BOTH = 3 };   // BOTH = BAError + BuildProblem association in one pass
 
 #ifdef IBA_STAMPS   // diagnostic build only: per-phase shader-clock deltas of thread 0 into partial slots 56..63
@@ -852,6 +947,183 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         }
         __syncthreads();
     };
+
+    if (MODE == MODE_BOTH) {
+        // ================= fused BAError + BuildProblem association: one work list, one kd traversal per MapPoint =================
+        uint2* arow = assoc_out + (size_t)b * dp.n_kp_total + h.kp_base;
+        const bool usedA = !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
+        const bool usedC = !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
+        uint32_t* s_nnC = s_list + K;        // per list item: cost-path NN (aliases the 2nd half of best_d2)
+        uint32_t* s_nnA = s_list + 2 * K;    // per list item: association-path NN / flags (aliases best_idx: only after its last reader)
+        // work list: keypoints with a correspondence that own a MapPoint and/or a covisible match
+        for (uint32_t k = tid; k < Kceil; k += kThreads) {
+            const bool valid = k < K && s_best_idx[k] != kNone;
+            const int w = k < K ? (int)kp_mp[k].w : 0;
+            const bool want = (usedA || usedC) && valid && w != 0;
+            if (k < K && !(usedA && valid && w == 3)) arow[k] = make_uint2(kNone, kNone);
+            ordered_append(want, k, n3, s_list, s_wcnt);
+        }
+        // matched scan point of every item (needed by the residual loop, the plane pass and, in refit mode, the fits)
+        for (uint32_t i = tid; i < n3; i += kThreads) s_nnC[i] = inv_perm[s_best_idx[s_list[i]]];
+        __syncthreads();   // last read of s_best_idx: its storage now carries s_nnA
+        if (!cached && usedA) {   // ComputeLocalNeighbor at the matched point of every association-eligible item
+            for (uint32_t i = tid; i < n3; i += kThreads) s_nnA[i] = ((int)kp_mp[s_list[i]].w == 3) ? s_nnC[i] : kNone;
+            __syncthreads();
+            fit_points(s_nnA, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
+        }
+        double sum2d = 0.0, sum3d = 0.0;
+        uint32_t c2 = 0, v2 = 0, c3 = 0, v3 = 0, vpl = 0, vpt = 0;
+        for (uint32_t i = tid; i < n3; i += kThreads) {
+            const uint32_t k = s_list[i];
+            const uint32_t pos = s_nnC[i];
+            const int w = (int)kp_mp[k].w;
+            // association: local plane at the matched point (iba_local.cpp:207-231)
+            uint32_t flagA = kNone;
+            if (usedA && w == 3) {
+                const PlaneRec rec = planes_local[pos];
+                uint2 a = make_uint2(kNone, kNone);
+                const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
+                if (neigh_ok && rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) a.x = pos;
+                arow[k] = a;
+                if (neigh_ok) flagA = 0u;
+            }
+            s_nnA[i] = flagA;
+            // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328)
+            if (usedC && (w & 2)) {
+                const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
+                const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
+                const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
+                const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
+                for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
+                    const float2 mm = dp.match_uv[h.match_base + (size_t)sl * K + k];
+                    if (mm.x != mm.x) continue;
+                    const double* rel = s_rel + sl * 12;
+                    const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
+                    const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
+                    const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
+                    const double ou = h.fx * p1x / p1z + h.cx;
+                    const double ov = h.fy * p1y / p1z + h.cy;
+                    if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
+                    const double eu = ou - (double)mm.x, ev = ov - (double)mm.y;
+                    const double dist = sqrt(eu * eu + ev * ev);
+                    if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
+                    ++c2;
+                }
+            }
+        }
+        __syncthreads();
+        // the two MapPoint -> LiDAR-frame queries (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
+        const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;
+        auto queries = [&](uint32_t k, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
+            const float4 mp = kp_mp[k];
+            const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+            const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
+            const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
+            const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
+            const double sx = mx * s, sy = my * s, sz = mz * s;
+            ax = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
+            ay = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
+            az = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
+            const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;   // CV_32F product (:232)
+            const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
+            const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
+            const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
+            const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
+            qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
+            qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
+            qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+        };
+        {
+            const int G = n3 * 8u <= (uint32_t)kThreads ? 8 : (n3 * 4u <= (uint32_t)kThreads ? 4 : (n3 * 2u <= (uint32_t)kThreads ? 2 : 1));
+            for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
+                const uint32_t k = s_list[i];
+                const bool actA = s_nnA[i] != kNone;
+                const bool actC = usedC && prm.use_3d3d && (((int)kp_mp[k].w) & 1);
+                uint32_t rA = kNone, rC = kNone;
+                if (actA || actC) {
+                    double ax, ay, az, qx, qy, qz; queries(k, ax, ay, az, qx, qy, qz);
+                    double bestA, bestC;
+                    nn_search_dual(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, bestA, rA, bestC, rC);
+                    if (actA && bestA > prm.max_3d_dist2) rA = kNone;   // iba_local.cpp:289
+                    if (!actA) rA = kNone;
+                    if (!actC) rC = kNone;
+                }
+                if ((tid & (G - 1)) == 0) { s_nnA[i] = rA; s_nnC[i] = rC; }
+            }
+        }
+        __syncthreads();
+        if (!cached) {
+            fit_points(s_nnA, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
+            if (prm.use_plane) fit_points(s_nnC, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);
+        }
+        uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
+        for (uint32_t i = tid; i < n3; i += kThreads) {
+            const uint32_t k = s_list[i];
+            // association: kind of the 3d-3d block (pointcloud.h:699-717), dense block list for the factor kernel
+            const uint32_t bA = s_nnA[i];
+            uint32_t ay_ = kNone;
+            if (bA != kNone) {
+                const PlaneRec r2 = planes_local[bA];
+                const bool state = !(r2.k < prm.neigh_min_pts || r2.far_d2 < prm.local_min_diff_dist2) &&
+                                   (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);
+                ay_ = bA | (state ? 0x80000000u : 0u);
+            }
+            uint32_t ax_ = kNone;
+            if (usedA && (int)kp_mp[k].w == 3) { ax_ = arow[k].x; arow[k].y = ay_; }
+            fl[i] = make_uint4(k, ax_, ay_, 0u);
+            // cost: point-to-plane / point-to-point distance (iba_global.cpp:111-156, 241-249)
+            const uint32_t bC = s_nnC[i];
+            if (bC != kNone) {
+                double ax, ay, az, qx, qy, qz; queries(k, ax, ay, az, qx, qy, qz);
+                const double ex = (double)c.xs[bC] - qx, ey = (double)c.ys[bC] - qy, ez = (double)c.zs[bC] - qz;
+                double dist = sqrt((ex * ex + ey * ey) + ez * ez);
+                bool is_plane = false;
+                if (prm.use_plane) {
+                    const PlaneRec rec = planes_cost[bC];
+                    if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
+                        !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
+                        dist = fabs(ex * rec.nx + ey * rec.ny + ez * rec.nz);
+                        is_plane = true;
+                    }
+                }
+                if (dist < prm.corr_3d_3d_threshold) { sum3d += dist; ++v3; if (is_plane) ++vpl; else ++vpt; }
+                ++c3;
+            }
+        }
+        if (tid == 0) fcount[(size_t)b * nf + f] = usedA ? n3 : 0u;
+        // K8: reduction -> record (cost slots only if this frame counts for BAError)
+        {
+            const double w2d = wave_sum_f64(sum2d), w3d = wave_sum_f64(sum3d);
+            const unsigned long long wa = wave_sum_u64((unsigned long long)c2 | ((unsigned long long)v2 << 21) | ((unsigned long long)c3 << 42));
+            const unsigned long long wb = wave_sum_u64((unsigned long long)v3 | ((unsigned long long)vpl << 21) | ((unsigned long long)vpt << 42));
+            unsigned long long* s_redu = (unsigned long long*)s_red;
+            __syncthreads();
+            if (lane == 63) { s_red[wave * 4 + 0] = w2d; s_red[wave * 4 + 1] = w3d; s_redu[wave * 4 + 2] = wa; s_redu[wave * 4 + 3] = wb; }
+            __syncthreads();
+            if (tid < kPartialStride) {
+                double out = 0.0;
+                if (usedC) {
+                    if (tid == P_SUM_3D2D || tid == P_SUM_3D3D) { for (int w = 0; w < kWaves; ++w) out += s_red[w * 4 + (tid == P_SUM_3D2D ? 0 : 1)]; }
+                    else if (tid >= P_CNT_3D2D && tid <= P_VALID_PT) {
+                        unsigned long long a = 0, bb = 0;
+                        for (int w = 0; w < kWaves; ++w) { a += s_redu[w * 4 + 2]; bb += s_redu[w * 4 + 3]; }
+                        const unsigned long long msk = (1ull << 21) - 1ull;
+                        const unsigned long long vals[6] = {a & msk, (a >> 21) & msk, (a >> 42) & msk, bb & msk, (bb >> 21) & msk, (bb >> 42) & msk};
+                        out = (double)vals[tid - P_CNT_3D2D];
+                        if (!prm.use_3d3d && (tid == P_CNT_3D3D || tid == P_VALID_3D3D)) out = 1.0;   // iba_global.cpp:214-220
+                    }
+                    else if (tid == P_FRAMES) out = 1.0;
+                    else if (tid == P_NCORR) out = (double)n_corr;
+                    else if (tid == P_HE_SUM) out = h.he_valid ? he[(size_t)b * nf + f] : 0.0;
+                    else if (tid == P_HE_CNT) out = h.he_valid ? 1.0 : 0.0;
+                }
+                if (tid == P_FRAMES_N) out = usedA ? 1.0 : 0.0;
+                else if (tid == P_NCORR_N) out = usedA ? (double)n_corr : 0.0;
+                part[tid] = out;
+            }
+        }
+        return;
+    }
 
     bool used_assoc = false;
     if (MODE == MODE_ASSOC || MODE == MODE_BOTH) {

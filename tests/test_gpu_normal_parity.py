@@ -69,8 +69,8 @@ def test_local_params_differ_from_cost_params(pkg, synth, abi, ob, scene_small):
 
 
 def test_eval_full_equals_separate_calls(pkg, synth, abi, scene_small):
-    """iba_eval_full (one fused pass) must reproduce iba_eval_cost + iba_eval_normal: counters and the normal
-    equations bit for bit; f1/f2/C to the last ulps (the frame records are summed in a different grouping)."""
+    """iba_eval_full (one fused pass) must reproduce iba_eval_cost + iba_eval_normal: counters bit for bit;
+    sums to the last ulps (records and residual blocks are summed in a different, but fixed, grouping)."""
     prob, meta = scene_small
     h = pkg.IbaHandle(prob, abi.reference_yaml_params())
     rng = np.random.default_rng(21)
@@ -85,7 +85,13 @@ def test_eval_full_equals_separate_calls(pkg, synth, abi, scene_small):
             else:
                 assert da[k] == db[k], k
     for a, b in zip(nf, ns):
-        assert a.counts() == b.counts() and np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.cost == b.cost
+        # same residual blocks, summed in a different (fixed) order: the fused mode's work list also holds cost-only keypoints
+        assert a.counts() == b.counts()
+        assert np.max(np.abs(a.H_np() - b.H_np())) <= 1e-12 * np.max(np.abs(b.H_np())) and np.max(np.abs(a.b_np() - b.b_np())) <= 1e-11 * np.max(np.abs(b.b_np()))
+        assert abs(a.cost - b.cost) <= 1e-13 * abs(b.cost)
+    # and it is run-to-run reproducible bit for bit
+    cf2, nf2 = h.eval_full(xs)
+    assert all(np.array_equal(a.H_np(), b.H_np()) and a.cost == b.cost for a, b in zip(nf, nf2)) and all(a.f1 == b.f1 and a.f2 == b.f2 for a, b in zip(cf, cf2))
     h.close()
 
 
