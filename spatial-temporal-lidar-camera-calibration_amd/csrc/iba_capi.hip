@@ -159,9 +159,11 @@ bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
     off = align_up(off, 16); L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
     L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
     off = align_up(off, 8); L.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
-    L.off_bitmap = off; off += 4u * std::max(h->maxBitmapWords, 1u);
+    off = align_up(off, 16); L.off_red = off; off += red_bytes;
+    // keypoint bitmap, coarse CSR and candidate queue are contiguous: after phase 2 the fused mode parks its
+    // unfinished NN queries in [off_bitmap, total)
+    off = align_up(off, 16); L.off_bitmap = off; off += 4u * std::max(h->maxBitmapWords, 1u);
     L.off_cstart = off; off += 2u * std::max(h->maxCoarse, 1u);
-    off = align_up(off, 8); L.off_red = off; off += red_bytes;
     off = align_up(off, 16); L.off_cand = off;
     if (off + 1024u > kLdsBytes) return false;
     // candidate queue takes what is left (u16 entries when the scan is in LDS, u32 otherwise); a full queue only

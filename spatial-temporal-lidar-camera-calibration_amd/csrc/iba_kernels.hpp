@@ -472,6 +472,14 @@ __device__ unsigned long long g_dbg[64];
 // reads, one per tree level — is pure VALU: the deepest unfinished level whose split plane is within the current
 // best distance is found with an unrolled scan, its far child is entered, and only the levels below are fetched.
 constexpr int kPathMax = 16;   // deeper trees (> 1.5 M points per scan) use the generic LDS-walking branch
+#ifndef IBA_NN_TO_END
+#define IBA_NN_TO_END 0
+#endif
+#ifndef IBA_NN_END_AT
+#define IBA_NN_END_AT 128
+#endif
+constexpr int kNNEndAt = IBA_NN_END_AT;       // resume rounds run to the end once this few queries are left
+constexpr bool kNNToEnd = IBA_NN_TO_END;   // experiment switch: 1 = every query runs to completion in round 0
 __device__ __forceinline__ void nn_search_group(int G, const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
                                                 const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
                                                 double qx, double qy, double qz, double& best, uint32_t& bpos) {
@@ -564,47 +572,126 @@ __device__ __forceinline__ void nn_search_group(int G, const float* __restrict__
     }
 }
 
-// ---- two exact 1-NN searches in ONE traversal (fused mode): the association-path query qa and the cost-path query
-// qc of the same MapPoint differ by ~1e-7 relative (different float/double islands in the reference), so they visit
-// the same leaves. Pruning is the union of what either query still needs: per level the smaller of the two plane
-// distances (rounded down) against the larger of the two current bests (rounded up), confirmed exactly per query.
-// An inactive query has best = -inf for pruning purposes. Results are identical to two separate searches.
-__device__ __forceinline__ void nn_search_dual(int G, const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
-                                               const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
-                                               bool actA, double ax, double ay, double az, bool actC, double cx, double cy, double cz,
-                                               double& bestA, uint32_t& bposA, double& bestC, uint32_t& bposC) {
-    bestA = INFINITY; bposA = kNone; bestC = INFINITY; bposC = kNone;
-    if (D > (uint32_t)kPathMax) {   // very deep trees: two plain searches
-        if (actA) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, ax, ay, az, bestA, bposA);
-        if (actC) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, cx, cy, cz, bestC, bposC);
-        return;
+// exchange with the partner lane of a butterfly step on the VALU (DPP), no LDS round trip:
+// quad_perm [1,0,3,2] / [2,3,0,1], then row_half_mirror / row_mirror (after the quad steps every lane of a quad holds
+// the same value, so mirroring pairs the two halves). Only the 32-lane step needs a cross-row move (ds_swizzle).
+__device__ __forceinline__ void nn_merge(double& best, uint32_t& bpos, double od, uint32_t op, const uint32_t* __restrict__ perm_g) {
+    if (od < best) { best = od; bpos = op; }
+    else if (od == best && op != kNone && op != bpos) { if (bpos == kNone || perm_g[op] < perm_g[bpos]) bpos = op; }
+}
+__device__ __forceinline__ void nn_group_reduce(int G, double& best, uint32_t& bpos, const uint32_t* __restrict__ perm_g) {
+    if (G >= 2) nn_merge(best, bpos, dpp_f64<0xB1, 0xf>(best), (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bpos, 0xB1, 0xf, 0xf, false), perm_g);
+    if (G >= 4) nn_merge(best, bpos, dpp_f64<0x4E, 0xf>(best), (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bpos, 0x4E, 0xf, 0xf, false), perm_g);
+    if (G >= 8) nn_merge(best, bpos, dpp_f64<0x141, 0xf>(best), (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bpos, 0x141, 0xf, 0xf, false), perm_g);
+    if (G >= 16) nn_merge(best, bpos, dpp_f64<0x140, 0xf>(best), (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bpos, 0x140, 0xf, 0xf, false), perm_g);
+    if (G >= 32) nn_merge(best, bpos, __shfl_xor(best, 16), __shfl_xor(bpos, 16), perm_g);
+}
+
+// ---- two exact 1-NN searches in ONE traversal (fused mode), resumable leaf by leaf ----
+// The association-path query qa and the cost-path query qc of the same MapPoint differ by ~1e-7 relative (different
+// float/double islands in the reference), so they visit the same leaves. Pruning is the union of what either query
+// still needs: per level the smaller of the two plane distances (rounded down) against the larger of the two current
+// bests (rounded up), confirmed exactly per query. Results are identical to two separate searches.
+//
+// 72 % of the queries are finished after their first leaf, a few need 5..24: run to completion per lane group, a wave
+// idles on its slowest query for 3/4 of the search time. So the traversal is cut into steps of ONE leaf visit. A step
+// returns whether a far subtree is still within reach; the whole traversal state that has to survive is 64 bits
+// (current leaf, done mask, level to enter) + the running bests: everything else (the per-level plane distances, the
+// side bits) is a function of the current leaf's ancestors, which are addressable without walking
+// (ancestor at level L of heap node n: ((n+1) >> (D-L)) - 1). Between steps the unfinished queries are compacted
+// and re-spread over the block with more lanes each (see the fused branch of iba_frame_kernel).
+struct DualNN {
+    double bestA, bestC;        // running best d^2 (INFINITY at the start)
+    uint32_t bposA, bposC;      // tree position of the best point
+    uint32_t leaf, done;        // leaf index of the last visited leaf; per level: far side handled / out of reach
+    int go;                     // level whose far child comes next (valid when a step returned true)
+#ifdef IBA_STAMPS_FINE
+    uint32_t visits;
+#endif
+};
+__device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+                                             const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
+                                             bool actA, double ax, double ay, double az, bool actC, double cx, double cy, double cz,
+                                             DualNN& st, bool fresh, bool to_end) {
+    if (D > (uint32_t)kPathMax) {   // very deep trees: two plain searches, always to the end
+        st.bestA = INFINITY; st.bposA = kNone; st.bestC = INFINITY; st.bposC = kNone;
+        if (actA) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, ax, ay, az, st.bestA, st.bposA);
+        if (actC) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, cx, cy, cz, st.bestC, st.bposC);
+        return false;
     }
     const uint32_t sub = threadIdx.x & (uint32_t)(G - 1);
     const uint32_t first_leaf = (1u << D) - 1u;
-    const double px = actC ? cx : ax, py = actC ? cy : ay, pz = actC ? cz : az;   // query that steers the descent
+    // The tree walk is float32 and CONSERVATIVE; only the leaf scans are exact. One float query p steers the descent;
+    // del >= |q - p| (per axis, both queries). For a node with split s, d = fl(p - s):
+    //   exact |q - s| >= |p - s| - del >= |d| (1 - 2^-24) - del,
+    // so lb = max(|d| - del', 0)^2 * (1 - 2^-19) with del' = del (1 + 2^-19) stays below the exact squared plane
+    // distance of either query through all float roundings. A far side is skipped only if lb > RN_float(best), which
+    // implies lb > best; anything else is visited, so the result equals the exhaustive exact search.
+    const float p0 = (float)(actC ? cx : ax), p1 = (float)(actC ? cy : ay), p2 = (float)(actC ? cz : az);
+    float del;
+    {
+        double m = 0.0;
+        if (actA) m = fmax(fmax(fabs(ax - (double)p0), fabs(ay - (double)p1)), fabs(az - (double)p2));
+        if (actC) m = fmax(m, fmax(fmax(fabs(cx - (double)p0), fabs(cy - (double)p1)), fabs(cz - (double)p2)));
+        del = (float)m * 1.00001f + 1e-30f;
+    }
+    auto lower_bound = [&](float d) { const float a = fmaxf(fabsf(d) - del, 0.f); return (a * a) * 0.999998f; };
+#ifdef IBA_STAMPS_FINE
+    unsigned long long sg0 = __builtin_readcyclecounter(), sg1 = sg0, sg2 = sg0, sg3 = sg0, sg4 = sg0, sg5 = sg0;
+    const int sgb = fresh ? 48 : 56;
+#endif
+    double bestA = st.bestA, bestC = st.bestC; uint32_t bposA = st.bposA, bposC = st.bposC;
     float pd2[kPathMax];
+    uint32_t side = 0u, done = 0u, node = 0u; int start = 0, go = -1;
+    if (fresh) {
 #pragma unroll
-    for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
-    uint32_t side = 0u, done = 0u;
-    uint32_t node = 0u; int start = 0;
+        for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
+    } else {   // rebuild the path registers from the ancestors of the last leaf: independent LDS reads, issued together
+        node = first_leaf + st.leaf; done = st.done; go = st.go;
+#pragma unroll
+        for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
+#pragma unroll
+        for (int H = 0; H < kPathMax; H += 8) {   // eight levels per batch of reads
+            if (H < (int)D) {
+                TreeNode nn[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int L = H + q; nn[q] = nodes[((node + 1u) >> (D - (uint32_t)(L < (int)D ? L : (int)D - 1))) - 1u]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int L = H + q;
+                    const float lb = lower_bound((nn[q].dim == 0 ? p0 : (nn[q].dim == 1 ? p1 : p2)) - nn[q].split);
+                    pd2[L] = L < (int)D ? lb : INFINITY;
+                    if (L < (int)D) side |= (((node + 1u) >> (D - (uint32_t)L - 1u)) & 1u) << L;
+                }
+            }
+        }
+    }
     for (;;) {
+#ifdef IBA_STAMPS_FINE
+        sg1 = __builtin_readcyclecounter();
+#endif
+        if (go >= 0) {   // enter the far child at level go
+            const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
+            done |= 1u << go; side ^= 1u << go;
+            node = 2u * anc + 1u + ((side >> go) & 1u);
+            start = go + 1;
+        }
 #pragma unroll
         for (int L = 0; L < kPathMax; ++L) {
             if (L >= start && L < (int)D) {
                 const TreeNode n = nodes[node];
-                const double sp = (double)n.split;
-                const double dA = (n.dim == 0 ? ax : (n.dim == 1 ? ay : az)) - sp;
-                const double dC = (n.dim == 0 ? cx : (n.dim == 1 ? cy : cz)) - sp;
-                const double dP = (n.dim == 0 ? px : (n.dim == 1 ? py : pz)) - sp;
-                const uint32_t r = dP >= 0.0 ? 1u : 0u;
-                const double m = fmin(actA ? dA * dA : INFINITY, actC ? dC * dC : INFINITY);
-                pd2[L] = __double2float_rd(m);
+                const float d = (n.dim == 0 ? p0 : (n.dim == 1 ? p1 : p2)) - n.split;
+                const uint32_t r = d >= 0.f ? 1u : 0u;
+                pd2[L] = lower_bound(d);
                 side = (side & ~(1u << L)) | (r << L);
                 done &= ~(1u << L);
                 node = 2u * node + 1u + r;
             }
         }
         {
+#ifdef IBA_STAMPS_FINE
+            sg2 = __builtin_readcyclecounter();
+#endif
             const uint32_t j = node - first_leaf;
             const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
 #pragma unroll 2
@@ -614,49 +701,48 @@ __device__ __forceinline__ void nn_search_dual(int G, const float* __restrict__ 
                     const double dx = ax - x, dy = ay - y, dz = az - z;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
                     if (d2 < bestA) { bestA = d2; bposA = i; }
-                    else if (d2 == bestA && bposA != kNone) { if (perm_g[i] < perm_g[bposA]) bposA = i; }
+                    else if (d2 == bestA && bposA != kNone && bposA != i) { if (perm_g[i] < perm_g[bposA]) bposA = i; }
                 }
                 if (actC) {
                     const double dx = cx - x, dy = cy - y, dz = cz - z;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
                     if (d2 < bestC) { bestC = d2; bposC = i; }
-                    else if (d2 == bestC && bposC != kNone) { if (perm_g[i] < perm_g[bposC]) bposC = i; }
+                    else if (d2 == bestC && bposC != kNone && bposC != i) { if (perm_g[i] < perm_g[bposC]) bposC = i; }
                 }
             }
-            for (int off = 1; off < G; off <<= 1) {
-                {
-                    const double od = __shfl_xor(bestA, off); const uint32_t op = __shfl_xor(bposA, off);
-                    if (od < bestA) { bestA = od; bposA = op; }
-                    else if (od == bestA && op != kNone && op != bposA) { if (bposA == kNone || perm_g[op] < perm_g[bposA]) bposA = op; }
-                }
-                {
-                    const double od = __shfl_xor(bestC, off); const uint32_t op = __shfl_xor(bposC, off);
-                    if (od < bestC) { bestC = od; bposC = op; }
-                    else if (od == bestC && op != kNone && op != bposC) { if (bposC == kNone || perm_g[op] < perm_g[bposC]) bposC = op; }
-                }
-            }
+#ifdef IBA_STAMPS_FINE
+            sg3 = __builtin_readcyclecounter();
+#endif
+            if (actA) nn_group_reduce(G, bestA, bposA, perm_g);
+            if (actC) nn_group_reduce(G, bestC, bposC, perm_g);
+#ifdef IBA_STAMPS_FINE
+            sg4 = __builtin_readcyclecounter();
+#endif
         }
-        int go = -1;
-        for (;;) {
-            const float bestf = __double2float_ru(fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY));
+        {   // deepest level whose far side may still be within reach of either query
+            const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
             uint32_t cand = 0u;
 #pragma unroll
             for (int L = 0; L < kPathMax; ++L) cand |= (pd2[L] <= bestf ? 1u : 0u) << L;
             cand &= ~done & ((1u << D) - 1u);
-            done |= ~cand;
-            if (cand == 0u) break;
-            const int L = 31 - __clz((int)cand);
-            const uint32_t anc = ((node + 1u) >> (D - (uint32_t)L)) - 1u;
-            const TreeNode n = nodes[anc];
-            const double sp = (double)n.split;
-            const double dA = (n.dim == 0 ? ax : (n.dim == 1 ? ay : az)) - sp;
-            const double dC = (n.dim == 0 ? cx : (n.dim == 1 ? cy : cz)) - sp;
-            done |= 1u << L;
-            if ((actA && dA * dA <= bestA) || (actC && dC * dC <= bestC)) { go = L; side ^= 1u << L; node = 2u * anc + 1u + ((side >> L) & 1u); break; }
+            done |= ~cand;                               // the bests only shrink: out of reach stays out of reach
+            go = cand ? 31 - __clz((int)cand) : -1;
         }
-        if (go < 0) break;
-        start = go + 1;
+#ifdef IBA_STAMPS_FINE
+        sg5 = __builtin_readcyclecounter();
+        if (threadIdx.x == 0) { atomicAdd(&g_dbg[sgb + 1], sg2 - sg1); atomicAdd(&g_dbg[sgb + 2], sg3 - sg2); atomicAdd(&g_dbg[sgb + 3], sg4 - sg3); atomicAdd(&g_dbg[sgb + 4], sg5 - sg4); atomicAdd(&g_dbg[sgb + 5], 1ull); }
+#endif
+#ifdef IBA_STAMPS_FINE
+        st.visits++;
+#endif
+        if (go < 0 || !to_end) break;
     }
+#ifdef IBA_STAMPS_FINE
+    if (threadIdx.x == 0) { atomicAdd(&g_dbg[sgb + 0], sg1 - sg0); atomicAdd(&g_dbg[sgb + 6], 1ull); atomicAdd(&g_dbg[sgb + 7], __builtin_readcyclecounter() - sg0); }
+#endif
+    st.bestA = bestA; st.bestC = bestC; st.bposA = bposA; st.bposC = bposC;
+    st.leaf = node - first_leaf; st.done = done & 0xffffu; st.go = go;
+    return go >= 0;
 }
 
 enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2, MODE_BOTH = 3 };   // BOTH = BAError + BuildProblem association in one pass
@@ -768,7 +854,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
     const uint32_t ncs = h.gwc * h.ghc + 1u;
     for (uint32_t i = tid; i < ncs; i += kThreads) s_cstart[i] = (uint16_t)dp.coarse_start[h.coarse_base + i];
     if ((uint32_t)tid < h.n_slots * 12u) s_rel[tid] = dp.slots[h.slot_base + tid / 12].rel[tid % 12];
-    if (tid < 2) s_misc[tid] = 0u;
+    if (tid < 4) s_misc[tid] = 0u;
     __syncthreads();
 
     FrameCtx c;
@@ -1012,6 +1098,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             }
         }
         __syncthreads();
+        IBA_STAMP(4);
         // the two MapPoint -> LiDAR-frame queries (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
         const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;
         auto queries = [&](uint32_t k, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
@@ -1033,29 +1120,116 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
             qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
         };
-        {
-            const int G = n3 * 8u <= (uint32_t)kThreads ? 8 : (n3 * 4u <= (uint32_t)kThreads ? 4 : (n3 * 2u <= (uint32_t)kThreads ? 2 : 1));
-            for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
-                const uint32_t k = s_list[i];
-                const bool actA = s_nnA[i] != kNone;
-                const bool actC = usedC && prm.use_3d3d && (((int)kp_mp[k].w) & 1);
-                uint32_t rA = kNone, rC = kNone;
-                if (actA || actC) {
-                    double ax, ay, az, qx, qy, qz; queries(k, ax, ay, az, qx, qy, qz);
-                    double bestA, bestC;
-                    nn_search_dual(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, bestA, rA, bestC, rC);
-                    if (actA && bestA > prm.max_3d_dist2) rA = kNone;   // iba_local.cpp:289
-                    if (!actA) rA = kNone;
-                    if (!actC) rC = kNone;
+        // Rounds (nn_dual_step). Round 0: every MapPoint descends and scans its first leaf — uniform work, and 72 % of
+        // the queries end there. The unfinished ones park 64 B of state in LDS (the keypoint grid's and the candidate
+        // queue's storage, dead by now) and are re-spread over the block with more lanes each; a round visits one more
+        // leaf per query until few enough are left to run to the end. Slot order is irrelevant (results go to the
+        // per-item arrays), so the compaction is one LDS atomic per unfinished query.
+        struct HardState { double a[3], c[3]; uint32_t item_go, leaf_done, bposA, bposC; };   // item | go << 24 | actA << 30 | actC << 31
+        HardState* s_hard = (HardState*)(smem + lay.off_bitmap);
+        const uint32_t cap_hard = min((lay.total - lay.off_bitmap) / (uint32_t)sizeof(HardState), (uint32_t)kThreads);   // <= one pass per round
+        uint32_t n_items = n3; bool fresh = true; int round = 0;
+        for (;;) {
+            int G;
+            if (fresh) G = n_items * 8u <= (uint32_t)kThreads ? 8 : (n_items * 4u <= (uint32_t)kThreads ? 4 : (n_items * 2u <= (uint32_t)kThreads ? 2 : 1));
+            else { G = 32; while ((uint32_t)G * n_items > (uint32_t)kThreads) G >>= 1; }
+            const uint32_t per_it = (uint32_t)kThreads / (uint32_t)G;
+            uint32_t* cnt = s_misc + 2 + (round & 1);
+            if (tid == 0) *cnt = 0u;
+#ifdef IBA_STAMPS_FINE
+            const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+            if (tid == 0) { const int rr = round < 7 ? round : 7; atomicAdd(&g_dbg[8 + rr], (unsigned long long)n_items); atomicAdd(&g_dbg[24 + rr], 1ull); }
+#endif
+            __syncthreads();
+            for (uint32_t base = 0; base < n_items; base += per_it) {
+                const uint32_t e = base + (uint32_t)tid / (uint32_t)G;
+                uint32_t i = e; bool actA = false, actC = false;
+                double ax = 0, ay = 0, az = 0, qx = 0, qy = 0, qz = 0;
+                DualNN st; st.bestA = INFINITY; st.bestC = INFINITY; st.bposA = kNone; st.bposC = kNone; st.leaf = 0u; st.done = 0u; st.go = -1;
+#ifdef IBA_STAMPS_FINE
+                st.visits = 0u;
+#endif
+                if (e < n_items) {
+                    if (fresh) {
+                        const uint32_t k = s_list[i];
+                        actA = s_nnA[i] != kNone;
+                        actC = usedC && prm.use_3d3d && (((int)kp_mp[k].w) & 1);
+                        if (actA || actC) queries(k, ax, ay, az, qx, qy, qz);
+                    } else {
+                        const HardState hs = s_hard[e];
+                        i = hs.item_go & 0xffffffu; st.go = (int)((hs.item_go >> 24) & 31u); actA = (hs.item_go >> 30) & 1u; actC = hs.item_go >> 31;
+                        st.leaf = hs.leaf_done & 0xffffu; st.done = hs.leaf_done >> 16; st.bposA = hs.bposA; st.bposC = hs.bposC;
+                        ax = hs.a[0]; ay = hs.a[1]; az = hs.a[2]; qx = hs.c[0]; qy = hs.c[1]; qz = hs.c[2];
+                        // the running bests are the exact distances of the stored positions (same expression as the leaf scan)
+                        if (st.bposA != kNone) { const double dx = ax - (double)c.xs[st.bposA], dy = ay - (double)c.ys[st.bposA], dz = az - (double)c.zs[st.bposA]; st.bestA = (dx * dx + dy * dy) + dz * dz; }
+                        if (st.bposC != kNone) { const double dx = qx - (double)c.xs[st.bposC], dy = qy - (double)c.ys[st.bposC], dz = qz - (double)c.zs[st.bposC]; st.bestC = (dx * dx + dy * dy) + dz * dz; }
+                    }
                 }
-                if ((tid & (G - 1)) == 0) { s_nnA[i] = rA; s_nnC[i] = rC; }
+                __syncthreads();   // every state of this pass is in registers: its slot may be overwritten
+#ifdef IBA_STAMPS_FINE
+                const unsigned long long rt0 = __builtin_readcyclecounter(); unsigned long long rt1 = rt0, rt2 = rt0;
+#endif
+                if (e < n_items) {
+                    if (actA || actC) {
+                        bool fr = fresh, to_end = kNNToEnd || (!fresh && n_items <= (uint32_t)kNNEndAt);
+#ifdef IBA_STAMPS_FINE
+                        rt1 = __builtin_readcyclecounter();
+#endif
+                        for (;;) {
+                            const bool more = nn_dual_step(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, st, fr, to_end);
+                            if (!more) break;
+                            uint32_t slot = 0u;
+                            if ((tid & (G - 1)) == 0) slot = atomicAdd(cnt, 1u);
+                            slot = __shfl(slot, lane & ~(G - 1));
+                            if (slot < cap_hard) {   // park: one more leaf next round
+                                if ((tid & (G - 1)) == 0) {
+                                    HardState hs; hs.a[0] = ax; hs.a[1] = ay; hs.a[2] = az; hs.c[0] = qx; hs.c[1] = qy; hs.c[2] = qz;
+                                    hs.item_go = i | ((uint32_t)st.go << 24) | ((actA ? 1u : 0u) << 30) | ((actC ? 1u : 0u) << 31);
+                                    hs.leaf_done = st.leaf | (st.done << 16); hs.bposA = st.bposA; hs.bposC = st.bposC;
+                                    s_hard[slot] = hs;
+                                }
+                                i = kNone;
+                                break;
+                            }
+                            fr = false; to_end = true;   // no room to park it: finish right here
+                        }
+                    }
+#ifdef IBA_STAMPS_FINE
+                    if (kNNToEnd && (tid & (G - 1)) == 0 && (actA || actC)) {
+                        const uint32_t v = st.visits; const int bin = v <= 4 ? (int)v - 1 : (v <= 8 ? 4 : (v <= 16 ? 5 : (v <= 32 ? 6 : 7)));
+                        atomicAdd(&g_dbg[40 + bin], 1ull); atomicAdd(&g_dbg[6], (unsigned long long)v); atomicMax(&s_misc[1], v);
+                    }
+#endif
+                    if (i != kNone && (tid & (G - 1)) == 0) {
+                        // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
+                        s_nnC[i] = actC ? st.bposC : kNone;
+                        s_nnA[i] = (actA && !(st.bestA > prm.max_3d_dist2)) ? st.bposA : kNone;
+                    }
+                }
+#ifdef IBA_STAMPS_FINE
+                rt2 = __builtin_readcyclecounter();
+                __syncthreads();
+                if (tid == 0) { const int o = fresh ? 32 : 36; atomicAdd(&g_dbg[o], rt1 - rt0); atomicAdd(&g_dbg[o + 1], rt2 - rt1); atomicAdd(&g_dbg[o + 2], __builtin_readcyclecounter() - rt2); atomicAdd(&g_dbg[o + 3], 1ull); }
+#endif
+                __syncthreads();
             }
+            n_items = min(*cnt, cap_hard);
+#ifdef IBA_STAMPS_FINE
+            if (tid == 0) { const int rr = round < 7 ? round : 7; atomicAdd(&g_dbg[16 + rr], __builtin_readcyclecounter() - dbg_t0); }
+#endif
+#ifdef IBA_STAMPS_FINE
+            if (kNNToEnd && tid == 0) { const uint32_t v = s_misc[1]; const int bin = v <= 4 ? (int)v - 1 : (v <= 8 ? 4 : (v <= 16 ? 5 : (v <= 32 ? 6 : 7))); atomicAdd(&g_dbg[56 + (v ? bin : 0)], 1ull); atomicAdd(&g_dbg[7], (unsigned long long)v); }
+#endif
+            if (n_items == 0u) break;
+            fresh = false; ++round;
         }
         __syncthreads();
+        IBA_STAMP(5);
         if (!cached) {
             fit_points(s_nnA, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
             if (prm.use_plane) fit_points(s_nnC, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);
         }
+        IBA_STAMP(6);
         uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
         for (uint32_t i = tid; i < n3; i += kThreads) {
             const uint32_t k = s_list[i];
@@ -1122,6 +1296,10 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                 part[tid] = out;
             }
         }
+#ifdef IBA_STAMPS
+        __syncthreads();
+        if (tid == 0) { const unsigned long long te = __builtin_readcyclecounter(); for (int i = 0; i < 7; ++i) part[56 + i] = (double)((i < 6 ? stamp_t[i + 1] : te) - stamp_t[i]); part[63] = (double)(stamp_t[7] - stamp_t[1]); }
+#endif
         return;
     }
 
