@@ -428,7 +428,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
                 const int kr = d->match_kp_ref[m], kc = d->match_kp_covis[m];
                 if (kr < 0 || (uint32_t)kr >= x.K || kc < 0 || (uint64_t)kc >= cK) { bad_match = true; continue; }
                 match_uv[x.match_base + (uint64_t)sl * x.K + b.kp_inv[kr]] = float2{d->kp_uv[2 * (ck0 + kc)], d->kp_uv[2 * (ck0 + kc) + 1]};
-                kp_mp[x.kp_base + b.kp_inv[kr]].w = (float)(((int)kp_mp[x.kp_base + b.kp_inv[kr]].w) | 2);   // matched in >= 1 covisible KF
+                // w = 1 (owns a MapPoint) | 2 (matched in >= 1 covisible KF) | per-slot match bits << 2  (<= 12 bits: exact in float)
+                kp_mp[x.kp_base + b.kp_inv[kr]].w = (float)(((int)kp_mp[x.kp_base + b.kp_inv[kr]].w) | 2 | (4 << sl));
             }
         }
     });

@@ -475,6 +475,9 @@ constexpr int kPathMax = 16;   // deeper trees (> 1.5 M points per scan) use the
 #ifndef IBA_NN_TO_END
 #define IBA_NN_TO_END 0
 #endif
+#ifndef IBA_LEAF_UNROLL
+#define IBA_LEAF_UNROLL 1
+#endif
 #ifndef IBA_NN_END_AT
 #define IBA_NN_END_AT 128
 #endif
@@ -636,6 +639,7 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
         del = (float)m * 1.00001f + 1e-30f;
     }
     auto lower_bound = [&](float d) { const float a = fmaxf(fabsf(d) - del, 0.f); return (a * a) * 0.999998f; };
+    // contract: an inactive query comes in with NaN coordinates (the leaf scans run both queries unconditionally)
 #ifdef IBA_STAMPS_FINE
     unsigned long long sg0 = __builtin_readcyclecounter(), sg1 = sg0, sg2 = sg0, sg3 = sg0, sg4 = sg0, sg5 = sg0;
     const int sgb = fresh ? 48 : 56;
@@ -694,27 +698,31 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
 #endif
             const uint32_t j = node - first_leaf;
             const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
-#pragma unroll 2
+            // branch-free in the common case: an inactive query has NaN coordinates (every compare is false), the
+            // running best is a min, and only an exact tie (lowest original index wins) leaves the straight line
+#pragma unroll IBA_LEAF_UNROLL
             for (uint32_t i = lo + sub; i < hi; i += G) {
                 const double x = (double)xs[i], y = (double)ys[i], z = (double)zs[i];
-                if (actA) {
+                {
                     const double dx = ax - x, dy = ay - y, dz = az - z;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2 < bestA) { bestA = d2; bposA = i; }
-                    else if (d2 == bestA && bposA != kNone && bposA != i) { if (perm_g[i] < perm_g[bposA]) bposA = i; }
+                    const bool lt = d2 < bestA, eq = d2 == bestA;
+                    bestA = lt ? d2 : bestA; bposA = lt ? i : bposA;
+                    if (__builtin_expect(eq, 0)) { if (bposA != kNone && bposA != i && perm_g[i] < perm_g[bposA]) bposA = i; }
                 }
-                if (actC) {
+                {
                     const double dx = cx - x, dy = cy - y, dz = cz - z;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2 < bestC) { bestC = d2; bposC = i; }
-                    else if (d2 == bestC && bposC != kNone && bposC != i) { if (perm_g[i] < perm_g[bposC]) bposC = i; }
+                    const bool lt = d2 < bestC, eq = d2 == bestC;
+                    bestC = lt ? d2 : bestC; bposC = lt ? i : bposC;
+                    if (__builtin_expect(eq, 0)) { if (bposC != kNone && bposC != i && perm_g[i] < perm_g[bposC]) bposC = i; }
                 }
             }
 #ifdef IBA_STAMPS_FINE
             sg3 = __builtin_readcyclecounter();
 #endif
-            if (actA) nn_group_reduce(G, bestA, bposA, perm_g);
-            if (actC) nn_group_reduce(G, bestC, bposC, perm_g);
+            nn_group_reduce(G, bestA, bposA, perm_g);
+            nn_group_reduce(G, bestC, bposC, perm_g);
 #ifdef IBA_STAMPS_FINE
             sg4 = __builtin_readcyclecounter();
 #endif
@@ -1041,31 +1049,30 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         const bool usedC = !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
         uint32_t* s_nnC = s_list + K;        // per list item: cost-path NN (aliases the 2nd half of best_d2)
         uint32_t* s_nnA = s_list + 2 * K;    // per list item: association-path NN / flags (aliases best_idx: only after its last reader)
-        // work list: keypoints with a correspondence that own a MapPoint and/or a covisible match
+        // work list: keypoints with a correspondence that own a MapPoint and/or a covisible match; entry = k | w << 16
         for (uint32_t k = tid; k < Kceil; k += kThreads) {
             const bool valid = k < K && s_best_idx[k] != kNone;
             const int w = k < K ? (int)kp_mp[k].w : 0;
             const bool want = (usedA || usedC) && valid && w != 0;
-            if (k < K && !(usedA && valid && w == 3)) arow[k] = make_uint2(kNone, kNone);
-            ordered_append(want, k, n3, s_list, s_wcnt);
+            if (k < K && !(usedA && valid && (w & 3) == 3)) arow[k] = make_uint2(kNone, kNone);
+            ordered_append(want, k | ((uint32_t)w << 16), n3, s_list, s_wcnt);   // bits 16,17: flags; 18..27: covisible-slot mask
         }
         // matched scan point of every item (needed by the residual loop, the plane pass and, in refit mode, the fits)
-        for (uint32_t i = tid; i < n3; i += kThreads) s_nnC[i] = inv_perm[s_best_idx[s_list[i]]];
+        for (uint32_t i = tid; i < n3; i += kThreads) s_nnC[i] = inv_perm[s_best_idx[s_list[i] & 0xffffu]];
         __syncthreads();   // last read of s_best_idx: its storage now carries s_nnA
         if (!cached && usedA) {   // ComputeLocalNeighbor at the matched point of every association-eligible item
-            for (uint32_t i = tid; i < n3; i += kThreads) s_nnA[i] = ((int)kp_mp[s_list[i]].w == 3) ? s_nnC[i] : kNone;
+            for (uint32_t i = tid; i < n3; i += kThreads) s_nnA[i] = (((s_list[i] >> 16) & 3u) == 3u) ? s_nnC[i] : kNone;
             __syncthreads();
             fit_points(s_nnA, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
         }
         double sum2d = 0.0, sum3d = 0.0;
         uint32_t c2 = 0, v2 = 0, c3 = 0, v3 = 0, vpl = 0, vpt = 0;
+        // association: local plane at the matched point (iba_local.cpp:207-231)
         for (uint32_t i = tid; i < n3; i += kThreads) {
-            const uint32_t k = s_list[i];
-            const uint32_t pos = s_nnC[i];
-            const int w = (int)kp_mp[k].w;
-            // association: local plane at the matched point (iba_local.cpp:207-231)
+            const uint32_t k = s_list[i] & 0xffffu;
             uint32_t flagA = kNone;
-            if (usedA && w == 3) {
+            if (usedA && ((s_list[i] >> 16) & 3u) == 3u) {
+                const uint32_t pos = s_nnC[i];
                 const PlaneRec rec = planes_local[pos];
                 uint2 a = make_uint2(kNone, kNone);
                 const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
@@ -1074,15 +1081,24 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                 if (neigh_ok) flagA = 0u;
             }
             s_nnA[i] = flagA;
-            // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328)
-            if (usedC && (w & 2)) {
+        }
+        // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328): only the slots whose match bit is set
+        if (usedC) {
+            for (uint32_t i = tid; i < n3; i += kThreads) {
+                uint32_t mask = (s_list[i] >> 18) & 0x3ffu;
+                if (!mask) continue;
+                const uint32_t k = s_list[i] & 0xffffu, pos = s_nnC[i];
                 const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
                 const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
                 const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
                 const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
-                for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
-                    const float2 mm = dp.match_uv[h.match_base + (size_t)sl * K + k];
-                    if (mm.x != mm.x) continue;
+                const float2* mrow = dp.match_uv + h.match_base + k;
+                float2 mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];
+                while (mask) {
+                    const uint32_t sl = (uint32_t)__ffs((int)mask) - 1u;
+                    mask &= mask - 1u;
+                    const float2 cur = mm;
+                    if (mask) mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];   // next match is in flight during the arithmetic
                     const double* rel = s_rel + sl * 12;
                     const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
                     const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
@@ -1090,7 +1106,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                     const double ou = h.fx * p1x / p1z + h.cx;
                     const double ov = h.fy * p1y / p1z + h.cy;
                     if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
-                    const double eu = ou - (double)mm.x, ev = ov - (double)mm.y;
+                    const double eu = ou - (double)cur.x, ev = ov - (double)cur.y;
                     const double dist = sqrt(eu * eu + ev * ev);
                     if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
                     ++c2;
@@ -1151,10 +1167,12 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
 #endif
                 if (e < n_items) {
                     if (fresh) {
-                        const uint32_t k = s_list[i];
+                        const uint32_t k = s_list[i] & 0xffffu;
                         actA = s_nnA[i] != kNone;
-                        actC = usedC && prm.use_3d3d && (((int)kp_mp[k].w) & 1);
+                        actC = usedC && prm.use_3d3d && ((s_list[i] >> 16) & 1u);
                         if (actA || actC) queries(k, ax, ay, az, qx, qy, qz);
+                        if (!actA) { ax = NAN; ay = NAN; az = NAN; }   // nn_dual_step: every compare of an inactive query is false
+                        if (!actC) { qx = NAN; qy = NAN; qz = NAN; }
                     } else {
                         const HardState hs = s_hard[e];
                         i = hs.item_go & 0xffffffu; st.go = (int)((hs.item_go >> 24) & 31u); actA = (hs.item_go >> 30) & 1u; actC = hs.item_go >> 31;
@@ -1232,7 +1250,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         IBA_STAMP(6);
         uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
         for (uint32_t i = tid; i < n3; i += kThreads) {
-            const uint32_t k = s_list[i];
+            const uint32_t k = s_list[i] & 0xffffu;
             // association: kind of the 3d-3d block (pointcloud.h:699-717), dense block list for the factor kernel
             const uint32_t bA = s_nnA[i];
             uint32_t ay_ = kNone;
@@ -1243,7 +1261,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                 ay_ = bA | (state ? 0x80000000u : 0u);
             }
             uint32_t ax_ = kNone;
-            if (usedA && (int)kp_mp[k].w == 3) { ax_ = arow[k].x; arow[k].y = ay_; }
+            if (usedA && ((s_list[i] >> 16) & 3u) == 3u) { ax_ = arow[k].x; arow[k].y = ay_; }
             fl[i] = make_uint4(k, ax_, ay_, 0u);
             // cost: point-to-plane / point-to-point distance (iba_global.cpp:111-156, 241-249)
             const uint32_t bC = s_nnC[i];
@@ -1314,7 +1332,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
         // dense list of the keypoints that can own residual blocks: a correspondence, a MapPoint (iba_local.cpp:213)
         // AND a covisible match (:259-260). Everything else gets an empty association row right here.
         for (uint32_t k = tid; k < Kceil; k += kThreads) {
-            const bool want = used && k < K && s_best_idx[k] != kNone && ((int)kp_mp[k].w) == 3;
+            const bool want = used && k < K && s_best_idx[k] != kNone && (((int)kp_mp[k].w) & 3) == 3;
             if (k < K && !want) arow[k] = make_uint2(kNone, kNone);
             ordered_append(want, k, n3, s_list, s_wcnt);
         }
