@@ -612,14 +612,15 @@ struct DualNN {
     uint32_t visits;
 #endif
 };
+template <int WHICH>   // bit 0: association-path query a is present, bit 1: cost-path query c (single-query modes compile the other half away)
 __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
                                              const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
                                              bool actA, double ax, double ay, double az, bool actC, double cx, double cy, double cz,
                                              DualNN& st, bool fresh, bool to_end) {
     if (D > (uint32_t)kPathMax) {   // very deep trees: two plain searches, always to the end
         st.bestA = INFINITY; st.bposA = kNone; st.bestC = INFINITY; st.bposC = kNone;
-        if (actA) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, ax, ay, az, st.bestA, st.bposA);
-        if (actC) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, cx, cy, cz, st.bestC, st.bposC);
+        if ((WHICH & 1) && actA) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, ax, ay, az, st.bestA, st.bposA);
+        if ((WHICH & 2) && actC) nn_search_group(G, xs, ys, zs, nodes, perm_g, P, D, cx, cy, cz, st.bestC, st.bposC);
         return false;
     }
     const uint32_t sub = threadIdx.x & (uint32_t)(G - 1);
@@ -630,6 +631,8 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
     // so lb = max(|d| - del', 0)^2 * (1 - 2^-19) with del' = del (1 + 2^-19) stays below the exact squared plane
     // distance of either query through all float roundings. A far side is skipped only if lb > RN_float(best), which
     // implies lb > best; anything else is visited, so the result equals the exhaustive exact search.
+    if (!(WHICH & 1)) actA = false;
+    if (!(WHICH & 2)) actC = false;
     const float p0 = (float)(actC ? cx : ax), p1 = (float)(actC ? cy : ay), p2 = (float)(actC ? cz : az);
     float del;
     {
@@ -682,7 +685,8 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
         }
 #pragma unroll
         for (int L = 0; L < kPathMax; ++L) {
-            if (L >= start && L < (int)D) {
+            if (L >= (int)D) break;   // uniform: one scalar branch ends the unrolled chain
+            if (L >= start) {
                 const TreeNode n = nodes[node];
                 const float d = (n.dim == 0 ? p0 : (n.dim == 1 ? p1 : p2)) - n.split;
                 const uint32_t r = d >= 0.f ? 1u : 0u;
@@ -703,14 +707,14 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
 #pragma unroll IBA_LEAF_UNROLL
             for (uint32_t i = lo + sub; i < hi; i += G) {
                 const double x = (double)xs[i], y = (double)ys[i], z = (double)zs[i];
-                {
+                if (WHICH & 1) {
                     const double dx = ax - x, dy = ay - y, dz = az - z;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
                     const bool lt = d2 < bestA, eq = d2 == bestA;
                     bestA = lt ? d2 : bestA; bposA = lt ? i : bposA;
                     if (__builtin_expect(eq, 0)) { if (bposA != kNone && bposA != i && perm_g[i] < perm_g[bposA]) bposA = i; }
                 }
-                {
+                if (WHICH & 2) {
                     const double dx = cx - x, dy = cy - y, dz = cz - z;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
                     const bool lt = d2 < bestC, eq = d2 == bestC;
@@ -721,8 +725,8 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
 #ifdef IBA_STAMPS_FINE
             sg3 = __builtin_readcyclecounter();
 #endif
-            nn_group_reduce(G, bestA, bposA, perm_g);
-            nn_group_reduce(G, bestC, bposC, perm_g);
+            if (WHICH & 1) nn_group_reduce(G, bestA, bposA, perm_g);
+            if (WHICH & 2) nn_group_reduce(G, bestC, bposC, perm_g);
 #ifdef IBA_STAMPS_FINE
             sg4 = __builtin_readcyclecounter();
 #endif
@@ -731,8 +735,8 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
             const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
             uint32_t cand = 0u;
 #pragma unroll
-            for (int L = 0; L < kPathMax; ++L) cand |= (pd2[L] <= bestf ? 1u : 0u) << L;
-            cand &= ~done & ((1u << D) - 1u);
+            for (int L = 0; L < kPathMax; ++L) { if (L >= (int)D) break; cand |= (pd2[L] <= bestf ? 1u : 0u) << L; }
+            cand &= ~done;
             done |= ~cand;                               // the bests only shrink: out of reach stays out of reach
             go = cand ? 31 - __clz((int)cand) : -1;
         }
@@ -1194,7 +1198,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                         rt1 = __builtin_readcyclecounter();
 #endif
                         for (;;) {
-                            const bool more = nn_dual_step(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, st, fr, to_end);
+                            const bool more = nn_dual_step<3>(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, st, fr, to_end);
                             if (!more) break;
                             uint32_t slot = 0u;
                             if ((tid & (G - 1)) == 0) slot = atomicAdd(cnt, 1u);
@@ -1370,9 +1374,9 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
                 if (s_bpos[i] == kNone) continue;   // uniform within the lane group
                 double qx, qy, qz; q_assoc(s_list[i], qx, qy, qz);
-                double best; uint32_t bpos;
-                nn_search_group(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
-                if ((tid & (G - 1)) == 0) s_bpos[i] = (best > prm.max_3d_dist2) ? kNone : bpos;   // :289
+                DualNN st; st.bestA = INFINITY; st.bestC = INFINITY; st.bposA = kNone; st.bposC = kNone; st.leaf = 0u; st.done = 0u; st.go = -1;
+                nn_dual_step<1>(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, true, qx, qy, qz, false, 0.0, 0.0, 0.0, st, true, true);
+                if ((tid & (G - 1)) == 0) s_bpos[i] = (st.bestA > prm.max_3d_dist2) ? kNone : st.bposA;   // :289
             }
         }
         __syncthreads();
@@ -1470,9 +1474,9 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                 const uint32_t k = s_list[i];
                 if (!(((int)kp_mp[k].w) & 1)) { if ((tid & (G - 1)) == 0) s_bpos[i] = kNone; continue; }   // covisible match but no MapPoint
                 double qx, qy, qz; q_cost(k, qx, qy, qz);
-                double best; uint32_t bpos;
-                nn_search_group(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, qx, qy, qz, best, bpos);
-                if ((tid & (G - 1)) == 0) s_bpos[i] = bpos;
+                DualNN st; st.bestA = INFINITY; st.bestC = INFINITY; st.bposA = kNone; st.bposC = kNone; st.leaf = 0u; st.done = 0u; st.go = -1;
+                nn_dual_step<2>(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, false, 0.0, 0.0, 0.0, true, qx, qy, qz, st, true, true);
+                if ((tid & (G - 1)) == 0) s_bpos[i] = st.bposC;
             }
         }
         __syncthreads();
