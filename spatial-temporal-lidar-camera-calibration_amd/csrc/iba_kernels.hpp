@@ -858,14 +858,27 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
 #endif
     IBA_STAMP(0);
     // ---- phase 0: LDS init ----
-    for (uint32_t i = tid; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; }
+    // the first (usually only) element per thread of each static table is fetched before anything is stored, so the
+    // four global-load latencies overlap instead of queueing behind each other's LDS stores
     const uint32_t nnodes = (1u << D) - 1u;
-    for (uint32_t i = tid; i < nnodes; i += kThreads) s_nodes[i] = dp.nodes[h.node_base + i];
     const uint32_t nbw = (h.gw * h.gh + 31u) >> 5;
-    for (uint32_t i = tid; i < nbw; i += kThreads) s_bitmap[i] = dp.bitmap[h.bitmap_base + i];
     const uint32_t ncs = h.gwc * h.ghc + 1u;
-    for (uint32_t i = tid; i < ncs; i += kThreads) s_cstart[i] = (uint16_t)dp.coarse_start[h.coarse_base + i];
-    if ((uint32_t)tid < h.n_slots * 12u) s_rel[tid] = dp.slots[h.slot_base + tid / 12].rel[tid % 12];
+    const uint32_t ut = (uint32_t)tid;
+    TreeNode nv = TreeNode{0.f, 0u}; uint32_t bv = 0u, cv0 = 0u, cv1 = 0u; double rv = 0.0;
+    if (ut < nnodes) nv = dp.nodes[h.node_base + ut];
+    if (ut < nbw) bv = dp.bitmap[h.bitmap_base + ut];
+    if (ut < ncs) cv0 = dp.coarse_start[h.coarse_base + ut];
+    if (ut + kThreads < ncs) cv1 = dp.coarse_start[h.coarse_base + ut + kThreads];
+    if (ut < h.n_slots * 12u) rv = dp.slots[h.slot_base + ut / 12].rel[ut % 12];
+    for (uint32_t i = tid; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; }
+    if (ut < nnodes) s_nodes[ut] = nv;
+    if (ut < nbw) s_bitmap[ut] = bv;
+    if (ut < ncs) s_cstart[ut] = (uint16_t)cv0;
+    if (ut + kThreads < ncs) s_cstart[ut + kThreads] = (uint16_t)cv1;
+    for (uint32_t i = ut + kThreads; i < nnodes; i += kThreads) s_nodes[i] = dp.nodes[h.node_base + i];
+    for (uint32_t i = ut + kThreads; i < nbw; i += kThreads) s_bitmap[i] = dp.bitmap[h.bitmap_base + i];
+    for (uint32_t i = ut + 2u * kThreads; i < ncs; i += kThreads) s_cstart[i] = (uint16_t)dp.coarse_start[h.coarse_base + i];
+    if (ut < h.n_slots * 12u) s_rel[ut] = rv;
     if (tid < 4) s_misc[tid] = 0u;
     __syncthreads();
 
@@ -1048,7 +1061,8 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
 
     if (MODE == MODE_BOTH) {
         // ================= fused BAError + BuildProblem association: one work list, one kd traversal per MapPoint =================
-        uint2* arow = assoc_out + (size_t)b * dp.n_kp_total + h.kp_base;
+        // (the dense per-keypoint association rows are not written in this mode: the factor kernel is fed by the block list)
+        uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
         const bool usedA = !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
         const bool usedC = !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
         uint32_t* s_nnC = s_list + K;        // per list item: cost-path NN (aliases the 2nd half of best_d2)
@@ -1058,7 +1072,6 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             const bool valid = k < K && s_best_idx[k] != kNone;
             const int w = k < K ? (int)kp_mp[k].w : 0;
             const bool want = (usedA || usedC) && valid && w != 0;
-            if (k < K && !(usedA && valid && (w & 3) == 3)) arow[k] = make_uint2(kNone, kNone);
             ordered_append(want, k | ((uint32_t)w << 16), n3, s_list, s_wcnt);   // bits 16,17: flags; 18..27: covisible-slot mask
         }
         // matched scan point of every item (needed by the residual loop, the plane pass and, in refit mode, the fits)
@@ -1081,9 +1094,9 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                 uint2 a = make_uint2(kNone, kNone);
                 const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);
                 if (neigh_ok && rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) a.x = pos;
-                arow[k] = a;
                 if (neigh_ok) flagA = 0u;
-            }
+                fl[i] = make_uint4(k, a.x, kNone, 0u);   // .z (the 3d-3d block) follows once the neighbour is known
+            } else fl[i] = make_uint4(k, kNone, kNone, 0u);
             s_nnA[i] = flagA;
         }
         // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328): only the slots whose match bit is set
@@ -1252,7 +1265,6 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
             if (prm.use_plane) fit_points(s_nnC, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);
         }
         IBA_STAMP(6);
-        uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
         for (uint32_t i = tid; i < n3; i += kThreads) {
             const uint32_t k = s_list[i] & 0xffffu;
             // association: kind of the 3d-3d block (pointcloud.h:699-717), dense block list for the factor kernel
@@ -1264,9 +1276,7 @@ __global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevP
                                    (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);
                 ay_ = bA | (state ? 0x80000000u : 0u);
             }
-            uint32_t ax_ = kNone;
-            if (usedA && ((s_list[i] >> 16) & 3u) == 3u) { ax_ = arow[k].x; arow[k].y = ay_; }
-            fl[i] = make_uint4(k, ax_, ay_, 0u);
+            if (bA != kNone) fl[i].z = ay_;
             // cost: point-to-plane / point-to-point distance (iba_global.cpp:111-156, 241-249)
             const uint32_t bC = s_nnC[i];
             if (bC != kNone) {
