@@ -259,7 +259,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
     s = launch_frame<MODE_COST>(h, dc, B, h->d_frame_partials.p, nullptr, nullptr, h->n_frames, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->n_frames, d_partials);
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->n_frames, d_partials);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
     return IBA_OK;
@@ -619,7 +619,7 @@ static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B
     s = launch_frame<MODE_ASSOC>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
     s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
     return IBA_OK;
@@ -658,7 +658,7 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
     s = launch_frame<MODE_BOTH>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
     s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
     return IBA_OK;
@@ -684,7 +684,7 @@ iba_status iba_build_problem(iba_handle* h, const double* x) {
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
     s = launch_frame<MODE_ASSOC>(h, dc, 1, h->d_frame_partials.p, nullptr, h->d_assoc_frozen.p, h->n_frames, h->stream, 0); if (s != IBA_OK) return s;
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->d_frame_partials.p, h->n_frames, h->d_partials.p);
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, h->stream, h->d_frame_partials.p, h->n_frames, h->d_partials.p);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -701,7 +701,7 @@ iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_norma
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     s = launch_factors(h, dc, B, 0, h->d_frame_partials.p, h->nfb, 0, h->stream); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(256), 0, h->stream, h->d_frame_partials.p, h->nfb, h->d_partials.p);
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, h->stream, h->d_frame_partials.p, h->nfb, h->d_partials.p);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, h->stream)); h->timing_recorded = true; }
     HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));

@@ -1579,6 +1579,7 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
     const double num = (n0c[0] * p0c[0] + n0c[1] * p0c[1]) + n0c[2] * p0c[2];
     const double den = (Cxz * n0c[0] + Cyz * n0c[1]) + n0c[2];
     const double Z0 = num / den;
+    const double iden = 1.0 / den;   // derivative rows only: 1 ulp-level differences are inside the 1e-10 budget of H, b
     for (int kk = 0; kk < 6; ++kk) {
         double dpv[3], dnv[3] = {0, 0, 0};
         for (int r = 0; r < 3; ++r) {
@@ -1590,13 +1591,20 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
         }
         const double dnum = ((dnv[0] * p0c[0] + dnv[1] * p0c[1]) + dnv[2] * p0c[2]) + ((n0c[0] * dpv[0] + n0c[1] * dpv[1]) + n0c[2] * dpv[2]);
         const double dden = (Cxz * dnv[0] + Cyz * dnv[1]) + dnv[2];
-        z6[kk] = (dnum - Z0 * dden) / den;
+        z6[kk] = (dnum - Z0 * dden) * iden;
     }
     const double P0x = Cxz * Z0, P0y = Cyz * Z0, P0z = Z0;
     int nconv = 0;
-    for (uint32_t sl = 0; sl < h.n_slots; ++sl) {
-        const float2 m = dp.match_uv[h.match_base + (size_t)sl * K + k];
-        if (m.x != m.x) continue;
+    // only the covisible slots whose match bit is set in the keypoint flags (kp_mp.w >> 2), in slot order; the next
+    // match is in flight during the arithmetic of the current one
+    uint32_t mask = ((uint32_t)(int)dp.kp_mp[h.kp_base + k].w >> 2) & 0x3ffu;
+    const float2* mrow = dp.match_uv + h.match_base + k;
+    float2 mnext = mask ? mrow[(size_t)(__ffs((int)mask) - 1) * K] : make_float2(0.f, 0.f);
+    while (mask) {
+        const uint32_t sl = (uint32_t)__ffs((int)mask) - 1u;
+        mask &= mask - 1u;
+        const float2 m = mnext;
+        if (mask) mnext = mrow[(size_t)(__ffs((int)mask) - 1) * K];
         const double* rel = dp.slots[h.slot_base + sl].rel;
         const double tx = rel[3] * c.s, ty = rel[7] * c.s, tz = rel[11] * c.s;   // _t *= _s (IBACalib2.hpp:175)
         const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx;
@@ -1672,11 +1680,14 @@ __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const 
     }
 }
 
+#ifndef IBA_FACTOR_WAVES
+#define IBA_FACTOR_WAVES 2
+#endif
 constexpr int kFactorThreads = 256;
 // grid: (n_frames, B), 256 threads. Works through the dense residual-block list the association pass left for this
 // (candidate, frame): every lane owns a keypoint that has at least one block. list row = (per_cand ? b : 0).
 // record (b, rec_base + frame) of `partials` receives this block's sums.
-__global__ __launch_bounds__(kFactorThreads) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist,
+__global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(IBA_FACTOR_WAVES, IBA_FACTOR_WAVES))) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist,
                                                                     const uint32_t* __restrict__ fcount, int flist_stride, int per_cand,
                                                                     double* __restrict__ partials, int nrec, int rec_base) {
     __shared__ double s_part[kFactorThreads / 64][48];
@@ -1774,17 +1785,31 @@ __global__ __launch_bounds__(64) void iba_residual_kernel(DevProblem dp, DevPara
     }
 }
 
-// sums the per-frame records of each candidate in a fixed order. grid: B blocks of 256 threads
-__global__ __launch_bounds__(256) void iba_reduce_kernel(const double* __restrict__ frame_partials, int nf, double* __restrict__ out) {
-    __shared__ double s[4][kPartialStride];
+// sums the per-frame records of each candidate in a fixed order. grid: B blocks of kReduceThreads threads:
+// 16 frame groups x 64 slots, loads of a group issued ahead of its (ordered) adds, then an ordered sum of the groups
+constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void iba_reduce_kernel(const double* __restrict__ frame_partials, int nf, double* __restrict__ out) {
+    constexpr int NG = kReduceThreads / kPartialStride;
+    __shared__ double s[NG][kPartialStride];
     const int b = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
     const double* src = frame_partials + (size_t)b * nf * kPartialStride;
-    const int per = (nf + 3) / 4, f0 = g * per, f1 = min(nf, f0 + per);
+    const int per = (nf + NG - 1) / NG, f0 = g * per, f1 = min(nf, f0 + per);
     double x = 0;
-    for (int f = f0; f < f1; ++f) x += src[(size_t)f * kPartialStride + i];
+    int f = f0;
+    for (; f + 4 <= f1; f += 4) {
+        const double v0 = src[(size_t)f * kPartialStride + i], v1 = src[(size_t)(f + 1) * kPartialStride + i];
+        const double v2 = src[(size_t)(f + 2) * kPartialStride + i], v3 = src[(size_t)(f + 3) * kPartialStride + i];
+        x = (((x + v0) + v1) + v2) + v3;
+    }
+    for (; f < f1; ++f) x += src[(size_t)f * kPartialStride + i];
     s[g][i] = x;
     __syncthreads();
-    if (g == 0) out[(size_t)b * kPartialStride + i] = ((s[0][i] + s[1][i]) + s[2][i]) + s[3][i];
+    if (g == 0) {
+        double t = s[0][i];
+#pragma unroll
+        for (int q = 1; q < NG; ++q) t += s[q][i];
+        out[(size_t)b * kPartialStride + i] = t;
+    }
 }
 
 }  // namespace iba
