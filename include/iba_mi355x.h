@@ -35,7 +35,8 @@ typedef enum iba_status {
     IBA_ERR_NO_DEVICE = 2,   /* no gfx950 device / HIP runtime unusable: there is NO CPU fallback */
     IBA_ERR_HIP = 3,
     IBA_ERR_UNSUPPORTED = 4, /* problem shape outside what the kernels handle */
-    IBA_ERR_STATE = 5        /* e.g. iba_eval_factors before iba_build_problem */
+    IBA_ERR_STATE = 5,       /* e.g. iba_eval_factors before iba_build_problem */
+    IBA_ERR_IO = 6           /* a dataset file is missing, truncated or not in the reference's format */
 } iba_status;
 
 typedef struct iba_handle iba_handle;
@@ -246,6 +247,51 @@ iba_status iba_set_timing(iba_handle* h, int32_t enable);
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
 int64_t iba_num_points(const iba_handle* h);
 int64_t iba_num_keypoints(const iba_handle* h);
+
+/*
+ * ---- On-disk formats of the reference pipeline -> problem descriptor [SURVEY.md 8(f) row 1] ----
+ * Host-only (no GPU needed). Replaces, for the IBA path, what the reference does with OpenCV/ORB-SLAM2 objects in
+ * main(): iba_global.cpp:398-505, iba_local.cpp:325-406, System::RestoreSystemFromFile (System.cc:612-694),
+ * KeyFrameConstInfo (KeyFrame.cc:31-80), Map::RestoreMap (Map.cc:162-170), MapPoint(FileNode) (MapPoint.cc:435-451).
+ */
+typedef struct iba_dataset iba_dataset;
+typedef struct iba_dataset_paths {
+    const char* frame_id_file;    /* FrameId.yml: "mnId", "mnFrameId" (System.cc:597-609) */
+    const char* lidar_pose_file;  /* LOFile: 12 numbers per pose, row-major 3x4 (kitti_tools.h:66-87) */
+    const char* pointcloud_dir;   /* KITTI velodyne .bin files; file k (sorted by name, kitti_tools.h:48-62) = frame k */
+    const char* keyframe_dir;     /* KeyFrames/NNNNNN.yml written by KeyFrame::saveData (KeyFrame.cc:209-252); the .bin
+                                     twins hold only BoW vectors (KeyFrame.h:97-101) and are not read */
+    const char* map_file;         /* Map.yml (Map.cc:213-231, MapPoint.cc:454-476) */
+    int32_t pointcloud_skip;      /* readPointCloud `skip` (io_tools.h:142-196); iba_global passes 1 (iba_global.cpp:494) */
+    int32_t only_positive_x;      /* readPointCloud `only_positive_x`; iba_local passes its config value (iba_local.cpp:394) */
+    int32_t num_best_covis;       /* > 0: first N ordered covisible KFs (KeyFrame.cc:417-424); else by weight */
+    int32_t min_covis_weight;     /* GetCovisiblesByWeightSafe (KeyFrame.cc:426-439) */
+} iba_dataset_paths;
+
+/* Loads and packs a dataset; the descriptor (and everything it points to) lives until iba_dataset_free. */
+iba_status iba_dataset_load(const iba_dataset_paths* paths, iba_dataset** out);
+const iba_problem_desc* iba_dataset_desc(const iba_dataset* d);
+/* mnId / mnFrameId of keyframe f (FrameId.yml order = KeyFrame::lId order) */
+iba_status iba_dataset_frame_ids(const iba_dataset* d, int32_t frame, int32_t* mn_id, int32_t* mn_frame_id);
+void iba_dataset_free(iba_dataset* d);
+/* message of the last failing iba_dataset_* / iba_read_* / iba_write_* call on this thread */
+const char* iba_io_last_error(void);
+
+/* readPointCloud for .bin (io_tools.h:142-196): XYZI float32 records; with skip > 1 the reference advances its counter
+ * by `skip` but reads CONSECUTIVE records, i.e. it keeps the first floor((n - skip) / skip) + 1 points — reproduced.
+ * *xyz is malloc'ed (release with iba_io_free). */
+iba_status iba_read_kitti_bin(const char* file, int32_t skip, int32_t only_positive_x, float** xyz, int64_t* n_points);
+/* ReadPoseList (kitti_tools.h:66-87): complete 12-number records only (the reference additionally appends one junk
+ * pose when the file ends with a newline; nothing on the IBA path indexes it). *poses12 is malloc'ed. */
+iba_status iba_read_pose_list(const char* file, double** poses12, int64_t* n_poses);
+/* readSim3 / writeSim3 (kitti_tools.h:96-158): 12 row-major 3x4 numbers + scale, max_digits10 precision */
+iba_status iba_read_sim3(const char* file, double rigid12[12], double* scale);
+iba_status iba_write_sim3(const char* file, const double rigid12[12], double scale);
+void iba_io_free(void* p);
+/* (R, t, s) <-> the 7-vector the evaluators take: x[0:6] = g2o::SE3Quat(R, t).log() (rotation first), x[6] = s raw
+ * (iba_global.cpp:511-515, iba_local.cpp:414); inverse = Sim3Exp (g2o_tools.h:105-140). */
+iba_status iba_sim3_to_x(const double rigid12[12], double scale, double x[7]);
+iba_status iba_x_to_sim3(const double x[7], double rigid12[12], double* scale);
 
 #ifdef __cplusplus
 }

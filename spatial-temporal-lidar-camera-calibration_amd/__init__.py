@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IBA_LIB", os.path.join(_HERE, "libiba_mi355x.so"))  # IBA_LIB: diagnostic builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "iba_mi355x.h")
 
-STATUS = {0: "IBA_OK", 1: "IBA_ERR_INVALID_ARG", 2: "IBA_ERR_NO_DEVICE", 3: "IBA_ERR_HIP", 4: "IBA_ERR_UNSUPPORTED", 5: "IBA_ERR_STATE"}
+STATUS = {0: "IBA_OK", 1: "IBA_ERR_INVALID_ARG", 2: "IBA_ERR_NO_DEVICE", 3: "IBA_ERR_HIP", 4: "IBA_ERR_UNSUPPORTED", 5: "IBA_ERR_STATE", 6: "IBA_ERR_IO"}
 
 
 class IbaError(RuntimeError):

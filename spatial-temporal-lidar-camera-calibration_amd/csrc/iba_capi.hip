@@ -570,6 +570,24 @@ extern "C" int iba_debug_counters(unsigned long long* out8, int reset) {
     return 0;
 }
 #endif
+// ---- (R, t, s) <-> x (iba_global.cpp:511-515: x[0:6] = g2o::SE3Quat(R, t).log(), x[6] = scale; Sim3Exp g2o_tools.h:105-140) ----
+iba_status iba_sim3_to_x(const double rigid12[12], double scale, double x[7]) {
+    if (!rigid12 || !x) return IBA_ERR_INVALID_ARG;
+    const double R[9] = {rigid12[0], rigid12[1], rigid12[2], rigid12[4], rigid12[5], rigid12[6], rigid12[8], rigid12[9], rigid12[10]};
+    const double t[3] = {rigid12[3], rigid12[7], rigid12[11]};
+    dev_se3log(R, t, x);
+    x[6] = scale;
+    return IBA_OK;
+}
+iba_status iba_x_to_sim3(const double x[7], double rigid12[12], double* scale) {
+    if (!rigid12 || !x || !scale) return IBA_ERR_INVALID_ARG;
+    double R[9], t[3];
+    se3_exp<double>(x, R, t);
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) rigid12[r * 4 + c] = R[r * 3 + c]; rigid12[r * 4 + 3] = t[r]; }
+    *scale = x[6];
+    return IBA_OK;
+}
+
 // debug: host copy of the last summed partial blocks (B x iba_partial_stride() doubles)
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
     if (!h || !out || B < 1 || B > IBA_MAX_BATCH) return IBA_ERR_INVALID_ARG;

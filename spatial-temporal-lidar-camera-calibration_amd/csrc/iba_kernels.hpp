@@ -65,7 +65,7 @@ constexpr int kRedSlots = 16;   // doubles per wave in the reduction slab
 __device__ __forceinline__ unsigned long long d2bits(double d) { return (unsigned long long)__double_as_longlong(d); }
 
 // ---- SE3Log on device: g2o::SE3Quat(R,t).log() restated (see oracle/oracle_math.hpp) ----
-__device__ inline void dev_se3log(const double* R, const double* t, double* out) {
+__host__ __device__ inline void dev_se3log(const double* R, const double* t, double* out) {
     double q[4];
     double tr = R[0] + R[4] + R[8];
     if (tr > 0.0) {

@@ -259,7 +259,9 @@ def make_scene(n_frames=50, pts_per_frame=4000, n_keypoints=2000, seed=0, n_covi
         Tc_next=Tc_next.reshape(-1),
         Tl_next=Tl_next.reshape(-1),
     )
-    meta = dict(x_gt=x_gt, Twl=Twl, s_star=s_star, seed=seed)
+    # identities behind the flat arrays (what the on-disk KeyFrame / Map files of the reference carry)
+    mp_orb_f32 = (mp_cam0 / s_star).astype(np.float32) if len(mp_cam0) else np.zeros((0, 3), np.float32)
+    meta = dict(x_gt=x_gt, Twl=Twl, s_star=s_star, seed=seed, mp2kp=mp2kp, mp_orb_f32=mp_orb_f32)
     return prob, meta
 
 

@@ -1,0 +1,60 @@
+"""A dataset directory in the reference's on-disk formats, packed by the C++ loader (iba_dataset_load) and evaluated on
+the GPU: parity with the CPU oracle on the SAME packed arrays, and agreement with the in-memory scene the files were
+written from (only the CV_32F relative poses differ, by float rounding)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd")
+fmt = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.formats")
+synth = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.synth")
+abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi")
+from oracle import binding as ob  # noqa: E402
+from oracle import formats as ofmt  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dataset_directory_end_to_end(tmp_path):
+    prob, meta = synth.make_scene(n_frames=8, pts_per_frame=3000, n_keypoints=600, seed=21, new_mappoints=120, scan_kp=150)
+    paths = ofmt.write_dataset(str(tmp_path), prob, meta, keypoint_layout="nested", frame_id_stride=2)
+    packed, mn_id, mn_frame_id = fmt.load_dataset(**paths, num_best_covis=3)
+    assert list(mn_frame_id) == [2 * f for f in range(8)]
+    # init_sim3 file -> x0 the way main() does it (iba_global.cpp:507-515)
+    R, t, s = synth.sim3_exp(meta["x_gt"])
+    rigid = np.concatenate([R, t[:, None]], 1)
+    fmt.write_sim3(str(tmp_path / "init_sim3.txt"), rigid, s)
+    r0, s0 = fmt.read_sim3(str(tmp_path / "init_sim3.txt"))
+    x0 = fmt.sim3_to_x(r0, s0)
+    assert np.allclose(x0, meta["x_gt"], atol=1e-12)
+    xs = np.concatenate([x0[None, :], synth.perturb(x0, np.random.default_rng(0), n=3)], 0)
+    params = abi.reference_yaml_params()
+    h = pkg.IbaHandle(packed, params)
+    got = h.eval_cost(xs)
+    # (1) parity with the CPU oracle on the packed arrays: counters exact, sums to 1e-10
+    ref = ob.Oracle(packed).eval_cost(params, xs)
+    for o, r in zip(got, ref):
+        for k in ("valid_cnt_3d_2d", "cnt_3d_2d", "cnt_3d_3d", "valid_cnt_3d_3d", "valid_pl_3d_3d", "valid_pt_3d_3d", "frames_used", "n_corr"):
+            assert getattr(o, k) == getattr(r, k), k
+        for k in ("f1", "f2"):
+            assert getattr(o, k) == pytest.approx(getattr(r, k), rel=1e-10), k
+        assert abs(o.C - r.C) <= 1e-12 + 1e-9 * abs(r.C)
+    # (2) against the in-memory scene: identical association, costs equal up to the float rounding of the relative poses
+    h2 = pkg.IbaHandle(prob, params)
+    mem = h2.eval_cost(xs)
+    for b in range(len(xs)):
+        assert got[b].n_corr == mem[b].n_corr and got[b].cnt_3d_3d == mem[b].cnt_3d_3d and got[b].cnt_3d_2d == mem[b].cnt_3d_2d
+        assert got[b].f2 == pytest.approx(mem[b].f2, rel=1e-12)          # 3d-3d term does not touch the relative poses
+        assert got[b].f1 == pytest.approx(mem[b].f1, rel=1e-5)
+        assert got[b].C == pytest.approx(mem[b].C, rel=1e-3, abs=1e-6)
+    # (3) result file of the optimiser, as main() writes it (iba_global.cpp:604-614)
+    x_opt, _ = h.calibrate_lm(xs[1])
+    rr, ss = fmt.x_to_sim3(x_opt)
+    fmt.write_sim3(str(tmp_path / "result.txt"), rr, ss)
+    r2, s2 = ofmt.read_sim3(str(tmp_path / "result.txt"))
+    assert np.array_equal(r2[:3, :], rr) and s2 == ss
