@@ -249,6 +249,39 @@ int64_t iba_num_points(const iba_handle* h);
 int64_t iba_num_keypoints(const iba_handle* h);
 
 /*
+ * Batch-aware mesh adaptive direct search for the global stage [SURVEY.md 8(f) row 2]: the caller the reference gets
+ * from NOMAD 4 (iba_global.cpp:551-602: 7 variables, bounds x0 + lb / x0 + ub, OBJ + 3 progressive-barrier
+ * constraints from BALoss::eval_x, OrthoMADS 2N, INITIAL_POLL_SIZE, MIN_MESH_SIZE, MAX_BB_EVAL). One iteration =
+ * one iba_eval_bbo batch (full polls around the feasible and the infeasible incumbent). csrc/iba_mads.hpp.
+ */
+typedef struct iba_mads_options {
+    int32_t max_bb_eval;     /* max_bbeval, 5000 */
+    double lb[7], ub[7];     /* ABSOLUTE bounds (the reference adds its yml lb/ub to x0, iba_global.cpp:530-533) */
+    double init_frame[7];    /* init_frame, 0.5 each */
+    double min_mesh;         /* min_mesh, 1e-6 */
+    double he_threshold;     /* constraint |C| <= he_threshold (iba_global.cpp:387) */
+    double valid_rate;       /* constraint valid/(cnt+1) >= valid_rate (:388) */
+    int32_t seed;
+    int32_t bases_per_poll;  /* orthogonal 2n-direction sets per poll centre and iteration (1 = OrthoMADS 2N) */
+    int32_t speculative;     /* 1: one extra point along the last successful direction */
+    int32_t vns_max_idle;    /* variable-neighbourhood restarts (use_vns): stop after this many in a row without gain; 0 = none */
+} iba_mads_options;
+typedef struct iba_mads_result {
+    double x[7];
+    double f, c1, c2, c3;
+    int32_t feasible;        /* 1: x satisfies the three constraints (findBestFeas, iba_global.cpp:593-599) */
+    int32_t evaluations, iterations, batches, cache_hits, restarts;
+    int32_t stop_reason;     /* 1 converged (min mesh, restarts exhausted), 2 evaluation budget */
+} iba_mads_result;
+/* defaults of config/calib/00/iba_calib_global.yml:21-47 around x0 (lb/ub = x0 -/+ (0.1,0.1,0.1,0.3,0.3,0.3,1.0)) */
+iba_status iba_default_mads_options(const double* x0, iba_mads_options* o);
+iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res);
+/* the same driver on built-in analytic black boxes (host only; for tests of the search logic without a GPU):
+ * 0 smooth bowl, 1 bowl with an active constraint and an infeasible start, 2 nonsmooth with two constraints,
+ * 3 shallow bowl covered with narrow local basins (for the variable-neighbourhood restarts) */
+iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res);
+
+/*
  * ---- On-disk formats of the reference pipeline -> problem descriptor [SURVEY.md 8(f) row 1] ----
  * Host-only (no GPU needed). Replaces, for the IBA path, what the reference does with OpenCV/ORB-SLAM2 objects in
  * main(): iba_global.cpp:398-505, iba_local.cpp:325-406, System::RestoreSystemFromFile (System.cc:612-694),

@@ -14,7 +14,7 @@ import subprocess
 
 import numpy as np
 
-from .abi import (IBA_MAX_BATCH, IbaLmOptions, IbaLmResult, IbaBbo, IbaCostOut, IbaNormalOut, IbaParams, IbaProblemDesc, Problem, copy_params,
+from .abi import (IBA_MAX_BATCH, IbaLmOptions, IbaLmResult, IbaMadsOptions, IbaMadsResult, IbaBbo, IbaCostOut, IbaNormalOut, IbaParams, IbaProblemDesc, Problem, copy_params,
                   reference_yaml_params)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -178,6 +178,16 @@ class IbaHandle:
         self._chk(self.lib.iba_calibrate_lm(self.h, _p(x0), C.byref(o), C.byref(r)))
         return np.array(r.x[:]), r
 
+    def calibrate_mads(self, x0, **opts):
+        """Global stage: batch-aware MADS on BALoss::eval_x's objective + 3 progressive-barrier constraints
+        (the caller the reference gets from NOMAD, iba_global.cpp:551-602). opts override iba_default_mads_options;
+        lb/ub given as 7-vectors are ABSOLUTE bounds."""
+        x0 = np.ascontiguousarray(x0, np.float64)
+        o = mads_options(x0, **opts)
+        r = IbaMadsResult()
+        self._chk(self.lib.iba_calibrate_mads(self.h, _p(x0), C.byref(o), C.byref(r)))
+        return np.array(r.x[:]), r
+
     def build_problem(self, x):
         x = np.ascontiguousarray(x, np.float64)
         self._chk(self.lib.iba_build_problem(self.h, _p(x)))
@@ -246,6 +256,32 @@ class IbaHandle:
     @property
     def n_keypoints(self):
         return int(self.lib.iba_num_keypoints(self.h))
+
+
+def mads_options(x0, **opts):
+    L = load_library()
+    x0 = np.ascontiguousarray(x0, np.float64)
+    o = IbaMadsOptions()
+    L.iba_default_mads_options(_p(x0), C.byref(o))
+    for k, v in opts.items():
+        if k in ("lb", "ub", "init_frame"):
+            for i in range(7):
+                getattr(o, k)[i] = float(v[i])
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def mads_selftest(problem, x0, **opts):
+    """The MADS driver on a built-in analytic black box (host only, no GPU)."""
+    L = load_library()
+    x0 = np.ascontiguousarray(x0, np.float64)
+    o = mads_options(x0, **opts)
+    r = IbaMadsResult()
+    st = L.iba_mads_selftest(C.c_int32(problem), _p(x0), C.byref(o), C.byref(r))
+    if st != 0:
+        raise IbaError(st, "iba_mads_selftest")
+    return np.array(r.x[:]), r
 
 
 def shard_frames(n_frames, world_size, rank, weights=None):

@@ -111,6 +111,16 @@ class IbaLmResult(C.Structure):
                 ("converged", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double)]
 
 
+class IbaMadsOptions(C.Structure):
+    _fields_ = [("max_bb_eval", C.c_int32), ("lb", C.c_double * 7), ("ub", C.c_double * 7), ("init_frame", C.c_double * 7), ("min_mesh", C.c_double),
+                ("he_threshold", C.c_double), ("valid_rate", C.c_double), ("seed", C.c_int32), ("bases_per_poll", C.c_int32), ("speculative", C.c_int32), ("vns_max_idle", C.c_int32)]
+
+
+class IbaMadsResult(C.Structure):
+    _fields_ = [("x", C.c_double * 7), ("f", C.c_double), ("c1", C.c_double), ("c2", C.c_double), ("c3", C.c_double), ("feasible", C.c_int32),
+                ("evaluations", C.c_int32), ("iterations", C.c_int32), ("batches", C.c_int32), ("cache_hits", C.c_int32), ("restarts", C.c_int32), ("stop_reason", C.c_int32)]
+
+
 class IbaBbo(C.Structure):
     _fields_ = [("f", C.c_double), ("c1", C.c_double), ("c2", C.c_double), ("c3", C.c_double)]
 

@@ -19,6 +19,7 @@
 #include "iba_host_math.hpp"
 #include "iba_kernels.hpp"
 #include "iba_lm.hpp"
+#include "iba_mads.hpp"
 #include "iba_types.hpp"
 
 using namespace iba;
@@ -760,6 +761,78 @@ iba_status iba_calibrate_lm(iba_handle* h, const double* x0, const iba_lm_option
     std::memcpy(res->x, r.x, sizeof(r.x));
     res->outer_iterations = r.outer_iterations; res->inner_iterations = r.inner_iterations; res->evaluations = r.evaluations; res->converged = r.converged;
     res->initial_cost = r.initial_cost; res->final_cost = r.final_cost;
+    return IBA_OK;
+}
+
+// ---- global stage caller (csrc/iba_mads.hpp) ----
+iba_status iba_default_mads_options(const double* x0, iba_mads_options* o) {
+    if (!x0 || !o) return IBA_ERR_INVALID_ARG;
+    static const double lb[7] = {-0.1, -0.1, -0.1, -0.3, -0.3, -0.3, -1.0}, ub[7] = {0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0};   // iba_calib_global.yml:39-40
+    o->max_bb_eval = 5000;
+    for (int i = 0; i < 7; ++i) { o->lb[i] = x0[i] + lb[i]; o->ub[i] = x0[i] + ub[i]; o->init_frame[i] = 0.5; }
+    o->min_mesh = 1e-6; o->he_threshold = 0.094; o->valid_rate = 0.95; o->seed = 0; o->bases_per_poll = 2; o->speculative = 1; o->vns_max_idle = 6;
+    return IBA_OK;
+}
+static void to_mads(const iba_mads_options* opt, MadsOptions& o) {
+    o.max_bb_eval = opt->max_bb_eval; o.min_mesh = opt->min_mesh; o.seed = opt->seed;
+    o.bases_per_poll = std::max(1, std::min(4, opt->bases_per_poll)); o.speculative = opt->speculative != 0; o.max_batch = IBA_MAX_BATCH; o.vns_max_idle = std::max(0, opt->vns_max_idle);
+    for (int i = 0; i < 7; ++i) { o.lb[i] = opt->lb[i]; o.ub[i] = opt->ub[i]; o.init_frame[i] = opt->init_frame[i]; }
+}
+static void from_mads(const MadsResult& r, iba_mads_result* res) {
+    std::memcpy(res->x, r.best.x, sizeof(res->x));
+    res->f = r.best.f; res->c1 = r.best.c[0]; res->c2 = r.best.c[1]; res->c3 = r.best.c[2];
+    res->feasible = r.feasible; res->evaluations = r.evaluations; res->iterations = r.iterations; res->batches = r.batches;
+    res->cache_hits = r.cache_hits; res->restarts = r.restarts; res->stop_reason = r.stop_reason;
+}
+static bool mads_options_ok(const iba_mads_options* opt) {
+    if (!opt || opt->max_bb_eval < 1 || !(opt->min_mesh > 0)) return false;
+    for (int i = 0; i < 7; ++i) if (!(opt->lb[i] <= opt->ub[i]) || !(opt->init_frame[i] > 0)) return false;
+    return true;
+}
+iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res) {
+    if (!h || !x0 || !res) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    iba_mads_options dflt;
+    if (!opt) { iba_default_mads_options(x0, &dflt); opt = &dflt; }
+    if (!mads_options_ok(opt)) return fail(h, IBA_ERR_INVALID_ARG, "bad MADS options (bounds, frame sizes, budget)");
+    MadsOptions o; to_mads(opt, o);
+    iba_status st = IBA_OK;
+    MadsResult r;
+    const bool ok = mads_minimize(x0, o, [&](const double* X, int B, MadsPoint* out) {
+        iba_bbo bbo[IBA_MAX_BATCH];
+        st = iba_eval_bbo(h, X, B, opt->he_threshold, opt->valid_rate, bbo);
+        if (st != IBA_OK) return false;
+        for (int b = 0; b < B; ++b) { out[b].f = bbo[b].f; out[b].c[0] = bbo[b].c1; out[b].c[1] = bbo[b].c2; out[b].c[2] = bbo[b].c3; }
+        return true;
+    }, r);
+    if (!ok) return st == IBA_OK ? IBA_ERR_STATE : st;
+    from_mads(r, res);
+    return IBA_OK;
+}
+iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res) {
+    if (!x0 || !res || !mads_options_ok(opt) || problem < 0 || problem > 3) return IBA_ERR_INVALID_ARG;
+    MadsOptions o; to_mads(opt, o);
+    static const double a[7] = {0.3, -0.2, 0.1, 0.25, -0.15, 0.05, 9.5};
+    MadsResult r;
+    mads_minimize(x0, o, [&](const double* X, int B, MadsPoint* out) {
+        for (int b = 0; b < B; ++b) {
+            const double* x = X + 7 * b;
+            double f = 0, c0 = -1, c1 = -1, c2 = -1;
+            if (problem == 0) { for (int i = 0; i < 7; ++i) f += (1.0 + i) * (x[i] - a[i]) * (x[i] - a[i]); }
+            else if (problem == 1) { f = (x[0] - 1.0) * (x[0] - 1.0); for (int i = 1; i < 7; ++i) f += (x[i] - a[i]) * (x[i] - a[i]); c0 = x[0] - 0.5; }
+            else if (problem == 3) {   // many narrow local basins (period 0.08) under a shallow bowl: the global one is at a
+                const double two_pi = 6.283185307179586;
+                for (int i = 0; i < 7; ++i) { const double d = x[i] - a[i] - 0.0123 * (i + 1); f += 2.0 * d * d + 0.3 * (1.0 - std::cos(two_pi * d / 0.08)); }
+            }
+            else {
+                double m = 0, s1 = 0;
+                for (int i = 0; i < 7; ++i) { const double d = std::fabs(x[i] - a[i]); m = std::max(m, d); s1 += d; }
+                f = m + 0.1 * s1; c0 = 0.2 - x[1]; c1 = x[3] + x[4] - 0.05;   // optimum on both constraint boundaries
+            }
+            out[b].f = f; out[b].c[0] = c0; out[b].c[1] = c1; out[b].c[2] = c2;
+        }
+        return true;
+    }, r);
+    from_mads(r, res);
     return IBA_OK;
 }
 
