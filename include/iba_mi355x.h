@@ -326,6 +326,20 @@ void iba_io_free(void* p);
 iba_status iba_sim3_to_x(const double rigid12[12], double scale, double x[7]);
 iba_status iba_x_to_sim3(const double x[7], double rigid12[12], double* scale);
 
+/*
+ * ---- Hand-eye initialiser [SURVEY.md 8(f) row 3]: the init_sim3 of the IBA stages without g2o (host only) ----
+ * Ta = camera motions (scale-free), Tb = LiDAR motions, each n x 12 (row-major 3x4); result: T_AB (B -> A) and the
+ * monocular scale. csrc/iba_handeye.cpp.
+ */
+iba_status iba_pose_to_motion(const double* poses12, int64_t n, double* motions12 /* (n-1) x 12 */); /* kitti_tools.h:160-165 */
+iba_status iba_handeye(const double* Ta12, const double* Tb12, int64_t n, double rigid12[12], double* scale); /* HECalib.h:12-57 */
+/* The cost HECalibRobustKernelg2o minimises (NLHECalib.hpp:121-163): EdgeHE residual (:27-48), Huber(delta) per pair,
+ * optional regulariser on upsilon with information n * ratio; Levenberg-Marquardt with a numerical Jacobian instead of
+ * g2o's Dogleg on the reference's hand-written one (see csrc/iba_handeye.cpp). he_calib.cpp: 10 iterations. */
+iba_status iba_handeye_robust(const double* Ta12, const double* Tb12, int64_t n, const double rigid12_init[12], double scale_init,
+                              double robust_kernel_size, int32_t regulation, double regulation_ratio, int32_t iterations,
+                              double rigid12[12], double* scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,10 @@ def _lib():
         L.iba_io_free.argtypes = [C.c_void_p]
         L.iba_sim3_to_x.argtypes = [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
         L.iba_x_to_sim3.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.iba_pose_to_motion.argtypes = [C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double)]
+        L.iba_handeye.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.iba_handeye_robust.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int32,
+                                         C.c_double, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L._io_ready = True
     return L
 
@@ -135,3 +139,46 @@ def load_dataset(frame_id_file, lidar_pose_file, pointcloud_dir, keyframe_dir, m
     finally:
         L.iba_dataset_free(h)
     return Problem(**arrays), ids[:, 0].copy(), ids[:, 1].copy()
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def pose_to_motion(poses):
+    """pose2Motion (kitti_tools.h:160-165): T(i+1) * T(i)^-1 for poses given as (n, 3|4, 4)."""
+    L = _lib()
+    P = np.ascontiguousarray(np.asarray(poses, np.float64)[:, :3, :4]).reshape(-1, 12)
+    M = np.zeros((len(P) - 1, 12))
+    st = L.iba_pose_to_motion(_dp(P), len(P), _dp(M))
+    if st != 0:
+        raise IbaError(st, "iba_pose_to_motion")
+    return M.reshape(-1, 3, 4)
+
+
+def handeye(Ta, Tb):
+    """HECalib (HECalib.h:12-57): returns (rigid 3x4 = T_AB, scale)."""
+    L = _lib()
+    A = np.ascontiguousarray(np.asarray(Ta, np.float64)[:, :3, :4]).reshape(-1, 12)
+    B = np.ascontiguousarray(np.asarray(Tb, np.float64)[:, :3, :4]).reshape(-1, 12)
+    r = np.zeros(12)
+    s = C.c_double(0)
+    st = L.iba_handeye(_dp(A), _dp(B), len(A), _dp(r), C.byref(s))
+    if st != 0:
+        raise IbaError(st, "iba_handeye")
+    return r.reshape(3, 4), s.value
+
+
+def handeye_robust(Ta, Tb, rigid0, scale0, robust_kernel_size=0.1, regulation=True, regulation_ratio=0.005, iterations=10):
+    """HECalibRobustKernelg2o (NLHECalib.hpp:121-163) on the device-independent host path."""
+    L = _lib()
+    A = np.ascontiguousarray(np.asarray(Ta, np.float64)[:, :3, :4]).reshape(-1, 12)
+    B = np.ascontiguousarray(np.asarray(Tb, np.float64)[:, :3, :4]).reshape(-1, 12)
+    r0 = np.ascontiguousarray(np.asarray(rigid0, np.float64)[:3, :4]).reshape(12)
+    r = np.zeros(12)
+    s = C.c_double(0)
+    st = L.iba_handeye_robust(_dp(A), _dp(B), len(A), _dp(r0), float(scale0), float(robust_kernel_size), 1 if regulation else 0, float(regulation_ratio),
+                              int(iterations), _dp(r), C.byref(s))
+    if st != 0:
+        raise IbaError(st, "iba_handeye_robust")
+    return r.reshape(3, 4), s.value
