@@ -136,7 +136,11 @@ def main():
     achieved = B * per_eval / (frame_ms * 1e-3) / 1e9
 
     evals = B * args.steps
-    value = evals / dt
+    # Unit of work = one candidate evaluated against ONE GPU's share: 200 keyframes / 2 M points (configs[1]). Weak scaling:
+    # at N GPUs every candidate is evaluated against N x that many keyframes (configs[2], [3] grow the map with the GPU
+    # count), i.e. N units per candidate; `value` is the aggregate over all ranks, the rate of the N-times larger sharded
+    # problem itself is reported as config.sharded_problem_evals_per_s.
+    value = world * evals / dt
     res = {
         "metric": "IBA residual+Jacobian evals/sec",
         "value": value,
@@ -159,6 +163,9 @@ def main():
             "mean_n_corr": float(np.mean([c.n_corr for c in out[0]])), "mean_cnt_3d_3d": float(np.mean([c.cnt_3d_3d for c in out[0]])),
             "mean_factors": float(np.mean([n.n_factor_3d2d + n.n_factor_p2pl + n.n_factor_p2pt for n in out[1]])),
             "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of %d doubles per call" % (world, B * stride),
+            "unit_definition": "1 eval = one candidate x against %d keyframes / %.1fM points (+ normal equations); at N GPUs a candidate covers N x %d keyframes = N units"
+                               % (args.frames, args.frames * args.pts / 1e6, args.frames),
+            "sharded_problem_evals_per_s": evals / dt,
         },
         "roofline": {
             "bound": "hbm", "kernel": "iba_frame_kernel<MODE_BOTH>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -186,7 +193,7 @@ def main():
             t = torch.tensor([t_other], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_other = float(t.item())
-        res["value_plane_refit" if args.plane_cache else "value_plane_cache"] = B * nrep / t_other
+        res["value_plane_refit" if args.plane_cache else "value_plane_cache"] = world * B * nrep / t_other
         h.set_params(params)
         # (2) final SE(3): iba_local's outer loop + LM on the device path from a perturbed start (N=1 only)
         if world == 1:
