@@ -340,6 +340,56 @@ iba_status iba_handeye_robust(const double* Ta12, const double* Tb12, int64_t n,
                               double robust_kernel_size, int32_t regulation, double regulation_ratio, int32_t iterations,
                               double rigid12[12], double* scale);
 
+/*
+ * ---- ORB-only extrinsic bundle adjustment [SURVEY.md 8(f) row 4] ----
+ * One 7-vector vertex x = [rotation vector of R_cl, t_cl, scale] (CalibVertex, Optimizer.cc:40-63: additive update) and
+ * N unary reprojection edges (calibEdge, Optimizer.cc:65-205): X_c0 = s * Xw; X_l0 = T_cl^-1 X_c0; X_li = T_lw X_l0;
+ * X_ci = T_cl X_li; e = obs - project(X_ci). Per edge: information invSigma2 * I, Huber(sqrt(5.991)).
+ * The device evaluates every edge (residual, Jacobian by forward-mode duals exactly as g2o's auto-diff does, robust
+ * weight) and reduces the normal equations; the host runs g2o's Levenberg-Marquardt and the reference's four
+ * optimise / classify rounds (Optimizer.cc:1511-1556 = 1698-1743). csrc/iba_ba.hip.
+ */
+typedef struct iba_ba_handle iba_ba_handle;
+typedef struct iba_ba_desc {
+    int64_t n_edges;
+    int32_t n_frames;
+    const double* frame_Tlw6;   /* [F*6] e->Tlw_quat: rotation vector and translation (Optimizer.cc:1457-1462 / 1627-1632) */
+    const double* frame_intr;   /* [F*4] fx, fy, cx, cy */
+    const int32_t* edge_frame;  /* [N] */
+    const double* edge_Xw;      /* [N*3] e->Xw (the MapPoint in the reference camera frame, CV_32F values widened) */
+    const double* edge_obs;     /* [N*2] kpUn.pt */
+    const double* edge_info;    /* [N] invSigma2 = mvInvLevelSigma2[octave] */
+    const int32_t* edge_slot;   /* [N] vnIndexEdgeMono: MapPoint slot inside its keyframe — the reference indexes its
+                                   outlier flags with it, so flags alias across keyframes (reproduced) */
+} iba_ba_desc;
+typedef struct iba_ba_result {
+    double x[7];
+    int32_t n_inliers;          /* nInitialCorrespondences - nBad */
+    int32_t n_edges;
+    int32_t lm_iterations;      /* over the four rounds */
+    int32_t evaluations;        /* device evaluations of the edge set */
+    double chi2[4];             /* robustified chi2 of the active edges at the end of each round */
+    int32_t n_bad[4];
+} iba_ba_result;
+iba_status iba_ba_create(const iba_ba_desc* desc, int device, iba_ba_handle** out);
+void iba_ba_destroy(iba_ba_handle* h);
+const char* iba_ba_last_error(const iba_ba_handle* h);
+/* One linearisation at x: H (49, row-major, symmetric), b (7) and the robustified chi2 summed over the edges with
+ * active[i] != 0 (NULL = all); robust = 0 drops the Huber kernel (round 4 of the reference). chi2_edges (NULL or [N])
+ * receives e^T Omega e of EVERY edge. Sign convention of g2o: solve (H + lambda I) dx = b, x += dx. */
+iba_status iba_ba_eval(iba_ba_handle* h, const double* x, const uint8_t* active, int32_t robust, double* H, double* b,
+                       double* chi2_robust, double* chi2_edges);
+/* OptimizeExtrinsicGlobal / OptimizeExtrinsicLocal schedule on the edge list (which of the two it is depends only on how
+ * Xw and Tlw6 were built): 4 x (reset to x0, 10 LM iterations, classify at chi2 > 5.991), kernel off after round 3. */
+iba_status iba_ba_optimize(iba_ba_handle* h, const double* x0, iba_ba_result* res);
+
+/* Edge list of the ORB-only extrinsic BA straight from the dataset directory (OptimizeExtrinsicGlobal constants,
+ * Optimizer.cc:1611-1676; LiDAR poses as ba_calib.cpp:43-44 passes them). global = 0 (the Local variant) is not packed. */
+typedef struct iba_ba_dataset iba_ba_dataset;
+iba_status iba_dataset_load_ba(const iba_dataset_paths* paths, int32_t global, iba_ba_dataset** out);
+const iba_ba_desc* iba_ba_dataset_desc(const iba_ba_dataset* d);
+void iba_ba_dataset_free(iba_ba_dataset* d);
+
 #ifdef __cplusplus
 }
 #endif

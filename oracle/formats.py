@@ -172,13 +172,13 @@ def write_keyframe_yml(path, kf, keypoint_layout="nested"):
         def write_kps(key, pts):
             if keypoint_layout == "flat":
                 vals = []
-                for p in pts:
-                    vals += [float(p[0]), float(p[1]), 31.0, -1.0, 0.0, 0, -1]
+                for j, p in enumerate(pts):
+                    vals += [float(p[0]), float(p[1]), 31.0, -1.0, 0.0, j % 8, -1]
                 _write_seq(f, key, vals)
             else:
                 f.write(key + ":\n")
-                for p in pts:
-                    f.write("   - [ %s, %s, 31., -1., 0., 0, -1 ]\n" % (_num(float(p[0])), _num(float(p[1]))))
+                for j, p in enumerate(pts):
+                    f.write("   - [ %s, %s, 31., -1., 0., %d, -1 ]\n" % (_num(float(p[0])), _num(float(p[1])), j % 8))
 
         write_kps("mvKeys", uv + f32(0.25))     # distorted keypoints: present in the file, never read by the IBA path
         write_kps("mvKeysUn", uv)
@@ -511,3 +511,43 @@ def write_dataset(root, prob, meta, keypoint_layout="nested", frame_id_stride=1,
     write_map_yml(os.path.join(root, "Map.yml"), [dict(mnId=m, mWorldPos=mp_world[m], obs=obs[m]) for m in sorted(obs)], mn_ids)
     return dict(frame_id_file=os.path.join(root, "FrameId.yml"), lidar_pose_file=os.path.join(root, "lidar_poses.txt"),
                 pointcloud_dir=os.path.join(root, "velodyne"), keyframe_dir=os.path.join(root, "KeyFrames"), map_file=os.path.join(root, "Map.yml"))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ORB-only extrinsic BA: edge constants of OptimizeExtrinsicGlobal (Optimizer.cc:1611-1676) from the dataset directory
+# ----------------------------------------------------------------------------------------------------------------------
+def load_ba_edges_global(frame_id_file, lidar_pose_file, pointcloud_dir, keyframe_dir, map_file, **_):
+    from scipy.spatial.transform import Rotation
+    vKFFrameId = [int(v) for v in parse_opencv_yaml(frame_id_file)["mnFrameId"]]
+    raw = read_pose_list(lidar_pose_file)                                   # ba_calib.cpp:40-45: raw poses, no re-referencing
+    mp_nodes = parse_opencv_yaml(map_file)["mspMapPoints"] or {}
+    map_points = {int(n["mnId"]): np.asarray(n["mWorldPos"], f32).reshape(3) for n in mp_nodes.values()}
+    kf_dir = keyframe_dir if keyframe_dir.endswith("/") else keyframe_dir + "/"
+    names = sorted(n for n in os.listdir(kf_dir) if os.path.isfile(kf_dir + n) and n.rsplit(".", 1)[-1] in ("yml", "yaml") and n != "FrameId.yml")
+    kfs = sorted((parse_opencv_yaml(kf_dir + n) for n in names), key=lambda k: int(k["mnId"]))
+    T0 = np.asarray(kfs[0]["Pose"], f32)                                    # Tc0w
+    out = dict(frame_Tlw6=[], frame_intr=[], edge_frame=[], edge_Xw=[], edge_obs=[], edge_info=[], edge_slot=[])
+    for f, kf in enumerate(kfs):
+        Twl = raw[vKFFrameId[f]]
+        out["frame_Tlw6"].append(np.concatenate([Rotation.from_matrix(Twl[:3, :3]).as_rotvec(), Twl[:3, 3]]))
+        out["frame_intr"].append([float(f32(kf[k])) for k in ("fx", "fy", "cx", "cy")])
+        kps = np.array(kf["mvKeysUn"], np.float64).reshape(-1, 7)
+        sig = [f32(v) for v in kf["mvInvLevelSigma2"]]
+        first = {}
+        for m, k in zip(kf["mvpMapPointsId"], kf["mvpCorrKeyPointsId"]):
+            first.setdefault(int(m), int(k))
+        slot = 0
+        for m in kf["mvpMapPointsId"]:
+            m = int(m)
+            if m not in map_points:
+                continue
+            kp = first[m]
+            Xw = map_points[m]
+            X = [f32(f32(f32(f32(T0[r, 0] * Xw[0]) + f32(T0[r, 1] * Xw[1])) + f32(T0[r, 2] * Xw[2])) + T0[r, 3]) for r in range(3)]
+            out["edge_Xw"].append([float(v) for v in X])
+            out["edge_obs"].append([float(f32(kps[kp, 0])), float(f32(kps[kp, 1]))])
+            out["edge_info"].append(float(sig[int(kps[kp, 5])]))
+            out["edge_frame"].append(f)
+            out["edge_slot"].append(slot)
+            slot += 1
+    return {k: np.array(v, np.int32 if k in ("edge_frame", "edge_slot") else np.float64) for k, v in out.items()}

@@ -246,6 +246,8 @@ struct KeyFrameInfo {
     float fx = 0, fy = 0, cx = 0, cy = 0;
     int maxX = 0, maxY = 0;
     std::vector<float> uv;                    // 2 per keypoint (mvKeysUn[i].pt)
+    std::vector<int> octave;                  // mvKeysUn[i].octave
+    std::vector<float> inv_level_sigma2;      // mvInvLevelSigma2 (optional in the file: only the BA edges need it)
     float Tcw[16], Twc[16];
     std::vector<int> conn_ids, weights;       // mvpOrderedConnectedKeyFramesId, mvOrderedWeights
     std::unordered_map<int, int> mpt2kpt_id;  // KeyFrameConstInfo::mmapMpt2KptId (first insertion wins, KeyFrame.cc:76-79)
@@ -296,7 +298,11 @@ bool load_keyframe(const std::string& path, KeyFrameInfo& kf) {
         if (!y.numbers(k, t) || t.size() % 7 != 0) { kf.err = path + ": mvKeysUn is not a sequence of 7-number keypoints"; return false; }
         const size_t K = t.size() / 7;
         kf.uv.resize(2 * K);
-        for (size_t i = 0; i < K; ++i) { kf.uv[2 * i] = (float)t[7 * i]; kf.uv[2 * i + 1] = (float)t[7 * i + 1]; }
+        kf.octave.resize(K);
+        for (size_t i = 0; i < K; ++i) { kf.uv[2 * i] = (float)t[7 * i]; kf.uv[2 * i + 1] = (float)t[7 * i + 1]; kf.octave[i] = (int)t[7 * i + 5]; }
+        const int ks = y.find(0, y.size(), 0, "mvInvLevelSigma2");
+        std::vector<double> sg;
+        if (ks >= 0 && y.numbers(ks, sg)) { kf.inv_level_sigma2.resize(sg.size()); for (size_t i = 0; i < sg.size(); ++i) kf.inv_level_sigma2[i] = (float)sg[i]; }
     }
     {
         const int k = need("Pose");
@@ -602,6 +608,135 @@ iba_status iba_dataset_load(const iba_dataset_paths* P, iba_dataset** out) {
     d.covis_offset = D->covis_offset.data(); d.covis_frame = D->covis_frame.data(); d.covis_relpose = D->covis_relpose.data();
     d.match_offset = D->match_offset.data(); d.match_kp_ref = D->match_kp_ref.data(); d.match_kp_covis = D->match_kp_covis.data();
     d.Tc_next = D->Tc_next.data(); d.Tl_next = D->Tl_next.data();
+    *out = D;
+    return IBA_OK;
+}
+
+}  // extern "C"
+
+// ---- edge list of the ORB-only extrinsic BA, OptimizeExtrinsicGlobal variant (Optimizer.cc:1566-1676; ba_calib.cpp:40-45, 71) ----
+struct iba_ba_dataset {
+    iba_ba_desc desc;
+    std::vector<double> frame_Tlw6, frame_intr, edge_Xw, edge_obs, edge_info;
+    std::vector<int32_t> edge_frame, edge_slot;
+};
+
+namespace {
+void rotvec_from_matrix(const double* R, double* out) {   // Eigen::AngleAxisd(R): quaternion route, angle * axis
+    double q[4];
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0.0) { double s = std::sqrt(tr + 1.0); q[3] = 0.5 * s; s = 0.5 / s; q[0] = (R[7] - R[5]) * s; q[1] = (R[2] - R[6]) * s; q[2] = (R[3] - R[1]) * s; }
+    else {
+        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        q[i] = 0.5 * s; s = 0.5 / s;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * s; q[j] = (R[j * 3 + i] + R[i * 3 + j]) * s; q[k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
+    }
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    if (n < 2.220446049250313e-16) n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    if (n != 0.0) {
+        double w = q[3];
+        if (w < 0) { n = -n; w = -w; }
+        const double angle = 2.0 * std::atan2(std::fabs(n), w);
+        for (int i = 0; i < 3; ++i) out[i] = angle * (q[i] / n);
+    } else out[0] = out[1] = out[2] = 0.0;
+}
+}  // namespace
+
+extern "C" {
+
+const iba_ba_desc* iba_ba_dataset_desc(const iba_ba_dataset* d) { return d ? &d->desc : nullptr; }
+void iba_ba_dataset_free(iba_ba_dataset* d) { delete d; }
+
+iba_status iba_dataset_load_ba(const iba_dataset_paths* P, int32_t global, iba_ba_dataset** out) {
+    if (!P || !out || !P->frame_id_file || !P->lidar_pose_file || !P->keyframe_dir || !P->map_file) return io_fail(IBA_ERR_INVALID_ARG, "null path");
+    *out = nullptr;
+    if (!global) return io_fail(IBA_ERR_UNSUPPORTED, "only the OptimizeExtrinsicGlobal edge constants are packed (the Local variant needs the 20 best covisible keyframes)");
+    std::vector<int> vKFFrameId;
+    {
+        CvYaml y;
+        if (!y.load(P->frame_id_file)) return io_fail(IBA_ERR_IO, std::string("cannot open ") + P->frame_id_file);
+        const int b = y.find(0, y.size(), 0, "mnFrameId");
+        std::vector<double> tb;
+        if (b < 0 || !y.numbers(b, tb)) return io_fail(IBA_ERR_IO, std::string(P->frame_id_file) + ": 'mnFrameId' missing");
+        for (double v : tb) vKFFrameId.push_back((int)v);
+    }
+    const int F = (int)vKFFrameId.size();
+    if (F == 0) return io_fail(IBA_ERR_IO, "FrameId.yml lists no keyframes");
+    std::vector<double> raw;
+    { const iba_status s = read_numbers(P->lidar_pose_file, raw); if (s != IBA_OK) return s; }
+    const int n_raw = (int)(raw.size() / 12);
+    for (int f = 0; f < F; ++f)
+        if (vKFFrameId[f] < 0 || vKFFrameId[f] >= n_raw) return io_fail(IBA_ERR_IO, "FrameId.yml refers to a frame beyond the LiDAR pose list");
+    std::unordered_map<int, std::array<float, 3>> map_points;
+    {
+        CvYaml y;
+        if (!y.load(P->map_file)) return io_fail(IBA_ERR_IO, std::string("cannot open ") + P->map_file);
+        const int top = y.find(0, y.size(), 0, "mspMapPoints");
+        if (top < 0) return io_fail(IBA_ERR_IO, std::string(P->map_file) + ": 'mspMapPoints' missing");
+        const int end = y.block_end(top);
+        if (end > top + 1) {
+            const int ind = y.lines[top + 1].indent;
+            for (int k = top + 1; k < end;) {
+                if (y.lines[k].indent != ind) { ++k; continue; }
+                const int ke = y.block_end(k);
+                if (ke > k + 1) {
+                    const int cind = y.lines[k + 1].indent;
+                    const int a = y.find(k + 1, ke, cind, "mnId"), b = y.find(k + 1, ke, cind, "mWorldPos");
+                    double idv; int rows, cols; std::vector<double> dd;
+                    if (a < 0 || b < 0 || !y.scalar(a, idv) || !y.matrix(b, rows, cols, dd) || rows * cols != 3) return io_fail(IBA_ERR_IO, std::string(P->map_file) + ": malformed MapPoint node");
+                    map_points[(int)idv] = {(float)dd[0], (float)dd[1], (float)dd[2]};
+                }
+                k = ke;
+            }
+        }
+    }
+    const std::string kf_dir = with_slash(P->keyframe_dir);
+    std::vector<std::string> names, info_files;
+    if (!list_regular_files(kf_dir, names)) return io_fail(IBA_ERR_IO, "Cannot open directory: " + kf_dir);
+    for (const std::string& n : names)
+        if ((suffix_is(n, "yml") || suffix_is(n, "yaml")) && n != "FrameId.yml") info_files.push_back(kf_dir + n);
+    if ((int)info_files.size() != F) return io_fail(IBA_ERR_IO, "FrameId.yml and the keyframe directory disagree on the number of keyframes");
+    std::vector<KeyFrameInfo> kfs(F);
+    for (int i = 0; i < F; ++i) if (!load_keyframe(info_files[i], kfs[i])) return io_fail(IBA_ERR_IO, kfs[i].err);
+    std::sort(kfs.begin(), kfs.end(), [](const KeyFrameInfo& a, const KeyFrameInfo& b) { return a.mnId < b.mnId; });   // System.cc:511-512
+    iba_ba_dataset* D = new iba_ba_dataset();
+    const float* T0 = kfs[0].Tcw;   // Tc0w = allKF[0]->GetPose() (Optimizer.cc:1585)
+    for (int f = 0; f < F; ++f) {
+        const KeyFrameInfo& kf = kfs[f];
+        const double* Twl = raw.data() + 12 * (size_t)vKFFrameId[f];   // ba_calib.cpp:43-44: raw pose of the keyframe's frame id
+        const double R[9] = {Twl[0], Twl[1], Twl[2], Twl[4], Twl[5], Twl[6], Twl[8], Twl[9], Twl[10]};
+        double T6[6];
+        rotvec_from_matrix(R, T6);                                      // Rlw = Twl.rotation(): the reference's naming (:1627-1632)
+        T6[3] = Twl[3]; T6[4] = Twl[7]; T6[5] = Twl[11];
+        D->frame_Tlw6.insert(D->frame_Tlw6.end(), T6, T6 + 6);
+        const double in[4] = {(double)kf.fx, (double)kf.fy, (double)kf.cx, (double)kf.cy};
+        D->frame_intr.insert(D->frame_intr.end(), in, in + 4);
+        const int K = (int)(kf.uv.size() / 2);
+        int slot = 0;   // index in the restored mvpMapPoints (KeyFrame.cc:120-129): MapPoints that exist in the map, file order
+        for (int id : kf.mpt_ids) {
+            auto it = map_points.find(id);
+            if (it == map_points.end()) continue;
+            const int kp = kf.mpt2kpt_id.at(id);
+            if (kp < 0 || kp >= K) { delete D; return io_fail(IBA_ERR_IO, kf.file + ": keypoint index of a MapPoint is out of range"); }
+            const int oc = kf.octave[kp];
+            if (oc < 0 || oc >= (int)kf.inv_level_sigma2.size()) { delete D; return io_fail(IBA_ERR_IO, kf.file + ": keypoint octave outside mvInvLevelSigma2"); }
+            const float* Xw = it->second.data();
+            for (int r = 0; r < 3; ++r) {   // Tc0w.R * Xw + Tc0w.t in CV_32F (Optimizer.cc:1661-1665)
+                const float t = (T0[r * 4 + 0] * Xw[0] + T0[r * 4 + 1] * Xw[1]) + T0[r * 4 + 2] * Xw[2];
+                D->edge_Xw.push_back((double)(t + T0[r * 4 + 3]));
+            }
+            D->edge_obs.push_back((double)kf.uv[2 * kp]); D->edge_obs.push_back((double)kf.uv[2 * kp + 1]);
+            D->edge_info.push_back((double)kf.inv_level_sigma2[oc]);
+            D->edge_frame.push_back(f);
+            D->edge_slot.push_back(slot++);
+        }
+    }
+    iba_ba_desc& d = D->desc;
+    d.n_edges = (int64_t)D->edge_frame.size(); d.n_frames = F;
+    d.frame_Tlw6 = D->frame_Tlw6.data(); d.frame_intr = D->frame_intr.data(); d.edge_frame = D->edge_frame.data();
+    d.edge_Xw = D->edge_Xw.data(); d.edge_obs = D->edge_obs.data(); d.edge_info = D->edge_info.data(); d.edge_slot = D->edge_slot.data();
     *out = D;
     return IBA_OK;
 }
