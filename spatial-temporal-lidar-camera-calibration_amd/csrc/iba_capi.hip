@@ -170,7 +170,8 @@ bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
     // candidate queue takes what is left (u16 entries when the scan is in LDS, u32 otherwise); a full queue only
     // costs speed (inline matching + rescan), never correctness
     const uint32_t entry = with_scan ? 2u : 4u;
-    const uint32_t want = std::max<uint32_t>(h->maxPpad / 2u, 512u) * entry;
+    uint32_t want = std::max<uint32_t>(h->maxPpad / 2u, 512u) * entry;
+    if (const char* e = std::getenv("IBA_CAND_BYTES")) want = (uint32_t)std::atoi(e);   // diagnostic
     const uint32_t avail = (kLdsBytes - off) & ~15u;
     const uint32_t bytes = std::min(want, avail);
     L.cand_cap = bytes / entry;
@@ -438,7 +439,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (bad_match) { delete h; return fail(nullptr, IBA_ERR_INVALID_ARG, "covisibility / match index out of range"); }
 
     // ---- LDS plan: stage the scan in LDS when it fits (<= ~10.9k points with 2000 keypoints) ----
-    h->scan_lds = layout(h, true, h->lay);
+    // Staging the scan in LDS (120 KB for 10 k points) pins the CU to ONE block; reading it through L2 instead costs ~5 % per
+    // block but lets two blocks overlap their phases (-24 % wall time). The LDS-scan variant stays selectable for experiments.
+    h->scan_lds = std::getenv("IBA_SCAN_LDS") && layout(h, true, h->lay);
     if (!h->scan_lds && !layout(h, false, h->lay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
 
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };

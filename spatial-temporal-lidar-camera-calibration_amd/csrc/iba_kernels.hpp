@@ -821,7 +821,7 @@ __device__ __forceinline__ uint32_t block_count(uint32_t my_count_wave_uniform, 
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so
 // all candidates of one frame share that XCD's L2 copy of the scan.
 template <int MODE, bool SCAN_LDS>
-__global__ __launch_bounds__(kThreads) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
                                                              double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out,
                                                              uint2* __restrict__ assoc_out, int nrec, const double* __restrict__ he,
                                                              uint4* __restrict__ flist, uint32_t* __restrict__ fcount, int flist_stride) {

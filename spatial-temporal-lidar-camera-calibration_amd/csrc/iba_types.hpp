@@ -13,7 +13,13 @@ namespace iba {
 constexpr int kMaxCovis = 10;        // IBAPlaneEdge pads to 10 covisible KFs (IBACalib.hpp:133-137)
 constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum block
 constexpr int kGridCell = 4;         // keypoint grid cell (px); must be >= 2*(max_pixel_dist+margin)
-constexpr int kThreads = 1024;       // frame-kernel block size (16 waves, 1 block per CU)
+#ifndef IBA_THREADS
+#define IBA_THREADS 512
+#endif
+// frame-kernel block size. 512 threads = 8 waves at <= 128 VGPRs and ~50 KB of LDS: TWO blocks share a CU, and while
+// one sits in a latency-bound phase (exact association, kd rounds, finalize) the other keeps the SIMDs busy. Measured on
+// the C2 shape: 1024 threads + scan staged in LDS (one block per CU) 2.06 ms, 512 threads + scan read through L2 1.57 ms.
+constexpr int kThreads = IBA_THREADS;
 constexpr int kLeafTarget = 24;      // max points per kd-tree leaf
 
 // partial-sum block layout (all doubles; counters < 2^53 carried exactly)
