@@ -1683,8 +1683,11 @@ __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const 
 #ifndef IBA_FACTOR_WAVES
 #define IBA_FACTOR_WAVES 2
 #endif
-constexpr int kFactorThreads = 256;
-// grid: (n_frames, B), 256 threads. Works through the dense residual-block list the association pass left for this
+#ifndef IBA_FACTOR_THREADS
+#define IBA_FACTOR_THREADS 64   /* ~264 blocks per (candidate, frame): 64-thread blocks waste the least of their last pass (256: 0.34 ms, 64: 0.24 ms) */
+#endif
+constexpr int kFactorThreads = IBA_FACTOR_THREADS;
+// grid: (n_frames, B), kFactorThreads threads (one wave). Works through the dense residual-block list the association pass left for this
 // (candidate, frame): every lane owns a keypoint that has at least one block. list row = (per_cand ? b : 0).
 // record (b, rec_base + frame) of `partials` receives this block's sums.
 __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(IBA_FACTOR_WAVES, IBA_FACTOR_WAVES))) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist,
@@ -1737,7 +1740,7 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
         else if (i >= P_B0 && i < P_B0 + 7) src = 28 + (i - P_B0);
         else if (i == P_CHI2) src = 35; else if (i == P_COST) src = 36; else if (i == P_NF_3D2D) src = 37;
         else if (i == P_NF_P2PL) src = 38; else if (i == P_NF_P2PT) src = 39; else if (i == P_NRES) src = 40;
-        if (src >= 0) out = ((s_part[0][src] + s_part[1][src]) + s_part[2][src]) + s_part[3][src];
+        if (src >= 0) { out = s_part[0][src]; for (int w = 1; w < kFactorThreads / 64; ++w) out += s_part[w][src]; }
         partials[((size_t)b * nrec + rec_base + f) * kPartialStride + i] = out;
     }
 }

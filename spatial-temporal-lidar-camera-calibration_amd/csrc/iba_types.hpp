@@ -20,7 +20,10 @@ constexpr int kGridCell = 4;         // keypoint grid cell (px); must be >= 2*(m
 // one sits in a latency-bound phase (exact association, kd rounds, finalize) the other keeps the SIMDs busy. Measured on
 // the C2 shape: 1024 threads + scan staged in LDS (one block per CU) 2.06 ms, 512 threads + scan read through L2 1.57 ms.
 constexpr int kThreads = IBA_THREADS;
-constexpr int kLeafTarget = 24;      // max points per kd-tree leaf
+#ifndef IBA_LEAF_TARGET
+#define IBA_LEAF_TARGET 24
+#endif
+constexpr int kLeafTarget = IBA_LEAF_TARGET;      // max points per kd-tree leaf
 
 // partial-sum block layout (all doubles; counters < 2^53 carried exactly)
 enum Partial {
