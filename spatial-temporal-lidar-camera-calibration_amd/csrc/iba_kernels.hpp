@@ -761,6 +761,8 @@ enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2, MODE_BOTH = 3 }; 
 
 #ifdef IBA_STAMPS   // diagnostic build only: per-phase shader-clock deltas of thread 0 into partial slots 56..63
 #define IBA_STAMP(i) do { if (threadIdx.x == 0) { stamp_t[i] = __builtin_readcyclecounter(); } } while (0)
+#elif defined(IBA_STOP_AFTER)   // diagnostic: cut the kernel short after a phase (results are garbage) to attribute time / instructions
+#define IBA_STAMP(i) do { if ((i) == IBA_STOP_AFTER) return; } while (0)
 #else
 #define IBA_STAMP(i) do { } while (0)
 #endif
@@ -966,22 +968,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (tid == 0) { atomicAdd(&g_dbg[1], (unsigned long long)s_misc[0]); atomicAdd(&g_dbg[2], 1ull); }
 #endif
     const bool overflow = s_misc[1] != 0u;
-    // the first two queue entries of each lane keep their (<= 2) hits in registers, so the tie pass needs no second
-    // grid walk; later entries (queue longer than two blocks) take the re-walk path
-    Hits h0, h1; h0.n = 0; h1.n = 0; h0.k0 = h0.k1 = h1.k0 = h1.k1 = 0u; h0.d0 = h0.d1 = h1.d0 = h1.d1 = 0ull;
+    // the first kHitSlots queue entries of each lane keep their (<= 2) hits in registers, so the tie pass needs no second
+    // grid walk; later entries (queue longer than kHitSlots blocks) take the re-walk path
+    constexpr int kHitSlots = kThreads >= 1024 ? 2 : 3;   // ~1100 queued points per block at the C2 shape
+    Hits hh[kHitSlots];
     bool redo = false;
-    if ((uint32_t)tid < ncand) {
-        const uint32_t pos = (uint32_t)s_cand[tid];
-        double u, v;
-        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) h0 = grid_match_rec(c, u, v);
+#pragma unroll
+    for (int q = 0; q < kHitSlots; ++q) {
+        hh[q].n = 0; hh[q].k0 = hh[q].k1 = 0u; hh[q].d0 = hh[q].d1 = 0ull;
+        if ((uint32_t)tid + (uint32_t)q * kThreads < ncand) {
+            const uint32_t pos = (uint32_t)s_cand[tid + q * kThreads];
+            double u, v;
+            if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) hh[q] = grid_match_rec(c, u, v);
+        }
+        redo |= hh[q].n > 2;
     }
-    if ((uint32_t)tid + kThreads < ncand) {
-        const uint32_t pos = (uint32_t)s_cand[tid + kThreads];
-        double u, v;
-        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) h1 = grid_match_rec(c, u, v);
-    }
-    redo = h0.n > 2 || h1.n > 2;
-    for (uint32_t i = (uint32_t)tid + 2u * kThreads; i < ncand; i += kThreads) {
+    for (uint32_t i = (uint32_t)tid + (uint32_t)kHitSlots * kThreads; i < ncand; i += kThreads) {
         const uint32_t pos = (uint32_t)s_cand[i];
         double u, v;
         if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) redo |= grid_match<1>(c, u, v, pos);
@@ -989,22 +991,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
     __syncthreads();
     IBA_STAMP(2);
     // ---- phase 2: the winner of each keypoint records its original index; exact ties -> lowest index ----
-    if (h0.n > 0) {
-        const bool w0 = s_best_d2[h0.k0] == h0.d0;
-        const bool w1 = h0.n > 1 && s_best_d2[h0.k1] == h0.d1;
-        if (w0 || w1) {
-            const uint32_t orig = c.perm[(uint32_t)s_cand[tid]];
-            if (w0) atomicMin(&s_best_idx[h0.k0], orig);
-            if (w1) atomicMin(&s_best_idx[h0.k1], orig);
-        }
-    }
-    if (h1.n > 0) {
-        const bool w0 = s_best_d2[h1.k0] == h1.d0;
-        const bool w1 = h1.n > 1 && s_best_d2[h1.k1] == h1.d1;
-        if (w0 || w1) {
-            const uint32_t orig = c.perm[(uint32_t)s_cand[tid + kThreads]];
-            if (w0) atomicMin(&s_best_idx[h1.k0], orig);
-            if (w1) atomicMin(&s_best_idx[h1.k1], orig);
+#pragma unroll
+    for (int q = 0; q < kHitSlots; ++q) {
+        if (hh[q].n > 0) {
+            const bool w0 = s_best_d2[hh[q].k0] == hh[q].d0;
+            const bool w1 = hh[q].n > 1 && s_best_d2[hh[q].k1] == hh[q].d1;
+            if (w0 || w1) {
+                const uint32_t orig = c.perm[(uint32_t)s_cand[tid + q * kThreads]];
+                if (w0) atomicMin(&s_best_idx[hh[q].k0], orig);
+                if (w1) atomicMin(&s_best_idx[hh[q].k1], orig);
+            }
         }
     }
     if (redo) {   // rare: a point within reach of > 2 keypoints, or a queue longer than two blocks: walk the grid again
