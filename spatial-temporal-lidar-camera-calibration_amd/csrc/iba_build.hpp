@@ -88,12 +88,12 @@ inline void build_kp_grid(const float* uv, uint32_t K, double W, double H, doubl
     g.gw = (uint32_t)std::ceil(W / kGridCell) + 3;
     g.gh = (uint32_t)std::ceil(H / kGridCell) + 3;
     const size_t nc = (size_t)g.gw * g.gh;
-    g.gwc = (g.gw + 3) >> 2; g.ghc = (g.gh + 3) >> 2;
+    g.gwc = (g.gw + (1u << kCoarseShift) - 1u) >> kCoarseShift; g.ghc = (g.gh + (1u << kCoarseShift) - 1u) >> kCoarseShift;
     const size_t ncc = (size_t)g.gwc * g.ghc;
     g.coarse_start.assign(ncc + 1, 0);
     std::vector<uint32_t> cell_of(K);
     for (uint32_t k = 0; k < K; ++k) {
-        const int cxi = grid_cell(uv[2 * k], (int)g.gw) >> 2, cyi = grid_cell(uv[2 * k + 1], (int)g.gh) >> 2;
+        const int cxi = grid_cell(uv[2 * k], (int)g.gw) >> kCoarseShift, cyi = grid_cell(uv[2 * k + 1], (int)g.gh) >> kCoarseShift;
         cell_of[k] = (uint32_t)cyi * g.gwc + (uint32_t)cxi;
         g.coarse_start[cell_of[k] + 1]++;
     }

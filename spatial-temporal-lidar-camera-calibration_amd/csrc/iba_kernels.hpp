@@ -414,8 +414,8 @@ __device__ __forceinline__ bool near_keypoint(const FrameCtx& c, double u, doubl
 template <int PASS>
 __device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v, uint32_t pos) {
     const float uf = (float)u, vf = (float)v;
-    const int x0 = grid_cell(uf - c.margin, c.gw) >> 2, x1 = grid_cell(uf + c.margin, c.gw) >> 2;
-    const int y0 = grid_cell(vf - c.margin, c.gh) >> 2, y1 = grid_cell(vf + c.margin, c.gh) >> 2;
+    const int x0 = grid_cell(uf - c.margin, c.gw) >> kCoarseShift, x1 = grid_cell(uf + c.margin, c.gw) >> kCoarseShift;
+    const int y0 = grid_cell(vf - c.margin, c.gh) >> kCoarseShift, y1 = grid_cell(vf + c.margin, c.gh) >> kCoarseShift;
     bool hit = false;
     for (int yy = y0; yy <= y1; ++yy) {
         const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
@@ -439,8 +439,8 @@ __device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v
 struct Hits { uint32_t k0, k1; unsigned long long d0, d1; int n; };
 __device__ __forceinline__ Hits grid_match_rec(const FrameCtx& c, double u, double v) {
     const float uf = (float)u, vf = (float)v;
-    const int x0 = grid_cell(uf - c.margin, c.gw) >> 2, x1 = grid_cell(uf + c.margin, c.gw) >> 2;
-    const int y0 = grid_cell(vf - c.margin, c.gh) >> 2, y1 = grid_cell(vf + c.margin, c.gh) >> 2;
+    const int x0 = grid_cell(uf - c.margin, c.gw) >> kCoarseShift, x1 = grid_cell(uf + c.margin, c.gw) >> kCoarseShift;
+    const int y0 = grid_cell(vf - c.margin, c.gh) >> kCoarseShift, y1 = grid_cell(vf + c.margin, c.gh) >> kCoarseShift;
     Hits hh; hh.k0 = hh.k1 = 0u; hh.d0 = hh.d1 = 0ull; hh.n = 0;
     for (int yy = y0; yy <= y1; ++yy) {
         const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
@@ -477,6 +477,15 @@ constexpr int kPathMax = 16;   // deeper trees (> 1.5 M points per scan) use the
 #endif
 #ifndef IBA_LEAF_UNROLL
 #define IBA_LEAF_UNROLL 1
+#endif
+#ifndef IBA_NN_RESUME_GMAX
+#define IBA_NN_RESUME_GMAX 32
+#endif
+#ifndef IBA_NN_FRESH_GMAX
+#define IBA_NN_FRESH_GMAX 8
+#endif
+#ifndef IBA_NN_G_SLACK
+#define IBA_NN_G_SLACK 0
 #endif
 #ifndef IBA_NN_END_AT
 #define IBA_NN_END_AT 128
@@ -1160,8 +1169,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
         uint32_t n_items = n3; bool fresh = true; int round = 0;
         for (;;) {
             int G;
-            if (fresh) G = n_items * 8u <= (uint32_t)kThreads ? 8 : (n_items * 4u <= (uint32_t)kThreads ? 4 : (n_items * 2u <= (uint32_t)kThreads ? 2 : 1));
-            else { G = 32; while ((uint32_t)G * n_items > (uint32_t)kThreads) G >>= 1; }
+            if (fresh) {
+                // lanes per query of the first round: as many as fit; a handful of items over a power-of-two boundary
+                // are cheaper as a short second pass than as half the lanes for everybody
+                const uint32_t slack = (uint32_t)IBA_NN_G_SLACK;
+                G = (IBA_NN_FRESH_GMAX >= 8 && n_items * 8u <= (uint32_t)kThreads + 8u * slack) ? 8 : ((IBA_NN_FRESH_GMAX >= 4 && n_items * 4u <= (uint32_t)kThreads + 4u * slack) ? 4 : ((IBA_NN_FRESH_GMAX >= 2 && n_items * 2u <= (uint32_t)kThreads + 2u * slack) ? 2 : 1));
+            }
+            else { G = IBA_NN_RESUME_GMAX; while ((uint32_t)G * n_items > (uint32_t)kThreads) G >>= 1; }
             const uint32_t per_it = (uint32_t)kThreads / (uint32_t)G;
             uint32_t* cnt = s_misc + 2 + (round & 1);
             if (tid == 0) *cnt = 0u;

@@ -12,7 +12,11 @@ namespace iba {
 
 constexpr int kMaxCovis = 10;        // IBAPlaneEdge pads to 10 covisible KFs (IBACalib.hpp:133-137)
 constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum block
-constexpr int kGridCell = 4;         // keypoint grid cell (px); must be >= 2*(max_pixel_dist+margin)
+#ifndef IBA_GRID_CELL
+#define IBA_GRID_CELL 4
+#endif
+constexpr int kGridCell = IBA_GRID_CELL;   // cell of the 1-bit reject bitmap (px)
+constexpr int kCoarseShift = kGridCell == 1 ? 4 : (kGridCell == 2 ? 3 : 2);   // CSR cells stay 16 px: coarse = fine >> kCoarseShift
 #ifndef IBA_THREADS
 #define IBA_THREADS 512
 #endif
