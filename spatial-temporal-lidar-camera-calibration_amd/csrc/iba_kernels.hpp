@@ -478,6 +478,12 @@ constexpr int kPathMax = 16;   // deeper trees (> 1.5 M points per scan) use the
 #ifndef IBA_LEAF_UNROLL
 #define IBA_LEAF_UNROLL 1
 #endif
+#ifndef IBA_LEAF_BATCH
+#define IBA_LEAF_BATCH 1   /* leaf-scan steps whose loads are issued together (2: no gain, 4+: register spills) */
+#endif
+#ifndef IBA_FRAME_WAVES
+#define IBA_FRAME_WAVES 4   /* waves per SIMD the frame kernel is compiled for (register budget 512 / this) */
+#endif
 #ifndef IBA_NN_RESUME_GMAX
 #define IBA_NN_RESUME_GMAX 32
 #endif
@@ -712,23 +718,35 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
             const uint32_t j = node - first_leaf;
             const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
             // branch-free in the common case: an inactive query has NaN coordinates (every compare is false), the
-            // running best is a min, and only an exact tie (lowest original index wins) leaves the straight line
-#pragma unroll IBA_LEAF_UNROLL
-            for (uint32_t i = lo + sub; i < hi; i += G) {
-                const double x = (double)xs[i], y = (double)ys[i], z = (double)zs[i];
-                if (WHICH & 1) {
-                    const double dx = ax - x, dy = ay - y, dz = az - z;
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    const bool lt = d2 < bestA, eq = d2 == bestA;
-                    bestA = lt ? d2 : bestA; bposA = lt ? i : bposA;
-                    if (__builtin_expect(eq, 0)) { if (bposA != kNone && bposA != i && perm_g[i] < perm_g[bposA]) bposA = i; }
+            // running best is a select, and only an exact tie (lowest original index wins) leaves the straight line.
+            // The scan is read through L2 (iba_types.hpp: block shape), so the loads of kLeafBatch steps are issued
+            // together before any of them is consumed; a step beyond the leaf gets NaN coordinates.
+            constexpr int kLeafBatch = IBA_LEAF_BATCH;
+            for (uint32_t i0 = lo + sub; i0 < hi; i0 += (uint32_t)(kLeafBatch * G)) {
+                float X[kLeafBatch], Y[kLeafBatch], Z[kLeafBatch];
+#pragma unroll
+                for (int u = 0; u < kLeafBatch; ++u) {
+                    const uint32_t iu = i0 + (uint32_t)(u * G), ic = iu < hi ? iu : hi - 1u;
+                    X[u] = xs[ic]; Y[u] = ys[ic]; Z[u] = zs[ic];
                 }
-                if (WHICH & 2) {
-                    const double dx = cx - x, dy = cy - y, dz = cz - z;
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    const bool lt = d2 < bestC, eq = d2 == bestC;
-                    bestC = lt ? d2 : bestC; bposC = lt ? i : bposC;
-                    if (__builtin_expect(eq, 0)) { if (bposC != kNone && bposC != i && perm_g[i] < perm_g[bposC]) bposC = i; }
+#pragma unroll
+                for (int u = 0; u < kLeafBatch; ++u) {
+                    const uint32_t i = i0 + (uint32_t)(u * G);
+                    const double x = i < hi ? (double)X[u] : (double)NAN, y = (double)Y[u], z = (double)Z[u];
+                    if (WHICH & 1) {
+                        const double dx = ax - x, dy = ay - y, dz = az - z;
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        const bool lt = d2 < bestA, eq = d2 == bestA;
+                        bestA = lt ? d2 : bestA; bposA = lt ? i : bposA;
+                        if (__builtin_expect(eq, 0)) { if (bposA != kNone && bposA != i && perm_g[i] < perm_g[bposA]) bposA = i; }
+                    }
+                    if (WHICH & 2) {
+                        const double dx = cx - x, dy = cy - y, dz = cz - z;
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        const bool lt = d2 < bestC, eq = d2 == bestC;
+                        bestC = lt ? d2 : bestC; bposC = lt ? i : bposC;
+                        if (__builtin_expect(eq, 0)) { if (bposC != kNone && bposC != i && perm_g[i] < perm_g[bposC]) bposC = i; }
+                    }
                 }
             }
 #ifdef IBA_STAMPS_FINE
@@ -832,7 +850,7 @@ __device__ __forceinline__ uint32_t block_count(uint32_t my_count_wave_uniform, 
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so
 // all candidates of one frame share that XCD's L2 copy of the scan.
 template <int MODE, bool SCAN_LDS>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FRAME_WAVES, IBA_FRAME_WAVES))) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
                                                              double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out,
                                                              uint2* __restrict__ assoc_out, int nrec, const double* __restrict__ he,
                                                              uint4* __restrict__ flist, uint32_t* __restrict__ fcount, int flist_stride) {
