@@ -63,7 +63,7 @@ struct iba_handle {
     LdsLayout lay{};
 
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
-    DevBuf<float> xs, ys, zs; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
+    DevBuf<float> xs, ys, zs, chunk_box; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
     DevBuf<float2> kp_uv; DevBuf<float4> kp_mp;
     DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
@@ -96,7 +96,7 @@ struct iba_handle {
 
     DevProblem dev_problem() const {
         DevProblem dp{};
-        dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p;
+        dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p; dp.chunk_box = chunk_box.p;
         dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.coarse_start = coarse_start.p; dp.crec = crec.p;
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
@@ -161,6 +161,9 @@ bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
     L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
     off = align_up(off, 8); L.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
     off = align_up(off, 16); L.off_red = off; off += red_bytes;
+    // visibility bits of the culling chunks, written one 64-bit ballot per wave and pass: room for whole passes
+    L.off_vis = off; L.vis_words = 2u * kWaves * ((h->maxPpad / (uint32_t)kChunk + kThreads) / kThreads) + 2u;
+    off += 4u * L.vis_words + 2u * (h->maxPpad / (uint32_t)kChunk + 2u);   // bit words, then the compacted u16 list of visible chunks
     // keypoint bitmap, coarse CSR and candidate queue are contiguous: after phase 2 the fused mode parks its
     // unfinished NN queries in [off_bitmap, total)
     off = align_up(off, 16); L.off_bitmap = off; off += 4u * std::max(h->maxBitmapWords, 1u);
@@ -292,7 +295,7 @@ void iba_destroy(iba_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release();
+    h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
     h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
     if (h->h_cands) (void)hipHostFree(h->h_cands);
@@ -330,7 +333,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     // ---- validation of the owned slice ----
     for (int f = frame_begin; f < frame_end; ++f) {
         const uint64_t P = d->pt_offset[f + 1] - d->pt_offset[f], K = d->kp_offset[f + 1] - d->kp_offset[f];
-        if (P >= (1ull << 24) || K >= 65535ull) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan (>= 2^24 points) or keypoint count (>= 65535) too large"); }
+        if (P >= (1ull << 22) || K >= 65535ull) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan (>= 2^22 points) or keypoint count (>= 65535) too large"); }
         const uint64_t ns = d->covis_offset[f + 1] - d->covis_offset[f];
         if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 10 covisible keyframes per frame"); }
     }
@@ -364,11 +367,12 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
 
     // ---- flatten ----
     std::vector<FrameHdr>& hdr = h->h_frames; hdr.resize(nf);
-    uint64_t pt_base = 0, kp_base = 0, coarse_base = 0, bm_base = 0, match_base = 0; uint32_t node_base = 0, slot_base = 0;
+    uint64_t pt_base = 0, kp_base = 0, coarse_base = 0, bm_base = 0, match_base = 0, box_base = 0; uint32_t node_base = 0, slot_base = 0;
     for (int lf = 0; lf < nf; ++lf) {
         const int f = frame_begin + lf;
         FrameHdr& x = hdr[lf]; std::memset(&x, 0, sizeof(x));
         x.P = (uint32_t)(d->pt_offset[f + 1] - d->pt_offset[f]); x.Ppad = (x.P + 3u) & ~3u; x.pt_base = pt_base; pt_base += x.Ppad;
+        x.box_base = box_base; box_base += (x.P + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
         x.depth = fb[lf].D; x.node_base = node_base; node_base += (uint32_t)fb[lf].nodes.size();
         x.K = (uint32_t)(d->kp_offset[f + 1] - d->kp_offset[f]); x.kp_base = kp_base; kp_base += x.K;
         x.gw = fb[lf].grid.gw; x.gh = fb[lf].grid.gh; x.gwc = fb[lf].grid.gwc; x.ghc = fb[lf].grid.ghc;
@@ -393,6 +397,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     const float qnan = std::numeric_limits<float>::quiet_NaN();
     std::vector<float> xs(pt_base, qnan), ys(pt_base, qnan), zs(pt_base, qnan);
     std::vector<uint32_t> perm(pt_base, 0u), inv_perm(pt_base, 0u);
+    std::vector<float> chunk_box(6 * (size_t)box_base, qnan);
     std::vector<TreeNode> nodes(node_base);
     std::vector<float2> kp_uv(kp_base); std::vector<float4> kp_mp(kp_base), crec(kp_base);
     std::vector<uint32_t>& kp_ext = h->h_kp_ext; kp_ext.resize(kp_base);
@@ -407,6 +412,15 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
             const uint32_t o = b.idx[i];
             xs[x.pt_base + i] = src[3 * (size_t)o]; ys[x.pt_base + i] = src[3 * (size_t)o + 1]; zs[x.pt_base + i] = src[3 * (size_t)o + 2];
             perm[x.pt_base + i] = o; inv_perm[x.pt_base + o] = i;
+        }
+        for (uint32_t c0 = 0; c0 < x.P; c0 += (uint32_t)kChunk) {   // static AABB of every kChunk consecutive tree positions
+            float* bx = &chunk_box[6 * (size_t)(x.box_base + c0 / (uint32_t)kChunk)];
+            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t i = c0; i < std::min<uint32_t>(c0 + (uint32_t)kChunk, x.P); ++i) {
+                const float v[3] = {xs[x.pt_base + i], ys[x.pt_base + i], zs[x.pt_base + i]};
+                for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }   // NaN coordinates never narrow a box
+            }
+            for (int a = 0; a < 3; ++a) { bx[a] = mn[a]; bx[3 + a] = mx[a]; }
         }
         std::copy(b.nodes.begin(), b.nodes.end(), nodes.begin() + x.node_base);
         const uint64_t k0 = d->kp_offset[f];
@@ -446,7 +460,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
 
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
 #define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
-    UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes);
+    UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes); UP(chunk_box, chunk_box);
     UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv);
 #undef UP
     hipError_t er;

@@ -38,6 +38,7 @@ struct DevProblem {
     const float* xs; const float* ys; const float* zs;
     const uint32_t* perm;      // tree position -> original point index
     const uint32_t* inv_perm;  // original point index -> tree position
+    const float* chunk_box;    // [chunk][6]: min xyz, max xyz of kChunk consecutive tree positions (NaN padding ignored)
     const TreeNode* nodes;
     const float2* kp_uv;
     const float4* kp_mp;       // MapPoint world position (x,y,z); w = 1*(owns a MapPoint) + 2*(matched in >= 1 covisible KF)
@@ -55,7 +56,7 @@ struct DevProblem {
 
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
     uint32_t scan_stride;   // floats per coordinate array (0 = scan not staged in LDS)
-    uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_cstart, off_red, off_cand, cand_cap, total;
+    uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_cstart, off_red, off_vis, vis_words, off_cand, cand_cap, total;
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -930,21 +931,99 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
     //      proves that the exact (f64) test could not produce a match. Everything that survives (~6 %) — and
     //      everything the f32 test cannot decide (|depth| <= 0.1 m) — is queued for the exact f64 path below.
     const uint32_t cand_cap = lay.cand_cap;
+    // ---- phase 0.5: conservative frustum test of the static per-chunk boxes. A LiDAR sweeps 180-360 degrees, the camera
+    //      sees ~80 x 30: most chunks of kChunk consecutive tree positions (a few neighbouring kd leaves) cannot project
+    //      into the image for this candidate and are neither loaded nor projected. The five half-spaces (left, right, top,
+    //      bottom with an 8 px margin, depth > -0.2 m) are the pre-cull's own acceptance region widened far beyond its
+    //      float error, moved into the LiDAR frame (n = R^T a, d = a . t); a box is dropped only if its farthest corner
+    //      violates one of them by more than 1e-3 relative.
+    uint32_t* s_vis = (uint32_t*)(smem + lay.off_vis);
+    {
+        const uint32_t nchunks = (P + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
+        const float m = 8.0f;
+        const float A[5][3] = {{(float)c.fx, 0.f, (float)c.cx + m}, {-(float)c.fx, 0.f, (float)c.W + m - (float)c.cx},
+                               {0.f, (float)c.fx, (float)c.cy + m}, {0.f, -(float)c.fx, (float)c.H + m - (float)c.cy}, {0.f, 0.f, 1.f}};
+        float N[5][3], Dd[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) N[q][j] = (float)c.R[0 * 3 + j] * A[q][0] + (float)c.R[1 * 3 + j] * A[q][1] + (float)c.R[2 * 3 + j] * A[q][2];
+            Dd[q] = (float)c.t[0] * A[q][0] + (float)c.t[1] * A[q][1] + (float)c.t[2] * A[q][2] + (q == 4 ? 0.2f : 0.f);
+        }
+        const float* boxes = dp.chunk_box + 6 * h.box_base;
+        for (uint32_t ch0 = 0; ch0 < nchunks; ch0 += kThreads) {
+            const uint32_t ch = ch0 + (uint32_t)tid;
+            bool vis = false;
+            if (ch < nchunks) {
+                const float* b = boxes + 6 * (size_t)ch;
+                const float lo3[3] = {b[0], b[1], b[2]}, hi3[3] = {b[3], b[4], b[5]};
+                vis = true;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    float smax = Dd[q], mag = fabsf(Dd[q]);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        smax += N[q][j] >= 0.f ? N[q][j] * hi3[j] : N[q][j] * lo3[j];
+                        mag += fabsf(N[q][j]) * fmaxf(fabsf(lo3[j]), fabsf(hi3[j]));
+                    }
+                    vis = vis && !(smax < -1e-3f * mag - 1e-6f);   // NaN boxes (empty chunk) compare false -> kept, harmless
+                }
+            }
+            const unsigned long long bal = __ballot(vis);
+#ifdef IBA_STAMPS
+            if (lane == 0) { atomicAdd(&g_dbg[3], (unsigned long long)__popcll(bal)); if (wave == 0 && ch0 == 0) atomicAdd(&g_dbg[4], (unsigned long long)nchunks); }
+#endif
+            if (lane == 0) { s_vis[(ch0 >> 5) + 2u * (uint32_t)wave] = (uint32_t)bal; s_vis[(ch0 >> 5) + 2u * (uint32_t)wave + 1u] = (uint32_t)(bal >> 32); }
+        }
+    }
+    __syncthreads();
+    // visible chunks, compacted in order into a u16 list right behind the bit words (wave 0: one bit word per lane and pass)
+    const uint32_t nchunks_all = (P + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
+    const uint32_t nvis_words = (nchunks_all + 31u) >> 5;
+    uint16_t* s_vlist = (uint16_t*)(s_vis + lay.vis_words);
+    if (!SCAN_LDS) {
+        if (wave == 0) {
+            uint32_t run = 0;
+            for (uint32_t w0 = 0; w0 < nvis_words; w0 += 64u) {
+                const uint32_t wi = w0 + (uint32_t)lane;
+                uint32_t bits = wi < nvis_words ? s_vis[wi] : 0u;
+                if (wi == nvis_words - 1u && (nchunks_all & 31u)) bits &= (1u << (nchunks_all & 31u)) - 1u;   // stale bits beyond the last chunk
+                const uint32_t cntb = (uint32_t)__popc(bits);
+                uint32_t incl = cntb;   // inclusive prefix over the wave
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+                uint32_t at = run + incl - cntb;
+                while (bits) { const uint32_t bpos = (uint32_t)__ffs((int)bits) - 1u; bits &= bits - 1u; s_vlist[at++] = (uint16_t)(wi * 32u + bpos); }
+                run += __shfl(incl, 63);
+            }
+            if (lane == 0) s_misc[1 + 2] = run;   // s_misc[3]: number of visible chunks (the NN rounds re-zero their counters later)
+        }
+        __syncthreads();
+    }
+    const uint32_t n_vis = SCAN_LDS ? 0u : s_misc[3];
     {
         const float r0 = (float)c.R[0], r1 = (float)c.R[1], r2 = (float)c.R[2], r3 = (float)c.R[3], r4 = (float)c.R[4], r5 = (float)c.R[5],
                     r6 = (float)c.R[6], r7 = (float)c.R[7], r8 = (float)c.R[8], t0 = (float)c.t[0], t1 = (float)c.t[1], t2 = (float)c.t[2];
         const float fxf = (float)c.fx, cxf = (float)c.cx, cyf = (float)c.cy, Wf = (float)c.W + 1.0f, Hf = (float)c.H + 1.0f;
-        const uint32_t n_iter = (Ppad + kThreads * 4u - 1u) / (kThreads * 4u);
+        // SCAN_LDS: every point, in tree order (it has to be staged). Otherwise: the 4-point groups of the visible chunks only
+        // (16 groups per chunk), so the number of dependent load rounds shrinks with the culling.
+        const uint32_t n_groups = SCAN_LDS ? (Ppad + 3u) / 4u : n_vis * (uint32_t)(kChunk / 4);
+        const uint32_t n_iter = (n_groups + kThreads - 1u) / kThreads;
         const float qn = __builtin_nanf("");
         const float4 nan4 = make_float4(qn, qn, qn, qn);
+        auto group_base = [&](uint32_t g) -> uint32_t {   // first tree position of group g, or kNone
+            if (g >= n_groups) return kNone;
+            const uint32_t b4 = SCAN_LDS ? g * 4u : (uint32_t)s_vlist[g >> 4] * (uint32_t)kChunk + (g & 15u) * 4u;
+            return b4 < Ppad ? b4 : kNone;
+        };
         float4 X = nan4, Y = nan4, Z = nan4;   // software pipeline: the next 16-byte loads are in flight while 4 points are tested
-        if ((uint32_t)tid * 4u < Ppad) { X = *(const float4*)(gxs + tid * 4); Y = *(const float4*)(gys + tid * 4); Z = *(const float4*)(gzs + tid * 4); }
+        uint32_t base = group_base((uint32_t)tid);
+        if (base != kNone) { X = *(const float4*)(gxs + base); Y = *(const float4*)(gys + base); Z = *(const float4*)(gzs + base); }
         for (uint32_t it = 0; it < n_iter; ++it) {
-            const uint32_t base = (uint32_t)tid * 4u + it * (kThreads * 4u);
-            const uint32_t nbase = base + kThreads * 4u;
+            const uint32_t nbase = group_base((uint32_t)tid + (it + 1u) * kThreads);
             float4 Xn = nan4, Yn = nan4, Zn = nan4;
-            if (nbase < Ppad) { Xn = *(const float4*)(gxs + nbase); Yn = *(const float4*)(gys + nbase); Zn = *(const float4*)(gzs + nbase); }
-            if (SCAN_LDS && base < Ppad) { *(float4*)(s_xs + base) = X; *(float4*)(s_ys + base) = Y; *(float4*)(s_zs + base) = Z; }
+            if (nbase != kNone) { Xn = *(const float4*)(gxs + nbase); Yn = *(const float4*)(gys + nbase); Zn = *(const float4*)(gzs + nbase); }
+            if (SCAN_LDS && base != kNone) { *(float4*)(s_xs + base) = X; *(float4*)(s_ys + base) = Y; *(float4*)(s_zs + base) = Z; }
             const float px[4] = {X.x, X.y, X.z, X.w}, py[4] = {Y.x, Y.y, Y.z, Y.w}, pz[4] = {Z.x, Z.y, Z.z, Z.w};
             bool pass[4];
 #pragma unroll
@@ -975,7 +1054,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (!pass[j]) continue;
-                    if (off[j] < cand_cap) s_cand[off[j]] = (CandT)(base + j);
+                    if (off[j] < cand_cap) s_cand[off[j]] = (CandT)(base + j);   // pass[j] implies base != kNone (NaN coordinates never pass)
                     else {   // queue full: exact path inline, full rescan in phase 2 (speed only)
                         double u, v;
                         if (project_uv(c, px[j], py[j], pz[j], u, v)) grid_match<1>(c, u, v, base + j);
@@ -983,7 +1062,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
                     }
                 }
             }
-            X = Xn; Y = Yn; Z = Zn;
+            X = Xn; Y = Yn; Z = Zn; base = nbase;
         }
     }
     __syncthreads();
@@ -1277,6 +1356,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
                 __syncthreads();
             }
             n_items = min(*cnt, cap_hard);
+#ifdef IBA_STOP_NN_ROUND
+            if (round == IBA_STOP_NN_ROUND) return;   // diagnostic: time attribution
+#endif
 #ifdef IBA_STAMPS_FINE
             if (tid == 0) { const int rr = round < 7 ? round : 7; atomicAdd(&g_dbg[16 + rr], __builtin_readcyclecounter() - dbg_t0); }
 #endif

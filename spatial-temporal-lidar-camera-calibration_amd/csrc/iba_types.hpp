@@ -10,6 +10,7 @@
 
 namespace iba {
 
+constexpr int kChunk = 64;           // points per culling chunk (~3 kd leaves): static AABB, frustum-tested per candidate
 constexpr int kMaxCovis = 10;        // IBAPlaneEdge pads to 10 covisible KFs (IBACalib.hpp:133-137)
 constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum block
 #ifndef IBA_GRID_CELL
@@ -43,6 +44,7 @@ struct FrameHdr {
     // scan (tree order)
     uint64_t pt_base;     // offset (elements) of this frame in xs/ys/zs/perm/inv_perm/plane arrays
     uint32_t P, Ppad;     // points, padded to x4
+    uint64_t box_base;    // offset (chunks) into chunk_box[]: one AABB per kChunk consecutive tree positions
     uint32_t depth;       // kd-tree depth D: 2^D leaves, leaf j = [j*P>>D, (j+1)*P>>D)
     uint32_t node_base;   // offset into nodes[] (2^D - 1 entries)
     // keypoints

@@ -106,3 +106,25 @@ def test_c3_three_trajectories_four_shards(pkg, synth, abi, c2):
     for a, b in zip(c3, c1):
         assert a.n_corr == 3 * b.n_corr and a.cnt_3d_3d == 3 * b.cnt_3d_3d and a.cnt_3d_2d == 3 * b.cnt_3d_2d and a.frames_used == 3 * b.frames_used
         assert abs(a.f1 - b.f1) <= 1e-12 * b.f1 and abs(a.f2 - b.f2) <= 1e-12 * b.f2
+
+
+def test_kitti_sized_scans(pkg, synth, abi, ob):
+    """Raw KITTI scans are ~120 k points (~60 k with PointCloudOnlyPositiveX): deeper kd-trees (D = 12), candidate queues and
+    work lists several times longer than at the bench shape. Cost tuple and normal equations vs the oracle."""
+    prob, meta = synth.make_scene(n_frames=3, pts_per_frame=60000, seed=8)
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(prob, p)
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(8), n=2)])
+    cost, nrm = h.eval_full(xs)
+    orc = ob.Oracle(prob)
+    oc, on = orc.eval_cost(p, xs), orc.eval_normal(p, xs)
+    for a, b in zip(cost, oc):
+        _cmp_cost(a, b)
+    for a, b in zip(nrm, on):
+        assert a.counts() == b.counts()
+        assert np.allclose(a.H_np(), b.H_np(), rtol=1e-9, atol=1e-9 * np.abs(b.H_np()).max())
+    for f in range(3):
+        gk, gp = h.correspondences(xs[1], f)
+        ok, op = orc.correspondences(p, xs[1], f)
+        assert np.array_equal(gk, ok) and np.array_equal(gp, op)
+    h.close()

@@ -113,3 +113,48 @@ def test_many_covisible_keyframes(pkg, synth, abi, ob):
     for a, b in zip(nf, o.eval_normal(p, xs)):
         _cmpn(a, b)
     h.close()
+
+
+def test_frustum_culling_is_conservative(pkg, synth, abi, ob, scene_small):
+    """Chunks of the scan that cannot project into the image are skipped per candidate (phase 0.5): full-sweep scans (points
+    behind and beside the camera), a candidate that looks the other way (nothing visible), and extrinsics far from the
+    truth must give exactly the oracle's correspondences and counters."""
+    prob, meta = scene_small
+    a = {k: v.copy() for k, v in prob.arrays.items()}
+    pts = a["pts_xyz"].reshape(-1, 3)
+    F = prob.n_frames
+    po = a["pt_offset"].astype(np.int64)
+    new_pts, new_off = [], [0]
+    rng = np.random.default_rng(3)
+    for f in range(F):   # full 360-degree sweep: mirror every other point behind the sensor and shuffle
+        p = pts[po[f]:po[f + 1]].copy()
+        p[::2, 0] *= -1.0
+        rng.shuffle(p)
+        new_pts.append(p)
+        new_off.append(new_off[-1] + len(p))
+    a["pts_xyz"] = np.concatenate(new_pts).reshape(-1).astype(np.float32)
+    a["pt_offset"] = np.array(new_off, np.uint64)
+    full = abi.Problem(**a)
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(full, p)
+    o = ob.Oracle(full)
+    x_gt = meta["x_gt"]
+    back = x_gt.copy()
+    back[:3] = synth_rotvec_compose(x_gt[:3], np.array([0.0, np.pi, 0.0]))   # camera turned around its y axis
+    xs = np.vstack([x_gt[None], synth.perturb(x_gt, rng, rot=0.05, trans=0.3, scale_rel=0.05, n=3), back[None]])
+    g = h.eval_cost(xs)
+    oo = o.eval_cost(p, xs)
+    for gi, oi in zip(g, oo):
+        for k in ("valid_cnt_3d_2d", "cnt_3d_2d", "cnt_3d_3d", "valid_cnt_3d_3d", "frames_used", "n_corr"):
+            assert getattr(gi, k) == getattr(oi, k), k
+    for x in (xs[0], xs[2], xs[4]):
+        for f in (0, F - 1):
+            gk, gp = h.correspondences(x, f)
+            ok, op = o.correspondences(p, x, f)
+            assert np.array_equal(gk, ok) and np.array_equal(gp, op)
+    h.close()
+
+
+def synth_rotvec_compose(w, dw):
+    from scipy.spatial.transform import Rotation
+    return (Rotation.from_rotvec(dw) * Rotation.from_rotvec(w)).as_rotvec()
