@@ -223,6 +223,25 @@ def main():
                                         "mads_evaluations": mr.evaluations, "mads_batches": mr.batches, "mads_restarts": mr.restarts, "mads_feasible": mr.feasible,
                                         "mads_f": mr.f, "mads_seconds": t_mads, "total_seconds": t_all,
                                         "note": "reference budget: 5000 NOMAD evaluations on one CPU thread (iba_calib_global.yml:42) at ~2 evals/s"}
+            # (4) ORB-only extrinsic BA on a planted edge list of the C2 scale: 200 keyframes x 600 observations
+            import ba_scene
+            ba = importlib.import_module(PKG + ".ba")
+            bprob, bx_gt = ba_scene.make(n_frames=200, pts_per_frame=600, seed=1, ba=ba)
+            bh = ba.BaHandle(bprob)
+            bx0 = bx_gt + np.array([0.008, -0.006, 0.005, 0.03, -0.02, 0.02, 0.3])
+            bh.eval(bx0, want_chi2=False)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                bh.eval(bx0, want_chi2=False)
+            t_lin = (time.perf_counter() - t0) / 20
+            t0 = time.perf_counter()
+            bx, br = bh.optimize(bx0)
+            t_opt = time.perf_counter() - t0
+            be = lm_ref.se3_error_rt(bx, bx_gt) if hasattr(lm_ref, "se3_error_rt") else None
+            res["orb_only_ba"] = {"edges": int(br.n_edges), "inliers": int(br.n_inliers), "linearisation_ms": t_lin * 1e3,
+                                  "edges_per_s": br.n_edges / t_lin, "optimize_seconds": t_opt, "device_evaluations": int(br.evaluations),
+                                  "err_vs_planted": {"rot_rad": float(np.linalg.norm(bx[:3] - bx_gt[:3])), "trans_m": float(np.linalg.norm(bx[3:6] - bx_gt[3:6])), "scale": float(abs(bx[6] - bx_gt[6]))}}
+            bh.close()
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tfile):
         try:
