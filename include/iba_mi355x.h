@@ -383,8 +383,9 @@ iba_status iba_ba_eval(iba_ba_handle* h, const double* x, const uint8_t* active,
  * Xw and Tlw6 were built): 4 x (reset to x0, 10 LM iterations, classify at chi2 > 5.991), kernel off after round 3. */
 iba_status iba_ba_optimize(iba_ba_handle* h, const double* x0, iba_ba_result* res);
 
-/* Edge list of the ORB-only extrinsic BA straight from the dataset directory (OptimizeExtrinsicGlobal constants,
- * Optimizer.cc:1611-1676; LiDAR poses as ba_calib.cpp:43-44 passes them). global = 0 (the Local variant) is not packed. */
+/* Edge list of the ORB-only extrinsic BA straight from the dataset directory; LiDAR poses as ba_calib.cpp:43-44 passes them.
+ * global = 1: OptimizeExtrinsicGlobal constants (Optimizer.cc:1611-1676); global = 0: OptimizeExtrinsicLocal (:1437-1501: MapPoints
+ * in the frame of the oldest of the 20 best covisible keyframes, LiDAR pose relative to it). */
 typedef struct iba_ba_dataset iba_ba_dataset;
 iba_status iba_dataset_load_ba(const iba_dataset_paths* paths, int32_t global, iba_ba_dataset** out);
 const iba_ba_desc* iba_ba_dataset_desc(const iba_ba_dataset* d);

@@ -457,7 +457,7 @@ def load_dataset(frame_id_file, lidar_pose_file, pointcloud_dir, keyframe_dir, m
 # ----------------------------------------------------------------------------------------------------------------------
 # synthetic scene -> dataset directory
 # ----------------------------------------------------------------------------------------------------------------------
-def write_dataset(root, prob, meta, keypoint_layout="nested", frame_id_stride=1, first_frame_id=0, extra_points=0, weights=None):
+def write_dataset(root, prob, meta, keypoint_layout="nested", frame_id_stride=1, first_frame_id=0, extra_points=0, weights=None, contiguous_ids=False):
     """Lays the scene of synth.make_scene out as the reference pipeline would have produced it. Frames that are not
     keyframes (frame_id_stride > 1) get filler scans and poses. Returns the dict of paths for load_dataset /
     iba_dataset_load."""
@@ -483,7 +483,7 @@ def write_dataset(root, prob, meta, keypoint_layout="nested", frame_id_stride=1,
             write_kitti_bin(os.path.join(root, "velodyne", "%06d.bin" % i), rng.normal(0, 5, (7, 3)))
             poses.append(np.eye(4))
     write_pose_list(os.path.join(root, "lidar_poses.txt"), poses)
-    mn_ids = [3 * f + 1 for f in range(F)]   # keyframe ids are not contiguous in a real map (culling)
+    mn_ids = list(range(F)) if contiguous_ids else [3 * f + 1 for f in range(F)]   # keyframe ids are not contiguous in a real map (culling)
     write_frame_id_yml(os.path.join(root, "FrameId.yml"), mn_ids, frame_ids)
     mp2kp = meta["mp2kp"]
     mp_world = meta["mp_orb_f32"]
@@ -516,7 +516,12 @@ def write_dataset(root, prob, meta, keypoint_layout="nested", frame_id_stride=1,
 # ----------------------------------------------------------------------------------------------------------------------
 # ORB-only extrinsic BA: edge constants of OptimizeExtrinsicGlobal (Optimizer.cc:1611-1676) from the dataset directory
 # ----------------------------------------------------------------------------------------------------------------------
-def load_ba_edges_global(frame_id_file, lidar_pose_file, pointcloud_dir, keyframe_dir, map_file, **_):
+def load_ba_edges_global(*a, **k):
+    return load_ba_edges(*a, global_variant=True, **k)
+
+
+def load_ba_edges(frame_id_file, lidar_pose_file, pointcloud_dir, keyframe_dir, map_file, global_variant=True, **_):
+    """global_variant: OptimizeExtrinsicGlobal (Optimizer.cc:1611-1676); else OptimizeExtrinsicLocal (:1437-1501)."""
     from scipy.spatial.transform import Rotation
     vKFFrameId = [int(v) for v in parse_opencv_yaml(frame_id_file)["mnFrameId"]]
     raw = read_pose_list(lidar_pose_file)                                   # ba_calib.cpp:40-45: raw poses, no re-referencing
@@ -525,11 +530,21 @@ def load_ba_edges_global(frame_id_file, lidar_pose_file, pointcloud_dir, keyfram
     kf_dir = keyframe_dir if keyframe_dir.endswith("/") else keyframe_dir + "/"
     names = sorted(n for n in os.listdir(kf_dir) if os.path.isfile(kf_dir + n) and n.rsplit(".", 1)[-1] in ("yml", "yaml") and n != "FrameId.yml")
     kfs = sorted((parse_opencv_yaml(kf_dir + n) for n in names), key=lambda k: int(k["mnId"]))
-    T0 = np.asarray(kfs[0]["Pose"], f32)                                    # Tc0w
+    KFIdMap = {int(k["mnId"]): i for i, k in enumerate(kfs)}
     out = dict(frame_Tlw6=[], frame_intr=[], edge_frame=[], edge_Xw=[], edge_obs=[], edge_info=[], edge_slot=[])
     for f, kf in enumerate(kfs):
         Twl = raw[vKFFrameId[f]]
-        out["frame_Tlw6"].append(np.concatenate([Rotation.from_matrix(Twl[:3, :3]).as_rotvec(), Twl[:3, 3]]))
+        if global_variant:
+            T0 = np.asarray(kfs[0]["Pose"], f32)                                # Tc0w
+            T6 = np.concatenate([Rotation.from_matrix(Twl[:3, :3]).as_rotvec(), Twl[:3, 3]])
+        else:
+            con = [KFIdMap[int(i)] for i in kf["mvpOrderedConnectedKeyFramesId"] if int(i) in KFIdMap][:20]
+            oldest = min(con, key=lambda g: int(kfs[g]["mnId"]))
+            T0 = np.asarray(kfs[oldest]["Pose"], f32)                           # T_old_w
+            Twold = raw[vKFFrameId[int(kfs[oldest]["mnId"])]]                   # vTwl[nKFID]: the mnId used as an index
+            Tl_old = np.linalg.inv(np.linalg.inv(Twold) @ Twl)
+            T6 = np.concatenate([Rotation.from_matrix(Tl_old[:3, :3]).as_rotvec(), Tl_old[:3, 3]])
+        out["frame_Tlw6"].append(T6)
         out["frame_intr"].append([float(f32(kf[k])) for k in ("fx", "fy", "cx", "cy")])
         kps = np.array(kf["mvKeysUn"], np.float64).reshape(-1, 7)
         sig = [f32(v) for v in kf["mvInvLevelSigma2"]]

@@ -83,8 +83,8 @@ class BaHandle:
         return np.array(r.x[:]), r
 
 
-def load_ba_dataset(frame_id_file, lidar_pose_file, pointcloud_dir, keyframe_dir, map_file, **_):
-    """Edge list of OptimizeExtrinsicGlobal from a dataset directory of the reference pipeline (iba_dataset_load_ba)."""
+def load_ba_dataset(frame_id_file, lidar_pose_file, pointcloud_dir, keyframe_dir, map_file, global_variant=True, **_):
+    """Edge list of OptimizeExtrinsicGlobal (or ...Local) from a dataset directory of the reference pipeline (iba_dataset_load_ba)."""
     from .formats import IbaDatasetPaths, _lib
     L = _lib()
     L.iba_dataset_load_ba.argtypes = [C.POINTER(IbaDatasetPaths), C.c_int32, C.POINTER(C.c_void_p)]
@@ -94,7 +94,7 @@ def load_ba_dataset(frame_id_file, lidar_pose_file, pointcloud_dir, keyframe_dir
     paths = IbaDatasetPaths(str(frame_id_file).encode(), str(lidar_pose_file).encode(), str(pointcloud_dir).encode(), str(keyframe_dir).encode(),
                             str(map_file).encode(), 1, 0, 3, 100)
     h = C.c_void_p()
-    st = L.iba_dataset_load_ba(C.byref(paths), 1, C.byref(h))
+    st = L.iba_dataset_load_ba(C.byref(paths), 1 if global_variant else 0, C.byref(h))
     if st != 0:
         raise IbaError(st, (L.iba_io_last_error() or b"").decode())
     try:

@@ -652,7 +652,6 @@ void iba_ba_dataset_free(iba_ba_dataset* d) { delete d; }
 iba_status iba_dataset_load_ba(const iba_dataset_paths* P, int32_t global, iba_ba_dataset** out) {
     if (!P || !out || !P->frame_id_file || !P->lidar_pose_file || !P->keyframe_dir || !P->map_file) return io_fail(IBA_ERR_INVALID_ARG, "null path");
     *out = nullptr;
-    if (!global) return io_fail(IBA_ERR_UNSUPPORTED, "only the OptimizeExtrinsicGlobal edge constants are packed (the Local variant needs the 20 best covisible keyframes)");
     std::vector<int> vKFFrameId;
     {
         CvYaml y;
@@ -702,14 +701,44 @@ iba_status iba_dataset_load_ba(const iba_dataset_paths* P, int32_t global, iba_b
     for (int i = 0; i < F; ++i) if (!load_keyframe(info_files[i], kfs[i])) return io_fail(IBA_ERR_IO, kfs[i].err);
     std::sort(kfs.begin(), kfs.end(), [](const KeyFrameInfo& a, const KeyFrameInfo& b) { return a.mnId < b.mnId; });   // System.cc:511-512
     iba_ba_dataset* D = new iba_ba_dataset();
-    const float* T0 = kfs[0].Tcw;   // Tc0w = allKF[0]->GetPose() (Optimizer.cc:1585)
+    std::unordered_map<int, int> KFIdMap;
+    for (int f = 0; f < F; ++f) KFIdMap[kfs[f].mnId] = f;
+    // vTwl as ba_calib.cpp:43-44 builds it: raw LiDAR pose of each keyframe's frame id, in keyframe order
+    auto twl_of = [&](int index) { return raw.data() + 12 * (size_t)vKFFrameId[index]; };
     for (int f = 0; f < F; ++f) {
         const KeyFrameInfo& kf = kfs[f];
-        const double* Twl = raw.data() + 12 * (size_t)vKFFrameId[f];   // ba_calib.cpp:43-44: raw pose of the keyframe's frame id
-        const double R[9] = {Twl[0], Twl[1], Twl[2], Twl[4], Twl[5], Twl[6], Twl[8], Twl[9], Twl[10]};
+        const double* Twl = twl_of(f);
+        const float* T0 = kfs[0].Tcw;   // Global: Tc0w = allKF[0]->GetPose() (Optimizer.cc:1585)
         double T6[6];
-        rotvec_from_matrix(R, T6);                                      // Rlw = Twl.rotation(): the reference's naming (:1627-1632)
-        T6[3] = Twl[3]; T6[4] = Twl[7]; T6[5] = Twl[11];
+        if (global) {
+            const double R[9] = {Twl[0], Twl[1], Twl[2], Twl[4], Twl[5], Twl[6], Twl[8], Twl[9], Twl[10]};
+            rotvec_from_matrix(R, T6);                                  // Rlw = Twl.rotation(): the reference's naming (:1627-1632)
+            T6[3] = Twl[3]; T6[4] = Twl[7]; T6[5] = Twl[11];
+        } else {
+            // Local (Optimizer.cc:1441-1462): the oldest of the 20 best covisible keyframes is the reference frame;
+            // Told_l = vTwl[nKFID]^-1 * Twl with nKFID = its mnId used AS AN INDEX into vTwl (reproduced), Tl_old = Told_l^-1
+            std::vector<int> con;
+            for (int id : kf.conn_ids) { auto it = KFIdMap.find(id); if (it != KFIdMap.end()) con.push_back(it->second); }
+            if (con.size() > 20) con.resize(20);
+            if (con.empty()) { delete D; return io_fail(IBA_ERR_UNSUPPORTED, kf.file + ": keyframe without covisible keyframes (the reference dereferences ConKFS[0])"); }
+            int oldest = con[0];
+            for (int g : con) if (kfs[g].mnId < kfs[oldest].mnId) oldest = g;   // sort by KeyFrame::lId, take [0]
+            T0 = kfs[oldest].Tcw;                                                // T_old_w
+            const int nKFID = kfs[oldest].mnId;
+            if (nKFID < 0 || nKFID >= F) { delete D; return io_fail(IBA_ERR_UNSUPPORTED, kf.file + ": mnId of the oldest covisible keyframe is not a valid index into the pose list (the reference indexes vTwl with it)"); }
+            const double* A = twl_of(nKFID);   // Twold
+            double Ri[9], ti[3], M[12];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Ri[r * 3 + c] = A[c * 4 + r];
+            for (int r = 0; r < 3; ++r) ti[r] = -((Ri[r * 3] * A[3] + Ri[r * 3 + 1] * A[7]) + Ri[r * 3 + 2] * A[11]);
+            for (int r = 0; r < 3; ++r) {      // Told_l = Twold^-1 * Twl
+                for (int c = 0; c < 3; ++c) M[r * 4 + c] = (Ri[r * 3] * Twl[c] + Ri[r * 3 + 1] * Twl[4 + c]) + Ri[r * 3 + 2] * Twl[8 + c];
+                M[r * 4 + 3] = ((Ri[r * 3] * Twl[3] + Ri[r * 3 + 1] * Twl[7]) + Ri[r * 3 + 2] * Twl[11]) + ti[r];
+            }
+            double Rinv[9];                    // Told_linv
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rinv[r * 3 + c] = M[c * 4 + r];
+            rotvec_from_matrix(Rinv, T6);
+            for (int r = 0; r < 3; ++r) T6[3 + r] = -((Rinv[r * 3] * M[3] + Rinv[r * 3 + 1] * M[7]) + Rinv[r * 3 + 2] * M[11]);
+        }
         D->frame_Tlw6.insert(D->frame_Tlw6.end(), T6, T6 + 6);
         const double in[4] = {(double)kf.fx, (double)kf.fy, (double)kf.cx, (double)kf.cy};
         D->frame_intr.insert(D->frame_intr.end(), in, in + 4);
@@ -723,7 +752,7 @@ iba_status iba_dataset_load_ba(const iba_dataset_paths* P, int32_t global, iba_b
             const int oc = kf.octave[kp];
             if (oc < 0 || oc >= (int)kf.inv_level_sigma2.size()) { delete D; return io_fail(IBA_ERR_IO, kf.file + ": keypoint octave outside mvInvLevelSigma2"); }
             const float* Xw = it->second.data();
-            for (int r = 0; r < 3; ++r) {   // Tc0w.R * Xw + Tc0w.t in CV_32F (Optimizer.cc:1661-1665)
+            for (int r = 0; r < 3; ++r) {   // T.R * Xw + T.t in CV_32F, T = Tc0w (Global, :1661-1665) or T_old_w (Local, :1493-1497)
                 const float t = (T0[r * 4 + 0] * Xw[0] + T0[r * 4 + 1] * Xw[1]) + T0[r * 4 + 2] * Xw[2];
                 D->edge_Xw.push_back((double)(t + T0[r * 4 + 3]));
             }

@@ -149,13 +149,15 @@ def test_ba_edge_list_from_directory(tmp_path, scene):
     assert np.allclose(got.frame_Tlw6, ref["frame_Tlw6"], rtol=0, atol=1e-12)               # quaternion route vs scipy's as_rotvec
     n_mp = sum(len(m) for m in meta["mp2kp"])
     assert len(got.edge_frame) == n_mp and got.edge_slot.max() < 300
+    # Local variant: MapPoints in the frame of the oldest of the 20 best covisible keyframes, LiDAR pose relative to it. The
+    # reference indexes its pose list with that keyframe's mnId, so it only works on maps whose keyframe ids are 0..F-1.
     with pytest.raises(pkg.IbaError):
-        lib = pkg.load_library()
-        fmt._lib()
-        import ctypes as C
-        p = fmt.IbaDatasetPaths(*[str(paths[k]).encode() for k in ("frame_id_file", "lidar_pose_file", "pointcloud_dir", "keyframe_dir", "map_file")], 1, 0, 3, 100)
-        h = C.c_void_p()
-        lib.iba_dataset_load_ba.argtypes = [C.POINTER(fmt.IbaDatasetPaths), C.c_int32, C.POINTER(C.c_void_p)]
-        st = lib.iba_dataset_load_ba(C.byref(p), 0, C.byref(h))        # the Local variant is reported as unsupported, not faked
-        if st != 0:
-            raise pkg.IbaError(st, lib.iba_io_last_error().decode())
+        ba.load_ba_dataset(**paths, global_variant=False)
+    paths2 = ofmt.write_dataset(str(tmp_path / "contig"), prob, meta, contiguous_ids=True)
+    got = ba.load_ba_dataset(**paths2, global_variant=False)
+    ref = ofmt.load_ba_edges(**paths2, global_variant=False)
+    for k in ("edge_frame", "edge_slot", "frame_intr", "edge_Xw", "edge_obs", "edge_info"):
+        assert np.array_equal(getattr(got, k).reshape(-1), ref[k].reshape(-1)), k
+    assert np.allclose(got.frame_Tlw6, ref["frame_Tlw6"], rtol=0, atol=1e-10)
+    glob = ba.load_ba_dataset(**paths2, global_variant=True)
+    assert not np.array_equal(got.edge_Xw, glob.edge_Xw) and np.array_equal(got.edge_obs, glob.edge_obs)
