@@ -25,7 +25,7 @@ struct TreeNode { float split; uint32_t dim; };
 
 inline uint32_t tree_depth_for(uint32_t P) {
     uint32_t D = 0;
-    while ((P >> D) > (uint32_t)kLeafTarget) ++D;   // leaf size = ceil(P / 2^D) <= kLeafTarget
+    while ((P >> D) > (uint32_t)kLeafTarget && D < (uint32_t)kMaxTreeDepth) ++D;   // leaf size = ceil(P / 2^D) <= kLeafTarget up to the depth cap
     return D;
 }
 

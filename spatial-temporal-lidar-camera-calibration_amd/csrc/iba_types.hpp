@@ -28,6 +28,12 @@ constexpr int kThreads = IBA_THREADS;
 #ifndef IBA_LEAF_TARGET
 #define IBA_LEAF_TARGET 24
 #endif
+#ifndef IBA_MAX_TREE_DEPTH
+#define IBA_MAX_TREE_DEPTH 11
+#endif
+// the node table (8 B x 2^D) lives in LDS; beyond depth 11 (16 KB) it would push a block over half of the LDS and cost
+// the second resident block, so larger scans get larger leaves instead (60 k points: 30 per leaf, 120 k: 59)
+constexpr int kMaxTreeDepth = IBA_MAX_TREE_DEPTH;
 constexpr int kLeafTarget = IBA_LEAF_TARGET;      // max points per kd-tree leaf
 
 // partial-sum block layout (all doubles; counters < 2^53 carried exactly)

@@ -111,7 +111,7 @@ def test_c3_three_trajectories_four_shards(pkg, synth, abi, c2):
 def test_kitti_sized_scans(pkg, synth, abi, ob):
     """Raw KITTI scans are ~120 k points (~60 k with PointCloudOnlyPositiveX): deeper kd-trees (D = 12), candidate queues and
     work lists several times longer than at the bench shape. Cost tuple and normal equations vs the oracle."""
-    prob, meta = synth.make_scene(n_frames=3, pts_per_frame=60000, seed=8)
+    prob, meta = synth.make_scene(n_frames=3, pts_per_frame=60000, seed=8)   # depth-capped tree: 30 points per leaf
     p = abi.reference_yaml_params()
     h = pkg.IbaHandle(prob, p)
     xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(8), n=2)])
@@ -127,4 +127,24 @@ def test_kitti_sized_scans(pkg, synth, abi, ob):
         gk, gp = h.correspondences(xs[1], f)
         ok, op = orc.correspondences(p, xs[1], f)
         assert np.array_equal(gk, ok) and np.array_equal(gp, op)
+    h.close()
+
+
+def test_raw_kitti_sweep_size(pkg, synth, abi, ob):
+    """120 k points per scan: the kd-tree hits its depth cap (59 points per leaf), the candidate queue and the culling list
+    are at their largest."""
+    prob, meta = synth.make_scene(n_frames=2, pts_per_frame=120000, seed=9)
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(prob, p)
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(9), n=1)])
+    cost, nrm = h.eval_full(xs)
+    orc = ob.Oracle(prob)
+    for a, b in zip(cost, orc.eval_cost(p, xs)):
+        _cmp_cost(a, b)
+    for a, b in zip(nrm, orc.eval_normal(p, xs)):
+        assert a.counts() == b.counts()
+        assert np.allclose(a.H_np(), b.H_np(), rtol=1e-9, atol=1e-9 * np.abs(b.H_np()).max())
+    h.set_params(abi.reference_yaml_params(plane_cache=0))     # refit path on the same scans
+    c0 = h.eval_cost(xs[:1])[0]
+    assert c0.n_corr == cost[0].n_corr and c0.valid_pl_3d_3d == cost[0].valid_pl_3d_3d and abs(c0.f2 - cost[0].f2) <= 1e-12 * cost[0].f2
     h.close()
