@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
     const bool overflow = s_misc[1] != 0u;
     // the first kHitSlots queue entries of each lane keep their (<= 2) hits in registers, so the tie pass needs no second
     // grid walk; later entries (queue longer than kHitSlots blocks) take the re-walk path
-    constexpr int kHitSlots = kThreads >= 1024 ? 2 : 3;   // ~1100 queued points per block at the C2 shape
+    constexpr int kHitSlots = kThreads >= 1024 ? 2 : (kThreads >= 512 ? 3 : 4);   // ~1100 queued points per block at the C2 shape
     Hits hh[kHitSlots];
     bool redo = false;
 #pragma unroll
