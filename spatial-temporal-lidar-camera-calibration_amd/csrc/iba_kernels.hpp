@@ -1,19 +1,23 @@
 // CDNA4 (gfx950) kernels of the IBA cross-modality evaluation path. Written for wave64 / 160 KB LDS.
 //
-// iba_frame_kernel: ONE workgroup (16 waves) evaluates ONE keyframe for ONE candidate extrinsic,
-// start to finish, with the whole scan (<= ~10.9k points as float32 SoA), the scan's kd-tree nodes,
-// the keypoint reject-bitmap and the per-keypoint 1-NN slots resident in LDS:
-//   phase 1  K1+K2+K3: stream the scan (16 B/lane coalesced), Tcl*p, pinhole project, FOV cull,
-//            look the pixel up in the static keypoint grid, ds_min_u64 on the keypoint's best d^2
-//            (replaces TransformPointCloud + the per-evaluation KDTree2D rebuild + 1-NN queries,
-//            pointcloud.h:82-86, iba_global.cpp:55-96)
-//   phase 2  exact tie resolution (lowest original point index) for the few points that hit
-//   phase 3  corrset size test (iba_global.cpp:203)
-//   phase 4  K6: covisible reprojection residuals (iba_global.cpp:291-328);
-//            K4+K5: MapPoint -> LiDAR frame, stackless 1-NN in the LDS-resident tree, local plane
-//            (memoised per scan point, or refitted per evaluation) (iba_global.cpp:223-252, 111-156);
-//            K7: hand-eye term (iba_global.cpp:264-276)
-//   phase 5  K8: fixed-order wave/block reduction -> one partial record per (candidate, frame)
+// iba_frame_kernel: ONE workgroup (kThreads = 512: 8 waves, two workgroups per CU) evaluates ONE keyframe for ONE
+// candidate extrinsic, start to finish. The scan's kd-tree nodes, the keypoint reject-bitmap, the coarse keypoint CSR,
+// the per-keypoint 1-NN slots, the candidate queue and the work lists live in LDS; the scan itself (float32 SoA in kd
+// leaf order) is read through the XCD's L2, which all candidates of a frame share (see iba_types.hpp / DESIGN.md 5):
+//   phase 0.5 conservative frustum test of static 64-point chunk boxes -> compacted list of visible chunks
+//   phase 1a  stream the visible chunks (16 B/lane), project in float32, test one bit of the dilated reject bitmap,
+//             queue the ~10 % that may match
+//   phase 1b  K1+K2+K3 exact: Tcl*p, pinhole projection, FOV test in f64, lookup in the static keypoint grid,
+//             ds_min_u64 on the keypoint's best d^2 (replaces TransformPointCloud + the per-evaluation KDTree2D
+//             rebuild + 1-NN queries, pointcloud.h:82-86, iba_global.cpp:55-96)
+//   phase 2   exact tie resolution (lowest original point index) for the few points that hit
+//   phase 3   corrset size test (iba_global.cpp:203, iba_local.cpp:192)
+//   phase 4   K6: covisible reprojection residuals (iba_global.cpp:291-328);
+//             K4+K5: MapPoint -> LiDAR frame, exact 1-NN by a resumable float32-conservative walk of the LDS-resident
+//             tree with exact leaf scans, local plane (memoised per scan point, or refitted per evaluation)
+//             (iba_global.cpp:223-252, 111-156; iba_local.cpp:207-300); K7: hand-eye term (iba_global.cpp:264-276)
+//   phase 5   K8: fixed-order wave/block reduction -> one partial record per (candidate, frame); in the fused mode also
+//             the dense residual-block list iba_factor_kernel consumes
 // iba_reduce_kernel sums the records over frames in a fixed order (bitwise reproducible).
 // iba_plane_kernel: wave-per-query kNN(<=32)+covariance+closed-form eigen = the x-independent part of
 // ComputeAlignmentDist / ComputeLocalNeighbor / ComputeLocalNormalSingleThre.
