@@ -175,10 +175,10 @@ bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
     const uint32_t entry = with_scan ? 2u : 4u;
     uint32_t want = std::max<uint32_t>(h->maxPpad / 2u, 512u) * entry;
     const uint32_t avail = (kLdsBytes - off) & ~15u;
-    // Two blocks per CU are worth more than a queue nobody fills: at 2000 keypoints ~11 % of a scan survives the pre-cull.
-    // If half of the LDS still leaves room for 10 % of the points, stop there (60 k-point scans: 1.55 -> 2 blocks per CU).
+    // Two blocks per CU are worth more than a queue nobody fills: at 2000 keypoints ~4 % of a scan survives the pre-cull
+    // (2-px reject bitmap). If half of the LDS still leaves room for 1/16 of the points, stop there.
     const uint32_t half = kLdsBytes / 2u;
-    if (!with_scan && off < half && (half - off) / entry >= std::max<uint32_t>(h->maxPpad / 10u, 512u)) want = std::min(want, (half - off) & ~15u);
+    if (!with_scan && off < half && (half - off) / entry >= std::max<uint32_t>(h->maxPpad / 16u, 512u)) want = std::min(want, (half - off) & ~15u);
     if (const char* e = std::getenv("IBA_CAND_BYTES")) want = (uint32_t)std::atoi(e);   // diagnostic
     const uint32_t bytes = std::min(want, avail);
     L.cand_cap = bytes / entry;

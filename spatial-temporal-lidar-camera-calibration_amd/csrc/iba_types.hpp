@@ -14,9 +14,9 @@ constexpr int kChunk = 64;           // points per culling chunk (~3 kd leaves):
 constexpr int kMaxCovis = 10;        // IBAPlaneEdge pads to 10 covisible KFs (IBACalib.hpp:133-137)
 constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum block
 #ifndef IBA_GRID_CELL
-#define IBA_GRID_CELL 4
+#define IBA_GRID_CELL 2
 #endif
-constexpr int kGridCell = IBA_GRID_CELL;   // cell of the 1-bit reject bitmap (px)
+constexpr int kGridCell = IBA_GRID_CELL;   // cell of the 1-bit reject bitmap (px): 2 px = 15 KB of LDS at 1241x376, ~4 % of a scan queued (4 px: 4 KB, 11 %)
 constexpr int kCoarseShift = kGridCell == 1 ? 4 : (kGridCell == 2 ? 3 : 2);   // CSR cells stay 16 px: coarse = fine >> kCoarseShift
 #ifndef IBA_THREADS
 #define IBA_THREADS 512
