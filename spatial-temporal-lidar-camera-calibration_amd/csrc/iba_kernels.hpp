@@ -483,6 +483,9 @@ constexpr int kPathMax = 16;   // deeper trees (> 1.5 M points per scan) use the
 #ifndef IBA_LEAF_UNROLL
 #define IBA_LEAF_UNROLL 1
 #endif
+#ifndef IBA_HIT_SLOTS
+#define IBA_HIT_SLOTS 3
+#endif
 #ifndef IBA_LEAF_BATCH
 #define IBA_LEAF_BATCH 1   /* leaf-scan steps whose loads are issued together (2: no gain, 4+: register spills) */
 #endif
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
     const bool overflow = s_misc[1] != 0u;
     // the first kHitSlots queue entries of each lane keep their (<= 2) hits in registers, so the tie pass needs no second
     // grid walk; later entries (queue longer than kHitSlots blocks) take the re-walk path
-    constexpr int kHitSlots = kThreads >= 1024 ? 2 : (kThreads >= 512 ? 3 : 4);   // ~1100 queued points per block at the C2 shape
+    constexpr int kHitSlots = IBA_HIT_SLOTS;   // ~400 queued points per block at the C2 shape (2-px reject bitmap)
     Hits hh[kHitSlots];
     bool redo = false;
 #pragma unroll
