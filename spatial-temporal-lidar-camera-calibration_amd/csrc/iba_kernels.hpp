@@ -1168,6 +1168,88 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         __syncthreads();
     };
 
+    // ---- exact 1-NN of a work list in rounds (nn_dual_step). Round 0: every item descends and scans its first leaf —
+    // uniform work, and 72 % of the queries end there. The unfinished ones park 64 B of state in LDS (the keypoint grid's and
+    // the candidate queue's storage, dead by now) and are re-spread over the block with more lanes each; a round visits
+    // one more leaf per query until few enough are left to run to the end. Slot order is irrelevant (results go to
+    // per-item arrays), so the compaction is one LDS atomic per unfinished query.
+    //   load(i, actA, actC, ax, ay, az, qx, qy, qz): which queries item i has, and their coordinates
+    //   store(i, actA, actC, st): the finished search of item i
+    struct HardState { double a[3], c[3]; uint32_t item_go, leaf_done, bposA, bposC; };   // item | go << 24 | actA << 30 | actC << 31
+    auto nn_rounds = [&](auto which_tag, uint32_t n_list, auto&& load, auto&& store) {
+        constexpr int WHICH = decltype(which_tag)::value;
+        HardState* s_hard = (HardState*)(smem + lay.off_bitmap);
+        const uint32_t cap_hard = min((lay.total - lay.off_bitmap) / (uint32_t)sizeof(HardState), (uint32_t)kThreads);   // <= one pass per round
+        uint32_t n_items = n_list; bool fresh = true; int round = 0;
+        for (;;) {
+            int G;
+            if (fresh) {
+                // lanes per query of the first round: as many as fit (a second pass for a few items over a power-of-two
+                // boundary was measured and is slower than half the lanes for everybody)
+                const uint32_t slack = (uint32_t)IBA_NN_G_SLACK;
+                G = (IBA_NN_FRESH_GMAX >= 8 && n_items * 8u <= (uint32_t)kThreads + 8u * slack) ? 8 : ((IBA_NN_FRESH_GMAX >= 4 && n_items * 4u <= (uint32_t)kThreads + 4u * slack) ? 4 : ((IBA_NN_FRESH_GMAX >= 2 && n_items * 2u <= (uint32_t)kThreads + 2u * slack) ? 2 : 1));
+            }
+            else { G = IBA_NN_RESUME_GMAX; while ((uint32_t)G * n_items > (uint32_t)kThreads) G >>= 1; }
+            const uint32_t per_it = (uint32_t)kThreads / (uint32_t)G;
+            uint32_t* cnt = s_misc + 2 + (round & 1);
+            if (tid == 0) *cnt = 0u;
+            __syncthreads();
+            for (uint32_t base = 0; base < n_items; base += per_it) {
+                const uint32_t e = base + (uint32_t)tid / (uint32_t)G;
+                uint32_t i = e; bool actA = false, actC = false;
+                double ax = NAN, ay = NAN, az = NAN, qx = NAN, qy = NAN, qz = NAN;   // an absent query has NaN coordinates (nn_dual_step)
+                DualNN st; st.bestA = INFINITY; st.bestC = INFINITY; st.bposA = kNone; st.bposC = kNone; st.leaf = 0u; st.done = 0u; st.go = -1;
+                if (e < n_items) {
+                    if (fresh) {
+                        load(i, actA, actC, ax, ay, az, qx, qy, qz);
+                        if (!actA) { ax = NAN; ay = NAN; az = NAN; }
+                        if (!actC) { qx = NAN; qy = NAN; qz = NAN; }
+                    } else {
+                        const HardState hs = s_hard[e];
+                        i = hs.item_go & 0xffffffu; st.go = (int)((hs.item_go >> 24) & 31u); actA = (hs.item_go >> 30) & 1u; actC = hs.item_go >> 31;
+                        st.leaf = hs.leaf_done & 0xffffu; st.done = hs.leaf_done >> 16; st.bposA = hs.bposA; st.bposC = hs.bposC;
+                        ax = hs.a[0]; ay = hs.a[1]; az = hs.a[2]; qx = hs.c[0]; qy = hs.c[1]; qz = hs.c[2];
+                        // the running bests are the exact distances of the stored positions (same expression as the leaf scan)
+                        if (st.bposA != kNone) { const double dx = ax - (double)c.xs[st.bposA], dy = ay - (double)c.ys[st.bposA], dz = az - (double)c.zs[st.bposA]; st.bestA = (dx * dx + dy * dy) + dz * dz; }
+                        if (st.bposC != kNone) { const double dx = qx - (double)c.xs[st.bposC], dy = qy - (double)c.ys[st.bposC], dz = qz - (double)c.zs[st.bposC]; st.bestC = (dx * dx + dy * dy) + dz * dz; }
+                    }
+                }
+                __syncthreads();   // every state of this pass is in registers: its slot may be overwritten
+                if (e < n_items) {
+                    if (actA || actC) {
+                        bool fr = fresh, to_end = kNNToEnd || (!fresh && n_items <= (uint32_t)kNNEndAt);
+                        for (;;) {
+                            const bool more = nn_dual_step<WHICH>(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, st, fr, to_end);
+                            if (!more) break;
+                            uint32_t slot = 0u;
+                            if ((tid & (G - 1)) == 0) slot = atomicAdd(cnt, 1u);
+                            slot = __shfl(slot, lane & ~(G - 1));
+                            if (slot < cap_hard) {   // park: one more leaf next round
+                                if ((tid & (G - 1)) == 0) {
+                                    HardState hs; hs.a[0] = ax; hs.a[1] = ay; hs.a[2] = az; hs.c[0] = qx; hs.c[1] = qy; hs.c[2] = qz;
+                                    hs.item_go = i | ((uint32_t)st.go << 24) | ((actA ? 1u : 0u) << 30) | ((actC ? 1u : 0u) << 31);
+                                    hs.leaf_done = st.leaf | (st.done << 16); hs.bposA = st.bposA; hs.bposC = st.bposC;
+                                    s_hard[slot] = hs;
+                                }
+                                i = kNone;
+                                break;
+                            }
+                            fr = false; to_end = true;   // no room to park it: finish right here
+                        }
+                    }
+                    if (i != kNone && (tid & (G - 1)) == 0) store(i, actA, actC, st);
+                }
+                __syncthreads();
+            }
+            n_items = min(*cnt, cap_hard);
+#ifdef IBA_STOP_NN_ROUND
+            if (round == IBA_STOP_NN_ROUND) return;   // diagnostic (fused mode): time attribution
+#endif
+            if (n_items == 0u) break;
+            fresh = false; ++round;
+        }
+    };
+
     if (MODE == MODE_BOTH) {
         // ================= fused BAError + BuildProblem association: one work list, one kd traversal per MapPoint =================
         // (the dense per-keypoint association rows are not written in this mode: the factor kernel is fed by the block list)
@@ -1262,119 +1344,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
             qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
         };
-        // Rounds (nn_dual_step). Round 0: every MapPoint descends and scans its first leaf — uniform work, and 72 % of
-        // the queries end there. The unfinished ones park 64 B of state in LDS (the keypoint grid's and the candidate
-        // queue's storage, dead by now) and are re-spread over the block with more lanes each; a round visits one more
-        // leaf per query until few enough are left to run to the end. Slot order is irrelevant (results go to the
-        // per-item arrays), so the compaction is one LDS atomic per unfinished query.
-        struct HardState { double a[3], c[3]; uint32_t item_go, leaf_done, bposA, bposC; };   // item | go << 24 | actA << 30 | actC << 31
-        HardState* s_hard = (HardState*)(smem + lay.off_bitmap);
-        const uint32_t cap_hard = min((lay.total - lay.off_bitmap) / (uint32_t)sizeof(HardState), (uint32_t)kThreads);   // <= one pass per round
-        uint32_t n_items = n3; bool fresh = true; int round = 0;
-        for (;;) {
-            int G;
-            if (fresh) {
-                // lanes per query of the first round: as many as fit; a handful of items over a power-of-two boundary
-                // are cheaper as a short second pass than as half the lanes for everybody
-                const uint32_t slack = (uint32_t)IBA_NN_G_SLACK;
-                G = (IBA_NN_FRESH_GMAX >= 8 && n_items * 8u <= (uint32_t)kThreads + 8u * slack) ? 8 : ((IBA_NN_FRESH_GMAX >= 4 && n_items * 4u <= (uint32_t)kThreads + 4u * slack) ? 4 : ((IBA_NN_FRESH_GMAX >= 2 && n_items * 2u <= (uint32_t)kThreads + 2u * slack) ? 2 : 1));
-            }
-            else { G = IBA_NN_RESUME_GMAX; while ((uint32_t)G * n_items > (uint32_t)kThreads) G >>= 1; }
-            const uint32_t per_it = (uint32_t)kThreads / (uint32_t)G;
-            uint32_t* cnt = s_misc + 2 + (round & 1);
-            if (tid == 0) *cnt = 0u;
-#ifdef IBA_STAMPS_FINE
-            const unsigned long long dbg_t0 = __builtin_readcyclecounter();
-            if (tid == 0) { const int rr = round < 7 ? round : 7; atomicAdd(&g_dbg[8 + rr], (unsigned long long)n_items); atomicAdd(&g_dbg[24 + rr], 1ull); }
-#endif
-            __syncthreads();
-            for (uint32_t base = 0; base < n_items; base += per_it) {
-                const uint32_t e = base + (uint32_t)tid / (uint32_t)G;
-                uint32_t i = e; bool actA = false, actC = false;
-                double ax = 0, ay = 0, az = 0, qx = 0, qy = 0, qz = 0;
-                DualNN st; st.bestA = INFINITY; st.bestC = INFINITY; st.bposA = kNone; st.bposC = kNone; st.leaf = 0u; st.done = 0u; st.go = -1;
-#ifdef IBA_STAMPS_FINE
-                st.visits = 0u;
-#endif
-                if (e < n_items) {
-                    if (fresh) {
-                        const uint32_t k = s_list[i] & 0xffffu;
-                        actA = s_nnA[i] != kNone;
-                        actC = usedC && prm.use_3d3d && ((s_list[i] >> 16) & 1u);
-                        if (actA || actC) queries(k, ax, ay, az, qx, qy, qz);
-                        if (!actA) { ax = NAN; ay = NAN; az = NAN; }   // nn_dual_step: every compare of an inactive query is false
-                        if (!actC) { qx = NAN; qy = NAN; qz = NAN; }
-                    } else {
-                        const HardState hs = s_hard[e];
-                        i = hs.item_go & 0xffffffu; st.go = (int)((hs.item_go >> 24) & 31u); actA = (hs.item_go >> 30) & 1u; actC = hs.item_go >> 31;
-                        st.leaf = hs.leaf_done & 0xffffu; st.done = hs.leaf_done >> 16; st.bposA = hs.bposA; st.bposC = hs.bposC;
-                        ax = hs.a[0]; ay = hs.a[1]; az = hs.a[2]; qx = hs.c[0]; qy = hs.c[1]; qz = hs.c[2];
-                        // the running bests are the exact distances of the stored positions (same expression as the leaf scan)
-                        if (st.bposA != kNone) { const double dx = ax - (double)c.xs[st.bposA], dy = ay - (double)c.ys[st.bposA], dz = az - (double)c.zs[st.bposA]; st.bestA = (dx * dx + dy * dy) + dz * dz; }
-                        if (st.bposC != kNone) { const double dx = qx - (double)c.xs[st.bposC], dy = qy - (double)c.ys[st.bposC], dz = qz - (double)c.zs[st.bposC]; st.bestC = (dx * dx + dy * dy) + dz * dz; }
-                    }
-                }
-                __syncthreads();   // every state of this pass is in registers: its slot may be overwritten
-#ifdef IBA_STAMPS_FINE
-                const unsigned long long rt0 = __builtin_readcyclecounter(); unsigned long long rt1 = rt0, rt2 = rt0;
-#endif
-                if (e < n_items) {
-                    if (actA || actC) {
-                        bool fr = fresh, to_end = kNNToEnd || (!fresh && n_items <= (uint32_t)kNNEndAt);
-#ifdef IBA_STAMPS_FINE
-                        rt1 = __builtin_readcyclecounter();
-#endif
-                        for (;;) {
-                            const bool more = nn_dual_step<3>(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, st, fr, to_end);
-                            if (!more) break;
-                            uint32_t slot = 0u;
-                            if ((tid & (G - 1)) == 0) slot = atomicAdd(cnt, 1u);
-                            slot = __shfl(slot, lane & ~(G - 1));
-                            if (slot < cap_hard) {   // park: one more leaf next round
-                                if ((tid & (G - 1)) == 0) {
-                                    HardState hs; hs.a[0] = ax; hs.a[1] = ay; hs.a[2] = az; hs.c[0] = qx; hs.c[1] = qy; hs.c[2] = qz;
-                                    hs.item_go = i | ((uint32_t)st.go << 24) | ((actA ? 1u : 0u) << 30) | ((actC ? 1u : 0u) << 31);
-                                    hs.leaf_done = st.leaf | (st.done << 16); hs.bposA = st.bposA; hs.bposC = st.bposC;
-                                    s_hard[slot] = hs;
-                                }
-                                i = kNone;
-                                break;
-                            }
-                            fr = false; to_end = true;   // no room to park it: finish right here
-                        }
-                    }
-#ifdef IBA_STAMPS_FINE
-                    if (kNNToEnd && (tid & (G - 1)) == 0 && (actA || actC)) {
-                        const uint32_t v = st.visits; const int bin = v <= 4 ? (int)v - 1 : (v <= 8 ? 4 : (v <= 16 ? 5 : (v <= 32 ? 6 : 7)));
-                        atomicAdd(&g_dbg[40 + bin], 1ull); atomicAdd(&g_dbg[6], (unsigned long long)v); atomicMax(&s_misc[1], v);
-                    }
-#endif
-                    if (i != kNone && (tid & (G - 1)) == 0) {
-                        // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
-                        s_nnC[i] = actC ? st.bposC : kNone;
-                        s_nnA[i] = (actA && !(st.bestA > prm.max_3d_dist2)) ? st.bposA : kNone;
-                    }
-                }
-#ifdef IBA_STAMPS_FINE
-                rt2 = __builtin_readcyclecounter();
-                __syncthreads();
-                if (tid == 0) { const int o = fresh ? 32 : 36; atomicAdd(&g_dbg[o], rt1 - rt0); atomicAdd(&g_dbg[o + 1], rt2 - rt1); atomicAdd(&g_dbg[o + 2], __builtin_readcyclecounter() - rt2); atomicAdd(&g_dbg[o + 3], 1ull); }
-#endif
-                __syncthreads();
-            }
-            n_items = min(*cnt, cap_hard);
-#ifdef IBA_STOP_NN_ROUND
-            if (round == IBA_STOP_NN_ROUND) return;   // diagnostic: time attribution
-#endif
-#ifdef IBA_STAMPS_FINE
-            if (tid == 0) { const int rr = round < 7 ? round : 7; atomicAdd(&g_dbg[16 + rr], __builtin_readcyclecounter() - dbg_t0); }
-#endif
-#ifdef IBA_STAMPS_FINE
-            if (kNNToEnd && tid == 0) { const uint32_t v = s_misc[1]; const int bin = v <= 4 ? (int)v - 1 : (v <= 8 ? 4 : (v <= 16 ? 5 : (v <= 32 ? 6 : 7))); atomicAdd(&g_dbg[56 + (v ? bin : 0)], 1ull); atomicAdd(&g_dbg[7], (unsigned long long)v); }
-#endif
-            if (n_items == 0u) break;
-            fresh = false; ++round;
-        }
+        nn_rounds(std::integral_constant<int, 3>(), n3,
+            [&](uint32_t i, bool& actA, bool& actC, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
+                actA = s_nnA[i] != kNone;
+                actC = usedC && prm.use_3d3d && ((s_list[i] >> 16) & 1u);
+                if (actA || actC) queries(s_list[i] & 0xffffu, ax, ay, az, qx, qy, qz);
+            },
+            [&](uint32_t i, bool actA, bool actC, const DualNN& st) {
+                s_nnC[i] = actC ? st.bposC : kNone;
+                s_nnA[i] = (actA && !(st.bestA > prm.max_3d_dist2)) ? st.bposA : kNone;   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
+            });
         __syncthreads();
         IBA_STAMP(5);
         if (!cached) {
@@ -1496,16 +1475,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             qy = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
             qz = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
         };
-        {
-            const int G = n3 * 8u <= (uint32_t)kThreads ? 8 : (n3 * 4u <= (uint32_t)kThreads ? 4 : (n3 * 2u <= (uint32_t)kThreads ? 2 : 1));
-            for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
-                if (s_bpos[i] == kNone) continue;   // uniform within the lane group
-                double qx, qy, qz; q_assoc(s_list[i], qx, qy, qz);
-                DualNN st; st.bestA = INFINITY; st.bestC = INFINITY; st.bposA = kNone; st.bposC = kNone; st.leaf = 0u; st.done = 0u; st.go = -1;
-                nn_dual_step<1>(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, true, qx, qy, qz, false, 0.0, 0.0, 0.0, st, true, true);
-                if ((tid & (G - 1)) == 0) s_bpos[i] = (st.bestA > prm.max_3d_dist2) ? kNone : st.bposA;   // :289
-            }
-        }
+        nn_rounds(std::integral_constant<int, 1>(), n3,
+            [&](uint32_t i, bool& actA, bool& actC, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
+                actA = s_bpos[i] != kNone; actC = false;
+                if (actA) q_assoc(s_list[i], ax, ay, az);
+            },
+            [&](uint32_t i, bool actA, bool actC, const DualNN& st) { s_bpos[i] = (actA && !(st.bestA > prm.max_3d_dist2)) ? st.bposA : kNone; });   // :289
         __syncthreads();
         if (!cached) fit_points(s_bpos, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
         for (uint32_t i = tid; i < n3; i += kThreads) {
@@ -1595,17 +1570,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
             qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
         };
-        {
-            const int G = n3 * 8u <= (uint32_t)kThreads ? 8 : (n3 * 4u <= (uint32_t)kThreads ? 4 : (n3 * 2u <= (uint32_t)kThreads ? 2 : 1));
-            for (uint32_t i = (uint32_t)tid / G; i < n3; i += kThreads / G) {
+        nn_rounds(std::integral_constant<int, 2>(), n3,
+            [&](uint32_t i, bool& actA, bool& actC, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
                 const uint32_t k = s_list[i];
-                if (!(((int)kp_mp[k].w) & 1)) { if ((tid & (G - 1)) == 0) s_bpos[i] = kNone; continue; }   // covisible match but no MapPoint
-                double qx, qy, qz; q_cost(k, qx, qy, qz);
-                DualNN st; st.bestA = INFINITY; st.bestC = INFINITY; st.bposA = kNone; st.bposC = kNone; st.leaf = 0u; st.done = 0u; st.go = -1;
-                nn_dual_step<2>(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, false, 0.0, 0.0, 0.0, true, qx, qy, qz, st, true, true);
-                if ((tid & (G - 1)) == 0) s_bpos[i] = st.bposC;
-            }
-        }
+                actA = false; actC = (((int)kp_mp[k].w) & 1) != 0;   // a covisible match without a MapPoint has no 3d-3d term
+                if (actC) q_cost(k, qx, qy, qz);
+            },
+            [&](uint32_t i, bool actA, bool actC, const DualNN& st) { s_bpos[i] = actC ? st.bposC : kNone; });
         __syncthreads();
         if (!cached && prm.use_plane) fit_points(s_bpos, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);   // iba_global.cpp:125-147
         for (uint32_t i = tid; i < n3; i += kThreads) {
