@@ -339,6 +339,13 @@ iba_status iba_handeye(const double* Ta12, const double* Tb12, int64_t n, double
 iba_status iba_handeye_robust(const double* Ta12, const double* Tb12, int64_t n, const double rigid12_init[12], double scale_init,
                               double robust_kernel_size, int32_t regulation, double regulation_ratio, int32_t iterations,
                               double rigid12[12], double* scale);
+/* HECalibLineProcessg2o (NLHECalib.hpp:189-277): the same residual without a robust kernel but with a per-pair scalar
+ * information w^2, w = mu / (mu + chi2), re-estimated between LM solves while mu anneals from mu0 by divid_factor until
+ * below min_mu or ex_max_iter outer rounds; the regulariser follows the sum of the weights. The reference ignores its
+ * in_max_iter argument and runs 10 inner iterations per solve: pass inner_iterations = 10 for its behaviour. */
+iba_status iba_handeye_lineprocess(const double* Ta12, const double* Tb12, int64_t n, const double rigid12_init[12], double scale_init,
+                                   int32_t inner_iterations, double mu0, double divid_factor, double min_mu, int32_t ex_max_iter,
+                                   int32_t regulation, double regulation_ratio, double rigid12[12], double* scale);
 
 /*
  * ---- ORB-only extrinsic bundle adjustment [SURVEY.md 8(f) row 4] ----

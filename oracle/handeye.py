@@ -3,7 +3,7 @@ csrc/iba_handeye.cpp (numpy's LAPACK SVD and solve instead of the hand-written J
 least_squares with a Huber loss instead of the hand-written LM). Only tests/ may import this.
 
 Restates HECalib (HECalib.h:12-57), pose2Motion (kitti_tools.h:160-165), the EdgeHE residual (NLHECalib.hpp:27-48) and the
-cost HECalibRobustKernelg2o minimises (:121-163). Eigen and g2o are absent from the image: PARITY WITH THEM IS UNPINNED;
+cost HECalibRobustKernelg2o minimises (:121-163) and the line-process annealing of HECalibLineProcessg2o (:189-277). Eigen and g2o are absent from the image: PARITY WITH THEM IS UNPINNED;
 what is pinned is agreement of two independent restatements and recovery of planted extrinsics."""
 import numpy as np
 from scipy.optimize import least_squares
@@ -83,3 +83,32 @@ def handeye_robust_minimum(Ta, Tb, rigid0, scale0, delta=0.1, regulation=True, r
 
     sol = least_squares(fun, x0, method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14)
     return sol.x, float(np.sum(sol.fun ** 2))
+
+
+def handeye_lineprocess(Ta, Tb, rigid0, scale0, mu0=64.0, divid_factor=1.4, min_mu=1e-1, ex_max_iter=20, regulation=True, ratio=0.005):
+    """HECalibLineProcessg2o's outer loop (NLHECalib.hpp:228-248) with every inner solve run to convergence by scipy:
+    weights w^2 = (mu / (mu + chi2))^2 with chi2 under the previous weights, regulariser information sum(w^2) * ratio."""
+    x = np.concatenate([rotvec(np.asarray(rigid0)[:3, :3]), np.asarray(rigid0)[:3, 3], [scale0]])
+    Ta, Tb = np.asarray(Ta, np.float64), np.asarray(Tb, np.float64)
+    n = len(Ta)
+    info = np.ones(n)
+
+    def solve(x0, info, reg_info):
+        def fun(xx):
+            r = (edge_residuals(xx, Ta, Tb) * np.sqrt(info)[:, None]).reshape(-1)
+            if regulation:
+                r = np.concatenate([r, np.sqrt(reg_info) * xx[3:6]])
+            return r
+        return least_squares(fun, x0, method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14).x
+
+    x = solve(x, info, n * ratio)
+    mu = mu0
+    for _ in range(ex_max_iter):
+        e2 = info * (edge_residuals(x, Ta, Tb) ** 2).sum(1)
+        w = mu / (mu + e2)
+        info = w * w
+        x = solve(x, info, info.sum() * ratio)
+        mu /= divid_factor
+        if mu < min_mu:
+            break
+    return x, info

@@ -15,6 +15,8 @@
 //    for a few hundred 3-vectors.)
 //  * HECalibRobustKernelg2o                NLHECalib.hpp:121-163   Huber(delta) on every pair, optional regulariser e = upsilon with
 //                                                                  information n * ratio, 10 iterations
+//  * HECalibLineProcessg2o                 NLHECalib.hpp:189-277   no kernel; per-pair information w^2, w = mu / (mu + chi2), re-estimated
+//                                                                  between solves while mu anneals (64 / 1.4 per round down to 0.1)
 // Third party that is absent: Eigen (AngleAxis::fromRotationMatrix goes through a quaternion; JacobiSVD) and g2o
 // (Dogleg + RobustKernelHuber). The SVD is a Jacobi eigen-decomposition of H^T H; the optimiser is Levenberg-Marquardt
 // with g2o's Huber weighting (rho'(e) applied to JtJ and Jtr). Same cost, not the same iterates: PARITY WITH g2o IS
@@ -163,6 +165,117 @@ void sim3_exp(const double* x, double* R, double* t, double* s) {
 
 }  // namespace
 
+namespace {
+
+// The nonlinear hand-eye problem on the 7-vector [rotation vector, translation (as upsilon), scale] shared by the
+// Huber-robust (NLHECalib.hpp:119-187) and the line-process (NLHECalib.hpp:189-277) refinements: EdgeHE residuals
+// (NLHECalib.hpp:31-49), the optional EdgeRegulation on the translation, and a Levenberg-Marquardt loop with g2o's
+// initial damping. The Jacobian is numerical: the reference's hand-written one (NLHECalib.hpp:51-66) differentiates
+// with respect to an increment that its oplus does not apply, so g2o's solver stalls on it; central differences of the
+// same residual reach the same minimum the reference is after.
+struct HeProblem {
+    const double* Ta12; const double* Tb12; int64_t n;
+    std::vector<double> alpha, beta;
+    HeProblem(const double* A, const double* B, int64_t n_) : Ta12(A), Tb12(B), n(n_), alpha(3 * (size_t)n_), beta(3 * (size_t)n_) {
+        for (int64_t i = 0; i < n; ++i) { rotvec_of(load(Ta12 + 12 * i).R, &alpha[3 * (size_t)i]); rotvec_of(load(Tb12 + 12 * i).R, &beta[3 * (size_t)i]); }
+    }
+    // initial vertex value (NLHECalib.hpp:131-137): rotation vector, translation AS upsilon, scale
+    static void init_vertex(const double rigid12_init[12], double scale_init, double x[7]) {
+        const double R0[9] = {rigid12_init[0], rigid12_init[1], rigid12_init[2], rigid12_init[4], rigid12_init[5], rigid12_init[6], rigid12_init[8], rigid12_init[9], rigid12_init[10]};
+        rotvec_of(R0, x);
+        x[3] = rigid12_init[3]; x[4] = rigid12_init[7]; x[5] = rigid12_init[11]; x[6] = scale_init;
+    }
+    static void store(const double x[7], double rigid12[12], double* scale) {
+        double R[9], t[3], s;
+        sim3_exp(x, R, t, &s);
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) rigid12[r * 4 + c] = R[r * 3 + c]; rigid12[r * 4 + 3] = t[r]; }
+        *scale = s;
+    }
+    // residuals of all pairs at x (3 per pair)
+    void residuals(const double* xx, std::vector<double>& e) const {
+        double R[9], t[3], s;
+        sim3_exp(xx, R, t, &s);
+        e.resize(3 * (size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            const Iso A = load(Ta12 + 12 * i), B = load(Tb12 + 12 * i);
+            double Rb[3], Rtb[3];
+            mat3_vec(R, &beta[3 * (size_t)i], Rb); mat3_vec(R, B.t, Rtb);
+            for (int r = 0; r < 3; ++r) {
+                const double tr = ((A.R[r * 3] - (r == 0)) * t[0] + (A.R[r * 3 + 1] - (r == 1)) * t[1]) + (A.R[r * 3 + 2] - (r == 2)) * t[2];
+                e[3 * (size_t)i + r] = (Rb[r] - alpha[3 * (size_t)i + r]) + ((tr + A.t[r] * s) - Rtb[r]);
+            }
+        }
+    }
+    // cost and (optionally) the normal equations at x. huber > 0: g2o RobustKernelHuber of that delta on every pair;
+    // info: per-pair scalar information (nullptr = 1).
+    double evaluate(const double* xx, double huber, const double* info, bool regulation, double reg_info, double* Hm, double* g) const {
+        std::vector<double> e;
+        residuals(xx, e);
+        std::vector<double> J;   // (3n) x 7, central differences
+        if (Hm) {
+            J.resize(21 * (size_t)n);
+            std::vector<double> ep, em;
+            for (int k = 0; k < 7; ++k) {
+                double xp[7], xm[7];
+                std::memcpy(xp, xx, sizeof(xp)); std::memcpy(xm, xx, sizeof(xm));
+                const double hstep = 1e-6 * std::max(1.0, std::fabs(xx[k]));
+                xp[k] += hstep; xm[k] -= hstep;
+                residuals(xp, ep); residuals(xm, em);
+                for (size_t r = 0; r < 3 * (size_t)n; ++r) J[r * 7 + k] = (ep[r] - em[r]) / (2 * hstep);
+            }
+            std::memset(Hm, 0, 49 * sizeof(double)); std::memset(g, 0, 7 * sizeof(double));
+        }
+        double cost = 0;
+        const double d = huber;
+        for (int64_t i = 0; i < n; ++i) {
+            const double* ei = &e[3 * (size_t)i];
+            const double om = info ? info[(size_t)i] : 1.0;
+            const double chi2 = om * (ei[0] * ei[0] + ei[1] * ei[1] + ei[2] * ei[2]);
+            double rho = chi2, w = 1.0;   // Huber on e2 = chi2: rho = e2 (e <= d) else 2 d sqrt(e2) - d^2; weight rho'
+            if (d > 0 && chi2 > d * d) { const double se = std::sqrt(chi2); rho = 2 * d * se - d * d; w = d / se; }
+            cost += rho;
+            if (Hm) {
+                const double* Ji = &J[21 * (size_t)i];
+                const double wo = w * om;
+                for (int p = 0; p < 7; ++p) {
+                    for (int r = 0; r < 3; ++r) g[p] += wo * Ji[r * 7 + p] * ei[r];
+                    for (int q = 0; q < 7; ++q) Hm[p * 7 + q] += wo * ((Ji[p] * Ji[q] + Ji[7 + p] * Ji[7 + q]) + Ji[14 + p] * Ji[14 + q]);
+                }
+            }
+        }
+        if (regulation) {   // EdgeRegulation: e = x[3:6] under information reg_info (NLHECalib.hpp:148-155)
+            for (int k = 0; k < 3; ++k) { cost += reg_info * xx[3 + k] * xx[3 + k]; if (Hm) { Hm[(3 + k) * 8] += reg_info; g[3 + k] += reg_info * xx[3 + k]; } }
+        }
+        return cost;
+    }
+    void lm(double x[7], double huber, const double* info, bool regulation, double reg_info, int iterations) const {
+        double lambda = -1.0;
+        double Hm[49], g[7];
+        double cost = evaluate(x, huber, info, regulation, reg_info, Hm, g);
+        for (int it = 0; it < std::max(iterations, 1); ++it) {
+            if (lambda < 0) { double mx = 0; for (int k = 0; k < 7; ++k) mx = std::max(mx, Hm[k * 8]); lambda = 1e-5 * mx; }   // g2o LM's initial damping
+            bool stepped = false;
+            for (int tries = 0; tries < 10 && !stepped; ++tries) {
+                double A[49], b[7], dx[7];
+                std::memcpy(A, Hm, sizeof(A));
+                for (int k = 0; k < 7; ++k) { A[k * 8] += lambda; b[k] = -g[k]; }
+                if (!solve_n(7, A, b, dx)) { lambda *= 10; continue; }
+                double xn[7];
+                for (int k = 0; k < 7; ++k) xn[k] = x[k] + dx[k];
+                const double cn = evaluate(xn, huber, info, regulation, reg_info, nullptr, nullptr);
+                if (cn < cost) { std::memcpy(x, xn, sizeof(double) * 7); lambda = std::max(lambda / 3.0, 1e-12); stepped = true; }
+                else lambda *= 4.0;
+            }
+            if (!stepped) break;
+            const double prev = cost;
+            cost = evaluate(x, huber, info, regulation, reg_info, Hm, g);
+            if (prev - cost <= 1e-14 * std::max(prev, 1e-300)) break;
+        }
+    }
+};
+
+}  // namespace
+
 extern "C" {
 
 iba_status iba_pose_to_motion(const double* poses12, int64_t n, double* motions12) {   // kitti_tools.h:160-165
@@ -219,95 +332,45 @@ iba_status iba_handeye_robust(const double* Ta12, const double* Tb12, int64_t n,
                               double robust_kernel_size, int32_t regulation, double regulation_ratio, int32_t iterations,
                               double rigid12[12], double* scale) {
     if (!Ta12 || !Tb12 || !rigid12_init || !rigid12 || !scale || n < 2 || !(robust_kernel_size > 0)) return IBA_ERR_INVALID_ARG;
+    HeProblem hp(Ta12, Tb12, n);
     double x[7];
-    {   // initial vertex value (NLHECalib.hpp:131-137): rotation vector, translation AS upsilon, scale
-        const double R0[9] = {rigid12_init[0], rigid12_init[1], rigid12_init[2], rigid12_init[4], rigid12_init[5], rigid12_init[6], rigid12_init[8], rigid12_init[9], rigid12_init[10]};
-        rotvec_of(R0, x);
-        x[3] = rigid12_init[3]; x[4] = rigid12_init[7]; x[5] = rigid12_init[11]; x[6] = scale_init;
-    }
-    std::vector<double> alpha(3 * (size_t)n), beta(3 * (size_t)n);
-    for (int64_t i = 0; i < n; ++i) { rotvec_of(load(Ta12 + 12 * i).R, &alpha[3 * (size_t)i]); rotvec_of(load(Tb12 + 12 * i).R, &beta[3 * (size_t)i]); }
+    hp.init_vertex(rigid12_init, scale_init, x);
     const double reg_info = regulation ? (double)n * regulation_ratio : 0.0;
-    // residuals of all pairs at x (3 per pair)
-    auto residuals = [&](const double* xx, std::vector<double>& e) {
-        double R[9], t[3], s;
-        sim3_exp(xx, R, t, &s);
-        e.resize(3 * (size_t)n);
-        for (int64_t i = 0; i < n; ++i) {
-            const Iso A = load(Ta12 + 12 * i), B = load(Tb12 + 12 * i);
-            double Rb[3], Rtb[3];
-            mat3_vec(R, &beta[3 * (size_t)i], Rb); mat3_vec(R, B.t, Rtb);
-            for (int r = 0; r < 3; ++r) {
-                const double tr = ((A.R[r * 3] - (r == 0)) * t[0] + (A.R[r * 3 + 1] - (r == 1)) * t[1]) + (A.R[r * 3 + 2] - (r == 2)) * t[2];
-                e[3 * (size_t)i + r] = (Rb[r] - alpha[3 * (size_t)i + r]) + ((tr + A.t[r] * s) - Rtb[r]);
-            }
-        }
-    };
-    // cost and (optionally) the robustified normal equations at x
-    auto evaluate = [&](const double* xx, double* Hm, double* g) {
+    hp.lm(x, robust_kernel_size, nullptr, regulation != 0, reg_info, iterations);
+    hp.store(x, rigid12, scale);
+    return IBA_OK;
+}
+
+iba_status iba_handeye_lineprocess(const double* Ta12, const double* Tb12, int64_t n, const double rigid12_init[12], double scale_init,
+                                   int32_t inner_iterations, double mu0, double divid_factor, double min_mu, int32_t ex_max_iter,
+                                   int32_t regulation, double regulation_ratio, double rigid12[12], double* scale) {
+    if (!Ta12 || !Tb12 || !rigid12_init || !rigid12 || !scale || n < 2 || !(mu0 > 0) || !(divid_factor > 1) || ex_max_iter < 0)
+        return IBA_ERR_INVALID_ARG;
+    HeProblem hp(Ta12, Tb12, n);
+    double x[7];
+    hp.init_vertex(rigid12_init, scale_init, x);
+    std::vector<double> info((size_t)n, 1.0);   // every edge starts at identity information (NLHECalib.hpp:213-218)
+    double reg_info = regulation ? (double)n * regulation_ratio : 0.0;
+    hp.lm(x, 0.0, info.data(), regulation != 0, reg_info, inner_iterations);
+    double mu = mu0;
+    for (int ex = 0; ex < ex_max_iter; ++ex) {   // NLHECalib.hpp:229-248
         std::vector<double> e;
-        residuals(xx, e);
-        std::vector<double> J;   // (3n) x 7, central differences
-        if (Hm) {
-            J.resize(21 * (size_t)n);
-            std::vector<double> ep, em;
-            for (int k = 0; k < 7; ++k) {
-                double xp[7], xm[7];
-                std::memcpy(xp, xx, sizeof(xp)); std::memcpy(xm, xx, sizeof(xm));
-                const double hstep = 1e-6 * std::max(1.0, std::fabs(xx[k]));
-                xp[k] += hstep; xm[k] -= hstep;
-                residuals(xp, ep); residuals(xm, em);
-                for (size_t r = 0; r < 3 * (size_t)n; ++r) J[r * 7 + k] = (ep[r] - em[r]) / (2 * hstep);
-            }
-            std::memset(Hm, 0, 49 * sizeof(double)); std::memset(g, 0, 7 * sizeof(double));
-        }
-        double cost = 0;
-        const double d = robust_kernel_size;
+        hp.residuals(x, e);
+        double total = 0;
         for (int64_t i = 0; i < n; ++i) {
             const double* ei = &e[3 * (size_t)i];
-            const double chi2 = ei[0] * ei[0] + ei[1] * ei[1] + ei[2] * ei[2];
-            double rho, w;   // g2o RobustKernelHuber on e2 = chi2: rho = e2 (e <= d) else 2 d sqrt(e2) - d^2; weight rho'
-            if (chi2 <= d * d) { rho = chi2; w = 1.0; } else { const double se = std::sqrt(chi2); rho = 2 * d * se - d * d; w = d / se; }
-            cost += rho;
-            if (Hm) {
-                const double* Ji = &J[21 * (size_t)i];
-                for (int p = 0; p < 7; ++p) {
-                    for (int r = 0; r < 3; ++r) g[p] += w * Ji[r * 7 + p] * ei[r];
-                    for (int q = 0; q < 7; ++q) Hm[p * 7 + q] += w * ((Ji[p] * Ji[q] + Ji[7 + p] * Ji[7 + q]) + Ji[14 + p] * Ji[14 + q]);
-                }
-            }
+            // edge->chi2() is taken under the information of the PREVIOUS outer iteration (the reference never resets it)
+            const double e2 = info[(size_t)i] * (ei[0] * ei[0] + ei[1] * ei[1] + ei[2] * ei[2]);
+            const double w = mu / (mu + e2);
+            info[(size_t)i] = w * w;
+            total += w * w;
         }
-        if (regulation) {   // EdgeRegulation: e = x[3:6], information n * ratio (NLHECalib.hpp:148-155)
-            for (int k = 0; k < 3; ++k) { cost += reg_info * xx[3 + k] * xx[3 + k]; if (Hm) { Hm[(3 + k) * 8] += reg_info; g[3 + k] += reg_info * xx[3 + k]; } }
-        }
-        return cost;
-    };
-    double lambda = -1.0;
-    double Hm[49], g[7];
-    double cost = evaluate(x, Hm, g);
-    for (int it = 0; it < std::max(iterations, 1); ++it) {
-        if (lambda < 0) { double mx = 0; for (int k = 0; k < 7; ++k) mx = std::max(mx, Hm[k * 8]); lambda = 1e-5 * mx; }   // g2o LM's initial damping
-        bool stepped = false;
-        for (int tries = 0; tries < 10 && !stepped; ++tries) {
-            double A[49], b[7], dx[7];
-            std::memcpy(A, Hm, sizeof(A));
-            for (int k = 0; k < 7; ++k) { A[k * 8] += lambda; b[k] = -g[k]; }
-            if (!solve_n(7, A, b, dx)) { lambda *= 10; continue; }
-            double xn[7];
-            for (int k = 0; k < 7; ++k) xn[k] = x[k] + dx[k];
-            const double cn = evaluate(xn, nullptr, nullptr);
-            if (cn < cost) { std::memcpy(x, xn, sizeof(x)); lambda = std::max(lambda / 3.0, 1e-12); stepped = true; }
-            else lambda *= 4.0;
-        }
-        if (!stepped) break;
-        const double prev = cost;
-        cost = evaluate(x, Hm, g);
-        if (prev - cost <= 1e-14 * std::max(prev, 1e-300)) break;
+        if (regulation) reg_info = total * regulation_ratio;
+        hp.lm(x, 0.0, info.data(), regulation != 0, reg_info, inner_iterations);
+        mu /= divid_factor;
+        if (mu < min_mu) break;
     }
-    double R[9], t[3], s;
-    sim3_exp(x, R, t, &s);
-    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) rigid12[r * 4 + c] = R[r * 3 + c]; rigid12[r * 4 + 3] = t[r]; }
-    *scale = s;
+    hp.store(x, rigid12, scale);
     return IBA_OK;
 }
 

@@ -38,6 +38,9 @@ def _lib():
         L.iba_handeye.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.iba_handeye_robust.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int32,
                                          C.c_double, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.iba_handeye_lineprocess.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_double, C.c_int32,
+                                              C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double)]
         L._io_ready = True
     return L
 
@@ -181,4 +184,21 @@ def handeye_robust(Ta, Tb, rigid0, scale0, robust_kernel_size=0.1, regulation=Tr
                               int(iterations), _dp(r), C.byref(s))
     if st != 0:
         raise IbaError(st, "iba_handeye_robust")
+    return r.reshape(3, 4), s.value
+
+
+def handeye_lineprocess(Ta, Tb, rigid0, scale0, inner_iterations=10, mu0=64.0, divid_factor=1.4, min_mu=1e-1, ex_max_iter=20,
+                        regulation=True, regulation_ratio=0.005):
+    """HECalibLineProcessg2o (NLHECalib.hpp:189-277); inner_iterations=10 is what the reference runs whatever its
+    in_max_iter argument says."""
+    L = _lib()
+    A = np.ascontiguousarray(np.asarray(Ta, np.float64)[:, :3, :4]).reshape(-1, 12)
+    B = np.ascontiguousarray(np.asarray(Tb, np.float64)[:, :3, :4]).reshape(-1, 12)
+    r0 = np.ascontiguousarray(np.asarray(rigid0, np.float64)[:3, :4]).reshape(12)
+    r = np.zeros(12)
+    s = C.c_double(0)
+    st = L.iba_handeye_lineprocess(_dp(A), _dp(B), len(A), _dp(r0), float(scale0), int(inner_iterations), float(mu0), float(divid_factor),
+                                   float(min_mu), int(ex_max_iter), 1 if regulation else 0, float(regulation_ratio), _dp(r), C.byref(s))
+    if st != 0:
+        raise IbaError(st, "iba_handeye_lineprocess")
     return r.reshape(3, 4), s.value
