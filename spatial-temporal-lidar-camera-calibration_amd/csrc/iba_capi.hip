@@ -64,6 +64,7 @@ struct iba_handle {
 
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
     DevBuf<float> xs, ys, zs, chunk_box; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
+    DevBuf<float4> pts4;   // the same scan points as (x, y, z, original index bits): one 16 B gather per point where lanes diverge
     DevBuf<float2> kp_uv; DevBuf<float4> kp_mp;
     DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
@@ -96,7 +97,7 @@ struct iba_handle {
 
     DevProblem dev_problem() const {
         DevProblem dp{};
-        dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p; dp.chunk_box = chunk_box.p;
+        dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p; dp.chunk_box = chunk_box.p; dp.pts4 = pts4.p;
         dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.coarse_start = coarse_start.p; dp.crec = crec.p;
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
@@ -299,7 +300,7 @@ void iba_destroy(iba_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release();
+    h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
     h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
     if (h->h_cands) (void)hipHostFree(h->h_cands);
@@ -401,6 +402,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     const float qnan = std::numeric_limits<float>::quiet_NaN();
     std::vector<float> xs(pt_base, qnan), ys(pt_base, qnan), zs(pt_base, qnan);
     std::vector<uint32_t> perm(pt_base, 0u), inv_perm(pt_base, 0u);
+    std::vector<float4> pts4(pt_base, float4{qnan, qnan, qnan, 0.f});
     std::vector<float> chunk_box(6 * (size_t)box_base, qnan);
     std::vector<TreeNode> nodes(node_base);
     std::vector<float2> kp_uv(kp_base); std::vector<float4> kp_mp(kp_base), crec(kp_base);
@@ -416,6 +418,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
             const uint32_t o = b.idx[i];
             xs[x.pt_base + i] = src[3 * (size_t)o]; ys[x.pt_base + i] = src[3 * (size_t)o + 1]; zs[x.pt_base + i] = src[3 * (size_t)o + 2];
             perm[x.pt_base + i] = o; inv_perm[x.pt_base + o] = i;
+            float ob; std::memcpy(&ob, &o, 4);
+            pts4[x.pt_base + i] = float4{src[3 * (size_t)o], src[3 * (size_t)o + 1], src[3 * (size_t)o + 2], ob};
         }
         for (uint32_t c0 = 0; c0 < x.P; c0 += (uint32_t)kChunk) {   // static AABB of every kChunk consecutive tree positions
             float* bx = &chunk_box[6 * (size_t)(x.box_base + c0 / (uint32_t)kChunk)];
@@ -464,7 +468,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
 
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
 #define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
-    UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes); UP(chunk_box, chunk_box);
+    UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes); UP(chunk_box, chunk_box); UP(pts4, pts4);
     UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv);
 #undef UP
     hipError_t er;

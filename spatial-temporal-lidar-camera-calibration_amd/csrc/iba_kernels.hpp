@@ -42,6 +42,7 @@ struct DevProblem {
     const float* xs; const float* ys; const float* zs;
     const uint32_t* perm;      // tree position -> original point index
     const uint32_t* inv_perm;  // original point index -> tree position
+    const float4* pts4;        // the scan again as (x, y, z, original index bits) per tree position: divergent gathers take one 16 B load
     const float* chunk_box;    // [chunk][6]: min xyz, max xyz of kChunk consecutive tree positions (NaN padding ignored)
     const TreeNode* nodes;
     const float2* kp_uv;
@@ -384,6 +385,7 @@ __device__ inline void block_reduce(double* v, double* s_red /* (kWaves+1)*kRedS
 
 struct FrameCtx {   // wave-uniform per-block context
     const float* xs; const float* ys; const float* zs;   // LDS or HBM
+    const float4* p4;                                    // HBM (x, y, z, index bits) per tree position; nullptr when the scan is staged in LDS
     const TreeNode* nodes;                               // LDS
     const uint32_t* bitmap;                              // LDS
     unsigned long long* best_d2; uint32_t* best_idx;     // LDS
@@ -407,6 +409,19 @@ __device__ __forceinline__ bool project_uv(const FrameCtx& c, float xf, float yf
     u = (c.fx * pcx + c.cx * pcz) / pcz;
     v = (c.fx * pcy + c.cy * pcz) / pcz;   // fx on purpose: iba_global.cpp:73
     return 0 <= u && u < c.W && 0 <= v && v < c.H;
+}
+// one scan point by tree position, where the lanes of a wave ask for unrelated positions: one 16 B gather instead of three
+// 4 B gathers (the texture path handles one lane's address per clock either way)
+template <bool AOS>
+__device__ __forceinline__ void load_pt(const FrameCtx& c, uint32_t pos, float& x, float& y, float& z) {
+    if (AOS) { const float4 v = c.p4[pos]; x = v.x; y = v.y; z = v.z; }
+    else { x = c.xs[pos]; y = c.ys[pos]; z = c.zs[pos]; }
+}
+template <bool AOS>
+__device__ __forceinline__ bool project_pos(const FrameCtx& c, uint32_t pos, double& u, double& v) {
+    float x, y, z;
+    load_pt<AOS>(c, pos, x, y, z);
+    return project_uv(c, x, y, z, u, v);
 }
 // one LDS bit: can any keypoint be within max_pixel_dist of this pixel?
 __device__ __forceinline__ bool near_keypoint(const FrameCtx& c, double u, double v) {
@@ -487,7 +502,7 @@ constexpr int kPathMax = 16;   // deeper trees (> 1.5 M points per scan) use the
 #define IBA_HIT_SLOTS 3
 #endif
 #ifndef IBA_LEAF_BATCH
-#define IBA_LEAF_BATCH 1   /* leaf-scan steps whose loads are issued together (2: no gain, 4+: register spills) */
+#define IBA_LEAF_BATCH 2   /* points of a leaf scan whose loads are in flight together */
 #endif
 #ifndef IBA_FRAME_WAVES
 #define IBA_FRAME_WAVES 4   /* waves per SIMD the frame kernel is compiled for (register budget 512 / this) */
@@ -635,8 +650,8 @@ struct DualNN {
     uint32_t visits;
 #endif
 };
-template <int WHICH>   // bit 0: association-path query a is present, bit 1: cost-path query c (single-query modes compile the other half away)
-__device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+template <int WHICH, bool AOS>   // WHICH bit 0: association-path query a is present, bit 1: cost-path query c (single-query modes compile the other half away); AOS: leaves are read from p4
+__device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, const float4* __restrict__ p4,
                                              const TreeNode* __restrict__ nodes, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
                                              bool actA, double ax, double ay, double az, bool actC, double cx, double cy, double cz,
                                              DualNN& st, bool fresh, bool to_end) {
@@ -665,6 +680,7 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
         del = (float)m * 1.00001f + 1e-30f;
     }
     auto lower_bound = [&](float d) { const float a = fmaxf(fabsf(d) - del, 0.f); return (a * a) * 0.999998f; };
+    const float e_lin = 2.01f * del, e_const = 3.01f * del * del + 1e-37f;   // leaf filter, see the leaf scan below
     // contract: an inactive query comes in with NaN coordinates (the leaf scans run both queries unconditionally)
 #ifdef IBA_STAMPS_FINE
     unsigned long long sg0 = __builtin_readcyclecounter(), sg1 = sg0, sg2 = sg0, sg3 = sg0, sg4 = sg0, sg5 = sg0;
@@ -725,43 +741,107 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
 #endif
             const uint32_t j = node - first_leaf;
             const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
-            // branch-free in the common case: an inactive query has NaN coordinates (every compare is false), the
-            // running best is a select, and only an exact tie (lowest original index wins) leaves the straight line.
-            // The scan is read through L2 (iba_types.hpp: block shape), so the loads of kLeafBatch steps are issued
-            // together before any of them is consumed; a step beyond the leaf gets NaN coordinates.
+            // The leaf is scanned in FLOAT first and confirmed exactly afterwards. With d_k = fl(p_k - x_k) every exact
+            // axis difference of either query lies within del + 2^-24 |d_k| of d_k, so for u = fl(sum d_k^2) and
+            // s1 = sum |d_k| <= sqrt(3 u):  |exact d^2 - u| <= 2 del s1 + 3 del^2 + 3.2e-7 u <= E(u) with
+            //   E(u) = 1.001 e_lin sqrt(3 u) + 1.5e-6 u + e_const      (e_lin = 2.01 del, e_const = 3.01 del^2; the f64
+            // rounding of the exact value is 1e-16, far inside the slack). g(u) = u - E(u) is a lower bound of a point's
+            // exact d^2 and is increasing for u >= 4 e_lin^2. The scan keeps the two smallest u and the index of the
+            // smallest. If g(m2) > m1 + E(m1) (all but ~1e-4 of the visits) only the arg-min can hold the leaf's exact
+            // minimum and only that point is evaluated in double for the two queries — or none at all when g(m1) is
+            // already above both running bests; otherwise every point with g(u) <= m1 + E(m1) is evaluated. Either way
+            // the running bests see the same exact values and the same tie rule (lowest original index) as an
+            // all-double scan. An inactive query has NaN coordinates: every compare is false, its index stays kNone.
+            float m1 = INFINITY, m2 = INFINITY; uint32_t mi = kNone;
+            auto point = [&](uint32_t i, float& x, float& y, float& z) {
+                if (AOS) { const float4 v = p4[i]; x = v.x; y = v.y; z = v.z; }
+                else { x = xs[i]; y = ys[i]; z = zs[i]; }
+            };
+            auto err_of = [&](float u) { return fmaf(1.001f * e_lin, sqrtf(3.f * u), fmaf(1.5e-6f, u, e_const)); };
+            float thi = INFINITY;   // m1 + E(m1): nothing above it can be the leaf's minimum
+            bool single = false, skip = false;
+#ifndef IBA_LEAF_EXACT_ONLY
+            // the scan is read through L2: the loads of kLeafBatch points are issued together before any is consumed
+            // (a step beyond the leaf re-reads its last point and is discarded)
             constexpr int kLeafBatch = IBA_LEAF_BATCH;
             for (uint32_t i0 = lo + sub; i0 < hi; i0 += (uint32_t)(kLeafBatch * G)) {
                 float X[kLeafBatch], Y[kLeafBatch], Z[kLeafBatch];
 #pragma unroll
                 for (int u = 0; u < kLeafBatch; ++u) {
                     const uint32_t iu = i0 + (uint32_t)(u * G), ic = iu < hi ? iu : hi - 1u;
-                    X[u] = xs[ic]; Y[u] = ys[ic]; Z[u] = zs[ic];
+                    if (AOS) { const float4 v = p4[ic]; X[u] = v.x; Y[u] = v.y; Z[u] = v.z; }
+                    else { X[u] = xs[ic]; Y[u] = ys[ic]; Z[u] = zs[ic]; }
                 }
 #pragma unroll
                 for (int u = 0; u < kLeafBatch; ++u) {
                     const uint32_t i = i0 + (uint32_t)(u * G);
-                    const double x = i < hi ? (double)X[u] : (double)NAN, y = (double)Y[u], z = (double)Z[u];
-                    if (WHICH & 1) {
-                        const double dx = ax - x, dy = ay - y, dz = az - z;
-                        const double d2 = (dx * dx + dy * dy) + dz * dz;
-                        const bool lt = d2 < bestA, eq = d2 == bestA;
-                        bestA = lt ? d2 : bestA; bposA = lt ? i : bposA;
-                        if (__builtin_expect(eq, 0)) { if (bposA != kNone && bposA != i && perm_g[i] < perm_g[bposA]) bposA = i; }
-                    }
-                    if (WHICH & 2) {
-                        const double dx = cx - x, dy = cy - y, dz = cz - z;
-                        const double d2 = (dx * dx + dy * dy) + dz * dz;
-                        const bool lt = d2 < bestC, eq = d2 == bestC;
-                        bestC = lt ? d2 : bestC; bposC = lt ? i : bposC;
-                        if (__builtin_expect(eq, 0)) { if (bposC != kNone && bposC != i && perm_g[i] < perm_g[bposC]) bposC = i; }
-                    }
+                    const float dx = p0 - X[u], dy = p1 - Y[u], dz = p2 - Z[u];
+                    float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    uu = i < hi ? uu : INFINITY;
+                    mi = uu < m1 ? i : mi;
+                    m2 = __builtin_amdgcn_fmed3f(m1, m2, uu);   // second smallest of {m1 <= m2, uu}
+                    m1 = __builtin_fminf(m1, uu);
                 }
             }
-#ifdef IBA_STAMPS_FINE
-            sg3 = __builtin_readcyclecounter();
+#define IBA_DPPF(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+#define IBA_DPPU(v, ctrl) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xf, 0xf, false)
+#define IBA_LEAF_MERGE(o1e, o2e, oie) do { const float o1 = (o1e), o2 = (o2e); const uint32_t oi = (oie); \
+                m2 = fminf(fmaxf(m1, o1), fminf(m2, o2)); mi = o1 < m1 ? oi : mi; m1 = fminf(m1, o1); } while (0)
+            if (G >= 2) IBA_LEAF_MERGE(IBA_DPPF(m1, 0xB1), IBA_DPPF(m2, 0xB1), IBA_DPPU(mi, 0xB1));
+            if (G >= 4) IBA_LEAF_MERGE(IBA_DPPF(m1, 0x4E), IBA_DPPF(m2, 0x4E), IBA_DPPU(mi, 0x4E));
+            if (G >= 8) IBA_LEAF_MERGE(IBA_DPPF(m1, 0x141), IBA_DPPF(m2, 0x141), IBA_DPPU(mi, 0x141));
+            if (G >= 16) IBA_LEAF_MERGE(IBA_DPPF(m1, 0x140), IBA_DPPF(m2, 0x140), IBA_DPPU(mi, 0x140));
+            if (G >= 32) IBA_LEAF_MERGE(__shfl_xor(m1, 16), __shfl_xor(m2, 16), __shfl_xor(mi, 16));
+#undef IBA_LEAF_MERGE
+#undef IBA_DPPF
+#undef IBA_DPPU
+            // m1, m2 are the same in every lane of the group after the butterfly; mi may differ only when two lanes hold
+            // equal m1, and then m2 == m1: not single.
+            {
+                const float mono = 4.f * e_lin * e_lin;   // g is increasing from here on
+                thi = m1 + err_of(m1);
+                single = m2 >= mono && m2 - err_of(m2) > thi;
+                const float bmax = __double2float_ru(fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY));
+                skip = m1 >= mono && m1 - err_of(m1) > bmax;   // no point of this leaf can reach either running best
+            }
+#else
+            mi = 0u;
 #endif
-            if (WHICH & 1) nn_group_reduce(G, bestA, bposA, perm_g);
-            if (WHICH & 2) nn_group_reduce(G, bestC, bposC, perm_g);
+            // exact confirmation: the one candidate, or (rarely) every point of this lane's slice that can reach below
+            // thi — then the lanes of the group hold different candidates and the bests are reduced over the group
+            if (mi != kNone && !skip) {
+                uint32_t i = single ? mi : lo + sub;
+                while (single || i < hi) {
+                    float xf, yf, zf;
+                    point(i, xf, yf, zf);
+                    bool take = single;
+                    if (!single) {
+                        const float dx = p0 - xf, dy = p1 - yf, dz = p2 - zf;
+                        const float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        take = uu - err_of(uu) <= thi;
+                    }
+                    if (take) {
+                        const double x = (double)xf, y = (double)yf, z = (double)zf;
+                        if (WHICH & 1) {
+                            const double dx = ax - x, dy = ay - y, dz = az - z;
+                            nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, i, perm_g);
+                        }
+                        if (WHICH & 2) {
+                            const double dx = cx - x, dy = cy - y, dz = cz - z;
+                            nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, i, perm_g);
+                        }
+                    }
+                    if (single) break;
+                    i += (uint32_t)G;
+                }
+#ifdef IBA_STAMPS_FINE
+                sg3 = __builtin_readcyclecounter();
+#endif
+                if (!single) {
+                    if (WHICH & 1) nn_group_reduce(G, bestA, bposA, perm_g);
+                    if (WHICH & 2) nn_group_reduce(G, bestC, bposC, perm_g);
+                }
+            }
 #ifdef IBA_STAMPS_FINE
             sg4 = __builtin_readcyclecounter();
 #endif
@@ -770,8 +850,8 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
             const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
             uint32_t cand = 0u;
 #pragma unroll
-            for (int L = 0; L < kPathMax; ++L) { if (L >= (int)D) break; cand |= (pd2[L] <= bestf ? 1u : 0u) << L; }
-            cand &= ~done;
+            for (int L = 0; L < kPathMax; ++L) cand |= (pd2[L] <= bestf ? 1u : 0u) << L;
+            cand &= ~done & ((1u << D) - 1u);
             done |= ~cand;                               // the bests only shrink: out of reach stays out of reach
             go = cand ? 31 - __clz((int)cand) : -1;
         }
@@ -924,6 +1004,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
     c.nodes = s_nodes; c.bitmap = s_bitmap; c.best_d2 = s_best_d2; c.best_idx = s_best_idx;
     c.cstart = s_cstart; c.gwc = (int)h.gwc; c.crec = dp.crec + h.kp_base;
     c.perm = dp.perm + h.pt_base;
+    c.p4 = SCAN_LDS ? nullptr : dp.pts4 + h.pt_base;
     c.gw = (int)h.gw; c.gh = (int)h.gh; c.margin = (float)prm.grid_margin; c.gate2 = prm.gate2;
     c.fx = h.fx; c.cx = h.cx; c.cy = h.cy; c.W = h.W; c.H = h.H;
 #pragma unroll
@@ -1092,14 +1173,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         if ((uint32_t)tid + (uint32_t)q * kThreads < ncand) {
             const uint32_t pos = (uint32_t)s_cand[tid + q * kThreads];
             double u, v;
-            if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) hh[q] = grid_match_rec(c, u, v);
+            if (project_pos<!SCAN_LDS>(c, pos, u, v)) hh[q] = grid_match_rec(c, u, v);
         }
         redo |= hh[q].n > 2;
     }
     for (uint32_t i = (uint32_t)tid + (uint32_t)kHitSlots * kThreads; i < ncand; i += kThreads) {
         const uint32_t pos = (uint32_t)s_cand[i];
         double u, v;
-        if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) redo |= grid_match<1>(c, u, v, pos);
+        if (project_pos<!SCAN_LDS>(c, pos, u, v)) redo |= grid_match<1>(c, u, v, pos);
     }
     __syncthreads();
     IBA_STAMP(2);
@@ -1120,13 +1201,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         for (uint32_t i = tid; i < ncand; i += kThreads) {
             const uint32_t pos = (uint32_t)s_cand[i];
             double u, v;
-            if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) grid_match<2>(c, u, v, pos);
+            if (project_pos<!SCAN_LDS>(c, pos, u, v)) grid_match<2>(c, u, v, pos);
         }
     }
     if (overflow) {
         for (uint32_t pos = tid; pos < P; pos += kThreads) {
             double u, v;
-            if (project_uv(c, c.xs[pos], c.ys[pos], c.zs[pos], u, v)) grid_match<2>(c, u, v, pos);
+            if (project_pos<!SCAN_LDS>(c, pos, u, v)) grid_match<2>(c, u, v, pos);
         }
     }
     __syncthreads();
@@ -1210,8 +1291,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
                         st.leaf = hs.leaf_done & 0xffffu; st.done = hs.leaf_done >> 16; st.bposA = hs.bposA; st.bposC = hs.bposC;
                         ax = hs.a[0]; ay = hs.a[1]; az = hs.a[2]; qx = hs.c[0]; qy = hs.c[1]; qz = hs.c[2];
                         // the running bests are the exact distances of the stored positions (same expression as the leaf scan)
-                        if (st.bposA != kNone) { const double dx = ax - (double)c.xs[st.bposA], dy = ay - (double)c.ys[st.bposA], dz = az - (double)c.zs[st.bposA]; st.bestA = (dx * dx + dy * dy) + dz * dz; }
-                        if (st.bposC != kNone) { const double dx = qx - (double)c.xs[st.bposC], dy = qy - (double)c.ys[st.bposC], dz = qz - (double)c.zs[st.bposC]; st.bestC = (dx * dx + dy * dy) + dz * dz; }
+                        if (st.bposA != kNone) { float x, y, z; load_pt<!SCAN_LDS>(c, st.bposA, x, y, z); const double dx = ax - (double)x, dy = ay - (double)y, dz = az - (double)z; st.bestA = (dx * dx + dy * dy) + dz * dz; }
+                        if (st.bposC != kNone) { float x, y, z; load_pt<!SCAN_LDS>(c, st.bposC, x, y, z); const double dx = qx - (double)x, dy = qy - (double)y, dz = qz - (double)z; st.bestC = (dx * dx + dy * dy) + dz * dz; }
                     }
                 }
                 __syncthreads();   // every state of this pass is in registers: its slot may be overwritten
@@ -1219,7 +1300,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
                     if (actA || actC) {
                         bool fr = fresh, to_end = kNNToEnd || (!fresh && n_items <= (uint32_t)kNNEndAt);
                         for (;;) {
-                            const bool more = nn_dual_step<WHICH>(G, c.xs, c.ys, c.zs, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, st, fr, to_end);
+                            const bool more = nn_dual_step<WHICH, !SCAN_LDS>(G, c.xs, c.ys, c.zs, c.p4, s_nodes, c.perm, P, D, actA, ax, ay, az, actC, qx, qy, qz, st, fr, to_end);
                             if (!more) break;
                             uint32_t slot = 0u;
                             if ((tid & (G - 1)) == 0) slot = atomicAdd(cnt, 1u);
@@ -1296,7 +1377,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
                 uint32_t mask = (s_list[i] >> 18) & 0x3ffu;
                 if (!mask) continue;
                 const uint32_t k = s_list[i] & 0xffffu, pos = s_nnC[i];
-                const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
+                float xf_, yf_, zf_; load_pt<!SCAN_LDS>(c, pos, xf_, yf_, zf_);
+                const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
                 const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
                 const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
                 const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
@@ -1377,7 +1459,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             const uint32_t bC = s_nnC[i];
             if (bC != kNone) {
                 double ax, ay, az, qx, qy, qz; queries(k, ax, ay, az, qx, qy, qz);
-                const double ex = (double)c.xs[bC] - qx, ey = (double)c.ys[bC] - qy, ez = (double)c.zs[bC] - qz;
+                float xf_, yf_, zf_; load_pt<!SCAN_LDS>(c, bC, xf_, yf_, zf_);
+                const double ex = (double)xf_ - qx, ey = (double)yf_ - qy, ez = (double)zf_ - qz;
                 double dist = sqrt((ex * ex + ey * ey) + ez * ez);
                 bool is_plane = false;
                 if (prm.use_plane) {
@@ -1528,7 +1611,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) m[sl] = (uint32_t)sl < h.n_slots ? dp.match_uv[h.match_base + (size_t)sl * K + k] : make_float2(__builtin_nanf(""), 0.f);
         const uint32_t pos = inv_perm[s_best_idx[k]];   // issued together with the match loads
-        const double x = (double)c.xs[pos], y = (double)c.ys[pos], z = (double)c.zs[pos];
+        float xf_, yf_, zf_; load_pt<!SCAN_LDS>(c, pos, xf_, yf_, zf_);
+        const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
         const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
         const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
         const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
@@ -1583,7 +1667,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             const uint32_t bpos = s_bpos[i];
             if (bpos == kNone) continue;
             double qx, qy, qz; q_cost(s_list[i], qx, qy, qz);
-            const double ax = (double)c.xs[bpos] - qx, ay = (double)c.ys[bpos] - qy, az = (double)c.zs[bpos] - qz;
+            float xf_, yf_, zf_; load_pt<!SCAN_LDS>(c, bpos, xf_, yf_, zf_);
+            const double ax = (double)xf_ - qx, ay = (double)yf_ - qy, az = (double)zf_ - qz;
             double dist = sqrt((ax * ax + ay * ay) + az * az);   // (nn_pt - query_pt).norm()  (:122)
             bool is_plane = false;
             if (prm.use_plane) {
