@@ -680,7 +680,8 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
         del = (float)m * 1.00001f + 1e-30f;
     }
     auto lower_bound = [&](float d) { const float a = fmaxf(fabsf(d) - del, 0.f); return (a * a) * 0.999998f; };
-    const float e_lin = 2.01f * del, e_const = 3.01f * del * del + 1e-37f;   // leaf filter, see the leaf scan below
+    // leaf filter, see the leaf scan below; the middle term of e_const covers a flushed sqrt of a denormal u
+    const float e_lin = 2.01f * del, e_const = 3.01f * del * del + 2.1e-19f * e_lin + 1e-37f;
     // contract: an inactive query comes in with NaN coordinates (the leaf scans run both queries unconditionally)
 #ifdef IBA_STAMPS_FINE
     unsigned long long sg0 = __builtin_readcyclecounter(), sg1 = sg0, sg2 = sg0, sg3 = sg0, sg4 = sg0, sg5 = sg0;
@@ -757,7 +758,8 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
                 if (AOS) { const float4 v = p4[i]; x = v.x; y = v.y; z = v.z; }
                 else { x = xs[i]; y = ys[i]; z = zs[i]; }
             };
-            auto err_of = [&](float u) { return fmaf(1.001f * e_lin, sqrtf(3.f * u), fmaf(1.5e-6f, u, e_const)); };
+            // (raw v_sqrt_f32 is good to 1 ulp, covered by the 1.001 factor; a denormal argument may come back as 0, covered by e_const)
+            auto err_of = [&](float u) { return fmaf(1.001f * e_lin, __builtin_amdgcn_sqrtf(3.f * u), fmaf(1.5e-6f, u, e_const)); };
             float thi = INFINITY;   // m1 + E(m1): nothing above it can be the leaf's minimum
             bool single = false, skip = false;
 #ifndef IBA_LEAF_EXACT_ONLY
@@ -801,7 +803,9 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
                 const float mono = 4.f * e_lin * e_lin;   // g is increasing from here on
                 thi = m1 + err_of(m1);
                 single = m2 >= mono && m2 - err_of(m2) > thi;
-                const float bmax = __double2float_ru(fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY));
+                // an upper bound of the larger running best in float: round to nearest, then one part in 2^23 up
+                const float bnear = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+                const float bmax = fmaf(fabsf(bnear), 1.2e-7f, bnear);
                 skip = m1 >= mono && m1 - err_of(m1) > bmax;   // no point of this leaf can reach either running best
             }
 #else
@@ -1743,6 +1747,7 @@ __device__ __forceinline__ int hidx(int i, int j) { return i * 7 - (i * (i - 1))
 template <class SlotFn>
 __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K,
                                                  double u0, double v0, const double* p0, const double* n0, double* z6, SlotFn slot) {
+    #pragma clang fp contract(fast)   // Jacobian path: H, b carry a 1e-10 relative budget, not bit parity
     double p0c[3], n0c[3];
     for (int r = 0; r < 3; ++r) {
         p0c[r] = ((c.R[r * 3] * p0[0] + c.R[r * 3 + 1] * p0[1]) + c.R[r * 3 + 2] * p0[2]) + c.t[r];
@@ -1797,9 +1802,11 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
 
 __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
                                           double u0, double v0, const double* p0, const double* n0, NAcc& A) {
+    #pragma clang fp contract(fast)   // Jacobian path: H, b carry a 1e-10 relative budget, not bit parity
     double z6[6];
     double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0;
     const int nconv = plane_factor_core(c, h, dp, k, K, u0, v0, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
+#pragma clang fp contract(fast)
         ssq += ru * ru + rv * rv;
         G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
         Gr += gu * ru + gv * rv; Hr += hu * ru + hv * rv;
@@ -1818,6 +1825,7 @@ __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, cons
 
 // M = Rlc (s m) + tlc and dM/dx for the 3d-3d factors (IBACalib2.hpp:570-584, 611-625)
 __device__ __forceinline__ void p2x_core(const Cand& c, const FrameHdr& h, const float4 mp, double* M, double dM[7][3]) {
+    #pragma clang fp contract(fast)   // Jacobian path: H, b carry a 1e-10 relative budget, not bit parity
     const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
     const double m[3] = {((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3], ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7],
                          ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11]};
@@ -1834,6 +1842,7 @@ __device__ __forceinline__ void p2x_core(const Cand& c, const FrameHdr& h, const
 }
 
 __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const DevParams& prm, const float4 mp, const double* Q, const double* n, bool is_plane, NAcc& A) {
+    #pragma clang fp contract(fast)   // Jacobian path: H, b carry a 1e-10 relative budget, not bit parity
     double M[3], dM[7][3];
     p2x_core(c, h, mp, M, dM);
     const double e[3] = {M[0] - Q[0], M[1] - Q[1], M[2] - Q[2]};
@@ -1878,7 +1887,7 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
     for (int i = 0; i < 28; ++i) A.H[i] = 0;
     for (int i = 0; i < 7; ++i) A.b[i] = 0;
     A.chi2 = A.cost = A.nf2d = A.nfpl = A.nfpt = A.nres = 0;
-    const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
+    const float4* p4 = dp.pts4 + h.pt_base;
     const PlaneRec* planes = prm.plane_cache ? dp.plane_local + h.pt_base
                                              : dp.scratch_local + (size_t)(per_cand ? dp.scratch_slot_base + b : 0) * (size_t)dp.n_pt_total + h.pt_base;
     for (uint32_t i = tid; i < n; i += kFactorThreads) {
@@ -1886,14 +1895,16 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
         const uint32_t k = e.x;
         if (e.y != kNone) {
             const PlaneRec rec = planes[e.y];
-            const double p0[3] = {(double)xs[e.y], (double)ys[e.y], (double)zs[e.y]}, n0[3] = {rec.nx, rec.ny, rec.nz};
+            const float4 pt = p4[e.y];
+            const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, n0[3] = {rec.nx, rec.ny, rec.nz};
             const float2 uv = dp.kp_uv[h.kp_base + k];
             plane_factor_accum(c, h, dp, prm, k, h.K, (double)uv.x, (double)uv.y, p0, n0, A);
         }
         if (e.z != kNone) {
             const uint32_t pos = e.z & 0x7FFFFFFFu; const bool is_plane = (e.z >> 31) != 0;
             const PlaneRec rec = planes[pos];
-            const double Q[3] = {(double)xs[pos], (double)ys[pos], (double)zs[pos]}, nn[3] = {rec.nx, rec.ny, rec.nz};
+            const float4 pt = p4[pos];
+            const double Q[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, nn[3] = {rec.nx, rec.ny, rec.nz};
             p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, nn, is_plane, A);
         }
     }
