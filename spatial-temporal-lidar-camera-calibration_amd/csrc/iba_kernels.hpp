@@ -628,6 +628,12 @@ __device__ __forceinline__ void nn_group_reduce(int G, double& best, uint32_t& b
     if (G >= 32) nn_merge(best, bpos, __shfl_xor(best, 16), __shfl_xor(bpos, 16), perm_g);
 }
 
+// v_min / v_max without the canonicalising v_max the IEEE-exact fminf / fmaxf expansion adds in front (a NaN operand
+// returns the other one, like minnum / maxnum)
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // ---- two exact 1-NN searches in ONE traversal (fused mode), resumable leaf by leaf ----
 // The association-path query qa and the cost-path query qc of the same MapPoint differ by ~1e-7 relative (different
 // float/double islands in the reference), so they visit the same leaves. Pruning is the union of what either query
@@ -679,7 +685,9 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
         if (actC) m = fmax(m, fmax(fmax(fabs(cx - (double)p0), fabs(cy - (double)p1)), fabs(cz - (double)p2)));
         del = (float)m * 1.00001f + 1e-30f;
     }
-    auto lower_bound = [&](float d) { const float a = fmaxf(fabsf(d) - del, 0.f); return (a * a) * 0.999998f; };
+    // (the factor is applied to a as c = 0.999999f, c^2 <= 1 - 2^-19: one fma instead of a subtraction and a multiplication)
+    const float delc = del * 0.999999f;
+    auto lower_bound = [&](float d) { const float a = fmaxf(fmaf(fabsf(d), 0.999999f, -delc), 0.f); return a * a; };
     // leaf filter, see the leaf scan below; the middle term of e_const covers a flushed sqrt of a denormal u
     const float e_lin = 2.01f * del, e_const = 3.01f * del * del + 2.1e-19f * e_lin + 1e-37f;
     // contract: an inactive query comes in with NaN coordinates (the leaf scans run both queries unconditionally)
@@ -723,18 +731,25 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
             node = 2u * anc + 1u + ((side >> go) & 1u);
             start = go + 1;
         }
+        {   // levels start .. D-1: their side / done bits are rewritten; n1 = node + 1 (children 2 n1 and 2 n1 + 1)
+            const uint32_t keep = (1u << start) - 1u;
+            side &= keep; done &= keep;
+            uint32_t n1 = node + 1u;
 #pragma unroll
-        for (int L = 0; L < kPathMax; ++L) {
-            if (L >= (int)D) break;   // uniform: one scalar branch ends the unrolled chain
-            if (L >= start) {
-                const TreeNode n = nodes[node];
-                const float d = (n.dim == 0 ? p0 : (n.dim == 1 ? p1 : p2)) - n.split;
-                const uint32_t r = d >= 0.f ? 1u : 0u;
-                pd2[L] = lower_bound(d);
-                side = (side & ~(1u << L)) | (r << L);
-                done &= ~(1u << L);
-                node = 2u * node + 1u + r;
+            for (int L = 0; L < kPathMax; ++L) {
+                if (L >= (int)D) break;   // uniform: one scalar branch ends the unrolled chain
+                if (L >= start) {
+                    const TreeNode n = nodes[n1 - 1u];
+                    const float d = (n.dim == 0 ? p0 : (n.dim == 1 ? p1 : p2)) - n.split;
+                    // right child iff the sign bit of d is clear (d = -0 goes left where d >= 0 would go right: the bound
+                    // of that plane is 0 either way, so both children are visited and the result does not depend on it)
+                    const uint32_t r = (~__float_as_uint(d)) >> 31;
+                    pd2[L] = lower_bound(d);
+                    side |= r << L;
+                    n1 = (n1 << 1) | r;
+                }
             }
+            node = n1 - 1u;
         }
         {
 #ifdef IBA_STAMPS_FINE
@@ -782,13 +797,13 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
                     uu = i < hi ? uu : INFINITY;
                     mi = uu < m1 ? i : mi;
                     m2 = __builtin_amdgcn_fmed3f(m1, m2, uu);   // second smallest of {m1 <= m2, uu}
-                    m1 = __builtin_fminf(m1, uu);
+                    m1 = vmin(m1, uu);
                 }
             }
 #define IBA_DPPF(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
 #define IBA_DPPU(v, ctrl) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xf, 0xf, false)
 #define IBA_LEAF_MERGE(o1e, o2e, oie) do { const float o1 = (o1e), o2 = (o2e); const uint32_t oi = (oie); \
-                m2 = fminf(fmaxf(m1, o1), fminf(m2, o2)); mi = o1 < m1 ? oi : mi; m1 = fminf(m1, o1); } while (0)
+                m2 = vmin3(vmax(m1, o1), m2, o2); mi = o1 < m1 ? oi : mi; m1 = vmin(m1, o1); } while (0)
             if (G >= 2) IBA_LEAF_MERGE(IBA_DPPF(m1, 0xB1), IBA_DPPF(m2, 0xB1), IBA_DPPU(mi, 0xB1));
             if (G >= 4) IBA_LEAF_MERGE(IBA_DPPF(m1, 0x4E), IBA_DPPF(m2, 0x4E), IBA_DPPU(mi, 0x4E));
             if (G >= 8) IBA_LEAF_MERGE(IBA_DPPF(m1, 0x141), IBA_DPPF(m2, 0x141), IBA_DPPU(mi, 0x141));
