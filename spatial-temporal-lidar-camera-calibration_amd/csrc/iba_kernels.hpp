@@ -491,7 +491,8 @@ __device__ unsigned long long g_dbg[64];
 // (split value per level, 2-bit dim, side and done bits), so backtracking — otherwise a chain of dependent LDS
 // reads, one per tree level — is pure VALU: the deepest unfinished level whose split plane is within the current
 // best distance is found with an unrolled scan, its far child is entered, and only the levels below are fetched.
-constexpr int kPathMax = 16;   // deeper trees (> 1.5 M points per scan) use the generic LDS-walking branch
+constexpr int kPathMax = 12;   // levels whose plane bounds are kept in registers (the builder caps D at kMaxTreeDepth = 11); deeper trees use the generic LDS-walking branch
+static_assert(kPathMax % 4 == 0 && kPathMax >= kMaxTreeDepth, "register path must cover the depth cap");
 #ifndef IBA_NN_TO_END
 #define IBA_NN_TO_END 0
 #endif
@@ -706,13 +707,13 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
 #pragma unroll
         for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
 #pragma unroll
-        for (int H = 0; H < kPathMax; H += 8) {   // eight levels per batch of reads
+        for (int H = 0; H < kPathMax; H += 4) {   // four levels per batch of reads
             if (H < (int)D) {
-                TreeNode nn[8];
+                TreeNode nn[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const int L = H + q; nn[q] = nodes[((node + 1u) >> (D - (uint32_t)(L < (int)D ? L : (int)D - 1))) - 1u]; }
+                for (int q = 0; q < 4; ++q) { const int L = H + q; nn[q] = nodes[((node + 1u) >> (D - (uint32_t)(L < (int)D ? L : (int)D - 1))) - 1u]; }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < 4; ++q) {
                     const int L = H + q;
                     const float lb = lower_bound((nn[q].dim == 0 ? p0 : (nn[q].dim == 1 ? p1 : p2)) - nn[q].split);
                     pd2[L] = L < (int)D ? lb : INFINITY;
