@@ -241,8 +241,8 @@ iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_fra
     const int per_xcd = (h->n_frames + 7) / 8;
     const dim3 grid(8 * per_xcd * B), block(kThreads);
     if (h->n_frames == 0) return IBA_OK;
-    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->maxK);
-    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, dp, h->dprm, h->lay, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->maxK);
+    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, KArgs{dp, h->dprm, h->lay}, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->maxK);
+    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, KArgs{dp, h->dprm, h->lay}, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->maxK);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }

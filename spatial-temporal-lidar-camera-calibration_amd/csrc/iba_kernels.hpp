@@ -63,6 +63,7 @@ struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from
     uint32_t scan_stride;   // floats per coordinate array (0 = scan not staged in LDS)
     uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_cstart, off_red, off_vis, vis_words, off_cand, cand_cap, total;
 };
+struct KArgs { DevProblem dp; DevParams prm; LdsLayout lay; };   // the frame kernel's parameter blocks, first kernel argument
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kWaves = kThreads / 64;
@@ -504,6 +505,9 @@ static_assert(kPathMax % 4 == 0 && kPathMax >= kMaxTreeDepth, "register path mus
 #endif
 #ifndef IBA_LEAF_BATCH
 #define IBA_LEAF_BATCH 2   /* points of a leaf scan whose loads are in flight together */
+#endif
+#ifndef IBA_RELOAD_MASK
+#define IBA_RELOAD_MASK 0xff   /* phase boundaries (IBA_STAMP indices) at which the kernarg pointer is laundered */
 #endif
 #ifndef IBA_FRAME_WAVES
 #define IBA_FRAME_WAVES 4   /* waves per SIMD the frame kernel is compiled for (register budget 512 / this) */
@@ -958,11 +962,24 @@ __device__ __forceinline__ uint32_t block_count(uint32_t my_count_wave_uniform, 
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so
 // all candidates of one frame share that XCD's L2 copy of the scan.
 template <int MODE, bool SCAN_LDS>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FRAME_WAVES, IBA_FRAME_WAVES))) void iba_frame_kernel(DevProblem dp, DevParams prm, LdsLayout lay, const Cand* __restrict__ cands, int B,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FRAME_WAVES, IBA_FRAME_WAVES))) void iba_frame_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B,
                                                              double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out,
                                                              uint2* __restrict__ assoc_out, int nrec, const double* __restrict__ he,
                                                              uint4* __restrict__ flist, uint32_t* __restrict__ fcount, int flist_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // The three parameter blocks (about 100 scalar registers' worth) are read from the kernarg segment — constant address
+    // space, scalar loads — where they are used, and the pointer is passed through an empty asm at every phase boundary so
+    // that the loads of a phase cannot be merged with, and kept alive since, those of the kernel entry. Left to itself
+    // the compiler loads everything up front and spills 169 SGPRs into VGPR lanes (822 v_readlane / v_writelane in the
+    // fused kernel); this way it is 99 and 352. (The same treatment of the frame header and the candidate constants, which
+    // sit behind ordinary global pointers, made it worse: their fields are copied into locals at the top anyway.)
+    typedef __attribute__((address_space(4))) const KArgs KArgsC;
+    KArgsC* ka = (KArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // ka_by_value is the first argument: offset 0
+    (void)ka_by_value;
+#define dp (ka->dp)
+#define prm (ka->prm)
+#define lay (ka->lay)
+#define IBA_RELOAD_AT(i) do { if ((IBA_RELOAD_MASK >> (i)) & 1) asm volatile("" : "+s"(ka)); } while (0)
     typedef typename std::conditional<SCAN_LDS, uint16_t, uint32_t>::type CandT;   // LDS mode implies P < 65536
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = dp.n_frames;
@@ -993,7 +1010,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
 #ifdef IBA_STAMPS
     unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    IBA_STAMP(0);
+    IBA_STAMP(0); IBA_RELOAD_AT(0);
     // ---- phase 0: LDS init ----
     // the first (usually only) element per thread of each static table is fetched before anything is stored, so the
     // four global-load latencies overlap instead of queueing behind each other's LDS stores
@@ -1032,7 +1049,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
 #pragma unroll
     for (int i = 0; i < 3; ++i) c.t[i] = cd.t[i];
 
-    IBA_STAMP(1);
+    IBA_STAMP(1); IBA_RELOAD_AT(1);
     // ---- phase 1a: stream the scan once (16 B/lane), keep it in LDS, and PRE-CULL in float32:
     //      a point can only matter if it may project within ~1.5 px of a keypoint. The f32 projection errs by
     //      < 0.3 px for depth > 0.1 m; the reject bitmap is dilated by max_pixel_dist + 0.45 px, so a clear bit
@@ -1174,7 +1191,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         }
     }
     __syncthreads();
-    IBA_STAMP(7);
+    IBA_STAMP(7); IBA_RELOAD_AT(7);
     // ---- phase 1b: exact f64 projection + FOV test of the queued points, keypoint grid lookup,
     //      ds_min_u64 on the keypoint's best d^2 ----
     const uint32_t ncand = min(s_misc[0], cand_cap);
@@ -1203,7 +1220,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         if (project_pos<!SCAN_LDS>(c, pos, u, v)) redo |= grid_match<1>(c, u, v, pos);
     }
     __syncthreads();
-    IBA_STAMP(2);
+    IBA_STAMP(2); IBA_RELOAD_AT(2);
     // ---- phase 2: the winner of each keypoint records its original index; exact ties -> lowest index ----
 #pragma unroll
     for (int q = 0; q < kHitSlots; ++q) {
@@ -1237,7 +1254,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         return;
     }
 
-    IBA_STAMP(3);
+    IBA_STAMP(3); IBA_RELOAD_AT(3);
     const float4* kp_mp = dp.kp_mp + h.kp_base;
     const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
     const uint32_t Kceil = (K + kThreads - 1) / kThreads * kThreads;
@@ -1424,7 +1441,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             }
         }
         __syncthreads();
-        IBA_STAMP(4);
+        IBA_STAMP(4); IBA_RELOAD_AT(4);
         // the two MapPoint -> LiDAR-frame queries (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
         const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;
         auto queries = [&](uint32_t k, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
@@ -1457,12 +1474,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
                 s_nnA[i] = (actA && !(st.bestA > prm.max_3d_dist2)) ? st.bposA : kNone;   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
             });
         __syncthreads();
-        IBA_STAMP(5);
+        IBA_STAMP(5); IBA_RELOAD_AT(5);
         if (!cached) {
             fit_points(s_nnA, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
             if (prm.use_plane) fit_points(s_nnC, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);
         }
-        IBA_STAMP(6);
+        IBA_STAMP(6); IBA_RELOAD_AT(6);
         for (uint32_t i = tid; i < n3; i += kThreads) {
             const uint32_t k = s_list[i] & 0xffffu;
             // association: kind of the 3d-3d block (pointcloud.h:699-717), dense block list for the factor kernel
@@ -1614,7 +1631,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         return;
     }
 
-    IBA_STAMP(4);
+    IBA_STAMP(4); IBA_RELOAD_AT(4);
     // ---- phase 4: ONE dense work list (keypoints with a correspondence that own a MapPoint and/or a covisible match:
     //      ~1 keypoint in 8), built in keypoint order with the only barriers of the phase; then all the arithmetic
     //      runs on full waves instead of dragging every wave through code most of its lanes skip ----
@@ -1656,7 +1673,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
 #ifdef IBA_STAMPS
     __syncthreads();
 #endif
-    IBA_STAMP(5);
+    IBA_STAMP(5); IBA_RELOAD_AT(5);
     // K4+K5: 3d-3d (MapPoint -> LiDAR frame, 1-NN with G lanes per query, memoised local plane)
 #ifdef IBA_STAMPS
     const unsigned long long tw0 = __builtin_readcyclecounter();
@@ -1707,7 +1724,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
 #ifdef IBA_STAMPS
     __syncthreads();
 #endif
-    IBA_STAMP(6);
+    IBA_STAMP(6); IBA_RELOAD_AT(6);
     // ---- phase 5 (K8): two double sums + six exact integer counters packed 21 bits each; DPP wave sums, then the
     //      16 waves in fixed order. No atomics => bitwise reproducible.
     {
@@ -1742,6 +1759,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
     if (tid == 0) { const unsigned long long te = __builtin_readcyclecounter(); for (int i = 0; i < 7; ++i) part[56 + i] = (double)((i < 6 ? stamp_t[i + 1] : te) - stamp_t[i]); part[63] = (double)(stamp_t[7] - stamp_t[1]); }
 #endif
 }
+#undef dp
+#undef prm
+#undef lay
+#undef IBA_RELOAD_AT
 
 // ---- Jacobian path: residual blocks of the frozen association, evaluated at candidate x ----
 // IBA_PlaneFactor (IBACalib2.hpp:152-184), Point2Plane/Point2Point_Factor (:570-584, 611-625), Huber
