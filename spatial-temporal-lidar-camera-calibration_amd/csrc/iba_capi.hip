@@ -621,6 +621,29 @@ iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
     return IBA_OK;
 }
 
+// debug: exact 1-NN of n LiDAR-frame queries in the scan of a local frame, through the frame kernels' own search
+iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n, int32_t lanes_per_query, uint32_t* out_idx, double* out_d2) {
+    if (!h || !q || !out_idx || !out_d2 || n < 1 || frame < 0 || frame >= h->n_frames) return IBA_ERR_INVALID_ARG;
+    const int G = lanes_per_query;
+    if (G < 1 || G > 32 || (G & (G - 1))) return fail(h, IBA_ERR_INVALID_ARG, "lanes_per_query must be a power of two <= 32");
+    (void)hipSetDevice(h->device);
+    DevBuf<double> dq, dd; DevBuf<uint32_t> di;
+    std::vector<double> hq(q, q + 3 * (size_t)n);
+    hipError_t er = dq.upload(hq);
+    if (er == hipSuccess) er = dd.alloc((size_t)n);
+    if (er == hipSuccess) er = di.alloc((size_t)n);
+    if (er != hipSuccess) return fail(h, IBA_ERR_HIP, hipGetErrorString(er));
+    const size_t lds = 8u * (size_t)std::max(h->maxNodes, 1u);
+    const int blocks = (int)(((size_t)n * G + 255) / 256);
+    hipLaunchKernelGGL(iba_nn_probe_kernel, dim3(blocks), dim3(256), lds, h->stream, h->dev_problem(), frame, dq.p, n, G, di.p, dd.p);
+    er = hipStreamSynchronize(h->stream);
+    if (er == hipSuccess) er = hipMemcpy(out_idx, di.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(out_d2, dd.p, sizeof(double) * n, hipMemcpyDeviceToHost);
+    dq.release(); dd.release(); di.release();
+    if (er != hipSuccess) return fail(h, IBA_ERR_HIP, hipGetErrorString(er));
+    return IBA_OK;
+}
+
 // ---- Jacobian path ----
 iba_status iba_finalize_normal(const iba_params* p, const double* part, int32_t B, iba_normal_out* out) {
     if (!p || !part || !out || B < 1) return IBA_ERR_INVALID_ARG;

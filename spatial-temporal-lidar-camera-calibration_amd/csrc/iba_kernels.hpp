@@ -827,6 +827,9 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
                 const float bnear = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
                 const float bmax = fmaf(fabsf(bnear), 1.2e-7f, bnear);
                 skip = m1 >= mono && m1 - err_of(m1) > bmax;   // no point of this leaf can reach either running best
+#ifdef IBA_LEAF_FORCE_SINGLE   /* fault injection for tests/test_gpu_edge_cases.py: trust the float arg-min blindly */
+                single = true;
+#endif
             }
 #else
             mi = 0u;
@@ -894,6 +897,31 @@ __device__ __forceinline__ bool nn_dual_step(int G, const float* __restrict__ xs
     st.bestA = bestA; st.bestC = bestC; st.bposA = bposA; st.bposC = bposC;
     st.leaf = node - first_leaf; st.done = done & 0xffffu; st.go = go;
     return go >= 0;
+}
+
+// diagnostic: the exact 1-NN search of the frame kernels on caller-supplied LiDAR-frame queries (iba_debug_nn). One lane
+// group of G lanes per query, the search runs to its end; out_idx = ORIGINAL point index, out_d2 = exact squared distance.
+__global__ __launch_bounds__(256) void iba_nn_probe_kernel(DevProblem dp, int frame, const double* __restrict__ q, int n, int G,
+                                                           uint32_t* __restrict__ out_idx, double* __restrict__ out_d2) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    TreeNode* s_nodes = (TreeNode*)smem;
+    const FrameHdr& h = dp.frames[frame];
+    const uint32_t P = h.P, D = h.depth;
+    for (uint32_t i = threadIdx.x; i < (1u << D) - 1u; i += blockDim.x) s_nodes[i] = dp.nodes[h.node_base + i];
+    __syncthreads();
+    const int e = (int)((blockIdx.x * blockDim.x + threadIdx.x) / (uint32_t)G);
+    const bool act = e < n && P > 0;
+    double qx = NAN, qy = NAN, qz = NAN;
+    if (act) { qx = q[3 * e]; qy = q[3 * e + 1]; qz = q[3 * e + 2]; }
+    DualNN st; st.bestA = INFINITY; st.bestC = INFINITY; st.bposA = kNone; st.bposC = kNone; st.leaf = 0u; st.done = 0u; st.go = -1;
+#ifdef IBA_STAMPS_FINE
+    st.visits = 0u;
+#endif
+    const uint32_t* perm = dp.perm + h.pt_base;
+    if (P > 0)   // whole lane groups are active or inactive together (n is padded to the group size by the launch)
+        nn_dual_step<2, true>(G, dp.xs + h.pt_base, dp.ys + h.pt_base, dp.zs + h.pt_base, dp.pts4 + h.pt_base, s_nodes, perm, P, D,
+                              false, NAN, NAN, NAN, act, qx, qy, qz, st, true, true);
+    if (act && (threadIdx.x & (uint32_t)(G - 1)) == 0) { out_idx[e] = st.bposC != kNone ? perm[st.bposC] : kNone; out_d2[e] = st.bestC; }
 }
 
 enum FrameMode { MODE_COST = 0, MODE_CORR = 1, MODE_ASSOC = 2, MODE_BOTH = 3 };   // BOTH = BAError + BuildProblem association in one pass

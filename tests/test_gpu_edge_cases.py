@@ -101,6 +101,41 @@ def test_duplicate_points_tie_semantics(pkg, synth, abi, ob):
     h.close()
 
 
+def test_one_ulp_neighbours_are_told_apart(pkg, synth, abi, ob):
+    """Every second point of every scan is a copy of its neighbour moved by ONE float ulp along one axis: for any query the two
+    copies' squared distances differ by ~1e-7 relative, far inside the float leaf filter's error interval, so the
+    search has to confirm both in double. Picking the wrong copy would move a 3d-3d residual by ~1e-6 m; the rows are
+    compared at 1e-9."""
+    prob, meta = synth.make_scene(n_frames=8, pts_per_frame=3000, n_keypoints=800, seed=23, new_mappoints=100, scan_kp=150)
+    a = {k: v.copy() for k, v in prob.arrays.items()}
+    pts = a["pts_xyz"].reshape(-1, 3)
+    rng = np.random.default_rng(5)
+    for f in range(8):
+        s = 3000 * f
+        twin = pts[s:s + 3000:2].copy()                  # every odd point becomes the twin of its even neighbour
+        ax = rng.integers(0, 3, 1500)
+        up = rng.integers(0, 2, 1500).astype(bool)
+        twin[np.arange(1500), ax] = np.nextafter(twin[np.arange(1500), ax], np.where(up, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32))
+        pts[s + 1:s + 3000:2] = twin
+    assert pts.dtype == np.float32
+    prob2 = abi.Problem(**a)
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(prob2, p)
+    o = ob.Oracle(prob2)
+    x0 = synth.perturb(meta["x_gt"], rng, n=1)[0]
+    cf, nf = h.eval_full(x0)
+    _cmp(cf[0], o.eval_cost(p, x0)[0])
+    _cmpn(nf[0], o.eval_normal(p, x0)[0])
+    h.build_problem(x0)
+    o.build_problem(p, x0)
+    x = synth.perturb(x0, rng, rot=1e-3, trans=1e-2, scale_rel=2e-3, n=1)[0]
+    rg, Jg, bg, kg = h.eval_residuals(x)
+    ro, Jo, bo, ko, _ = o.eval_residuals(x)
+    assert len(rg) == len(ro) > 150 and np.array_equal(kg, ko) and np.array_equal(bg, bo)
+    assert np.allclose(rg, ro, rtol=1e-9, atol=1e-9)
+    h.close()
+
+
 def test_many_covisible_keyframes(pkg, synth, abi, ob):
     prob, meta = synth.make_scene(n_frames=9, pts_per_frame=2000, n_keypoints=700, seed=19, n_covis=6, new_mappoints=80, scan_kp=120)
     p = abi.reference_yaml_params()
