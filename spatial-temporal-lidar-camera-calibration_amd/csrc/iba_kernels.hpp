@@ -497,9 +497,6 @@ static_assert(kPathMax % 4 == 0 && kPathMax >= kMaxTreeDepth, "register path mus
 #ifndef IBA_NN_TO_END
 #define IBA_NN_TO_END 0
 #endif
-#ifndef IBA_LEAF_UNROLL
-#define IBA_LEAF_UNROLL 1
-#endif
 #ifndef IBA_HIT_SLOTS
 #define IBA_HIT_SLOTS 3
 #endif
