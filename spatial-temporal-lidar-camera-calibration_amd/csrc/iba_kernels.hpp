@@ -1468,8 +1468,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         __syncthreads();
         IBA_STAMP(4); IBA_RELOAD_AT(4);
         // the two MapPoint -> LiDAR-frame queries (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
-        const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;
         auto queries = [&](uint32_t k, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
+            // the ~56 scalars of the two transforms are re-read from constant memory at each call site instead of being
+            // carried (spilled to VGPR lanes) across the 1-NN phase: see the note on the kernarg pointer at the top
+            typedef __attribute__((address_space(4))) const FrameHdr FrameHdrC;
+            typedef __attribute__((address_space(4))) const Cand CandC;
+            FrameHdrC* hq = (FrameHdrC*)&h; CandC* cq = (CandC*)&cd;
+            asm volatile("" : "+s"(hq), "+s"(cq));
+#define h (*hq)
+#define cd (*cq)
+            const double s = cd.s;
+            const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;
             const float4 mp = kp_mp[k];
             const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
             const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
@@ -1487,6 +1496,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
             qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
             qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+#undef h
+#undef cd
         };
         nn_rounds(std::integral_constant<int, 3>(), n3,
             [&](uint32_t i, bool& actA, bool& actC, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
