@@ -495,6 +495,18 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     for (const void* fn : fns)
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
 
+    {   // the frame kernel's view of its kernarg segment (see iba_kernarg_probe_kernel)
+        DevBuf<int32_t> okb; std::vector<int32_t> z(1, 0);
+        er = okb.upload(z);
+        if (er != hipSuccess) return bail("kernarg probe", er);
+        hipLaunchKernelGGL(iba_kernarg_probe_kernel, dim3(1), dim3(1), 0, h->stream, KArgs{h->dev_problem(), h->dprm, h->lay}, okb.p);
+        int32_t okv = 0;
+        er = hipStreamSynchronize(h->stream);
+        if (er == hipSuccess) er = hipMemcpy(&okv, okb.p, sizeof(okv), hipMemcpyDeviceToHost);
+        okb.release();
+        if (er != hipSuccess) return bail("kernarg probe", er);
+        if (!okv) { iba_destroy(h); return fail(nullptr, IBA_ERR_UNSUPPORTED, "kernel arguments do not start at offset 0 of the kernarg segment"); }
+    }
     iba_status ps = compute_plane_cache(h);
     if (ps != IBA_OK) { g_create_error = h->err; iba_destroy(h); return ps; }
     *out = h;

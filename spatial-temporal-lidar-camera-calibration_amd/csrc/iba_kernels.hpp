@@ -986,6 +986,16 @@ __device__ __forceinline__ uint32_t block_count(uint32_t my_count_wave_uniform, 
 
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so
 // all candidates of one frame share that XCD's L2 copy of the scan.
+// The frame kernel reads its first argument through __builtin_amdgcn_kernarg_segment_ptr() at offset 0. This probe,
+// launched once per handle with the same argument shape, confirms that the explicit arguments do start there.
+__global__ void iba_kernarg_probe_kernel(KArgs ka_by_value, int32_t* ok) {
+    typedef __attribute__((address_space(4))) const KArgs KArgsC;
+    KArgsC* ka = (KArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    *ok = (ka->lay.total == ka_by_value.lay.total && ka->lay.cand_cap == ka_by_value.lay.cand_cap && ka->dp.n_frames == ka_by_value.dp.n_frames &&
+           ka->dp.frames == ka_by_value.dp.frames && ka->prm.gate2 == ka_by_value.prm.gate2 && ka->prm.plane_cache == ka_by_value.prm.plane_cache) ? 1 : 0;
+}
+
 template <int MODE, bool SCAN_LDS>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FRAME_WAVES, IBA_FRAME_WAVES))) void iba_frame_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B,
                                                              double* __restrict__ frame_partials, uint32_t* __restrict__ corr_out,
