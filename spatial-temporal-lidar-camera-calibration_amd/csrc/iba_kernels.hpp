@@ -1311,10 +1311,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
     const PlaneRec* planes_cost = cached ? dp.plane_cost + h.pt_base : dp.scratch_cost + scr_off;
     const PlaneRec* planes_local = cached ? dp.plane_local + h.pt_base : dp.scratch_local + scr_off;
     uint32_t* s_bpos = s_list + K;   // NN results of the 3d-3d work list (second half of the aliased region)
-    auto fit_points = [&](const uint32_t* list, uint32_t count, double r2, int max_pts, PlaneRec* dst) {
+    auto fit_points = [&](const uint32_t* list, uint32_t count, double r2, int max_pts, PlaneRec* dst, const uint32_t* same_as = nullptr) {
         for (uint32_t i = (uint32_t)wave; i < count; i += kWaves) {   // one wave per point: kNN + covariance + eigen
             const uint32_t pos = list[i];
-            if (pos == kNone) continue;
+            if (pos == kNone || (same_as && same_as[i] == pos)) continue;   // same_as: this item's record already exists elsewhere
             const PlaneRec rec = plane_fit_wave(c.xs, c.ys, c.zs, s_nodes, P, D, pos, r2, max_pts);
             if (lane == 0) dst[pos] = rec;
         }
@@ -1523,7 +1523,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         IBA_STAMP(5); IBA_RELOAD_AT(5);
         if (!cached) {
             fit_points(s_nnA, n3, prm.neigh_radius2, prm.neigh_max_pts, dp.scratch_local + scr_off);
-            if (prm.use_plane) fit_points(s_nnC, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off);
+            if (prm.use_plane) {
+                // The cost path's neighbour is almost always the association's (the two queries differ by 1e-7): with the
+                // same radius and cap — the reference's yaml values — the record just fitted is the record wanted.
+                const bool same = prm.norm_radius2 == prm.neigh_radius2 && prm.norm_max_pts == prm.neigh_max_pts;
+                fit_points(s_nnC, n3, prm.norm_radius2, prm.norm_max_pts, dp.scratch_cost + scr_off, same ? s_nnA : nullptr);
+                if (same) {
+                    const PlaneRec* lc = dp.scratch_local + scr_off; PlaneRec* cc = dp.scratch_cost + scr_off;
+                    for (uint32_t i = tid; i < n3; i += kThreads) { const uint32_t pc = s_nnC[i]; if (pc != kNone && pc == s_nnA[i]) cc[pc] = lc[pc]; }
+                    __syncthreads();
+                }
+            }
         }
         IBA_STAMP(6); IBA_RELOAD_AT(6);
         for (uint32_t i = tid; i < n3; i += kThreads) {
