@@ -245,6 +245,19 @@ __device__ __forceinline__ void nn_search(const float* __restrict__ xs, const fl
     }
 }
 
+// value of lane j for a wave-uniform j (two v_readlane), and the value of lane - 1 (DPP wave_shr:1; lane 0 gets 0)
+__device__ __forceinline__ double lane_bcast(double v, int j) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, j), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), j);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_shr1(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x138, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // ---- wave-cooperative kNN(max_pts <= 32, d^2 < r2) + plane fit around scan point `cpos` ----
 // All 64 lanes must be active; traversal state is wave-uniform; leaf points are tested one per lane and
 // inserted into the sorted list held one entry per lane (lane i = i-th nearest).
@@ -274,17 +287,17 @@ __device__ inline PlaneRec plane_fit_wave(const float* __restrict__ xs, const fl
                     d2 = (dx * dx + dy * dy) + dz * dz;
                 }
                 unsigned long long mask = __ballot(d2 < bound);
-                while (mask) {
+                while (mask) {   // l, ins, count are wave-uniform: broadcasts are v_readlane, the shift is one DPP wave_shr — no LDS round trips
                     const int l = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    const double cd = __shfl(d2, l);
+                    const double cd = lane_bcast(d2, l);
                     if (cd < bound) {
                         const int ins = __popcll(__ballot(lane < count && my_d <= cd));
-                        const double up_d = __shfl_up(my_d, 1); const uint32_t up_p = __shfl_up(my_pos, 1);
+                        const double up_d = wave_shr1(my_d); const uint32_t up_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)my_pos, 0x138, 0xf, 0xf, false);
                         if (lane > ins) { my_d = up_d; my_pos = up_p; }
                         else if (lane == ins) { my_d = cd; my_pos = base + l; }
                         if (count < max_pts) ++count;
-                        if (count == max_pts) bound = fmin(r2, __shfl(my_d, max_pts - 1));
+                        if (count == max_pts) bound = fmin(r2, lane_bcast(my_d, max_pts - 1));
                     }
                 }
             }
@@ -304,14 +317,21 @@ __device__ inline PlaneRec plane_fit_wave(const float* __restrict__ xs, const fl
     }
     PlaneRec rec;
     rec.k = count; rec.pad = 0;
-    rec.far_d2 = count > 0 ? __shfl(my_d, count - 1) : 0.0;
-    // ComputeCovariance: one-pass raw moments in list order (pointcloud.h:126-158)
+    rec.far_d2 = count > 0 ? lane_bcast(my_d, count - 1) : 0.0;
+    // ComputeCovariance: one-pass raw moments in list order (pointcloud.h:126-158). Lane j gathers list entry j and forms
+    // its nine terms (all gathers in flight together); the sums then run over j in list order on broadcast values, so
+    // every addition happens in the reference's order.
+    double mine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double mx = 0, my = 0, mz = 0;
+    if (lane < count) {
+        mx = (double)xs[my_pos]; my = (double)ys[my_pos]; mz = (double)zs[my_pos];
+        mine[0] = mx; mine[1] = my; mine[2] = mz;
+        mine[3] = mx * mx; mine[4] = mx * my; mine[5] = mx * mz; mine[6] = my * my; mine[7] = my * mz; mine[8] = mz * mz;
+    }
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < count; ++j) {
-        const uint32_t pj = __shfl(my_pos, j);
-        const double px = (double)xs[pj], py = (double)ys[pj], pz = (double)zs[pj];
-        c[0] += px; c[1] += py; c[2] += pz;
-        c[3] += px * px; c[4] += px * py; c[5] += px * pz; c[6] += py * py; c[7] += py * pz; c[8] += pz * pz;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) c[q] += lane_bcast(mine[q], j);
     }
     const double inv_n = (double)count;
     for (int i = 0; i < 9; ++i) c[i] /= inv_n;
@@ -320,17 +340,20 @@ __device__ inline PlaneRec plane_fit_wave(const float* __restrict__ xs, const fl
     cov[1] = cov[3] = c[4] - c[0] * c[1]; cov[2] = cov[6] = c[5] - c[0] * c[2]; cov[5] = cov[7] = c[7] - c[1] * c[2];
     double nrm[3]; dev_smallest_evec(cov, nrm);
     double reg = 0;
-    for (int j = 0; j < count; ++j) {
-        const uint32_t pj = __shfl(my_pos, j);
-        const double ax = (double)xs[pj] - qx, ay = (double)ys[pj] - qy, az = (double)zs[pj] - qz;
-        reg += fabs(ax * nrm[0] + ay * nrm[1] + az * nrm[2]);
+    {
+        const double ax = mx - qx, ay = my - qy, az = mz - qz;
+        const double term = fabs(ax * nrm[0] + ay * nrm[1] + az * nrm[2]);   // lane j: |(p_j - c) . n|
+        for (int j = 0; j < count; ++j) reg += lane_bcast(term, j);
     }
     rec.nx = nrm[0]; rec.ny = nrm[1]; rec.nz = nrm[2]; rec.reg_sum = reg;
     return rec;
 }
 
 // grid: (ceil(maxP / waves_per_block), n_frames); one wave per scan point
-__global__ __launch_bounds__(256) void iba_plane_kernel(DevProblem dp, double r2, int max_pts, PlaneRec* out) {
+#ifndef IBA_PLANE_WAVES
+#define IBA_PLANE_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IBA_PLANE_WAVES, IBA_PLANE_WAVES))) void iba_plane_kernel(DevProblem dp, double r2, int max_pts, PlaneRec* out) {
     const FrameHdr& h = dp.frames[blockIdx.y];
     const uint32_t pos = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (pos >= h.P) return;
