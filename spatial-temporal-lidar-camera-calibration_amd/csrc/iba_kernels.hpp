@@ -1345,13 +1345,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
     };
 
     // ---- exact 1-NN of a work list in rounds (nn_dual_step). Round 0: every item descends and scans its first leaf —
-    // uniform work, and 72 % of the queries end there. The unfinished ones park 64 B of state in LDS (the keypoint grid's and
+    // uniform work, and 72 % of the queries end there. The unfinished ones park 80 B of state in LDS (the keypoint grid's and
     // the candidate queue's storage, dead by now) and are re-spread over the block with more lanes each; a round visits
     // one more leaf per query until few enough are left to run to the end. Slot order is irrelevant (results go to
     // per-item arrays), so the compaction is one LDS atomic per unfinished query.
     //   load(i, actA, actC, ax, ay, az, qx, qy, qz): which queries item i has, and their coordinates
     //   store(i, actA, actC, st): the finished search of item i
-    struct HardState { double a[3], c[3]; uint32_t item_go, leaf_done, bposA, bposC; };   // item | go << 24 | actA << 30 | actC << 31
+    struct HardState { double a[3], c[3], bestA, bestC; uint32_t item_go, leaf_done, bposA, bposC; };   // item | go << 24 | actA << 30 | actC << 31
     auto nn_rounds = [&](auto which_tag, uint32_t n_list, auto&& load, auto&& store) {
         constexpr int WHICH = decltype(which_tag)::value;
         HardState* s_hard = (HardState*)(smem + lay.off_bitmap);
@@ -1385,9 +1385,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
                         i = hs.item_go & 0xffffffu; st.go = (int)((hs.item_go >> 24) & 31u); actA = (hs.item_go >> 30) & 1u; actC = hs.item_go >> 31;
                         st.leaf = hs.leaf_done & 0xffffu; st.done = hs.leaf_done >> 16; st.bposA = hs.bposA; st.bposC = hs.bposC;
                         ax = hs.a[0]; ay = hs.a[1]; az = hs.a[2]; qx = hs.c[0]; qy = hs.c[1]; qz = hs.c[2];
-                        // the running bests are the exact distances of the stored positions (same expression as the leaf scan)
-                        if (st.bposA != kNone) { float x, y, z; load_pt<!SCAN_LDS>(c, st.bposA, x, y, z); const double dx = ax - (double)x, dy = ay - (double)y, dz = az - (double)z; st.bestA = (dx * dx + dy * dy) + dz * dz; }
-                        if (st.bposC != kNone) { float x, y, z; load_pt<!SCAN_LDS>(c, st.bposC, x, y, z); const double dx = qx - (double)x, dy = qy - (double)y, dz = qz - (double)z; st.bestC = (dx * dx + dy * dy) + dz * dz; }
+                        st.bestA = hs.bestA; st.bestC = hs.bestC;   // parked with the state: no gather + recomputation on the way back in
                     }
                 }
                 __syncthreads();   // every state of this pass is in registers: its slot may be overwritten
@@ -1404,7 +1402,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
                                 if ((tid & (G - 1)) == 0) {
                                     HardState hs; hs.a[0] = ax; hs.a[1] = ay; hs.a[2] = az; hs.c[0] = qx; hs.c[1] = qy; hs.c[2] = qz;
                                     hs.item_go = i | ((uint32_t)st.go << 24) | ((actA ? 1u : 0u) << 30) | ((actC ? 1u : 0u) << 31);
-                                    hs.leaf_done = st.leaf | (st.done << 16); hs.bposA = st.bposA; hs.bposC = st.bposC;
+                                    hs.leaf_done = st.leaf | (st.done << 16); hs.bposA = st.bposA; hs.bposC = st.bposC; hs.bestA = st.bestA; hs.bestC = st.bestC;
                                     s_hard[slot] = hs;
                                 }
                                 i = kNone;
