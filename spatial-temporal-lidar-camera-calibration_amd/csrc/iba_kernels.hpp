@@ -1756,8 +1756,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
     const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
     if (prm.use_3d3d) {
-        const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
         auto q_cost = [&](uint32_t k, double& qx, double& qy, double& qz) {
+            // transform constants re-read from constant memory at each call site (see `queries` in the fused branch)
+            typedef __attribute__((address_space(4))) const FrameHdr FrameHdrC;
+            typedef __attribute__((address_space(4))) const Cand CandC;
+            FrameHdrC* hq = (FrameHdrC*)&h; CandC* cq = (CandC*)&cd;
+            asm volatile("" : "+s"(hq), "+s"(cq));
+#define h (*hq)
+#define cd (*cq)
+            const double s = cd.s;
+            const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
             const float4 mp = kp_mp[k];
             const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;   // CV_32F product (:232)
             const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
@@ -1767,6 +1775,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
             qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
             qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+#undef h
+#undef cd
         };
         nn_rounds(std::integral_constant<int, 2>(), n3,
             [&](uint32_t i, bool& actA, bool& actC, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
