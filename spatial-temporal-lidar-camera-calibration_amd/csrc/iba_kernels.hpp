@@ -1856,6 +1856,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
 // IRLS weights as Ceres' Corrector applies them (rho'' <= 0), accumulated as the upper triangle of
 // H = sum w J^T J, b = sum w J^T r. Derivatives are analytic: the chain rule through the same
 // expressions the reference's Jets differentiate, with dR/dx, dt/dx from the host duals (Cand).
+// FMA contraction inside the Jacobian-path functions only (the cost path is compiled with -ffp-contract=off throughout).
+// -DIBA_JAC_NO_FMA builds them uncontracted, for parity studies (tools/soak_parity.py).
+#ifdef IBA_JAC_NO_FMA
+#define IBA_JAC_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define IBA_JAC_CONTRACT _Pragma("clang fp contract(fast)")
+#endif
 struct NAcc { double H[28], b[7], chi2, cost, nf2d, nfpl, nfpt, nres; };
 
 __device__ __forceinline__ void huber_w(double a, double s, double& rho0, double& w) {
@@ -1871,7 +1878,7 @@ __device__ __forceinline__ int hidx(int i, int j) { return i * 7 - (i * (i - 1))
 template <class SlotFn>
 __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K,
                                                  double u0, double v0, const double* p0, const double* n0, double* z6, SlotFn slot) {
-    #pragma clang fp contract(fast)   // Jacobian path: H, b carry a 1e-10 relative budget, not bit parity
+    IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
     double p0c[3], n0c[3];
     for (int r = 0; r < 3; ++r) {
         p0c[r] = ((c.R[r * 3] * p0[0] + c.R[r * 3 + 1] * p0[1]) + c.R[r * 3 + 2] * p0[2]) + c.t[r];
@@ -1926,11 +1933,11 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
 
 __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
                                           double u0, double v0, const double* p0, const double* n0, NAcc& A) {
-    #pragma clang fp contract(fast)   // Jacobian path: H, b carry a 1e-10 relative budget, not bit parity
+    IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
     double z6[6];
     double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0;
     const int nconv = plane_factor_core(c, h, dp, k, K, u0, v0, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
-#pragma clang fp contract(fast)
+IBA_JAC_CONTRACT
         ssq += ru * ru + rv * rv;
         G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
         Gr += gu * ru + gv * rv; Hr += hu * ru + hv * rv;
@@ -1949,7 +1956,7 @@ __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, cons
 
 // M = Rlc (s m) + tlc and dM/dx for the 3d-3d factors (IBACalib2.hpp:570-584, 611-625)
 __device__ __forceinline__ void p2x_core(const Cand& c, const FrameHdr& h, const float4 mp, double* M, double dM[7][3]) {
-    #pragma clang fp contract(fast)   // Jacobian path: H, b carry a 1e-10 relative budget, not bit parity
+    IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
     const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
     const double m[3] = {((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3], ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7],
                          ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11]};
@@ -1966,7 +1973,7 @@ __device__ __forceinline__ void p2x_core(const Cand& c, const FrameHdr& h, const
 }
 
 __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const DevParams& prm, const float4 mp, const double* Q, const double* n, bool is_plane, NAcc& A) {
-    #pragma clang fp contract(fast)   // Jacobian path: H, b carry a 1e-10 relative budget, not bit parity
+    IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
     double M[3], dM[7][3];
     p2x_core(c, h, mp, M, dM);
     const double e[3] = {M[0] - Q[0], M[1] - Q[1], M[2] - Q[2]};
