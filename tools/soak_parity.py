@@ -48,6 +48,18 @@ for sc in range(n_scenes):
             dev = float(np.max(np.abs(nfm[b].H_np() - Ho)) / np.max(np.abs(Ho)))
             worst_h = max(worst_h, dev)
             if dev > 1e-7: msgs.append((b, "H", dev))
+    # frozen problem (BuildProblem at xs[0], residual blocks at the other candidates) and the raw correspondence set of a frame
+    h.build_problem(xs[0]); o.build_problem(p, xs[0])
+    for b, (gf, of) in enumerate(zip(h.eval_factors(xs), o.eval_factors(p, xs))):
+        if gf.counts() != of.counts(): msgs.append((b, "frozen counts", gf.counts(), of.counts()))
+        Ho = of.H_np()
+        if np.max(np.abs(Ho)) > 0:
+            dev = float(np.max(np.abs(gf.H_np() - Ho)) / np.max(np.abs(Ho)))
+            worst_h = max(worst_h, dev)
+            if dev > 1e-7: msgs.append((b, "frozen H", dev))
+    fsel = int(rng.integers(0, nf))
+    gk, gp = h.correspondences(xs[0], fsel); ok_, op_ = o.correspondences(p, xs[0], fsel)
+    if not (np.array_equal(gk, ok_) and np.array_equal(gp, op_)): msgs.append(("corr", fsel, len(gk), len(ok_)))
     h.close()
     tag = "ok " if not msgs else "BAD"
     bad += bool(msgs)
