@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
         const float4 nan4 = make_float4(qn, qn, qn, qn);
         auto group_base = [&](uint32_t g) -> uint32_t {   // first tree position of group g, or kNone
             if (g >= n_groups) return kNone;
-            const uint32_t b4 = SCAN_LDS ? g * 4u : (uint32_t)s_vlist[g >> 4] * (uint32_t)kChunk + (g & 15u) * 4u;
+            const uint32_t b4 = SCAN_LDS ? g * 4u : (uint32_t)s_vlist[g / (uint32_t)(kChunk / 4)] * (uint32_t)kChunk + (g % (uint32_t)(kChunk / 4)) * 4u;
             return b4 < Ppad ? b4 : kNone;
         };
         float4 X = nan4, Y = nan4, Z = nan4;   // software pipeline: the next 16-byte loads are in flight while 4 points are tested

@@ -10,7 +10,10 @@
 
 namespace iba {
 
-constexpr int kChunk = 64;           // points per culling chunk (~3 kd leaves): static AABB, frustum-tested per candidate
+#ifndef IBA_CHUNK
+#define IBA_CHUNK 64
+#endif
+constexpr int kChunk = IBA_CHUNK;           // points per culling chunk (~3 kd leaves): static AABB, frustum-tested per candidate
 constexpr int kMaxCovis = 10;        // IBAPlaneEdge pads to 10 covisible KFs (IBACalib.hpp:133-137)
 constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum block
 #ifndef IBA_GRID_CELL
