@@ -15,17 +15,7 @@ synth = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.s
 abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi")
 from oracle import binding as ob
 ob.lib()
-n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-INT = ("valid_cnt_3d_2d", "cnt_3d_2d", "cnt_3d_3d", "valid_cnt_3d_3d", "valid_pl_3d_3d", "valid_pt_3d_3d", "frames_used", "n_corr")
-bad = 0
-worst_h = 0.0
-t0 = time.time()
-for sc in range(n_scenes):
-    seed = seed0 + sc
-    rng = np.random.default_rng(seed)
-    nf = int(rng.integers(1, 5)); pts = int(rng.choice([300, 900, 2500, 6000, 14000, 40000])); kp = int(rng.choice([150, 600, 2000, 3000]))
-    prob, meta = synth.make_scene(n_frames=nf, pts_per_frame=pts, n_keypoints=kp, seed=seed)
+def random_params(rng):
     p = abi.reference_yaml_params()
     if rng.random() < 0.3: p.use_plane = 0
     if rng.random() < 0.2: p.err_weight[1] = 0.0
@@ -40,6 +30,20 @@ for sc in range(n_scenes):
         p.corr_3d_2d_threshold = float(rng.choice([5.0, 40.0])); p.corr_3d_3d_threshold = float(rng.choice([0.3, 2.0, 10.0]))
         p.max_3d_dist = float(rng.choice([0.3, 1.0, 5.0])); p.num_min_corr = int(rng.choice([10, 30, 100])); p.num_min_corr_cost = int(rng.choice([10, 30, 100]))
         p.robust_kernel_delta = float(rng.choice([1.0, 2.98])); p.robust_kernel_3ddelta = float(rng.choice([0.2, 1.0]))
+    return p
+
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+INT = ("valid_cnt_3d_2d", "cnt_3d_2d", "cnt_3d_3d", "valid_cnt_3d_3d", "valid_pl_3d_3d", "valid_pt_3d_3d", "frames_used", "n_corr")
+bad = 0
+worst_h = 0.0
+t0 = time.time()
+for sc in range(n_scenes):
+    seed = seed0 + sc
+    rng = np.random.default_rng(seed)
+    nf = int(rng.integers(1, 5)); pts = int(rng.choice([300, 900, 2500, 6000, 14000, 40000])); kp = int(rng.choice([150, 600, 2000, 3000]))
+    prob, meta = synth.make_scene(n_frames=nf, pts_per_frame=pts, n_keypoints=kp, seed=seed)
+    p = random_params(rng)
     h = pkg.IbaHandle(prob, p); o = ob.Oracle(prob)
     scale = float(rng.choice([1e-4, 1e-3, 5e-3, 2e-2]))
     xs = synth.perturb(meta["x_gt"], rng, rot=scale, trans=5 * scale, scale_rel=2 * scale, n=int(rng.integers(1, 9)))
@@ -71,6 +75,18 @@ for sc in range(n_scenes):
     fsel = int(rng.integers(0, nf))
     gk, gp = h.correspondences(xs[0], fsel); ok_, op_ = o.correspondences(p, xs[0], fsel)
     if not (np.array_equal(gk, ok_) and np.array_equal(gp, op_)): msgs.append(("corr", fsel, len(gk), len(ok_)))
+    # new parameters on the live handle (plane memo rebuilt / dropped as needed), same candidates
+    p2 = random_params(rng)
+    p2.max_pixel_dist = p.max_pixel_dist   # baked into the keypoint grid: iba_set_params refuses to change it (checked by the tests)
+    h.set_params(p2)
+    cf2, nf2 = h.eval_full(xs); oc2 = o.eval_cost(p2, xs); on2 = o.eval_normal(p2, xs)
+    for b in range(len(xs)):
+        for k in INT:
+            if getattr(cf2[b], k) != getattr(oc2[b], k): msgs.append((b, "after set_params", k, getattr(cf2[b], k), getattr(oc2[b], k)))
+        for k in ("f1", "f2", "C"):
+            a, r = getattr(cf2[b], k), getattr(oc2[b], k)
+            if not ((np.isnan(a) and np.isnan(r)) or a == r or abs(a - r) <= 1e-9 * abs(r) + 1e-12): msgs.append((b, "after set_params", k, a, r))
+        if nf2[b].counts() != on2[b].counts(): msgs.append((b, "after set_params normal counts"))
     h.close()
     tag = "ok " if not msgs else "BAD"
     bad += bool(msgs)
