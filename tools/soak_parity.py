@@ -43,6 +43,18 @@ for sc in range(n_scenes):
     rng = np.random.default_rng(seed)
     nf = int(rng.integers(1, 5)); pts = int(rng.choice([300, 900, 2500, 6000, 14000, 40000])); kp = int(rng.choice([150, 600, 2000, 3000]))
     prob, meta = synth.make_scene(n_frames=nf, pts_per_frame=pts, n_keypoints=kp, seed=seed)
+    if rng.random() < 0.4:   # ragged frames: truncated scans down to a handful of points, or none at all
+        a = {k: v.copy() for k, v in prob.arrays.items()}
+        po = a["pt_offset"].astype(np.int64)
+        keep = np.ones(int(po[-1]), bool)
+        for f in range(nf):
+            if rng.random() < 0.6:
+                cnt = int(rng.choice([0, 1, 2, 3, 5, 17, 63, 64, 65, int(rng.integers(0, pts + 1))]))
+                keep[po[f] + min(cnt, pts):po[f + 1]] = False
+        cnts = np.array([keep[po[i]:po[i + 1]].sum() for i in range(nf)])
+        a["pts_xyz"] = a["pts_xyz"].reshape(-1, 3)[keep].reshape(-1)
+        a["pt_offset"] = np.concatenate([[0], np.cumsum(cnts)]).astype(np.uint64)
+        prob = abi.Problem(**a)
     p = random_params(rng)
     h = pkg.IbaHandle(prob, p); o = ob.Oracle(prob)
     scale = float(rng.choice([1e-4, 1e-3, 5e-3, 2e-2]))
