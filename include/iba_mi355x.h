@@ -243,6 +243,9 @@ iba_status iba_finalize_normal(const iba_params* params, const double* partials,
  * measured with HIP events on the launch stream (ms), and the frame-kernel launch shape. */
 iba_status iba_last_kernel_ms(iba_handle* h, float* frame_kernel_ms, float* total_ms);
 iba_status iba_set_timing(iba_handle* h, int32_t enable);
+/* the same split by kernel: association kernel (projection, 2d-3d association, 3d-2d residuals), grouped 1-NN search kernel
+ * (3d-3d terms), and everything after them (factor kernel, sums) */
+iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_kernel_ms, float* rest_ms);
 /* debug: host copy of the summed partial blocks of the last iba_eval_* call */
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
 /* debug: exact 1-NN (nanoflann semantics with the lowest-index tie rule, iba_global.cpp:116-122) of n LiDAR-frame query

@@ -20,6 +20,7 @@
 #include "iba_kernels.hpp"
 #include "iba_lm.hpp"
 #include "iba_mads.hpp"
+#include "iba_split_kernels.hpp"
 #include "iba_types.hpp"
 
 using namespace iba;
@@ -55,17 +56,31 @@ struct iba_handle {
     std::string err;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    bool timing = false, timing_recorded = false;
+    bool timing = false, timing_recorded = false, timing_split = false, frozen_split = false;
     float last_frame_ms = 0.f, last_total_ms = 0.f;
     int64_t n_points = 0, n_keypoints = 0;
     uint32_t maxP = 0, maxPpad = 0, maxK = 0, maxNodes = 0, maxBitmapWords = 0, maxCoarse = 0;
     bool scan_lds = false;
     LdsLayout lay{};
+    // two-kernel path (plane_cache = 1): association kernel + grouped search kernel (iba_split_kernels.hpp)
+    bool split = true;                    // IBA_MONOLITHIC=1 selects the one-kernel path for comparisons
+    LdsLayout alay{};                     // LDS plan of iba_assoc_kernel
+    uint32_t maxKw = 0;                   // max over frames of the keypoints that can own a term (MapPoint or covisible match)
+    int assoc_dbg = 0;
+    int nn_dbg = 0;                       // IBA_NN_DBG: cut the search kernel short (timing attribution; results are garbage)
+    int nn_cg_max = 8;                    // candidates per search block (power of two <= kMaxGroup)
+    DevBuf<uint32_t> d_lcount, d_lcount_frozen;   // work-list length per (candidate, frame)
+    DevBuf<float4> d_fmp, d_fmp_frozen;   // MapPoint of every work-list entry
+    uint32_t lstride = 1;                 // entries per (candidate, frame) row of the lists: no list is longer than maxKw
+    int nn_ns = 1;                        // search blocks per (frame, candidate group): ceil(maxKw / kSliceW)
+    DevBuf<double> d_nn_partials;         // IBA_MAX_BATCH * n_frames * kMaxSlices * kNNPartial
+    hipEvent_t ev_mid = nullptr;
+    float last_assoc_ms = 0.f, last_nn_ms = 0.f;
 
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
     DevBuf<float> xs, ys, zs, chunk_box; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
     DevBuf<float4> pts4;   // the same scan points as (x, y, z, original index bits): one 16 B gather per point where lanes diverge
-    DevBuf<float2> kp_uv; DevBuf<float4> kp_mp;
+    DevBuf<float2> kp_uv; DevBuf<float4> kp_mp; DevBuf<uint16_t> kp_fl;
     DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
     DevBuf<PlaneRec> plane_cost, plane_local;
@@ -98,7 +113,7 @@ struct iba_handle {
     DevProblem dev_problem() const {
         DevProblem dp{};
         dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p; dp.chunk_box = chunk_box.p; dp.pts4 = pts4.p;
-        dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.coarse_start = coarse_start.p; dp.crec = crec.p;
+        dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.kp_fl = kp_fl.p; dp.coarse_start = coarse_start.p; dp.crec = crec.p;
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
@@ -187,6 +202,58 @@ bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
     return L.total <= kLdsBytes;
 }
 
+// LDS plan of iba_assoc_kernel: per-keypoint tables, the candidate queue (4 B per queued point), and the reject bitmap, whose
+// storage — dead after the streaming pass — becomes the head of the pair list (16 B per (point, keypoint) pair). What is left
+// of half of the LDS (two blocks per CU) is split between queue and pair list; a full queue or list only costs speed (inline
+// exact tests + a rescan), never correctness.
+bool layout_assoc(iba_handle* h, LdsLayout& L) {
+    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;
+    L = LdsLayout{};
+    uint32_t off = 0;
+    L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
+    L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
+    off = align_up(off, 8); L.off_nodes = off;
+    off = align_up(off, 16); L.off_red = off; off += red_bytes;
+    L.off_vis = off; L.vis_words = 2u * kWaves * ((h->maxPpad / (uint32_t)kChunk + kThreads) / kThreads) + 2u;
+    off += 4u * L.vis_words + 2u * (h->maxPpad / (uint32_t)kChunk + 2u);
+    off = align_up(off, 4); L.off_cstart = off; off += 2u * std::max(h->maxCoarse, 1u);
+    off = align_up(off, 16); L.off_kuv = off; off += 8u * std::max(h->maxK, 1u);
+    L.off_kfl = off; off += 2u * std::max(h->maxK, 1u);
+    off = align_up(off, 16);
+    const uint32_t bm_bytes = align_up(4u * std::max(h->maxBitmapWords, 1u), 16u);
+    if (off + bm_bytes + 4u * 512u > kLdsBytes) return false;
+    const uint32_t want_q = std::max<uint32_t>(h->maxPpad / 2u, 512u) * 4u;      // nothing queues more than half of a scan
+    const uint32_t want_p = std::max<uint32_t>(2u * h->maxK, 256u) * 16u;         // ~1 pair per matched keypoint, x 1.7 for the f32 margin
+    int nb_max = 2;
+    if (const char* e = std::getenv("IBA_ASSOC_BLOCKS")) nb_max = std::max(1, std::atoi(e));   // diagnostic
+    uint32_t room = (kLdsBytes - off - bm_bytes) & ~15u;   // beyond the tables and the bitmap
+    for (int nb = nb_max; nb >= 2; --nb) {
+        const uint32_t share = (kLdsBytes / (uint32_t)nb) & ~255u;
+        if (off + bm_bytes < share && share - off - bm_bytes >= std::max<uint32_t>(h->maxPpad / 16u, 512u) * 4u) { room = (share - off - bm_bytes) & ~15u; break; }
+    }
+    // the queue first (a scan queues ~8 % of its points at 2000 keypoints), the pair list gets the bitmap and the rest
+    uint32_t bytes_q = std::min(want_q, std::max<uint32_t>(std::min<uint32_t>(room, std::max<uint32_t>(h->maxPpad / 8u, 1024u) * 4u), room / 2u) & ~15u);
+    uint32_t bytes_p = std::min(want_p, bm_bytes + ((room - bytes_q) & ~15u));
+    if (const char* e = std::getenv("IBA_CAND_BYTES")) bytes_q = std::min<uint32_t>((uint32_t)std::atoi(e) & ~15u, bytes_q);   // diagnostic
+    if (const char* e = std::getenv("IBA_PAIR_BYTES")) bytes_p = std::min<uint32_t>((uint32_t)std::atoi(e) & ~15u, bytes_p);   // diagnostic
+    L.off_cand = off; L.cand_cap = bytes_q / 4u; off += bytes_q;
+    L.off_bitmap = off; L.off_pair = off; L.pair_cap = bytes_p / 16u; off += std::max(bm_bytes, bytes_p);
+    L.total = off;
+    return L.total <= kLdsBytes;
+}
+
+// LDS plan of iba_nn_kernel: kd nodes, counters, the candidates' transform constants and one result slot (8 B) per work entry
+bool layout_nn(const iba_handle* h, NNLayout& L) {
+    L = NNLayout{};
+    uint32_t off = 0;
+    L.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
+    off = align_up(off, 16); L.off_misc = off; off += 128u;
+    off = align_up(off, 16); L.off_cd = off; off += 8u * (uint32_t)kCdDoubles * (uint32_t)kMaxGroup;
+    off = align_up(off, 16); L.off_res = off; off += 8u * kSliceW * (uint32_t)kMaxGroup;
+    L.total = off;
+    return L.total <= kLdsBytes;
+}
+
 iba_status compute_plane_cache(iba_handle* h) {
     const iba_params& p = h->params;
     if (!p.plane_cache) return IBA_OK;   // planes are refitted inside every evaluation
@@ -241,8 +308,8 @@ iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_fra
     const int per_xcd = (h->n_frames + 7) / 8;
     const dim3 grid(8 * per_xcd * B), block(kThreads);
     if (h->n_frames == 0) return IBA_OK;
-    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, KArgs{dp, h->dprm, h->lay}, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->maxK);
-    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, KArgs{dp, h->dprm, h->lay}, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->maxK);
+    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, KArgs{dp, h->dprm, h->lay}, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->lstride);
+    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, KArgs{dp, h->dprm, h->lay}, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->lstride);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }
@@ -261,11 +328,94 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     return IBA_OK;
 }
 
+iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
+    if (h->n_frames == 0 || h->maxK == 0) return IBA_OK;
+    const dim3 grid(h->n_frames, B);
+    const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
+    hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+    HIP_TRY(h, hipGetLastError());
+    return IBA_OK;
+}
+
+
+// work lists of B candidates (the lists also carry the residual blocks to the factor kernel)
+iba_status ensure_lists(iba_handle* h, int B, hipStream_t st) {
+    if (h->assoc_cap >= B) return IBA_OK;
+    HIP_TRY(h, hipStreamSynchronize(st)); HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->d_assoc.release(); h->d_flist.release(); h->d_fcount.release(); h->d_lcount.release(); h->d_fmp.release();
+    if (!h->split || !h->params.plane_cache) HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
+    HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
+    HIP_TRY(h, h->d_fmp.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
+    HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
+    HIP_TRY(h, h->d_lcount.alloc((size_t)B * std::max(h->n_frames, 1)));
+    h->assoc_cap = B;
+    return IBA_OK;
+}
+
+bool use_split(const iba_handle* h) { return h->split && h->params.plane_cache != 0; }
+
+// Two-kernel evaluation chain (plane_cache = 1) on stream st: [hand-eye] -> association -> grouped 1-NN -> [factors] -> sums.
+// want: bit 0 = BuildProblem association (+ normal equations when `factors`), bit 1 = BAError cost.
+// frozen: B = 1, the lists go to the frozen problem's buffers (iba_build_problem).
+iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen, bool factors, double* d_partials, hipStream_t st) {
+    const int nf = h->n_frames;
+    if (!frozen) { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
+    uint4* fl = frozen ? h->d_flist_frozen.p : h->d_flist.p;
+    uint32_t* fc = frozen ? h->d_fcount_frozen.p : h->d_fcount.p;
+    uint32_t* lc = frozen ? h->d_lcount_frozen.p : h->d_lcount.p;
+    const DevProblem dp = h->dev_problem();
+    const int nrec = factors ? h->nrec : nf;
+    float4* fm = frozen ? h->d_fmp_frozen.p : h->d_fmp.p;
+    // candidates per search block: a power of two; list positions are cut into slices of a fixed width
+    int CG = 1; while (CG < std::min(B, h->nn_cg_max)) CG <<= 1;
+    const int ngroups = (B + CG - 1) / CG;
+    const int NS = h->nn_ns;
+    NNLayout nl;
+    if (!layout_nn(h, nl)) return fail(h, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel");
+    if (nf == 0) {
+        HIP_TRY(h, hipMemsetAsync(d_partials, 0, sizeof(double) * (size_t)B * kPartialStride, st));
+        if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev0, st)); HIP_TRY(h, hipEventRecord(h->ev_mid, st)); HIP_TRY(h, hipEventRecord(h->ev1, st)); HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
+        return IBA_OK;
+    }
+    if (want & 2) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
+        hipLaunchKernelGGL(iba_he_kernel, dim3((B * nf + 63) / 64), dim3(64), 0, st, dp, dc, B, h->d_he.p);
+        HIP_TRY(h, hipGetLastError());
+    }
+    const int per_xcd = (nf + 7) / 8;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    const bool search = (want & 1) || h->dprm.use_3d3d;
+    const int nn_nrec = nf * NS;
+    // (Splitting the batch into chunks so that the association kernel of chunk i + 1 runs beside the search kernel of chunk i
+    // on a second stream was measured: 0.93 ms -> 0.99 / 1.07 / 1.22 ms for 2 / 4 / 8 chunks. The kernels do not overlap enough
+    // to pay for the extra launches and event hops; one launch each it is.)
+    hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (h->assoc_dbg << 8),
+                       h->d_frame_partials.p, nrec, (uint32_t*)nullptr, h->d_he.p, fl, fm, fc, lc, (int)h->lstride);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_mid, st));
+    if (search) {
+        const dim3 grid(8 * per_xcd * ngroups * NS), block(kNNThreads);
+        const NNArgs na{dp, h->dprm, nl};
+        const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
+        if (wA && wC) hipLaunchKernelGGL((iba_nn_kernel<3>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg);
+        else if (wA) hipLaunchKernelGGL((iba_nn_kernel<1>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg);
+        else hipLaunchKernelGGL((iba_nn_kernel<2>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
+    if (factors) { iba_status s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, nf, st); if (s != IBA_OK) return s; }
+    hipLaunchKernelGGL(iba_reduce2_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, search ? h->d_nn_partials.p : (const double*)nullptr, nn_nrec, d_partials);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
+    return IBA_OK;
+}
+
 iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
     if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    if (use_split(h)) return run_split(h, dc, B, 2, false, false, d_partials, st);
+    h->timing_split = false;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
     s = launch_frame<MODE_COST>(h, dc, B, h->d_frame_partials.p, nullptr, nullptr, h->n_frames, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
@@ -301,8 +451,9 @@ void iba_destroy(iba_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
-    h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release();
+    h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release();
+    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
@@ -359,10 +510,16 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         const double* in = d->intrinsics + 6 * f;
         auto part1by1 = [](uint32_t v) { v &= 0xFFFFu; v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
         const float* uv0 = d->kp_uv + 2 * d->kp_offset[f];
-        std::vector<std::pair<uint32_t, uint32_t>> key(K);
+        // internal keypoint order = coarse cell of the keypoint grid (row-major), Morton order of the pixel inside a cell: the
+        // grid's record e IS keypoint e, so the kernels keep (u, v) of all keypoints in LDS and need no id lookup; neighbours
+        // in the list are neighbours in the image, and their MapPoint queries walk neighbouring kd leaves
+        const int gw_ = (int)std::ceil(in[4] / kGridCell) + 3, gh_ = (int)std::ceil(in[5] / kGridCell) + 3;
+        const uint32_t gwc_ = ((uint32_t)gw_ + (1u << kCoarseShift) - 1u) >> kCoarseShift;
+        std::vector<std::pair<uint64_t, uint32_t>> key(K);
         for (uint32_t k = 0; k < K; ++k) {
             const uint32_t qx = (uint32_t)std::min(65535.f, std::max(0.f, uv0[2 * k] * 8.f)), qy = (uint32_t)std::min(65535.f, std::max(0.f, uv0[2 * k + 1] * 8.f));
-            key[k] = {part1by1(qx) | (part1by1(qy) << 1), k};
+            const uint32_t cell = (uint32_t)(grid_cell(uv0[2 * k + 1], gh_) >> kCoarseShift) * gwc_ + (uint32_t)(grid_cell(uv0[2 * k], gw_) >> kCoarseShift);
+            key[k] = {((uint64_t)cell << 32) | (part1by1(qx) | (part1by1(qy) << 1)), k};
         }
         std::sort(key.begin(), key.end());
         b.kp_order.resize(K); b.kp_inv.resize(K); b.uv.resize(2 * (size_t)K);
@@ -403,7 +560,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     std::vector<float> xs(pt_base, qnan), ys(pt_base, qnan), zs(pt_base, qnan);
     std::vector<uint32_t> perm(pt_base, 0u), inv_perm(pt_base, 0u);
     std::vector<float4> pts4(pt_base, float4{qnan, qnan, qnan, 0.f});
-    std::vector<float> chunk_box(6 * (size_t)box_base, qnan);
+    std::vector<float> chunk_box(8 * (size_t)box_base, qnan);   // [chunk][8]: min xyz, -, max xyz, - (two 16-byte loads)
     std::vector<TreeNode> nodes(node_base);
     std::vector<float2> kp_uv(kp_base); std::vector<float4> kp_mp(kp_base), crec(kp_base);
     std::vector<uint32_t>& kp_ext = h->h_kp_ext; kp_ext.resize(kp_base);
@@ -422,13 +579,13 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
             pts4[x.pt_base + i] = float4{src[3 * (size_t)o], src[3 * (size_t)o + 1], src[3 * (size_t)o + 2], ob};
         }
         for (uint32_t c0 = 0; c0 < x.P; c0 += (uint32_t)kChunk) {   // static AABB of every kChunk consecutive tree positions
-            float* bx = &chunk_box[6 * (size_t)(x.box_base + c0 / (uint32_t)kChunk)];
+            float* bx = &chunk_box[8 * (size_t)(x.box_base + c0 / (uint32_t)kChunk)];
             float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (uint32_t i = c0; i < std::min<uint32_t>(c0 + (uint32_t)kChunk, x.P); ++i) {
                 const float v[3] = {xs[x.pt_base + i], ys[x.pt_base + i], zs[x.pt_base + i]};
                 for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }   // NaN coordinates never narrow a box
             }
-            for (int a = 0; a < 3; ++a) { bx[a] = mn[a]; bx[3 + a] = mx[a]; }
+            for (int a = 0; a < 3; ++a) { bx[a] = mn[a]; bx[4 + a] = mx[a]; }
         }
         std::copy(b.nodes.begin(), b.nodes.end(), nodes.begin() + x.node_base);
         const uint64_t k0 = d->kp_offset[f];
@@ -457,8 +614,18 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
             }
         }
     });
+    std::vector<uint16_t> kp_fl(kp_base);
+    bool crec_ok = true;
+    for (size_t k = 0; k < (size_t)kp_base; ++k) kp_fl[k] = (uint16_t)(int)kp_mp[k].w;
+    for (int lf = 0; lf < nf; ++lf) {
+        uint32_t cnt = 0;
+        for (uint32_t k = 0; k < hdr[lf].K; ++k) { uint32_t idb; std::memcpy(&idb, &crec[hdr[lf].kp_base + k].z, 4); crec_ok = crec_ok && idb == k; }
+        for (uint32_t k = 0; k < hdr[lf].K; ++k) cnt += kp_mp[hdr[lf].kp_base + k].w != 0.f ? 1u : 0u;
+        h->maxKw = std::max(h->maxKw, cnt);
+    }
     fb.clear(); fb.shrink_to_fit();
     if (bad_match) { delete h; return fail(nullptr, IBA_ERR_INVALID_ARG, "covisibility / match index out of range"); }
+    if (!crec_ok) { delete h; return fail(nullptr, IBA_ERR_STATE, "internal: keypoint grid records are not in keypoint order"); }
 
     // ---- LDS plan: stage the scan in LDS when it fits (<= ~10.9k points with 2000 keypoints) ----
     // Staging the scan in LDS (120 KB for 10 k points) pins the CU to ONE block; reading it through L2 instead costs ~5 % per
@@ -466,10 +633,20 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     h->scan_lds = std::getenv("IBA_SCAN_LDS") && layout(h, true, h->lay);
     if (!h->scan_lds && !layout(h, false, h->lay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
 
+    h->split = !(std::getenv("IBA_MONOLITHIC") && std::atoi(std::getenv("IBA_MONOLITHIC")) != 0);
+    if (const char* e = std::getenv("IBA_NN_CG")) h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e)));
+    if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
+    if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
+    if (!layout_assoc(h, h->alay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
+    if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
+    { NNLayout probe; if (!layout_nn(h, probe)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel"); } }
+    h->lstride = std::max(1u, std::min(h->maxK, h->maxKw));
+    h->nn_ns = (int)((h->lstride + kSliceW - 1u) / kSliceW);
+
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
 #define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
     UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes); UP(chunk_box, chunk_box); UP(pts4, pts4);
-    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv);
+    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(kp_fl, kp_fl); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv);
 #undef UP
     hipError_t er;
     if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);
@@ -477,8 +654,12 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     h->nfb = nf; h->nrec = nf + h->nfb;   // one factor-kernel record per frame
     if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(h->nrec, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
     if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
-    if ((er = h->d_flist_frozen.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u))) != hipSuccess) return bail("alloc flist", er);
+    if ((er = h->d_flist_frozen.alloc((size_t)std::max(nf, 1) * h->lstride)) != hipSuccess) return bail("alloc flist", er);
+    if ((er = h->d_fmp_frozen.alloc((size_t)std::max(nf, 1) * h->lstride)) != hipSuccess) return bail("alloc fmp", er);
     if ((er = h->d_fcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc fcount", er);
+    if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
+    if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
+    if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
     if ((er = h->d_he.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1))) != hipSuccess) return bail("alloc he", er);
     if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
@@ -494,6 +675,10 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
                           (const void*)iba_frame_kernel<MODE_BOTH, true>, (const void*)iba_frame_kernel<MODE_BOTH, false>};
     for (const void* fn : fns)
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    const void* nfns[3] = {(const void*)iba_nn_kernel<1>, (const void*)iba_nn_kernel<2>, (const void*)iba_nn_kernel<3>};
+    for (const void* fn : nfns)
+        if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
 
     {   // the frame kernel's view of its kernarg segment (see iba_kernarg_probe_kernel)
         DevBuf<int32_t> okb; std::vector<int32_t> z(1, 0);
@@ -529,9 +714,21 @@ iba_status iba_last_kernel_ms(iba_handle* h, float* frame_kernel_ms, float* tota
         HIP_TRY(h, hipEventSynchronize(h->ev2));
         HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1));
         HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2));
+        if (h->timing_split) { HIP_TRY(h, hipEventElapsedTime(&h->last_assoc_ms, h->ev0, h->ev_mid)); HIP_TRY(h, hipEventElapsedTime(&h->last_nn_ms, h->ev_mid, h->ev1)); }
+        else { h->last_assoc_ms = h->last_frame_ms; h->last_nn_ms = 0.f; }
     }
     if (frame_kernel_ms) *frame_kernel_ms = h->last_frame_ms;
     if (total_ms) *total_ms = h->last_total_ms;
+    return IBA_OK;
+}
+
+iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_kernel_ms, float* rest_ms) {
+    if (!h) return IBA_ERR_INVALID_ARG;
+    float fk = 0.f, tot = 0.f;
+    iba_status s = iba_last_kernel_ms(h, &fk, &tot); if (s != IBA_OK) return s;
+    if (assoc_kernel_ms) *assoc_kernel_ms = h->last_assoc_ms;
+    if (nn_kernel_ms) *nn_kernel_ms = h->last_nn_ms;
+    if (rest_ms) *rest_ms = tot - fk;
     return IBA_OK;
 }
 
@@ -586,7 +783,11 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
-    s = launch_frame<MODE_CORR>(h, dc, 1, h->d_frame_partials.p, h->d_corr.p, nullptr, h->n_frames, h->stream); if (s != IBA_OK) return s;
+    if (h->split) {
+        hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * ((h->n_frames + 7) / 8)), dim3(kThreads), h->alay.total, h->stream, KArgs{h->dev_problem(), h->dprm, h->alay}, dc, 1, 0,
+                           h->d_frame_partials.p, h->n_frames, h->d_corr.p, h->d_he.p, h->d_flist_frozen.p, h->d_fmp_frozen.p, h->d_fcount_frozen.p, h->d_lcount_frozen.p, (int)h->lstride);
+        HIP_TRY(h, hipGetLastError());
+    } else { s = launch_frame<MODE_CORR>(h, dc, 1, h->d_frame_partials.p, h->d_corr.p, nullptr, h->n_frames, h->stream); if (s != IBA_OK) return s; }
     const uint64_t k0 = h->h_kp_off[lf], K = h->h_kp_off[lf + 1] - k0;
     std::vector<uint32_t> tmp(K);
     HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_corr.p + k0, sizeof(uint32_t) * K, hipMemcpyDeviceToHost, h->stream));
@@ -672,28 +873,14 @@ iba_status iba_finalize_normal(const iba_params* p, const double* part, int32_t 
     return IBA_OK;
 }
 
-static iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
-    if (h->n_frames == 0 || h->maxK == 0) return IBA_OK;
-    const dim3 grid(h->n_frames, B);
-    const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
-    hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->maxK, per_cand, partials, nrec, rec_base);
-    HIP_TRY(h, hipGetLastError());
-    return IBA_OK;
-}
-
 static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
     if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->assoc_cap < B) {
-        HIP_TRY(h, hipStreamSynchronize(st));
-        h->d_assoc.release(); h->d_flist.release(); h->d_fcount.release();
-        HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
-        HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * std::max(h->maxK, 1u)));
-        HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
-        h->assoc_cap = B;
-    }
+    { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    if (use_split(h)) return run_split(h, dc, B, 1, false, true, d_partials, st);
+    h->timing_split = false;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
     s = launch_frame<MODE_ASSOC>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
@@ -723,16 +910,11 @@ iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal
 static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
     if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->assoc_cap < B) {
-        HIP_TRY(h, hipStreamSynchronize(st));
-        h->d_assoc.release(); h->d_flist.release(); h->d_fcount.release();
-        HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
-        HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * std::max(h->maxK, 1u)));
-        HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
-        h->assoc_cap = B;
-    }
+    { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    if (use_split(h)) return run_split(h, dc, B, 3, false, true, d_partials, st);
+    h->timing_split = false;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
     s = launch_frame<MODE_BOTH>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
@@ -762,9 +944,13 @@ iba_status iba_build_problem(iba_handle* h, const double* x) {
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
-    s = launch_frame<MODE_ASSOC>(h, dc, 1, h->d_frame_partials.p, nullptr, h->d_assoc_frozen.p, h->n_frames, h->stream, 0); if (s != IBA_OK) return s;
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, h->stream, h->d_frame_partials.p, h->n_frames, h->d_partials.p);
-    HIP_TRY(h, hipGetLastError());
+    h->frozen_split = use_split(h);
+    if (h->frozen_split) { s = run_split(h, dc, 1, 1, true, false, h->d_partials.p, h->stream); if (s != IBA_OK) return s; }
+    else {
+        s = launch_frame<MODE_ASSOC>(h, dc, 1, h->d_frame_partials.p, nullptr, h->d_assoc_frozen.p, h->n_frames, h->stream, 0); if (s != IBA_OK) return s;
+        hipLaunchKernelGGL(iba_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, h->stream, h->d_frame_partials.p, h->n_frames, h->d_partials.p);
+        HIP_TRY(h, hipGetLastError());
+    }
     HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->frozen_frames = (int32_t)h->h_partials[P_FRAMES_N]; h->frozen_ncorr = (int32_t)h->h_partials[P_NCORR_N]; h->frozen_valid = true;
@@ -902,6 +1088,19 @@ iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double*
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t KT = (size_t)h->n_keypoints;
     std::vector<uint2> a(KT);
+    if (h->frozen_split) {   // the two-kernel path keeps the association as per-frame block lists: expand them to one row per keypoint
+        std::fill(a.begin(), a.end(), make_uint2(kNone, kNone));
+        std::vector<uint32_t> fcn((size_t)std::max(h->n_frames, 1));
+        HIP_TRY(h, hipMemcpy(fcn.data(), h->d_fcount_frozen.p, sizeof(uint32_t) * (size_t)h->n_frames, hipMemcpyDeviceToHost));
+        std::vector<uint4> row(h->lstride);
+        for (int lf = 0; lf < h->n_frames; ++lf) {
+            const uint32_t n = fcn[lf];
+            if (!n) continue;
+            HIP_TRY(h, hipMemcpy(row.data(), h->d_flist_frozen.p + (size_t)lf * h->lstride, sizeof(uint4) * n, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n; ++i) a[h->h_frames[lf].kp_base + row[i].x] = make_uint2(row[i].y, row[i].z);
+        }
+        if (KT) HIP_TRY(h, hipMemcpy(h->d_assoc_frozen.p, a.data(), KT * sizeof(uint2), hipMemcpyHostToDevice));
+    } else
     HIP_TRY(h, hipMemcpy(a.data(), h->d_assoc_frozen.p, KT * sizeof(uint2), hipMemcpyDeviceToHost));
     std::vector<float2> muv; std::vector<float2> dummy;
     // covisible-match counts per keypoint decide the number of plane-factor rows (2 per matched covisible KF)

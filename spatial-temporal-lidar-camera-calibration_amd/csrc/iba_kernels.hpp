@@ -43,10 +43,11 @@ struct DevProblem {
     const uint32_t* perm;      // tree position -> original point index
     const uint32_t* inv_perm;  // original point index -> tree position
     const float4* pts4;        // the scan again as (x, y, z, original index bits) per tree position: divergent gathers take one 16 B load
-    const float* chunk_box;    // [chunk][6]: min xyz, max xyz of kChunk consecutive tree positions (NaN padding ignored)
+    const float* chunk_box;    // [chunk][8]: min xyz, -, max xyz, - of kChunk consecutive tree positions (NaN padding ignored)
     const TreeNode* nodes;
     const float2* kp_uv;
     const float4* kp_mp;       // MapPoint world position (x,y,z); w = 1*(owns a MapPoint) + 2*(matched in >= 1 covisible KF)
+    const uint16_t* kp_fl;     // the same flag word (w) as an integer, for kernels that keep it in LDS
     const uint32_t* coarse_start; const float4* crec; const uint32_t* bitmap;   // keypoint grid (see iba_build.hpp)
     const float2* match_uv;    // [slot][K] matched covisible keypoint, NaN = no match
     const PlaneRec* plane_cost;   // x-independent plane records (norm_radius / norm_max_pts)
@@ -62,6 +63,8 @@ struct DevProblem {
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
     uint32_t scan_stride;   // floats per coordinate array (0 = scan not staged in LDS)
     uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_cstart, off_red, off_vis, vis_words, off_cand, cand_cap, total;
+    uint32_t off_pair, pair_cap;   // iba_assoc_kernel only: (point, keypoint) pairs, 16 B each
+    uint32_t off_kuv, off_kfl;     // iba_assoc_kernel only: (u, v) and flag word of every keypoint
 };
 struct KArgs { DevProblem dp; DevParams prm; LdsLayout lay; };   // the frame kernel's parameter blocks, first kernel argument
 
@@ -1133,13 +1136,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
             for (int j = 0; j < 3; ++j) N[q][j] = (float)c.R[0 * 3 + j] * A[q][0] + (float)c.R[1 * 3 + j] * A[q][1] + (float)c.R[2 * 3 + j] * A[q][2];
             Dd[q] = (float)c.t[0] * A[q][0] + (float)c.t[1] * A[q][1] + (float)c.t[2] * A[q][2] + (q == 4 ? 0.2f : 0.f);
         }
-        const float* boxes = dp.chunk_box + 6 * h.box_base;
+        const float* boxes = dp.chunk_box + 8 * h.box_base;
         for (uint32_t ch0 = 0; ch0 < nchunks; ch0 += kThreads) {
             const uint32_t ch = ch0 + (uint32_t)tid;
             bool vis = false;
             if (ch < nchunks) {
-                const float* b = boxes + 6 * (size_t)ch;
-                const float lo3[3] = {b[0], b[1], b[2]}, hi3[3] = {b[3], b[4], b[5]};
+                const float* b = boxes + 8 * (size_t)ch;
+                const float lo3[3] = {b[0], b[1], b[2]}, hi3[3] = {b[4], b[5], b[6]};
                 vis = true;
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {

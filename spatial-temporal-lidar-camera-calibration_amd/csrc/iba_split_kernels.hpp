@@ -1,0 +1,882 @@
+// The evaluation path as TWO kernels (plane_cache = 1; the per-evaluation refit mode keeps the one-kernel path of
+// iba_kernels.hpp):
+//
+//   iba_assoc_kernel   one workgroup per (keyframe, candidate): frustum cull, float pre-cull, exact projection + keypoint
+//                      grid match, ties, corrset size, ONE dense work list per (candidate, keyframe) in keypoint order, local
+//                      plane at the matched point, 3d-2d covisible residuals -> partial record + list handed to
+//                      iba_nn_kernel (and, through it, to iba_factor_kernel).
+//                      = TransformPointCloud + FindProjectCorrespondences (pointcloud.h:82-86, iba_global.cpp:55-96 =
+//                      iba_local.cpp:17-58), the 3d-2d loop (iba_global.cpp:291-328), ComputeLocalNeighbor validity
+//                      (iba_local.cpp:207-231).
+//   iba_nn_kernel      one workgroup per (keyframe, GROUP of up to 16 candidates, keypoint slice): the MapPoint -> scan 1-NN
+//                      of iba_global.cpp:231-234,116-122 and iba_local.cpp:282-290 for ALL candidates of the group in ONE kd
+//                      traversal per MapPoint. The candidates' queries of one MapPoint differ by millimetres to centimetres:
+//                      lane j of a lane group owns candidate j's two queries (association path / cost path); the group walks
+//                      the tree together, steered by the centre of its queries with a pruning radius that covers all of
+//                      them, so every query sees a SUPERSET of the leaves it would visit alone; each lane scans the visited
+//                      leaf for its own queries (float filter + exact f64 confirmation, lowest-original-index ties) — results
+//                      are identical to separate exact searches. Then, per (MapPoint, candidate): point-to-plane /
+//                      point-to-point cost distance (ComputeAlignmentDist, iba_global.cpp:111-156, 241-249) and the kind of
+//                      the 3d-3d residual block (pointcloud.h:699-717).
+//
+// Why: in the one-kernel form 43 % of the time went into the 1-NN phase, each (keyframe, candidate) block descending the
+// same tree to the same leaves for ~264 MapPoints with half of its lanes idle, and 13 % into a finalize pass that
+// recomputed the queries. Splitting also frees the association kernel from the search's registers and LDS.
+#pragma once
+#include "iba_kernels.hpp"
+
+namespace iba {
+
+#ifndef IBA_NN_THREADS
+#define IBA_NN_THREADS 256
+#endif
+constexpr int kNNThreads = IBA_NN_THREADS;
+constexpr int kNNWaves = kNNThreads / 64;
+#ifndef IBA_NN_SLICE
+#define IBA_NN_SLICE 128
+#endif
+constexpr uint32_t kSliceW = IBA_NN_SLICE;   // list positions per search block: a constant, so that the order of every sum is the same whatever the batch
+constexpr int kNNPartial = 8;   // doubles per (candidate, nn record): sum3d, cnt, valid, valid_pl, valid_pt, 3 spare
+constexpr int kMaxGroup = kNNThreads / 32 < 16 ? kNNThreads / 32 : 16;   // candidates per block (32 threads each in the final sums)
+
+struct NNLayout {   // byte offsets into the dynamic LDS of iba_nn_kernel
+    uint32_t off_nodes, off_res, off_misc, off_cd, total;
+};
+constexpr int kCdDoubles = 14;   // per candidate in LDS: s, Ri[9], ti[3], (s32, pad) = doubles 12..25 of Cand
+#ifndef IBA_NN_WAVES
+#define IBA_NN_WAVES 5   /* waves per SIMD the search kernel is compiled for (<= 96 VGPRs) */
+#endif
+#ifndef IBA_NN_LEAF_BATCH
+#define IBA_NN_LEAF_BATCH 4   /* points of a leaf scan whose loads are in flight together */
+#endif
+struct NNArgs { DevProblem dp; DevParams prm; NNLayout lay; };
+
+// list entry flags (uint4.w) written by iba_assoc_kernel
+constexpr uint32_t kFlagC = 1u;   // cost-path 1-NN wanted (keypoint owns a MapPoint, frame counts for BAError, 3d-3d enabled)
+constexpr uint32_t kFlagA = 2u;   // association-path 1-NN wanted (ComputeLocalNeighbor at the matched point is valid)
+
+// ------------------------------------------------------------------------------------------------------------------
+// iba_assoc_kernel. want: bit 0 = BuildProblem association wanted, bit 1 = BAError cost wanted. corr_out != nullptr: dump
+// the correspondences and return (iba_get_correspondences).
+// grid: 8 * ceil(n_frames/8) * B blocks of kThreads; block i runs on XCD i%8, so all candidates of a frame share an L2.
+// ------------------------------------------------------------------------------------------------------------------
+#ifdef IBA_ASSOC_WAVES
+#define IBA_ASSOC_ATTR __attribute__((amdgpu_waves_per_eu(IBA_ASSOC_WAVES, IBA_ASSOC_WAVES)))
+#else
+#define IBA_ASSOC_ATTR
+#endif
+__global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want,
+                                                             double* __restrict__ frame_partials, int nrec, uint32_t* __restrict__ corr_out,
+                                                             const double* __restrict__ he, uint4* __restrict__ flist, float4* __restrict__ fmp, uint32_t* __restrict__ fcount,
+                                                             uint32_t* __restrict__ lcount, int flist_stride) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef __attribute__((address_space(4))) const KArgs KArgsC;
+    KArgsC* ka = (KArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // see iba_frame_kernel: parameter blocks are read where they are used
+    (void)ka_by_value;
+#define dp (ka->dp)
+#define prm (ka->prm)
+#define lay (ka->lay)
+#define IBA_RELOAD() asm volatile("" : "+s"(ka))
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nf = dp.n_frames;
+    const int per_xcd = (nf + 7) / 8;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int f = xcd + 8 * (jj / B), b = jj % B;
+    if (f >= nf || jj / B >= per_xcd) return;
+    const FrameHdr& h = dp.frames[f];
+    const Cand& cd = cands[b];
+    double* part = frame_partials + ((size_t)b * nrec + f) * kPartialStride;
+
+    unsigned long long* s_best_d2 = (unsigned long long*)(smem + lay.off_best_d2);
+    uint32_t* s_best_idx = (uint32_t*)(smem + lay.off_best_idx);
+    uint32_t* s_bitmap = (uint32_t*)(smem + lay.off_bitmap);
+    uint16_t* s_cstart = (uint16_t*)(smem + lay.off_cstart);
+    double* s_red = (double*)(smem + lay.off_red);
+    double* s_rel = s_red + kWaves * 4;
+    uint32_t* s_wcnt = (uint32_t*)(s_rel + kMaxCovis * 12);
+    uint32_t* s_misc = s_wcnt + kWaves;
+    uint32_t* s_cand = (uint32_t*)(smem + lay.off_cand);
+    uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 after phase 2
+    float2* s_kuv = (float2*)(smem + lay.off_kuv);            // (u, v) of every keypoint; keypoint ids are in grid-record order
+    uint16_t* s_kfl = (uint16_t*)(smem + lay.off_kfl);        // flag word of every keypoint (MapPoint, covisible matches)
+
+    const uint32_t P = h.P, Ppad = h.Ppad, K = h.K;
+    const float* gxs = dp.xs + h.pt_base; const float* gys = dp.ys + h.pt_base; const float* gzs = dp.zs + h.pt_base;
+
+    // ---- phase 0: LDS init (first element per thread of each static table fetched before anything is stored) ----
+    const uint32_t nbw = (h.gw * h.gh + 31u) >> 5;
+    const uint32_t ncs = h.gwc * h.ghc + 1u;
+    const uint32_t ut = (uint32_t)tid;
+    uint32_t bv = 0u, cv0 = 0u, cv1 = 0u; double rv = 0.0;
+    if (ut < nbw) bv = dp.bitmap[h.bitmap_base + ut];
+    if (ut < ncs) cv0 = dp.coarse_start[h.coarse_base + ut];
+    if (ut + kThreads < ncs) cv1 = dp.coarse_start[h.coarse_base + ut + kThreads];
+    if (ut < h.n_slots * 12u) rv = dp.slots[h.slot_base + ut / 12].rel[ut % 12];
+    for (uint32_t i = tid; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = dp.kp_uv[h.kp_base + i]; s_kfl[i] = dp.kp_fl[h.kp_base + i]; }
+    if (ut < nbw) s_bitmap[ut] = bv;
+    if (ut < ncs) s_cstart[ut] = (uint16_t)cv0;
+    if (ut + kThreads < ncs) s_cstart[ut + kThreads] = (uint16_t)cv1;
+    for (uint32_t i = ut + kThreads; i < nbw; i += kThreads) s_bitmap[i] = dp.bitmap[h.bitmap_base + i];
+    for (uint32_t i = ut + 2u * kThreads; i < ncs; i += kThreads) s_cstart[i] = (uint16_t)dp.coarse_start[h.coarse_base + i];
+    if (ut < h.n_slots * 12u) s_rel[ut] = rv;
+    if (tid < 4) s_misc[tid] = 0u;
+    __syncthreads();
+
+    const int dbg = want >> 8;   // diagnostic: cut the kernel short after a phase (timing attribution; results are garbage)
+    if (dbg == 1) return;
+    FrameCtx c;
+    c.xs = gxs; c.ys = gys; c.zs = gzs;
+    c.nodes = nullptr; c.bitmap = s_bitmap; c.best_d2 = s_best_d2; c.best_idx = s_best_idx;
+    c.cstart = s_cstart; c.gwc = (int)h.gwc; c.crec = dp.crec + h.kp_base;
+    c.perm = dp.perm + h.pt_base;
+    c.p4 = dp.pts4 + h.pt_base;
+    c.gw = (int)h.gw; c.gh = (int)h.gh; c.margin = (float)prm.grid_margin; c.gate2 = prm.gate2;
+    c.fx = h.fx; c.cx = h.cx; c.cy = h.cy; c.W = h.W; c.H = h.H;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = cd.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.t[i] = cd.t[i];
+
+    IBA_RELOAD();
+    const uint32_t cand_cap = lay.cand_cap;
+    // ---- phase 0.5: conservative frustum test of the static per-chunk boxes (see iba_frame_kernel) ----
+    uint32_t* s_vis = (uint32_t*)(smem + lay.off_vis);
+    {
+        const uint32_t nchunks = (P + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
+        const float m = 8.0f;
+        const float A[5][3] = {{(float)c.fx, 0.f, (float)c.cx + m}, {-(float)c.fx, 0.f, (float)c.W + m - (float)c.cx},
+                               {0.f, (float)c.fx, (float)c.cy + m}, {0.f, -(float)c.fx, (float)c.H + m - (float)c.cy}, {0.f, 0.f, 1.f}};
+        float N[5][3], Dd[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) N[q][j] = (float)c.R[0 * 3 + j] * A[q][0] + (float)c.R[1 * 3 + j] * A[q][1] + (float)c.R[2 * 3 + j] * A[q][2];
+            Dd[q] = (float)c.t[0] * A[q][0] + (float)c.t[1] * A[q][1] + (float)c.t[2] * A[q][2] + (q == 4 ? 0.2f : 0.f);
+        }
+        const float4* boxes = (const float4*)(dp.chunk_box + 8 * h.box_base);   // two 16-byte loads per chunk
+        uint32_t vis_cnt = 0u;
+        for (uint32_t ch0 = 0; ch0 < nchunks; ch0 += kThreads) {
+            const uint32_t ch = ch0 + (uint32_t)tid;
+            bool vis = false;
+            if (ch < nchunks) {
+                const float4 blo = boxes[2 * (size_t)ch], bhi = boxes[2 * (size_t)ch + 1];
+                const float lo3[3] = {blo.x, blo.y, blo.z}, hi3[3] = {bhi.x, bhi.y, bhi.z};
+                vis = true;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    float smax = Dd[q], mag = fabsf(Dd[q]);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        smax += N[q][j] >= 0.f ? N[q][j] * hi3[j] : N[q][j] * lo3[j];
+                        mag += fabsf(N[q][j]) * fmaxf(fabsf(lo3[j]), fabsf(hi3[j]));
+                    }
+                    vis = vis && !(smax < -1e-3f * mag - 1e-6f);   // NaN boxes (empty chunk) compare false -> kept, harmless
+                }
+            }
+            const unsigned long long bal = __ballot(vis);
+            vis_cnt += (uint32_t)__popcll(bal);
+            if (lane == 0) { s_vis[(ch0 >> 5) + 2u * (uint32_t)wave] = (uint32_t)bal; s_vis[(ch0 >> 5) + 2u * (uint32_t)wave + 1u] = (uint32_t)(bal >> 32); }
+        }
+        if (lane == 0) s_wcnt[wave] = vis_cnt;
+    }
+    __syncthreads();
+    // visible chunks, compacted into a u16 list right behind the ballot words: every wave appends the chunks it tested
+    const uint32_t nchunks_all = (P + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
+    uint16_t* s_vlist = (uint16_t*)(s_vis + lay.vis_words);
+    uint32_t n_vis = 0u;
+    {
+        uint32_t at = 0u;
+        for (int w = 0; w < kWaves; ++w) { const uint32_t cw = s_wcnt[w]; n_vis += cw; if (w < wave) at += cw; }
+        for (uint32_t ch0 = 0; ch0 < nchunks_all; ch0 += kThreads) {
+            const unsigned long long bal = (unsigned long long)s_vis[(ch0 >> 5) + 2u * (uint32_t)wave] | ((unsigned long long)s_vis[(ch0 >> 5) + 2u * (uint32_t)wave + 1u] << 32);
+            if ((bal >> lane) & 1ull) s_vlist[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(ch0 + (uint32_t)tid);
+            at += (uint32_t)__popcll(bal);
+        }
+    }
+    __syncthreads();
+    if (dbg == 2) return;
+    // ---- phase 1a: stream the visible chunks (16 B/lane), float32 projection, one bit of the dilated reject bitmap ----
+    {
+        const float r0 = (float)c.R[0], r1 = (float)c.R[1], r2 = (float)c.R[2], r3 = (float)c.R[3], r4 = (float)c.R[4], r5 = (float)c.R[5],
+                    r6 = (float)c.R[6], r7 = (float)c.R[7], r8 = (float)c.R[8], t0 = (float)c.t[0], t1 = (float)c.t[1], t2 = (float)c.t[2];
+        const float fxf = (float)c.fx, cxf = (float)c.cx, cyf = (float)c.cy, Wf = (float)c.W + 1.0f, Hf = (float)c.H + 1.0f;
+        const uint32_t n_groups = n_vis * (uint32_t)(kChunk / 4);
+        const uint32_t n_iter = (n_groups + kThreads - 1u) / kThreads;
+        const float qn = __builtin_nanf("");
+        const float4 nan4 = make_float4(qn, qn, qn, qn);
+        auto group_base = [&](uint32_t g) -> uint32_t {
+            if (g >= n_groups) return kNone;
+            const uint32_t b4 = (uint32_t)s_vlist[g / (uint32_t)(kChunk / 4)] * (uint32_t)kChunk + (g % (uint32_t)(kChunk / 4)) * 4u;
+            return b4 < Ppad ? b4 : kNone;
+        };
+        float4 X = nan4, Y = nan4, Z = nan4;
+        uint32_t base = group_base((uint32_t)tid);
+        if (base != kNone) { X = *(const float4*)(gxs + base); Y = *(const float4*)(gys + base); Z = *(const float4*)(gzs + base); }
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            const uint32_t nbase = group_base((uint32_t)tid + (it + 1u) * kThreads);
+            float4 Xn = nan4, Yn = nan4, Zn = nan4;
+            if (nbase != kNone) { Xn = *(const float4*)(gxs + nbase); Yn = *(const float4*)(gys + nbase); Zn = *(const float4*)(gzs + nbase); }
+            const float px[4] = {X.x, X.y, X.z, X.w}, py[4] = {Y.x, Y.y, Y.z, Y.w}, pz[4] = {Z.x, Z.y, Z.z, Z.w};
+            bool pass[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float zc = fmaf(r6, px[j], fmaf(r7, py[j], fmaf(r8, pz[j], t2)));
+                pass[j] = false;
+                if (zc > 0.1f) {
+                    const float xc = fmaf(r0, px[j], fmaf(r1, py[j], fmaf(r2, pz[j], t0)));
+                    const float yc = fmaf(r3, px[j], fmaf(r4, py[j], fmaf(r5, pz[j], t1)));
+                    const float rz = __builtin_amdgcn_rcpf(zc);
+                    const float uf = fmaf(fxf * xc, rz, cxf), vf = fmaf(fxf * yc, rz, cyf);
+                    if (uf > -1.0f && uf < Wf && vf > -1.0f && vf < Hf) {
+                        const uint32_t cell = (uint32_t)grid_cell(vf, c.gh) * (uint32_t)c.gw + (uint32_t)grid_cell(uf, c.gw);
+                        pass[j] = (s_bitmap[cell >> 5] >> (cell & 31)) & 1u;
+                    }
+                } else if (zc > -0.1f) pass[j] = true;   // undecidable in f32 (NaN padding fails both tests): exact path decides
+            }
+            const unsigned long long b0 = __ballot(pass[0]), b1 = __ballot(pass[1]), b2 = __ballot(pass[2]), b3 = __ballot(pass[3]);
+            const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3q = (uint32_t)__popcll(b3);
+            if (n0 + n1 + n2 + n3q) {
+                uint32_t wb = 0;
+                if (lane == 0) wb = atomicAdd(&s_misc[0], n0 + n1 + n2 + n3q);
+                wb = __shfl(wb, 0);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const uint32_t off[4] = {wb + (uint32_t)__popcll(b0 & lt), wb + n0 + (uint32_t)__popcll(b1 & lt), wb + n0 + n1 + (uint32_t)__popcll(b2 & lt),
+                                         wb + n0 + n1 + n2 + (uint32_t)__popcll(b3 & lt)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!pass[j]) continue;
+                    if (off[j] < cand_cap) s_cand[off[j]] = base + j;
+                    else {   // queue full: exact path inline, full rescan in phase 2 (speed only)
+                        double u, v;
+                        if (project_uv(c, px[j], py[j], pz[j], u, v)) grid_match<1>(c, u, v, base + j);
+                        s_misc[1] = 1u;
+                    }
+                }
+            }
+            X = Xn; Y = Yn; Z = Zn; base = nbase;
+        }
+    }
+    __syncthreads();
+    if (dbg == 3) return;
+    IBA_RELOAD();
+    // ---- phase 1b: float32 walk of the keypoint grid for the queued points -> compact list of (point, keypoint) PAIRS that
+    //      may be within max_pixel_dist. The f32 projection errs by < 0.3 px per axis for depth > 0.1 m (see phase 1a), so a
+    //      pair whose f32 distance exceeds max_pixel_dist + 0.45 px cannot pass the exact test. About one queued point in
+    //      four yields a pair: the f64 projection and the exact distance below run on those only, one lane per pair.
+    const uint32_t ncand = min(s_misc[0], cand_cap);
+    uint4* s_pair = (uint4*)(smem + lay.off_pair);   // {tree position, keypoint record -> keypoint id, d^2 bits}
+    const uint32_t pair_cap = lay.pair_cap;
+    {
+        const float r0 = (float)c.R[0], r1 = (float)c.R[1], r2 = (float)c.R[2], r3 = (float)c.R[3], r4 = (float)c.R[4], r5 = (float)c.R[5],
+                    r6 = (float)c.R[6], r7 = (float)c.R[7], r8 = (float)c.R[8], t0 = (float)c.t[0], t1 = (float)c.t[1], t2 = (float)c.t[2];
+        const float fxf = (float)c.fx, cxf = (float)c.cx, cyf = (float)c.cy;
+        const float rB = (float)prm.bitmap_margin, rB2 = rB * rB * 1.00001f, wm = rB + 0.01f;
+        for (uint32_t i = tid; i < ncand; i += kThreads) {
+            const uint32_t pos = s_cand[i];
+            const float4 pv = c.p4[pos];
+            const float zc = fmaf(r6, pv.x, fmaf(r7, pv.y, fmaf(r8, pv.z, t2)));
+            if (!(zc > 0.1f)) {   // undecidable in f32 (queued by phase 1a for that reason): exact path inline, ties by the full rescan
+                double u, v;
+                if (project_uv(c, pv.x, pv.y, pv.z, u, v)) grid_match<1>(c, u, v, pos);
+                s_misc[1] = 1u;
+                continue;
+            }
+            const float xc = fmaf(r0, pv.x, fmaf(r1, pv.y, fmaf(r2, pv.z, t0)));
+            const float yc = fmaf(r3, pv.x, fmaf(r4, pv.y, fmaf(r5, pv.z, t1)));
+            const float rz = __builtin_amdgcn_rcpf(zc);
+            const float uf = fmaf(fxf * xc, rz, cxf), vf = fmaf(fxf * yc, rz, cyf);
+            const int x0 = grid_cell(uf - wm, c.gw) >> kCoarseShift, x1 = grid_cell(uf + wm, c.gw) >> kCoarseShift;
+            const int y0 = grid_cell(vf - wm, c.gh) >> kCoarseShift, y1 = grid_cell(vf + wm, c.gh) >> kCoarseShift;
+            for (int yy = y0; yy <= y1; ++yy) {
+                const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
+                for (uint32_t e = e0; e < e1; ++e) {
+                    const float2 rec = s_kuv[e];
+                    const float du = rec.x - uf, dv = rec.y - vf;
+                    if (fmaf(dv, dv, du * du) <= rB2) {
+                        const unsigned long long hb = __ballot(1);   // the lanes that hit: one LDS atomic reserves the slots of all of them
+                        uint32_t sb = 0u;
+                        const int first = __ffsll((long long)hb) - 1;
+                        if (lane == first) sb = atomicAdd(&s_misc[2], (uint32_t)__popcll(hb));
+                        sb = (uint32_t)__shfl((int)sb, first);
+                        const uint32_t slot = sb + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+                        if (slot < pair_cap) s_pair[slot] = make_uint4(pos, e, 0u, 0u);
+                        else {   // pair list full: exact test inline, ties by the full rescan (speed only)
+                            double u, v;
+                            if (project_uv(c, pv.x, pv.y, pv.z, u, v)) {
+                                const double du_ = (double)rec.x - u, dv_ = (double)rec.y - v;
+                                const double d2 = du_ * du_ + dv_ * dv_;
+                                if (d2 <= c.gate2) atomicMin(&s_best_d2[e], d2bits(d2));
+                            }
+                            s_misc[1] = 1u;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (dbg == 4) return;
+    // ---- phase 1c: exact f64 projection + FOV test (K1 + K2) and exact d^2 of every pair, ds_min_u64 on the keypoint's best ----
+    const uint32_t npair = min(s_misc[2], pair_cap);
+    const bool overflow = s_misc[1] != 0u;
+    for (uint32_t i = tid; i < npair; i += kThreads) {
+        const uint4 pr = s_pair[i];
+        const float2 rec = s_kuv[pr.y];
+        const float4 pv = c.p4[pr.x];   // .w: original index of the point
+        double u, v;
+        uint32_t k = kNone; unsigned long long bits = 0ull;
+        if (project_uv(c, pv.x, pv.y, pv.z, u, v)) {
+            const double du = (double)rec.x - u, dv = (double)rec.y - v;
+            const double d2 = du * du + dv * dv;
+            if (d2 <= c.gate2) { k = pr.y; bits = d2bits(d2); atomicMin(&s_best_d2[k], bits); }
+        }
+        s_pair[i] = make_uint4(__float_as_uint(pv.w), k, (uint32_t)bits, (uint32_t)(bits >> 32));
+    }
+    __syncthreads();
+    // ---- phase 2: the winner of each keypoint records its original index; exact ties -> lowest index ----
+    for (uint32_t i = tid; i < npair; i += kThreads) {
+        const uint4 pr = s_pair[i];
+        if (pr.y != kNone && s_best_d2[pr.y] == ((unsigned long long)pr.z | ((unsigned long long)pr.w << 32))) atomicMin(&s_best_idx[pr.y], pr.x);
+    }
+    if (overflow) {   // some exact tests ran inline: every point again, for the ties
+        for (uint32_t pos = tid; pos < P; pos += kThreads) {
+            double u, v;
+            if (project_pos<true>(c, pos, u, v)) grid_match<2>(c, u, v, pos);
+        }
+    }
+    __syncthreads();
+
+    if (corr_out) {   // dense dump: corr_out[kp_base + k] = original point index or kNone
+        for (uint32_t k = tid; k < K; k += kThreads) corr_out[h.kp_base + k] = s_best_idx[k];
+        return;
+    }
+
+    if (dbg == 5) return;
+    IBA_RELOAD();
+    const float4* kp_mp = dp.kp_mp + h.kp_base;
+    const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
+
+    const double s = cd.s;
+    uint32_t n3 = 0;
+
+    // ---- phase 3: corrset.size() and the sizes of the work list, one contiguous range of keypoints per wave ----
+    // (the list is in keypoint order; two barriers in all: counts -> prefix -> entries)
+    const uint32_t kw = ((K + (uint32_t)kWaves * 64u - 1u) / ((uint32_t)kWaves * 64u)) * 64u;   // keypoints per wave, a multiple of 64
+    const uint32_t kbeg = (uint32_t)wave * kw;
+    uint32_t n_corr = 0u, cntC = 0u, cntA = 0u;
+    {
+        uint32_t nv = 0u, nc = 0u, na = 0u;
+        for (uint32_t k = kbeg + (uint32_t)lane; k < kbeg + kw; k += 64u) {
+            const bool valid = k < K && s_best_idx[k] != kNone;
+            const int w = valid ? (int)s_kfl[k] : 0;
+            nv += (uint32_t)__popcll(__ballot(valid));
+            nc += (uint32_t)__popcll(__ballot(w != 0));
+            na += (uint32_t)__popcll(__ballot((w & 3) == 3));
+        }
+        uint32_t* s_cnt3 = (uint32_t*)s_red;   // 3 counts per wave (the reduction slab is not in use yet)
+        if (lane == 0) { s_cnt3[wave * 3] = nv; s_cnt3[wave * 3 + 1] = nc; s_cnt3[wave * 3 + 2] = na; }
+        __syncthreads();
+        for (int w = 0; w < kWaves; ++w) {
+            n_corr += s_cnt3[w * 3];
+            if (w < wave) { cntC += s_cnt3[w * 3 + 1]; cntA += s_cnt3[w * 3 + 2]; }
+        }
+    }
+    const bool usedA = (want & 1) && !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
+    const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
+    const PlaneRec* planes_local = dp.plane_local + h.pt_base;
+    uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
+    float4* fm = fmp + ((size_t)b * nf + f) * (size_t)flist_stride;   // the MapPoint of every entry, for the search kernel
+    uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
+    // ---- work list: keypoints with a correspondence that can own a term: a MapPoint and/or a covisible match for the
+    //      cost (iba_global.cpp:225, 295-300), both for a residual block (iba_local.cpp:213, 259-260); entry = k | w << 16
+    //      (bits 16,17: MapPoint / covisible-match flags; 18..27: covisible-slot mask) ----
+    {
+        uint32_t* s_cnt3 = (uint32_t*)s_red;
+        uint32_t at = usedC ? cntC : (usedA ? cntA : 0u);   // entries of the waves before this one
+        for (int w = 0; w < kWaves; ++w) n3 += usedC ? s_cnt3[w * 3 + 1] : (usedA ? s_cnt3[w * 3 + 2] : 0u);
+        for (uint32_t k = kbeg + (uint32_t)lane; k < kbeg + kw; k += 64u) {
+            const bool valid = k < K && s_best_idx[k] != kNone;
+            const int w = valid ? (int)s_kfl[k] : 0;
+            const bool wantk = (usedC && w != 0) || (usedA && (w & 3) == 3);
+            const unsigned long long bal = __ballot(wantk);
+            if (wantk) {
+                const uint32_t i = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                s_list[i] = k | ((uint32_t)w << 16);
+                s_pos[i] = inv_perm[s_best_idx[k]];
+            }
+            at += (uint32_t)__popcll(bal);
+        }
+    }
+    __syncthreads();
+    if (dbg == 6) return;
+    double sum2d = 0.0;
+    uint32_t c2 = 0, v2 = 0;
+    // association: local plane at the matched point (iba_local.cpp:207-231); list entry for the search / factor kernels
+    for (uint32_t i = tid; i < n3; i += kThreads) {
+        const uint32_t e = s_list[i], k = e & 0xffffu;
+        uint32_t ax_ = kNone, flags = 0u;
+        if (usedA && ((e >> 16) & 3u) == 3u) {
+            const uint32_t pos = s_pos[i];
+            const PlaneRec rec = planes_local[pos];
+            const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);   // pointcloud.h:752
+            if (neigh_ok && rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) ax_ = pos;   // bvalid_plane (:231)
+            if (neigh_ok) flags |= kFlagA;   // no 3d-3d block either otherwise (the `continue` at :209-211)
+        }
+        if (usedC && prm.use_3d3d && ((e >> 16) & 1u)) flags |= kFlagC;
+        fl[i] = make_uint4(k, ax_, kNone, flags);   // .z (the 3d-3d block) is filled in by iba_nn_kernel
+        if (flags) fm[i] = kp_mp[k];
+    }
+    if (dbg == 7) return;
+    // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328): only the slots whose match bit is set
+    if (usedC) {
+        for (uint32_t i = tid; i < n3; i += kThreads) {
+            uint32_t mask = (s_list[i] >> 18) & 0x3ffu;
+            if (!mask) continue;
+            const uint32_t k = s_list[i] & 0xffffu, pos = s_pos[i];
+            float xf_, yf_, zf_; load_pt<true>(c, pos, xf_, yf_, zf_);
+            const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
+            const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
+            const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
+            const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
+            const float2* mrow = dp.match_uv + h.match_base + k;
+            float2 mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];
+            while (mask) {
+                const uint32_t sl = (uint32_t)__ffs((int)mask) - 1u;
+                mask &= mask - 1u;
+                const float2 cur = mm;
+                if (mask) mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];   // next match is in flight during the arithmetic
+                const double* rel = s_rel + sl * 12;
+                const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
+                const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
+                const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
+                const double ou = h.fx * p1x / p1z + h.cx;
+                const double ov = h.fy * p1y / p1z + h.cy;
+                if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
+                const double eu = ou - (double)cur.x, ev = ov - (double)cur.y;
+                const double dist = sqrt(eu * eu + ev * ev);
+                if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
+                ++c2;
+            }
+        }
+    }
+    if (tid == 0) { fcount[(size_t)b * nf + f] = usedA ? n3 : 0u; lcount[(size_t)b * nf + f] = n3; }
+    // K8: reduction -> record. The 3d-3d sums of this (candidate, frame) come from iba_nn_kernel's own records.
+    {
+        const double w2d = wave_sum_f64(sum2d);
+        const unsigned long long wa = wave_sum_u64((unsigned long long)c2 | ((unsigned long long)v2 << 32));
+        unsigned long long* s_redu = (unsigned long long*)s_red;
+        __syncthreads();
+        if (lane == 63) { s_red[wave * 4 + 0] = w2d; s_redu[wave * 4 + 2] = wa; }
+        __syncthreads();
+        if (tid < kPartialStride) {
+            double out = 0.0;
+            if (usedC) {
+                if (tid == P_SUM_3D2D) { for (int w = 0; w < kWaves; ++w) out += s_red[w * 4 + 0]; }
+                else if (tid == P_CNT_3D2D || tid == P_VALID_3D2D) {
+                    unsigned long long a = 0;
+                    for (int w = 0; w < kWaves; ++w) a += s_redu[w * 4 + 2];
+                    out = (double)(tid == P_CNT_3D2D ? (a & 0xffffffffull) : (a >> 32));
+                }
+                else if ((tid == P_CNT_3D3D || tid == P_VALID_3D3D) && !prm.use_3d3d) out = 1.0;   // iba_global.cpp:214-220
+                else if (tid == P_FRAMES) out = 1.0;
+                else if (tid == P_NCORR) out = (double)n_corr;
+                else if (tid == P_HE_SUM) out = h.he_valid ? he[(size_t)b * nf + f] : 0.0;
+                else if (tid == P_HE_CNT) out = h.he_valid ? 1.0 : 0.0;
+            }
+            if (tid == P_FRAMES_N) out = usedA ? 1.0 : 0.0;
+            else if (tid == P_NCORR_N) out = usedA ? (double)n_corr : 0.0;
+            part[tid] = out;
+        }
+    }
+#undef dp
+#undef prm
+#undef lay
+#undef IBA_RELOAD
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// iba_nn_kernel<WHICH>. WHICH bit 0: association-path queries present, bit 1: cost-path queries.
+// grid: 8 * ceil(n_frames/8) * NG * NS blocks (NG = ceil(B / CG) candidate groups, NS keypoint slices) of kNNThreads.
+//
+// One LANE per (MapPoint, candidate): the exact 1-NN searches of one list entry (association-path query a, cost-path query c:
+// the same MapPoint through different float/double islands of the reference, 1e-7 apart) — the float32-conservative tree walk
+// and float-filtered, f64-confirmed leaf scans of nn_dual_step with one lane per query pair. The waves of a block run
+// INDEPENDENTLY of each other, without barriers: a lane that has finished its entry takes the next one from the block's
+// work list (one LDS atomic per wave and iteration), so every lane of a wave is searching in every iteration however uneven
+// the searches are (72 % end in their first leaf, a few need 5..24), and the visited path stays in registers from one leaf
+// to the next. The work list of a block = the list entries, of up to CG candidates, that want a search and whose keypoint
+// falls into the block's slice, compacted in (candidate, list) order.
+// Results: flist[b][f][i].z (kind | tree position of the 3d-3d block's scan point) directly; the cost distance of an entry
+// goes to its slot of an LDS array (sign bit = point-to-point), which is summed per candidate in a FIXED order afterwards —
+// which lane ran which search does not matter, so the sums are bitwise reproducible. One record of kNNPartial doubles per
+// (candidate, frame, slice).
+// ------------------------------------------------------------------------------------------------------------------
+template <int WHICH>
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_NN_WAVES, IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
+                                                                                                  double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist, const float4* __restrict__ fmp,
+                                                                                                  const uint32_t* __restrict__ lcount, int flist_stride, int dbg) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef __attribute__((address_space(4))) const NNArgs NNArgsC;
+    NNArgsC* ka = (NNArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)ka_by_value;
+#define dp (ka->dp)
+#define prm (ka->prm)
+#define lay (ka->lay)
+    constexpr int T = kNNThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nf = dp.n_frames;
+    const int per_xcd = (nf + 7) / 8;
+    const int NG = (B + CG - 1) / CG;
+    const int per_frame = NG * NS;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int f = xcd + 8 * (jj / per_frame);
+    if (f >= nf || jj / per_frame >= per_xcd) return;
+    const int g = (jj % per_frame) / NS, sl = (jj % per_frame) % NS;
+    const FrameHdr& h = dp.frames[f];
+    const uint32_t P = h.P, D = h.depth, K = h.K;
+    const int cands_here = min(CG, B - g * CG);
+    constexpr uint32_t kWantMask = ((WHICH & 2) ? kFlagC : 0u) | ((WHICH & 1) ? kFlagA : 0u);
+
+    TreeNode* s_nodes = (TreeNode*)(smem + lay.off_nodes);
+    double* s_res = (double*)(smem + lay.off_res);           // cost distance of a work entry (NaN: none; sign bit: point-to-point)
+    uint32_t* s_n = (uint32_t*)(smem + lay.off_misc);        // [kMaxGroup] list length per candidate of the group
+    uint32_t* s_ctr = s_n + kMaxGroup;                       // [1] next unclaimed work entry
+    double* s_cd = (double*)(smem + lay.off_cd);             // [kMaxGroup][kCdDoubles] candidate constants of the query transform
+    int cg_shift = 0; while ((1 << cg_shift) < CG) ++cg_shift;   // CG is a power of two (host)
+
+    // ---- kd nodes -> LDS; list lengths of the group's candidates ----
+    const uint32_t nnodes = (1u << D) - 1u;
+    uint32_t my_n = 0u;
+    if (tid < cands_here) my_n = lcount[(size_t)(g * CG + tid) * nf + f];
+    for (uint32_t i = tid; i < nnodes; i += T) s_nodes[i] = dp.nodes[h.node_base + i];
+    if (tid < kMaxGroup) s_n[tid] = my_n;
+    if (tid < cands_here * kCdDoubles) s_cd[tid] = ((const double*)&cands[g * CG + tid / kCdDoubles])[12 + tid % kCdDoubles];
+    __syncthreads();
+    if (dbg == 1) return;
+    // Work entry w of the block = (candidate w % CG, list position i_lo + w / CG): the candidates' lists interleaved, so that the
+    // lanes of a wave search for (nearly) the same MapPoints under different candidates and walk the same leaves. The slices
+    // of a (frame, group) split the list positions.
+    uint32_t nmax = 0u;
+#pragma unroll
+    for (int cc = 0; cc < kMaxGroup; ++cc) nmax = max(nmax, s_n[cc]);
+    const uint32_t i_lo = min(nmax, (uint32_t)sl * kSliceW), i_hi = min(nmax, i_lo + kSliceW);
+    const uint32_t W = (i_hi - i_lo) << cg_shift;   // <= kSliceW * kMaxGroup result slots
+
+    const float4* p4 = dp.pts4 + h.pt_base;
+    const uint32_t* perm_g = dp.perm + h.pt_base;
+    const PlaneRec* planes_cost = dp.plane_cost + h.pt_base;
+    const PlaneRec* planes_local = dp.plane_local + h.pt_base;
+    const uint32_t first_leaf = (1u << D) - 1u;
+
+    // per-thread partial sums of the final (fixed-order) pass: thread t sums entries of candidate t / 32
+    double fin_sum = 0.0; uint32_t fin_c = 0, fin_v = 0, fin_pl = 0, fin_pt = 0;
+
+    {
+        const uint32_t c0 = 0u, c1 = W;
+        if (tid == 0) *s_ctr = c0;
+        if (WHICH & 2) for (uint32_t i = tid; i < c1 - c0; i += T) s_res[i] = NAN;   // entries that turn out to want no cost search
+        __syncthreads();
+        if (dbg == 2) return;
+
+        // ---- the searches: persistent lanes, refilled from the work list ----
+        {
+            bool have = false;
+            uint32_t w = 0u, wi_list = 0u, b_own = 0u, kk = 0u;
+            bool actA = false, actC = false;
+            double ax = NAN, ay = NAN, az = NAN, qx = NAN, qy = NAN, qz = NAN;
+            double bestA = INFINITY, bestC = INFINITY; uint32_t bposA = kNone, bposC = kNone;
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, delc = 0.f, e_lin = 0.f, e_const = 0.f;
+            float pd2[kPathMax];
+            uint32_t side = 0u, done = 0u, node = 0u; int go = -1;
+#pragma unroll
+            for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
+            bool exhausted = false;   // wave-uniform: the work list has been handed out
+            for (;;) {
+                // ---- refill: idle lanes claim the next entries (one LDS atomic per wave) ----
+                const unsigned long long idle = __ballot(!have);
+                if (idle != 0ull && !exhausted) {
+                    const uint32_t nidle = (uint32_t)__popcll(idle);
+                    uint32_t base = 0u;
+                    if (lane == 0) base = atomicAdd(s_ctr, nidle);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    exhausted = base + nidle >= c1;
+                    if (!have) {
+                        const uint32_t wn = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
+                        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                        float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (wn < c1 && il < s_n[cc]) {
+                            b_own = (uint32_t)(g * CG) + cc;
+                            const size_t at = ((size_t)b_own * nf + f) * (size_t)flist_stride + il;
+                            e = flist[at]; mp = fmp[at];
+                        }
+                        if (e.w & kWantMask) {
+                            w = wn; wi_list = il;
+                            kk = e.x;
+                            actC = (WHICH & 2) && (e.w & kFlagC);
+                            actA = (WHICH & 1) && (e.w & kFlagA);
+                            // the two MapPoint -> LiDAR-frame queries (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
+                            const double* cdl = s_cd + cc * kCdDoubles;
+                            struct { double s, Ri[9], ti[3]; float s32; } cd;
+                            cd.s = cdl[0];
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) cd.Ri[q] = cdl[1 + q];
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) cd.ti[q] = cdl[10 + q];
+                            cd.s32 = *(const float*)(cdl + 13);
+                            const double s = cd.s;
+                            ax = NAN; ay = NAN; az = NAN; qx = NAN; qy = NAN; qz = NAN;
+                            if (actA) {
+                                const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+                                const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
+                                const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
+                                const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
+                                const double sx = mx * s, sy = my * s, sz = mz * s;
+                                ax = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
+                                ay = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
+                                az = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
+                            }
+                            if (actC) {
+                                const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
+                                const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;       // CV_32F product (:232)
+                                const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
+                                const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
+                                const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
+                                const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
+                                qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
+                                qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
+                                qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+                            }
+                            // float steering point o and the radius del >= |q - o| per axis of both queries (see nn_dual_step)
+                            o0 = (float)(actC ? qx : ax); o1 = (float)(actC ? qy : ay); o2 = (float)(actC ? qz : az);
+                            double m = 0.0;
+                            if (actA) m = fmax(fmax(fabs(ax - (double)o0), fabs(ay - (double)o1)), fabs(az - (double)o2));
+                            if (actC) m = fmax(m, fmax(fmax(fabs(qx - (double)o0), fabs(qy - (double)o1)), fabs(qz - (double)o2)));
+                            const float del = (float)m * 1.00001f + 1e-30f;
+                            delc = del * 0.999999f;
+                            e_lin = 2.01f * del; e_const = 3.01f * del * del + 2.1e-19f * e_lin + 1e-37f;
+                            bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
+                            side = 0u; done = 0u; node = 0u; go = -1;
+                            have = true;
+                        }
+                    }
+                }
+                if (__ballot(have) == 0ull) break;
+                if (have && dbg == 4) { have = false; continue; }
+                if (have) {
+                    // ---- one leaf visit (nn_dual_step with one lane per query pair; the path registers persist) ----
+                    auto lower_bound = [&](float d) { const float a = fmaxf(fmaf(fabsf(d), 0.999999f, -delc), 0.f); return a * a; };
+                    int start = 0;
+                    if (go >= 0) {   // enter the far child at level go
+                        const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
+                        done |= 1u << go; side ^= 1u << go;
+                        node = 2u * anc + 1u + ((side >> go) & 1u);
+                        start = go + 1;
+                    }
+                    {
+                        const uint32_t keep = (1u << start) - 1u;
+                        side &= keep; done &= keep;
+                        uint32_t n1 = node + 1u;
+#pragma unroll
+                        for (int L = 0; L < kPathMax; ++L) {
+                            if (L >= (int)D) break;
+                            if (L >= start) {
+                                const TreeNode n = s_nodes[n1 - 1u];
+                                const float d = (n.dim == 0 ? o0 : (n.dim == 1 ? o1 : o2)) - n.split;
+                                const uint32_t r = (~__float_as_uint(d)) >> 31;
+                                pd2[L] = lower_bound(d);
+                                side |= r << L;
+                                n1 = (n1 << 1) | r;
+                            }
+                        }
+                        node = n1 - 1u;
+                    }
+                    {
+                        const uint32_t j = node - first_leaf;
+                        const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+                        float m1 = INFINITY, m2 = INFINITY; uint32_t mi = kNone;
+                        auto err_of = [&](float u) { return fmaf(1.001f * e_lin, __builtin_amdgcn_sqrtf(3.f * u), fmaf(1.5e-6f, u, e_const)); };
+                        constexpr int kLeafBatch = IBA_NN_LEAF_BATCH;
+                        for (uint32_t i0 = lo; i0 < hi; i0 += (uint32_t)kLeafBatch) {
+                            float X[kLeafBatch], Y[kLeafBatch], Z[kLeafBatch];
+#pragma unroll
+                            for (int u = 0; u < kLeafBatch; ++u) {
+                                const uint32_t iu = i0 + (uint32_t)u, ic = iu < hi ? iu : hi - 1u;
+                                const float4 v = p4[ic]; X[u] = v.x; Y[u] = v.y; Z[u] = v.z;
+                            }
+#pragma unroll
+                            for (int u = 0; u < kLeafBatch; ++u) {
+                                const uint32_t i = i0 + (uint32_t)u;
+                                const float dx = o0 - X[u], dy = o1 - Y[u], dz = o2 - Z[u];
+                                float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                                uu = i < hi ? uu : INFINITY;
+                                mi = uu < m1 ? i : mi;
+                                m2 = __builtin_amdgcn_fmed3f(m1, m2, uu);
+                                m1 = vmin(m1, uu);
+                            }
+                        }
+                        const float mono = 4.f * e_lin * e_lin;
+                        const float thi = m1 + err_of(m1);
+                        bool single = m2 >= mono && m2 - err_of(m2) > thi;
+                        const float bnear = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+                        const float bmax = fmaf(fabsf(bnear), 1.2e-7f, bnear);
+                        const bool skip = m1 >= mono && m1 - err_of(m1) > bmax;
+#ifdef IBA_LEAF_FORCE_SINGLE
+                        single = true;
+#endif
+                        if (mi != kNone && !skip) {
+                            uint32_t i = single ? mi : lo;
+                            while (single || i < hi) {
+                                const float4 pv = p4[i];
+                                bool take = single;
+                                if (!single) {
+                                    const float dx = o0 - pv.x, dy = o1 - pv.y, dz = o2 - pv.z;
+                                    const float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                                    take = uu - err_of(uu) <= thi;
+                                }
+                                if (take) {
+                                    const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+                                    if (WHICH & 1) {
+                                        const double dx = ax - x, dy = ay - y, dz = az - z;
+                                        nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, i, perm_g);
+                                    }
+                                    if (WHICH & 2) {
+                                        const double dx = qx - x, dy = qy - y, dz = qz - z;
+                                        nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, i, perm_g);
+                                    }
+                                }
+                                if (single) break;
+                                ++i;
+                            }
+                        }
+                    }
+                    {   // deepest level whose far side may still be within reach of either query
+                        const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+                        uint32_t cnd = 0u;
+#pragma unroll
+                        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= bestf ? 1u : 0u) << L;
+                        cnd &= ~done & ((1u << D) - 1u);
+                        done |= ~cnd;
+                        go = cnd ? 31 - __clz((int)cnd) : -1;
+                    }
+                }
+                if (have && go < 0) {
+                    // ---- the finished searches of this entry ----
+                    if (dbg != 5) {
+                    if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2)) {   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
+                        const PlaneRec r2 = planes_local[bposA];
+                        const bool state = !(r2.k < prm.neigh_min_pts || r2.far_d2 < prm.local_min_diff_dist2) &&
+                                           (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);   // pointcloud.h:699-717
+                        flist[((size_t)b_own * nf + f) * (size_t)flist_stride + wi_list].z = bposA | (state ? 0x80000000u : 0u);
+                    }
+                    double res = NAN;
+                    if ((WHICH & 2) && actC) {   // point-to-plane / point-to-point distance (iba_global.cpp:111-156, 241-249)
+                        const float4 pv = p4[bposC];
+                        const double ex = (double)pv.x - qx, ey = (double)pv.y - qy, ez = (double)pv.z - qz;
+                        double dist = sqrt((ex * ex + ey * ey) + ez * ez);
+                        bool is_plane = false;
+                        if (prm.use_plane) {
+                            const PlaneRec rec = planes_cost[bposC];
+                            if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
+                                !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
+                                dist = fabs(ex * rec.nx + ey * rec.ny + ez * rec.nz);
+                                is_plane = true;
+                            }
+                        }
+                        res = is_plane ? dist : -dist;   // dist >= 0: the sign bit carries the kind (also for a zero distance)
+                    }
+                    if (WHICH & 2) s_res[w - c0] = res;
+                    }
+                    have = false;
+                }
+            }
+        }
+        __syncthreads();
+        if (dbg == 3) return;
+        // ---- fixed-order sums of the chunk: 32 threads per candidate, each over a strided subset of its entries ----
+        if (WHICH & 2) {
+            const uint32_t cc = (uint32_t)tid >> 5, q = (uint32_t)tid & 31u;
+            if (cc < (uint32_t)cands_here) {
+                for (uint32_t wi = c0 + cc + (q << cg_shift); wi < c1; wi += 32u << cg_shift) {   // c0 is a multiple of CG
+                    const double r = s_res[wi - c0];
+                    if (r == r) {
+                        const double dist = fabs(r);
+                        const bool is_pt = __double_as_longlong(r) < 0;
+                        ++fin_c;
+                        if (dist < prm.corr_3d_3d_threshold) { fin_sum += dist; ++fin_v; fin_pl += is_pt ? 0u : 1u; fin_pt += is_pt ? 1u : 0u; }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // s_res is rewritten by the next chunk
+    }
+
+    // ---- per-candidate totals: butterfly over the 32 threads of a candidate (fixed order) ----
+    {
+        unsigned long long cnt = (unsigned long long)fin_c | ((unsigned long long)fin_v << 32);
+        unsigned long long cnt2 = (unsigned long long)fin_pl | ((unsigned long long)fin_pt << 32);
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) { fin_sum += __shfl_xor(fin_sum, off); cnt += __shfl_xor(cnt, off); cnt2 += __shfl_xor(cnt2, off); }
+        const int cc = tid >> 5, q = tid & 31;
+        if (cc < cands_here && q < kNNPartial) {
+            double out = 0.0;
+            if (q == 0) out = fin_sum;
+            else if (q == 1) out = (double)(cnt & 0xffffffffull);
+            else if (q == 2) out = (double)(cnt >> 32);
+            else if (q == 3) out = (double)(cnt2 & 0xffffffffull);
+            else if (q == 4) out = (double)(cnt2 >> 32);
+            nn_partials[((size_t)(g * CG + cc) * nn_nrec + (size_t)f * NS + sl) * kNNPartial + q] = out;
+        }
+    }
+#undef dp
+#undef prm
+#undef lay
+}
+
+
+// sums the per-frame records of each candidate in a fixed order, plus the search kernel's own (narrow) records.
+// grid: B blocks of kReduceThreads threads: 16 record groups x 64 slots for the wide records; 128 record lanes x 8 slots
+// for the narrow ones.
+__global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, const double* __restrict__ nn_partials, int nn_nrec,
+                                                                     double* __restrict__ out) {
+    constexpr int NG = kReduceThreads / kPartialStride;
+    constexpr int NL = kReduceThreads / kNNPartial;
+    __shared__ double s[NG][kPartialStride];
+    __shared__ double s2[NL][kNNPartial];
+    const int b = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const double* src = frame_partials + (size_t)b * nrec * kPartialStride;
+    const int per = (nrec + NG - 1) / NG, f0 = g * per, f1 = min(nrec, f0 + per);
+    double x = 0;
+    int f = f0;
+    for (; f + 4 <= f1; f += 4) {
+        const double v0 = src[(size_t)f * kPartialStride + i], v1 = src[(size_t)(f + 1) * kPartialStride + i];
+        const double v2 = src[(size_t)(f + 2) * kPartialStride + i], v3 = src[(size_t)(f + 3) * kPartialStride + i];
+        x = (((x + v0) + v1) + v2) + v3;
+    }
+    for (; f < f1; ++f) x += src[(size_t)f * kPartialStride + i];
+    s[g][i] = x;
+    if (nn_partials) {   // record lane rl sums the records rl, rl + NL, ... of slot q
+        const int q = threadIdx.x & (kNNPartial - 1), rl = threadIdx.x / kNNPartial;
+        const double* ns = nn_partials + (size_t)b * nn_nrec * kNNPartial;
+        double y = 0;
+        for (int r = rl; r < nn_nrec; r += NL) y += ns[(size_t)r * kNNPartial + q];
+        s2[rl][q] = y;
+    }
+    __syncthreads();
+    if (g == 0) {
+        double t = s[0][i];
+#pragma unroll
+        for (int qq = 1; qq < NG; ++qq) t += s[qq][i];
+        // the search kernel's slot q belongs to partial slot nn_slot[q]
+        int q = -1;
+        if (i == P_SUM_3D3D) q = 0; else if (i == P_CNT_3D3D) q = 1; else if (i == P_VALID_3D3D) q = 2; else if (i == P_VALID_PL) q = 3; else if (i == P_VALID_PT) q = 4;
+        if (q >= 0 && nn_partials) {
+            double y = 0;
+            for (int rl = 0; rl < NL; ++rl) y += s2[rl][q];
+            t += y;
+        }
+        out[(size_t)b * kPartialStride + i] = t;
+    }
+}
+
+}  // namespace iba

@@ -20,7 +20,10 @@ constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum
 #define IBA_GRID_CELL 2
 #endif
 constexpr int kGridCell = IBA_GRID_CELL;   // cell of the 1-bit reject bitmap (px): 2 px = 15 KB of LDS at 1241x376, ~4 % of a scan queued (4 px: 4 KB, 11 %)
-constexpr int kCoarseShift = kGridCell == 1 ? 4 : (kGridCell == 2 ? 3 : 2);   // CSR cells stay 16 px: coarse = fine >> kCoarseShift
+#ifndef IBA_COARSE_SHIFT
+#define IBA_COARSE_SHIFT (IBA_GRID_CELL == 1 ? 4 : (IBA_GRID_CELL == 2 ? 3 : 2))
+#endif
+constexpr int kCoarseShift = IBA_COARSE_SHIFT;   // CSR cells of 16 px by default: coarse = fine >> kCoarseShift
 #ifndef IBA_THREADS
 #define IBA_THREADS 512
 #endif

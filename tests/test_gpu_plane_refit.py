@@ -1,6 +1,7 @@
 """plane_cache = 0: every local plane (kNN(30) + covariance + closed-form eigen, iba_global.cpp:125-147,
 pointcloud.h:733-760 / 699-717) is refitted inside each evaluation, exactly the work the reference does.
-Results must equal the memoised mode bit for bit, and match the oracle to the usual bars."""
+Every term must equal the memoised mode's (all counters exact, every distance the same: the two modes differ only in the
+order in which they sum, so the means agree to a few ulp), and match the oracle to the usual bars."""
 import numpy as np
 import pytest
 
@@ -19,7 +20,12 @@ def test_refit_equals_memoised_and_oracle(pkg, synth, abi, ob, scene_small):
     cc, nc = hc.eval_full(xs)
     cr, nr = hr.eval_full(xs)
     for a, b in zip(cc, cr):
-        assert a.as_dict() == b.as_dict()
+        da, db = a.as_dict(), b.as_dict()
+        for key in da:
+            if key in ("f1", "f2", "C"):
+                assert abs(da[key] - db[key]) <= 1e-13 * abs(db[key]), key   # same terms, different summation order
+            else:
+                assert da[key] == db[key], key
     for a, b in zip(nc, nr):
         assert a.counts() == b.counts() and np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.cost == b.cost
     oc = o.eval_cost(pr, xs)

@@ -50,3 +50,12 @@ def test_candidate_queue_overflow(pkg, synth, abi, ob):
         _check(pkg, synth, ob, prob, meta, abi.reference_yaml_params())
     finally:
         del os.environ["IBA_CAND_BYTES"]
+
+
+def test_pair_list_overflow(pkg, synth, abi, ob):
+    os.environ["IBA_PAIR_BYTES"] = "1024"   # diagnostic knob: room for 64 (point, keypoint) pairs -> inline exact tests + rescan for the ties
+    try:
+        prob, meta = synth.make_scene(n_frames=3, pts_per_frame=9000, n_keypoints=2000, seed=8)
+        _check(pkg, synth, ob, prob, meta, abi.reference_yaml_params())
+    finally:
+        del os.environ["IBA_PAIR_BYTES"]

@@ -1,0 +1,30 @@
+"""Per-kernel time of the two-kernel evaluation chain at the bench shape (association kernel, grouped search kernel, rest)."""
+import importlib, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+pkg = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd")
+synth = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.synth")
+abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi")
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+wide = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0   # multiplier on the candidate spread
+prob, meta = synth.make_scene(n_frames=F, pts_per_frame=P, seed=0)
+h = pkg.IbaHandle(prob, abi.reference_yaml_params())
+h.set_timing(True)
+L = pkg.load_library()
+L.iba_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+def phases():
+    a, n, r = C.c_float(0), C.c_float(0), C.c_float(0)
+    L.iba_last_phase_ms(h.h, C.byref(a), C.byref(n), C.byref(r))
+    return a.value, n.value, r.value
+tag = "CG=%s NS=%s mono=%s" % (os.environ.get("IBA_NN_CG", "-"), os.environ.get("IBA_NN_NS", "-"), os.environ.get("IBA_MONOLITHIC", "0"))
+for B in (1, 8, 14, 64):
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(0), rot=5e-4 * wide, trans=5e-3 * wide, scale_rel=1e-3 * wide, n=B)
+    for mode, fn in (("full", h.eval_full), ("cost", h.eval_cost)):
+        ts = []
+        for _ in range(6):
+            fn(xs)
+            ts.append(phases())
+        t = np.median(np.array(ts[1:]), axis=0)
+        print("%s B=%2d %s: assoc %.3f ms  nn %.3f ms  rest %.3f ms  sum %.3f ms" % (tag, B, mode, t[0], t[1], t[2], t.sum()), flush=True)
