@@ -67,6 +67,7 @@ struct iba_handle {
     LdsLayout alay{};                     // LDS plan of iba_assoc_kernel
     uint32_t maxKw = 0;                   // max over frames of the keypoints that can own a term (MapPoint or covisible match)
     int assoc_dbg = 0;
+    bool factor_valu = true;              // IBA_FACTOR_MFMA=1 selects the matrix-core variant of the factor kernel (slower on gfx950: see iba_kernels.hpp)
     int nn_dbg = 0;                       // IBA_NN_DBG: cut the search kernel short (timing attribution; results are garbage)
     int nn_cg_max = 8;                    // candidates per search block (power of two <= kMaxGroup)
     DevBuf<uint32_t> d_lcount, d_lcount_frozen;   // work-list length per (candidate, frame)
@@ -332,7 +333,8 @@ iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, do
     if (h->n_frames == 0 || h->maxK == 0) return IBA_OK;
     const dim3 grid(h->n_frames, B);
     const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
-    hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+    if (h->factor_valu) hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+    else hipLaunchKernelGGL(iba_factor_mfma_kernel, grid, dim3(64), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }
@@ -637,6 +639,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_NN_CG")) h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e)));
     if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
+    if (const char* e = std::getenv("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
     if (!layout_assoc(h, h->alay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
     if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
     { NNLayout probe; if (!layout_nn(h, probe)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel"); } }

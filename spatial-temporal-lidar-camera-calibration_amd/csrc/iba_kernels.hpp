@@ -1999,6 +1999,9 @@ __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const 
 #ifndef IBA_FACTOR_WAVES
 #define IBA_FACTOR_WAVES 2
 #endif
+#ifndef IBA_FACTOR_MFMA_WAVES
+#define IBA_FACTOR_MFMA_WAVES 3   /* waves per SIMD the MFMA factor kernel is compiled for (<= 168 VGPRs: no spills; 4 spills 132 B per lane and is slower) */
+#endif
 #ifndef IBA_FACTOR_THREADS
 #define IBA_FACTOR_THREADS 64   /* ~264 blocks per (candidate, frame): 64-thread blocks waste the least of their last pass (256: 0.34 ms, 64: 0.24 ms) */
 #endif
@@ -2010,6 +2013,7 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
                                                                     const uint32_t* __restrict__ fcount, int flist_stride, int per_cand,
                                                                     double* __restrict__ partials, int nrec, int rec_base) {
     __shared__ double s_part[kFactorThreads / 64][48];
+    __shared__ double s_tr[kFactorThreads / 64][21][65];   // [sum][lane], rows padded against bank conflicts
     const int f = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameHdr& h = dp.frames[f];
@@ -2042,12 +2046,23 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
             p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, nn, is_plane, A);
         }
     }
-    // fixed-order reduction: DPP wave sums (VALU), then the 4 waves in order
+    // fixed-order reduction through LDS: every lane parks its 41 sums (two halves of <= 21 through an 11 KB transposing
+    // buffer), then lane v adds the 64 lanes' values of sum v in lane order. (The DPP butterfly this replaces cost 12 moves
+    // and 6 adds per 64-bit sum: 1.5 k instructions per block, a quarter of the kernel.)
     double* v = (double*)&A;   // 41 contiguous doubles
 #pragma unroll
-    for (int i = 0; i < 41; ++i) {
-        const double x = wave_sum_f64(v[i]);
-        if (lane == 63) s_part[wave][i] = x;
+    for (int half = 0; half < 2; ++half) {
+        const int base = half * 21, cnt = half ? 20 : 21;
+#pragma unroll
+        for (int q = 0; q < 21; ++q) if (q < cnt) s_tr[wave][q][lane] = v[base + q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < cnt) {
+            double x = 0;
+#pragma unroll 16
+            for (int j = 0; j < 64; ++j) x += s_tr[wave][lane][j];
+            s_part[wave][base + lane] = x;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     if (tid < kPartialStride) {
@@ -2061,6 +2076,201 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
         if (src >= 0) { out = s_part[0][src]; for (int w = 1; w < kFactorThreads / 64; ++w) out += s_part[w][src]; }
         partials[((size_t)b * nrec + rec_base + f) * kPartialStride + i] = out;
     }
+}
+
+// ---- the same sums on the matrix cores: H = sum_rows u v^T on v_mfma_f64_16x16x4_f64 (IBA_FACTOR_MFMA=1; NOT the default) ----
+// Measured on MI355X (C2 shape, 64 candidates, profiles/r02_factor_mfma.md): 0.22 ms at 3 waves per SIMD against 0.16 ms for
+// the all-VALU kernel above. gfx950 runs v_mfma_f64_16x16x4_f64 at 64 cycles = 16 FMA / clock / SIMD, the rate of v_fma_f64
+// itself, and a wave's VALU stream beside it slows to half (tools/ubench/mfma_f64.hip); only 2 x 8 x 8 of the 16 x 16 tile are
+// useful here, and the Jacobians that produce the rows (95 % of the kernel's VALU work) stay on the VALU. The kernel is kept
+// as the measured answer to "MFMA for the J^T J block" and is covered by the parity tests.
+// Every residual block is a few rank-1 terms u v^T of the 8 x 8 matrix [H | b] (row / column 7 = the residual column):
+//   IBA_PlaneFactor  J = [g z6^T | h] (2 NConv rows, g, h in R^{2 NConv}):  u1 = [z6, 0, 0], v1 = w [G z6, GH, Gr];
+//                    u2 = e6, v2 = w [GH z6, HH, Hr]   with G = g.g, GH = g.h, HH = h.h, Gr = g.r, Hr = h.r
+//   Point2Plane      u = [J, 0], v = w [J, r];          Point2Point: three such rows (the columns of dM, e)
+// A lane computes its block's terms with the VALU exactly as iba_factor_kernel does, parks them in LDS (z6 and five scalars
+// for a plane factor, up to three 8-double rows and the weight for a 3d-3d block), and the wave then feeds them to the MFMA
+// four k-slots x two 8-column halves at a time: lane l supplies A[m = l & 15][k = l >> 4] and B[k][n = l & 15]; columns
+// 0..7 and 8..15 carry DIFFERENT rows, so the two diagonal 8 x 8 blocks of the 16 x 16 accumulator are two partial sums of
+// [H | b] (the off-diagonal blocks are ignored) and one instruction retires eight rows. The 36 sums live in 8 accumulator
+// registers instead of 41 VGPR pairs; the scalars (cost, chi2, counts) stay on the VALU.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int kFactorPl = 12;    // doubles parked per lane: z6[6], wG, wGH, wGr, wHH, wHr of its plane factor, weight of its 3d-3d block
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IBA_FACTOR_MFMA_WAVES, IBA_FACTOR_MFMA_WAVES))) void iba_factor_mfma_kernel(
+    DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist, const uint32_t* __restrict__ fcount, int flist_stride, int per_cand,
+    double* __restrict__ partials, int nrec, int rec_base) {
+    __shared__ __align__(16) double s_pl[64][kFactorPl];   // 6 KB + 4 KB: sixteen one-wave blocks per CU
+    __shared__ __align__(16) double s_r3[64][8];           // one row [u (7) | residual] of every lane's 3d-3d block at a time
+    double* s_out = &s_pl[0][0];                           // the finished record (after the last pass)
+    const int f = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x;
+    const FrameHdr& h = dp.frames[f];
+    const Cand& c = cands[b];
+    const size_t row = (size_t)(per_cand ? b : 0) * dp.n_frames + f;
+    const uint4* fl = flist + row * (size_t)flist_stride;
+    const uint32_t n = fcount[row];
+    const float4* p4 = dp.pts4 + h.pt_base;
+    const PlaneRec* planes = prm.plane_cache ? dp.plane_local + h.pt_base
+                                             : dp.scratch_local + (size_t)(per_cand ? dp.scratch_slot_base + b : 0) * (size_t)dp.n_pt_total + h.pt_base;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double cost = 0, chi2 = 0, nf2d = 0, nfpl = 0, nfpt = 0, nres = 0, h66 = 0, b6 = 0;
+    const int kslot = lane >> 4, half = (lane >> 3) & 1, ci = lane & 7;   // this lane's place in the MFMA operands
+    auto lds_sync = [&]() {   // LDS hand-over between the lanes of the one wave of this block
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        uint4 e = make_uint4(0u, kNone, kNone, 0u);
+        if (i < n) e = fl[i];
+        const uint32_t k = e.x;
+        bool has_pl = false, is_pt = false;
+        double* P = s_pl[lane];
+        {   // IBA_PlaneFactor (IBACalib2.hpp:152-184)
+            IBA_JAC_CONTRACT
+            double z6[6] = {0, 0, 0, 0, 0, 0};
+            double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0, w = 0;
+            if (e.y != kNone) {
+                const PlaneRec rec = planes[e.y];
+                const float4 pt = p4[e.y];
+                const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, n0[3] = {rec.nx, rec.ny, rec.nz};
+                const float2 uv = dp.kp_uv[h.kp_base + k];
+                const int nconv = plane_factor_core(c, h, dp, k, h.K, (double)uv.x, (double)uv.y, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
+IBA_JAC_CONTRACT
+                    ssq += ru * ru + rv * rv;
+                    G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
+                    Gr += gu * ru + gv * rv; Hr += hu * ru + hv * rv;
+                });
+                if (nconv > 0) {
+                    double rho0; huber_w(prm.robust_kernel_delta, ssq, rho0, w);
+                    cost += 0.5 * rho0; chi2 += ssq; nf2d += 1.0; nres += 2.0 * nconv;
+                    h66 += w * HH; b6 += w * Hr;
+                    has_pl = true;
+                }
+            }
+            if (!has_pl) { w = 0; for (int q = 0; q < 6; ++q) z6[q] = 0; }
+            *(double2*)(P + 0) = make_double2(z6[0], z6[1]); *(double2*)(P + 2) = make_double2(z6[2], z6[3]); *(double2*)(P + 4) = make_double2(z6[4], z6[5]);
+            *(double2*)(P + 6) = make_double2(w * G, w * GH); P[8] = w * Gr;
+        }
+        {   // Point2Plane / Point2Point (IBACalib2.hpp:570-584, 611-625): first row [u | residual] and the weight
+            IBA_JAC_CONTRACT
+            double w = 0;
+            double* Q = s_r3[lane];
+            if (e.z != kNone) {
+                const uint32_t pos = e.z & 0x7FFFFFFFu; const bool is_plane = (e.z >> 31) != 0;
+                const PlaneRec rec = planes[pos];
+                const float4 pt = p4[pos];
+                double M[3], dM[7][3];
+                p2x_core(c, h, dp.kp_mp[h.kp_base + k], M, dM);
+                const double ev[3] = {M[0] - (double)pt.x, M[1] - (double)pt.y, M[2] - (double)pt.z};
+                if (is_plane) {
+                    const double r = (ev[0] * rec.nx + ev[1] * rec.ny) + ev[2] * rec.nz;
+                    double J[8];
+                    for (int kk = 0; kk < 7; ++kk) J[kk] = (dM[kk][0] * rec.nx + dM[kk][1] * rec.ny) + dM[kk][2] * rec.nz;
+                    J[7] = r;
+                    double rho0; huber_w(prm.robust_kernel_3ddelta, r * r, rho0, w);
+                    cost += 0.5 * rho0; chi2 += r * r; nfpl += 1.0; nres += 1.0;
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) *(double2*)(Q + q) = make_double2(J[q], J[q + 1]);
+                } else {
+                    const double ssq = (ev[0] * ev[0] + ev[1] * ev[1]) + ev[2] * ev[2];
+                    double rho0; huber_w(prm.robust_kernel_3ddelta, ssq, rho0, w);
+                    cost += 0.5 * rho0; chi2 += ssq; nfpt += 1.0; nres += 3.0;
+                    is_pt = true;
+                    *(double2*)(Q + 0) = make_double2(dM[0][0], dM[1][0]); *(double2*)(Q + 2) = make_double2(dM[2][0], dM[3][0]);
+                    *(double2*)(Q + 4) = make_double2(dM[4][0], dM[5][0]); *(double2*)(Q + 6) = make_double2(dM[6][0], ev[0]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) *(double2*)(Q + q) = make_double2(0.0, 0.0);
+            }
+            P[11] = w;
+        }
+        const unsigned long long balT = __ballot(is_pt);
+        lds_sync();
+        // All operands of a group of instructions are fetched before the first of them issues (the LDS latency is paid once per
+        // group, not once per instruction); empty slots hold zeros, so there is nothing to skip.
+        // plane factors, one row each: eight source lanes per instruction. (The second rank-1 term of a plane factor, e6 v2^T,
+        // only contributes H[6][6] and b[6] beyond what symmetry gives: those two sums stay on the VALU.)
+        {
+            double a[8], bb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double* S = s_pl[8 * j + 2 * kslot + half];
+                const double zi = S[ci < 6 ? ci : 5], sc = S[ci < 6 ? 6 : (ci == 6 ? 7 : 8)];   // b = wG z_i | wGH | wGr
+                a[j] = ci < 6 ? zi : 0.0;
+                bb[j] = ci < 6 ? sc * zi : sc;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], bb[j], acc, 0, 0, 0);
+        }
+        // first row of every 3d-3d block: eight source lanes per instruction
+        {
+            double a[8], bb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int src = 8 * j + 2 * kslot + half;
+                const double ui = s_r3[src][ci], w = s_pl[src][11];
+                a[j] = ci < 7 ? ui : 0.0;
+                bb[j] = w * ui;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], bb[j], acc, 0, 0, 0);
+        }
+        // rows 2 and 3 of the point-to-point blocks take the same slots, one row at a time
+        if (balT) {
+            for (int r = 1; r < 3; ++r) {
+                __builtin_amdgcn_wave_barrier();
+                if (is_pt) {   // rare: the block's Jacobian again rather than 48 registers held across the common path
+                    IBA_JAC_CONTRACT
+                    const float4 pt = p4[e.z & 0x7FFFFFFFu];
+                    double M[3], dM[7][3];
+                    p2x_core(c, h, dp.kp_mp[h.kp_base + k], M, dM);
+                    const double er = r == 1 ? M[1] - (double)pt.y : M[2] - (double)pt.z;
+                    double* Q = s_r3[lane];
+                    *(double2*)(Q + 0) = make_double2(dM[0][r], dM[1][r]); *(double2*)(Q + 2) = make_double2(dM[2][r], dM[3][r]);
+                    *(double2*)(Q + 4) = make_double2(dM[4][r], dM[5][r]); *(double2*)(Q + 6) = make_double2(dM[6][r], er);
+                }
+                lds_sync();
+                for (int j = 0; j < 8; ++j) {
+                    if (((balT >> (8 * j)) & 0xFFull) == 0ull) continue;
+                    const int src = 8 * j + 2 * kslot + half;
+                    const bool on = (balT >> src) & 1ull;   // the other lanes' slots still hold their first rows
+                    const double ui = on ? s_r3[src][ci] : 0.0, w = s_pl[src][11];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ci < 7 ? ui : 0.0, w * ui, acc, 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the slots are rewritten by the next pass
+    }
+    // [H | b] = diagonal block 0 + diagonal block 1 of the accumulator: lane l holds D[row = (l >> 4) + 4 reg][col = l & 15]
+    s_out[lane] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    {
+        // rows 8..15 / columns 8..15 live 8 lanes up (same row group, col + 8) in registers 2, 3
+        const double up0 = __shfl_down(acc[2], 8), up1 = __shfl_down(acc[3], 8);
+        if ((lane & 15) < 8) {
+            const int col = lane & 15;
+            const double v[2] = {acc[0] + up0, acc[1] + up1};
+            for (int q = 0; q < 2; ++q) {
+                const int r = (lane >> 4) + 4 * q;
+                if (r <= col && col < 7) s_out[P_H0 + hidx(r, col)] = v[q];
+                else if (col == 7 && r < 7) s_out[P_B0 + r] = v[q];
+            }
+        }
+    }
+    {
+        const double t0 = wave_sum_f64(chi2), t1 = wave_sum_f64(cost), t2 = wave_sum_f64(nf2d), t3 = wave_sum_f64(nfpl), t4 = wave_sum_f64(nfpt), t5 = wave_sum_f64(nres);
+        const double t6 = wave_sum_f64(h66), t7 = wave_sum_f64(b6);
+        lds_sync();
+        if (lane == 63) {
+            s_out[P_CHI2] = t0; s_out[P_COST] = t1; s_out[P_NF_3D2D] = t2; s_out[P_NF_P2PL] = t3; s_out[P_NF_P2PT] = t4; s_out[P_NRES] = t5;
+            s_out[P_H0 + hidx(6, 6)] += t6; s_out[P_B0 + 6] += t7;   // the plane factors' share of H[6][6], b[6]
+        }
+    }
+    lds_sync();
+    partials[((size_t)b * nrec + rec_base + f) * kPartialStride + lane] = s_out[lane];
 }
 
 // Per-residual output of the frozen problem (for Ceres/g2o adaptors and tests): one lane per keypoint, rows at

@@ -113,3 +113,29 @@ def test_per_residual_rows_match_oracle(pkg, synth, abi, ob, scene_small):
     assert np.allclose(rg, ro, rtol=1e-9, atol=1e-9)
     assert np.allclose(Jg, Jo, rtol=1e-8, atol=1e-8 * np.abs(Jo).max())
     h.close()
+
+
+def test_mfma_factor_kernel_matches_oracle(pkg, synth, abi, ob, scene_small, monkeypatch):
+    """IBA_FACTOR_MFMA=1: the normal equations accumulated on v_mfma_f64_16x16x4_f64 (rank-1 rows through LDS) instead of the
+    VALU: same bars as the default kernel, and equal to it to summation order."""
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(11), n=3)])
+    hv = pkg.IbaHandle(prob, p)
+    monkeypatch.setenv("IBA_FACTOR_MFMA", "1")
+    hm = pkg.IbaHandle(prob, p)
+    monkeypatch.delenv("IBA_FACTOR_MFMA")
+    o = ob.Oracle(prob)
+    gm, gv, r = hm.eval_normal(xs), hv.eval_normal(xs), o.eval_normal(p, xs)
+    for a, v, b in zip(gm, gv, r):
+        assert a.counts() == b.counts() == v.counts()
+        scale = np.abs(b.H_np()).max()
+        assert np.max(np.abs(a.H_np() - b.H_np())) <= 1e-9 * scale and np.max(np.abs(a.b_np() - b.b_np())) <= 1e-9 * np.abs(b.b_np()).max()
+        assert np.max(np.abs(a.H_np() - v.H_np())) <= 1e-12 * scale
+        assert abs(a.cost - b.cost) <= 1e-10 * abs(b.cost) and abs(a.chi2 - b.chi2) <= 1e-10 * abs(b.chi2)
+    hm.build_problem(xs[1])
+    o.build_problem(p, xs[1])
+    a, b = hm.eval_factors(xs[2])[0], o.eval_factors(p, xs[2])[0]
+    assert a.counts() == b.counts() and np.max(np.abs(a.H_np() - b.H_np())) <= 1e-9 * np.abs(b.H_np()).max()
+    hm.close()
+    hv.close()
