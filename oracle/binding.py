@@ -127,6 +127,11 @@ class Oracle:
         lib().oracle_eval_factors(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out)
         return list(out)
 
+    @staticmethod
+    def set_exact_sums(on):
+        """test aid: add the per-block contributions of the normal equations in long double (see iba_oracle.cpp)"""
+        lib().oracle_set_exact_sums(C.c_int(1 if on else 0))
+
     def eval_normal(self, params, x, nthreads=1):
         x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
         B = len(x)

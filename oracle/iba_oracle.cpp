@@ -406,10 +406,41 @@ inline void huber(double a, double s, double& rho0, double& rho1) {
     else { rho0 = s; rho1 = 1.0; }
 }
 
+// TEST AID (no reference counterpart): with g_exact_sums the per-block contributions rho1 J^T J, rho1 J^T r, rho — the same
+// doubles as otherwise — are ADDED in long double (x87 80-bit), i.e. the sums are taken (nearly) exactly instead of in the
+// order-dependent double arithmetic of a sequential loop. Used to separate "the device differs from the reference's terms"
+// from "two double summations of 10^5 cancelling terms differ from each other" (tests/test_gpu_golden_and_shapes.py).
+static bool g_exact_sums = false;
+
 void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_normal_out& out, bool multithread = false) {
     std::memset(&out, 0, sizeof(out));
     const long n = (long)O.factors.size();
     (void)multithread;
+    if (g_exact_sums) {
+        long double LH[49] = {0}, Lb[7] = {0}, Lcost = 0, Lchi2 = 0;
+        double r[64], J[64 * 7];
+        for (long fi = 0; fi < n; ++fi) {
+            const Factor& f = O.factors[fi];
+            const int rows = f.rows();
+            if (rows > 64) continue;
+            eval_factor(f, x, r, J);
+            double s = 0; for (int i = 0; i < rows; ++i) s += r[i] * r[i];
+            double rho0, rho1; huber(f.kind == 0 ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, s, rho0, rho1);
+            Lcost += 0.5 * rho0; Lchi2 += s;
+            for (int i = 0; i < rows; ++i)
+                for (int a = 0; a < 7; ++a) {
+                    Lb[a] += rho1 * J[i * 7 + a] * r[i];
+                    for (int c = 0; c < 7; ++c) LH[a * 7 + c] += rho1 * J[i * 7 + a] * J[i * 7 + c];
+                }
+            out.n_residuals += rows;
+            if (f.kind == 0) out.n_factor_3d2d++; else if (f.kind == 1) out.n_factor_p2pl++; else out.n_factor_p2pt++;
+        }
+        for (int i = 0; i < 49; ++i) out.H[i] = (double)LH[i];
+        for (int i = 0; i < 7; ++i) out.b[i] = (double)Lb[i];
+        out.cost = (double)Lcost; out.chi2 = (double)Lchi2;
+        out.frames_used = O.bp_frames_used; out.n_corr = O.bp_n_corr;
+        return;
+    }
 #pragma omp parallel if (multithread)
     {
         iba_normal_out loc; std::memset(&loc, 0, sizeof(loc));
@@ -515,6 +546,7 @@ int oracle_eval_factors(void* h, const iba_params* p, const double* x, int B, ib
     for (int b = 0; b < B; ++b) EvalFactors(*(Oracle*)h, *p, x + 7 * b, out[b]);
     return 0;
 }
+void oracle_set_exact_sums(int on) { g_exact_sums = on != 0; }
 int oracle_eval_normal(void* h, const iba_params* p, const double* x, int B, iba_normal_out* out, int nthreads) {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);

@@ -33,9 +33,10 @@ class IbaError(RuntimeError):
 def build_extension(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). Returns the .so path."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp"))] + [HEADER_PATH]
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if force or stale:
+    # make tracks the dependencies itself (every .hip / .cpp / .hpp of csrc and the public header)
+    if force:
+        subprocess.check_call(["make", "-C", src_dir, "-s", "-B"])
+    else:
         subprocess.check_call(["make", "-C", src_dir, "-s"])
     return LIB_PATH
 

@@ -255,9 +255,10 @@ bool layout_nn(const iba_handle* h, NNLayout& L) {
     return L.total <= kLdsBytes;
 }
 
+iba_status ensure_scratch(iba_handle* h);
 iba_status compute_plane_cache(iba_handle* h) {
     const iba_params& p = h->params;
-    if (!p.plane_cache) return IBA_OK;   // planes are refitted inside every evaluation
+    if (!p.plane_cache) return ensure_scratch(h);   // planes are refitted inside every evaluation, into per-candidate scratch
     const DevProblem dp = h->dev_problem();
     auto run = [&](double r2, int max_pts, PlaneRec* out) -> hipError_t {
         dim3 grid((h->maxP + 3) / 4, h->n_frames);
@@ -280,17 +281,19 @@ iba_status compute_plane_cache(iba_handle* h) {
     return IBA_OK;
 }
 
-// plane_cache = 0: private plane records for B candidates (+ slot 0 for the frozen problem of iba_build_problem)
-iba_status ensure_scratch(iba_handle* h, int B, hipStream_t st) {
+// plane_cache = 0: private plane records for IBA_MAX_BATCH candidates (+ slot 0 for the frozen problem of iba_build_problem),
+// allocated when the mode is entered (iba_create / iba_set_params) and never during an evaluation: the *_partial entry points
+// do not synchronise, and the frozen problem's planes (slot 0) survive evaluations of any batch size.
+iba_status ensure_scratch(iba_handle* h) {
     if (h->params.plane_cache) return IBA_OK;
     const bool alias = (h->params.norm_radius == h->params.neigh_radius && h->params.norm_max_pts == h->params.neigh_max_pts);
-    if (h->scratch_cap >= B && h->scratch_local_aliases == alias) return IBA_OK;
-    HIP_TRY(h, hipStreamSynchronize(st)); HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->scratch_cap >= IBA_MAX_BATCH && h->scratch_local_aliases == alias) return IBA_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->scratch_cost.release(); h->scratch_local.release();
-    const size_t n = (size_t)(B + 1) * (size_t)std::max<int64_t>(h->n_pt_total, 1);
+    const size_t n = (size_t)(IBA_MAX_BATCH + 1) * (size_t)std::max<int64_t>(h->n_pt_total, 1);
     HIP_TRY(h, h->scratch_cost.alloc(n));
     if (!alias) HIP_TRY(h, h->scratch_local.alloc(n));
-    h->scratch_cap = B; h->scratch_local_aliases = alias;
+    h->scratch_cap = IBA_MAX_BATCH; h->scratch_local_aliases = alias;
     h->frozen_valid = false;   // slot 0 (the frozen problem's planes) went with the old buffer
     return IBA_OK;
 }
@@ -299,7 +302,7 @@ template <int MODE>
 iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, uint2* d_assoc, int nrec, hipStream_t st, int scratch_slot_base = 1) {
     const bool frozen = (d_assoc == h->d_assoc_frozen.p);
     uint4* fl = frozen ? h->d_flist_frozen.p : h->d_flist.p; uint32_t* fc = frozen ? h->d_fcount_frozen.p : h->d_fcount.p;
-    if (MODE != MODE_CORR) { iba_status es = ensure_scratch(h, B, st); if (es != IBA_OK) return es; }
+    if (MODE != MODE_CORR && !h->params.plane_cache && h->scratch_cap < B) return fail(h, IBA_ERR_STATE, "plane scratch not allocated");
     DevProblem dp = h->dev_problem();
     dp.scratch_slot_base = scratch_slot_base;
     if ((MODE == MODE_COST || MODE == MODE_BOTH) && h->n_frames > 0) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
@@ -476,6 +479,16 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         iba_status ps = check_params(nullptr, *params);
         if (ps != IBA_OK) return ps;
     }
+    // ---- validation: every CSR array of the descriptor (covisible keyframes outside the owned slice are dereferenced too) ----
+    {
+        auto monotonic = [](const uint64_t* o, int64_t n) { if (!o) return false; for (int64_t i = 0; i < n; ++i) if (o[i + 1] < o[i]) return false; return true; };
+        if (F > 0 && (!d->pt_offset || !d->kp_offset || !d->covis_offset || !d->intrinsics || !d->Tcw || !d->Tc_next || !d->Tl_next)) { return fail(nullptr, IBA_ERR_INVALID_ARG, "null array in the problem descriptor"); }
+        if (F > 0 && (!monotonic(d->pt_offset, F) || !monotonic(d->kp_offset, F) || !monotonic(d->covis_offset, F))) { return fail(nullptr, IBA_ERR_INVALID_ARG, "pt_offset / kp_offset / covis_offset must be non-decreasing"); }
+        const uint64_t S = F > 0 ? d->covis_offset[F] : 0, Ntot = F > 0 ? d->pt_offset[F] : 0, Ktot = F > 0 ? d->kp_offset[F] : 0;
+        if ((Ntot > 0 && !d->pts_xyz) || (Ktot > 0 && (!d->kp_uv || !d->kp_has_mappoint || !d->kp_mappoint_w))) { return fail(nullptr, IBA_ERR_INVALID_ARG, "null point / keypoint array in the problem descriptor"); }
+        if (S > 0 && (!d->covis_frame || !d->covis_relpose || !d->match_offset || !monotonic(d->match_offset, (int64_t)S))) { return fail(nullptr, IBA_ERR_INVALID_ARG, "covisibility arrays missing or match_offset not non-decreasing"); }
+        if (S > 0 && d->match_offset[S] > 0 && (!d->match_kp_ref || !d->match_kp_covis)) { return fail(nullptr, IBA_ERR_INVALID_ARG, "null match arrays in the problem descriptor"); }
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, IBA_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -488,7 +501,6 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     h->global_frames = F; h->frame_begin = frame_begin; h->n_frames = frame_end - frame_begin;
     const int nf = h->n_frames;
 
-    // ---- validation of the owned slice ----
     for (int f = frame_begin; f < frame_end; ++f) {
         const uint64_t P = d->pt_offset[f + 1] - d->pt_offset[f], K = d->kp_offset[f + 1] - d->kp_offset[f];
         if (P >= (1ull << 22) || K >= 65535ull) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan (>= 2^22 points) or keypoint count (>= 65535) too large"); }

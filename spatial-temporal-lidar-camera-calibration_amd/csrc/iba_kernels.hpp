@@ -1859,12 +1859,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(IBA_FR
 // IRLS weights as Ceres' Corrector applies them (rho'' <= 0), accumulated as the upper triangle of
 // H = sum w J^T J, b = sum w J^T r. Derivatives are analytic: the chain rule through the same
 // expressions the reference's Jets differentiate, with dR/dx, dt/dx from the host duals (Cand).
-// FMA contraction inside the Jacobian-path functions only (the cost path is compiled with -ffp-contract=off throughout).
-// -DIBA_JAC_NO_FMA builds them uncontracted, for parity studies (tools/soak_parity.py).
-#ifdef IBA_JAC_NO_FMA
-#define IBA_JAC_CONTRACT _Pragma("clang fp contract(off)")
-#else
+// The Jacobian path is compiled WITHOUT FMA contraction, like the cost path: measured on the C2 / C3 scenes
+// (tools/entry_parity_c2.py, r02), every entry of H and b above 1e-6 of the largest then agrees with the oracle's forward-mode
+// duals to 6e-14 .. 2e-13 of ITSELF (cost 2e-12); with contraction the same figures are 5e-11 .. 1.2e-10 — inside BASELINE.md's
+// 1e-10 gate only just, for 0.05 ms per 64 candidates (0.17 -> 0.22 ms). -DIBA_JAC_FMA builds the contracted variant.
+// (What neither build can remove: a plane factor whose viewing ray lies almost in its plane — Z0 = num / den with a
+// cancelling den, residuals of 10^4 px, Jacobian entries of 10^9 — carries a relative uncertainty of ~1e-10 in the
+// reference's own double arithmetic; one such block shifts entries of b by up to 1e-7 of themselves in either build.)
+#ifdef IBA_JAC_FMA
 #define IBA_JAC_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define IBA_JAC_CONTRACT _Pragma("clang fp contract(off)")
 #endif
 struct NAcc { double H[28], b[7], chi2, cost, nf2d, nfpl, nfpt, nres; };
 

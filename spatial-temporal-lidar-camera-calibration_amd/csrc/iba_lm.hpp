@@ -3,7 +3,8 @@
 // Ceres itself is a third-party dependency of the reference (absent here); this follows its published
 // trust-region LM (LevenbergMarquardtStrategy + TrustRegionMinimizer): Jacobi column scaling,
 // (H + diag(H)/radius) dx = -g, step acceptance by relative decrease, radius update
-// radius /= max(1/3, 1 - (2 rho - 1)^3), and its three convergence tests.
+// radius /= max(1/3, 1 - (2 rho - 1)^3), and its three convergence tests in the minimizer's own order (gradient tolerance
+// at the top of an iteration; parameter and function tolerance after the candidate's evaluation and before acceptance).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -71,18 +72,20 @@ inline bool calibrate_lm(const double* x0, const LmOptions& o, Build build, Eval
             if (!ok || !(model > 0)) { radius = std::max(o.min_trust_region_radius, radius / decrease_factor); decrease_factor *= 2; if (radius <= o.min_trust_region_radius) break; continue; }
             double xn[7], step2 = 0, xn2 = 0;
             for (int i = 0; i < 7; ++i) { const double d = scale[i] * ds[i]; xn[i] = x[i] + d; step2 += d * d; xn2 += x[i] * x[i]; }
-            if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) break;
+            // TrustRegionMinimizer::Minimize order: evaluate the candidate, then the parameter- and the function-tolerance
+            // tests against the CURRENT point's cost — a run that stops on either keeps x (the candidate is not committed,
+            // and the stop can come on a step that would have been rejected) — and only then accept or reject.
             double Hn[49], gn[7], cn;
             if (!eval(xn, Hn, gn, cn)) return false;
             ++r.evaluations;
+            if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) break;
+            if (std::fabs(cost - cn) <= o.function_tolerance * cost) break;
             const double rho = (cost - cn) / model;
             if (rho > o.min_relative_decrease) {
-                const double dc = cost - cn;
                 std::memcpy(x, xn, sizeof(x)); std::memcpy(H, Hn, sizeof(H)); std::memcpy(g, gn, sizeof(g));
-                const double prev = cost; cost = cn;
+                cost = cn;
                 const double t = 2.0 * rho - 1.0;
                 radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t)); decrease_factor = 2.0;
-                if (std::fabs(dc) <= o.function_tolerance * prev) break;
             } else {
                 radius = std::max(o.min_trust_region_radius, radius / decrease_factor); decrease_factor *= 2;
                 if (radius <= o.min_trust_region_radius) break;

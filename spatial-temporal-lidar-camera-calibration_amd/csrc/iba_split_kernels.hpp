@@ -661,7 +661,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                         }
                     }
                 }
-                if (__ballot(have) == 0ull) break;
+                if (__ballot(have) == 0ull) { if (exhausted) break; continue; }   // a claim of 64 entries none of which wants a search: claim again
                 if (have && dbg == 4) { have = false; continue; }
                 if (have) {
                     // ---- one leaf visit (nn_dual_step with one lane per query pair; the path registers persist) ----

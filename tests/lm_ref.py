@@ -36,20 +36,19 @@ def calibrate_lm(x0, build, evalf, max_outer=30, max_inner=30, min_diff=1e-6, ft
                     break
                 continue
             d = scale * ds
+            xn = x + d
+            Hn, gn, cn = evalf(xn)   # Ceres order: candidate first, tolerance tests before acceptance (x is kept on a stop)
+            stats["evals"] += 1
             if np.linalg.norm(d) <= ptol * (np.linalg.norm(x) + ptol):
                 break
-            xn = x + d
-            Hn, gn, cn = evalf(xn)
-            stats["evals"] += 1
+            if abs(cost - cn) <= ftol * cost:
+                break
             rho = (cost - cn) / model
             if rho > 1e-3:
-                dc, prev = cost - cn, cost
                 x, H, g, cost = xn, Hn, gn, cn
                 t = 2.0 * rho - 1.0
                 radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - t ** 3))
                 dec = 2.0
-                if abs(dc) <= ftol * prev:
-                    break
             else:
                 radius = max(1e-32, radius / dec)
                 dec *= 2

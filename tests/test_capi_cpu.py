@@ -92,3 +92,20 @@ def test_synth_scene_is_deterministic_and_consistent(synth):
     assert np.allclose(R, Rg, atol=1e-12) and np.allclose(t, tg, atol=1e-12) and s == ma["s_star"]
     t2, _ = synth.tile_scene(a, ma, 2)
     assert t2.n_frames == 6 and t2.n_points == 2 * a.n_points and t2.arrays["covis_frame"][-1] >= 3
+
+
+def test_descriptor_validation_precedes_the_device_probe(pkg, abi, synth):
+    """Non-monotonic CSR offsets are refused with IBA_ERR_INVALID_ARG before anything is dereferenced — also for covisible
+    keyframes outside the owned frame range."""
+    import copy
+    prob, _ = synth.make_scene(n_frames=3, pts_per_frame=300, n_keypoints=100, seed=0, new_mappoints=10, scan_kp=10)
+    for name in ("kp_offset", "pt_offset", "covis_offset", "match_offset"):
+        bad = copy.copy(prob)
+        bad.arrays = {k: v.copy() for k, v in prob.arrays.items()}
+        o = bad.arrays[name]
+        o[2] = o[1] - 1 if o[1] > 0 else o[-1] + 7   # decreases at index 2 (or at the end)
+        if not np.any(np.diff(o.astype(np.int64)) < 0):
+            o[1] = o[-1] + 7
+        with pytest.raises(pkg.IbaError) as e:
+            pkg.IbaHandle(bad, abi.reference_yaml_params(), frame_begin=0, frame_end=1)
+        assert e.value.status == 1, name
