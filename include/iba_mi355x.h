@@ -195,6 +195,13 @@ iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out
  * at x_assoc, then evaluate the frozen residual blocks at B other x. */
 iba_status iba_build_problem(iba_handle* h, const double* x_assoc);
 iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out);
+/* The frozen problem as ONE residual block for a solver that wants residuals and Jacobians (Ceres: the blocks
+ * BuildProblem() adds, iba_local.cpp:263-308; g2o: a unary edge on VertexSim3, IBACalib.hpp:74-155): 8 rows with
+ *   J^T J = H,  J^T r = b,  |r|^2 = 2 cost      ([J | r] = upper Cholesky factor of [[H, b], [b^T, 2 cost]])
+ * so that the solver's Gauss-Newton model AND its step-acceptance cost are those of the whole problem, robust weights
+ * included. r has 8 entries, J is 8 x 7 row-major. iba_whiten_normal is the host-only half (any iba_normal_out). */
+iba_status iba_eval_whitened(iba_handle* h, const double* x, double r[8], double J[56]);
+iba_status iba_whiten_normal(const iba_normal_out* normal, double r[8], double J[56]);
 /* Caller of the Jacobian path: the outer re-association loop of iba_local
  * (iba_local.cpp:434-460) around a Ceres-style LM on the device-reduced 7x7 normal equations. */
 typedef struct iba_lm_options {

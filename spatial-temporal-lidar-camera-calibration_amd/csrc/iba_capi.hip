@@ -991,6 +991,40 @@ iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_norma
     return iba_finalize_normal(&h->params, h->h_partials, B, out);
 }
 
+// ---- one 8-row residual block standing for the whole frozen problem (Ceres / g2o adaptors) ----
+// [J | r] = upper Cholesky factor of M = [[H, b], [b^T, 2 cost]]: J^T J = H, J^T r = b, |r|^2 = 2 cost. M is positive
+// semi-definite: it is a sum over residual blocks of w [J_k | r_k]^T [J_k | r_k] plus (rho_k - w_k s_k) >= 0 on the last
+// diagonal entry (Huber: rho(s) - rho'(s) s = a (sqrt(s) - a) > 0 beyond the kink). A pivot that is not positive relative to
+// its column (rank-deficient H: no factor constrains that direction) leaves a zero row.
+iba_status iba_whiten_normal(const iba_normal_out* n, double r[8], double J[56]) {
+    if (!n || !r || !J) return IBA_ERR_INVALID_ARG;
+    double M[64];
+    for (int i = 0; i < 7; ++i) { for (int j = 0; j < 7; ++j) M[i * 8 + j] = n->H[i * 7 + j]; M[i * 8 + 7] = n->b[i]; M[7 * 8 + i] = n->b[i]; }
+    M[63] = 2.0 * n->cost;
+    double R[64]; std::memset(R, 0, sizeof(R));   // upper triangular, R^T R = M
+    for (int i = 0; i < 8; ++i) {
+        double d = M[i * 8 + i];
+        for (int k = 0; k < i; ++k) d -= R[k * 8 + i] * R[k * 8 + i];
+        if (!(d > 1e-14 * std::fabs(M[i * 8 + i])) || !(d > 0)) continue;   // zero row
+        const double rii = std::sqrt(d);
+        R[i * 8 + i] = rii;
+        for (int j = i + 1; j < 8; ++j) {
+            double v = M[i * 8 + j];
+            for (int k = 0; k < i; ++k) v -= R[k * 8 + i] * R[k * 8 + j];
+            R[i * 8 + j] = v / rii;
+        }
+    }
+    for (int i = 0; i < 8; ++i) { for (int j = 0; j < 7; ++j) J[i * 7 + j] = R[i * 8 + j]; r[i] = R[i * 8 + 7]; }
+    return IBA_OK;
+}
+
+iba_status iba_eval_whitened(iba_handle* h, const double* x, double r[8], double J[56]) {
+    if (!h || !x || !r || !J) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    iba_normal_out n;
+    iba_status s = iba_eval_factors(h, x, 1, &n); if (s != IBA_OK) return s;
+    return iba_whiten_normal(&n, r, J);
+}
+
 iba_status iba_default_lm_options(iba_lm_options* o) {
     if (!o) return IBA_ERR_INVALID_ARG;
     const LmOptions d;

@@ -6,8 +6,9 @@
 //
 //   iba::PackedProblem / iba::pack()   KeyFrame*/PointClouds/vTwl -> iba_problem_desc (done ONCE)
 //   iba::BAError(...)                  drop-in for BAError() of iba_global.cpp:169-173 / iba_func.cpp:179-183
-//   iba::IbaAggregateCostFunction      ceres::CostFunction replacing the blocks BuildProblem() adds (iba_local.cpp:263-308)
+//   iba::IbaAggregateCostFunction      ceres::SizedCostFunction<8, 7> replacing the blocks BuildProblem() adds (iba_local.cpp:263-308)
 //   iba::IbaAggregateEdge              g2o::BaseUnaryEdge<8, ..., VertexSim3> (same vertex type as IBACalib.hpp:74)
+// The two solver adaptors only forward to iba_eval_whitened (the math is behind the C-ABI and tested there).
 #pragma once
 #include <cstdint>
 #include <stdexcept>
@@ -114,21 +115,15 @@ inline std::tuple<double, double, double, int, int> BAError(const double* xvec, 
 #if __has_include(<ceres/ceres.h>)
 #include <ceres/ceres.h>
 namespace iba {
-// One cost function standing in for all residual blocks BuildProblem() would add. It returns the 7
-// whitened rows L^T (dx) with H = L L^T so that Ceres' J^T J = H and J^T r = b exactly:
-//   J = L^T (7x7),  r = L^-1 b.   Robust weighting is already folded in on device.
-class IbaAggregateCostFunction : public ceres::SizedCostFunction<7, 7> {
+// One cost function standing in for all residual blocks BuildProblem() would add (iba_local.cpp:263-308): the 8 rows
+// iba_eval_whitened returns — J^T J = H, J^T r = b, |r|^2 = 2 cost, robust weights folded in on the device — so Ceres'
+// Gauss-Newton model and its step acceptance both see the whole problem. No ceres::LossFunction on this block.
+class IbaAggregateCostFunction : public ceres::SizedCostFunction<8, 7> {
 public:
     explicit IbaAggregateCostFunction(Evaluator& ev) : ev_(ev) {}
     bool Evaluate(double const* const* x, double* residuals, double** jacobians) const override {
-        iba_normal_out o;
-        if (iba_eval_factors(ev_.get(), x[0], 1, &o) != IBA_OK) return false;   // association frozen by iba_build_problem
-        Eigen::Map<Eigen::Matrix<double, 7, 7, Eigen::RowMajor>> H(o.H);
-        Eigen::Map<Eigen::Matrix<double, 7, 1>> b(o.b);
-        Eigen::LLT<Eigen::Matrix<double, 7, 7>> llt(H + 1e-12 * H.diagonal().maxCoeff() * Eigen::Matrix<double, 7, 7>::Identity());
-        const Eigen::Matrix<double, 7, 7> L = llt.matrixL();
-        Eigen::Map<Eigen::Matrix<double, 7, 1>>(residuals) = L.triangularView<Eigen::Lower>().solve(b);
-        if (jacobians && jacobians[0]) Eigen::Map<Eigen::Matrix<double, 7, 7, Eigen::RowMajor>>(jacobians[0]) = L.transpose();
+        double J[56];   // 8 x 7 row-major, Ceres' own layout
+        if (iba_eval_whitened(ev_.get(), x[0], residuals, jacobians && jacobians[0] ? jacobians[0] : J) != IBA_OK) return false;   // association frozen by iba_build_problem
         return true;
     }
 private:
@@ -141,27 +136,22 @@ private:
 #include <g2o/core/base_unary_edge.h>
 #include "g2o_tools.h"   // VertexSim3 (g2o_tools.h:13-30): additive 7-vector
 namespace iba {
-// Unary edge on the reference's own VertexSim3: error = L^-1 b (7) padded with 0, Jacobian = L^T.
-class IbaAggregateEdge : public g2o::BaseUnaryEdge<7, g2o::Vector7, VertexSim3> {
+// Unary edge on the reference's own VertexSim3 (the shape of IBAPlaneEdge, IBACalib.hpp:74-155): 8-d error = r,
+// Jacobian = J of iba_eval_whitened, information = identity: chi2 = |r|^2 = 2 cost.
+class IbaAggregateEdge : public g2o::BaseUnaryEdge<8, Eigen::Matrix<double, 8, 1>, VertexSim3> {
 public:
-    explicit IbaAggregateEdge(Evaluator& ev) : ev_(ev) { setInformation(Eigen::Matrix<double, 7, 7>::Identity()); }
-    void computeError() override { eval(); _error = r_; }
-    void linearizeOplus() override { eval(); _jacobianOplusXi = Jt_; }
+    explicit IbaAggregateEdge(Evaluator& ev) : ev_(ev) { setInformation(Eigen::Matrix<double, 8, 8>::Identity()); }
+    void computeError() override { eval(); for (int i = 0; i < 8; ++i) _error[i] = r_[i]; }
+    void linearizeOplus() override { eval(); _jacobianOplusXi = Eigen::Map<const Eigen::Matrix<double, 8, 7, Eigen::RowMajor>>(J_); }
     bool read(std::istream&) override { return false; }
     bool write(std::ostream&) const override { return false; }
 private:
     void eval() {
         const VertexSim3* v = static_cast<const VertexSim3*>(_vertices[0]);
-        iba_normal_out o;
-        if (iba_eval_factors(ev_.get(), v->estimate().data(), 1, &o) != IBA_OK) throw std::runtime_error(iba_last_error(ev_.get()));
-        Eigen::Map<Eigen::Matrix<double, 7, 7, Eigen::RowMajor>> H(o.H);
-        Eigen::Map<Eigen::Matrix<double, 7, 1>> b(o.b);
-        Eigen::LLT<Eigen::Matrix<double, 7, 7>> llt(H + 1e-12 * H.diagonal().maxCoeff() * Eigen::Matrix<double, 7, 7>::Identity());
-        const Eigen::Matrix<double, 7, 7> L = llt.matrixL();
-        r_ = L.triangularView<Eigen::Lower>().solve(b); Jt_ = L.transpose();
+        if (iba_eval_whitened(ev_.get(), v->estimate().data(), r_, J_) != IBA_OK) throw std::runtime_error(iba_last_error(ev_.get()));
     }
     Evaluator& ev_;
-    g2o::Vector7 r_; Eigen::Matrix<double, 7, 7> Jt_;
+    double r_[8], J_[56];
 };
 }  // namespace iba
 #endif

@@ -109,3 +109,36 @@ def test_descriptor_validation_precedes_the_device_probe(pkg, abi, synth):
         with pytest.raises(pkg.IbaError) as e:
             pkg.IbaHandle(bad, abi.reference_yaml_params(), frame_begin=0, frame_end=1)
         assert e.value.status == 1, name
+
+
+def test_whiten_normal_host_math(pkg, abi):
+    """iba_whiten_normal: [J | r] = upper Cholesky factor of [[H, b], [b^T, 2 cost]] -> J^T J = H, J^T r = b, |r|^2 = 2 cost,
+    on a random robustified least-squares problem (Huber weights, cost = 1/2 sum rho) and on a rank-deficient one."""
+    import ctypes as C
+    lib = pkg.load_library()
+    rng = np.random.default_rng(0)
+    for rank_deficient in (False, True):
+        m = 400
+        Jb = rng.normal(size=(m, 7)) * np.array([1e3, 2e3, 5e2, 30, 40, 20, 3])
+        if rank_deficient:
+            Jb[:, 6] = 0.0                       # nothing constrains the scale
+        rb = rng.normal(size=m) * 3
+        a = 2.98
+        s = rb ** 2
+        w = np.where(s > a * a, a / np.sqrt(s), 1.0)
+        rho = np.where(s > a * a, 2 * a * np.sqrt(s) - a * a, s)
+        n = abi.IbaNormalOut()
+        H = (Jb * w[:, None]).T @ Jb
+        b = (Jb * w[:, None]).T @ rb
+        for i in range(49):
+            n.H[i] = H.flat[i]
+        for i in range(7):
+            n.b[i] = b[i]
+        n.cost = 0.5 * rho.sum()
+        r = np.zeros(8)
+        J = np.zeros((8, 7))
+        assert lib.iba_whiten_normal(C.byref(n), r.ctypes.data_as(C.c_void_p), J.ctypes.data_as(C.c_void_p)) == 0
+        assert np.allclose(J.T @ J, H, rtol=1e-10, atol=1e-10 * np.abs(H).max())
+        assert np.allclose(J.T @ r, b, rtol=1e-10, atol=1e-10 * np.abs(b).max())
+        assert abs(r @ r - 2 * n.cost) <= 1e-10 * 2 * n.cost
+        assert np.allclose(J, np.triu(J[:, :7].reshape(8, 7)) if False else J) and np.all(np.abs(np.tril(np.hstack([J, r[:, None]]), -1)) == 0)   # upper triangular

@@ -139,3 +139,28 @@ def test_mfma_factor_kernel_matches_oracle(pkg, synth, abi, ob, scene_small, mon
     assert a.counts() == b.counts() and np.max(np.abs(a.H_np() - b.H_np())) <= 1e-9 * np.abs(b.H_np()).max()
     hm.close()
     hv.close()
+
+
+def test_whitened_block_reproduces_the_frozen_problem(pkg, synth, abi, ob, scene_small):
+    """iba_eval_whitened (the Ceres / g2o adaptors' only call): J^T J, J^T r and |r|^2 / 2 against the ORACLE's H, b and cost
+    of the same frozen problem, at the build point and away from it."""
+    import ctypes as C
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(prob, p)
+    o = ob.Oracle(prob)
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(17), n=3)
+    h.build_problem(xs[0])
+    o.build_problem(p, xs[0])
+    for x in xs:
+        x = np.ascontiguousarray(x)
+        r = np.zeros(8)
+        J = np.zeros((8, 7))
+        st = h.lib.iba_eval_whitened(h.h, x.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), J.ctypes.data_as(C.c_void_p))
+        assert st == 0
+        ref = o.eval_factors(p, x)[0]
+        H, b = ref.H_np(), ref.b_np()
+        assert np.max(np.abs(J.T @ J - H)) <= 1e-9 * np.abs(H).max()
+        assert np.max(np.abs(J.T @ r - b)) <= 1e-9 * np.abs(b).max()
+        assert abs(0.5 * (r @ r) - ref.cost) <= 1e-9 * ref.cost
+    h.close()
