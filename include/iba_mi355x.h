@@ -246,6 +246,11 @@ iba_status iba_eval_full_partial(iba_handle* h, const double* x, int32_t B, void
 iba_status iba_finalize_cost(const iba_params* params, const double* partials, int32_t B, iba_cost_out* out);
 iba_status iba_finalize_normal(const iba_params* params, const double* partials, int32_t B, iba_normal_out* out);
 
+/* The frozen problem's residual blocks, as a partial block (the Jacobian-path half of the LM caller on several GPUs). */
+iba_status iba_eval_factors_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream);
+/* Calls on one handle must be issued in order, on one stream at a time: the handle's work buffers (candidate ring, lists,
+ * records) are reused from call to call and are ordered by that stream only. */
+
 /* Introspection for benchmarks: device-side duration of the last evaluation's dominant kernel
  * measured with HIP events on the launch stream (ms), and the frame-kernel launch shape. */
 iba_status iba_last_kernel_ms(iba_handle* h, float* frame_kernel_ms, float* total_ms);
@@ -294,6 +299,32 @@ iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_op
  * 0 smooth bowl, 1 bowl with an active constraint and an infeasible start, 2 nonsmooth with two constraints,
  * 3 shallow bowl covered with narrow local basins (for the variable-neighbourhood restarts) */
 iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res);
+
+/*
+ * Multi-GPU inside one process: the keyframes sharded over n devices of a node (contiguous ranges balanced by points), one
+ * handle and one RCCL communicator per device (ncclCommInitAll). The reference's one parallel strategy is the frame loop
+ * with critical-section sums (iba_global.cpp:193, 239, 318; iba_func.cpp:203; iba_local.cpp:162); here every device evaluates
+ * its frames, ONE ncclAllReduce(sum, f64) of the B x iba_partial_stride() block over xGMI adds them on the devices, and
+ * device 0's copy is finalised on the host. Same outputs and callers as the single-device entry points.
+ */
+typedef struct iba_group iba_group;
+iba_status iba_group_create(const iba_problem_desc* desc, const iba_params* params, const int32_t* devices, int32_t n_devices, iba_group** out);
+void iba_group_destroy(iba_group* g);
+const char* iba_group_last_error(const iba_group* g); /* g may be NULL for creation errors */
+int32_t iba_group_size(const iba_group* g);
+iba_status iba_group_frame_range(const iba_group* g, int32_t rank, int32_t* frame_begin, int32_t* frame_end);
+iba_status iba_group_set_params(iba_group* g, const iba_params* params);
+iba_status iba_group_eval_cost(iba_group* g, const double* x, int32_t B, iba_cost_out* out);
+iba_status iba_group_eval_bbo(iba_group* g, const double* x, int32_t B, double he_threshold, double valid_rate, iba_bbo* out);
+iba_status iba_group_eval_normal(iba_group* g, const double* x, int32_t B, iba_normal_out* out);
+iba_status iba_group_eval_full(iba_group* g, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal);
+iba_status iba_group_build_problem(iba_group* g, const double* x_assoc);
+iba_status iba_group_eval_factors(iba_group* g, const double* x, int32_t B, iba_normal_out* out);
+iba_status iba_group_calibrate_lm(iba_group* g, const double* x0, const iba_lm_options* opt, iba_lm_result* res);
+iba_status iba_group_calibrate_mads(iba_group* g, const double* x0, const iba_mads_options* opt, iba_mads_result* res);
+/* One process per GPU with a communicator of the caller's (MPI / torchrun style): the one collective of the path on the
+ * caller's ncclComm_t (passed as void*), in place on the device block written by iba_eval_*_partial. */
+iba_status iba_comm_allreduce(void* nccl_comm, void* d_partials, int32_t B, void* stream);
 
 /*
  * ---- On-disk formats of the reference pipeline -> problem descriptor [SURVEY.md 8(f) row 1] ----

@@ -127,6 +127,10 @@ class Oracle:
         lib().oracle_eval_factors(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), out)
         return list(out)
 
+    def set_frame_range(self, f_begin=0, f_end=-1):
+        """test aid: BuildProblem / eval_normal over the frames [f_begin, f_end) only (one rank's share)"""
+        lib().oracle_set_frame_range(C.c_void_p(self.h), C.c_int(f_begin), C.c_int(f_end))
+
     @staticmethod
     def set_exact_sums(on):
         """test aid: add the per-block contributions of the normal equations in long double (see iba_oracle.cpp)"""

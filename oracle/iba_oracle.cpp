@@ -78,6 +78,7 @@ struct Oracle {
     int leaf2d = 10, leaf3d = 30;
     std::vector<Factor> factors;  // frozen problem
     int bp_frames_used = 0, bp_n_corr = 0;
+    int bp_f_begin = 0, bp_f_end = -1;   // TEST AID: BuildProblem over a frame range only (what one rank of a sharded run owns); -1 = all
 };
 
 Iso3 iso_from_f32(const float* m) {
@@ -339,6 +340,7 @@ void BuildProblem(Oracle& O, const iba_params& prm, const double* params, bool m
     (void)multithread;
 #pragma omp parallel for schedule(static) if (multithread)   // iba_local.cpp:162
     for (size_t Fi = 0; Fi < O.frames.size(); ++Fi) {
+        if ((int)Fi < O.bp_f_begin || (O.bp_f_end >= 0 && (int)Fi >= O.bp_f_end)) continue;
         const Frame& kf = O.frames[Fi];
         std::vector<Factor>& out_factors = per_frame[Fi];
         std::vector<double> points; transform_cloud(kf, initSE3, points);
@@ -547,6 +549,7 @@ int oracle_eval_factors(void* h, const iba_params* p, const double* x, int B, ib
     return 0;
 }
 void oracle_set_exact_sums(int on) { g_exact_sums = on != 0; }
+void oracle_set_frame_range(void* h, int f_begin, int f_end) { ((Oracle*)h)->bp_f_begin = f_begin; ((Oracle*)h)->bp_f_end = f_end; }
 int oracle_eval_normal(void* h, const iba_params* p, const double* x, int B, iba_normal_out* out, int nthreads) {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);

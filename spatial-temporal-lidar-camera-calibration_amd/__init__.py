@@ -61,6 +61,8 @@ def load_library():
         L.iba_eval_cost_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.iba_eval_normal_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.iba_eval_full_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.iba_eval_factors_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.iba_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -267,6 +269,89 @@ class IbaHandle:
     @property
     def n_keypoints(self):
         return int(self.lib.iba_num_keypoints(self.h))
+
+
+class IbaGroup:
+    """iba_group wrapper: one process, several GPUs of a node, frames sharded over them, one RCCL all-reduce per evaluation."""
+
+    def __init__(self, problem, params=None, devices=(0,)):
+        self.lib = load_library()
+        self.problem = problem
+        self.params = copy_params(params) if params is not None else default_params()
+        self._desc = problem.desc()
+        self.g = C.c_void_p(None)
+        dev = (C.c_int32 * len(devices))(*devices)
+        self.lib.iba_group_last_error.restype = C.c_char_p
+        self.lib.iba_group_last_error.argtypes = [C.c_void_p]
+        self.lib.iba_group_destroy.argtypes = [C.c_void_p]
+        st = self.lib.iba_group_create(C.byref(self._desc), C.byref(self.params), dev, C.c_int32(len(devices)), C.byref(self.g))
+        if st != 0:
+            raise IbaError(st, self.lib.iba_group_last_error(None).decode())
+
+    def _chk(self, st):
+        if st != 0:
+            raise IbaError(st, self.lib.iba_group_last_error(self.g).decode())
+
+    def close(self):
+        if getattr(self, "g", None) and self.g.value:
+            self.lib.iba_group_destroy(self.g)
+            self.g = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def frame_range(self, rank):
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.iba_group_frame_range(self.g, C.c_int32(rank), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def eval_cost(self, x):
+        x = IbaHandle._x(x)
+        out = (IbaCostOut * len(x))()
+        self._chk(self.lib.iba_group_eval_cost(self.g, _p(x), C.c_int32(len(x)), out))
+        return list(out)
+
+    def eval_full(self, x):
+        x = IbaHandle._x(x)
+        cost, nrm = (IbaCostOut * len(x))(), (IbaNormalOut * len(x))()
+        self._chk(self.lib.iba_group_eval_full(self.g, _p(x), C.c_int32(len(x)), cost, nrm))
+        return list(cost), list(nrm)
+
+    def eval_normal(self, x):
+        x = IbaHandle._x(x)
+        nrm = (IbaNormalOut * len(x))()
+        self._chk(self.lib.iba_group_eval_normal(self.g, _p(x), C.c_int32(len(x)), nrm))
+        return list(nrm)
+
+    def build_problem(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        self._chk(self.lib.iba_group_build_problem(self.g, _p(x)))
+
+    def eval_factors(self, x):
+        x = IbaHandle._x(x)
+        nrm = (IbaNormalOut * len(x))()
+        self._chk(self.lib.iba_group_eval_factors(self.g, _p(x), C.c_int32(len(x)), nrm))
+        return list(nrm)
+
+    def calibrate_lm(self, x0, **opts):
+        o = IbaLmOptions()
+        self.lib.iba_default_lm_options(C.byref(o))
+        for k, v in opts.items():
+            setattr(o, k, v)
+        r = IbaLmResult()
+        x0 = np.ascontiguousarray(x0, np.float64)
+        self._chk(self.lib.iba_group_calibrate_lm(self.g, _p(x0), C.byref(o), C.byref(r)))
+        return np.array(r.x[:]), r
+
+    def calibrate_mads(self, x0, **opts):
+        x0 = np.ascontiguousarray(x0, np.float64)
+        o = mads_options(x0, **opts)
+        r = IbaMadsResult()
+        self._chk(self.lib.iba_group_calibrate_mads(self.g, _p(x0), C.byref(o), C.byref(r)))
+        return np.array(r.x[:]), r
 
 
 def mads_options(x0, **opts):

@@ -972,22 +972,35 @@ iba_status iba_build_problem(iba_handle* h, const double* x) {
     return IBA_OK;
 }
 
-iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
-    if (!h || !x || !out || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+static iba_status eval_factors_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
+    if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
     if (!h->frozen_valid) return fail(h, IBA_ERR_STATE, "iba_eval_factors called before iba_build_problem");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, h->stream, &dc); if (s != IBA_OK) return s;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    s = launch_factors(h, dc, B, 0, h->d_frame_partials.p, h->nfb, 0, h->stream); if (s != IBA_OK) return s;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, h->stream, h->d_frame_partials.p, h->nfb, h->d_partials.p);
+    iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    s = launch_factors(h, dc, B, 0, h->d_frame_partials.p, h->nfb, 0, st); if (s != IBA_OK) return s;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->nfb, d_partials);
     HIP_TRY(h, hipGetLastError());
-    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, h->stream)); h->timing_recorded = true; }
+    // the frozen problem's frame / correspondence counts (iba_build_problem) ride in their slots of the block
+    hipLaunchKernelGGL(iba_set_slots_kernel, dim3(1), dim3(64), 0, st, d_partials, B, (int)P_FRAMES_N, (double)h->frozen_frames, (int)P_NCORR_N, (double)h->frozen_ncorr);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = false; }
+    return IBA_OK;
+}
+
+iba_status iba_eval_factors_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
+    if (!h || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return eval_factors_partial_impl(h, x, B, (double*)d_partials, stream ? (hipStream_t)stream : h->stream);
+}
+
+iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
+    if (!h || !out) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    iba_status s = eval_factors_partial_impl(h, x, B, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
     HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
-    for (int b = 0; b < B; ++b) { h->h_partials[(size_t)b * kPartialStride + P_FRAMES_N] = h->frozen_frames; h->h_partials[(size_t)b * kPartialStride + P_NCORR_N] = h->frozen_ncorr; }
     return iba_finalize_normal(&h->params, h->h_partials, B, out);
 }
 

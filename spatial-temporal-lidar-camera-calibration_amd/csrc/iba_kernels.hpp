@@ -2348,4 +2348,10 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce_kernel(const double
     }
 }
 
+// writes two host-known values into their slots of B partial blocks (frozen-problem counts)
+__global__ void iba_set_slots_kernel(double* __restrict__ partials, int B, int slot_a, double va, int slot_b, double vb) {
+    const int b = threadIdx.x;
+    if (b < B) { partials[(size_t)b * kPartialStride + slot_a] = va; partials[(size_t)b * kPartialStride + slot_b] = vb; }
+}
+
 }  // namespace iba

@@ -1,7 +1,8 @@
 """N>1 path on CPU: frames shard across ranks with no data-path collective; each rank's partial block is
 summed with ONE all-reduce (gloo here, RCCL on the GPU box) and finalised by the product's host code.
 The per-shard partial blocks come from the oracle (no GPU in this container); what is under test is
-shard_frames + the partial-block layout + iba_finalize_cost over a real torch.distributed world of 2."""
+shard_frames + the WHOLE partial-block layout (cost slots 0..11, the 28 + 7 normal-equation slots, cost / chi2, the factor
+and frame counters) + iba_finalize_cost + iba_finalize_normal over a real torch.distributed world of 2."""
 import os
 import sys
 
@@ -30,16 +31,28 @@ def _worker(rank, world, port, q):
     f0, f1 = pkg.shard_frames(prob.n_frames, world, rank, np.diff(prob.arrays["pt_offset"].astype(np.int64)))
     S = pkg.partial_stride()
     part = np.zeros((len(xs), S))
+    o.set_frame_range(f0, f1)    # this rank's share of the Jacobian path (BuildProblem + factors over its frames)
     for b, x in enumerate(xs):
         part[b, :12] = o.eval_cost_raw(p, x, f0, f1)
+        n = o.eval_normal(p, x)[0]
+        H = n.H_np()
+        part[b, 12:40] = H[np.triu_indices(7)]          # P_H0: upper triangle, row-major
+        part[b, 40:47] = n.b_np()                        # P_B0
+        part[b, 47:55] = [n.chi2, n.cost, n.n_factor_3d2d, n.n_factor_p2pl, n.n_factor_p2pt, n.n_residuals, n.frames_used, n.n_corr]
+    o.set_frame_range(0, -1)
     t = torch.from_numpy(part)
     dist.all_reduce(t)           # the single exchange step of the path
     got = pkg.finalize_cost(p, t.numpy())
+    gotn = pkg.finalize_normal(p, t.numpy())
     ref = o.eval_cost(p, xs)
+    refn = o.eval_normal(p, xs)
+    okn = all(a.counts() == b.counts() and np.allclose(a.H_np(), b.H_np(), rtol=1e-12, atol=1e-12 * np.abs(b.H_np()).max()) and
+              np.allclose(a.b_np(), b.b_np(), rtol=1e-12, atol=1e-12 * np.abs(b.b_np()).max()) and abs(a.cost - b.cost) <= 1e-12 * b.cost and
+              abs(a.chi2 - b.chi2) <= 1e-12 * b.chi2 for a, b in zip(gotn, refn))
     ok = all((g.cnt_3d_2d, g.valid_cnt_3d_2d, g.cnt_3d_3d, g.valid_cnt_3d_3d, g.frames_used, g.n_corr) ==
              (r.cnt_3d_2d, r.valid_cnt_3d_2d, r.cnt_3d_3d, r.valid_cnt_3d_3d, r.frames_used, r.n_corr) and
              abs(g.f1 - r.f1) <= 1e-12 * abs(r.f1) and abs(g.f2 - r.f2) <= 1e-12 * abs(r.f2) and abs(g.C - r.C) <= 1e-12 for g, r in zip(got, ref))
-    q.put((rank, ok, (f0, f1)))
+    q.put((rank, ok and okn, (f0, f1)))
     dist.destroy_process_group()
 
 
