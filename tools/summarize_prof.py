@@ -1,42 +1,78 @@
-"""Condense rocprofv3 outputs under gpurun_out/ into the tracked profiles/ directory.
-usage: python tools/summarize_prof.py <round-tag> <stats-dir> [<fetch-dir> <write-dir>]
-FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by exactly 2x
-(MI355X_MICROARCH.md §HBM) -> both the raw and the x2-corrected read figure are recorded."""
-import csv, glob, json, os, sys
+"""Condense the rocprofv3 outputs of tools/prof_run.sh (gpurun_out/<tag>/) into the tracked profiles/ directory:
+profiles/<tag>_rocprof_summary.md (kernel stats + counters per launch) and profiles/pmc_latest.json (what bench.py quotes as
+roofline.traffic / issue_frac, stamped with the git head and a hash of the kernel sources so that it is dropped when stale).
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by exactly 2x
+(MI355X_MICROARCH.md, HBM) -> both the raw and the x2-corrected read figure are recorded, the corrected one is used.
+usage: python tools/summarize_prof.py <tag>"""
+import csv, glob, hashlib, json, os, subprocess, sys, time
 from collections import defaultdict
 
-tag, stats = sys.argv[1], sys.argv[2]
-out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+tag = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", tag)
+out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
+N_SIMD = 1024
 
 
 def short(name):
-    n = name.replace("void ", "").replace("iba::", "")
-    return n.split("(")[0]
+    return name.replace("void ", "").replace("iba::", "").split("(")[0]
 
 
-rows = list(csv.DictReader(open(glob.glob(os.path.join(stats, "**", "*_kernel_stats.csv"), recursive=True)[0])))
-lines = ["# rocprofv3 --kernel-trace --stats summary (%s)" % tag, "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+def counters(sub):
+    acc = defaultdict(lambda: defaultdict(list))
+    for fn in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+rows = list(csv.DictReader(open(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0])))
+lines = ["# rocprofv3 --kernel-trace --stats summary (%s): python3 bench.py --steps 15 --warmup 2 --no-cpu-baseline --no-extras" % tag, "",
+         "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+avg_us = {}
 for r in rows:
+    avg_us[short(r["Name"])] = float(r["AverageNs"]) / 1e3
     lines.append("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-traffic = {}
-if len(sys.argv) > 4:
-    for cname, d in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
-        acc = defaultdict(list)
-        for r in csv.DictReader(open(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0])):
-            if r["Counter_Name"] == cname:
-                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-        for k, v in acc.items():
-            traffic.setdefault(k, {})[cname] = (sum(v) / len(v), len(v))
-    lines += ["", "## HBM traffic per launch (separate --pmc passes, KiB -> bytes)", "", "| kernel | launches | FETCH_SIZE raw MB | FETCH x2 (gfx950 correction) MB | WRITE_SIZE MB |", "|---|---|---|---|---|"]
-    for k, v in traffic.items():
-        f = v.get("FETCH_SIZE", (0, 0)); w = v.get("WRITE_SIZE", (0, 0))
-        lines.append("| %s | %d | %.2f | %.2f | %.2f |" % (k, f[1], f[0] * 1024 / 1e6, 2 * f[0] * 1024 / 1e6, w[0] * 1024 / 1e6))
-    key = [k for k in traffic if k.startswith("iba_frame_kernel<3")] or [k for k in traffic if k.startswith("iba_frame_kernel<0")]
-    if key:
-        v = traffic[key[0]]
-        json.dump({"round": tag, "kernel": key[0], "fetch_bytes_raw": v["FETCH_SIZE"][0] * 1024, "write_bytes": v["WRITE_SIZE"][0] * 1024,
-                   "hbm_bytes_per_launch": 2 * v["FETCH_SIZE"][0] * 1024 + v["WRITE_SIZE"][0] * 1024,
-                   "note": "read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests at 64 B)"}, open(os.path.join(out_dir, "traffic_latest.json"), "w"), indent=1)
+fetch, write, insts, cyc, mfma = counters("fetch"), counters("write"), counters("insts"), counters("cycles"), counters("mfma")
+kernels = [k for k in avg_us if k.startswith(("iba_assoc_kernel", "iba_nn_kernel", "iba_factor", "iba_reduce2", "iba_he_kernel", "iba_frame_kernel"))]
+lines += ["", "## counters per launch (separate --pmc passes on the same command; KiB -> bytes, FETCH_SIZE x2 on gfx950)", "",
+          "| kernel | HBM read MB (x2) | HBM write MB | SQ_INSTS_VALU | SQ_INSTS_SALU | SQ_INSTS_LDS | SQ_INSTS_VMEM | VALU-active share of SIMD cycles | SQ_WAIT_ANY / SQ_WAVE_CYCLES | MFMA F64 insts |", "|---|---|---|---|---|---|---|---|---|---|"]
+tot_hbm = 0.0; act = 0.0; gui = 0.0
+for k in kernels:
+    f = 2 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024; w = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
+    i, c, m = insts.get(k, {}), cyc.get(k, {}), mfma.get(k, {})
+    share = 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (N_SIMD * c["GRBM_GUI_ACTIVE"] / 8) if c.get("GRBM_GUI_ACTIVE") else float("nan")
+    wait = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else float("nan")
+    lines.append("| %s | %.2f | %.2f | %.3g | %.3g | %.3g | %.3g | %.2f | %.2f | %.3g |" % (k, f / 1e6, w / 1e6, i.get("SQ_INSTS_VALU", 0), i.get("SQ_INSTS_SALU", 0), i.get("SQ_INSTS_LDS", 0),
+                                                                                        i.get("SQ_INSTS_VMEM", 0), share, wait, m.get("SQ_INSTS_VALU_MFMA_F64", 0)))
+    if k.startswith(("iba_assoc_kernel", "iba_nn_kernel")):
+        tot_hbm += f + w; act += 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0); gui += c.get("GRBM_GUI_ACTIVE", 0.0) / 8
+bench_line = None
+try:
+    bench_line = json.loads([l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][-1])
+except Exception:
+    pass
+hsh = hashlib.sha256()
+d = os.path.join(ROOT, "spatial-temporal-lidar-camera-calibration_amd", "csrc")
+for fn in sorted(os.listdir(d)):
+    if fn.endswith((".hip", ".hpp", ".cpp")):
+        hsh.update(open(os.path.join(d, fn), "rb").read())
+head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "spatial-temporal-lidar-camera-calibration_amd/csrc"], cwd=ROOT, capture_output=True, text=True).stdout.strip())
+cfg = (bench_line or {}).get("config", {})
+pmc = {"round": tag, "git_head": head + ("+uncommitted kernel changes" if dirty else ""), "source_stamp": hsh.hexdigest()[:16], "taken_on": time.strftime("%Y-%m-%d"),
+       "frames": cfg.get("frames_this_rank"), "pts": cfg.get("points_per_frame"), "batch": cfg.get("candidates_per_step"),
+       "kernels": "iba_assoc_kernel + iba_nn_kernel", "hbm_bytes_per_launch": tot_hbm, "valu_issue_frac": act / (N_SIMD * gui) if gui else None,
+       "counters": "FETCH_SIZE x2 + WRITE_SIZE (KiB); 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+       "note": "one rocprofv3 --pmc pass per counter list on `python3 bench.py --steps 15 --warmup 2 --no-cpu-baseline --no-extras`; mean per launch"}
+json.dump(pmc, open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
+lines += ["", "assoc + search kernels per launch: HBM %.1f MB, VALU-active share of the SIMD cycles %.2f  (source stamp %s, head %s)" % (tot_hbm / 1e6, pmc["valu_issue_frac"] or float("nan"), pmc["source_stamp"], pmc["git_head"])]
+if bench_line:
+    lines += ["", "bench line under rocprofv3 (kernel trace): value %.0f evals/s, ms_per_step %.3f, roofline %s" % (bench_line["value"], bench_line["ms_per_step"], json.dumps({k: bench_line["roofline"][k] for k in ("achieved", "frac", "launch_ms", "kernel_ms")}))]
 open(os.path.join(out_dir, "%s_rocprof_summary.md" % tag), "w").write("\n".join(lines) + "\n")
+for fn in ("bench_under_rocprof.json", "bench_full.json"):
+    p = os.path.join(src, fn)
+    if os.path.exists(p):
+        open(os.path.join(out_dir, "%s_%s" % (tag, fn)), "w").write(open(p).read())
 print("\n".join(lines))
