@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define IBA_ABI_VERSION 1
-#define IBA_MAX_BATCH 64 /* candidates per call */
+#define IBA_MAX_BATCH 64 /* candidates per launch chain; a call with more runs as consecutive chunks of this many */
 
 typedef enum iba_status {
     IBA_OK = 0,
@@ -71,7 +71,7 @@ typedef struct iba_problem_desc {
     const float* Tcw; /* [F*12] */
 
     /* pKF->GetBestCovisibilityKeyFramesSafe(num_best_covis) (or ByWeight), iba_global.cpp:254-258.
-     * One "slot" per (reference KF, covisible KF) pair. */
+     * One "slot" per (reference KF, covisible KF) pair; at most 22 per reference KF (10 with plane_cache = 0). */
     const uint64_t* covis_offset; /* [F+1] slots of frame f are covis_offset[f]..covis_offset[f+1] */
     const int32_t* covis_frame;   /* [S] frame index of the covisible KF */
     /* pKFConv->GetPose() * InvRefCVPose evaluated in CV_32F (iba_global.cpp:280), top 3 rows
@@ -103,7 +103,7 @@ typedef struct iba_params {
     int32_t num_min_corr_cost;   /* 30, hard-coded at iba_global.cpp:203 */
     double corr_3d_2d_threshold; /* 40 */
     double corr_3d_3d_threshold; /* 5 (yml: 10) */
-    int32_t norm_max_pts;        /* 30 (<= 32 supported) */
+    int32_t norm_max_pts;        /* 30 (<= 64 supported: the neighbour list lives one entry per lane of a wave) */
     int32_t norm_min_pts;        /* 5 */
     double norm_radius;          /* 0.6 */
     double norm_reg_threshold;   /* 0.04 (yml: 0.02) */
@@ -115,7 +115,7 @@ typedef struct iba_params {
     int32_t num_min_corr;             /* 30 */
     double max_3d_dist;               /* 1.0 */
     double neigh_radius;              /* 0.6 */
-    int32_t neigh_max_pts;            /* 30 (<= 32 supported) */
+    int32_t neigh_max_pts;            /* 30 (<= 64 supported) */
     int32_t neigh_min_pts;            /* 5 */
     double local_min_diff_dist;       /* 0.2 */
     double local_norm_reg_threshold;  /* 0.001 */
@@ -187,8 +187,9 @@ iba_status iba_eval_bbo(iba_handle* h, const double* x, int32_t B, double he_thr
 iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal_out* out);
 
 /* BAError tuple AND the re-associated normal equations of the same B candidates from one pass over the scans
- * (the two paths share projection + 2d-3d association). Results are identical to calling iba_eval_cost and
- * iba_eval_normal separately. */
+ * (the two paths share projection + 2d-3d association). Counters are identical to those of iba_eval_cost and
+ * iba_eval_normal called separately, sums agree to summation order (1e-15). A candidate's results do not depend on what
+ * else is in the batch. */
 iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal);
 
 /* The two halves separately, as Ceres uses them (iba_local.cpp:443-445): freeze the association

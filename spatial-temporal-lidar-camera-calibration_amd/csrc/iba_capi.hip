@@ -72,6 +72,7 @@ struct iba_handle {
     int nn_cg_max = 8;                    // candidates per search block (power of two <= kMaxGroup)
     DevBuf<uint32_t> d_lcount, d_lcount_frozen;   // work-list length per (candidate, frame)
     DevBuf<float4> d_fmp, d_fmp_frozen;   // MapPoint of every work-list entry
+    uint32_t max_slots = 0;               // covisible keyframes of the busiest frame
     uint32_t lstride = 1;                 // entries per (candidate, frame) row of the lists: no list is longer than maxKw
     int nn_ns = 1;                        // search blocks per (frame, candidate group): ceil(maxKw / kSliceW)
     DevBuf<double> d_nn_partials;         // IBA_MAX_BATCH * n_frames * kMaxSlices * kNNPartial
@@ -81,7 +82,7 @@ struct iba_handle {
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
     DevBuf<float> xs, ys, zs, chunk_box; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
     DevBuf<float4> pts4;   // the same scan points as (x, y, z, original index bits): one 16 B gather per point where lanes diverge
-    DevBuf<float2> kp_uv; DevBuf<float4> kp_mp; DevBuf<uint16_t> kp_fl;
+    DevBuf<float2> kp_uv; DevBuf<float4> kp_mp; DevBuf<uint32_t> kp_fl;
     DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
     DevBuf<PlaneRec> plane_cost, plane_local;
@@ -153,8 +154,10 @@ void to_dev_params(const iba_params& p, DevParams& d) {
 iba_status check_params(iba_handle* h, const iba_params& p) {
     if (!(p.max_pixel_dist > 0) || p.max_pixel_dist > 64.0)
         return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist must be in (0, 64] px");
-    if (p.norm_max_pts < 1 || p.norm_max_pts > 32 || p.neigh_max_pts < 1 || p.neigh_max_pts > 32)
-        return fail(h, IBA_ERR_UNSUPPORTED, "norm_max_pts / neigh_max_pts must be in [1, 32]");
+    if (p.norm_max_pts < 1 || p.norm_max_pts > 64 || p.neigh_max_pts < 1 || p.neigh_max_pts > 64)
+        return fail(h, IBA_ERR_UNSUPPORTED, "norm_max_pts / neigh_max_pts must be in [1, 64] (the neighbour list lives one entry per lane of a wave)");
+    if (h && !p.plane_cache && h->max_slots > (uint32_t)kMaxCovisRefit)
+        return fail(h, IBA_ERR_UNSUPPORTED, "plane_cache = 0 supports at most 10 covisible keyframes per frame");
     return IBA_OK;
 }
 
@@ -219,7 +222,7 @@ bool layout_assoc(iba_handle* h, LdsLayout& L) {
     off += 4u * L.vis_words + 2u * (h->maxPpad / (uint32_t)kChunk + 2u);
     off = align_up(off, 4); L.off_cstart = off; off += 2u * std::max(h->maxCoarse, 1u);
     off = align_up(off, 16); L.off_kuv = off; off += 8u * std::max(h->maxK, 1u);
-    L.off_kfl = off; off += 2u * std::max(h->maxK, 1u);
+    L.off_kfl = off; off += 4u * std::max(h->maxK, 1u);
     off = align_up(off, 16);
     const uint32_t bm_bytes = align_up(4u * std::max(h->maxBitmapWords, 1u), 16u);
     if (off + bm_bytes + 4u * 512u > kLdsBytes) return false;
@@ -414,6 +417,13 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     return IBA_OK;
 }
 
+// batches larger than IBA_MAX_BATCH (the candidates one launch chain takes) run as consecutive chunks
+template <class F>
+iba_status chunked(int B, F f) {
+    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) { const iba_status s = f(b0, std::min(IBA_MAX_BATCH, B - b0)); if (s != IBA_OK) return s; }
+    return IBA_OK;
+}
+
 iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
     if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -505,8 +515,11 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         const uint64_t P = d->pt_offset[f + 1] - d->pt_offset[f], K = d->kp_offset[f + 1] - d->kp_offset[f];
         if (P >= (1ull << 22) || K >= 65535ull) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan (>= 2^22 points) or keypoint count (>= 65535) too large"); }
         const uint64_t ns = d->covis_offset[f + 1] - d->covis_offset[f];
-        if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 10 covisible keyframes per frame"); }
+        if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 22 covisible keyframes per frame"); }
+        h->max_slots = std::max<uint32_t>(h->max_slots, (uint32_t)ns);
     }
+
+    if (!params->plane_cache && h->max_slots > (uint32_t)kMaxCovisRefit) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "plane_cache = 0 supports at most 10 covisible keyframes per frame"); }
 
     // ---- per-frame host build (parallel over frames; reference: omp parallel for at iba_global.cpp:363) ----
     // keypoints are stored in Morton order of their pixel (internal id j -> reference id kp_order[j]): queries that
@@ -628,9 +641,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
             }
         }
     });
-    std::vector<uint16_t> kp_fl(kp_base);
+    std::vector<uint32_t> kp_fl(kp_base);
     bool crec_ok = true;
-    for (size_t k = 0; k < (size_t)kp_base; ++k) kp_fl[k] = (uint16_t)(int)kp_mp[k].w;
+    for (size_t k = 0; k < (size_t)kp_base; ++k) kp_fl[k] = (uint32_t)(int)kp_mp[k].w;
     for (int lf = 0; lf < nf; ++lf) {
         uint32_t cnt = 0;
         for (uint32_t k = 0; k < hdr[lf].K; ++k) { uint32_t idb; std::memcpy(&idb, &crec[hdr[lf].kp_base + k].z, 4); crec_ok = crec_ok && idb == k; }
@@ -766,29 +779,33 @@ iba_status iba_finalize_cost(const iba_params* p, const double* part, int32_t B,
 }
 
 iba_status iba_eval_cost_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
-    if (!h || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return eval_cost_partial_impl(h, x, B, (double*)d_partials, stream ? (hipStream_t)stream : h->stream);
+    if (!h || !d_partials || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return chunked(B, [&](int b0, int Bc) { return eval_cost_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
 }
 
 iba_status iba_eval_cost(iba_handle* h, const double* x, int32_t B, iba_cost_out* out) {
-    if (!h || !out) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    iba_status s = eval_cost_partial_impl(h, x, B, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
-    return iba_finalize_cost(&h->params, h->h_partials, B, out);
+    if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return chunked(B, [&](int b0, int Bc) {
+        iba_status s = eval_cost_partial_impl(h, x + 7 * b0, Bc, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
+        HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * Bc * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
+        return iba_finalize_cost(&h->params, h->h_partials, Bc, out + b0);
+    });
 }
 
 iba_status iba_eval_bbo(iba_handle* h, const double* x, int32_t B, double he_threshold, double valid_rate, iba_bbo* out) {
-    if (!h || !out || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
-    iba_cost_out c[IBA_MAX_BATCH];
-    iba_status s = iba_eval_cost(h, x, B, c); if (s != IBA_OK) return s;
-    for (int b = 0; b < B; ++b) {   // iba_global.cpp:386-392
-        out[b].f = c[b].f1 * h->params.err_weight[0] + c[b].f2 * h->params.err_weight[1];
-        out[b].c1 = c[b].C - he_threshold; out[b].c2 = -c[b].C - he_threshold;
-        out[b].c3 = valid_rate - static_cast<double>(c[b].valid_cnt_3d_2d) / (c[b].cnt_3d_2d + 1);
-    }
-    return IBA_OK;
+    if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    return chunked(B, [&](int b0, int Bc) {
+        iba_cost_out c[IBA_MAX_BATCH];
+        iba_status s = iba_eval_cost(h, x + 7 * b0, Bc, c); if (s != IBA_OK) return s;
+        for (int b = 0; b < Bc; ++b) {   // iba_global.cpp:386-392
+            out[b0 + b].f = c[b].f1 * h->params.err_weight[0] + c[b].f2 * h->params.err_weight[1];
+            out[b0 + b].c1 = c[b].C - he_threshold; out[b0 + b].c2 = -c[b].C - he_threshold;
+            out[b0 + b].c3 = valid_rate - static_cast<double>(c[b].valid_cnt_3d_2d) / (c[b].cnt_3d_2d + 1);
+        }
+        return IBA_OK;
+    });
 }
 
 iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame, uint32_t* kp_idx, uint32_t* pt_idx, int32_t cap, int32_t* n_out) {
@@ -844,7 +861,7 @@ iba_status iba_x_to_sim3(const double x[7], double rigid12[12], double* scale) {
 
 // debug: host copy of the last summed partial blocks (B x iba_partial_stride() doubles)
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
-    if (!h || !out || B < 1 || B > IBA_MAX_BATCH) return IBA_ERR_INVALID_ARG;
+    if (!h || !out || B < 1 || B > IBA_MAX_BATCH) return IBA_ERR_INVALID_ARG;   // the last launch chain's block: at most IBA_MAX_BATCH candidates
     std::memcpy(out, h->h_partials, sizeof(double) * B * kPartialStride);
     return IBA_OK;
 }
@@ -907,17 +924,19 @@ static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B
 }
 
 iba_status iba_eval_normal_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
-    if (!h || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return eval_normal_partial_impl(h, x, B, (double*)d_partials, stream ? (hipStream_t)stream : h->stream);
+    if (!h || !d_partials || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return chunked(B, [&](int b0, int Bc) { return eval_normal_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
 }
 
 iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
-    if (!h || !out) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    iba_status s = eval_normal_partial_impl(h, x, B, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
-    return iba_finalize_normal(&h->params, h->h_partials, B, out);
+    if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return chunked(B, [&](int b0, int Bc) {
+        iba_status s = eval_normal_partial_impl(h, x + 7 * b0, Bc, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
+        HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * Bc * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
+        return iba_finalize_normal(&h->params, h->h_partials, Bc, out + b0);
+    });
 }
 
 // BAError tuple AND re-associated normal equations of the same candidates from ONE pass over the scans:
@@ -941,17 +960,19 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
 }
 
 iba_status iba_eval_full_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
-    if (!h || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return eval_full_partial_impl(h, x, B, (double*)d_partials, stream ? (hipStream_t)stream : h->stream);
+    if (!h || !d_partials || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return chunked(B, [&](int b0, int Bc) { return eval_full_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
 }
 
 iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal) {
-    if (!h || !cost || !normal) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    iba_status s = eval_full_partial_impl(h, x, B, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    s = iba_finalize_cost(&h->params, h->h_partials, B, cost); if (s != IBA_OK) return s;
-    return iba_finalize_normal(&h->params, h->h_partials, B, normal);
+    if (!h || !cost || !normal || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return chunked(B, [&](int b0, int Bc) {
+        iba_status s = eval_full_partial_impl(h, x + 7 * b0, Bc, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
+        HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * Bc * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        s = iba_finalize_cost(&h->params, h->h_partials, Bc, cost + b0); if (s != IBA_OK) return s;
+        return iba_finalize_normal(&h->params, h->h_partials, Bc, normal + b0);
+    });
 }
 
 iba_status iba_build_problem(iba_handle* h, const double* x) {
@@ -991,17 +1012,19 @@ static iba_status eval_factors_partial_impl(iba_handle* h, const double* x, int 
 }
 
 iba_status iba_eval_factors_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
-    if (!h || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return eval_factors_partial_impl(h, x, B, (double*)d_partials, stream ? (hipStream_t)stream : h->stream);
+    if (!h || !d_partials || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return chunked(B, [&](int b0, int Bc) { return eval_factors_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
 }
 
 iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
-    if (!h || !out) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    iba_status s = eval_factors_partial_impl(h, x, B, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * B * kPartialStride, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
-    return iba_finalize_normal(&h->params, h->h_partials, B, out);
+    if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    return chunked(B, [&](int b0, int Bc) {
+        iba_status s = eval_factors_partial_impl(h, x + 7 * b0, Bc, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
+        HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * Bc * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
+        return iba_finalize_normal(&h->params, h->h_partials, Bc, out + b0);
+    });
 }
 
 // ---- one 8-row residual block standing for the whole frozen problem (Ceres / g2o adaptors) ----

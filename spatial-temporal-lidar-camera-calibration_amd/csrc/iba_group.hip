@@ -136,17 +136,21 @@ iba_status iba_group_set_params(iba_group* g, const iba_params* p) {
 }
 
 iba_status iba_group_eval_cost(iba_group* g, const double* x, int32_t B, iba_cost_out* out) {
-    if (!g || !x || !out || B < 1 || B > IBA_MAX_BATCH) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_cost_partial(g->h[i], x, B, g->d_part[i], g->st[i]));
-    iba_status s = allreduce(g, B); if (s != IBA_OK) return s;
-    s = fetch(g, B); if (s != IBA_OK) return s;
-    return iba_finalize_cost(&g->params, g->h_part, B, out);
+    if (!g || !x || !out || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
+    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {   // larger batches run as consecutive chunks
+        const int Bc = std::min(IBA_MAX_BATCH, B - b0);
+        for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_cost_partial(g->h[i], x + 7 * b0, Bc, g->d_part[i], g->st[i]));
+        iba_status s = allreduce(g, Bc); if (s != IBA_OK) return s;
+        s = fetch(g, Bc); if (s != IBA_OK) return s;
+        s = iba_finalize_cost(&g->params, g->h_part, Bc, out + b0); if (s != IBA_OK) return s;
+    }
+    return IBA_OK;
 }
 
 iba_status iba_group_eval_bbo(iba_group* g, const double* x, int32_t B, double he_threshold, double valid_rate, iba_bbo* out) {
-    if (!g || !out || B < 1 || B > IBA_MAX_BATCH) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    iba_cost_out c[IBA_MAX_BATCH];
-    const iba_status s = iba_group_eval_cost(g, x, B, c); if (s != IBA_OK) return s;
+    if (!g || !out || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
+    std::vector<iba_cost_out> c((size_t)B);
+    const iba_status s = iba_group_eval_cost(g, x, B, c.data()); if (s != IBA_OK) return s;
     for (int b = 0; b < B; ++b) {   // iba_global.cpp:386-392
         out[b].f = c[b].f1 * g->params.err_weight[0] + c[b].f2 * g->params.err_weight[1];
         out[b].c1 = c[b].C - he_threshold; out[b].c2 = -c[b].C - he_threshold;
@@ -156,20 +160,28 @@ iba_status iba_group_eval_bbo(iba_group* g, const double* x, int32_t B, double h
 }
 
 iba_status iba_group_eval_full(iba_group* g, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal) {
-    if (!g || !x || !cost || !normal || B < 1 || B > IBA_MAX_BATCH) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_full_partial(g->h[i], x, B, g->d_part[i], g->st[i]));
-    iba_status s = allreduce(g, B); if (s != IBA_OK) return s;
-    s = fetch(g, B); if (s != IBA_OK) return s;
-    s = iba_finalize_cost(&g->params, g->h_part, B, cost); if (s != IBA_OK) return s;
-    return iba_finalize_normal(&g->params, g->h_part, B, normal);
+    if (!g || !x || !cost || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
+    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
+        const int Bc = std::min(IBA_MAX_BATCH, B - b0);
+        for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_full_partial(g->h[i], x + 7 * b0, Bc, g->d_part[i], g->st[i]));
+        iba_status s = allreduce(g, Bc); if (s != IBA_OK) return s;
+        s = fetch(g, Bc); if (s != IBA_OK) return s;
+        s = iba_finalize_cost(&g->params, g->h_part, Bc, cost + b0); if (s != IBA_OK) return s;
+        s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
+    }
+    return IBA_OK;
 }
 
 iba_status iba_group_eval_normal(iba_group* g, const double* x, int32_t B, iba_normal_out* normal) {
-    if (!g || !x || !normal || B < 1 || B > IBA_MAX_BATCH) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_normal_partial(g->h[i], x, B, g->d_part[i], g->st[i]));
-    iba_status s = allreduce(g, B); if (s != IBA_OK) return s;
-    s = fetch(g, B); if (s != IBA_OK) return s;
-    return iba_finalize_normal(&g->params, g->h_part, B, normal);
+    if (!g || !x || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
+    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
+        const int Bc = std::min(IBA_MAX_BATCH, B - b0);
+        for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_normal_partial(g->h[i], x + 7 * b0, Bc, g->d_part[i], g->st[i]));
+        iba_status s = allreduce(g, Bc); if (s != IBA_OK) return s;
+        s = fetch(g, Bc); if (s != IBA_OK) return s;
+        s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
+    }
+    return IBA_OK;
 }
 
 iba_status iba_group_build_problem(iba_group* g, const double* x_assoc) {
@@ -179,11 +191,15 @@ iba_status iba_group_build_problem(iba_group* g, const double* x_assoc) {
 }
 
 iba_status iba_group_eval_factors(iba_group* g, const double* x, int32_t B, iba_normal_out* normal) {
-    if (!g || !x || !normal || B < 1 || B > IBA_MAX_BATCH) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_factors_partial(g->h[i], x, B, g->d_part[i], g->st[i]));
-    iba_status s = allreduce(g, B); if (s != IBA_OK) return s;
-    s = fetch(g, B); if (s != IBA_OK) return s;
-    return iba_finalize_normal(&g->params, g->h_part, B, normal);
+    if (!g || !x || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
+    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
+        const int Bc = std::min(IBA_MAX_BATCH, B - b0);
+        for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_factors_partial(g->h[i], x + 7 * b0, Bc, g->d_part[i], g->st[i]));
+        iba_status s = allreduce(g, Bc); if (s != IBA_OK) return s;
+        s = fetch(g, Bc); if (s != IBA_OK) return s;
+        s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
+    }
+    return IBA_OK;
 }
 
 iba_status iba_group_calibrate_lm(iba_group* g, const double* x0, const iba_lm_options* opt, iba_lm_result* res) {

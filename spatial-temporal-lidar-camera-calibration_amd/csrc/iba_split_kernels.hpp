@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     uint32_t* s_cand = (uint32_t*)(smem + lay.off_cand);
     uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 after phase 2
     float2* s_kuv = (float2*)(smem + lay.off_kuv);            // (u, v) of every keypoint; keypoint ids are in grid-record order
-    uint16_t* s_kfl = (uint16_t*)(smem + lay.off_kfl);        // flag word of every keypoint (MapPoint, covisible matches)
+    uint32_t* s_kfl = (uint32_t*)(smem + lay.off_kfl);        // flag word of every keypoint: bit 0 MapPoint, bit 1 any covisible match, bits 2.. one per covisible slot
 
     const uint32_t P = h.P, Ppad = h.Ppad, K = h.K;
     const float* gxs = dp.xs + h.pt_base; const float* gys = dp.ys + h.pt_base; const float* gzs = dp.zs + h.pt_base;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
     // ---- work list: keypoints with a correspondence that can own a term: a MapPoint and/or a covisible match for the
     //      cost (iba_global.cpp:225, 295-300), both for a residual block (iba_local.cpp:213, 259-260); entry = k | w << 16
-    //      (bits 16,17: MapPoint / covisible-match flags; 18..27: covisible-slot mask) ----
+    //      (bits 16,17: MapPoint / covisible-match flags) ----
     {
         uint32_t* s_cnt3 = (uint32_t*)s_red;
         uint32_t at = usedC ? cntC : (usedA ? cntA : 0u);   // entries of the waves before this one
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
             const unsigned long long bal = __ballot(wantk);
             if (wantk) {
                 const uint32_t i = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                s_list[i] = k | ((uint32_t)w << 16);
+                s_list[i] = k | (((uint32_t)w & 3u) << 16);   // the slot mask is read from s_kfl where it is needed
                 s_pos[i] = inv_perm[s_best_idx[k]];
             }
             at += (uint32_t)__popcll(bal);
@@ -430,9 +430,9 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328): only the slots whose match bit is set
     if (usedC) {
         for (uint32_t i = tid; i < n3; i += kThreads) {
-            uint32_t mask = (s_list[i] >> 18) & 0x3ffu;
-            if (!mask) continue;
             const uint32_t k = s_list[i] & 0xffffu, pos = s_pos[i];
+            uint32_t mask = s_kfl[k] >> 2;
+            if (!mask) continue;
             float xf_, yf_, zf_; load_pt<true>(c, pos, xf_, yf_, zf_);
             const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
             const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];

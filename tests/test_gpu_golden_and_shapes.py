@@ -75,9 +75,9 @@ def test_golden_fixture_replayed_on_the_gpu(pkg, abi):
     kp, pt = h.correspondences(xs[0], 2)
     assert np.array_equal(kp, z["corr_f2_kp"]) and np.array_equal(pt, z["corr_f2_pt"])
     # the separate entry points see the same numbers
-    for a, b in zip(h.eval_cost(xs), cost):
+    for a, b in zip(h.eval_cost(xs), cost):   # the cost-only chain lists other keypoints: same terms, another summation order
         da, db = a.as_dict(), b.as_dict()
-        assert all(da[k] == db[k] or (da[k] != da[k] and db[k] != db[k]) for k in da), (da, db)
+        assert all(da[k] == db[k] or (da[k] != da[k] and db[k] != db[k]) or (k in ("f1", "f2") and abs(da[k] - db[k]) <= 1e-13 * abs(db[k])) for k in da), (da, db)
     h.close()
 
 

@@ -1,0 +1,75 @@
+"""Shapes the reference allows and round 1 refused: more than 10 covisible keyframes per frame
+(GetCovisiblesByWeightSafe is unbounded, iba_global.cpp:259), norm_max_pts / neigh_max_pts above 32, more than 64 candidates per call."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+INT = ("valid_cnt_3d_2d", "cnt_3d_2d", "cnt_3d_3d", "valid_cnt_3d_3d", "valid_pl_3d_3d", "valid_pt_3d_3d", "frames_used", "n_corr")
+
+
+def _check(h, o, p, xs):
+    cost, nrm = h.eval_full(xs)
+    for a, b in zip(cost, o.eval_cost(p, xs, nthreads=8)):
+        for k in INT:
+            assert getattr(a, k) == getattr(b, k), k
+        assert abs(a.f1 - b.f1) <= 1e-10 * abs(b.f1) and abs(a.f2 - b.f2) <= 1e-10 * abs(b.f2)
+    for a, b in zip(nrm, o.eval_normal(p, xs, nthreads=8)):
+        assert a.counts() == b.counts()
+        # (ill-conditioned plane blocks bound the agreement of the sums: tests/test_gpu_golden_and_shapes.py::test_c2_ill_conditioned_block)
+        assert np.max(np.abs(a.H_np() - b.H_np())) <= 1e-8 * np.abs(b.H_np()).max() and np.max(np.abs(a.b_np() - b.b_np())) <= 1e-8 * np.abs(b.b_np()).max()
+    return cost, nrm
+
+
+def test_fourteen_covisible_keyframes(pkg, synth, abi, ob):
+    prob, meta = synth.make_scene(n_frames=18, pts_per_frame=3000, n_keypoints=800, seed=41, n_covis=14)
+    assert int(np.diff(prob.arrays["covis_offset"].astype(np.int64)).max()) == 14
+    p = abi.reference_yaml_params()
+    h, o = pkg.IbaHandle(prob, p), ob.Oracle(prob)
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(41), n=3)])
+    cost, nrm = _check(h, o, p, xs)
+    assert cost[0].cnt_3d_2d > 3 * cost[0].n_corr // 2     # many covisible reprojections per correspondence
+    h.build_problem(xs[1])
+    o.build_problem(p, xs[1])
+    rg, Jg, _, kg = h.eval_residuals(xs[2])
+    ro, Jo, _, ko, _ = o.eval_residuals(xs[2])
+    assert np.array_equal(kg, ko) and np.allclose(rg, ro, rtol=1e-9, atol=1e-9) and np.allclose(Jg, Jo, rtol=1e-8, atol=1e-8 * np.abs(Jo).max())
+    h.close()
+    with pytest.raises(pkg.IbaError) as e:     # the per-evaluation refit path keeps the 10-slot packing and says so
+        pkg.IbaHandle(prob, abi.reference_yaml_params(plane_cache=0))
+    assert e.value.status == 4
+
+
+def test_neighbour_lists_longer_than_32(pkg, synth, abi, ob):
+    prob, meta = synth.make_scene(n_frames=4, pts_per_frame=9000, n_keypoints=900, seed=42)
+    p = abi.reference_yaml_params()
+    p.norm_max_pts, p.neigh_max_pts, p.norm_radius, p.neigh_radius = 50, 48, 0.9, 0.8
+    h, o = pkg.IbaHandle(prob, p), ob.Oracle(prob)
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(42), n=2)])
+    _check(h, o, p, xs)
+    h.set_params(abi.reference_yaml_params(plane_cache=0))    # refit mode with the long lists
+    pr = abi.reference_yaml_params(plane_cache=0)
+    pr.norm_max_pts, pr.neigh_max_pts, pr.norm_radius, pr.neigh_radius = 50, 48, 0.9, 0.8
+    h.set_params(pr)
+    _check(h, o, pr, xs[:2])
+    h.close()
+
+
+def test_more_than_sixty_four_candidates_per_call(pkg, synth, abi, scene_small):
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(prob, p)
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(43), n=150)
+    cost, nrm = h.eval_full(xs)
+    assert len(cost) == 150
+    for lo, hi in ((0, 64), (64, 128), (128, 150)):
+        c2, n2 = h.eval_full(xs[lo:hi])
+        for a, b in zip(cost[lo:hi], c2):
+            assert a.as_dict() == b.as_dict()
+        for a, b in zip(nrm[lo:hi], n2):
+            assert np.array_equal(a.H_np(), b.H_np()) and a.counts() == b.counts()
+    bb = h.eval_bbo(xs, 0.094, 0.95)
+    assert len(bb) == 150 and bb[100].f == cost[100].f1 * p.err_weight[0] + cost[100].f2 * p.err_weight[1]
+    c3 = h.eval_cost(xs)   # the cost-only chain lists other keypoints: same terms, another summation order
+    for a, b in zip(c3, cost):
+        assert all(getattr(a, k) == getattr(b, k) for k in INT) and abs(a.f1 - b.f1) <= 1e-13 * b.f1 and abs(a.f2 - b.f2) <= 1e-13 * b.f2
+    h.close()
