@@ -613,6 +613,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
                 for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }   // NaN coordinates never narrow a box
             }
             for (int a = 0; a < 3; ++a) { bx[a] = mn[a]; bx[4 + a] = mx[a]; }
+            float rmax = 0.f;   // largest |coordinate| of the box (slack term of the frustum test); NaN for an empty chunk
+            for (int a = 0; a < 3; ++a) rmax = std::max(rmax, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+            bx[7] = (mn[0] <= mx[0]) ? rmax : qnan;
         }
         std::copy(b.nodes.begin(), b.nodes.end(), nodes.begin() + x.node_base);
         const uint64_t k0 = d->kp_offset[f];

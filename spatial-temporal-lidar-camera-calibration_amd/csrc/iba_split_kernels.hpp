@@ -146,12 +146,13 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
         const float m = 8.0f;
         const float A[5][3] = {{(float)c.fx, 0.f, (float)c.cx + m}, {-(float)c.fx, 0.f, (float)c.W + m - (float)c.cx},
                                {0.f, (float)c.fx, (float)c.cy + m}, {0.f, -(float)c.fx, (float)c.H + m - (float)c.cy}, {0.f, 0.f, 1.f}};
-        float N[5][3], Dd[5];
+        float N[5][3], Dd[5], N1[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) N[q][j] = (float)c.R[0 * 3 + j] * A[q][0] + (float)c.R[1 * 3 + j] * A[q][1] + (float)c.R[2 * 3 + j] * A[q][2];
             Dd[q] = (float)c.t[0] * A[q][0] + (float)c.t[1] * A[q][1] + (float)c.t[2] * A[q][2] + (q == 4 ? 0.2f : 0.f);
+            N1[q] = fabsf(N[q][0]) + fabsf(N[q][1]) + fabsf(N[q][2]);
         }
         const float4* boxes = (const float4*)(dp.chunk_box + 8 * h.box_base);   // two 16-byte loads per chunk
         uint32_t vis_cnt = 0u;
@@ -162,14 +163,13 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
                 const float4 blo = boxes[2 * (size_t)ch], bhi = boxes[2 * (size_t)ch + 1];
                 const float lo3[3] = {blo.x, blo.y, blo.z}, hi3[3] = {bhi.x, bhi.y, bhi.z};
                 vis = true;
+                const float rmax = bhi.w;   // largest |coordinate| of the box: |n . x| <= |n|_1 rmax bounds the slack term
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
-                    float smax = Dd[q], mag = fabsf(Dd[q]);
+                    float smax = Dd[q];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        smax += N[q][j] >= 0.f ? N[q][j] * hi3[j] : N[q][j] * lo3[j];
-                        mag += fabsf(N[q][j]) * fmaxf(fabsf(lo3[j]), fabsf(hi3[j]));
-                    }
+                    for (int j = 0; j < 3; ++j) smax += fmaxf(N[q][j] * hi3[j], N[q][j] * lo3[j]);   // the farthest corner along n
+                    const float mag = fmaf(N1[q], rmax, fabsf(Dd[q]));
                     vis = vis && !(smax < -1e-3f * mag - 1e-6f);   // NaN boxes (empty chunk) compare false -> kept, harmless
                 }
             }
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
         const float r0 = (float)c.R[0], r1 = (float)c.R[1], r2 = (float)c.R[2], r3 = (float)c.R[3], r4 = (float)c.R[4], r5 = (float)c.R[5],
                     r6 = (float)c.R[6], r7 = (float)c.R[7], r8 = (float)c.R[8], t0 = (float)c.t[0], t1 = (float)c.t[1], t2 = (float)c.t[2];
         const float fxf = (float)c.fx, cxf = (float)c.cx, cyf = (float)c.cy, Wf = (float)c.W + 1.0f, Hf = (float)c.H + 1.0f;
+        constexpr float kInvCell = 1.0f / (float)kGridCell;
         const uint32_t n_groups = n_vis * (uint32_t)(kChunk / 4);
         const uint32_t n_iter = (n_groups + kThreads - 1u) / kThreads;
         const float qn = __builtin_nanf("");
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
                     const float yc = fmaf(r3, px[j], fmaf(r4, py[j], fmaf(r5, pz[j], t1)));
                     const float rz = __builtin_amdgcn_rcpf(zc);
                     const float uf = fmaf(fxf * xc, rz, cxf), vf = fmaf(fxf * yc, rz, cyf);
-                    if (uf > -1.0f && uf < Wf && vf > -1.0f && vf < Hf) {
-                        const uint32_t cell = (uint32_t)grid_cell(vf, c.gh) * (uint32_t)c.gw + (uint32_t)grid_cell(uf, c.gw);
+                    if (uf > -1.0f && uf < Wf && vf > -1.0f && vf < Hf) {   // inside the padded image: the cell needs no clamping
+                        const uint32_t cell = (uint32_t)((int)floorf(vf * kInvCell) + 1) * (uint32_t)c.gw + (uint32_t)((int)floorf(uf * kInvCell) + 1);
                         pass[j] = (s_bitmap[cell >> 5] >> (cell & 31)) & 1u;
                     }
                 } else if (zc > -0.1f) pass[j] = true;   // undecidable in f32 (NaN padding fails both tests): exact path decides
