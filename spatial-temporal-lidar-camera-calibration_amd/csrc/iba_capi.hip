@@ -266,7 +266,8 @@ iba_status compute_plane_cache(iba_handle* h) {
     auto run = [&](double r2, int max_pts, PlaneRec* out) -> hipError_t {
         dim3 grid((h->maxP + 3) / 4, h->n_frames);
         if (h->maxP == 0 || h->n_frames == 0) return hipSuccess;
-        hipLaunchKernelGGL(iba_plane_kernel, grid, dim3(256), 0, h->stream, dp, r2, max_pts, out);
+        if (max_pts <= 32) hipLaunchKernelGGL(iba_plane_kernel<2>, grid, dim3(64), 0, h->stream, dp, r2, max_pts, out);
+        else hipLaunchKernelGGL(iba_plane_kernel<4>, grid, dim3(64), 0, h->stream, dp, r2, max_pts, out);
         hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
         return hipStreamSynchronize(h->stream);
     };

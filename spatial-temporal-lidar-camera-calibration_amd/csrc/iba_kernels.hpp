@@ -352,16 +352,178 @@ __device__ inline PlaneRec plane_fit_wave(const float* __restrict__ xs, const fl
     return rec;
 }
 
-// grid: (ceil(maxP / waves_per_block), n_frames); one wave per scan point
+// ---- FOUR plane fits per wave: one DPP row (16 lanes) per fit ----
+// Same result, entry for entry, as plane_fit_wave. The sorted neighbour list of a row lives SLOTS entries per lane (entry
+// i = SLOTS * lane + slot; SLOTS = 2 serves max_pts <= 32, SLOTS = 4 up to 64). The traversal state is per row. A leaf is
+// tested 16 points per row and pass; candidate L of every row is broadcast with row_newbcast:L and inserted IN PLACE: an
+// entry that is > the candidate takes its left neighbour's value (row_shr:1 across lanes) or the candidate itself — no
+// insertion index, no ballot. A candidate that does not qualify is inserted as +inf, which moves nothing; the pruning bound
+// (the max_pts-th entry) is refreshed once per pass, which is safe: a candidate admitted under a stale bound sorts behind
+// max_pts entries and is never looked at. Covariance and regularity sums run in list order (ComputeCovariance,
+// pointcloud.h:126-158) as nine serial chains, one per lane, over moments transposed through LDS.
+// All 64 lanes must be active; one wave per workgroup (the __syncthreads below order the wave's own LDS traffic).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    const long long b = __double_as_longlong(v), o = __double_as_longlong(old);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowBcast0 = 0x150;   // row_shr:1; row_newbcast:0 (+L: lane L of each row to the row)
+
+template <int L, int SLOTS>
+__device__ __forceinline__ void fit_insert(double d2, uint32_t base, double bound, double (&ed)[SLOTS], uint32_t (&ep)[SLOTS]) {
+    const double c0 = dpp_f64<kDppRowBcast0 + L>(0.0, d2);
+    const double cd = c0 < bound ? c0 : INFINITY;
+    const uint32_t cp = base + (uint32_t)L;
+    const double pd = dpp_f64<kDppRowShr1>(-INFINITY, ed[SLOTS - 1]);
+    const uint32_t pp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ep[SLOTS - 1], kDppRowShr1, 0xf, 0xf, false);
+    double nd[SLOTS]; uint32_t np[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const double prevd = s ? ed[s ? s - 1 : 0] : pd; const uint32_t prevp = s ? ep[s ? s - 1 : 0] : pp;
+        const bool keep = ed[s] <= cd, pk = prevd <= cd;   // equal distances: the earlier visit stays in front (nanoflann's KNNResultSet)
+        nd[s] = keep ? ed[s] : (pk ? cd : prevd);
+        np[s] = keep ? ep[s] : (pk ? cp : prevp);
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) { ed[s] = nd[s]; ep[s] = np[s]; }
+}
+
+constexpr int kFitRowDoubles(int slots) { return 16 * slots * 9 + 1; }   // LDS doubles per row: nine moments per list entry, + the farthest kept distance
+
+template <int SLOTS>
+__device__ inline PlaneRec plane_fit_rows(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+                                          const TreeNode* __restrict__ nodes, uint32_t P, uint32_t D, uint32_t cpos /* of this lane's row; kNone: idle row */,
+                                          double r2, int max_pts, double* __restrict__ s_wave /* [4][kFitRowDoubles(SLOTS)] */) {
+    const int lane = threadIdx.x & 63, gl = lane & 15, row_sh = lane & 48;
+    double* buf = s_wave + (lane >> 4) * kFitRowDoubles(SLOTS);
+    const bool act = cpos != kNone;
+    double qx = 0, qy = 0, qz = 0;
+    if (act) { qx = (double)xs[cpos]; qy = (double)ys[cpos]; qz = (double)zs[cpos]; }
+    double ed[SLOTS]; uint32_t ep[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) { ed[s] = INFINITY; ep[s] = kNone; }
+    double bound = r2;
+    uint32_t node = 0, depth = 0;
+    const uint32_t first_leaf = (1u << D) - 1u;
+    const int kth_lane = row_sh + (max_pts - 1) / SLOTS, kth_slot = (max_pts - 1) % SLOTS;
+    bool running = act;
+    while (__ballot(running) != 0ull) {
+        uint32_t lo = 0, hi = 0;
+        if (running) {
+            while (depth < D) {
+                const TreeNode n = nodes[node];
+                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+                node = 2u * node + 1u + ((qd - (double)n.split) >= 0.0 ? 1u : 0u);
+                ++depth;
+            }
+            const uint32_t j = node - first_leaf;
+            lo = (uint32_t)(((uint64_t)j * P) >> D); hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+        }
+        for (uint32_t base = lo; __ballot(base < hi) != 0ull; base += 16u) {
+            const uint32_t i = base + (uint32_t)gl;
+            double d2 = INFINITY;
+            if (i < hi) {
+                const double dx = qx - (double)xs[i], dy = qy - (double)ys[i], dz = qz - (double)zs[i];
+                d2 = (dx * dx + dy * dy) + dz * dz;
+            }
+            const unsigned long long m = __ballot(d2 < bound);
+            if (m == 0ull) continue;
+            const uint32_t m16 = (uint32_t)(m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffu;   // lanes-of-a-row with a candidate in ANY row
+#define IBA_FIT_STEP(L) if (m16 & (1u << L)) fit_insert<L, SLOTS>(d2, base, bound, ed, ep);
+            IBA_FIT_STEP(0) IBA_FIT_STEP(1) IBA_FIT_STEP(2) IBA_FIT_STEP(3) IBA_FIT_STEP(4) IBA_FIT_STEP(5) IBA_FIT_STEP(6) IBA_FIT_STEP(7)
+            IBA_FIT_STEP(8) IBA_FIT_STEP(9) IBA_FIT_STEP(10) IBA_FIT_STEP(11) IBA_FIT_STEP(12) IBA_FIT_STEP(13) IBA_FIT_STEP(14) IBA_FIT_STEP(15)
+#undef IBA_FIT_STEP
+            double kv = ed[0];
+#pragma unroll
+            for (int s = 1; s < SLOTS; ++s) kv = kth_slot == s ? ed[s] : kv;
+            bound = fmin(r2, __shfl(kv, kth_lane));
+        }
+        if (running) {
+            bool go = false;
+            while (depth > 0) {
+                const uint32_t parent = (node - 1u) >> 1;
+                const bool was_right = (node & 1u) == 0u;
+                const TreeNode n = nodes[parent];
+                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+                const double diff = qd - (double)n.split;
+                const bool near_right = diff >= 0.0;
+                if (was_right == near_right && diff * diff < bound) { node = 2u * parent + 1u + (near_right ? 0u : 1u); go = true; break; }
+                node = parent; --depth;
+            }
+            running = go;
+        }
+    }
+    // kept neighbours of the row: finite entries below max_pts
+    int count = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const unsigned long long m = __ballot(SLOTS * gl + s < max_pts && ed[s] < INFINITY);
+        count += __popc((uint32_t)(m >> row_sh) & 0xffffu);
+    }
+    const int cmax = max(max(__builtin_amdgcn_readlane(count, 0), __builtin_amdgcn_readlane(count, 16)), max(__builtin_amdgcn_readlane(count, 32), __builtin_amdgcn_readlane(count, 48)));
+    PlaneRec rec;
+    rec.k = count; rec.pad = 0;
+    double ex[SLOTS], ey[SLOTS], ez[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int i = SLOTS * gl + s;
+        ex[s] = ey[s] = ez[s] = 0.0;
+        if (i < count) {
+            const uint32_t p = ep[s];
+            const double x = (double)xs[p], y = (double)ys[p], z = (double)zs[p];
+            ex[s] = x; ey[s] = y; ez[s] = z;
+            double* o = buf + i * 9;
+            o[0] = x; o[1] = y; o[2] = z; o[3] = x * x; o[4] = x * y; o[5] = x * z; o[6] = y * y; o[7] = y * z; o[8] = z * z;
+            if (i == count - 1) buf[16 * SLOTS * 9] = ed[s];
+        }
+    }
+    __syncthreads();
+    rec.far_d2 = count > 0 ? buf[16 * SLOTS * 9] : 0.0;
+    double c = 0.0;   // lane q < 9 of the row: moment q summed in list order
+    {
+        const double* src = buf + (gl < 9 ? gl : 0);
+        for (int j = 0; j < cmax; ++j) { const double v = src[j * 9]; if (j < count) c += v; }
+    }
+    c /= (double)count;
+    double cq[9];
+    cq[0] = dpp_f64<kDppRowBcast0 + 0>(0.0, c); cq[1] = dpp_f64<kDppRowBcast0 + 1>(0.0, c); cq[2] = dpp_f64<kDppRowBcast0 + 2>(0.0, c);
+    cq[3] = dpp_f64<kDppRowBcast0 + 3>(0.0, c); cq[4] = dpp_f64<kDppRowBcast0 + 4>(0.0, c); cq[5] = dpp_f64<kDppRowBcast0 + 5>(0.0, c);
+    cq[6] = dpp_f64<kDppRowBcast0 + 6>(0.0, c); cq[7] = dpp_f64<kDppRowBcast0 + 7>(0.0, c); cq[8] = dpp_f64<kDppRowBcast0 + 8>(0.0, c);
+    double cov[9];
+    cov[0] = cq[3] - cq[0] * cq[0]; cov[4] = cq[6] - cq[1] * cq[1]; cov[8] = cq[8] - cq[2] * cq[2];
+    cov[1] = cov[3] = cq[4] - cq[0] * cq[1]; cov[2] = cov[6] = cq[5] - cq[0] * cq[2]; cov[5] = cov[7] = cq[7] - cq[1] * cq[2];
+    double nrm[3]; dev_smallest_evec(cov, nrm);
+    __syncthreads();   // the moments have been read: the buffer now takes the regularity terms
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int i = SLOTS * gl + s;
+        if (i < count) {
+            const double ax = ex[s] - qx, ay = ey[s] - qy, az = ez[s] - qz;
+            buf[i] = fabs(ax * nrm[0] + ay * nrm[1] + az * nrm[2]);   // |(p_i - c) . n|
+        }
+    }
+    __syncthreads();
+    double reg = 0.0;
+    for (int j = 0; j < cmax; ++j) { const double v = buf[j]; if (j < count) reg += v; }
+    __syncthreads();   // the next fit of this wave rewrites the buffer
+    rec.nx = nrm[0]; rec.ny = nrm[1]; rec.nz = nrm[2]; rec.reg_sum = reg;
+    return rec;   // complete in every lane of the row
+}
+
+// grid: (ceil(maxP / 4), n_frames) workgroups of one wave; one DPP row per scan point
 #ifndef IBA_PLANE_WAVES
 #define IBA_PLANE_WAVES 4
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IBA_PLANE_WAVES, IBA_PLANE_WAVES))) void iba_plane_kernel(DevProblem dp, double r2, int max_pts, PlaneRec* out) {
+template <int SLOTS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IBA_PLANE_WAVES, IBA_PLANE_WAVES))) void iba_plane_kernel(DevProblem dp, double r2, int max_pts, PlaneRec* out) {
+    __shared__ double s_fit[4 * kFitRowDoubles(SLOTS)];
     const FrameHdr& h = dp.frames[blockIdx.y];
-    const uint32_t pos = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (pos >= h.P) return;
-    const PlaneRec rec = plane_fit_wave(dp.xs + h.pt_base, dp.ys + h.pt_base, dp.zs + h.pt_base, dp.nodes + h.node_base, h.P, h.depth, pos, r2, max_pts);
-    if ((threadIdx.x & 63) == 0) out[h.pt_base + pos] = rec;
+    const uint32_t pos = blockIdx.x * 4u + (threadIdx.x >> 4);
+    if (blockIdx.x * 4u >= h.P) return;
+    const PlaneRec rec = plane_fit_rows<SLOTS>(dp.xs + h.pt_base, dp.ys + h.pt_base, dp.zs + h.pt_base, dp.nodes + h.node_base, h.P, h.depth, pos < h.P ? pos : kNone, r2, max_pts, s_fit);
+    if ((threadIdx.x & 15) == 0 && pos < h.P) out[h.pt_base + pos] = rec;
 }
 
 // ---- wave64 sum on the VALU (DPP row shifts + row broadcasts, no LDS traffic); total lands in lane 63 ----

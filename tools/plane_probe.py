@@ -1,0 +1,26 @@
+"""Time of the plane memo (iba_plane_kernel over every scan point) at the bench shape, by re-entering iba_set_params with a
+changed radius; and of plane_cache = 0 evaluations. usage: plane_probe.py [frames] [points]"""
+import importlib, sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd")
+synth = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.synth")
+abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi")
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+prob, meta = synth.make_scene(n_frames=F, pts_per_frame=P, seed=0)
+prm = abi.reference_yaml_params()
+h = pkg.IbaHandle(prob, prm)
+for r, mp in ((0.61, 30), (0.6, 30), (0.61, 30), (0.6, 30), (0.6, 40), (0.6, 30)):
+    prm.norm_radius = r; prm.neigh_radius = r; prm.norm_max_pts = mp; prm.neigh_max_pts = mp
+    t0 = time.perf_counter(); h.set_params(prm); t1 = time.perf_counter()
+    print("set_params(radius %.2f, max_pts %d): %.2f ms (%d fits)" % (r, mp, (t1 - t0) * 1e3, prob.n_points), flush=True)
+xs = synth.perturb(meta["x_gt"], np.random.default_rng(0), n=64)
+ref = h.eval_full(xs)
+prm.plane_cache = 0
+h.set_params(prm)
+for mode, fn in (("full", h.eval_full), ("cost", h.eval_cost)):
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter(); out = fn(xs); ts.append(time.perf_counter() - t0)
+    print("plane_cache=0 %s B=64: %.2f ms per call -> %.0f evals/s" % (mode, np.median(ts[1:]) * 1e3, 64 / np.median(ts[1:])), flush=True)
