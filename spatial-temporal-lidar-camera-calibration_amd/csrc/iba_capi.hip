@@ -86,6 +86,7 @@ struct iba_handle {
     DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
     DevBuf<PlaneRec> plane_cost, plane_local;
+    DevBuf<double4> d_frefit;   // plane_cache = 0: per list entry, query offset + neighbour of the cost path between the search and the fit kernel
     DevBuf<PlaneRec> scratch_cost, scratch_local;   // plane_cache = 0: (scratch_cap + 1) x n_pt_total records
     int scratch_cap = -1; bool scratch_local_aliases = false; int64_t n_pt_total = 0;
     bool plane_local_aliases_cost = false;
@@ -156,7 +157,7 @@ iba_status check_params(iba_handle* h, const iba_params& p) {
         return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist must be in (0, 64] px");
     if (p.norm_max_pts < 1 || p.norm_max_pts > 64 || p.neigh_max_pts < 1 || p.neigh_max_pts > 64)
         return fail(h, IBA_ERR_UNSUPPORTED, "norm_max_pts / neigh_max_pts must be in [1, 64] (the neighbour list lives one entry per lane of a wave)");
-    if (h && !p.plane_cache && h->max_slots > (uint32_t)kMaxCovisRefit)
+    if (h && !h->split && !p.plane_cache && h->max_slots > (uint32_t)kMaxCovisRefit)
         return fail(h, IBA_ERR_UNSUPPORTED, "plane_cache = 0 supports at most 10 covisible keyframes per frame");
     return IBA_OK;
 }
@@ -264,7 +265,7 @@ iba_status compute_plane_cache(iba_handle* h) {
     if (!p.plane_cache) return ensure_scratch(h);   // planes are refitted inside every evaluation, into per-candidate scratch
     const DevProblem dp = h->dev_problem();
     auto run = [&](double r2, int max_pts, PlaneRec* out) -> hipError_t {
-        dim3 grid((h->maxP + 3) / 4, h->n_frames);
+        dim3 grid((h->maxP + 63) / 64, h->n_frames);
         if (h->maxP == 0 || h->n_frames == 0) return hipSuccess;
         if (max_pts <= 32) hipLaunchKernelGGL(iba_plane_kernel<2>, grid, dim3(64), 0, h->stream, dp, r2, max_pts, out);
         else hipLaunchKernelGGL(iba_plane_kernel<4>, grid, dim3(64), 0, h->stream, dp, r2, max_pts, out);
@@ -349,19 +350,22 @@ iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, do
 
 // work lists of B candidates (the lists also carry the residual blocks to the factor kernel)
 iba_status ensure_lists(iba_handle* h, int B, hipStream_t st) {
-    if (h->assoc_cap >= B) return IBA_OK;
+    if (h->assoc_cap >= B && (h->params.plane_cache || h->d_frefit.p)) return IBA_OK;
+    B = std::max(B, h->assoc_cap);
     HIP_TRY(h, hipStreamSynchronize(st)); HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->d_assoc.release(); h->d_flist.release(); h->d_fcount.release(); h->d_lcount.release(); h->d_fmp.release();
-    if (!h->split || !h->params.plane_cache) HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
+    if (!h->split) HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
     HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
     HIP_TRY(h, h->d_fmp.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
     HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
     HIP_TRY(h, h->d_lcount.alloc((size_t)B * std::max(h->n_frames, 1)));
+    h->d_frefit.release();
+    if (!h->params.plane_cache) HIP_TRY(h, h->d_frefit.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
     h->assoc_cap = B;
     return IBA_OK;
 }
 
-bool use_split(const iba_handle* h) { return h->split && h->params.plane_cache != 0; }
+bool use_split(const iba_handle* h) { return h->split; }
 
 // Two-kernel evaluation chain (plane_cache = 1) on stream st: [hand-eye] -> association -> grouped 1-NN -> [factors] -> sums.
 // want: bit 0 = BuildProblem association (+ normal equations when `factors`), bit 1 = BAError cost.
@@ -397,18 +401,43 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     // (Splitting the batch into chunks so that the association kernel of chunk i + 1 runs beside the search kernel of chunk i
     // on a second stream was measured: 0.93 ms -> 0.99 / 1.07 / 1.22 ms for 2 / 4 / 8 chunks. The kernels do not overlap enough
     // to pay for the extra launches and event hops; one launch each it is.)
-    hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (h->assoc_dbg << 8),
+    // plane_cache = 0: the planes are fitted per evaluation, between the kernels that produce the points and those that read
+    // the planes: association -> fit<1> (local planes at the matched points) -> searches -> fit<2> (planes at the neighbours,
+    // cost distances) -> the search kernel again for its fixed-order sums. Slot 0 of the plane scratch belongs to the frozen problem.
+    const bool refit = !h->params.plane_cache;
+    const int slot_base = frozen ? 0 : 1;
+    if (refit && h->scratch_cap < B) return fail(h, IBA_ERR_STATE, "plane scratch not allocated");
+    if (refit && frozen && !h->d_frefit.p) { iba_status es = ensure_lists(h, 1, st); if (es != IBA_OK) return es; }
+    const bool wide_fit = std::max(h->params.norm_max_pts, h->params.neigh_max_pts) > 32;
+    const dim3 fit_grid((h->lstride + 63) / 64, nf, B);
+    hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                        h->d_frame_partials.p, nrec, (uint32_t*)nullptr, h->d_he.p, fl, fm, fc, lc, (int)h->lstride);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_mid, st));
+    if (refit && (want & 1)) {
+        if (wide_fit) hipLaunchKernelGGL((iba_fit_kernel<4, 1>), fit_grid, dim3(64), 0, st, dp, h->dprm, fl, h->d_frefit.p, lc, (int)h->lstride, slot_base, want);
+        else hipLaunchKernelGGL((iba_fit_kernel<2, 1>), fit_grid, dim3(64), 0, st, dp, h->dprm, fl, h->d_frefit.p, lc, (int)h->lstride, slot_base, want);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (search) {
         const dim3 grid(8 * per_xcd * ngroups * NS), block(kNNThreads);
         const NNArgs na{dp, h->dprm, nl};
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
-        if (wA && wC) hipLaunchKernelGGL((iba_nn_kernel<3>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg);
-        else if (wA) hipLaunchKernelGGL((iba_nn_kernel<1>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg);
-        else hipLaunchKernelGGL((iba_nn_kernel<2>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg);
+        auto launch_nn = [&](int mode) {
+            const int dm = h->nn_dbg | (mode << 8);
+            if (wA && wC) hipLaunchKernelGGL((iba_nn_kernel<3>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, dm, h->d_frefit.p);
+            else if (wA) hipLaunchKernelGGL((iba_nn_kernel<1>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, dm, h->d_frefit.p);
+            else hipLaunchKernelGGL((iba_nn_kernel<2>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, dm, h->d_frefit.p);
+        };
+        launch_nn(refit ? kRefitSearch : 0);
         HIP_TRY(h, hipGetLastError());
+        if (refit) {
+            const int w2 = (wA ? 1 : 0) | (wC ? 2 : 0);
+            if (wide_fit) hipLaunchKernelGGL((iba_fit_kernel<4, 2>), fit_grid, dim3(64), 0, st, dp, h->dprm, fl, h->d_frefit.p, lc, (int)h->lstride, slot_base, w2);
+            else hipLaunchKernelGGL((iba_fit_kernel<2, 2>), fit_grid, dim3(64), 0, st, dp, h->dprm, fl, h->d_frefit.p, lc, (int)h->lstride, slot_base, w2);
+            HIP_TRY(h, hipGetLastError());
+            if (wC) { launch_nn(kRefitSums); HIP_TRY(h, hipGetLastError()); }
+        }
     }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
     if (factors) { iba_status s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, nf, st); if (s != IBA_OK) return s; }
@@ -468,7 +497,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -520,7 +549,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         h->max_slots = std::max<uint32_t>(h->max_slots, (uint32_t)ns);
     }
 
-    if (!params->plane_cache && h->max_slots > (uint32_t)kMaxCovisRefit) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "plane_cache = 0 supports at most 10 covisible keyframes per frame"); }
+    h->split = !(std::getenv("IBA_MONOLITHIC") && std::atoi(std::getenv("IBA_MONOLITHIC")) != 0);
+    if (!h->split && !params->plane_cache && h->max_slots > (uint32_t)kMaxCovisRefit) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "plane_cache = 0 supports at most 10 covisible keyframes per frame"); }
 
     // ---- per-frame host build (parallel over frames; reference: omp parallel for at iba_global.cpp:363) ----
     // keypoints are stored in Morton order of their pixel (internal id j -> reference id kp_order[j]): queries that

@@ -352,37 +352,38 @@ __device__ inline PlaneRec plane_fit_wave(const float* __restrict__ xs, const fl
     return rec;
 }
 
-// ---- FOUR plane fits per wave: one DPP row (16 lanes) per fit ----
-// Same result, entry for entry, as plane_fit_wave. The sorted neighbour list of a row lives SLOTS entries per lane (entry
-// i = SLOTS * lane + slot; SLOTS = 2 serves max_pts <= 32, SLOTS = 4 up to 64). The traversal state is per row. A leaf is
-// tested 16 points per row and pass; candidate L of every row is broadcast with row_newbcast:L and inserted IN PLACE: an
-// entry that is > the candidate takes its left neighbour's value (row_shr:1 across lanes) or the candidate itself — no
-// insertion index, no ballot. A candidate that does not qualify is inserted as +inf, which moves nothing; the pruning bound
-// (the max_pts-th entry) is refreshed once per pass, which is safe: a candidate admitted under a stale bound sorts behind
-// max_pts entries and is never looked at. Covariance and regularity sums run in list order (ComputeCovariance,
-// pointcloud.h:126-158) as nine serial chains, one per lane, over moments transposed through LDS.
-// All 64 lanes must be active; one wave per workgroup (the __syncthreads below order the wave's own LDS traffic).
+// ---- plane fits, 64 per wave, in two phases ----
+// Phase 1 (fit_list_rows): the sorted neighbour lists, FOUR at a time, one DPP row (16 lanes) per list. The list of a row
+// lives SLOTS entries per lane (entry i = SLOTS * lane + slot; SLOTS = 2 serves max_pts <= 32, SLOTS = 4 up to 64). The
+// traversal state is per row. A leaf is tested 16 points per row and pass; candidate L of every row is broadcast with
+// row_newbcast:L and inserted IN PLACE: new[i] = min(old[i], max(old[i - 1], candidate)) (row_shr:1 brings old[i - 1] across
+// lanes) — no insertion index, no ballot. A candidate that does not qualify is inserted as +inf, which moves nothing; the
+// pruning bound (the max_pts-th entry) is refreshed once per pass, which is safe: a candidate admitted under a stale bound
+// sorts behind max_pts entries and is never looked at. Same list, entry for entry, as plane_fit_wave (equal distances keep
+// their visiting order, as nanoflann's KNNResultSet does).
+// Phase 2 (fit_finish_lane): ONE LANE PER FIT. Covariance in list order (ComputeCovariance, pointcloud.h:126-158), the
+// closed-form eigenvector and the regularity sum are serial per fit anyway; with a lane each nothing is computed 16 times.
+// All 64 lanes must be active; one wave per workgroup (the __syncthreads order the wave's own LDS traffic).
 template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double old, double v) {
-    const long long b = __double_as_longlong(v), o = __double_as_longlong(old);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+__device__ __forceinline__ double dpp_f64(double v) {   // lanes without a source lane read 0
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 constexpr int kDppRowShr1 = 0x111, kDppRowBcast0 = 0x150;   // row_shr:1; row_newbcast:0 (+L: lane L of each row to the row)
 
 template <int L, int SLOTS>
-__device__ __forceinline__ void fit_insert(double d2, uint32_t base, double bound, double (&ed)[SLOTS], uint32_t (&ep)[SLOTS]) {
-    const double c0 = dpp_f64<kDppRowBcast0 + L>(0.0, d2);
-    const double cd = c0 < bound ? c0 : INFINITY;
+__device__ __forceinline__ void fit_insert(double d2q, uint32_t base, double (&ed)[SLOTS], uint32_t (&ep)[SLOTS]) {
+    const double cd = dpp_f64<kDppRowBcast0 + L>(d2q);
     const uint32_t cp = base + (uint32_t)L;
-    const double pd = dpp_f64<kDppRowShr1>(-INFINITY, ed[SLOTS - 1]);
-    const uint32_t pp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ep[SLOTS - 1], kDppRowShr1, 0xf, 0xf, false);
+    const double pd = dpp_f64<kDppRowShr1>(ed[SLOTS - 1]);   // lane 0 of a row: 0 <= any squared distance, so entry 0 takes the candidate itself
+    const uint32_t pp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ep[SLOTS - 1], kDppRowShr1, 0xf, 0xf, true);
     double nd[SLOTS]; uint32_t np[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const double prevd = s ? ed[s ? s - 1 : 0] : pd; const uint32_t prevp = s ? ep[s ? s - 1 : 0] : pp;
-        const bool keep = ed[s] <= cd, pk = prevd <= cd;   // equal distances: the earlier visit stays in front (nanoflann's KNNResultSet)
+        const bool keep = ed[s] <= cd, pk = prevd <= cd;   // equal distances: the earlier visit stays in front
         nd[s] = keep ? ed[s] : (pk ? cd : prevd);
         np[s] = keep ? ep[s] : (pk ? cp : prevp);
     }
@@ -390,17 +391,21 @@ __device__ __forceinline__ void fit_insert(double d2, uint32_t base, double boun
     for (int s = 0; s < SLOTS; ++s) { ed[s] = nd[s]; ep[s] = np[s]; }
 }
 
-constexpr int kFitRowDoubles(int slots) { return 16 * slots * 9 + 1; }   // LDS doubles per row: nine moments per list entry, + the farthest kept distance
+constexpr int kFitListStride(int slots) { return 16 * slots + 1; }   // words per list in LDS (odd: lane-per-fit reads are conflict-free)
+template <int SLOTS> struct FitLds {
+    uint32_t list[64][kFitListStride(SLOTS)];   // tree positions of the kept neighbours, nearest first
+    double far_d2[64];
+    int32_t count[64];
+};
 
+// lists of the four scan points `cpos` (one per row; kNone: idle row) -> lds.list[fit], count[fit], far_d2[fit]; fit = fit0 + row
 template <int SLOTS>
-__device__ inline PlaneRec plane_fit_rows(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
-                                          const TreeNode* __restrict__ nodes, uint32_t P, uint32_t D, uint32_t cpos /* of this lane's row; kNone: idle row */,
-                                          double r2, int max_pts, double* __restrict__ s_wave /* [4][kFitRowDoubles(SLOTS)] */) {
+__device__ __forceinline__ void fit_list_rows(const float4* __restrict__ p4, const TreeNode* __restrict__ nodes, uint32_t P, uint32_t D, uint32_t cpos, double r2, int max_pts,
+                                     FitLds<SLOTS>& lds, int fit0) {
     const int lane = threadIdx.x & 63, gl = lane & 15, row_sh = lane & 48;
-    double* buf = s_wave + (lane >> 4) * kFitRowDoubles(SLOTS);
     const bool act = cpos != kNone;
     double qx = 0, qy = 0, qz = 0;
-    if (act) { qx = (double)xs[cpos]; qy = (double)ys[cpos]; qz = (double)zs[cpos]; }
+    if (act) { const float4 c = p4[cpos]; qx = (double)c.x; qy = (double)c.y; qz = (double)c.z; }
     double ed[SLOTS]; uint32_t ep[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) { ed[s] = INFINITY; ep[s] = kNone; }
@@ -425,13 +430,16 @@ __device__ inline PlaneRec plane_fit_rows(const float* __restrict__ xs, const fl
             const uint32_t i = base + (uint32_t)gl;
             double d2 = INFINITY;
             if (i < hi) {
-                const double dx = qx - (double)xs[i], dy = qy - (double)ys[i], dz = qz - (double)zs[i];
+                const float4 v = p4[i];
+                const double dx = qx - (double)v.x, dy = qy - (double)v.y, dz = qz - (double)v.z;
                 d2 = (dx * dx + dy * dy) + dz * dz;
             }
-            const unsigned long long m = __ballot(d2 < bound);
+            const bool qual = d2 < bound;
+            const unsigned long long m = __ballot(qual);
             if (m == 0ull) continue;
+            const double d2q = qual ? d2 : INFINITY;
             const uint32_t m16 = (uint32_t)(m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffu;   // lanes-of-a-row with a candidate in ANY row
-#define IBA_FIT_STEP(L) if (m16 & (1u << L)) fit_insert<L, SLOTS>(d2, base, bound, ed, ep);
+#define IBA_FIT_STEP(L) if (m16 & (1u << L)) fit_insert<L, SLOTS>(d2q, base, ed, ep);
             IBA_FIT_STEP(0) IBA_FIT_STEP(1) IBA_FIT_STEP(2) IBA_FIT_STEP(3) IBA_FIT_STEP(4) IBA_FIT_STEP(5) IBA_FIT_STEP(6) IBA_FIT_STEP(7)
             IBA_FIT_STEP(8) IBA_FIT_STEP(9) IBA_FIT_STEP(10) IBA_FIT_STEP(11) IBA_FIT_STEP(12) IBA_FIT_STEP(13) IBA_FIT_STEP(14) IBA_FIT_STEP(15)
 #undef IBA_FIT_STEP
@@ -462,68 +470,68 @@ __device__ inline PlaneRec plane_fit_rows(const float* __restrict__ xs, const fl
         const unsigned long long m = __ballot(SLOTS * gl + s < max_pts && ed[s] < INFINITY);
         count += __popc((uint32_t)(m >> row_sh) & 0xffffu);
     }
-    const int cmax = max(max(__builtin_amdgcn_readlane(count, 0), __builtin_amdgcn_readlane(count, 16)), max(__builtin_amdgcn_readlane(count, 32), __builtin_amdgcn_readlane(count, 48)));
-    PlaneRec rec;
-    rec.k = count; rec.pad = 0;
-    double ex[SLOTS], ey[SLOTS], ez[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int i = SLOTS * gl + s;
-        ex[s] = ey[s] = ez[s] = 0.0;
-        if (i < count) {
-            const uint32_t p = ep[s];
-            const double x = (double)xs[p], y = (double)ys[p], z = (double)zs[p];
-            ex[s] = x; ey[s] = y; ez[s] = z;
-            double* o = buf + i * 9;
-            o[0] = x; o[1] = y; o[2] = z; o[3] = x * x; o[4] = x * y; o[5] = x * z; o[6] = y * y; o[7] = y * z; o[8] = z * z;
-            if (i == count - 1) buf[16 * SLOTS * 9] = ed[s];
-        }
-    }
-    __syncthreads();
-    rec.far_d2 = count > 0 ? buf[16 * SLOTS * 9] : 0.0;
-    double c = 0.0;   // lane q < 9 of the row: moment q summed in list order
-    {
-        const double* src = buf + (gl < 9 ? gl : 0);
-        for (int j = 0; j < cmax; ++j) { const double v = src[j * 9]; if (j < count) c += v; }
-    }
-    c /= (double)count;
-    double cq[9];
-    cq[0] = dpp_f64<kDppRowBcast0 + 0>(0.0, c); cq[1] = dpp_f64<kDppRowBcast0 + 1>(0.0, c); cq[2] = dpp_f64<kDppRowBcast0 + 2>(0.0, c);
-    cq[3] = dpp_f64<kDppRowBcast0 + 3>(0.0, c); cq[4] = dpp_f64<kDppRowBcast0 + 4>(0.0, c); cq[5] = dpp_f64<kDppRowBcast0 + 5>(0.0, c);
-    cq[6] = dpp_f64<kDppRowBcast0 + 6>(0.0, c); cq[7] = dpp_f64<kDppRowBcast0 + 7>(0.0, c); cq[8] = dpp_f64<kDppRowBcast0 + 8>(0.0, c);
-    double cov[9];
-    cov[0] = cq[3] - cq[0] * cq[0]; cov[4] = cq[6] - cq[1] * cq[1]; cov[8] = cq[8] - cq[2] * cq[2];
-    cov[1] = cov[3] = cq[4] - cq[0] * cq[1]; cov[2] = cov[6] = cq[5] - cq[0] * cq[2]; cov[5] = cov[7] = cq[7] - cq[1] * cq[2];
-    double nrm[3]; dev_smallest_evec(cov, nrm);
-    __syncthreads();   // the moments have been read: the buffer now takes the regularity terms
+    const int fit = fit0 + (lane >> 4);
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int i = SLOTS * gl + s;
         if (i < count) {
-            const double ax = ex[s] - qx, ay = ey[s] - qy, az = ez[s] - qz;
-            buf[i] = fabs(ax * nrm[0] + ay * nrm[1] + az * nrm[2]);   // |(p_i - c) . n|
+            lds.list[fit][i] = ep[s];
+            if (i == count - 1) lds.far_d2[fit] = ed[s];
         }
     }
-    __syncthreads();
-    double reg = 0.0;
-    for (int j = 0; j < cmax; ++j) { const double v = buf[j]; if (j < count) reg += v; }
-    __syncthreads();   // the next fit of this wave rewrites the buffer
-    rec.nx = nrm[0]; rec.ny = nrm[1]; rec.nz = nrm[2]; rec.reg_sum = reg;
-    return rec;   // complete in every lane of the row
+    if (gl == 0) lds.count[fit] = count;
 }
 
-// grid: (ceil(maxP / 4), n_frames) workgroups of one wave; one DPP row per scan point
+// the plane of one fit from its neighbour list (this lane's own fit; any subset of lanes)
+__device__ __forceinline__ PlaneRec fit_finish_lane(const float4* __restrict__ p4, uint32_t cpos, const uint32_t* list, int count, double far_d2) {
+    PlaneRec rec;
+    rec.k = count; rec.pad = 0;
+    rec.far_d2 = count > 0 ? far_d2 : 0.0;
+    const float4 cq = p4[cpos];
+    const double qx = (double)cq.x, qy = (double)cq.y, qz = (double)cq.z;
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < count; ++j) {
+        const float4 v = p4[list[j]];
+        const double x = (double)v.x, y = (double)v.y, z = (double)v.z;
+        c[0] += x; c[1] += y; c[2] += z;
+        c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+    }
+    const double inv_n = (double)count;
+    for (int i = 0; i < 9; ++i) c[i] /= inv_n;
+    double cov[9];
+    cov[0] = c[3] - c[0] * c[0]; cov[4] = c[6] - c[1] * c[1]; cov[8] = c[8] - c[2] * c[2];
+    cov[1] = cov[3] = c[4] - c[0] * c[1]; cov[2] = cov[6] = c[5] - c[0] * c[2]; cov[5] = cov[7] = c[7] - c[1] * c[2];
+    double nrm[3]; dev_smallest_evec(cov, nrm);
+    double reg = 0.0;
+    for (int j = 0; j < count; ++j) {
+        const float4 v = p4[list[j]];
+        const double ax = (double)v.x - qx, ay = (double)v.y - qy, az = (double)v.z - qz;
+        reg += fabs(ax * nrm[0] + ay * nrm[1] + az * nrm[2]);   // |(p_j - c) . n|
+    }
+    rec.nx = nrm[0]; rec.ny = nrm[1]; rec.nz = nrm[2]; rec.reg_sum = reg;
+    return rec;
+}
+
+// grid: (ceil(maxP / 64), n_frames) workgroups of one wave: 64 consecutive scan points (tree order)
 #ifndef IBA_PLANE_WAVES
 #define IBA_PLANE_WAVES 4
 #endif
 template <int SLOTS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IBA_PLANE_WAVES, IBA_PLANE_WAVES))) void iba_plane_kernel(DevProblem dp, double r2, int max_pts, PlaneRec* out) {
-    __shared__ double s_fit[4 * kFitRowDoubles(SLOTS)];
+__global__ __launch_bounds__(64) void iba_plane_kernel(DevProblem dp, double r2, int max_pts, PlaneRec* out) {
+    __shared__ FitLds<SLOTS> s_fit;
     const FrameHdr& h = dp.frames[blockIdx.y];
-    const uint32_t pos = blockIdx.x * 4u + (threadIdx.x >> 4);
-    if (blockIdx.x * 4u >= h.P) return;
-    const PlaneRec rec = plane_fit_rows<SLOTS>(dp.xs + h.pt_base, dp.ys + h.pt_base, dp.zs + h.pt_base, dp.nodes + h.node_base, h.P, h.depth, pos < h.P ? pos : kNone, r2, max_pts, s_fit);
-    if ((threadIdx.x & 15) == 0 && pos < h.P) out[h.pt_base + pos] = rec;
+    const uint32_t pos0 = blockIdx.x * 64u;
+    if (pos0 >= h.P) return;
+    const float4* p4 = dp.pts4 + h.pt_base;
+    const int lane = threadIdx.x;
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t pos = pos0 + 4u * (uint32_t)r + (uint32_t)(lane >> 4);
+        if (pos0 + 4u * (uint32_t)r >= h.P) break;
+        fit_list_rows<SLOTS>(p4, dp.nodes + h.node_base, h.P, h.depth, pos < h.P ? pos : kNone, r2, max_pts, s_fit, 4 * r);
+    }
+    __syncthreads();
+    const uint32_t pos = pos0 + (uint32_t)lane;
+    if (pos < h.P) out[h.pt_base + pos] = fit_finish_lane(p4, pos, s_fit.list[lane], s_fit.count[lane], s_fit.far_d2[lane]);
 }
 
 // ---- wave64 sum on the VALU (DPP row shifts + row broadcasts, no LDS traffic); total lands in lane 63 ----

@@ -53,10 +53,28 @@ struct NNArgs { DevProblem dp; DevParams prm; NNLayout lay; };
 
 // list entry flags (uint4.w) written by iba_assoc_kernel
 constexpr uint32_t kFlagC = 1u;   // cost-path 1-NN wanted (keypoint owns a MapPoint, frame counts for BAError, 3d-3d enabled)
+constexpr int kRefitSearch = 1, kRefitSums = 2;
 constexpr uint32_t kFlagA = 2u;   // association-path 1-NN wanted (ComputeLocalNeighbor at the matched point is valid)
 
 // ------------------------------------------------------------------------------------------------------------------
-// iba_assoc_kernel. want: bit 0 = BuildProblem association wanted, bit 1 = BAError cost wanted. corr_out != nullptr: dump
+// the gates on a local-plane record, shared by the memoised and the refit paths
+template <class PRM> __device__ __forceinline__ bool local_neigh_ok(const PRM& prm, const PlaneRec& rec) { return !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2); }
+template <class PRM> __device__ __forceinline__ bool local_plane_ok(const PRM& prm, const PlaneRec& rec) { return rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold; }
+// point-to-plane / point-to-point distance of the 3d-3d cost term (iba_global.cpp:111-156, 241-249) for e = neighbour - query;
+// rec: the plane at the neighbour (nullptr when use_plane is off). dist >= 0: the sign bit carries the kind (set: point-to-point)
+template <class PRM> __device__ __forceinline__ double cost_res(const PRM& prm, const PlaneRec* rec, double ex, double ey, double ez) {
+    double dist = sqrt((ex * ex + ey * ey) + ez * ez);
+    bool is_plane = false;
+    if (rec) {
+        if (!(rec->far_d2 < prm.min_diff_dist2) && !(rec->k < prm.norm_min_pts) && !(rec->reg_sum / (double)(rec->k - 1) > prm.norm_reg_threshold)) {
+            dist = fabs(ex * rec->nx + ey * rec->ny + ez * rec->nz);
+            is_plane = true;
+        }
+    }
+    return is_plane ? dist : -dist;
+}
+
+// iba_assoc_kernel. want: bit 0 = BuildProblem association wanted, bit 1 = BAError cost wanted, bit 2 = planes are refitted (plane_cache = 0). corr_out != nullptr: dump
 // the correspondences and return (iba_get_correspondences).
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads; block i runs on XCD i%8, so all candidates of a frame share an L2.
 // ------------------------------------------------------------------------------------------------------------------
@@ -123,6 +141,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     __syncthreads();
 
     const int dbg = want >> 8;   // diagnostic: cut the kernel short after a phase (timing attribution; results are garbage)
+    const bool refit = (want & 4) != 0;   // plane_cache = 0: the local planes are fitted after this kernel (iba_fit_kernel<.., 1>), which then settles .y and kFlagA
     if (dbg == 1) return;
     FrameCtx c;
     c.xs = gxs; c.ys = gys; c.zs = gzs;
@@ -418,10 +437,13 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
         uint32_t ax_ = kNone, flags = 0u;
         if (usedA && ((e >> 16) & 3u) == 3u) {
             const uint32_t pos = s_pos[i];
-            const PlaneRec rec = planes_local[pos];
-            const bool neigh_ok = !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2);   // pointcloud.h:752
-            if (neigh_ok && rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold) ax_ = pos;   // bvalid_plane (:231)
-            if (neigh_ok) flags |= kFlagA;   // no 3d-3d block either otherwise (the `continue` at :209-211)
+            if (refit) { ax_ = pos; flags |= kFlagA; }
+            else {
+                const PlaneRec rec = planes_local[pos];
+                const bool neigh_ok = local_neigh_ok(prm, rec);                     // pointcloud.h:752
+                if (neigh_ok && local_plane_ok(prm, rec)) ax_ = pos;               // bvalid_plane (:231)
+                if (neigh_ok) flags |= kFlagA;   // no 3d-3d block either otherwise (the `continue` at :209-211)
+            }
         }
         if (usedC && prm.use_3d3d && ((e >> 16) & 1u)) flags |= kFlagC;
         fl[i] = make_uint4(k, ax_, kNone, flags);   // .z (the 3d-3d block) is filled in by iba_nn_kernel
@@ -515,8 +537,12 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 template <int WHICH>
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_NN_WAVES, IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
                                                                                                   double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist, const float4* __restrict__ fmp,
-                                                                                                  const uint32_t* __restrict__ lcount, int flist_stride, int dbg) {
+                                                                                                  const uint32_t* __restrict__ lcount, int flist_stride, int dbg_mode, double4* __restrict__ frefit) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const int dbg = dbg_mode & 0xff;
+    // plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch = the searches only (neighbour and query
+    // offset of every entry -> flist.z / frefit), kRefitSums = the fixed-order sums over the distances the fit kernel left in frefit
+    const int refit = dbg_mode >> 8;
     typedef __attribute__((address_space(4))) const NNArgs NNArgsC;
     NNArgsC* ka = (NNArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)ka_by_value;
@@ -575,12 +601,19 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
     {
         const uint32_t c0 = 0u, c1 = W;
         if (tid == 0) *s_ctr = c0;
-        if (WHICH & 2) for (uint32_t i = tid; i < c1 - c0; i += T) s_res[i] = NAN;   // entries that turn out to want no cost search
+        if (WHICH & 2) for (uint32_t i = tid; i < c1 - c0; i += T) {
+            double r = NAN;   // entries that turn out to want no cost search
+            if (refit == kRefitSums) {
+                const uint32_t cc = i & ((1u << cg_shift) - 1u), il = i_lo + (i >> cg_shift);
+                if (il < s_n[cc]) r = frefit[((size_t)(g * CG + (int)cc) * nf + f) * (size_t)flist_stride + il].x;
+            }
+            s_res[i] = r;
+        }
         __syncthreads();
         if (dbg == 2) return;
 
         // ---- the searches: persistent lanes, refilled from the work list ----
-        {
+        if (refit != kRefitSums) {
             bool have = false;
             uint32_t w = 0u, wi_list = 0u, b_own = 0u, kk = 0u;
             bool actA = false, actC = false;
@@ -764,29 +797,20 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                 if (have && go < 0) {
                     // ---- the finished searches of this entry ----
                     if (dbg != 5) {
+                    const size_t at = ((size_t)b_own * nf + f) * (size_t)flist_stride + wi_list;
                     if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2)) {   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
-                        const PlaneRec r2 = planes_local[bposA];
-                        const bool state = !(r2.k < prm.neigh_min_pts || r2.far_d2 < prm.local_min_diff_dist2) &&
-                                           (r2.reg_sum / (double)(r2.k - 1) < prm.local_norm_reg_threshold);   // pointcloud.h:699-717
-                        flist[((size_t)b_own * nf + f) * (size_t)flist_stride + wi_list].z = bposA | (state ? 0x80000000u : 0u);
+                        bool state = false;   // refit: settled by the fit kernel
+                        if (!refit) { const PlaneRec r2 = planes_local[bposA]; state = local_neigh_ok(prm, r2) && local_plane_ok(prm, r2); }   // pointcloud.h:699-717
+                        flist[at].z = bposA | (state ? 0x80000000u : 0u);
                     }
                     double res = NAN;
-                    if ((WHICH & 2) && actC) {   // point-to-plane / point-to-point distance (iba_global.cpp:111-156, 241-249)
+                    if ((WHICH & 2) && actC) {
                         const float4 pv = p4[bposC];
                         const double ex = (double)pv.x - qx, ey = (double)pv.y - qy, ez = (double)pv.z - qz;
-                        double dist = sqrt((ex * ex + ey * ey) + ez * ez);
-                        bool is_plane = false;
-                        if (prm.use_plane) {
-                            const PlaneRec rec = planes_cost[bposC];
-                            if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) &&
-                                !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
-                                dist = fabs(ex * rec.nx + ey * rec.ny + ez * rec.nz);
-                                is_plane = true;
-                            }
-                        }
-                        res = is_plane ? dist : -dist;   // dist >= 0: the sign bit carries the kind (also for a zero distance)
+                        if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
+                        else res = cost_res(prm, prm.use_plane ? planes_cost + bposC : nullptr, ex, ey, ez);
                     }
-                    if (WHICH & 2) s_res[w - c0] = res;
+                    if ((WHICH & 2) && !refit) s_res[w - c0] = res;
                     }
                     have = false;
                 }
@@ -834,6 +858,100 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
 #undef lay
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// iba_fit_kernel<SLOTS, STAGE> (plane_cache = 0): the planes one evaluation needs, fitted for exactly that evaluation as the
+// reference does (ComputeLocalNeighbor / ComputeLocalNormalSingleThre, pointcloud.h:699-760; ComputeAlignmentDist,
+// iba_global.cpp:125-153), and the decisions that hang on them.
+//   STAGE 1 (after iba_assoc_kernel): local plane at the matched scan point of every association entry -> .y (the plane
+//            factor's point, or none) and kFlagA (no neighbourhood: no residual block at all) of the entry.
+//   STAGE 2 (after the searches): local plane at the association path's neighbour -> kind bit of .z; cost plane at the cost
+//            path's neighbour -> the entry's cost distance into frefit[..].x (NaN: no cost term), which the search kernel's
+//            second launch sums. When both planes use the same radius and size and the neighbour is the same point, it is
+//            one fit.
+// Plane records a residual block will read (iba_factor_kernel, iba_residual_kernel) go to the candidate's private scratch
+// slot. grid: (ceil(list stride / 64), frames, B) workgroups of one wave: 64 consecutive list entries; fits are packed four
+// to a round (fit_list_rows), then finished one per lane (fit_finish_lane).
+// ------------------------------------------------------------------------------------------------------------------
+template <int SLOTS, int STAGE>
+__global__ __launch_bounds__(64) void iba_fit_kernel(DevProblem dp, DevParams prm, uint4* __restrict__ flist, double4* __restrict__ frefit, const uint32_t* __restrict__ lcount,
+                                                     int flist_stride, int slot_base, int want) {
+    __shared__ FitLds<SLOTS> s_fit;
+    __shared__ uint32_t s_job[64];
+    const int nf = dp.n_frames, f = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const uint32_t n = lcount[(size_t)b * nf + f];
+    if (blockIdx.x * 64u >= n) return;
+    const FrameHdr& h = dp.frames[f];
+    const uint32_t i = blockIdx.x * 64u + (uint32_t)lane;
+    const size_t at = ((size_t)b * nf + f) * (size_t)flist_stride + i;
+    const float4* p4 = dp.pts4 + h.pt_base;
+    const TreeNode* nodes = dp.nodes + h.node_base;
+    PlaneRec* scratch = dp.scratch_local + (size_t)(slot_base + b) * (size_t)dp.n_pt_total + h.pt_base;
+    const bool live = i < n;
+    uint4 e = make_uint4(0u, kNone, kNone, 0u);
+    if (live) e = flist[at];
+    const double r2l = prm.neigh_radius2, r2c = prm.norm_radius2;
+    const bool same = (r2l == r2c && prm.neigh_max_pts == prm.norm_max_pts);
+    bool needA, needC = false; uint32_t posA, posC = kNone;
+    double ex = 0, ey = 0, ez = 0;
+    if (STAGE == 1) { needA = live && (e.w & kFlagA) && e.y != kNone; posA = e.y; }
+    else {
+        needA = live && (want & 1) && (e.w & kFlagA) && e.z != kNone; posA = e.z;
+        if (live && (want & 2) && (e.w & kFlagC)) {
+            const double4 q = frefit[at];
+            ex = q.x; ey = q.y; ez = q.z; posC = (uint32_t)__double_as_longlong(q.w);
+            needC = prm.use_plane != 0;
+        }
+    }
+    // pass 0: local-plane parameters; pass 1: cost-plane parameters, for the cost planes pass 0 did not produce
+    PlaneRec rec0, rec1;
+    rec0.k = 0; rec1.k = 0;
+    for (int pass = 0; pass < (STAGE == 1 ? 1 : 2); ++pass) {
+        const bool need = pass == 0 ? (needA || (same && needC)) : (needC && !(same && (!needA || posA == posC)));
+        const uint32_t pos = pass == 0 ? (needA ? posA : posC) : posC;
+        const unsigned long long nm = __ballot(need);
+        if (nm == 0ull) continue;
+        const int c = __popcll(nm & ((1ull << lane) - 1ull)), njobs = __popcll(nm);
+        if (need) s_job[c] = pos;
+        __syncthreads();
+        const double r2 = pass == 0 ? r2l : r2c; const int max_pts = pass == 0 ? prm.neigh_max_pts : prm.norm_max_pts;
+        for (int r = 0; 4 * r < njobs; ++r) {
+            const int j = 4 * r + (lane >> 4);
+            fit_list_rows<SLOTS>(p4, nodes, h.P, h.depth, j < njobs ? s_job[j] : kNone, r2, max_pts, s_fit, 4 * r);
+        }
+        __syncthreads();
+        if (need) {
+            const PlaneRec rec = fit_finish_lane(p4, pos, s_fit.list[c], s_fit.count[c], s_fit.far_d2[c]);
+            if (pass == 0) rec0 = rec; else rec1 = rec;
+        }
+        __syncthreads();   // the lists are rewritten by the next pass
+    }
+    if (!live) return;
+    if (STAGE == 1) {
+        if (needA) {
+            const bool neigh_ok = local_neigh_ok(prm, rec0);                           // pointcloud.h:752
+            const bool plane_ok = neigh_ok && local_plane_ok(prm, rec0);              // bvalid_plane (iba_local.cpp:231)
+            e.y = plane_ok ? posA : kNone;
+            if (!neigh_ok) e.w &= ~kFlagA;   // no 3d-3d block either (the `continue` at iba_local.cpp:209-211)
+            flist[at] = e;
+            if (plane_ok) scratch[posA] = rec0;
+        }
+    } else {
+        if (needA) {
+            const bool state = local_neigh_ok(prm, rec0) && local_plane_ok(prm, rec0);   // pointcloud.h:699-717
+            flist[at].z = posA | (state ? 0x80000000u : 0u);
+            if (state) scratch[posA] = rec0;
+        }
+        if (want & 2) {
+            double res = NAN;
+            if (e.w & kFlagC) {
+                const PlaneRec* rc = !needC ? nullptr : ((same && (!needA || posA == posC)) ? &rec0 : &rec1);
+                res = cost_res(prm, rc, ex, ey, ez);
+            }
+            frefit[at].x = res;
+        }
+    }
+}
 
 // sums the per-frame records of each candidate in a fixed order, plus the search kernel's own (narrow) records.
 // grid: B blocks of kReduceThreads threads: 16 record groups x 64 slots for the wide records; 128 record lanes x 8 slots

@@ -15,6 +15,8 @@ for r, mp in ((0.61, 30), (0.6, 30), (0.61, 30), (0.6, 30), (0.6, 40), (0.6, 30)
     prm.norm_radius = r; prm.neigh_radius = r; prm.norm_max_pts = mp; prm.neigh_max_pts = mp
     t0 = time.perf_counter(); h.set_params(prm); t1 = time.perf_counter()
     print("set_params(radius %.2f, max_pts %d): %.2f ms (%d fits)" % (r, mp, (t1 - t0) * 1e3, prob.n_points), flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "memo":
+    sys.exit(0)
 xs = synth.perturb(meta["x_gt"], np.random.default_rng(0), n=64)
 ref = h.eval_full(xs)
 prm.plane_cache = 0
