@@ -371,6 +371,9 @@ __device__ __forceinline__ double dpp_f64(double v) {   // lanes without a sourc
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// v_min_f64 / v_max_f64 on values known not to be NaN (fmin / fmax would first canonicalise what came through a DPP move)
+__device__ __forceinline__ double f64_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double f64_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 constexpr int kDppRowShr1 = 0x111, kDppRowBcast0 = 0x150;   // row_shr:1; row_newbcast:0 (+L: lane L of each row to the row)
 
 template <int L, int SLOTS>
@@ -384,13 +387,14 @@ __device__ __forceinline__ void fit_insert(double d2q, uint32_t base, double (&e
     for (int s = 0; s < SLOTS; ++s) {
         const double prevd = s ? ed[s ? s - 1 : 0] : pd; const uint32_t prevp = s ? ep[s ? s - 1 : 0] : pp;
         const bool keep = ed[s] <= cd, pk = prevd <= cd;   // equal distances: the earlier visit stays in front
-        nd[s] = keep ? ed[s] : (pk ? cd : prevd);
+        nd[s] = f64_min(ed[s], f64_max(prevd, cd));        // = keep ? ed[s] : (pk ? cd : prevd) for a sorted list
         np[s] = keep ? ep[s] : (pk ? cp : prevp);
     }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) { ed[s] = nd[s]; ep[s] = np[s]; }
 }
 
+constexpr int kFitPathMax = 12;   // >= the builder's depth cap (kMaxTreeDepth = 11)
 constexpr int kFitListStride(int slots) { return 16 * slots + 1; }   // words per list in LDS (odd: lane-per-fit reads are conflict-free)
 template <int SLOTS> struct FitLds {
     uint32_t list[64][kFitListStride(SLOTS)];   // tree positions of the kept neighbours, nearest first
@@ -410,19 +414,44 @@ __device__ __forceinline__ void fit_list_rows(const float4* __restrict__ p4, con
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) { ed[s] = INFINITY; ep[s] = kNone; }
     double bound = r2;
-    uint32_t node = 0, depth = 0;
     const uint32_t first_leaf = (1u << D) - 1u;
     const int kth_lane = row_sh + (max_pts - 1) / SLOTS, kth_slot = (max_pts - 1) % SLOTS;
-    bool running = act;
-    while (__ballot(running) != 0ull) {
+    // Traversal state of the row: the current root-to-leaf path. pl[L] = a float LOWER bound of the squared distance from the
+    // query to the splitting plane of level L, side bit L = the child taken there, done bit L = its other child needs no
+    // visit any more. Backtracking picks the deepest level whose far side may still hold a point below the pruning bound —
+    // compares on registers, no node is re-read on the way up. (A lower bound can only add a leaf none of whose points
+    // qualifies; the leaves are still visited in the exact order, so equal distances keep theirs.)
+    float pl[kFitPathMax];
+#pragma unroll
+    for (int L = 0; L < kFitPathMax; ++L) pl[L] = INFINITY;
+    uint32_t side = 0u, done = 0u, node = 0u;
+    int go = act ? 0 : -1;   // level to (re)start the descent at; -1: the row has finished
+    while (__ballot(go >= 0) != 0ull) {
         uint32_t lo = 0, hi = 0;
-        if (running) {
-            while (depth < D) {
-                const TreeNode n = nodes[node];
-                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
-                node = 2u * node + 1u + ((qd - (double)n.split) >= 0.0 ? 1u : 0u);
-                ++depth;
+        if (go >= 0) {
+            uint32_t n1 = 1u;   // heap index + 1 of the node the descent continues from
+            if (go > 0) {       // enter the far child of the ancestor at level go - 1
+                const int t = go - 1;
+                const uint32_t anc1 = (node + 1u) >> (D - (uint32_t)t);
+                done |= 1u << t; side ^= 1u << t;
+                n1 = (anc1 << 1) | ((side >> t) & 1u);
+                const uint32_t keep = (1u << go) - 1u;
+                side &= keep; done &= keep;
             }
+#pragma unroll
+            for (int L = 0; L < kFitPathMax; ++L) {
+                if (L >= (int)D) break;
+                if (L >= go) {
+                    const TreeNode n = nodes[n1 - 1u];
+                    const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
+                    const double diff = qd - (double)n.split;
+                    const uint32_t r = diff >= 0.0 ? 1u : 0u;
+                    pl[L] = (float)(diff * diff) * 0.9999998f;
+                    side |= r << L;
+                    n1 = (n1 << 1) | r;
+                }
+            }
+            node = n1 - 1u;
             const uint32_t j = node - first_leaf;
             lo = (uint32_t)(((uint64_t)j * P) >> D); hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
         }
@@ -448,19 +477,14 @@ __device__ __forceinline__ void fit_list_rows(const float4* __restrict__ p4, con
             for (int s = 1; s < SLOTS; ++s) kv = kth_slot == s ? ed[s] : kv;
             bound = fmin(r2, __shfl(kv, kth_lane));
         }
-        if (running) {
-            bool go = false;
-            while (depth > 0) {
-                const uint32_t parent = (node - 1u) >> 1;
-                const bool was_right = (node & 1u) == 0u;
-                const TreeNode n = nodes[parent];
-                const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
-                const double diff = qd - (double)n.split;
-                const bool near_right = diff >= 0.0;
-                if (was_right == near_right && diff * diff < bound) { node = 2u * parent + 1u + (near_right ? 0u : 1u); go = true; break; }
-                node = parent; --depth;
-            }
-            running = go;
+        if (go >= 0) {
+            const float bf = (float)bound * 1.0000002f;   // >= bound
+            uint32_t cnd = 0u;
+#pragma unroll
+            for (int L = 0; L < kFitPathMax; ++L) cnd |= (pl[L] < bf ? 1u : 0u) << L;
+            cnd &= ~done & ((1u << D) - 1u);
+            done |= ~cnd;            // a level that fails now fails for good: the bound only shrinks
+            go = cnd ? 32 - __clz((int)cnd) : -1;   // deepest candidate level + 1
         }
     }
     // kept neighbours of the row: finite entries below max_pts

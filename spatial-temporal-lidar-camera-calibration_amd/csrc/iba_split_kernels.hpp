@@ -61,13 +61,13 @@ constexpr uint32_t kFlagA = 2u;   // association-path 1-NN wanted (ComputeLocalN
 template <class PRM> __device__ __forceinline__ bool local_neigh_ok(const PRM& prm, const PlaneRec& rec) { return !(rec.k < prm.neigh_min_pts || rec.far_d2 < prm.local_min_diff_dist2); }
 template <class PRM> __device__ __forceinline__ bool local_plane_ok(const PRM& prm, const PlaneRec& rec) { return rec.reg_sum / (double)(rec.k - 1) < prm.local_norm_reg_threshold; }
 // point-to-plane / point-to-point distance of the 3d-3d cost term (iba_global.cpp:111-156, 241-249) for e = neighbour - query;
-// rec: the plane at the neighbour (nullptr when use_plane is off). dist >= 0: the sign bit carries the kind (set: point-to-point)
-template <class PRM> __device__ __forceinline__ double cost_res(const PRM& prm, const PlaneRec* rec, double ex, double ey, double ez) {
+// rec: the plane at the neighbour (has_rec false when use_plane is off). dist >= 0: the sign bit carries the kind (set: point-to-point)
+template <class PRM> __device__ __forceinline__ double cost_res(const PRM& prm, bool has_rec, const PlaneRec& rec, double ex, double ey, double ez) {
     double dist = sqrt((ex * ex + ey * ey) + ez * ez);
     bool is_plane = false;
-    if (rec) {
-        if (!(rec->far_d2 < prm.min_diff_dist2) && !(rec->k < prm.norm_min_pts) && !(rec->reg_sum / (double)(rec->k - 1) > prm.norm_reg_threshold)) {
-            dist = fabs(ex * rec->nx + ey * rec->ny + ez * rec->nz);
+    if (has_rec) {
+        if (!(rec.far_d2 < prm.min_diff_dist2) && !(rec.k < prm.norm_min_pts) && !(rec.reg_sum / (double)(rec.k - 1) > prm.norm_reg_threshold)) {
+            dist = fabs(ex * rec.nx + ey * rec.ny + ez * rec.nz);
             is_plane = true;
         }
     }
@@ -808,7 +808,11 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                         const float4 pv = p4[bposC];
                         const double ex = (double)pv.x - qx, ey = (double)pv.y - qy, ez = (double)pv.z - qz;
                         if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
-                        else res = cost_res(prm, prm.use_plane ? planes_cost + bposC : nullptr, ex, ey, ez);
+                        else {
+                            PlaneRec rec; rec.k = 0;
+                            if (prm.use_plane) rec = planes_cost[bposC];
+                            res = cost_res(prm, prm.use_plane != 0, rec, ex, ey, ez);
+                        }
                     }
                     if ((WHICH & 2) && !refit) s_res[w - c0] = res;
                     }
@@ -945,8 +949,11 @@ __global__ __launch_bounds__(64) void iba_fit_kernel(DevProblem dp, DevParams pr
         if (want & 2) {
             double res = NAN;
             if (e.w & kFlagC) {
-                const PlaneRec* rc = !needC ? nullptr : ((same && (!needA || posA == posC)) ? &rec0 : &rec1);
-                res = cost_res(prm, rc, ex, ey, ez);
+                const bool from0 = same && (!needA || posA == posC);
+                PlaneRec rc;
+                rc.nx = from0 ? rec0.nx : rec1.nx; rc.ny = from0 ? rec0.ny : rec1.ny; rc.nz = from0 ? rec0.nz : rec1.nz;
+                rc.reg_sum = from0 ? rec0.reg_sum : rec1.reg_sum; rc.far_d2 = from0 ? rec0.far_d2 : rec1.far_d2; rc.k = from0 ? rec0.k : rec1.k; rc.pad = 0;
+                res = cost_res(prm, needC, rc, ex, ey, ez);
             }
             frefit[at].x = res;
         }
