@@ -291,51 +291,73 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
                     r6 = (float)c.R[6], r7 = (float)c.R[7], r8 = (float)c.R[8], t0 = (float)c.t[0], t1 = (float)c.t[1], t2 = (float)c.t[2];
         const float fxf = (float)c.fx, cxf = (float)c.cx, cyf = (float)c.cy;
         const float rB = (float)prm.bitmap_margin, rB2 = rB * rB * 1.00001f, wm = rB + 0.01f;
-        for (uint32_t i = tid; i < ncand; i += kThreads) {
-            const uint32_t pos = s_cand[i];
-            const float4 pv = c.p4[pos];
-            const float zc = fmaf(r6, pv.x, fmaf(r7, pv.y, fmaf(r8, pv.z, t2)));
-            if (!(zc > 0.1f)) {   // undecidable in f32 (queued by phase 1a for that reason): exact path inline, ties by the full rescan
-                double u, v;
-                if (project_uv(c, pv.x, pv.y, pv.z, u, v)) grid_match<1>(c, u, v, pos);
-                s_misc[1] = 1u;
-                continue;
+        // the exact test of a pair when the pair list is full (speed only: ties are settled by the full rescan)
+        auto test_now = [&](const float4& pv, uint32_t e) {
+            const float2 rec = s_kuv[e];
+            double u, v;
+            if (project_uv(c, pv.x, pv.y, pv.z, u, v)) {
+                const double du_ = (double)rec.x - u, dv_ = (double)rec.y - v;
+                const double d2 = du_ * du_ + dv_ * dv_;
+                if (d2 <= c.gate2) atomicMin(&s_best_d2[e], d2bits(d2));
             }
-            const float xc = fmaf(r0, pv.x, fmaf(r1, pv.y, fmaf(r2, pv.z, t0)));
-            const float yc = fmaf(r3, pv.x, fmaf(r4, pv.y, fmaf(r5, pv.z, t1)));
-            const float rz = __builtin_amdgcn_rcpf(zc);
-            const float uf = fmaf(fxf * xc, rz, cxf), vf = fmaf(fxf * yc, rz, cyf);
-            const int x0 = grid_cell(uf - wm, c.gw) >> kCoarseShift, x1 = grid_cell(uf + wm, c.gw) >> kCoarseShift;
-            const int y0 = grid_cell(vf - wm, c.gh) >> kCoarseShift, y1 = grid_cell(vf + wm, c.gh) >> kCoarseShift;
-            for (int yy = y0; yy <= y1; ++yy) {
-                const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
-                for (uint32_t e = e0; e < e1; ++e) {
-                    const float2 rec = s_kuv[e];
-                    const float du = rec.x - uf, dv = rec.y - vf;
-                    if (fmaf(dv, dv, du * du) <= rB2) {
-                        const unsigned long long hb = __ballot(1);   // the lanes that hit: one LDS atomic reserves the slots of all of them
-                        uint32_t sb = 0u;
-                        const int first = __ffsll((long long)hb) - 1;
-                        if (lane == first) sb = atomicAdd(&s_misc[2], (uint32_t)__popcll(hb));
-                        sb = (uint32_t)__shfl((int)sb, first);
-                        const uint32_t slot = sb + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
-                        if (slot < pair_cap) s_pair[slot] = make_uint4(pos, e, 0u, 0u);
-                        else {   // pair list full: exact test inline, ties by the full rescan (speed only)
-                            double u, v;
-                            if (project_uv(c, pv.x, pv.y, pv.z, u, v)) {
-                                const double du_ = (double)rec.x - u, dv_ = (double)rec.y - v;
-                                const double d2 = du_ * du_ + dv_ * dv_;
-                                if (d2 <= c.gate2) atomicMin(&s_best_d2[e], d2bits(d2));
+            s_misc[1] = 1u;
+        };
+        for (uint32_t i0 = 0; i0 < ncand; i0 += kThreads) {   // wave-uniform trip count: the pairs of a wave are appended together
+            const uint32_t i = i0 + (uint32_t)tid;
+            uint32_t pos = 0u, h0 = 0u, h1 = 0u, h2 = 0u, h3 = 0u, nh = 0u;   // up to four hits of this lane's point wait in registers
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < ncand) {
+                pos = s_cand[i];
+                pv = c.p4[pos];
+                const float zc = fmaf(r6, pv.x, fmaf(r7, pv.y, fmaf(r8, pv.z, t2)));
+                if (!(zc > 0.1f)) {   // undecidable in f32 (queued by phase 1a for that reason): exact path inline, ties by the full rescan
+                    double u, v;
+                    if (project_uv(c, pv.x, pv.y, pv.z, u, v)) grid_match<1>(c, u, v, pos);
+                    s_misc[1] = 1u;
+                } else {
+                    const float xc = fmaf(r0, pv.x, fmaf(r1, pv.y, fmaf(r2, pv.z, t0)));
+                    const float yc = fmaf(r3, pv.x, fmaf(r4, pv.y, fmaf(r5, pv.z, t1)));
+                    const float rz = __builtin_amdgcn_rcpf(zc);
+                    const float uf = fmaf(fxf * xc, rz, cxf), vf = fmaf(fxf * yc, rz, cyf);
+                    const int x0 = grid_cell(uf - wm, c.gw) >> kCoarseShift, x1 = grid_cell(uf + wm, c.gw) >> kCoarseShift;
+                    const int y0 = grid_cell(vf - wm, c.gh) >> kCoarseShift, y1 = grid_cell(vf + wm, c.gh) >> kCoarseShift;
+                    for (int yy = y0; yy <= y1; ++yy) {
+                        const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
+                        for (uint32_t e = e0; e < e1; ++e) {
+                            const float2 rec = s_kuv[e];
+                            const float du = rec.x - uf, dv = rec.y - vf;
+                            if (fmaf(dv, dv, du * du) <= rB2) {
+                                if (nh >= 4u) test_now(pv, h3);   // a fifth hit: the oldest one is settled right here
+                                h3 = h2; h2 = h1; h1 = h0; h0 = e; ++nh;
                             }
-                            s_misc[1] = 1u;
                         }
+                    }
+                }
+            }
+            // one LDS atomic reserves the slots of all the hits of the wave
+            const uint32_t nk = min(nh, 4u);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long b0 = __ballot(nk & 1u), b1 = __ballot(nk & 2u), b2 = __ballot(nk & 4u);
+            const uint32_t tot = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+            if (tot) {
+                uint32_t sb = 0u;
+                if (lane == 0) sb = atomicAdd(&s_misc[2], tot);
+                sb = (uint32_t)__shfl((int)sb, 0);
+                uint32_t slot = sb + (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt);
+                const uint32_t hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((uint32_t)q < nk) {
+                        if (slot < pair_cap) s_pair[slot] = make_uint4(pos, hh[q], 0u, 0u);
+                        else test_now(pv, hh[q]);
+                        ++slot;
                     }
                 }
             }
         }
     }
     __syncthreads();
-    if (dbg == 4) return;
+    if (dbg == 4 || dbg >= 29) return;
     // ---- phase 1c: exact f64 projection + FOV test (K1 + K2) and exact d^2 of every pair, ds_min_u64 on the keypoint's best ----
     const uint32_t npair = min(s_misc[2], pair_cap);
     const bool overflow = s_misc[1] != 0u;
