@@ -130,6 +130,10 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     if (ut < ncs) cv0 = dp.coarse_start[h.coarse_base + ut];
     if (ut + kThreads < ncs) cv1 = dp.coarse_start[h.coarse_base + ut + kThreads];
     if (ut < h.n_slots * 12u) rv = dp.slots[h.slot_base + ut / 12].rel[ut % 12];
+    const float4* boxes = (const float4*)(dp.chunk_box + 8 * h.box_base);   // two 16-byte loads per chunk; the first pass of the frustum test is fetched here
+    const uint32_t nchunks = (P + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
+    float4 blo_n = make_float4(0.f, 0.f, 0.f, 0.f), bhi_n = blo_n;
+    if (ut < nchunks) { blo_n = boxes[2 * (size_t)ut]; bhi_n = boxes[2 * (size_t)ut + 1]; }
     for (uint32_t i = tid; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = dp.kp_uv[h.kp_base + i]; s_kfl[i] = dp.kp_fl[h.kp_base + i]; }
     if (ut < nbw) s_bitmap[ut] = bv;
     if (ut < ncs) s_cstart[ut] = (uint16_t)cv0;
@@ -161,7 +165,6 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     // ---- phase 0.5: conservative frustum test of the static per-chunk boxes (see iba_frame_kernel) ----
     uint32_t* s_vis = (uint32_t*)(smem + lay.off_vis);
     {
-        const uint32_t nchunks = (P + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
         const float m = 8.0f;
         const float A[5][3] = {{(float)c.fx, 0.f, (float)c.cx + m}, {-(float)c.fx, 0.f, (float)c.W + m - (float)c.cx},
                                {0.f, (float)c.fx, (float)c.cy + m}, {0.f, -(float)c.fx, (float)c.H + m - (float)c.cy}, {0.f, 0.f, 1.f}};
@@ -173,13 +176,12 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
             Dd[q] = (float)c.t[0] * A[q][0] + (float)c.t[1] * A[q][1] + (float)c.t[2] * A[q][2] + (q == 4 ? 0.2f : 0.f);
             N1[q] = fabsf(N[q][0]) + fabsf(N[q][1]) + fabsf(N[q][2]);
         }
-        const float4* boxes = (const float4*)(dp.chunk_box + 8 * h.box_base);   // two 16-byte loads per chunk
         uint32_t vis_cnt = 0u;
         for (uint32_t ch0 = 0; ch0 < nchunks; ch0 += kThreads) {
             const uint32_t ch = ch0 + (uint32_t)tid;
             bool vis = false;
             if (ch < nchunks) {
-                const float4 blo = boxes[2 * (size_t)ch], bhi = boxes[2 * (size_t)ch + 1];
+                const float4 blo = ch0 == 0u ? blo_n : boxes[2 * (size_t)ch], bhi = ch0 == 0u ? bhi_n : boxes[2 * (size_t)ch + 1];
                 const float lo3[3] = {blo.x, blo.y, blo.z}, hi3[3] = {bhi.x, bhi.y, bhi.z};
                 vis = true;
                 const float rmax = bhi.w;   // largest |coordinate| of the box: |n . x| <= |n|_1 rmax bounds the slack term
@@ -302,13 +304,15 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
             }
             s_misc[1] = 1u;
         };
+        // the gather of a pass is issued one pass ahead: every exposed global-memory round trip costs this kernel about 4 % of its time
+        uint32_t pos_n = 0u; float4 pv_n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((uint32_t)tid < ncand) { pos_n = s_cand[tid]; pv_n = c.p4[pos_n]; }
         for (uint32_t i0 = 0; i0 < ncand; i0 += kThreads) {   // wave-uniform trip count: the pairs of a wave are appended together
             const uint32_t i = i0 + (uint32_t)tid;
-            uint32_t pos = 0u, h0 = 0u, h1 = 0u, h2 = 0u, h3 = 0u, nh = 0u;   // up to four hits of this lane's point wait in registers
-            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t h0 = 0u, h1 = 0u, h2 = 0u, h3 = 0u, nh = 0u;   // up to four hits of this lane's point wait in registers
+            const uint32_t pos = pos_n; const float4 pv = pv_n;
+            if (i + kThreads < ncand) { pos_n = s_cand[i + kThreads]; pv_n = c.p4[pos_n]; }
             if (i < ncand) {
-                pos = s_cand[i];
-                pv = c.p4[pos];
                 const float zc = fmaf(r6, pv.x, fmaf(r7, pv.y, fmaf(r8, pv.z, t2)));
                 if (!(zc > 0.1f)) {   // undecidable in f32 (queued by phase 1a for that reason): exact path inline, ties by the full rescan
                     double u, v;
@@ -361,10 +365,13 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     // ---- phase 1c: exact f64 projection + FOV test (K1 + K2) and exact d^2 of every pair, ds_min_u64 on the keypoint's best ----
     const uint32_t npair = min(s_misc[2], pair_cap);
     const bool overflow = s_misc[1] != 0u;
+    uint4 pr_n = make_uint4(0u, 0u, 0u, 0u); float4 pq_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((uint32_t)tid < npair) { pr_n = s_pair[tid]; pq_n = c.p4[pr_n.x]; }
     for (uint32_t i = tid; i < npair; i += kThreads) {
-        const uint4 pr = s_pair[i];
+        const uint4 pr = pr_n;
+        const float4 pv = pq_n;   // .w: original index of the point
+        if (i + kThreads < npair) { pr_n = s_pair[i + kThreads]; pq_n = c.p4[pr_n.x]; }
         const float2 rec = s_kuv[pr.y];
-        const float4 pv = c.p4[pr.x];   // .w: original index of the point
         double u, v;
         uint32_t k = kNone; unsigned long long bits = 0ull;
         if (project_uv(c, pv.x, pv.y, pv.z, u, v)) {
