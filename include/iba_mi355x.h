@@ -262,9 +262,11 @@ iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_ke
 /* debug: host copy of the summed partial blocks of the last iba_eval_* call */
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
 /* debug: exact 1-NN (nanoflann semantics with the lowest-index tie rule, iba_global.cpp:116-122) of n LiDAR-frame query
- * points in the scan of local frame `frame`, run through the frame kernels' own kd search with `lanes_per_query` lanes
- * (1, 2, 4 ... 32) per query: original point index and exact squared distance. For parity tests of the search itself. */
-iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q_xyz, int32_t n, int32_t lanes_per_query, uint32_t* out_idx, double* out_d2);
+ * points in the scan of local frame `frame`, run through the search kernel's own kd search, one lane per query: original point
+ * index and exact squared distance. mode 1: as the association path's query alone; 2: as the cost path's alone; 3 / 4: both paths
+ * searched together as the kernel does, the query as the first (3) or the second (4) with its partner 1e-7 beside it.
+ * For parity tests of the search itself. */
+iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q_xyz, int32_t n, int32_t mode, uint32_t* out_idx, double* out_d2);
 int64_t iba_num_points(const iba_handle* h);
 int64_t iba_num_keypoints(const iba_handle* h);
 

@@ -226,13 +226,14 @@ class IbaHandle:
         return kp[: n.value].copy(), pt[: n.value].copy()
 
     # --- multi-GPU building blocks: partial sums into caller-owned device memory ---
-    def debug_nn(self, frame, queries, lanes_per_query=1):
-        """Exact 1-NN of LiDAR-frame query points in the scan of a (local) frame through the kernels' own kd search:
+    def debug_nn(self, frame, queries, mode=1):
+        """Exact 1-NN of LiDAR-frame query points in the scan of a (local) frame through the search kernel's own kd search
+        (mode 1: as the association path's query, 2: as the cost path's, 3 / 4: both paths together, the query first / second):
         (original point indices, exact squared distances)."""
         q = np.ascontiguousarray(queries, np.float64).reshape(-1, 3)
         idx = np.zeros(len(q), np.uint32)
         d2 = np.zeros(len(q), np.float64)
-        self._chk(self.lib.iba_debug_nn(self.h, C.c_int32(frame), _p(q), C.c_int32(len(q)), C.c_int32(lanes_per_query),
+        self._chk(self.lib.iba_debug_nn(self.h, C.c_int32(frame), _p(q), C.c_int32(len(q)), C.c_int32(mode),
                                         idx.ctypes.data_as(C.POINTER(C.c_uint32)), _p(d2)))
         return idx, d2
 

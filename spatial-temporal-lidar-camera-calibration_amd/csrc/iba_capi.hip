@@ -56,14 +56,11 @@ struct iba_handle {
     std::string err;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    bool timing = false, timing_recorded = false, timing_split = false, frozen_split = false;
+    bool timing = false, timing_recorded = false, timing_split = false;
     float last_frame_ms = 0.f, last_total_ms = 0.f;
     int64_t n_points = 0, n_keypoints = 0;
     uint32_t maxP = 0, maxPpad = 0, maxK = 0, maxNodes = 0, maxBitmapWords = 0, maxCoarse = 0;
-    bool scan_lds = false;
-    LdsLayout lay{};
-    // two-kernel path (plane_cache = 1): association kernel + grouped search kernel (iba_split_kernels.hpp)
-    bool split = true;                    // IBA_MONOLITHIC=1 selects the one-kernel path for comparisons
+    // the evaluation chain: association kernel + search kernel (+ fit kernels with plane_cache = 0) (iba_split_kernels.hpp)
     LdsLayout alay{};                     // LDS plan of iba_assoc_kernel
     uint32_t maxKw = 0;                   // max over frames of the keypoints that can own a term (MapPoint or covisible match)
     int assoc_dbg = 0;
@@ -96,7 +93,6 @@ struct iba_handle {
     DevBuf<double> d_partials;            // IBA_MAX_BATCH * kPartialStride
     DevBuf<uint32_t> d_corr;              // n_keypoints
     DevBuf<double> d_he;                  // IBA_MAX_BATCH * n_frames hand-eye values
-    DevBuf<uint2> d_assoc;                // assoc_cap * n_keypoints (per-candidate association of iba_eval_normal)
     int assoc_cap = 0;
     DevBuf<uint2> d_assoc_frozen;         // n_keypoints (iba_build_problem)
     DevBuf<uint4> d_flist, d_flist_frozen;       // dense residual-block lists: [cand][frame][maxK] / [frame][maxK]
@@ -157,8 +153,6 @@ iba_status check_params(iba_handle* h, const iba_params& p) {
         return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist must be in (0, 64] px");
     if (p.norm_max_pts < 1 || p.norm_max_pts > 64 || p.neigh_max_pts < 1 || p.neigh_max_pts > 64)
         return fail(h, IBA_ERR_UNSUPPORTED, "norm_max_pts / neigh_max_pts must be in [1, 64] (the neighbour list lives one entry per lane of a wave)");
-    if (h && !h->split && !p.plane_cache && h->max_slots > (uint32_t)kMaxCovisRefit)
-        return fail(h, IBA_ERR_UNSUPPORTED, "plane_cache = 0 supports at most 10 covisible keyframes per frame");
     return IBA_OK;
 }
 
@@ -173,39 +167,6 @@ void parallel_for(int n, F fn) {
 }
 
 uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
-
-bool layout(iba_handle* h, bool with_scan, LdsLayout& L) {
-    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;   // wave sums + covisible poses + wave counts + misc
-    L.scan_stride = with_scan ? h->maxPpad : 0;
-    uint32_t off = with_scan ? 12u * h->maxPpad : 0u;
-    off = align_up(off, 16); L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
-    L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
-    off = align_up(off, 8); L.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
-    off = align_up(off, 16); L.off_red = off; off += red_bytes;
-    // visibility bits of the culling chunks, written one 64-bit ballot per wave and pass: room for whole passes
-    L.off_vis = off; L.vis_words = 2u * kWaves * ((h->maxPpad / (uint32_t)kChunk + kThreads) / kThreads) + 2u;
-    off += 4u * L.vis_words + 2u * (h->maxPpad / (uint32_t)kChunk + 2u);   // bit words, then the compacted u16 list of visible chunks
-    // keypoint bitmap, coarse CSR and candidate queue are contiguous: after phase 2 the fused mode parks its
-    // unfinished NN queries in [off_bitmap, total)
-    off = align_up(off, 16); L.off_bitmap = off; off += 4u * std::max(h->maxBitmapWords, 1u);
-    L.off_cstart = off; off += 2u * std::max(h->maxCoarse, 1u);
-    off = align_up(off, 16); L.off_cand = off;
-    if (off + 1024u > kLdsBytes) return false;
-    // candidate queue takes what is left (u16 entries when the scan is in LDS, u32 otherwise); a full queue only
-    // costs speed (inline matching + rescan), never correctness
-    const uint32_t entry = with_scan ? 2u : 4u;
-    uint32_t want = std::max<uint32_t>(h->maxPpad / 2u, 512u) * entry;
-    const uint32_t avail = (kLdsBytes - off) & ~15u;
-    // Two blocks per CU are worth more than a queue nobody fills: at 2000 keypoints ~4 % of a scan survives the pre-cull
-    // (2-px reject bitmap). If half of the LDS still leaves room for 1/16 of the points, stop there.
-    const uint32_t half = kLdsBytes / 2u;
-    if (!with_scan && off < half && (half - off) / entry >= std::max<uint32_t>(h->maxPpad / 16u, 512u)) want = std::min(want, (half - off) & ~15u);
-    if (const char* e = std::getenv("IBA_CAND_BYTES")) want = (uint32_t)std::atoi(e);   // diagnostic
-    const uint32_t bytes = std::min(want, avail);
-    L.cand_cap = bytes / entry;
-    L.total = off + bytes;
-    return L.total <= kLdsBytes;
-}
 
 // LDS plan of iba_assoc_kernel: per-keypoint tables, the candidate queue (4 B per queued point), and the reject bitmap, whose
 // storage — dead after the streaming pass — becomes the head of the pair list (16 B per (point, keypoint) pair). What is left
@@ -303,26 +264,6 @@ iba_status ensure_scratch(iba_handle* h) {
     return IBA_OK;
 }
 
-template <int MODE>
-iba_status launch_frame(iba_handle* h, const Cand* d_cands, int B, double* d_frame_partials, uint32_t* d_corr, uint2* d_assoc, int nrec, hipStream_t st, int scratch_slot_base = 1) {
-    const bool frozen = (d_assoc == h->d_assoc_frozen.p);
-    uint4* fl = frozen ? h->d_flist_frozen.p : h->d_flist.p; uint32_t* fc = frozen ? h->d_fcount_frozen.p : h->d_fcount.p;
-    if (MODE != MODE_CORR && !h->params.plane_cache && h->scratch_cap < B) return fail(h, IBA_ERR_STATE, "plane scratch not allocated");
-    DevProblem dp = h->dev_problem();
-    dp.scratch_slot_base = scratch_slot_base;
-    if ((MODE == MODE_COST || MODE == MODE_BOTH) && h->n_frames > 0) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
-        hipLaunchKernelGGL(iba_he_kernel, dim3((B * h->n_frames + 63) / 64), dim3(64), 0, st, dp, d_cands, B, h->d_he.p);
-        HIP_TRY(h, hipGetLastError());
-    }
-    const int per_xcd = (h->n_frames + 7) / 8;
-    const dim3 grid(8 * per_xcd * B), block(kThreads);
-    if (h->n_frames == 0) return IBA_OK;
-    if (h->scan_lds) hipLaunchKernelGGL((iba_frame_kernel<MODE, true>), grid, block, h->lay.total, st, KArgs{dp, h->dprm, h->lay}, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->lstride);
-    else hipLaunchKernelGGL((iba_frame_kernel<MODE, false>), grid, block, h->lay.total, st, KArgs{dp, h->dprm, h->lay}, d_cands, B, d_frame_partials, d_corr, d_assoc, nrec, h->d_he.p, fl, fc, (int)h->lstride);
-    HIP_TRY(h, hipGetLastError());
-    return IBA_OK;
-}
-
 // stages B candidates into a pinned ring slot and enqueues the H2D copy; returns the device pointer
 iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out) {
     const int slot = h->ring_next; h->ring_next = (h->ring_next + 1) % kRing;
@@ -353,8 +294,7 @@ iba_status ensure_lists(iba_handle* h, int B, hipStream_t st) {
     if (h->assoc_cap >= B && (h->params.plane_cache || h->d_frefit.p)) return IBA_OK;
     B = std::max(B, h->assoc_cap);
     HIP_TRY(h, hipStreamSynchronize(st)); HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->d_assoc.release(); h->d_flist.release(); h->d_fcount.release(); h->d_lcount.release(); h->d_fmp.release();
-    if (!h->split) HIP_TRY(h, h->d_assoc.alloc((size_t)B * std::max<int64_t>(h->n_keypoints, 1)));
+    h->d_flist.release(); h->d_fcount.release(); h->d_lcount.release(); h->d_fmp.release();
     HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
     HIP_TRY(h, h->d_fmp.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
     HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
@@ -365,7 +305,6 @@ iba_status ensure_lists(iba_handle* h, int B, hipStream_t st) {
     return IBA_OK;
 }
 
-bool use_split(const iba_handle* h) { return h->split; }
 
 // Two-kernel evaluation chain (plane_cache = 1) on stream st: [hand-eye] -> association -> grouped 1-NN -> [factors] -> sums.
 // want: bit 0 = BuildProblem association (+ normal equations when `factors`), bit 1 = BAError cost.
@@ -423,20 +362,20 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         const dim3 grid(8 * per_xcd * ngroups * NS), block(kNNThreads);
         const NNArgs na{dp, h->dprm, nl};
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
-        auto launch_nn = [&](int mode) {
-            const int dm = h->nn_dbg | (mode << 8);
-            if (wA && wC) hipLaunchKernelGGL((iba_nn_kernel<3>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, dm, h->d_frefit.p);
-            else if (wA) hipLaunchKernelGGL((iba_nn_kernel<1>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, dm, h->d_frefit.p);
-            else hipLaunchKernelGGL((iba_nn_kernel<2>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, dm, h->d_frefit.p);
+        auto launch_nn = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            if (wA && wC) hipLaunchKernelGGL((iba_nn_kernel<3, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p);
+            else if (wA) hipLaunchKernelGGL((iba_nn_kernel<1, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p);
+            else hipLaunchKernelGGL((iba_nn_kernel<2, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p);
         };
-        launch_nn(refit ? kRefitSearch : 0);
+        if (refit) launch_nn(std::integral_constant<int, kRefitSearch>{}); else launch_nn(std::integral_constant<int, 0>{});
         HIP_TRY(h, hipGetLastError());
         if (refit) {
             const int w2 = (wA ? 1 : 0) | (wC ? 2 : 0);
             if (wide_fit) hipLaunchKernelGGL((iba_fit_kernel<4, 2>), fit_grid, dim3(64), 0, st, dp, h->dprm, fl, h->d_frefit.p, lc, (int)h->lstride, slot_base, w2);
             else hipLaunchKernelGGL((iba_fit_kernel<2, 2>), fit_grid, dim3(64), 0, st, dp, h->dprm, fl, h->d_frefit.p, lc, (int)h->lstride, slot_base, w2);
             HIP_TRY(h, hipGetLastError());
-            if (wC) { launch_nn(kRefitSums); HIP_TRY(h, hipGetLastError()); }
+            if (wC) { launch_nn(std::integral_constant<int, kRefitSums>{}); HIP_TRY(h, hipGetLastError()); }
         }
     }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
@@ -459,15 +398,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
-    if (use_split(h)) return run_split(h, dc, B, 2, false, false, d_partials, st);
-    h->timing_split = false;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    s = launch_frame<MODE_COST>(h, dc, B, h->d_frame_partials.p, nullptr, nullptr, h->n_frames, st); if (s != IBA_OK) return s;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->n_frames, d_partials);
-    HIP_TRY(h, hipGetLastError());
-    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
-    return IBA_OK;
+    return run_split(h, dc, B, 2, false, false, d_partials, st);
 }
 
 }  // namespace
@@ -497,7 +428,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -549,8 +480,6 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         h->max_slots = std::max<uint32_t>(h->max_slots, (uint32_t)ns);
     }
 
-    h->split = !(std::getenv("IBA_MONOLITHIC") && std::atoi(std::getenv("IBA_MONOLITHIC")) != 0);
-    if (!h->split && !params->plane_cache && h->max_slots > (uint32_t)kMaxCovisRefit) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "plane_cache = 0 supports at most 10 covisible keyframes per frame"); }
 
     // ---- per-frame host build (parallel over frames; reference: omp parallel for at iba_global.cpp:363) ----
     // keypoints are stored in Morton order of their pixel (internal id j -> reference id kp_order[j]): queries that
@@ -688,13 +617,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (bad_match) { delete h; return fail(nullptr, IBA_ERR_INVALID_ARG, "covisibility / match index out of range"); }
     if (!crec_ok) { delete h; return fail(nullptr, IBA_ERR_STATE, "internal: keypoint grid records are not in keypoint order"); }
 
-    // ---- LDS plan: stage the scan in LDS when it fits (<= ~10.9k points with 2000 keypoints) ----
-    // Staging the scan in LDS (120 KB for 10 k points) pins the CU to ONE block; reading it through L2 instead costs ~5 % per
-    // block but lets two blocks overlap their phases (-24 % wall time). The LDS-scan variant stays selectable for experiments.
-    h->scan_lds = std::getenv("IBA_SCAN_LDS") && layout(h, true, h->lay);
-    if (!h->scan_lds && !layout(h, false, h->lay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
-
-    h->split = !(std::getenv("IBA_MONOLITHIC") && std::atoi(std::getenv("IBA_MONOLITHIC")) != 0);
+    // ---- LDS plans ----
     if (const char* e = std::getenv("IBA_NN_CG")) h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e)));
     if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
@@ -731,22 +654,17 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel
-    const void* fns[8] = {(const void*)iba_frame_kernel<MODE_COST, true>, (const void*)iba_frame_kernel<MODE_COST, false>,
-                          (const void*)iba_frame_kernel<MODE_CORR, true>, (const void*)iba_frame_kernel<MODE_CORR, false>,
-                          (const void*)iba_frame_kernel<MODE_ASSOC, true>, (const void*)iba_frame_kernel<MODE_ASSOC, false>,
-                          (const void*)iba_frame_kernel<MODE_BOTH, true>, (const void*)iba_frame_kernel<MODE_BOTH, false>};
-    for (const void* fn : fns)
-        if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
-    const void* nfns[3] = {(const void*)iba_nn_kernel<1>, (const void*)iba_nn_kernel<2>, (const void*)iba_nn_kernel<3>};
+    const void* nfns[9] = {(const void*)iba_nn_kernel<1, 0>, (const void*)iba_nn_kernel<2, 0>, (const void*)iba_nn_kernel<3, 0>, (const void*)iba_nn_kernel<1, 1>, (const void*)iba_nn_kernel<2, 1>, (const void*)iba_nn_kernel<3, 1>,
+                           (const void*)iba_nn_kernel<1, 2>, (const void*)iba_nn_kernel<2, 2>, (const void*)iba_nn_kernel<3, 2>};
     for (const void* fn : nfns)
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
 
-    {   // the frame kernel's view of its kernarg segment (see iba_kernarg_probe_kernel)
+    {   // the association kernel's view of its kernarg segment (see iba_kernarg_probe_kernel)
         DevBuf<int32_t> okb; std::vector<int32_t> z(1, 0);
         er = okb.upload(z);
         if (er != hipSuccess) return bail("kernarg probe", er);
-        hipLaunchKernelGGL(iba_kernarg_probe_kernel, dim3(1), dim3(1), 0, h->stream, KArgs{h->dev_problem(), h->dprm, h->lay}, okb.p);
+        hipLaunchKernelGGL(iba_kernarg_probe_kernel, dim3(1), dim3(1), 0, h->stream, KArgs{h->dev_problem(), h->dprm, h->alay}, okb.p);
         int32_t okv = 0;
         er = hipStreamSynchronize(h->stream);
         if (er == hipSuccess) er = hipMemcpy(&okv, okb.p, sizeof(okv), hipMemcpyDeviceToHost);
@@ -849,11 +767,11 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
-    if (h->split) {
+    {
         hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * ((h->n_frames + 7) / 8)), dim3(kThreads), h->alay.total, h->stream, KArgs{h->dev_problem(), h->dprm, h->alay}, dc, 1, 0,
                            h->d_frame_partials.p, h->n_frames, h->d_corr.p, h->d_he.p, h->d_flist_frozen.p, h->d_fmp_frozen.p, h->d_fcount_frozen.p, h->d_lcount_frozen.p, (int)h->lstride);
         HIP_TRY(h, hipGetLastError());
-    } else { s = launch_frame<MODE_CORR>(h, dc, 1, h->d_frame_partials.p, h->d_corr.p, nullptr, h->n_frames, h->stream); if (s != IBA_OK) return s; }
+    }
     const uint64_t k0 = h->h_kp_off[lf], K = h->h_kp_off[lf + 1] - k0;
     std::vector<uint32_t> tmp(K);
     HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_corr.p + k0, sizeof(uint32_t) * K, hipMemcpyDeviceToHost, h->stream));
@@ -868,13 +786,6 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     return IBA_OK;
 }
 
-#ifdef IBA_STAMPS
-extern "C" int iba_debug_counters(unsigned long long* out8, int reset) {
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(iba::g_dbg), 512);
-    if (reset) { unsigned long long z[64] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(iba::g_dbg), z, 512); }
-    return 0;
-}
-#endif
 // ---- (R, t, s) <-> x (iba_global.cpp:511-515: x[0:6] = g2o::SE3Quat(R, t).log(), x[6] = scale; Sim3Exp g2o_tools.h:105-140) ----
 iba_status iba_sim3_to_x(const double rigid12[12], double scale, double x[7]) {
     if (!rigid12 || !x) return IBA_ERR_INVALID_ARG;
@@ -901,10 +812,9 @@ iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
 }
 
 // debug: exact 1-NN of n LiDAR-frame queries in the scan of a local frame, through the frame kernels' own search
-iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n, int32_t lanes_per_query, uint32_t* out_idx, double* out_d2) {
+iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n, int32_t mode, uint32_t* out_idx, double* out_d2) {
     if (!h || !q || !out_idx || !out_d2 || n < 1 || frame < 0 || frame >= h->n_frames) return IBA_ERR_INVALID_ARG;
-    const int G = lanes_per_query;
-    if (G < 1 || G > 32 || (G & (G - 1))) return fail(h, IBA_ERR_INVALID_ARG, "lanes_per_query must be a power of two <= 32");
+    if (mode < 1 || mode > 4) return fail(h, IBA_ERR_INVALID_ARG, "mode must be 1 (association query), 2 (cost query), 3 or 4 (both, the query as the first / the second)");
     (void)hipSetDevice(h->device);
     DevBuf<double> dq, dd; DevBuf<uint32_t> di;
     std::vector<double> hq(q, q + 3 * (size_t)n);
@@ -913,8 +823,8 @@ iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n
     if (er == hipSuccess) er = di.alloc((size_t)n);
     if (er != hipSuccess) return fail(h, IBA_ERR_HIP, hipGetErrorString(er));
     const size_t lds = 8u * (size_t)std::max(h->maxNodes, 1u);
-    const int blocks = (int)(((size_t)n * G + 255) / 256);
-    hipLaunchKernelGGL(iba_nn_probe_kernel, dim3(blocks), dim3(256), lds, h->stream, h->dev_problem(), frame, dq.p, n, G, di.p, dd.p);
+    const int blocks = (int)(((size_t)n + 255) / 256);
+    hipLaunchKernelGGL(iba_nn_probe_kernel, dim3(blocks), dim3(256), lds, h->stream, h->dev_problem(), frame, dq.p, n, mode, di.p, dd.p);
     er = hipStreamSynchronize(h->stream);
     if (er == hipSuccess) er = hipMemcpy(out_idx, di.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
     if (er == hipSuccess) er = hipMemcpy(out_d2, dd.p, sizeof(double) * n, hipMemcpyDeviceToHost);
@@ -945,16 +855,7 @@ static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
-    if (use_split(h)) return run_split(h, dc, B, 1, false, true, d_partials, st);
-    h->timing_split = false;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    s = launch_frame<MODE_ASSOC>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
-    HIP_TRY(h, hipGetLastError());
-    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
-    return IBA_OK;
+    return run_split(h, dc, B, 1, false, true, d_partials, st);
 }
 
 iba_status iba_eval_normal_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
@@ -981,16 +882,7 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
-    if (use_split(h)) return run_split(h, dc, B, 3, false, true, d_partials, st);
-    h->timing_split = false;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    s = launch_frame<MODE_BOTH>(h, dc, B, h->d_frame_partials.p, nullptr, h->d_assoc.p, h->nrec, st); if (s != IBA_OK) return s;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, h->n_frames, st); if (s != IBA_OK) return s;
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->nrec, d_partials);
-    HIP_TRY(h, hipGetLastError());
-    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; }
-    return IBA_OK;
+    return run_split(h, dc, B, 3, false, true, d_partials, st);
 }
 
 iba_status iba_eval_full_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
@@ -1014,13 +906,7 @@ iba_status iba_build_problem(iba_handle* h, const double* x) {
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
-    h->frozen_split = use_split(h);
-    if (h->frozen_split) { s = run_split(h, dc, 1, 1, true, false, h->d_partials.p, h->stream); if (s != IBA_OK) return s; }
-    else {
-        s = launch_frame<MODE_ASSOC>(h, dc, 1, h->d_frame_partials.p, nullptr, h->d_assoc_frozen.p, h->n_frames, h->stream, 0); if (s != IBA_OK) return s;
-        hipLaunchKernelGGL(iba_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, h->stream, h->d_frame_partials.p, h->n_frames, h->d_partials.p);
-        HIP_TRY(h, hipGetLastError());
-    }
+    s = run_split(h, dc, 1, 1, true, false, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
     HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->frozen_frames = (int32_t)h->h_partials[P_FRAMES_N]; h->frozen_ncorr = (int32_t)h->h_partials[P_NCORR_N]; h->frozen_valid = true;
@@ -1207,7 +1093,7 @@ iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double*
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t KT = (size_t)h->n_keypoints;
     std::vector<uint2> a(KT);
-    if (h->frozen_split) {   // the two-kernel path keeps the association as per-frame block lists: expand them to one row per keypoint
+    {   // the association is kept as per-frame block lists: expand them to one row per keypoint
         std::fill(a.begin(), a.end(), make_uint2(kNone, kNone));
         std::vector<uint32_t> fcn((size_t)std::max(h->n_frames, 1));
         HIP_TRY(h, hipMemcpy(fcn.data(), h->d_fcount_frozen.p, sizeof(uint32_t) * (size_t)h->n_frames, hipMemcpyDeviceToHost));
@@ -1219,8 +1105,7 @@ iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double*
             for (uint32_t i = 0; i < n; ++i) a[h->h_frames[lf].kp_base + row[i].x] = make_uint2(row[i].y, row[i].z);
         }
         if (KT) HIP_TRY(h, hipMemcpy(h->d_assoc_frozen.p, a.data(), KT * sizeof(uint2), hipMemcpyHostToDevice));
-    } else
-    HIP_TRY(h, hipMemcpy(a.data(), h->d_assoc_frozen.p, KT * sizeof(uint2), hipMemcpyDeviceToHost));
+    }
     std::vector<float2> muv; std::vector<float2> dummy;
     // covisible-match counts per keypoint decide the number of plane-factor rows (2 per matched covisible KF)
     std::vector<int> nconv(KT, 0);

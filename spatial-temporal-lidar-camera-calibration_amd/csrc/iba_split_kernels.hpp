@@ -1,27 +1,25 @@
-// The evaluation path as TWO kernels (plane_cache = 1; the per-evaluation refit mode keeps the one-kernel path of
-// iba_kernels.hpp):
+// CDNA4 (gfx950) kernels of the IBA cross-modality evaluation path, part 2: the evaluation chain of one batch of candidates.
 //
-//   iba_assoc_kernel   one workgroup per (keyframe, candidate): frustum cull, float pre-cull, exact projection + keypoint
-//                      grid match, ties, corrset size, ONE dense work list per (candidate, keyframe) in keypoint order, local
+//   iba_assoc_kernel   one workgroup per (keyframe, candidate): frustum cull of 64-point chunks, float32 pre-cull against the
+//                      keypoint bitmap, float32 walk of the keypoint grid -> (point, keypoint) pairs, exact f64 projection and
+//                      d^2 per pair, ties, corrset size, ONE work list per (candidate, keyframe) in keypoint order, local
 //                      plane at the matched point, 3d-2d covisible residuals -> partial record + list handed to
 //                      iba_nn_kernel (and, through it, to iba_factor_kernel).
 //                      = TransformPointCloud + FindProjectCorrespondences (pointcloud.h:82-86, iba_global.cpp:55-96 =
 //                      iba_local.cpp:17-58), the 3d-2d loop (iba_global.cpp:291-328), ComputeLocalNeighbor validity
 //                      (iba_local.cpp:207-231).
-//   iba_nn_kernel      one workgroup per (keyframe, GROUP of up to 16 candidates, keypoint slice): the MapPoint -> scan 1-NN
-//                      of iba_global.cpp:231-234,116-122 and iba_local.cpp:282-290 for ALL candidates of the group in ONE kd
-//                      traversal per MapPoint. The candidates' queries of one MapPoint differ by millimetres to centimetres:
-//                      lane j of a lane group owns candidate j's two queries (association path / cost path); the group walks
-//                      the tree together, steered by the centre of its queries with a pruning radius that covers all of
-//                      them, so every query sees a SUPERSET of the leaves it would visit alone; each lane scans the visited
-//                      leaf for its own queries (float filter + exact f64 confirmation, lowest-original-index ties) — results
-//                      are identical to separate exact searches. Then, per (MapPoint, candidate): point-to-plane /
-//                      point-to-point cost distance (ComputeAlignmentDist, iba_global.cpp:111-156, 241-249) and the kind of
-//                      the 3d-3d residual block (pointcloud.h:699-717).
+//   iba_nn_kernel      one workgroup per (keyframe, group of up to 8 candidates, slice of 128 list positions): the MapPoint ->
+//                      scan 1-NN of iba_global.cpp:231-234,116-122 and iba_local.cpp:282-290, ONE LANE per (MapPoint, candidate)
+//                      in a persistent loop without barriers (LaneNN / lane_nn_visit), then per entry the point-to-plane /
+//                      point-to-point cost distance (ComputeAlignmentDist, iba_global.cpp:111-156, 241-249), the kind of the
+//                      3d-3d residual block (pointcloud.h:699-717), and fixed-order sums.
+//   iba_fit_kernel     plane_cache = 0 only: the planes one evaluation needs, fitted for that evaluation between the kernels
+//                      above (stage 1: at the matched points; stage 2: at the searched neighbours).
+//   iba_reduce2_kernel fixed-order sums of the records of both kernels (and of iba_factor_kernel) per candidate.
 //
-// Why: in the one-kernel form 43 % of the time went into the 1-NN phase, each (keyframe, candidate) block descending the
-// same tree to the same leaves for ~264 MapPoints with half of its lanes idle, and 13 % into a finalize pass that
-// recomputed the queries. Splitting also frees the association kernel from the search's registers and LDS.
+// Why two kernels: in round 1's one-kernel form 43 % of the time went into the 1-NN phase, each (keyframe, candidate) block
+// descending the tree for ~264 MapPoints in barrier-separated rounds with half of its lanes idle, and 13 % into a finalize pass
+// that recomputed the queries. Splitting also frees the association kernel from the search's registers and LDS.
 #pragma once
 #include "iba_kernels.hpp"
 
@@ -546,6 +544,170 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 #undef IBA_RELOAD
 }
 
+// ---- one lane's exact 1-NN search of a query pair in the implicit balanced kd-tree: a = the association path's MapPoint query,
+//      c = the cost path's (the same MapPoint through different float/double islands of the reference, ~1e-7 apart). The walk is
+//      float32 and conservative around the steering point o (|q - o| <= del per axis for both queries: for a node with split s and
+//      d = fl(o - s), max(|d| - del', 0)^2 (1 - 2^-19) is a lower bound of the squared plane distance of either query); a leaf is
+//      scanned in float and only the arg-min is confirmed in double when the runner-up is separated by more than the error bound
+//      E(u), otherwise every point within the bound. The visited path stays in registers from one leaf to the next. ----
+// The state of a lane's search is a set of plain variables (a struct would be kept in scratch: the compiler turns the selects
+// on neighbouring members into indexed loads): declare them with IBA_LANE_NN_DECL, hand them over with IBA_LANE_NN_PASS.
+//   ax..qz: the queries (set by the caller together with actA / actC); go < 0 after a visit: the search has ended
+#define IBA_LANE_NN_DECL \
+    double ax = NAN, ay = NAN, az = NAN, qx = NAN, qy = NAN, qz = NAN, bestA = INFINITY, bestC = INFINITY; uint32_t bposA = kNone, bposC = kNone; \
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, delc = 0.f, e_lin = 0.f, e_const = 0.f; float pd2[kPathMax]; \
+    uint32_t side = 0u, done = 0u, node = 0u; int go = -1; bool actA = false, actC = false; \
+    _Pragma("unroll") for (int L_ = 0; L_ < kPathMax; ++L_) pd2[L_] = INFINITY
+#define IBA_LANE_NN_PARAMS \
+    double& ax, double& ay, double& az, double& qx, double& qy, double& qz, double& bestA, double& bestC, uint32_t& bposA, uint32_t& bposC, \
+    float& o0, float& o1, float& o2, float& delc, float& e_lin, float& e_const, float (&pd2)[kPathMax], uint32_t& side, uint32_t& done, uint32_t& node, int& go, \
+    bool& actA, bool& actC
+#define IBA_LANE_NN_PASS ax, ay, az, qx, qy, qz, bestA, bestC, bposA, bposC, o0, o1, o2, delc, e_lin, e_const, pd2, side, done, node, go, actA, actC
+__device__ __forceinline__ void lane_nn_begin(IBA_LANE_NN_PARAMS) {
+    // float steering point o and the radius del >= |q - o| per axis of both queries
+    o0 = (float)(actC ? qx : ax); o1 = (float)(actC ? qy : ay); o2 = (float)(actC ? qz : az);
+    double m = 0.0;
+    if (actA) m = fmax(fmax(fabs(ax - (double)o0), fabs(ay - (double)o1)), fabs(az - (double)o2));
+    if (actC) m = fmax(m, fmax(fmax(fabs(qx - (double)o0), fabs(qy - (double)o1)), fabs(qz - (double)o2)));
+    const float del = (float)m * 1.00001f + 1e-30f;
+    delc = del * 0.999999f;
+    e_lin = 2.01f * del; e_const = 3.01f * del * del + 2.1e-19f * e_lin + 1e-37f;
+    bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
+    side = 0u; done = 0u; node = 0u; go = -1;
+}
+// one leaf visit
+template <int WHICH>
+__device__ __forceinline__ void lane_nn_visit(IBA_LANE_NN_PARAMS, const TreeNode* s_nodes, const float4* __restrict__ p4, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D) {
+    const uint32_t first_leaf = (1u << D) - 1u;
+    auto lower_bound = [delc](float d) { const float a = fmaxf(fmaf(fabsf(d), 0.999999f, -delc), 0.f); return a * a; };
+    int start = 0;
+    if (go >= 0) {   // enter the far child at level go
+        const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
+        done |= 1u << go; side ^= 1u << go;
+        node = 2u * anc + 1u + ((side >> go) & 1u);
+        start = go + 1;
+    }
+    {
+        const uint32_t keep = (1u << start) - 1u;
+        side &= keep; done &= keep;
+        uint32_t n1 = node + 1u;
+#pragma unroll
+        for (int L = 0; L < kPathMax; ++L) {
+            if (L >= (int)D) break;
+            if (L >= start) {
+                const TreeNode n = s_nodes[n1 - 1u];
+                const float d = (n.dim == 0 ? o0 : (n.dim == 1 ? o1 : o2)) - n.split;
+                const uint32_t r = (~__float_as_uint(d)) >> 31;
+                pd2[L] = lower_bound(d);
+                side |= r << L;
+                n1 = (n1 << 1) | r;
+            }
+        }
+        node = n1 - 1u;
+    }
+    {
+        const uint32_t j = node - first_leaf;
+        const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+        float m1 = INFINITY, m2 = INFINITY; uint32_t mi = kNone;
+        auto err_of = [e_lin, e_const](float u) { return fmaf(1.001f * e_lin, __builtin_amdgcn_sqrtf(3.f * u), fmaf(1.5e-6f, u, e_const)); };
+        constexpr int kLeafBatch = IBA_NN_LEAF_BATCH;
+        for (uint32_t i0 = lo; i0 < hi; i0 += (uint32_t)kLeafBatch) {
+            float X[kLeafBatch], Y[kLeafBatch], Z[kLeafBatch];
+#pragma unroll
+            for (int u = 0; u < kLeafBatch; ++u) {
+                const uint32_t iu = i0 + (uint32_t)u, ic = iu < hi ? iu : hi - 1u;
+                const float4 v = p4[ic]; X[u] = v.x; Y[u] = v.y; Z[u] = v.z;
+            }
+#pragma unroll
+            for (int u = 0; u < kLeafBatch; ++u) {
+                const uint32_t i = i0 + (uint32_t)u;
+                const float dx = o0 - X[u], dy = o1 - Y[u], dz = o2 - Z[u];
+                float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                uu = i < hi ? uu : INFINITY;
+                mi = uu < m1 ? i : mi;
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, uu);
+                m1 = vmin(m1, uu);
+            }
+        }
+        const float mono = 4.f * e_lin * e_lin;
+        const float thi = m1 + err_of(m1);
+        bool single = m2 >= mono && m2 - err_of(m2) > thi;
+        const float bnear = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+        const float bmax = fmaf(fabsf(bnear), 1.2e-7f, bnear);
+        const bool skip = m1 >= mono && m1 - err_of(m1) > bmax;
+#ifdef IBA_LEAF_FORCE_SINGLE
+        single = true;
+#endif
+        if (mi != kNone && !skip) {
+            uint32_t i = single ? mi : lo;
+            while (single || i < hi) {
+                const float4 pv = p4[i];
+                bool take = single;
+                if (!single) {
+                    const float dx = o0 - pv.x, dy = o1 - pv.y, dz = o2 - pv.z;
+                    const float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    take = uu - err_of(uu) <= thi;
+                }
+                if (take) {
+                    const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+                    if (WHICH & 1) {
+                        const double dx = ax - x, dy = ay - y, dz = az - z;
+                        nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, i, perm_g);
+                    }
+                    if (WHICH & 2) {
+                        const double dx = qx - x, dy = qy - y, dz = qz - z;
+                        nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, i, perm_g);
+                    }
+                }
+                if (single) break;
+                ++i;
+            }
+        }
+    }
+    {   // deepest level whose far side may still be within reach of either query
+        const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+        uint32_t cnd = 0u;
+#pragma unroll
+        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= bestf ? 1u : 0u) << L;
+        cnd &= ~done & ((1u << D) - 1u);
+        done |= ~cnd;
+        go = cnd ? 31 - __clz((int)cnd) : -1;
+    }
+}
+
+// diagnostic (iba_debug_nn): the search of iba_nn_kernel on caller-supplied LiDAR-frame queries, one lane per query, run to its
+// end. mode 1: the query is the association path's (a) alone; 2: the cost path's (c) alone; 3 / 4: both paths are searched
+// together, the query as a (3) or as c (4), its partner 1e-7 beside it as the reference's two float/double islands are.
+// out_idx = ORIGINAL point index, out_d2 = exact squared distance.
+__global__ __launch_bounds__(256) void iba_nn_probe_kernel(DevProblem dp, int frame, const double* __restrict__ q, int n, int mode,
+                                                           uint32_t* __restrict__ out_idx, double* __restrict__ out_d2) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    TreeNode* s_nodes = (TreeNode*)smem;
+    const FrameHdr& h = dp.frames[frame];
+    const uint32_t P = h.P, D = h.depth;
+    for (uint32_t i = threadIdx.x; i < (1u << D) - 1u; i += blockDim.x) s_nodes[i] = dp.nodes[h.node_base + i];
+    __syncthreads();
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= n || P == 0) return;
+    const float4* p4 = dp.pts4 + h.pt_base;
+    const uint32_t* perm = dp.perm + h.pt_base;
+    const double x = q[3 * e], y = q[3 * e + 1], z = q[3 * e + 2];
+    const double ox = x + 1e-7, oy = y - 1e-7, oz = z + 0.5e-7;
+    IBA_LANE_NN_DECL;
+    actA = mode != 2; actC = mode != 1;
+    if (actA) { const bool own = mode != 4; ax = own ? x : ox; ay = own ? y : oy; az = own ? z : oz; }
+    if (actC) { const bool own = mode != 3; qx = own ? x : ox; qy = own ? y : oy; qz = own ? z : oz; }
+    lane_nn_begin(IBA_LANE_NN_PASS);
+    do {
+        if (mode == 1) lane_nn_visit<1>(IBA_LANE_NN_PASS, s_nodes, p4, perm, P, D);
+        else if (mode == 2) lane_nn_visit<2>(IBA_LANE_NN_PASS, s_nodes, p4, perm, P, D);
+        else lane_nn_visit<3>(IBA_LANE_NN_PASS, s_nodes, p4, perm, P, D);
+    } while (go >= 0);
+    const bool a = mode == 1 || mode == 3;
+    const uint32_t bp = a ? bposA : bposC;
+    out_idx[e] = bp != kNone ? perm[bp] : kNone; out_d2[e] = a ? bestA : bestC;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // iba_nn_kernel<WHICH>. WHICH bit 0: association-path queries present, bit 1: cost-path queries.
 // grid: 8 * ceil(n_frames/8) * NG * NS blocks (NG = ceil(B / CG) candidate groups, NS keypoint slices) of kNNThreads.
@@ -563,15 +725,14 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 // which lane ran which search does not matter, so the sums are bitwise reproducible. One record of kNNPartial doubles per
 // (candidate, frame, slice).
 // ------------------------------------------------------------------------------------------------------------------
-template <int WHICH>
+template <int WHICH, int REFIT>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_NN_WAVES, IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
                                                                                                   double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist, const float4* __restrict__ fmp,
-                                                                                                  const uint32_t* __restrict__ lcount, int flist_stride, int dbg_mode, double4* __restrict__ frefit) {
+                                                                                                  const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int dbg = dbg_mode & 0xff;
-    // plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch = the searches only (neighbour and query
-    // offset of every entry -> flist.z / frefit), kRefitSums = the fixed-order sums over the distances the fit kernel left in frefit
-    const int refit = dbg_mode >> 8;
+    // kRefitSearch = the searches only (neighbour and query offset of every entry -> flist.z / frefit), kRefitSums = the fixed-order
+    // sums over the distances the fit kernel left in frefit
+    constexpr int refit = REFIT;
     typedef __attribute__((address_space(4))) const NNArgs NNArgsC;
     NNArgsC* ka = (NNArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)ka_by_value;
@@ -579,7 +740,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
 #define prm (ka->prm)
 #define lay (ka->lay)
     constexpr int T = kNNThreads;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int nf = dp.n_frames;
     const int per_xcd = (nf + 7) / 8;
     const int NG = (B + CG - 1) / CG;
@@ -589,7 +750,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
     if (f >= nf || jj / per_frame >= per_xcd) return;
     const int g = (jj % per_frame) / NS, sl = (jj % per_frame) % NS;
     const FrameHdr& h = dp.frames[f];
-    const uint32_t P = h.P, D = h.depth, K = h.K;
+    const uint32_t P = h.P, D = h.depth;
     const int cands_here = min(CG, B - g * CG);
     constexpr uint32_t kWantMask = ((WHICH & 2) ? kFlagC : 0u) | ((WHICH & 1) ? kFlagA : 0u);
 
@@ -622,7 +783,6 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
     const uint32_t* perm_g = dp.perm + h.pt_base;
     const PlaneRec* planes_cost = dp.plane_cost + h.pt_base;
     const PlaneRec* planes_local = dp.plane_local + h.pt_base;
-    const uint32_t first_leaf = (1u << D) - 1u;
 
     // per-thread partial sums of the final (fixed-order) pass: thread t sums entries of candidate t / 32
     double fin_sum = 0.0; uint32_t fin_c = 0, fin_v = 0, fin_pl = 0, fin_pt = 0;
@@ -644,15 +804,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
         // ---- the searches: persistent lanes, refilled from the work list ----
         if (refit != kRefitSums) {
             bool have = false;
-            uint32_t w = 0u, wi_list = 0u, b_own = 0u, kk = 0u;
-            bool actA = false, actC = false;
-            double ax = NAN, ay = NAN, az = NAN, qx = NAN, qy = NAN, qz = NAN;
-            double bestA = INFINITY, bestC = INFINITY; uint32_t bposA = kNone, bposC = kNone;
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f, delc = 0.f, e_lin = 0.f, e_const = 0.f;
-            float pd2[kPathMax];
-            uint32_t side = 0u, done = 0u, node = 0u; int go = -1;
-#pragma unroll
-            for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
+            uint32_t w = 0u;   // the lane's work entry: candidate w % CG of the group, list position i_lo + w / CG
+            IBA_LANE_NN_DECL;
             bool exhausted = false;   // wave-uniform: the work list has been handed out
             for (;;) {
                 // ---- refill: idle lanes claim the next entries (one LDS atomic per wave) ----
@@ -669,13 +822,11 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                         uint4 e = make_uint4(0u, 0u, 0u, 0u);
                         float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (wn < c1 && il < s_n[cc]) {
-                            b_own = (uint32_t)(g * CG) + cc;
-                            const size_t at = ((size_t)b_own * nf + f) * (size_t)flist_stride + il;
+                            const size_t at = ((size_t)((uint32_t)(g * CG) + cc) * nf + f) * (size_t)flist_stride + il;
                             e = flist[at]; mp = fmp[at];
                         }
                         if (e.w & kWantMask) {
-                            w = wn; wi_list = il;
-                            kk = e.x;
+                            w = wn;
                             actC = (WHICH & 2) && (e.w & kFlagC);
                             actA = (WHICH & 1) && (e.w & kFlagA);
                             // the two MapPoint -> LiDAR-frame queries (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
@@ -710,123 +861,18 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                                 qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
                                 qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
                             }
-                            // float steering point o and the radius del >= |q - o| per axis of both queries (see nn_dual_step)
-                            o0 = (float)(actC ? qx : ax); o1 = (float)(actC ? qy : ay); o2 = (float)(actC ? qz : az);
-                            double m = 0.0;
-                            if (actA) m = fmax(fmax(fabs(ax - (double)o0), fabs(ay - (double)o1)), fabs(az - (double)o2));
-                            if (actC) m = fmax(m, fmax(fmax(fabs(qx - (double)o0), fabs(qy - (double)o1)), fabs(qz - (double)o2)));
-                            const float del = (float)m * 1.00001f + 1e-30f;
-                            delc = del * 0.999999f;
-                            e_lin = 2.01f * del; e_const = 3.01f * del * del + 2.1e-19f * e_lin + 1e-37f;
-                            bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
-                            side = 0u; done = 0u; node = 0u; go = -1;
+                            lane_nn_begin(IBA_LANE_NN_PASS);
                             have = true;
                         }
                     }
                 }
                 if (__ballot(have) == 0ull) { if (exhausted) break; continue; }   // a claim of 64 entries none of which wants a search: claim again
                 if (have && dbg == 4) { have = false; continue; }
-                if (have) {
-                    // ---- one leaf visit (nn_dual_step with one lane per query pair; the path registers persist) ----
-                    auto lower_bound = [&](float d) { const float a = fmaxf(fmaf(fabsf(d), 0.999999f, -delc), 0.f); return a * a; };
-                    int start = 0;
-                    if (go >= 0) {   // enter the far child at level go
-                        const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
-                        done |= 1u << go; side ^= 1u << go;
-                        node = 2u * anc + 1u + ((side >> go) & 1u);
-                        start = go + 1;
-                    }
-                    {
-                        const uint32_t keep = (1u << start) - 1u;
-                        side &= keep; done &= keep;
-                        uint32_t n1 = node + 1u;
-#pragma unroll
-                        for (int L = 0; L < kPathMax; ++L) {
-                            if (L >= (int)D) break;
-                            if (L >= start) {
-                                const TreeNode n = s_nodes[n1 - 1u];
-                                const float d = (n.dim == 0 ? o0 : (n.dim == 1 ? o1 : o2)) - n.split;
-                                const uint32_t r = (~__float_as_uint(d)) >> 31;
-                                pd2[L] = lower_bound(d);
-                                side |= r << L;
-                                n1 = (n1 << 1) | r;
-                            }
-                        }
-                        node = n1 - 1u;
-                    }
-                    {
-                        const uint32_t j = node - first_leaf;
-                        const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
-                        float m1 = INFINITY, m2 = INFINITY; uint32_t mi = kNone;
-                        auto err_of = [&](float u) { return fmaf(1.001f * e_lin, __builtin_amdgcn_sqrtf(3.f * u), fmaf(1.5e-6f, u, e_const)); };
-                        constexpr int kLeafBatch = IBA_NN_LEAF_BATCH;
-                        for (uint32_t i0 = lo; i0 < hi; i0 += (uint32_t)kLeafBatch) {
-                            float X[kLeafBatch], Y[kLeafBatch], Z[kLeafBatch];
-#pragma unroll
-                            for (int u = 0; u < kLeafBatch; ++u) {
-                                const uint32_t iu = i0 + (uint32_t)u, ic = iu < hi ? iu : hi - 1u;
-                                const float4 v = p4[ic]; X[u] = v.x; Y[u] = v.y; Z[u] = v.z;
-                            }
-#pragma unroll
-                            for (int u = 0; u < kLeafBatch; ++u) {
-                                const uint32_t i = i0 + (uint32_t)u;
-                                const float dx = o0 - X[u], dy = o1 - Y[u], dz = o2 - Z[u];
-                                float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                                uu = i < hi ? uu : INFINITY;
-                                mi = uu < m1 ? i : mi;
-                                m2 = __builtin_amdgcn_fmed3f(m1, m2, uu);
-                                m1 = vmin(m1, uu);
-                            }
-                        }
-                        const float mono = 4.f * e_lin * e_lin;
-                        const float thi = m1 + err_of(m1);
-                        bool single = m2 >= mono && m2 - err_of(m2) > thi;
-                        const float bnear = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
-                        const float bmax = fmaf(fabsf(bnear), 1.2e-7f, bnear);
-                        const bool skip = m1 >= mono && m1 - err_of(m1) > bmax;
-#ifdef IBA_LEAF_FORCE_SINGLE
-                        single = true;
-#endif
-                        if (mi != kNone && !skip) {
-                            uint32_t i = single ? mi : lo;
-                            while (single || i < hi) {
-                                const float4 pv = p4[i];
-                                bool take = single;
-                                if (!single) {
-                                    const float dx = o0 - pv.x, dy = o1 - pv.y, dz = o2 - pv.z;
-                                    const float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                                    take = uu - err_of(uu) <= thi;
-                                }
-                                if (take) {
-                                    const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
-                                    if (WHICH & 1) {
-                                        const double dx = ax - x, dy = ay - y, dz = az - z;
-                                        nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, i, perm_g);
-                                    }
-                                    if (WHICH & 2) {
-                                        const double dx = qx - x, dy = qy - y, dz = qz - z;
-                                        nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, i, perm_g);
-                                    }
-                                }
-                                if (single) break;
-                                ++i;
-                            }
-                        }
-                    }
-                    {   // deepest level whose far side may still be within reach of either query
-                        const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
-                        uint32_t cnd = 0u;
-#pragma unroll
-                        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= bestf ? 1u : 0u) << L;
-                        cnd &= ~done & ((1u << D) - 1u);
-                        done |= ~cnd;
-                        go = cnd ? 31 - __clz((int)cnd) : -1;
-                    }
-                }
+                if (have) lane_nn_visit<WHICH>(IBA_LANE_NN_PASS, s_nodes, p4, perm_g, P, D);
                 if (have && go < 0) {
                     // ---- the finished searches of this entry ----
                     if (dbg != 5) {
-                    const size_t at = ((size_t)b_own * nf + f) * (size_t)flist_stride + wi_list;
+                    const size_t at = ((size_t)((uint32_t)(g * CG) + (w & ((1u << cg_shift) - 1u))) * nf + f) * (size_t)flist_stride + (i_lo + (w >> cg_shift));
                     if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2)) {   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
                         bool state = false;   // refit: settled by the fit kernel
                         if (!refit) { const PlaneRec r2 = planes_local[bposA]; state = local_neigh_ok(prm, r2) && local_plane_ok(prm, r2); }   // pointcloud.h:699-717
@@ -839,7 +885,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                         if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
                         else {
                             PlaneRec rec; rec.k = 0;
-                            if (prm.use_plane) rec = planes_cost[bposC];
+                            if (prm.use_plane) rec = planes_cost[bposC];   // the whole record in one round trip
                             res = cost_res(prm, prm.use_plane != 0, rec, ex, ey, ez);
                         }
                     }

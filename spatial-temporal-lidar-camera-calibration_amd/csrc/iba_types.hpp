@@ -15,7 +15,6 @@ namespace iba {
 #endif
 constexpr int kChunk = IBA_CHUNK;           // points per culling chunk (~3 kd leaves): static AABB, frustum-tested per candidate
 constexpr int kMaxCovis = 22;        // covisible KFs per frame: one match bit each beside the two flag bits of the 24-bit-exact float flag word.
-constexpr int kMaxCovisRefit = 10;   // (the g2o twin IBAPlaneEdge pads to 10, IBACalib.hpp:133-137; the one-kernel refit path packs 10 bits)
 constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum block
 #ifndef IBA_GRID_CELL
 #define IBA_GRID_CELL 2

@@ -1,4 +1,4 @@
-"""GPU parity of the kd search itself (iba_debug_nn = the frame kernels' nn_dual_step run to its end) against brute force
+"""GPU parity of the kd search itself (iba_debug_nn = the search kernel's own per-lane search, lane_nn_visit, run to its end) against brute force
 in float64 with the same expression order and the lowest-index tie rule. The search filters leaves in float32 and
 confirms in double, so the queries are chosen to sit where a float cannot tell two points apart: exact midpoints of
 point pairs (exact ties), midpoints moved by 1e-6 ... 1e-15 of the pair distance (near ties on both sides of what
@@ -44,19 +44,19 @@ def _queries(pts64, rng):
     return np.concatenate(qs)
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 8, 32])
-def test_kd_search_is_exact_where_float_is_blind(pkg, synth, abi, lanes):
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])   # the query alone on either path of the kernel, and with a partner 1e-7 beside it
+def test_kd_search_is_exact_where_float_is_blind(pkg, synth, abi, mode):
     prob, meta = synth.make_scene(n_frames=2, pts_per_frame=6000, n_keypoints=300, seed=41, new_mappoints=50, scan_kp=100)
     a = {k: v.copy() for k, v in prob.arrays.items()}
     pts = a["pts_xyz"].reshape(-1, 3)
     pts[6000 + 100:6000 + 400] = pts[6000 + 1000:6000 + 1300]          # frame 1 also carries 300 exact duplicates
     prob2 = abi.Problem(**a)
     h = pkg.IbaHandle(prob2, abi.reference_yaml_params())
-    rng = np.random.default_rng(7 + lanes)
+    rng = np.random.default_rng(7 + mode)
     for f in (0, 1):
         pts64 = prob2.frame_points(f).astype(np.float64)
         q = _queries(pts64, rng)
-        gi, gd = h.debug_nn(f, q, lanes)
+        gi, gd = h.debug_nn(f, q, mode)
         bi, bd = _brute(pts64, q)
         assert np.array_equal(gd, bd), (f, np.flatnonzero(gd != bd)[:5])
         assert np.array_equal(gi.astype(np.int64), bi), (f, np.flatnonzero(gi != bi)[:5])

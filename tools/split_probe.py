@@ -18,7 +18,7 @@ def phases():
     a, n, r = C.c_float(0), C.c_float(0), C.c_float(0)
     L.iba_last_phase_ms(h.h, C.byref(a), C.byref(n), C.byref(r))
     return a.value, n.value, r.value
-tag = "CG=%s NS=%s mono=%s" % (os.environ.get("IBA_NN_CG", "-"), os.environ.get("IBA_NN_NS", "-"), os.environ.get("IBA_MONOLITHIC", "0"))
+tag = "CG=%s" % os.environ.get("IBA_NN_CG", "-")
 for B in (1, 8, 14, 64):
     xs = synth.perturb(meta["x_gt"], np.random.default_rng(0), rot=5e-4 * wide, trans=5e-3 * wide, scale_rel=1e-3 * wide, n=B)
     for mode, fn in (("full", h.eval_full), ("cost", h.eval_cost)):
