@@ -119,25 +119,38 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     const uint32_t P = h.P, Ppad = h.Ppad, K = h.K;
     const float* gxs = dp.xs + h.pt_base; const float* gys = dp.ys + h.pt_base; const float* gzs = dp.zs + h.pt_base;
 
-    // ---- phase 0: LDS init (first element per thread of each static table fetched before anything is stored) ----
+    // ---- phase 0: LDS init. The static tables come from global memory (L2) in batches: all loads of a batch are issued before
+    //      the first store waits for one, so the phase costs about two memory round trips instead of one per table row ----
     const uint32_t nbw = (h.gw * h.gh + 31u) >> 5;
     const uint32_t ncs = h.gwc * h.ghc + 1u;
     const uint32_t ut = (uint32_t)tid;
-    uint32_t bv = 0u, cv0 = 0u, cv1 = 0u; double rv = 0.0;
-    if (ut < nbw) bv = dp.bitmap[h.bitmap_base + ut];
-    if (ut < ncs) cv0 = dp.coarse_start[h.coarse_base + ut];
-    if (ut + kThreads < ncs) cv1 = dp.coarse_start[h.coarse_base + ut + kThreads];
+    double rv = 0.0;
     if (ut < h.n_slots * 12u) rv = dp.slots[h.slot_base + ut / 12].rel[ut % 12];
     const float4* boxes = (const float4*)(dp.chunk_box + 8 * h.box_base);   // two 16-byte loads per chunk; the first pass of the frustum test is fetched here
     const uint32_t nchunks = (P + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
     float4 blo_n = make_float4(0.f, 0.f, 0.f, 0.f), bhi_n = blo_n;
     if (ut < nchunks) { blo_n = boxes[2 * (size_t)ut]; bhi_n = boxes[2 * (size_t)ut + 1]; }
-    for (uint32_t i = tid; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = dp.kp_uv[h.kp_base + i]; s_kfl[i] = dp.kp_fl[h.kp_base + i]; }
-    if (ut < nbw) s_bitmap[ut] = bv;
-    if (ut < ncs) s_cstart[ut] = (uint16_t)cv0;
-    if (ut + kThreads < ncs) s_cstart[ut + kThreads] = (uint16_t)cv1;
-    for (uint32_t i = ut + kThreads; i < nbw; i += kThreads) s_bitmap[i] = dp.bitmap[h.bitmap_base + i];
-    for (uint32_t i = ut + 2u * kThreads; i < ncs; i += kThreads) s_cstart[i] = (uint16_t)dp.coarse_start[h.coarse_base + i];
+    {
+        const uint32_t* gbm = dp.bitmap + h.bitmap_base; const uint32_t* gcs = dp.coarse_start + h.coarse_base;
+        const float2* guv = dp.kp_uv + h.kp_base; const uint32_t* gfl = dp.kp_fl + h.kp_base;
+        uint32_t bw[8], cw[4], fw[4]; float2 uv[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; bw[j] = i < nbw ? gbm[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; cw[j] = i < ncs ? gcs[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; uv[j] = make_float2(0.f, 0.f); fw[j] = 0u; if (i < K) { uv[j] = guv[i]; fw[j] = gfl[i]; } }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; if (i < nbw) s_bitmap[i] = bw[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; if (i < ncs) s_cstart[i] = (uint16_t)cw[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; if (i < K) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = uv[j]; s_kfl[i] = fw[j]; } }
+        // what the first batch did not cover (more than 2048 keypoints, a larger image)
+        for (uint32_t i = ut + 8u * kThreads; i < nbw; i += kThreads) s_bitmap[i] = gbm[i];
+        for (uint32_t i = ut + 4u * kThreads; i < ncs; i += kThreads) s_cstart[i] = (uint16_t)gcs[i];
+        for (uint32_t i = ut + 4u * kThreads; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = guv[i]; s_kfl[i] = gfl[i]; }
+    }
     if (ut < h.n_slots * 12u) s_rel[ut] = rv;
     if (tid < 4) s_misc[tid] = 0u;
     __syncthreads();
