@@ -454,17 +454,29 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
         uint32_t* s_cnt3 = (uint32_t*)s_red;
         uint32_t at = usedC ? cntC : (usedA ? cntA : 0u);   // entries of the waves before this one
         for (int w = 0; w < kWaves; ++w) n3 += usedC ? s_cnt3[w * 3 + 1] : (usedA ? s_cnt3[w * 3 + 2] : 0u);
-        for (uint32_t k = kbeg + (uint32_t)lane; k < kbeg + kw; k += 64u) {
-            const bool valid = k < K && s_best_idx[k] != kNone;
-            const int w = valid ? (int)s_kfl[k] : 0;
-            const bool wantk = (usedC && w != 0) || (usedA && (w & 3) == 3);
-            const unsigned long long bal = __ballot(wantk);
-            if (wantk) {
-                const uint32_t i = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                s_list[i] = k | (((uint32_t)w & 3u) << 16);   // the slot mask is read from s_kfl where it is needed
-                s_pos[i] = inv_perm[s_best_idx[k]];
+        for (uint32_t k0 = kbeg + (uint32_t)lane; k0 < kbeg + kw; k0 += 256u) {   // four steps at a time: their gathers are in flight together
+            uint32_t ip[4]; int ww[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = k0 + 64u * (uint32_t)j;
+                const bool valid = k < kbeg + kw && k < K && s_best_idx[k] != kNone;
+                const int w = valid ? (int)s_kfl[k] : 0;
+                const bool wantk = (usedC && w != 0) || (usedA && (w & 3) == 3);
+                ww[j] = wantk ? (w & 3) | 4 : 0;
+                ip[j] = wantk ? inv_perm[s_best_idx[k]] : 0u;
             }
-            at += (uint32_t)__popcll(bal);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = k0 + 64u * (uint32_t)j;
+                const bool wantk = ww[j] != 0;
+                const unsigned long long bal = __ballot(wantk);
+                if (wantk) {
+                    const uint32_t i = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    s_list[i] = k | (((uint32_t)ww[j] & 3u) << 16);   // the slot mask is read from s_kfl where it is needed
+                    s_pos[i] = ip[j];
+                }
+                at += (uint32_t)__popcll(bal);
+            }
         }
     }
     __syncthreads();
