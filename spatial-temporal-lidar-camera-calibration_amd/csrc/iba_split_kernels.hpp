@@ -242,11 +242,13 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
             const uint32_t b4 = (uint32_t)s_vlist[g / (uint32_t)(kChunk / 4)] * (uint32_t)kChunk + (g % (uint32_t)(kChunk / 4)) * 4u;
             return b4 < Ppad ? b4 : kNone;
         };
-        float4 X = nan4, Y = nan4, Z = nan4;
-        uint32_t base = group_base((uint32_t)tid);
+        // two passes ahead: a frame streams ~2 passes per lane, so both are in flight before the first is looked at
+        float4 X = nan4, Y = nan4, Z = nan4, X1 = nan4, Y1 = nan4, Z1 = nan4;
+        uint32_t base = group_base((uint32_t)tid), base1 = group_base((uint32_t)tid + kThreads);
         if (base != kNone) { X = *(const float4*)(gxs + base); Y = *(const float4*)(gys + base); Z = *(const float4*)(gzs + base); }
+        if (base1 != kNone) { X1 = *(const float4*)(gxs + base1); Y1 = *(const float4*)(gys + base1); Z1 = *(const float4*)(gzs + base1); }
         for (uint32_t it = 0; it < n_iter; ++it) {
-            const uint32_t nbase = group_base((uint32_t)tid + (it + 1u) * kThreads);
+            const uint32_t nbase = group_base((uint32_t)tid + (it + 2u) * kThreads);
             float4 Xn = nan4, Yn = nan4, Zn = nan4;
             if (nbase != kNone) { Xn = *(const float4*)(gxs + nbase); Yn = *(const float4*)(gys + nbase); Zn = *(const float4*)(gzs + nbase); }
             const float px[4] = {X.x, X.y, X.z, X.w}, py[4] = {Y.x, Y.y, Y.z, Y.w}, pz[4] = {Z.x, Z.y, Z.z, Z.w};
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
                     }
                 }
             }
-            X = Xn; Y = Yn; Z = Zn; base = nbase;
+            X = X1; Y = Y1; Z = Z1; base = base1; X1 = Xn; Y1 = Yn; Z1 = Zn; base1 = nbase;
         }
     }
     __syncthreads();
