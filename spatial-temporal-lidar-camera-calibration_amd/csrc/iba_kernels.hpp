@@ -588,6 +588,9 @@ __global__ void iba_kernarg_probe_kernel(KArgs ka_by_value, int32_t* ok) {
 #else
 #define IBA_JAC_CONTRACT _Pragma("clang fp contract(off)")
 #endif
+// the accumulation H += (w J_i) J_j of terms that are already formed may fuse its multiply-add: that changes the sums by parts in
+// 1e-16 of a term, not by the cancellation the Jacobian chain is sensitive to (measured: per-entry agreement unchanged)
+#define IBA_ACC_CONTRACT _Pragma("clang fp contract(fast)")
 struct NAcc { double H[28], b[7], chi2, cost, nf2d, nfpl, nfpt, nres; };
 
 __device__ __forceinline__ void huber_w(double a, double s, double& rho0, double& w) {
@@ -662,7 +665,7 @@ __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, cons
     double z6[6];
     double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0;
     const int nconv = plane_factor_core(c, h, dp, k, K, u0, v0, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
-IBA_JAC_CONTRACT
+IBA_ACC_CONTRACT
         ssq += ru * ru + rv * rv;
         G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
         Gr += gu * ru + gv * rv; Hr += hu * ru + hv * rv;
@@ -670,13 +673,16 @@ IBA_JAC_CONTRACT
     if (nconv == 0) return;
     double rho0, w; huber_w(prm.robust_kernel_delta, ssq, rho0, w);
     A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0 * nconv;
-    for (int i = 0; i < 6; ++i) {
-        const double wz = w * z6[i];
-        for (int j = i; j < 6; ++j) A.H[hidx(i, j)] += wz * G * z6[j];
-        A.H[hidx(i, 6)] += wz * GH;
-        A.b[i] += wz * Gr;
+    {
+        IBA_ACC_CONTRACT
+        for (int i = 0; i < 6; ++i) {
+            const double wz = w * z6[i], wzG = wz * G;
+            for (int j = i; j < 6; ++j) A.H[hidx(i, j)] += wzG * z6[j];
+            A.H[hidx(i, 6)] += wz * GH;
+            A.b[i] += wz * Gr;
+        }
+        A.H[27] += w * HH; A.b[6] += w * Hr;
     }
-    A.H[27] += w * HH; A.b[6] += w * Hr;
 }
 
 // M = Rlc (s m) + tlc and dM/dx for the 3d-3d factors (IBACalib2.hpp:570-584, 611-625)
@@ -708,13 +714,13 @@ __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const 
         for (int kk = 0; kk < 7; ++kk) J[kk] = (dM[kk][0] * n[0] + dM[kk][1] * n[1]) + dM[kk][2] * n[2];
         double rho0, w; huber_w(prm.robust_kernel_3ddelta, r * r, rho0, w);
         A.cost += 0.5 * rho0; A.chi2 += r * r; A.nfpl += 1.0; A.nres += 1.0;
-        for (int i = 0; i < 7; ++i) { const double wj = w * J[i]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * J[j]; A.b[i] += wj * r; }
+        { IBA_ACC_CONTRACT for (int i = 0; i < 7; ++i) { const double wj = w * J[i]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * J[j]; A.b[i] += wj * r; } }
     } else {
         const double ssq = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
         double rho0, w; huber_w(prm.robust_kernel_3ddelta, ssq, rho0, w);
         A.cost += 0.5 * rho0; A.chi2 += ssq; A.nfpt += 1.0; A.nres += 3.0;
-        for (int r = 0; r < 3; ++r)
-            for (int i = 0; i < 7; ++i) { const double wj = w * dM[i][r]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * dM[j][r]; A.b[i] += wj * e[r]; }
+        { IBA_ACC_CONTRACT for (int r = 0; r < 3; ++r)
+            for (int i = 0; i < 7; ++i) { const double wj = w * dM[i][r]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * dM[j][r]; A.b[i] += wj * e[r]; } }
     }
 }
 

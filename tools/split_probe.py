@@ -9,7 +9,8 @@ abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 wide = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0   # multiplier on the candidate spread
-prob, meta = synth.make_scene(n_frames=F, pts_per_frame=P, seed=0)
+KP = int(os.environ.get("PROBE_KEYPOINTS", "2000"))
+prob, meta = synth.make_scene(n_frames=F, pts_per_frame=P, n_keypoints=KP, seed=0)
 h = pkg.IbaHandle(prob, abi.reference_yaml_params())
 h.set_timing(True)
 L = pkg.load_library()
