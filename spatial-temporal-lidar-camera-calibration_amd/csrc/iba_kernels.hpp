@@ -756,22 +756,28 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
     const float4* p4 = dp.pts4 + h.pt_base;
     const PlaneRec* planes = prm.plane_cache ? dp.plane_local + h.pt_base
                                              : dp.scratch_local + (size_t)(per_cand ? dp.scratch_slot_base + b : 0) * (size_t)dp.n_pt_total + h.pt_base;
+    uint4 e_n = make_uint4(0u, kNone, kNone, 0u);
+    if ((uint32_t)tid < n) e_n = fl[tid];
     for (uint32_t i = tid; i < n; i += kFactorThreads) {
-        const uint4 e = fl[i];
+        const uint4 e = e_n;
+        if (i + kFactorThreads < n) e_n = fl[i + kFactorThreads];   // the next entry is in flight during this one's arithmetic
         const uint32_t k = e.x;
+        // the gathers of both blocks of the entry are issued together
+        const bool has3 = e.z != kNone;
+        const uint32_t pos3 = e.z & 0x7FFFFFFFu;
+        float4 pt3 = make_float4(0.f, 0.f, 0.f, 0.f), mp3 = pt3; double n3x = 0, n3y = 0, n3z = 0;
+        if (has3) { pt3 = p4[pos3]; mp3 = dp.kp_mp[h.kp_base + k]; const PlaneRec& r3 = planes[pos3]; n3x = r3.nx; n3y = r3.ny; n3z = r3.nz; }
         if (e.y != kNone) {
-            const PlaneRec rec = planes[e.y];
+            const PlaneRec& rec = planes[e.y];
             const float4 pt = p4[e.y];
             const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, n0[3] = {rec.nx, rec.ny, rec.nz};
             const float2 uv = dp.kp_uv[h.kp_base + k];
             plane_factor_accum(c, h, dp, prm, k, h.K, (double)uv.x, (double)uv.y, p0, n0, A);
         }
-        if (e.z != kNone) {
-            const uint32_t pos = e.z & 0x7FFFFFFFu; const bool is_plane = (e.z >> 31) != 0;
-            const PlaneRec rec = planes[pos];
-            const float4 pt = p4[pos];
-            const double Q[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, nn[3] = {rec.nx, rec.ny, rec.nz};
-            p2x_factor_accum(c, h, prm, dp.kp_mp[h.kp_base + k], Q, nn, is_plane, A);
+        if (has3) {
+            const bool is_plane = (e.z >> 31) != 0;
+            const double Q[3] = {(double)pt3.x, (double)pt3.y, (double)pt3.z}, nn[3] = {n3x, n3y, n3z};
+            p2x_factor_accum(c, h, prm, mp3, Q, nn, is_plane, A);
         }
     }
     // fixed-order reduction through LDS: every lane parks its 41 sums (two halves of <= 21 through an 11 KB transposing
