@@ -605,7 +605,7 @@ __device__ __forceinline__ int hidx(int i, int j) { return i * 7 - (i * (i - 1))
 // (ru, rv) and their Jacobian rows are [gu * z6, hu], [gv * z6, hv] (z6 = dZ0/dx[0:6], last column d/ds).
 template <class SlotFn>
 __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K,
-                                                 double u0, double v0, const double* p0, const double* n0, double* z6, SlotFn slot) {
+                                                 double u0, double v0, const double* p0, const double* n0, double* z6, SlotFn slot, const double* rel_lds = nullptr) {
     IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
     double p0c[3], n0c[3];
     for (int r = 0; r < 3; ++r) {
@@ -642,7 +642,7 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
         mask &= mask - 1u;
         const float2 m = mnext;
         if (mask) mnext = mrow[(size_t)(__ffs((int)mask) - 1) * K];
-        const double* rel = dp.slots[h.slot_base + sl].rel;
+        const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel;   // the frame's relative poses: the caller's LDS copy, or global memory
         const double tx = rel[3] * c.s, ty = rel[7] * c.s, tz = rel[11] * c.s;   // _t *= _s (IBACalib2.hpp:175)
         const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx;
         const double P1y = ((rel[4] * P0x + rel[5] * P0y) + rel[6] * P0z) + ty;
@@ -660,7 +660,7 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
 }
 
 __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
-                                          double u0, double v0, const double* p0, const double* n0, NAcc& A) {
+                                          double u0, double v0, const double* p0, const double* n0, NAcc& A, const double* rel_lds = nullptr) {
     IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
     double z6[6];
     double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0;
@@ -669,7 +669,7 @@ IBA_ACC_CONTRACT
         ssq += ru * ru + rv * rv;
         G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
         Gr += gu * ru + gv * rv; Hr += hu * ru + hv * rv;
-    });
+    }, rel_lds);
     if (nconv == 0) return;
     double rho0, w; huber_w(prm.robust_kernel_delta, ssq, rho0, w);
     A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0 * nconv;
@@ -742,10 +742,13 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
                                                                     double* __restrict__ partials, int nrec, int rec_base) {
     __shared__ double s_part[kFactorThreads / 64][48];
     __shared__ double s_tr[kFactorThreads / 64][21][65];   // [sum][lane], rows padded against bank conflicts
+    __shared__ double s_rel[kMaxCovis * 12];               // relative poses of the frame's covisible slots
     const int f = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameHdr& h = dp.frames[f];
     const Cand& c = cands[b];
+    for (uint32_t i = tid; i < h.n_slots * 12u; i += kFactorThreads) s_rel[i] = dp.slots[h.slot_base + i / 12u].rel[i % 12u];
+    __syncthreads();
     const size_t row = (size_t)(per_cand ? b : 0) * dp.n_frames + f;
     const uint4* fl = flist + row * (size_t)flist_stride;
     const uint32_t n = fcount[row];
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
             const float4 pt = p4[e.y];
             const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, n0[3] = {rec.nx, rec.ny, rec.nz};
             const float2 uv = dp.kp_uv[h.kp_base + k];
-            plane_factor_accum(c, h, dp, prm, k, h.K, (double)uv.x, (double)uv.y, p0, n0, A);
+            plane_factor_accum(c, h, dp, prm, k, h.K, (double)uv.x, (double)uv.y, p0, n0, A, s_rel);
         }
         if (has3) {
             const bool is_plane = (e.z >> 31) != 0;
