@@ -788,6 +788,17 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
     double* s_cd = (double*)(smem + lay.off_cd);             // [kMaxGroup][kCdDoubles] candidate constants of the query transform
     int cg_shift = 0; while ((1 << cg_shift) < CG) ++cg_shift;   // CG is a power of two (host)
 
+    // ---- a slice beyond every list of the group has nothing to search or sum: zero record, done (the lists hold ~575 of
+    //      up to 7 x 128 positions at the bench shape: two blocks in seven) ----
+    {
+        uint32_t nmax_u = 0u;
+        for (int cc = 0; cc < cands_here; ++cc) nmax_u = max(nmax_u, lcount[(size_t)(g * CG + cc) * nf + f]);   // uniform addresses: scalar loads
+        if ((uint32_t)sl * kSliceW >= nmax_u) {
+            const int cc = tid >> 5, q = tid & 31;
+            if (cc < cands_here && q < kNNPartial) nn_partials[((size_t)(g * CG + cc) * nn_nrec + (size_t)f * NS + sl) * kNNPartial + q] = 0.0;
+            return;
+        }
+    }
     // ---- kd nodes -> LDS; list lengths of the group's candidates ----
     const uint32_t nnodes = (1u << D) - 1u;
     uint32_t my_n = 0u;
