@@ -76,4 +76,11 @@ def test_more_than_sixty_four_candidates_per_call(pkg, synth, abi, scene_small):
     c3 = h.eval_cost(xs)   # the cost-only chain lists other keypoints: same terms, another summation order
     for a, b in zip(c3, cost):
         assert all(getattr(a, k) == getattr(b, k) for k in INT) and abs(a.f1 - b.f1) <= 1e-13 * b.f1 and abs(a.f2 - b.f2) <= 1e-13 * b.f2
+    # the same batch with every plane fitted inside its evaluation (three chunks through the fit kernels): bit for bit
+    h.set_params(abi.reference_yaml_params(plane_cache=0))
+    cr, nr = h.eval_full(xs)
+    for a, b in zip(cost, cr):
+        assert all(x == y or (x != x and y != y) for x, y in zip(a.as_dict().values(), b.as_dict().values()))
+    for a, b in zip(nrm, nr):
+        assert np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.counts() == b.counts()
     h.close()
