@@ -71,7 +71,7 @@ typedef struct iba_problem_desc {
     const float* Tcw; /* [F*12] */
 
     /* pKF->GetBestCovisibilityKeyFramesSafe(num_best_covis) (or ByWeight), iba_global.cpp:254-258.
-     * One "slot" per (reference KF, covisible KF) pair; at most 22 per reference KF (10 with plane_cache = 0). */
+     * One "slot" per (reference KF, covisible KF) pair; at most 22 per reference KF. */
     const uint64_t* covis_offset; /* [F+1] slots of frame f are covis_offset[f]..covis_offset[f+1] */
     const int32_t* covis_frame;   /* [S] frame index of the covisible KF */
     /* pKFConv->GetPose() * InvRefCVPose evaluated in CV_32F (iba_global.cpp:280), top 3 rows
