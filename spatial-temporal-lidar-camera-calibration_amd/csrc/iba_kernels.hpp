@@ -244,6 +244,7 @@ template <int SLOTS> struct FitLds {
     uint32_t list[64][kFitListStride(SLOTS)];   // tree positions of the kept neighbours, nearest first
     double far_d2[64];
     int32_t count[64];
+    double first_d2[4][16]; uint32_t first_pos[4][16];   // the four rows' first pass, sorted (see fit_list_rows)
 };
 
 // lists of the four scan points `cpos` (one per row; kNone: idle row) -> lds.list[fit], count[fit], far_d2[fit]; fit = fit0 + row
@@ -253,7 +254,8 @@ __device__ __forceinline__ void fit_list_rows(const float4* __restrict__ p4, con
     const int lane = threadIdx.x & 63, gl = lane & 15, row_sh = lane & 48;
     const bool act = cpos != kNone;
     double qx = 0, qy = 0, qz = 0;
-    if (act) { const float4 c = p4[cpos]; qx = (double)c.x; qy = (double)c.y; qz = (double)c.z; }
+    float qxf = 0.f, qyf = 0.f, qzf = 0.f;
+    if (act) { const float4 c = p4[cpos]; qxf = c.x; qyf = c.y; qzf = c.z; qx = (double)c.x; qy = (double)c.y; qz = (double)c.z; }
     double ed[SLOTS]; uint32_t ep[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) { ed[s] = INFINITY; ep[s] = kNone; }
@@ -270,6 +272,7 @@ __device__ __forceinline__ void fit_list_rows(const float4* __restrict__ p4, con
     for (int L = 0; L < kFitPathMax; ++L) pl[L] = INFINITY;
     uint32_t side = 0u, done = 0u, node = 0u;
     int go = act ? 0 : -1;   // level to (re)start the descent at; -1: the row has finished
+    bool first = true;       // wave-uniform: no candidate has been looked at yet
     while (__ballot(go >= 0) != 0ull) {
         uint32_t lo = 0, hi = 0;
         if (go >= 0) {
@@ -287,10 +290,9 @@ __device__ __forceinline__ void fit_list_rows(const float4* __restrict__ p4, con
                 if (L >= (int)D) break;
                 if (L >= go) {
                     const TreeNode n = nodes[n1 - 1u];
-                    const double qd = n.dim == 0 ? qx : (n.dim == 1 ? qy : qz);
-                    const double diff = qd - (double)n.split;
-                    const uint32_t r = diff >= 0.0 ? 1u : 0u;
-                    pl[L] = (float)(diff * diff) * 0.9999998f;
+                    const float df = (n.dim == 0 ? qxf : (n.dim == 1 ? qyf : qzf)) - n.split;   // the query is a scan point: float32-exact, so the sign is the exact one
+                    const uint32_t r = df >= 0.0f ? 1u : 0u;
+                    pl[L] = df * df * 0.9999996f;   // <= the exact squared difference (two roundings of 2^-24 each)
                     side |= r << L;
                     n1 = (n1 << 1) | r;
                 }
@@ -311,11 +313,32 @@ __device__ __forceinline__ void fit_list_rows(const float4* __restrict__ p4, con
             const unsigned long long m = __ballot(qual);
             if (m == 0ull) continue;
             const double d2q = qual ? d2 : INFINITY;
+            if (first) {
+                // the first pass of every row meets an empty list: rank its 16 candidates by (distance, lane) — 15 rotations within the
+                // row — and drop them into place through LDS, instead of 16 insertions
+                first = false;
+                uint32_t rank = 0u;
+#define IBA_FIT_RANK(KK) { const double od = dpp_f64<0x120 + KK>(d2q); const int ol = __builtin_amdgcn_update_dpp(0, gl, 0x120 + KK, 0xf, 0xf, true); /* row_ror:KK */ \
+                        rank += (od < d2q || (od == d2q && ol < gl)) ? 1u : 0u; }
+                IBA_FIT_RANK(1) IBA_FIT_RANK(2) IBA_FIT_RANK(3) IBA_FIT_RANK(4) IBA_FIT_RANK(5) IBA_FIT_RANK(6) IBA_FIT_RANK(7) IBA_FIT_RANK(8)
+                IBA_FIT_RANK(9) IBA_FIT_RANK(10) IBA_FIT_RANK(11) IBA_FIT_RANK(12) IBA_FIT_RANK(13) IBA_FIT_RANK(14) IBA_FIT_RANK(15)
+#undef IBA_FIT_RANK
+                const int row = lane >> 4;
+                lds.first_d2[row][rank] = d2q; lds.first_pos[row][rank] = qual ? i : kNone;
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int e = SLOTS * gl + s;
+                    ed[s] = e < 16 ? lds.first_d2[row][e & 15] : INFINITY; ep[s] = e < 16 ? lds.first_pos[row][e & 15] : kNone;
+                }
+                __syncthreads();
+            } else {
             const uint32_t m16 = (uint32_t)(m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffu;   // lanes-of-a-row with a candidate in ANY row
 #define IBA_FIT_STEP(L) if (m16 & (1u << L)) fit_insert<L, SLOTS>(d2q, base, ed, ep);
             IBA_FIT_STEP(0) IBA_FIT_STEP(1) IBA_FIT_STEP(2) IBA_FIT_STEP(3) IBA_FIT_STEP(4) IBA_FIT_STEP(5) IBA_FIT_STEP(6) IBA_FIT_STEP(7)
             IBA_FIT_STEP(8) IBA_FIT_STEP(9) IBA_FIT_STEP(10) IBA_FIT_STEP(11) IBA_FIT_STEP(12) IBA_FIT_STEP(13) IBA_FIT_STEP(14) IBA_FIT_STEP(15)
 #undef IBA_FIT_STEP
+            }
             double kv = ed[0];
 #pragma unroll
             for (int s = 1; s < SLOTS; ++s) kv = kth_slot == s ? ed[s] : kv;
