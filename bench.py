@@ -273,6 +273,13 @@ def main():
             t_other = float(t.item())
         res["value_plane_refit" if args.plane_cache else "value_plane_cache"] = units * B * nrep / t_other
         h.set_params(params)
+        # (3b) the plane memo itself: what a change of a plane parameter costs (every scan point of this rank refitted)
+        moved = abi.reference_yaml_params(plane_cache=1)
+        moved.norm_radius = params.norm_radius * 1.01; moved.neigh_radius = params.neigh_radius * 1.01
+        h.set_params(moved); h.set_params(abi.reference_yaml_params(plane_cache=1))   # warm
+        t0 = time.perf_counter(); h.set_params(moved); tm = time.perf_counter() - t0
+        extras["plane_memo"] = {"ms": tm * 1e3, "fits": int(prob.n_points // max(world, 1)) if args.scaling == "weak" else int(prob.n_points), "note": "iba_set_params with a changed norm_radius: iba_plane_kernel over every scan point, synchronous"}
+        h.set_params(params)
         if world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import lm_ref
