@@ -62,7 +62,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plane-cache", type=int, default=1, help="1 = memoise the x-independent local-plane fits (default), 0 = refit inside every evaluation")
     ap.add_argument("--no-extras", action="store_true", help="timed region and roofline only (profiling runs)")
+    ap.add_argument("--launch", choices=("auto", "ranks", "group"), default="auto",
+                    help="how N GPUs are driven: ranks = one process per GPU over torch.distributed / RCCL (what the driver's torchrun line gives; "
+                         "without WORLD_SIZE in the environment bench.py starts the N ranks itself), group = ONE process, iba_group_* with one issuing "
+                         "thread and one RCCL communicator per device; auto = ranks")
     args = ap.parse_args()
+
+    # ---- how many GPUs, really: --gpus is the contract, WORLD_SIZE what a launcher gave us; they must agree ----
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if env_world is not None and int(env_world) != args.gpus and not os.environ.get("IBA_FORCE_DIST"):
+        sys.exit("bench.py: --gpus %d disagrees with WORLD_SIZE=%s of the launcher: refusing to report a number for the wrong GPU count" % (args.gpus, env_world))
+    if args.launch == "group" and env_world is not None and int(env_world) > 1:
+        sys.exit("bench.py: --launch group is one process for all GPUs; do not start it under torchrun")
+    if env_world is None and args.gpus > 1:
+        import torch   # device_count() does not initialise the GPU: the ranks below are started from a process that never touched it
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d asked for, %d GPU(s) visible: not measuring a smaller job under that label" % (args.gpus, have))
+        if args.launch != "group":
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                   os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ, IBA_BENCH_SPAWNED="1")
+            sys.exit(subprocess.call(cmd, env=env))
 
     t_start = time.perf_counter()
 
@@ -78,6 +105,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or bool(os.environ.get("IBA_FORCE_DIST"))   # IBA_FORCE_DIST: exercise the RCCL path with one rank
+    group_mode = args.launch == "group"
+    n_gpus = args.gpus if group_mode else world
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -96,11 +125,18 @@ def main():
     base, meta = synth.make_scene(n_frames=args.frames, pts_per_frame=args.pts, n_keypoints=KEYPOINTS, seed=0)
     params = abi.reference_yaml_params(plane_cache=args.plane_cache)
     if args.scaling == "weak":     # configs[1]'s shape on every GPU, tiled once per rank
-        prob = base if world == 1 else synth.tile_scene(base, meta, world)[0]
+        prob = base if n_gpus == 1 else synth.tile_scene(base, meta, n_gpus)[0]
         f0, f1 = rank * args.frames, (rank + 1) * args.frames
     else:                          # the 200-keyframe problem split over the ranks (contiguous ranges balanced by points)
         prob = base
-        f0, f1 = pkg.shard_frames(prob.n_frames, world, rank, np.diff(prob.arrays["pt_offset"].astype(np.int64)))
+        f0, f1 = pkg.shard_frames(prob.n_frames, n_gpus, rank, np.diff(prob.arrays["pt_offset"].astype(np.int64)))
+    grp = None
+    if group_mode:   # ONE process: every device's shard, issuing thread and communicator inside the library
+        grp = pkg.IbaGroup(prob, params, devices=tuple(range(n_gpus)))
+        f0, f1 = grp.frame_range(0)
+        if grp.comm_ranks != n_gpus:
+            sys.exit("bench.py: the group's communicator has %d ranks, %d GPUs were asked for" % (grp.comm_ranks, n_gpus))
+    # (in group mode this handle only serves the per-kernel timing of device 0's shard after the timed region)
     h = pkg.IbaHandle(prob, params, device=local_rank, frame_begin=f0, frame_end=f1)
     stage("scene generated, handle created (static indices + plane memo)")
     h.set_timing(True)
@@ -112,6 +148,8 @@ def main():
 
     def step(i, xsrc=xs_all):
         xs = xsrc[i % len(xsrc)]
+        if grp is not None:   # candidate block once, the devices issued concurrently, one ncclAllReduce, device 0's copy finalised
+            return grp.eval_full(xs)
         st = torch.cuda.current_stream().cuda_stream
         h.eval_full_partial(xs, d_part.data_ptr(), st)   # cost tuple + normal equations from one pass over the scans
         if use_dist:   # frames shard across ranks: ONE sum all-reduce of the partial blocks (RCCL over xGMI)
@@ -163,13 +201,20 @@ def main():
     achieved = B * per_eval / (pair_ms * 1e-3) / 1e9
 
     evals = B * args.steps
-    units = world if args.scaling == "weak" else 1
+    units = n_gpus if args.scaling == "weak" else 1
     value = units * evals / dt
+    if group_mode:
+        launch, rccl_ranks = "group: one process, iba_group_* (one issuing thread + one RCCL communicator per device)", grp.comm_ranks
+    elif use_dist:
+        launch = "ranks: one process per GPU, torch.distributed backend nccl (= RCCL)" + (", started by bench.py itself" if os.environ.get("IBA_BENCH_SPAWNED") else ", started by the caller's launcher")
+        rccl_ranks = dist.get_world_size()
+    else:
+        launch, rccl_ranks = "single process, no collective", 0
     res = {
         "metric": "IBA residual+Jacobian evals/sec",
         "value": value,
         "unit": "evals/s",
-        "n_gpus": world,
+        "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -187,7 +232,8 @@ def main():
             "plane_cache": int(params.plane_cache),
             "mean_n_corr": float(np.mean([c.n_corr for c in out[0]])), "mean_cnt_3d_3d": float(np.mean([c.cnt_3d_3d for c in out[0]])),
             "mean_factors": float(np.mean([n.n_factor_3d2d + n.n_factor_p2pl + n.n_factor_p2pt for n in out[1]])),
-            "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of %d doubles per call" % (world, B * stride),
+            "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of %d doubles per call" % (n_gpus, B * stride),
+            "launch": launch, "rccl_ranks": rccl_ranks,
             "unit_definition": ("weak scaling: 1 eval = one candidate x against %d keyframes / %.1fM points (+ normal equations); at N GPUs a candidate covers N x %d "
                                 "keyframes = N units, value = units/s over all ranks" % (args.frames, args.frames * args.pts / 1e6, args.frames)) if args.scaling == "weak" else
                                "strong scaling: 1 eval = one candidate x against the whole %d-keyframe problem, whatever the GPU count" % args.frames,
@@ -220,7 +266,11 @@ def main():
         except Exception:
             pass
 
-    if not args.no_extras:
+    if group_mode:
+        res["config"]["group_issue_us_last_call"] = grp.last_issue_us
+    if not args.no_extras and group_mode:
+        stage("extras are measured in the default launch mode: skipped with --launch group")
+    if not args.no_extras and not group_mode:
         extras = {}
         st = torch.cuda.current_stream().cuda_stream
         # (1) batch-size sweep: wall and device time per call (NOMAD polls 8..14 points, the BAError shim calls B = 1)
@@ -330,7 +380,7 @@ def main():
         res["extras"] = extras
     stage("extras done")
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle — a port of the reference algorithm, per-evaluation 2-D tree rebuild included — on
         #      this box's host cores: x0 and 16 seeded perturbations, cost tuple + normal equations each; 1 warm-up, then the
         #      median over the 17 candidates on ONE thread (what the reference's NOMAD loop runs, iba_global.cpp:385) and the
@@ -393,8 +443,10 @@ def main():
                 "reading": "device and CPU LM end at the same point: the shift away from the planted extrinsic is the iba_local objective's own optimum on this scene"}
     res.pop("_lm_check_start", None)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)   # flushed before any teardown
     h.close()
+    if grp is not None:
+        grp.close()
     if use_dist:
         dist.destroy_process_group()
 

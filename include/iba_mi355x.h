@@ -302,19 +302,32 @@ iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_op
  * 0 smooth bowl, 1 bowl with an active constraint and an infeasible start, 2 nonsmooth with two constraints,
  * 3 shallow bowl covered with narrow local basins (for the variable-neighbourhood restarts) */
 iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res);
+/* the same two calls with the sequence of black-box evaluations recorded: `trace` receives up to `cap` rows of 8 doubles
+ * (x[7], f) in evaluation order, *n_trace the number of evaluations (tests diff the sequence against oracle/mads.py) */
+iba_status iba_calibrate_mads_trace(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace);
+iba_status iba_mads_selftest_trace(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace);
 
 /*
  * Multi-GPU inside one process: the keyframes sharded over n devices of a node (contiguous ranges balanced by points), one
- * handle and one RCCL communicator per device (ncclCommInitAll). The reference's one parallel strategy is the frame loop
- * with critical-section sums (iba_global.cpp:193, 239, 318; iba_func.cpp:203; iba_local.cpp:162); here every device evaluates
- * its frames, ONE ncclAllReduce(sum, f64) of the B x iba_partial_stride() block over xGMI adds them on the devices, and
- * device 0's copy is finalised on the host. Same outputs and callers as the single-device entry points.
+ * handle, one issuing thread and one RCCL communicator per device (ncclCommInitAll). The reference's one parallel strategy is the
+ * frame loop with critical-section sums (iba_global.cpp:193, 239, 318; iba_func.cpp:203; iba_local.cpp:162); here every device
+ * evaluates its frames, ONE ncclAllReduce(sum, f64) of the B x iba_partial_stride() block over xGMI adds them on the devices,
+ * and device 0's copy is finalised on the host. Same outputs and callers as the single-device entry points. The candidate
+ * block (Sim3Exp and its derivatives) is computed once per call, the devices are issued concurrently, and the caller's current
+ * HIP device is left alone. librccl is loaded (dlopen) when the first communicator is needed: single-device and host-only
+ * users of this library do not need it installed.
  */
 typedef struct iba_group iba_group;
 iba_status iba_group_create(const iba_problem_desc* desc, const iba_params* params, const int32_t* devices, int32_t n_devices, iba_group** out);
+/* flags: IBA_GROUP_REDUCE_HOST = the partial blocks are copied to the host and summed there in rank order (bitwise
+ * reproducible, no RCCL needed, and the same device may appear more than once in `devices`) instead of one ncclAllReduce */
+#define IBA_GROUP_REDUCE_HOST 1
+iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* params, const int32_t* devices, int32_t n_devices, int32_t flags, iba_group** out);
 void iba_group_destroy(iba_group* g);
 const char* iba_group_last_error(const iba_group* g); /* g may be NULL for creation errors */
 int32_t iba_group_size(const iba_group* g);
+int32_t iba_group_comm_ranks(const iba_group* g);     /* ncclCommCount of the group's communicator; 0 with IBA_GROUP_REDUCE_HOST */
+double iba_group_last_issue_us(const iba_group* g);   /* host wall time of the last chunk: candidate block, hand-over to the device threads, wait */
 iba_status iba_group_frame_range(const iba_group* g, int32_t rank, int32_t* frame_begin, int32_t* frame_end);
 iba_status iba_group_set_params(iba_group* g, const iba_params* params);
 iba_status iba_group_eval_cost(iba_group* g, const double* x, int32_t B, iba_cost_out* out);
@@ -328,6 +341,15 @@ iba_status iba_group_calibrate_mads(iba_group* g, const double* x0, const iba_ma
 /* One process per GPU with a communicator of the caller's (MPI / torchrun style): the one collective of the path on the
  * caller's ncclComm_t (passed as void*), in place on the device block written by iba_eval_*_partial. */
 iba_status iba_comm_allreduce(void* nccl_comm, void* d_partials, int32_t B, void* stream);
+/* For callers without RCCL headers of their own: communicators over devices of this process (comms[i] belongs to
+ * devices[i]; ncclCommInitAll), their rank count, their release. */
+iba_status iba_comm_init_all(void** comms, const int32_t* devices, int32_t n);
+int32_t iba_comm_count(void* nccl_comm);
+iba_status iba_comm_destroy(void* nccl_comm);
+/* Which librccl this process runs — "path=<file> runtime=<code> header=<code> match=<0|1>" — and the two version codes
+ * (ncclGetVersion of the loaded library, NCCL_VERSION_CODE of the headers this library was compiled against). Inside a
+ * torch process the already-mapped torch/lib/librccl.so is the one that is used. */
+iba_status iba_rccl_info(char* buf, int32_t cap, int32_t* runtime_version, int32_t* header_version);
 
 /*
  * ---- On-disk formats of the reference pipeline -> problem descriptor [SURVEY.md 8(f) row 1] ----

@@ -99,11 +99,11 @@ class Oracle:
         lib().oracle_eval_cost_raw(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(f_begin), C.c_int(f_end), _p(raw))
         return raw
 
-    def eval_bbo(self, params, x, he_threshold, valid_rate):
+    def eval_bbo(self, params, x, he_threshold, valid_rate, nthreads=1):
         x = np.ascontiguousarray(np.atleast_2d(x), np.float64)
         B = len(x)
         out = (IbaBbo * B)()
-        lib().oracle_eval_bbo(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), C.c_double(he_threshold), C.c_double(valid_rate), out, C.c_int(1))
+        lib().oracle_eval_bbo(C.c_void_p(self.h), C.byref(params), _p(x), C.c_int(B), C.c_double(he_threshold), C.c_double(valid_rate), out, C.c_int(nthreads))
         return list(out)
 
     def correspondences(self, params, x, frame):

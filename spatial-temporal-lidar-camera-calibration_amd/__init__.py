@@ -181,15 +181,20 @@ class IbaHandle:
         self._chk(self.lib.iba_calibrate_lm(self.h, _p(x0), C.byref(o), C.byref(r)))
         return np.array(r.x[:]), r
 
-    def calibrate_mads(self, x0, **opts):
+    def calibrate_mads(self, x0, trace=False, **opts):
         """Global stage: batch-aware MADS on BALoss::eval_x's objective + 3 progressive-barrier constraints
         (the caller the reference gets from NOMAD, iba_global.cpp:551-602). opts override iba_default_mads_options;
-        lb/ub given as 7-vectors are ABSOLUTE bounds."""
+        lb/ub given as 7-vectors are ABSOLUTE bounds. trace=True also returns the evaluated points (rows of x[7], f)."""
         x0 = np.ascontiguousarray(x0, np.float64)
         o = mads_options(x0, **opts)
         r = IbaMadsResult()
-        self._chk(self.lib.iba_calibrate_mads(self.h, _p(x0), C.byref(o), C.byref(r)))
-        return np.array(r.x[:]), r
+        if not trace:
+            self._chk(self.lib.iba_calibrate_mads(self.h, _p(x0), C.byref(o), C.byref(r)))
+            return np.array(r.x[:]), r
+        tr = np.zeros((int(o.max_bb_eval), 8))
+        n = C.c_int32(0)
+        self._chk(self.lib.iba_calibrate_mads_trace(self.h, _p(x0), C.byref(o), C.byref(r), _p(tr), C.c_int32(len(tr)), C.byref(n)))
+        return np.array(r.x[:]), r, tr[: n.value]
 
     def build_problem(self, x):
         x = np.ascontiguousarray(x, np.float64)
@@ -275,7 +280,8 @@ class IbaHandle:
 class IbaGroup:
     """iba_group wrapper: one process, several GPUs of a node, frames sharded over them, one RCCL all-reduce per evaluation."""
 
-    def __init__(self, problem, params=None, devices=(0,)):
+    def __init__(self, problem, params=None, devices=(0,), host_reduce=False):
+        """host_reduce: sum the partial blocks on the host in rank order (IBA_GROUP_REDUCE_HOST; no RCCL, a device may repeat)."""
         self.lib = load_library()
         self.problem = problem
         self.params = copy_params(params) if params is not None else default_params()
@@ -285,9 +291,25 @@ class IbaGroup:
         self.lib.iba_group_last_error.restype = C.c_char_p
         self.lib.iba_group_last_error.argtypes = [C.c_void_p]
         self.lib.iba_group_destroy.argtypes = [C.c_void_p]
-        st = self.lib.iba_group_create(C.byref(self._desc), C.byref(self.params), dev, C.c_int32(len(devices)), C.byref(self.g))
+        self.lib.iba_group_last_issue_us.restype = C.c_double
+        self.lib.iba_group_last_issue_us.argtypes = [C.c_void_p]
+        self.lib.iba_group_comm_ranks.argtypes = [C.c_void_p]
+        st = self.lib.iba_group_create_ex(C.byref(self._desc), C.byref(self.params), dev, C.c_int32(len(devices)), C.c_int32(1 if host_reduce else 0), C.byref(self.g))
         if st != 0:
             raise IbaError(st, self.lib.iba_group_last_error(None).decode())
+
+    @property
+    def comm_ranks(self):
+        """ncclCommCount of the group's communicator (0: host reduction)."""
+        return int(self.lib.iba_group_comm_ranks(self.g))
+
+    @property
+    def last_issue_us(self):
+        return float(self.lib.iba_group_last_issue_us(self.g))
+
+    def set_params(self, params):
+        self.params = copy_params(params)
+        self._chk(self.lib.iba_group_set_params(self.g, C.byref(self.params)))
 
     def _chk(self, st):
         if st != 0:
@@ -355,6 +377,17 @@ class IbaGroup:
         return np.array(r.x[:]), r
 
 
+def rccl_info():
+    """(text, runtime version code, header version code) of the librccl this process runs (loaded lazily by the library)."""
+    L = load_library()
+    buf = C.create_string_buffer(1024)
+    rv, hv = C.c_int32(0), C.c_int32(0)
+    st = L.iba_rccl_info(buf, C.c_int32(1024), C.byref(rv), C.byref(hv))
+    if st != 0:
+        raise IbaError(st, buf.value.decode())
+    return buf.value.decode(), rv.value, hv.value
+
+
 def mads_options(x0, **opts):
     L = load_library()
     x0 = np.ascontiguousarray(x0, np.float64)
@@ -369,16 +402,18 @@ def mads_options(x0, **opts):
     return o
 
 
-def mads_selftest(problem, x0, **opts):
-    """The MADS driver on a built-in analytic black box (host only, no GPU)."""
+def mads_selftest(problem, x0, trace=False, **opts):
+    """The MADS driver on a built-in analytic black box (host only, no GPU). trace=True also returns the evaluated points."""
     L = load_library()
     x0 = np.ascontiguousarray(x0, np.float64)
     o = mads_options(x0, **opts)
     r = IbaMadsResult()
-    st = L.iba_mads_selftest(C.c_int32(problem), _p(x0), C.byref(o), C.byref(r))
+    tr = np.zeros((int(o.max_bb_eval) if trace else 1, 8))
+    n = C.c_int32(0)
+    st = L.iba_mads_selftest_trace(C.c_int32(problem), _p(x0), C.byref(o), C.byref(r), _p(tr) if trace else None, C.c_int32(len(tr) if trace else 0), C.byref(n))
     if st != 0:
         raise IbaError(st, "iba_mads_selftest")
-    return np.array(r.x[:]), r
+    return (np.array(r.x[:]), r, tr[: n.value]) if trace else (np.array(r.x[:]), r)
 
 
 def shard_frames(n_frames, world_size, rank, weights=None):

@@ -17,6 +17,7 @@
 #include "../../include/iba_mi355x.h"
 #include "iba_build.hpp"
 #include "iba_host_math.hpp"
+#include "iba_internal.hpp"
 #include "iba_kernels.hpp"
 #include "iba_lm.hpp"
 #include "iba_mads.hpp"
@@ -265,12 +266,14 @@ iba_status ensure_scratch(iba_handle* h) {
     return IBA_OK;
 }
 
-// stages B candidates into a pinned ring slot and enqueues the H2D copy; returns the device pointer
-iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out) {
+// stages B candidates into a pinned ring slot and enqueues the H2D copy; returns the device pointer. The block is computed
+// from x here, or copied from `pre` when the caller (iba_group) has already computed it for all its devices.
+iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr) {
     const int slot = h->ring_next; h->ring_next = (h->ring_next + 1) % kRing;
     if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
     Cand* hc = h->h_cands + (size_t)slot * IBA_MAX_BATCH;
-    for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
+    if (pre) std::memcpy(hc, pre, sizeof(Cand) * (size_t)B);
+    else for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
     Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
     HIP_TRY(h, hipMemcpyAsync(dc, hc, sizeof(Cand) * B, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipEventRecord(h->ring_ev[slot], st));
@@ -280,7 +283,9 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
 }
 
 iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
-    if (h->n_frames == 0 || h->maxK == 0) return IBA_OK;
+    if (h->n_frames == 0) return IBA_OK;
+    // (a handle whose frames hold no keypoint at all still launches: every list is empty and the kernel writes zero records,
+    // which is what the sums over the records expect)
     const dim3 grid(h->n_frames, B);
     const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
     if (h->factor_valu) hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
@@ -398,11 +403,11 @@ iba_status chunked(int B, F f) {
     return IBA_OK;
 }
 
-iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
-    if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr) {
+    if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 2, false, false, d_partials, st);
 }
 
@@ -854,12 +859,12 @@ iba_status iba_finalize_normal(const iba_params* p, const double* part, int32_t 
     return IBA_OK;
 }
 
-static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
-    if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr) {
+    if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 1, false, true, d_partials, st);
 }
 
@@ -881,12 +886,12 @@ iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal
 
 // BAError tuple AND re-associated normal equations of the same candidates from ONE pass over the scans:
 // the two paths share projection + 2d-3d association (iba_global.cpp:55-96 = iba_local.cpp:17-58).
-static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
-    if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr) {
+    if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 3, false, true, d_partials, st);
 }
 
@@ -906,24 +911,25 @@ iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out
     });
 }
 
-iba_status iba_build_problem(iba_handle* h, const double* x) {
-    if (!h || !x) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+static iba_status build_problem_impl(iba_handle* h, const double* x, const Cand* pre) {
+    if (!h || (!x && !pre)) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, 1, h->stream, &dc, pre); if (s != IBA_OK) return s;
     s = run_split(h, dc, 1, 1, true, false, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
     HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->frozen_frames = (int32_t)h->h_partials[P_FRAMES_N]; h->frozen_ncorr = (int32_t)h->h_partials[P_NCORR_N]; h->frozen_valid = true;
     return IBA_OK;
 }
+iba_status iba_build_problem(iba_handle* h, const double* x) { return build_problem_impl(h, x, nullptr); }
 
-static iba_status eval_factors_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st) {
-    if (!h || !x || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+static iba_status eval_factors_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr) {
+    if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
     if (!h->frozen_valid) return fail(h, IBA_ERR_STATE, "iba_eval_factors called before iba_build_problem");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
     s = launch_factors(h, dc, B, 0, h->d_frame_partials.p, h->nfb, 0, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
@@ -1045,12 +1051,20 @@ static bool mads_options_ok(const iba_mads_options* opt) {
     for (int i = 0; i < 7; ++i) if (!(opt->lb[i] <= opt->ub[i]) || !(opt->init_frame[i] > 0)) return false;
     return true;
 }
-iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res) {
+// copies the recorded evaluations (8 doubles each: x, f) into the caller's buffer; *n = how many there were
+static void hand_over_trace(const std::vector<double>& tr, double* trace, int32_t cap, int32_t* n) {
+    const int32_t have = (int32_t)(tr.size() / 8);
+    if (n) *n = have;
+    if (trace && cap > 0) std::memcpy(trace, tr.data(), sizeof(double) * 8 * (size_t)std::min(have, cap));
+}
+iba_status iba_calibrate_mads_trace(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace) {
     if (!h || !x0 || !res) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     iba_mads_options dflt;
     if (!opt) { iba_default_mads_options(x0, &dflt); opt = &dflt; }
     if (!mads_options_ok(opt)) return fail(h, IBA_ERR_INVALID_ARG, "bad MADS options (bounds, frame sizes, budget)");
     MadsOptions o; to_mads(opt, o);
+    std::vector<double> tr;
+    if (trace || n_trace) o.trace = &tr;
     iba_status st = IBA_OK;
     MadsResult r;
     const bool ok = mads_minimize(x0, o, [&](const double* X, int B, MadsPoint* out) {
@@ -1062,11 +1076,17 @@ iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_op
     }, r);
     if (!ok) return st == IBA_OK ? IBA_ERR_STATE : st;
     from_mads(r, res);
+    hand_over_trace(tr, trace, cap, n_trace);
     return IBA_OK;
 }
-iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res) {
+iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res) {
+    return iba_calibrate_mads_trace(h, x0, opt, res, nullptr, 0, nullptr);
+}
+iba_status iba_mads_selftest_trace(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace) {
     if (!x0 || !res || !mads_options_ok(opt) || problem < 0 || problem > 3) return IBA_ERR_INVALID_ARG;
     MadsOptions o; to_mads(opt, o);
+    std::vector<double> tr;
+    if (trace || n_trace) o.trace = &tr;
     static const double a[7] = {0.3, -0.2, 0.1, 0.25, -0.15, 0.05, 9.5};
     MadsResult r;
     mads_minimize(x0, o, [&](const double* X, int B, MadsPoint* out) {
@@ -1089,7 +1109,11 @@ iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_o
         return true;
     }, r);
     from_mads(r, res);
+    hand_over_trace(tr, trace, cap, n_trace);
     return IBA_OK;
+}
+iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res) {
+    return iba_mads_selftest_trace(problem, x0, opt, res, nullptr, 0, nullptr);
 }
 
 iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double* J, int32_t* block_id, int32_t* block_kind, int64_t* n_rows) {
@@ -1159,3 +1183,25 @@ iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double*
 }
 
 }  // extern "C"
+
+// ---- library-internal interface of iba_group (iba_internal.hpp) ----
+namespace iba {
+void make_cands_host(const double* x, int B, Cand* out) { for (int b = 0; b < B; ++b) make_cand(x + 7 * b, out[b]); }
+iba_status eval_partial_cands(iba_handle* h, const Cand* hc, int B, EvalKind kind, double* d_partials, hipStream_t st) {
+    if (!h || !hc || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    if (!st) st = h->stream;
+    switch (kind) {
+        case kEvalCost: return eval_cost_partial_impl(h, nullptr, B, d_partials, st, hc);
+        case kEvalNormal: return eval_normal_partial_impl(h, nullptr, B, d_partials, st, hc);
+        case kEvalFull: return eval_full_partial_impl(h, nullptr, B, d_partials, st, hc);
+        case kEvalFactors: return eval_factors_partial_impl(h, nullptr, B, d_partials, st, hc);
+    }
+    return fail(h, IBA_ERR_INVALID_ARG, "bad evaluation kind");
+}
+iba_status build_problem_cands(iba_handle* h, const Cand* hc) { return build_problem_impl(h, nullptr, hc); }
+iba_status reserve_batch(iba_handle* h, int B) {
+    if (!h || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return ensure_lists(h, B, h->stream);
+}
+}  // namespace iba

@@ -1,36 +1,111 @@
-// Multi-GPU evaluation inside ONE process: the keyframes of a problem sharded over the GPUs of a node, one iba_handle per
-// device, one RCCL communicator per device (ncclCommInitAll). The reference's only parallel strategy is the frame loop
-// (`#pragma omp parallel for` over keyframes with critical-section sums: iba_global.cpp:193, 239, 318; iba_func.cpp:203;
+// Multi-GPU evaluation inside ONE process: the keyframes of a problem sharded over the GPUs of a node, one iba_handle, one
+// issuing thread and one RCCL communicator per device (ncclCommInitAll). The reference's only parallel strategy is the frame
+// loop (`#pragma omp parallel for` over keyframes with critical-section sums: iba_global.cpp:193, 239, 318; iba_func.cpp:203;
 // iba_local.cpp:162): here every device evaluates its frames into a partial block of B x 64 doubles, ONE
 // ncclAllReduce(sum, f64) over xGMI adds the blocks in place on every device, and device 0's copy is finalised on the host
 // (iba_finalize_*). No point, keypoint or tree ever crosses a link; the message is 32 KB at B = 64, latency-bound.
-// Built on the public single-device entry points only (iba_eval_*_partial, iba_build_problem, iba_finalize_*).
+//
+// Host side of a call: the candidate block (Sim3Exp, SE3Exp(-x), their duals) is computed ONCE on the calling thread; every
+// device has a worker thread pinned to it (hipSetDevice once, at start) that copies the block into its handle's pinned ring,
+// issues the launch chain and the collective on its own stream and waits for that stream — the devices are issued
+// concurrently, the caller's current HIP device is never touched. Workers spin for a short while after a job (an optimiser
+// calls back within microseconds) and sleep on a condition variable otherwise.
+//
+// RCCL is loaded lazily (dlopen) the first time a communicator is needed: the core library depends on libamdhip64 only.
+// IBA_GROUP_REDUCE_HOST sums the blocks on the host in rank order instead (no RCCL; the same device may then appear more
+// than once in the device list, which is how the n > 1 logic is exercised on a one-GPU box).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and NCCL_VERSION_CODE only: no symbol of librccl is linked
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/iba_mi355x.h"
+#include "iba_internal.hpp"
 #include "iba_lm.hpp"
 #include "iba_mads.hpp"
 
 using namespace iba;
 
+namespace {
+
+// ---- librccl, loaded on first use ----
+struct Rccl {
+    void* lib = nullptr;
+    std::string path, err;
+    int runtime_version = 0;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return lib != nullptr; }
+};
+Rccl& rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        // A copy the process has already mapped (torch ships its own librccl.so, SONAME librccl.so.1) is used in preference to a
+        // second one. A fresh copy is loaded RTLD_LOCAL: /opt/rocm's librccl drags in /opt/rocm's librocm_smi64, and were their
+        // symbols global, a torch imported LATER would run the static initialisers of its own bundled copy on the first copy's
+        // objects (measured: "double free or corruption" in a std::map destructor of librocm_smi64 at exit).
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void* lib = nullptr;
+        for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!lib) for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!lib) { const char* e = dlerror(); R.err = std::string("librccl not found: ") + (e ? e : "dlopen failed"); return; }
+#define IBA_SYM(field, name) R.field = (decltype(R.field))dlsym(lib, name); if (!R.field) { R.err = std::string("librccl lacks ") + name; dlclose(lib); return; }
+        IBA_SYM(GetVersion, "ncclGetVersion") IBA_SYM(CommInitAll, "ncclCommInitAll") IBA_SYM(CommDestroy, "ncclCommDestroy") IBA_SYM(CommCount, "ncclCommCount")
+        IBA_SYM(AllReduce, "ncclAllReduce") IBA_SYM(GetErrorString, "ncclGetErrorString")
+#undef IBA_SYM
+        Dl_info info;
+        if (dladdr((void*)R.AllReduce, &info) && info.dli_fname) R.path = info.dli_fname;
+        (void)R.GetVersion(&R.runtime_version);
+        R.lib = lib;
+    });
+    return R;
+}
+
+}  // namespace
+
 struct iba_group {
     int n = 0;
+    bool host_reduce = false;
     std::vector<int> dev;
     std::vector<iba_handle*> h;
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> st;
     std::vector<double*> d_part;          // per device: IBA_MAX_BATCH x stride doubles
+    std::vector<double*> h_parts;         // per device, pinned (host reduction); h_part = h_parts[0] otherwise
     std::vector<int32_t> f_begin, f_end;
-    double* h_part = nullptr;             // pinned
+    double* h_part = nullptr;             // the summed block, host
+    std::vector<double> h_sum;            // host reduction: the sum in rank order
+    std::vector<Cand> cands;              // candidate block of the current chunk, computed once per call
     iba_params params{};
     int stride = 64;
     std::string err;
+    double last_issue_us = 0.0;           // host time of the last chunk: candidate block + hand-over to the workers + wait
+    // ---- one worker thread per device ----
+    std::vector<std::thread> workers;
+    std::vector<iba_status> wstatus;
+    std::vector<std::string> werr;
+    std::function<iba_status(int)> job;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::atomic<uint64_t> gen{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> quit{false};
 };
 
 namespace {
@@ -38,9 +113,58 @@ thread_local std::string g_group_create_error;
 
 iba_status gfail(iba_group* g, iba_status s, const std::string& m) { if (g) g->err = m; else g_group_create_error = m; return s; }
 
-#define G_HIP(g, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return gfail(g, IBA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
-#define G_NCCL(g, expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) return gfail(g, IBA_ERR_HIP, std::string(#expr) + ": " + ncclGetErrorString(_r)); } while (0)
-#define G_IBA(g, i, expr) do { iba_status _s = (expr); if (_s != IBA_OK) return gfail(g, _s, std::string("device ") + std::to_string((g)->dev[i]) + ": " + iba_last_error((g)->h[i])); } while (0)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+constexpr auto kSpinFor = std::chrono::microseconds(200);
+
+void worker_main(iba_group* g, int i) {
+    (void)hipSetDevice(g->dev[i]);   // once: every HIP call of this thread targets its device
+    uint64_t seen = 0;
+    for (;;) {
+        auto t0 = std::chrono::steady_clock::now();
+        int polls = 0;
+        while (g->gen.load(std::memory_order_acquire) == seen && !g->quit.load(std::memory_order_acquire)) {
+            cpu_relax();
+            if ((++polls & 63) == 0 && std::chrono::steady_clock::now() - t0 > kSpinFor) {
+                std::unique_lock<std::mutex> lk(g->mu);
+                g->cv_job.wait(lk, [&]() { return g->gen.load(std::memory_order_acquire) != seen || g->quit.load(std::memory_order_acquire); });
+            }
+        }
+        if (g->quit.load(std::memory_order_acquire) && g->gen.load(std::memory_order_acquire) == seen) return;
+        seen = g->gen.load(std::memory_order_acquire);
+        g->wstatus[i] = g->job(i);
+        if (g->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(g->mu); g->cv_done.notify_all(); }
+    }
+}
+
+// runs fn(i) on every device's worker, concurrently; the first failure is reported
+iba_status run_all(iba_group* g, std::function<iba_status(int)> fn) {
+    g->job = std::move(fn);
+    g->pending.store(g->n, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(g->mu); g->gen.fetch_add(1, std::memory_order_acq_rel); }
+    g->cv_job.notify_all();
+    auto t0 = std::chrono::steady_clock::now();
+    int polls = 0;
+    while (g->pending.load(std::memory_order_acquire) != 0) {
+        cpu_relax();
+        if ((++polls & 63) == 0 && std::chrono::steady_clock::now() - t0 > kSpinFor) {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_done.wait(lk, [&]() { return g->pending.load(std::memory_order_acquire) == 0; });
+        }
+    }
+    for (int i = 0; i < g->n; ++i)
+        if (g->wstatus[i] != IBA_OK) return gfail(g, g->wstatus[i], std::string("device ") + std::to_string(g->dev[i]) + ": " + g->werr[i]);
+    return IBA_OK;
+}
+
+iba_status wfail(iba_group* g, int i, iba_status s, const std::string& m) { g->werr[i] = m; return s; }
+#define W_HIP(g, i, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return wfail(g, i, IBA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+#define W_IBA(g, i, expr) do { iba_status _s = (expr); if (_s != IBA_OK) return wfail(g, i, _s, iba_last_error((g)->h[i])); } while (0)
 
 // contiguous frame ranges balanced by scan points: the cut before rank r is the first frame boundary at or beyond r / n of
 // the points (the rule of shard_frames in the Python plumbing, so that both launch styles partition a problem identically)
@@ -59,22 +183,38 @@ void shard(const iba_problem_desc* d, int n, std::vector<int32_t>& b, std::vecto
     b.assign(cuts.begin(), cuts.begin() + n); e.assign(cuts.begin() + 1, cuts.end());
 }
 
-// sum of the partial blocks over the devices, in place on every device: ONE collective per evaluation
-iba_status allreduce(iba_group* g, int B) {
-    G_NCCL(g, ncclGroupStart());
-    for (int i = 0; i < g->n; ++i) {
-        ncclResult_t r = ncclAllReduce(g->d_part[i], g->d_part[i], (size_t)B * g->stride, ncclDouble, ncclSum, g->comm[i], g->st[i]);
-        if (r != ncclSuccess) { ncclGroupEnd(); return gfail(g, IBA_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
-    }
-    G_NCCL(g, ncclGroupEnd());
+// One chunk (Bc <= IBA_MAX_BATCH candidates) on every device: launch chain -> sum over the devices -> the summed block in
+// g->h_part. Per device, on its own thread: pinned copy of the candidate block, kernels, ONE collective, stream drained.
+iba_status eval_chunk(iba_group* g, const double* x, int Bc, EvalKind kind) {
+    const auto t0 = std::chrono::steady_clock::now();
+    make_cands_host(x, Bc, g->cands.data());
+    const size_t bytes = sizeof(double) * (size_t)Bc * g->stride;
+    iba_status s = run_all(g, [g, Bc, kind, bytes](int i) -> iba_status {
+        W_IBA(g, i, eval_partial_cands(g->h[i], g->cands.data(), Bc, kind, g->d_part[i], g->st[i]));
+        if (g->host_reduce) W_HIP(g, i, hipMemcpyAsync(g->h_parts[i], g->d_part[i], bytes, hipMemcpyDeviceToHost, g->st[i]));
+        else {
+            const ncclResult_t r = rccl().AllReduce(g->d_part[i], g->d_part[i], (size_t)Bc * g->stride, ncclDouble, ncclSum, g->comm[i], g->st[i]);
+            if (r != ncclSuccess) return wfail(g, i, IBA_ERR_HIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(r));
+            if (i == 0) W_HIP(g, i, hipMemcpyAsync(g->h_parts[0], g->d_part[0], bytes, hipMemcpyDeviceToHost, g->st[0]));
+        }
+        W_HIP(g, i, hipStreamSynchronize(g->st[i]));
+        return IBA_OK;
+    });
+    if (s != IBA_OK) return s;
+    if (g->host_reduce && g->n > 1) {   // rank order: bitwise reproducible whatever the timing
+        const size_t m = (size_t)Bc * g->stride;
+        for (size_t k = 0; k < m; ++k) { double a = g->h_parts[0][k]; for (int i = 1; i < g->n; ++i) a += g->h_parts[i][k]; g->h_sum[k] = a; }
+        g->h_part = g->h_sum.data();
+    } else g->h_part = g->h_parts[0];
+    g->last_issue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     return IBA_OK;
 }
 
-iba_status fetch(iba_group* g, int B) {   // device 0's summed block -> pinned host memory; every stream drained
-    G_HIP(g, hipSetDevice(g->dev[0]));
-    G_HIP(g, hipMemcpyAsync(g->h_part, g->d_part[0], sizeof(double) * (size_t)B * g->stride, hipMemcpyDeviceToHost, g->st[0]));
-    for (int i = 0; i < g->n; ++i) { G_HIP(g, hipSetDevice(g->dev[i])); G_HIP(g, hipStreamSynchronize(g->st[i])); }
-    return IBA_OK;
+void stop_workers(iba_group* g) {
+    { std::lock_guard<std::mutex> lk(g->mu); g->quit.store(true, std::memory_order_release); }
+    g->cv_job.notify_all();
+    for (auto& t : g->workers) if (t.joinable()) t.join();
+    g->workers.clear();
 }
 }  // namespace
 
@@ -91,46 +231,80 @@ iba_status iba_group_frame_range(const iba_group* g, int32_t rank, int32_t* fram
 
 void iba_group_destroy(iba_group* g) {
     if (!g) return;
-    for (int i = 0; i < g->n; ++i) {
-        (void)hipSetDevice(g->dev[i]);
-        if (i < (int)g->st.size() && g->st[i]) (void)hipStreamSynchronize(g->st[i]);
-        if (i < (int)g->comm.size() && g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
-        if (i < (int)g->h.size() && g->h[i]) iba_destroy(g->h[i]);
-        if (i < (int)g->d_part.size() && g->d_part[i]) (void)hipFree(g->d_part[i]);
-        if (i < (int)g->st.size() && g->st[i]) (void)hipStreamDestroy(g->st[i]);
+    if (!g->workers.empty()) {
+        // every device's teardown on its own thread (and device)
+        (void)run_all(g, [g](int i) -> iba_status {
+            if (g->st[i]) (void)hipStreamSynchronize(g->st[i]);
+            if (g->comm[i]) (void)rccl().CommDestroy(g->comm[i]);
+            if (g->h[i]) iba_destroy(g->h[i]);
+            if (g->d_part[i]) (void)hipFree(g->d_part[i]);
+            if (g->h_parts[i]) (void)hipHostFree(g->h_parts[i]);
+            if (g->st[i]) (void)hipStreamDestroy(g->st[i]);
+            return IBA_OK;
+        });
+        stop_workers(g);
     }
-    if (g->h_part) (void)hipHostFree(g->h_part);
     delete g;
 }
 
-iba_status iba_group_create(const iba_problem_desc* desc, const iba_params* params, const int32_t* devices, int32_t n_devices, iba_group** out) {
+iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* params, const int32_t* devices, int32_t n_devices, int32_t flags, iba_group** out) {
     g_group_create_error.clear();
     if (!desc || !params || !devices || !out || n_devices < 1) return gfail(nullptr, IBA_ERR_INVALID_ARG, "bad arguments");
     *out = nullptr;
-    iba_group* g = new iba_group;
-    g->n = n_devices; g->params = *params; g->stride = iba_partial_stride();
-    g->dev.assign(devices, devices + n_devices);
-    g->h.assign(n_devices, nullptr); g->comm.assign(n_devices, nullptr); g->st.assign(n_devices, nullptr); g->d_part.assign(n_devices, nullptr);
-    shard(desc, n_devices, g->f_begin, g->f_end);
-    auto bail = [&](iba_status s, const std::string& m) { g_group_create_error = m; iba_group_destroy(g); return s; };
+    const bool host_reduce = (flags & IBA_GROUP_REDUCE_HOST) != 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gfail(nullptr, IBA_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     for (int i = 0; i < n_devices; ++i) {
-        const iba_status s = iba_create(desc, params, devices[i], g->f_begin[i], g->f_end[i], &g->h[i]);
-        if (s != IBA_OK) return bail(s, std::string("iba_create on device ") + std::to_string(devices[i]) + ": " + iba_last_error(nullptr));
-        hipError_t e = hipSetDevice(devices[i]);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->st[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMalloc((void**)&g->d_part[i], sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride);
-        if (e != hipSuccess) return bail(IBA_ERR_HIP, std::string("stream / buffer on device ") + std::to_string(devices[i]) + ": " + hipGetErrorString(e));
+        if (devices[i] < 0 || devices[i] >= ndev) return gfail(nullptr, IBA_ERR_NO_DEVICE, "device index " + std::to_string(devices[i]) + " out of range: " + std::to_string(ndev) + " device(s) visible");
+        if (!host_reduce) for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) return gfail(nullptr, IBA_ERR_INVALID_ARG, "a device may appear once in an RCCL group (IBA_GROUP_REDUCE_HOST lifts this)");
     }
-    if (hipHostMalloc((void**)&g->h_part, sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride) != hipSuccess) return bail(IBA_ERR_HIP, "hipHostMalloc");
-    const ncclResult_t r = ncclCommInitAll(g->comm.data(), n_devices, g->dev.data());
-    if (r != ncclSuccess) return bail(IBA_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+    if (!host_reduce && !rccl().ok()) return gfail(nullptr, IBA_ERR_UNSUPPORTED, rccl().err);
+    iba_group* g = new iba_group;
+    g->n = n_devices; g->params = *params; g->stride = iba_partial_stride(); g->host_reduce = host_reduce;
+    g->dev.assign(devices, devices + n_devices);
+    g->h.assign(n_devices, nullptr); g->comm.assign(n_devices, nullptr); g->st.assign(n_devices, nullptr); g->d_part.assign(n_devices, nullptr); g->h_parts.assign(n_devices, nullptr);
+    g->wstatus.assign(n_devices, IBA_OK); g->werr.assign(n_devices, "");
+    g->cands.resize(IBA_MAX_BATCH); g->h_sum.resize((size_t)IBA_MAX_BATCH * g->stride);
+    shard(desc, n_devices, g->f_begin, g->f_end);
+    for (int i = 0; i < n_devices; ++i) g->workers.emplace_back(worker_main, g, i);
+    // the handles (static index builds, uploads, plane memo) are created concurrently, one per worker
+    iba_status s = run_all(g, [g, desc, params](int i) -> iba_status {
+        const iba_status cs = iba_create(desc, params, g->dev[i], g->f_begin[i], g->f_end[i], &g->h[i]);
+        if (cs != IBA_OK) return wfail(g, i, cs, std::string("iba_create: ") + iba_last_error(nullptr));
+        W_HIP(g, i, hipSetDevice(g->dev[i]));
+        W_HIP(g, i, hipStreamCreateWithFlags(&g->st[i], hipStreamNonBlocking));
+        W_HIP(g, i, hipMalloc((void**)&g->d_part[i], sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride));
+        W_HIP(g, i, hipHostMalloc((void**)&g->h_parts[i], sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride));
+        W_IBA(g, i, reserve_batch(g->h[i], IBA_MAX_BATCH));   // no allocation inside an evaluation (several threads are inside HIP then)
+        return IBA_OK;
+    });
+    if (s == IBA_OK && !host_reduce) {
+        int cur = -1; (void)hipGetDevice(&cur);   // the caller's current device survives the communicator setup
+        const ncclResult_t r = rccl().CommInitAll(g->comm.data(), n_devices, g->dev.data());
+        if (cur >= 0) (void)hipSetDevice(cur);
+        if (r != ncclSuccess) s = gfail(g, IBA_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r));
+    }
+    if (s != IBA_OK) { g_group_create_error = g->err; iba_group_destroy(g); return s; }
     *out = g;
     return IBA_OK;
 }
 
+iba_status iba_group_create(const iba_problem_desc* desc, const iba_params* params, const int32_t* devices, int32_t n_devices, iba_group** out) {
+    return iba_group_create_ex(desc, params, devices, n_devices, 0, out);
+}
+
+int32_t iba_group_comm_ranks(const iba_group* g) {   // what RCCL itself says about the communicator (0: host reduction)
+    if (!g || g->host_reduce || !g->comm[0]) return 0;
+    int c = 0;
+    return rccl().CommCount(g->comm[0], &c) == ncclSuccess ? c : -1;
+}
+
+double iba_group_last_issue_us(const iba_group* g) { return g ? g->last_issue_us : 0.0; }
+
 iba_status iba_group_set_params(iba_group* g, const iba_params* p) {
     if (!g || !p) return IBA_ERR_INVALID_ARG;
-    for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_set_params(g->h[i], p));
+    const iba_status s = run_all(g, [g, p](int i) -> iba_status { W_IBA(g, i, iba_set_params(g->h[i], p)); W_IBA(g, i, reserve_batch(g->h[i], IBA_MAX_BATCH)); return IBA_OK; });
+    if (s != IBA_OK) return s;
     g->params = *p;
     return IBA_OK;
 }
@@ -139,9 +313,7 @@ iba_status iba_group_eval_cost(iba_group* g, const double* x, int32_t B, iba_cos
     if (!g || !x || !out || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
     for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {   // larger batches run as consecutive chunks
         const int Bc = std::min(IBA_MAX_BATCH, B - b0);
-        for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_cost_partial(g->h[i], x + 7 * b0, Bc, g->d_part[i], g->st[i]));
-        iba_status s = allreduce(g, Bc); if (s != IBA_OK) return s;
-        s = fetch(g, Bc); if (s != IBA_OK) return s;
+        iba_status s = eval_chunk(g, x + 7 * b0, Bc, kEvalCost); if (s != IBA_OK) return s;
         s = iba_finalize_cost(&g->params, g->h_part, Bc, out + b0); if (s != IBA_OK) return s;
     }
     return IBA_OK;
@@ -163,9 +335,7 @@ iba_status iba_group_eval_full(iba_group* g, const double* x, int32_t B, iba_cos
     if (!g || !x || !cost || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
     for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
         const int Bc = std::min(IBA_MAX_BATCH, B - b0);
-        for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_full_partial(g->h[i], x + 7 * b0, Bc, g->d_part[i], g->st[i]));
-        iba_status s = allreduce(g, Bc); if (s != IBA_OK) return s;
-        s = fetch(g, Bc); if (s != IBA_OK) return s;
+        iba_status s = eval_chunk(g, x + 7 * b0, Bc, kEvalFull); if (s != IBA_OK) return s;
         s = iba_finalize_cost(&g->params, g->h_part, Bc, cost + b0); if (s != IBA_OK) return s;
         s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
     }
@@ -176,9 +346,7 @@ iba_status iba_group_eval_normal(iba_group* g, const double* x, int32_t B, iba_n
     if (!g || !x || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
     for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
         const int Bc = std::min(IBA_MAX_BATCH, B - b0);
-        for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_normal_partial(g->h[i], x + 7 * b0, Bc, g->d_part[i], g->st[i]));
-        iba_status s = allreduce(g, Bc); if (s != IBA_OK) return s;
-        s = fetch(g, Bc); if (s != IBA_OK) return s;
+        iba_status s = eval_chunk(g, x + 7 * b0, Bc, kEvalNormal); if (s != IBA_OK) return s;
         s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
     }
     return IBA_OK;
@@ -186,17 +354,15 @@ iba_status iba_group_eval_normal(iba_group* g, const double* x, int32_t B, iba_n
 
 iba_status iba_group_build_problem(iba_group* g, const double* x_assoc) {
     if (!g || !x_assoc) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_build_problem(g->h[i], x_assoc));
-    return IBA_OK;
+    make_cands_host(x_assoc, 1, g->cands.data());
+    return run_all(g, [g](int i) -> iba_status { W_IBA(g, i, build_problem_cands(g->h[i], g->cands.data())); return IBA_OK; });
 }
 
 iba_status iba_group_eval_factors(iba_group* g, const double* x, int32_t B, iba_normal_out* normal) {
     if (!g || !x || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
     for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
         const int Bc = std::min(IBA_MAX_BATCH, B - b0);
-        for (int i = 0; i < g->n; ++i) G_IBA(g, i, iba_eval_factors_partial(g->h[i], x + 7 * b0, Bc, g->d_part[i], g->st[i]));
-        iba_status s = allreduce(g, Bc); if (s != IBA_OK) return s;
-        s = fetch(g, Bc); if (s != IBA_OK) return s;
+        iba_status s = eval_chunk(g, x + 7 * b0, Bc, kEvalFactors); if (s != IBA_OK) return s;
         s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
     }
     return IBA_OK;
@@ -258,8 +424,41 @@ iba_status iba_group_calibrate_mads(iba_group* g, const double* x0, const iba_ma
 // path on the caller's ncclComm_t, so that nothing but this header is needed on the caller's side.
 iba_status iba_comm_allreduce(void* nccl_comm, void* d_partials, int32_t B, void* stream) {
     if (!nccl_comm || !d_partials || B < 1) return IBA_ERR_INVALID_ARG;
-    const ncclResult_t r = ncclAllReduce(d_partials, d_partials, (size_t)B * (size_t)iba_partial_stride(), ncclDouble, ncclSum, (ncclComm_t)nccl_comm, (hipStream_t)stream);
+    if (!rccl().ok()) return IBA_ERR_UNSUPPORTED;
+    const ncclResult_t r = rccl().AllReduce(d_partials, d_partials, (size_t)B * (size_t)iba_partial_stride(), ncclDouble, ncclSum, (ncclComm_t)nccl_comm, (hipStream_t)stream);
     return r == ncclSuccess ? IBA_OK : IBA_ERR_HIP;
+}
+
+// a communicator over the given devices of this process, for callers of iba_comm_allreduce that have no RCCL headers of
+// their own (and for its test): comms[i] belongs to devices[i]
+iba_status iba_comm_init_all(void** comms, const int32_t* devices, int32_t n) {
+    if (!comms || !devices || n < 1) return IBA_ERR_INVALID_ARG;
+    if (!rccl().ok()) return IBA_ERR_UNSUPPORTED;
+    std::vector<ncclComm_t> c((size_t)n, nullptr); std::vector<int> d(devices, devices + n);
+    if (rccl().CommInitAll(c.data(), n, d.data()) != ncclSuccess) return IBA_ERR_HIP;
+    for (int i = 0; i < n; ++i) comms[i] = (void*)c[i];
+    return IBA_OK;
+}
+int32_t iba_comm_count(void* nccl_comm) {
+    int c = 0;
+    if (!nccl_comm || !rccl().ok() || rccl().CommCount((ncclComm_t)nccl_comm, &c) != ncclSuccess) return -1;
+    return c;
+}
+iba_status iba_comm_destroy(void* nccl_comm) {
+    if (!nccl_comm) return IBA_ERR_INVALID_ARG;
+    if (!rccl().ok()) return IBA_ERR_UNSUPPORTED;
+    return rccl().CommDestroy((ncclComm_t)nccl_comm) == ncclSuccess ? IBA_OK : IBA_ERR_HIP;
+}
+
+// which librccl this process runs, and whether it is the version the library was compiled against:
+// "path=<file> runtime=<code> header=<code> match=<0|1>"
+iba_status iba_rccl_info(char* buf, int32_t cap, int32_t* runtime_version, int32_t* header_version) {
+    if (header_version) *header_version = NCCL_VERSION_CODE;
+    if (runtime_version) *runtime_version = 0;
+    if (!rccl().ok()) { if (buf && cap > 0) std::snprintf(buf, (size_t)cap, "%s", rccl().err.c_str()); return IBA_ERR_UNSUPPORTED; }
+    if (runtime_version) *runtime_version = rccl().runtime_version;
+    if (buf && cap > 0) std::snprintf(buf, (size_t)cap, "path=%s runtime=%d header=%d match=%d", rccl().path.c_str(), rccl().runtime_version, (int)NCCL_VERSION_CODE, rccl().runtime_version == NCCL_VERSION_CODE ? 1 : 0);
+    return IBA_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,24 @@
+// Library-internal interface between the single-device entry points (iba_capi.hip) and the multi-GPU group (iba_group.hip):
+// the host-side candidate block is computed ONCE per call (Sim3Exp, SE3Exp(-x) and their duals: ~0.7 us per candidate) and
+// handed to every device's launch chain, instead of once per device.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/iba_mi355x.h"
+#include "iba_types.hpp"
+
+namespace iba {
+
+enum EvalKind { kEvalCost = 0, kEvalNormal = 1, kEvalFull = 2, kEvalFactors = 3 };
+
+// Cand block of B candidates x (7 doubles each): g2o_tools.h:105-140, 149-183 on the host
+void make_cands_host(const double* x, int B, Cand* out);
+// launch chain of one chunk (B <= IBA_MAX_BATCH) on `st` from a ready candidate block (host memory, copied into the handle's
+// pinned ring before the call returns); no synchronisation
+iba_status eval_partial_cands(iba_handle* h, const Cand* host_cands, int B, EvalKind kind, double* d_partials, hipStream_t st);
+// iba_build_problem from a ready candidate (synchronises the handle's stream: the frozen counts are read back)
+iba_status build_problem_cands(iba_handle* h, const Cand* host_cand);
+// work buffers for batches of up to B candidates, so that no evaluation allocates
+iba_status reserve_batch(iba_handle* h, int B);
+
+}  // namespace iba

@@ -42,6 +42,7 @@ struct MadsOptions {
     int vns_max_k = 6;                              // largest shake, in multiples of vns_amplitude * first frame
     double vns_amplitude = 0.5;
     int vns_mesh_index = 0;                         // mesh index a restarted descent begins with
+    std::vector<double>* trace = nullptr;           // optional: every point handed to the black box, in order, as 8 doubles (x, f)
 };
 struct MadsPoint { double x[kMadsN]; double f, c[3], h; };
 struct MadsResult {
@@ -111,6 +112,7 @@ inline bool mads_minimize(const double* x0, const MadsOptions& o, EvalBatch eval
                 p.h = (p.f == p.f) ? mads_h(p.c) : inf;
                 cache[key_of(p.x)] = p;
                 ++res.evaluations;
+                if (o.trace) { o.trace->insert(o.trace->end(), p.x, p.x + n); o.trace->push_back(p.f); }
             }
         }
         return true;

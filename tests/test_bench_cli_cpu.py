@@ -1,0 +1,35 @@
+"""bench.py's GPU-count contract, checked without a GPU: `--gpus N` is what the number will be labelled with, so a run that
+cannot drive N devices must stop with a message instead of measuring something smaller (round 2's bench.py parsed the flag and
+ignored it)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IBA_FORCE_DIST")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_more_gpus_than_devices_is_refused():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box has the devices")
+    for launch in ("auto", "group"):
+        r = _run(["--gpus", "2", "--launch", launch, "--steps", "1", "--warmup", "0"])
+        assert r.returncode != 0
+        assert "--gpus 2 asked for" in r.stderr and "visible" in r.stderr, r.stderr
+        assert "{" not in r.stdout            # no JSON line under a wrong label
+
+
+def test_gpus_flag_must_agree_with_the_launcher():
+    r = _run(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE=4" in r.stderr
+    r = _run(["--gpus", "0"])
+    assert r.returncode != 0
+    r = _run(["--gpus", "2", "--launch", "group"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "one process for all GPUs" in r.stderr

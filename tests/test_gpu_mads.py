@@ -51,3 +51,44 @@ def test_mads_recovers_the_planted_extrinsic():
     x3, _ = h.calibrate_lm(x)
     e3 = _err(x3, x_gt)
     assert e3[0] < 3e-3 and e3[1] < 0.03
+
+
+def test_iterates_equal_the_oracle_driven_restatement():
+    """SURVEY 8(f) row 2 with an oracle: the device MADS (csrc/iba_mads.hpp on iba_eval_bbo) against the independent Python
+    restatement of the same rules (oracle/mads.py) driven by the CPU oracle's eval_bbo, on a 30-keyframe scene. The two black
+    boxes agree to ~1e-11 relative, so the sequences of evaluated points are identical until a comparison of two nearly equal
+    objective values falls the other way; they must be identical for at least the first 200 evaluations, and the end points of
+    the two runs must agree within 1e-4 rad / 1e-3 m."""
+    from oracle import binding as ob
+    from oracle import mads as om
+    prob, meta = synth.make_scene(n_frames=30, pts_per_frame=6000, n_keypoints=1000, seed=4)
+    x_gt = meta["x_gt"]
+    rng = np.random.default_rng(1)
+    x0 = x_gt + np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3), [0.4]])
+    p = abi.reference_yaml_params()
+    budget = 1200
+    h = pkg.IbaHandle(prob, p)
+    x, r, tr = h.calibrate_mads(x0, trace=True, max_bb_eval=budget, vns_max_idle=0)
+    h.close()
+    o = ob.Oracle(prob)
+    nt = min(16, ob.max_threads())
+
+    def box(X):
+        out = o.eval_bbo(p, np.array(X), 0.094, 0.95, nthreads=nt)
+        return [(b.f, (b.c1, b.c2, b.c3)) for b in out]
+
+    opt = om.default_options(list(x0))
+    opt.update(max_bb_eval=budget, vns_max_idle=0)
+    ro, tro = om.minimize(list(x0), opt, box)
+    ox = np.array([t[0] for t in tro])
+    n = min(len(tr), len(ox))
+    same = np.all(tr[:n, :7] == ox[:n], axis=1)
+    prefix = n if same.all() else int(np.argmin(same))
+    fdiff = np.max(np.abs(tr[:prefix, 7] - np.array([t[1] for t in tro[:prefix]])) / np.abs(tr[:prefix, 7]))
+    e = _err(x, np.array(ro["x"]))
+    print(f"MADS vs oracle-driven restatement: {len(tr)} / {len(ox)} evaluations, identical for the first {prefix}; objective values agree to {fdiff:.1e}; end points {e[0]:.2e} rad, {e[1]:.2e} m apart")
+    assert prefix >= 200
+    assert fdiff < 1e-9
+    assert e[0] <= 1e-4 and e[1] <= 1e-3 and abs(x[6] - ro["x"][6]) <= 1e-3
+    if prefix == n:   # never diverged: everything else is equal too
+        assert r.evaluations == ro["evaluations"] and r.iterations == ro["iterations"] and r.feasible == ro["feasible"]

@@ -70,3 +70,47 @@ def test_variable_neighbourhood_restarts_leave_local_basins():
     assert f_local[1] < 0.5 * f_local[0]          # the restarts found a much deeper basin than the single descent
     x, r = pkg.mads_selftest(0, X0, lb=lb, ub=ub, vns_max_idle=3, max_bb_eval=200000)
     assert r.restarts >= 3 and r.stop_reason == 1 and np.allclose(x, A, atol=1e-3)   # the restarts end by themselves
+
+
+# ---- the driver against its independent restatement (oracle/mads.py): identical evaluation sequences ----
+def _diff_sequences(problem, x0, **opts):
+    from oracle import mads as om
+    x, r, tr = pkg.mads_selftest(problem, x0, trace=True, **opts)
+    o = {k: (list(v) if k in ("lb", "ub", "init_frame") else v) for k, v in opts.items()}
+    if "speculative" in o:
+        o["speculative"] = bool(o["speculative"])
+    ro, tro = om.minimize(list(x0), o, om.selftest_box(problem))
+    assert len(tr) == r.evaluations == ro["evaluations"] == len(tro), (len(tr), r.evaluations, ro["evaluations"])
+    ox = np.array([t[0] for t in tro])
+    of = np.array([t[1] for t in tro])
+    assert np.array_equal(tr[:, :7], ox), "first differing evaluation: %d" % int(np.argmax(np.any(tr[:, :7] != ox, axis=1)))
+    assert np.array_equal(tr[:, 7], of)
+    assert np.array_equal(x, np.array(ro["x"])) and r.f == ro["f"] and r.feasible == ro["feasible"]
+    assert (r.iterations, r.batches, r.cache_hits, r.restarts, r.stop_reason) == (ro["iterations"], ro["batches"], ro["cache_hits"], ro["restarts"], ro["stop_reason"])
+    return r
+
+
+def test_iterates_equal_the_restatement_on_the_four_boxes():
+    """Every point handed to the black box, in order, bit for bit: mesh / frame update, OrthoMADS directions (Halton stream),
+    progressive barrier incl. the infeasible incumbent and the h_max update, speculative point, cache, budget cut."""
+    x_inf = X0.copy()
+    x_inf[0] = 0.9
+    r = _diff_sequences(0, X0, **BOX)
+    assert r.evaluations > 300
+    r = _diff_sequences(1, x_inf, **BOX)                      # infeasible start: both incumbents live
+    assert r.feasible == 1
+    _diff_sequences(2, X0, **BOX)                             # two constraints active at the optimum
+    _diff_sequences(0, X0, max_bb_eval=200, **BOX)            # the budget cuts a batch short
+    _diff_sequences(0, X0, bases_per_poll=1, speculative=0, seed=3, **BOX)   # plain OrthoMADS 2N, another Halton stream
+    lb, ub = X0 - 1.0, X0 + 1.0
+    ub[0] = 0.1
+    _diff_sequences(0, X0, lb=lb, ub=ub, vns_max_idle=0)      # the minimiser is outside the box
+
+
+def test_restarts_equal_the_restatement():
+    """Variable-neighbourhood restarts: shake amplitude k, idle counter, the 'better' rule — on the box with many local
+    basins, where restarts do change the answer."""
+    lb, ub = X0 - 0.5, X0 + 0.5
+    r = _diff_sequences(3, X0, lb=lb, ub=ub, vns_max_idle=3, max_bb_eval=60000)
+    assert r.restarts >= 3
+    _diff_sequences(1, X0, lb=lb, ub=ub, vns_max_idle=2, max_bb_eval=60000)
