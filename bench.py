@@ -92,6 +92,11 @@ def main():
             sys.exit(subprocess.call(cmd, env=env))
 
     t_start = time.perf_counter()
+    # stdout carries ONE line, the JSON record: RCCL prints a version banner to stdout when its first communicator is made,
+    # so everything but the record goes to stderr's descriptor
+    sys.stdout.flush()
+    fd_record = os.dup(1)
+    os.dup2(2, 1)
 
     def stage(msg):
         if int(os.environ.get("RANK", "0")) == 0:
@@ -442,8 +447,8 @@ def main():
                 "after_lm_err_rad_m_vs_planted": [ec[0], ec[1]], "device_vs_cpu_end_point_rad_m": [ed[0], ed[1]], "cpu_seconds": time.perf_counter() - t0,
                 "reading": "device and CPU LM end at the same point: the shift away from the planted extrinsic is the iba_local objective's own optimum on this scene"}
     res.pop("_lm_check_start", None)
-    if rank == 0:
-        print(json.dumps(res), flush=True)   # flushed before any teardown
+    if rank == 0:   # written (and flushed) before any teardown
+        os.write(fd_record, (json.dumps(res) + "\n").encode())
     h.close()
     if grp is not None:
         grp.close()

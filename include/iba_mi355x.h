@@ -261,6 +261,10 @@ iba_status iba_set_timing(iba_handle* h, int32_t enable);
 iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_kernel_ms, float* rest_ms);
 /* debug: host copy of the summed partial blocks of the last iba_eval_* call */
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
+/* debug: which 2d-3d association ran in the last evaluation chain: 1 = the batch shared one pair search per keyframe
+ * (a batch of >= 4 nearby candidates), 0 = every candidate searched for itself. The results are the same bits either way.
+ * Environment (read at iba_create): IBA_COMMON_PAIRS=0 never share, 2 share whenever the bound allows; IBA_COMMON_MAX_PX. */
+int32_t iba_debug_last_path(const iba_handle* h);
 /* debug: exact 1-NN (nanoflann semantics with the lowest-index tie rule, iba_global.cpp:116-122) of n LiDAR-frame query
  * points in the scan of local frame `frame`, run through the search kernel's own kd search, one lane per query: original point
  * index and exact squared distance. mode 1: as the association path's query alone; 2: as the cost path's alone; 3 / 4: both paths

@@ -259,6 +259,12 @@ class IbaHandle:
         x = self._x(x)
         self._chk(self.lib.iba_eval_full_partial(self.h, _p(x), C.c_int32(len(x)), C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
 
+    @property
+    def last_path(self):
+        """1: the last evaluation shared the 2d-3d pair search over the batch, 0: every candidate searched for itself"""
+        self.lib.iba_debug_last_path.argtypes = [C.c_void_p]
+        return int(self.lib.iba_debug_last_path(self.h))
+
     def set_timing(self, on=True):
         self._chk(self.lib.iba_set_timing(self.h, C.c_int32(1 if on else 0)))
 

@@ -77,6 +77,17 @@ struct iba_handle {
     DevBuf<double> d_nn_partials;         // IBA_MAX_BATCH * n_frames * kMaxSlices * kNNPartial
     hipEvent_t ev_mid = nullptr;
     float last_assoc_ms = 0.f, last_nn_ms = 0.f;
+    // common pairs of a batch of nearby candidates (iba_pairs_kernel + iba_assoc2_kernel)
+    LdsLayout alay2{};                    // LDS plan of iba_assoc2_kernel
+    DevBuf<PairRec> d_pairs;              // n_frames x pair_cap
+    DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
+    int pair_cap = 0, hard_cap = 0, pairs_slices = 8;
+    int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
+    int common_min_batch = 4;             // IBA_COMMON_MIN_BATCH
+    double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
+    double max_fx = 0.0;
+    const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
+    int last_path = 0;                    // 1: the last evaluation chain used the common pairs
 
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
     DevBuf<float> xs, ys, zs, chunk_box; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
@@ -222,6 +233,58 @@ bool layout_nn(const iba_handle* h, NNLayout& L) {
     return L.total <= kLdsBytes;
 }
 
+// LDS plan of iba_assoc2_kernel: best d^2, best index and flag word per keypoint, the reduction slab
+bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
+    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;
+    L = LdsLayout{};
+    uint32_t off = 0;
+    L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
+    L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
+    L.off_kfl = off; off += 4u * std::max(h->maxK, 1u);
+    off = align_up(off, 16); L.off_red = off; off += red_bytes;
+    L.total = align_up(off, 16);
+    return L.total <= kLdsBytes;
+}
+
+// The reference candidate of a batch and the spread of the batch around it (see iba_pairs_kernel): reference = the candidate
+// nearest the batch mean, rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i, both inflated for their own
+// rounding. Returns false when the batch is too wide for common pairs to pay (nominal projection spread above max_px at a
+// point 12 m out, 10 m deep), in which case every candidate searches for itself (iba_assoc_kernel).
+bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
+    double mean[12] = {0};
+    for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].R[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].t[i]; }
+    for (double& m : mean) m /= (double)B;
+    int ref = 0; double best = INFINITY;
+    for (int b = 0; b < B; ++b) {
+        double d = 0;
+        for (int i = 0; i < 9; ++i) d = std::max(d, 12.0 * std::fabs(hc[b].R[i] - mean[i]));
+        for (int i = 0; i < 3; ++i) d = std::max(d, std::fabs(hc[b].t[i] - mean[9 + i]));
+        if (d < best) { best = d; ref = b; }
+    }
+    if (!(best < INFINITY)) return false;   // a NaN candidate: no bound
+    const Cand& c0 = hc[ref];
+    std::memcpy(cr.R, c0.R, sizeof(cr.R)); std::memcpy(cr.t, c0.t, sizeof(cr.t));
+    for (int i = 0; i < 9; ++i) cr.rho[i] = 0; for (int i = 0; i < 3; ++i) cr.tau[i] = 0;
+    for (int b = 0; b < B; ++b) {
+        double A[9];
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) A[r * 3 + q] = (hc[b].R[r * 3] * c0.R[q * 3] + hc[b].R[r * 3 + 1] * c0.R[q * 3 + 1]) + hc[b].R[r * 3 + 2] * c0.R[q * 3 + 2];   // R_b R_0^T
+        for (int r = 0; r < 3; ++r) {
+            const double a = hc[b].t[r] - ((A[r * 3] * c0.t[0] + A[r * 3 + 1] * c0.t[1]) + A[r * 3 + 2] * c0.t[2]);
+            if (!(std::fabs(a) <= 1e30)) return false;
+            cr.tau[r] = std::max(cr.tau[r], std::fabs(a));
+            for (int q = 0; q < 3; ++q) { const double e = std::fabs(A[r * 3 + q] - (r == q ? 1.0 : 0.0)); if (!(e <= 4.0)) return false; cr.rho[r * 3 + q] = std::max(cr.rho[r * 3 + q], e); }
+        }
+    }
+    double rho_row = 0, tau_max = 0;
+    for (int r = 0; r < 3; ++r) { rho_row = std::max(rho_row, cr.rho[r * 3] + cr.rho[r * 3 + 1] + cr.rho[r * 3 + 2]); tau_max = std::max(tau_max, cr.tau[r]); }
+    for (int i = 0; i < 9; ++i) cr.rho[i] = cr.rho[i] * (1.0 + 1e-9) + 1e-15;
+    for (int i = 0; i < 3; ++i) cr.tau[i] = cr.tau[i] * (1.0 + 1e-9) + 1e-15;
+    if (h->common_mode >= 2) return true;
+    const double nominal_px = h->max_fx * (rho_row * 12.0 + tau_max) * 1.8 / 10.0;
+    return nominal_px <= h->common_max_px;
+}
+
 iba_status ensure_scratch(iba_handle* h);
 iba_status compute_plane_cache(iba_handle* h) {
     const iba_params& p = h->params;
@@ -275,6 +338,7 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     if (pre) std::memcpy(hc, pre, sizeof(Cand) * (size_t)B);
     else for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
     Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
+    h->last_hc = hc;
     HIP_TRY(h, hipMemcpyAsync(dc, hc, sizeof(Cand) * B, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipEventRecord(h->ring_ev[slot], st));
     h->ring_used[slot] = true;
@@ -359,6 +423,20 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     if (refit && frozen && !h->d_frefit.p) { iba_status es = ensure_lists(h, 1, st); if (es != IBA_OK) return es; }
     const bool wide_fit = std::max(h->params.norm_max_pts, h->params.neigh_max_pts) > 32;
     const dim3 fit_grid((h->lstride + 63) / 64, nf, B);
+    // 2d-3d association: a batch of nearby candidates shares ONE search for the (scan point, keypoint) pairs per keyframe
+    // (iba_pairs_kernel) and every candidate runs the exact test on that list (iba_assoc2_kernel); a lone candidate, a small or a
+    // wide batch searches per candidate (iba_assoc_kernel). Same results either way, bit for bit.
+    CommonRef cref;
+    const bool common = h->common_mode > 0 && !frozen && B >= h->common_min_batch && h->d_pairs.p && h->last_hc && common_ref(h, h->last_hc, B, cref);
+    h->last_path = common ? 1 : 0;
+    if (common) {
+        HIP_TRY(h, hipMemsetAsync(h->d_pcounts.p, 0, sizeof(uint32_t) * (size_t)nf * kCountStride, st));
+        hipLaunchKernelGGL(iba_pairs_kernel, dim3(h->pairs_slices, nf), dim3(kPairsThreads), 0, st, dp, cref, h->params.max_pixel_dist, h->pairs_slices, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p,
+                           h->pair_cap, h->hard_cap);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(iba_assoc2_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                           h->d_frame_partials.p, nrec, h->d_he.p, fl, fm, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
+    } else
     hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                        h->d_frame_partials.p, nrec, (uint32_t*)nullptr, h->d_he.p, fl, fm, fc, lc, (int)h->lstride);
     HIP_TRY(h, hipGetLastError());
@@ -438,7 +516,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -545,6 +623,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         for (int i = 0; i < 12; ++i) { x.Tcw[i] = (double)d->Tcw[12 * f + i]; x.Tc_next[i] = (double)d->Tc_next[12 * f + i]; x.Tl_next[i] = d->Tl_next[12 * f + i]; }
         x.he_valid = f < F - 1 ? 1 : 0; x.global_frame = f;
         h->maxP = std::max(h->maxP, x.P); h->maxPpad = std::max(h->maxPpad, x.Ppad); h->maxK = std::max(h->maxK, x.K);
+        h->max_fx = std::max(h->max_fx, std::max(std::fabs(x.fx), std::fabs(x.fy)));
         h->maxNodes = std::max<uint32_t>(h->maxNodes, (uint32_t)fb[lf].nodes.size());
         h->maxBitmapWords = std::max<uint32_t>(h->maxBitmapWords, (uint32_t)fb[lf].grid.bitmap.size());
     }
@@ -632,7 +711,12 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
+    if (const char* e = std::getenv("IBA_COMMON_PAIRS")) h->common_mode = std::atoi(e);
+    if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
+    if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
     if (!layout_assoc(h, h->alay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
+    if (!layout_assoc2(h, h->alay2)) h->common_mode = 0;
     if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
     { NNLayout probe; if (!layout_nn(h, probe)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel"); } }
     h->lstride = std::max(1u, std::min(h->maxK, h->maxKw));
@@ -655,6 +739,14 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
     if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
     if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
+    if (h->common_mode > 0) {   // common lists of one batch: (scan point, keypoint) pairs and hard points per frame
+        h->pair_cap = (int)std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, 4u * h->maxK));
+        h->hard_cap = 1024;
+        if (const char* e = std::getenv("IBA_DEBUG_PAIR_CAP")) { h->pair_cap = std::max(1, std::atoi(e)); h->hard_cap = std::max(1, std::atoi(e) / 8); }   // tests: force the overflow path
+        if ((er = h->d_pairs.alloc((size_t)std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
+        if ((er = h->d_hard.alloc((size_t)std::max(nf, 1) * h->hard_cap)) != hipSuccess) return bail("alloc hard list", er);
+        if ((er = h->d_pcounts.alloc((size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("alloc pair counts", er);
+    }
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
     if ((er = h->d_he.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1))) != hipSuccess) return bail("alloc he", er);
     if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
@@ -665,6 +757,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel
     if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     const void* nfns[9] = {(const void*)iba_nn_kernel<1, 0>, (const void*)iba_nn_kernel<2, 0>, (const void*)iba_nn_kernel<3, 0>, (const void*)iba_nn_kernel<1, 1>, (const void*)iba_nn_kernel<2, 1>, (const void*)iba_nn_kernel<3, 1>,
                            (const void*)iba_nn_kernel<1, 2>, (const void*)iba_nn_kernel<2, 2>, (const void*)iba_nn_kernel<3, 2>};
     for (const void* fn : nfns)
@@ -820,6 +913,9 @@ iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
     std::memcpy(out, h->h_partials, sizeof(double) * B * kPartialStride);
     return IBA_OK;
 }
+
+// debug: 1 when the last evaluation chain shared the 2d-3d pair search over the batch (iba_pairs_kernel + iba_assoc2_kernel)
+int32_t iba_debug_last_path(const iba_handle* h) { return h ? h->last_path : -1; }
 
 // debug: exact 1-NN of n LiDAR-frame queries in the scan of a local frame, through the frame kernels' own search
 iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n, int32_t mode, uint32_t* out_idx, double* out_d2) {

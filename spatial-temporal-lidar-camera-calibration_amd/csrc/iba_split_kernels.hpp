@@ -72,6 +72,174 @@ template <class PRM> __device__ __forceinline__ double cost_res(const PRM& prm, 
     return is_plane ? dist : -dist;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The second half of an association block, shared by iba_assoc_kernel and iba_assoc2_kernel: from the winners of the 2d-3d
+// association (s_best_idx[k] = original index of keypoint k's scan point, or kNone) to corrset size, the work list in keypoint
+// order, the local plane at the matched point, the 3d-2d covisible residuals (iba_global.cpp:291-328) and the partial record.
+// One function, one order of every sum: which kernel ran the first half cannot be told from the results.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(4))) const KArgs KArgsC;
+__device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, const uint32_t* s_best_idx, const uint32_t* s_kfl, uint32_t* s_list,
+                                           double* s_red, const double* s_rel, const uint32_t K, const int want, const int dbg, const bool refit, const int b, const int f, const int nf,
+                                           double* __restrict__ part, const double* __restrict__ he, uint4* __restrict__ flist, float4* __restrict__ fmp,
+                                           uint32_t* __restrict__ fcount, uint32_t* __restrict__ lcount, const int flist_stride) {
+#define dp (ka->dp)
+#define prm (ka->prm)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4* kp_mp = dp.kp_mp + h.kp_base;
+    const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
+
+    const double s = cd.s;
+    uint32_t n3 = 0;
+
+    // ---- phase 3: corrset.size() and the sizes of the work list, one contiguous range of keypoints per wave ----
+    // (the list is in keypoint order; two barriers in all: counts -> prefix -> entries)
+    const uint32_t kw = ((K + (uint32_t)kWaves * 64u - 1u) / ((uint32_t)kWaves * 64u)) * 64u;   // keypoints per wave, a multiple of 64
+    const uint32_t kbeg = (uint32_t)wave * kw;
+    uint32_t n_corr = 0u, cntC = 0u, cntA = 0u;
+    {
+        uint32_t nv = 0u, nc = 0u, na = 0u;
+        for (uint32_t k = kbeg + (uint32_t)lane; k < kbeg + kw; k += 64u) {
+            const bool valid = k < K && s_best_idx[k] != kNone;
+            const int w = valid ? (int)s_kfl[k] : 0;
+            nv += (uint32_t)__popcll(__ballot(valid));
+            nc += (uint32_t)__popcll(__ballot(w != 0));
+            na += (uint32_t)__popcll(__ballot((w & 3) == 3));
+        }
+        uint32_t* s_cnt3 = (uint32_t*)s_red;   // 3 counts per wave (the reduction slab is not in use yet)
+        if (lane == 0) { s_cnt3[wave * 3] = nv; s_cnt3[wave * 3 + 1] = nc; s_cnt3[wave * 3 + 2] = na; }
+        __syncthreads();
+        for (int w = 0; w < kWaves; ++w) {
+            n_corr += s_cnt3[w * 3];
+            if (w < wave) { cntC += s_cnt3[w * 3 + 1]; cntA += s_cnt3[w * 3 + 2]; }
+        }
+    }
+    const bool usedA = (want & 1) && !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
+    const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
+    const PlaneRec* planes_local = dp.plane_local + h.pt_base;
+    uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
+    float4* fm = fmp + ((size_t)b * nf + f) * (size_t)flist_stride;   // the MapPoint of every entry, for the search kernel
+    uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
+    // ---- work list: keypoints with a correspondence that can own a term: a MapPoint and/or a covisible match for the
+    //      cost (iba_global.cpp:225, 295-300), both for a residual block (iba_local.cpp:213, 259-260); entry = k | w << 16
+    //      (bits 16,17: MapPoint / covisible-match flags) ----
+    {
+        uint32_t* s_cnt3 = (uint32_t*)s_red;
+        uint32_t at = usedC ? cntC : (usedA ? cntA : 0u);   // entries of the waves before this one
+        for (int w = 0; w < kWaves; ++w) n3 += usedC ? s_cnt3[w * 3 + 1] : (usedA ? s_cnt3[w * 3 + 2] : 0u);
+        for (uint32_t k0 = kbeg + (uint32_t)lane; k0 < kbeg + kw; k0 += 256u) {   // four steps at a time: their gathers are in flight together
+            uint32_t ip[4]; int ww[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = k0 + 64u * (uint32_t)j;
+                const bool valid = k < kbeg + kw && k < K && s_best_idx[k] != kNone;
+                const int w = valid ? (int)s_kfl[k] : 0;
+                const bool wantk = (usedC && w != 0) || (usedA && (w & 3) == 3);
+                ww[j] = wantk ? (w & 3) | 4 : 0;
+                ip[j] = wantk ? inv_perm[s_best_idx[k]] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = k0 + 64u * (uint32_t)j;
+                const bool wantk = ww[j] != 0;
+                const unsigned long long bal = __ballot(wantk);
+                if (wantk) {
+                    const uint32_t i = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    s_list[i] = k | (((uint32_t)ww[j] & 3u) << 16);   // the slot mask is read from s_kfl where it is needed
+                    s_pos[i] = ip[j];
+                }
+                at += (uint32_t)__popcll(bal);
+            }
+        }
+    }
+    __syncthreads();
+    if (dbg == 6) return;
+    double sum2d = 0.0;
+    uint32_t c2 = 0, v2 = 0;
+    // association: local plane at the matched point (iba_local.cpp:207-231); list entry for the search / factor kernels
+    for (uint32_t i = tid; i < n3; i += kThreads) {
+        const uint32_t e = s_list[i], k = e & 0xffffu;
+        uint32_t ax_ = kNone, flags = 0u;
+        if (usedA && ((e >> 16) & 3u) == 3u) {
+            const uint32_t pos = s_pos[i];
+            if (refit) { ax_ = pos; flags |= kFlagA; }
+            else {
+                const PlaneRec rec = planes_local[pos];
+                const bool neigh_ok = local_neigh_ok(prm, rec);                     // pointcloud.h:752
+                if (neigh_ok && local_plane_ok(prm, rec)) ax_ = pos;               // bvalid_plane (:231)
+                if (neigh_ok) flags |= kFlagA;   // no 3d-3d block either otherwise (the `continue` at :209-211)
+            }
+        }
+        if (usedC && prm.use_3d3d && ((e >> 16) & 1u)) flags |= kFlagC;
+        fl[i] = make_uint4(k, ax_, kNone, flags);   // .z (the 3d-3d block) is filled in by iba_nn_kernel
+        if (flags) fm[i] = kp_mp[k];
+    }
+    if (dbg == 7) return;
+    // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328): only the slots whose match bit is set
+    if (usedC) {
+        for (uint32_t i = tid; i < n3; i += kThreads) {
+            const uint32_t k = s_list[i] & 0xffffu, pos = s_pos[i];
+            uint32_t mask = s_kfl[k] >> 2;
+            if (!mask) continue;
+            float xf_, yf_, zf_; load_pt<true>(c, pos, xf_, yf_, zf_);
+            const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
+            const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
+            const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
+            const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
+            const float2* mrow = dp.match_uv + h.match_base + k;
+            float2 mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];
+            while (mask) {
+                const uint32_t sl = (uint32_t)__ffs((int)mask) - 1u;
+                mask &= mask - 1u;
+                const float2 cur = mm;
+                if (mask) mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];   // next match is in flight during the arithmetic
+                const double* rel = s_rel + sl * 12;
+                const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
+                const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
+                const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
+                const double ou = h.fx * p1x / p1z + h.cx;
+                const double ov = h.fy * p1y / p1z + h.cy;
+                if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
+                const double eu = ou - (double)cur.x, ev = ov - (double)cur.y;
+                const double dist = sqrt(eu * eu + ev * ev);
+                if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
+                ++c2;
+            }
+        }
+    }
+    if (tid == 0) { fcount[(size_t)b * nf + f] = usedA ? n3 : 0u; lcount[(size_t)b * nf + f] = n3; }
+    // K8: reduction -> record. The 3d-3d sums of this (candidate, frame) come from iba_nn_kernel's own records.
+    {
+        const double w2d = wave_sum_f64(sum2d);
+        const unsigned long long wa = wave_sum_u64((unsigned long long)c2 | ((unsigned long long)v2 << 32));
+        unsigned long long* s_redu = (unsigned long long*)s_red;
+        __syncthreads();
+        if (lane == 63) { s_red[wave * 4 + 0] = w2d; s_redu[wave * 4 + 2] = wa; }
+        __syncthreads();
+        if (tid < kPartialStride) {
+            double out = 0.0;
+            if (usedC) {
+                if (tid == P_SUM_3D2D) { for (int w = 0; w < kWaves; ++w) out += s_red[w * 4 + 0]; }
+                else if (tid == P_CNT_3D2D || tid == P_VALID_3D2D) {
+                    unsigned long long a = 0;
+                    for (int w = 0; w < kWaves; ++w) a += s_redu[w * 4 + 2];
+                    out = (double)(tid == P_CNT_3D2D ? (a & 0xffffffffull) : (a >> 32));
+                }
+                else if ((tid == P_CNT_3D3D || tid == P_VALID_3D3D) && !prm.use_3d3d) out = 1.0;   // iba_global.cpp:214-220
+                else if (tid == P_FRAMES) out = 1.0;
+                else if (tid == P_NCORR) out = (double)n_corr;
+                else if (tid == P_HE_SUM) out = h.he_valid ? he[(size_t)b * nf + f] : 0.0;
+                else if (tid == P_HE_CNT) out = h.he_valid ? 1.0 : 0.0;
+            }
+            if (tid == P_FRAMES_N) out = usedA ? 1.0 : 0.0;
+            else if (tid == P_NCORR_N) out = usedA ? (double)n_corr : 0.0;
+            part[tid] = out;
+        }
+    }
+#undef dp
+#undef prm
+}
+
 // iba_assoc_kernel. want: bit 0 = BuildProblem association wanted, bit 1 = BAError cost wanted, bit 2 = planes are refitted (plane_cache = 0). corr_out != nullptr: dump
 // the correspondences and return (iba_get_correspondences).
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads; block i runs on XCD i%8, so all candidates of a frame share an L2.
@@ -86,7 +254,6 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
                                                              const double* __restrict__ he, uint4* __restrict__ flist, float4* __restrict__ fmp, uint32_t* __restrict__ fcount,
                                                              uint32_t* __restrict__ lcount, int flist_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
-    typedef __attribute__((address_space(4))) const KArgs KArgsC;
     KArgsC* ka = (KArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // see iba_frame_kernel: parameter blocks are read where they are used
     (void)ka_by_value;
 #define dp (ka->dp)
@@ -415,160 +582,250 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 
     if (dbg == 5) return;
     IBA_RELOAD();
-    const float4* kp_mp = dp.kp_mp + h.kp_base;
-    const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
-
-    const double s = cd.s;
-    uint32_t n3 = 0;
-
-    // ---- phase 3: corrset.size() and the sizes of the work list, one contiguous range of keypoints per wave ----
-    // (the list is in keypoint order; two barriers in all: counts -> prefix -> entries)
-    const uint32_t kw = ((K + (uint32_t)kWaves * 64u - 1u) / ((uint32_t)kWaves * 64u)) * 64u;   // keypoints per wave, a multiple of 64
-    const uint32_t kbeg = (uint32_t)wave * kw;
-    uint32_t n_corr = 0u, cntC = 0u, cntA = 0u;
-    {
-        uint32_t nv = 0u, nc = 0u, na = 0u;
-        for (uint32_t k = kbeg + (uint32_t)lane; k < kbeg + kw; k += 64u) {
-            const bool valid = k < K && s_best_idx[k] != kNone;
-            const int w = valid ? (int)s_kfl[k] : 0;
-            nv += (uint32_t)__popcll(__ballot(valid));
-            nc += (uint32_t)__popcll(__ballot(w != 0));
-            na += (uint32_t)__popcll(__ballot((w & 3) == 3));
-        }
-        uint32_t* s_cnt3 = (uint32_t*)s_red;   // 3 counts per wave (the reduction slab is not in use yet)
-        if (lane == 0) { s_cnt3[wave * 3] = nv; s_cnt3[wave * 3 + 1] = nc; s_cnt3[wave * 3 + 2] = na; }
-        __syncthreads();
-        for (int w = 0; w < kWaves; ++w) {
-            n_corr += s_cnt3[w * 3];
-            if (w < wave) { cntC += s_cnt3[w * 3 + 1]; cntA += s_cnt3[w * 3 + 2]; }
-        }
-    }
-    const bool usedA = (want & 1) && !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
-    const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
-    const PlaneRec* planes_local = dp.plane_local + h.pt_base;
-    uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
-    float4* fm = fmp + ((size_t)b * nf + f) * (size_t)flist_stride;   // the MapPoint of every entry, for the search kernel
-    uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
-    // ---- work list: keypoints with a correspondence that can own a term: a MapPoint and/or a covisible match for the
-    //      cost (iba_global.cpp:225, 295-300), both for a residual block (iba_local.cpp:213, 259-260); entry = k | w << 16
-    //      (bits 16,17: MapPoint / covisible-match flags) ----
-    {
-        uint32_t* s_cnt3 = (uint32_t*)s_red;
-        uint32_t at = usedC ? cntC : (usedA ? cntA : 0u);   // entries of the waves before this one
-        for (int w = 0; w < kWaves; ++w) n3 += usedC ? s_cnt3[w * 3 + 1] : (usedA ? s_cnt3[w * 3 + 2] : 0u);
-        for (uint32_t k0 = kbeg + (uint32_t)lane; k0 < kbeg + kw; k0 += 256u) {   // four steps at a time: their gathers are in flight together
-            uint32_t ip[4]; int ww[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t k = k0 + 64u * (uint32_t)j;
-                const bool valid = k < kbeg + kw && k < K && s_best_idx[k] != kNone;
-                const int w = valid ? (int)s_kfl[k] : 0;
-                const bool wantk = (usedC && w != 0) || (usedA && (w & 3) == 3);
-                ww[j] = wantk ? (w & 3) | 4 : 0;
-                ip[j] = wantk ? inv_perm[s_best_idx[k]] : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t k = k0 + 64u * (uint32_t)j;
-                const bool wantk = ww[j] != 0;
-                const unsigned long long bal = __ballot(wantk);
-                if (wantk) {
-                    const uint32_t i = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                    s_list[i] = k | (((uint32_t)ww[j] & 3u) << 16);   // the slot mask is read from s_kfl where it is needed
-                    s_pos[i] = ip[j];
-                }
-                at += (uint32_t)__popcll(bal);
-            }
-        }
-    }
-    __syncthreads();
-    if (dbg == 6) return;
-    double sum2d = 0.0;
-    uint32_t c2 = 0, v2 = 0;
-    // association: local plane at the matched point (iba_local.cpp:207-231); list entry for the search / factor kernels
-    for (uint32_t i = tid; i < n3; i += kThreads) {
-        const uint32_t e = s_list[i], k = e & 0xffffu;
-        uint32_t ax_ = kNone, flags = 0u;
-        if (usedA && ((e >> 16) & 3u) == 3u) {
-            const uint32_t pos = s_pos[i];
-            if (refit) { ax_ = pos; flags |= kFlagA; }
-            else {
-                const PlaneRec rec = planes_local[pos];
-                const bool neigh_ok = local_neigh_ok(prm, rec);                     // pointcloud.h:752
-                if (neigh_ok && local_plane_ok(prm, rec)) ax_ = pos;               // bvalid_plane (:231)
-                if (neigh_ok) flags |= kFlagA;   // no 3d-3d block either otherwise (the `continue` at :209-211)
-            }
-        }
-        if (usedC && prm.use_3d3d && ((e >> 16) & 1u)) flags |= kFlagC;
-        fl[i] = make_uint4(k, ax_, kNone, flags);   // .z (the 3d-3d block) is filled in by iba_nn_kernel
-        if (flags) fm[i] = kp_mp[k];
-    }
-    if (dbg == 7) return;
-    // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328): only the slots whose match bit is set
-    if (usedC) {
-        for (uint32_t i = tid; i < n3; i += kThreads) {
-            const uint32_t k = s_list[i] & 0xffffu, pos = s_pos[i];
-            uint32_t mask = s_kfl[k] >> 2;
-            if (!mask) continue;
-            float xf_, yf_, zf_; load_pt<true>(c, pos, xf_, yf_, zf_);
-            const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
-            const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
-            const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
-            const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
-            const float2* mrow = dp.match_uv + h.match_base + k;
-            float2 mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];
-            while (mask) {
-                const uint32_t sl = (uint32_t)__ffs((int)mask) - 1u;
-                mask &= mask - 1u;
-                const float2 cur = mm;
-                if (mask) mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];   // next match is in flight during the arithmetic
-                const double* rel = s_rel + sl * 12;
-                const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
-                const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
-                const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
-                const double ou = h.fx * p1x / p1z + h.cx;
-                const double ov = h.fy * p1y / p1z + h.cy;
-                if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
-                const double eu = ou - (double)cur.x, ev = ov - (double)cur.y;
-                const double dist = sqrt(eu * eu + ev * ev);
-                if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
-                ++c2;
-            }
-        }
-    }
-    if (tid == 0) { fcount[(size_t)b * nf + f] = usedA ? n3 : 0u; lcount[(size_t)b * nf + f] = n3; }
-    // K8: reduction -> record. The 3d-3d sums of this (candidate, frame) come from iba_nn_kernel's own records.
-    {
-        const double w2d = wave_sum_f64(sum2d);
-        const unsigned long long wa = wave_sum_u64((unsigned long long)c2 | ((unsigned long long)v2 << 32));
-        unsigned long long* s_redu = (unsigned long long*)s_red;
-        __syncthreads();
-        if (lane == 63) { s_red[wave * 4 + 0] = w2d; s_redu[wave * 4 + 2] = wa; }
-        __syncthreads();
-        if (tid < kPartialStride) {
-            double out = 0.0;
-            if (usedC) {
-                if (tid == P_SUM_3D2D) { for (int w = 0; w < kWaves; ++w) out += s_red[w * 4 + 0]; }
-                else if (tid == P_CNT_3D2D || tid == P_VALID_3D2D) {
-                    unsigned long long a = 0;
-                    for (int w = 0; w < kWaves; ++w) a += s_redu[w * 4 + 2];
-                    out = (double)(tid == P_CNT_3D2D ? (a & 0xffffffffull) : (a >> 32));
-                }
-                else if ((tid == P_CNT_3D3D || tid == P_VALID_3D3D) && !prm.use_3d3d) out = 1.0;   // iba_global.cpp:214-220
-                else if (tid == P_FRAMES) out = 1.0;
-                else if (tid == P_NCORR) out = (double)n_corr;
-                else if (tid == P_HE_SUM) out = h.he_valid ? he[(size_t)b * nf + f] : 0.0;
-                else if (tid == P_HE_CNT) out = h.he_valid ? 1.0 : 0.0;
-            }
-            if (tid == P_FRAMES_N) out = usedA ? 1.0 : 0.0;
-            else if (tid == P_NCORR_N) out = usedA ? (double)n_corr : 0.0;
-            part[tid] = out;
-        }
-    }
+    assoc_tail(ka, h, cd, c, s_best_idx, s_kfl, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fmp, fcount, lcount, flist_stride);
 #undef dp
 #undef prm
 #undef lay
 #undef IBA_RELOAD
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The association of a BATCH of nearby candidates: common pairs.
+//
+// iba_assoc_kernel spends 56 % of its vector instructions (r03 counters, tools/pmc_cuts.sh) on finding, for ONE candidate, the
+// (scan point, keypoint) pairs that can be within max_pixel_dist of each other: the float stream of the visible chunks and the
+// walk of the keypoint grid. The candidates of one call are usually close to each other (a poll of the mesh search late in its
+// run, the perturbations of a line search, bench.py's batch): their projections of a point differ by a few pixels. So the
+// pairs are found ONCE per keyframe for the whole batch, around a reference candidate, with a search radius per point that
+// rigorously covers every candidate of the batch; each candidate then runs only the exact f64 test on that list.
+//
+// The bound. Candidate b maps a point p to q_b = R_b p + t_b = A_b q_0 + a_b with the reference's q_0 = R_0 p + t_0,
+// A_b = R_b R_0^T, a_b = t_b - A_b t_0. With rho_ij = max_b |A_b - I|_ij and tau_i = max_b |a_b|_i (host, once per call),
+// |q_b - q_0|_i <= delta_i = sum_j rho_ij |q_0|_j + tau_i for every b. For z_0 > 2 delta_z the pinhole projection
+// (iba_global.cpp:72-73; v uses fx as the reference does) moves by
+//     |u_b - u_0| <= Du = fx (delta_x z_0 + |x_0| delta_z) / (z_0 (z_0 - delta_z))            (and Dv alike),
+// so a keypoint within max_pixel_dist of candidate b's projection is within r = max_pixel_dist + sqrt(Du^2 + Dv^2) (+ slack
+// for rounding) of the reference's, and a point whose reference projection is more than (Du, Dv) outside the image is inside
+// it for no candidate. Points with z_0 < -delta_z are behind every candidate's camera. What is left — depth not bounded away
+// from zero and not provably outside the image — goes to a short "hard" list that every candidate projects exactly.
+// Every decision of a candidate (visibility, d^2 <= gate^2, nearest point, ties) is still made by its own exact f64
+// arithmetic in iba_assoc2_kernel, in the reference's expression order: the pair list only has to be a superset.
+// ------------------------------------------------------------------------------------------------------------------
+struct CommonRef { double R[9], t[3], rho[9], tau[3]; };
+struct PairRec { float x, y, z; uint32_t idx; float u, v; uint32_t k, pad; };   // scan point (+ original index), keypoint (+ id): 32 B, streamed
+constexpr int kPairsThreads = 256;
+constexpr int kCountStride = 4;   // per frame: pairs, hard points, overflow flag, spare
+
+// grid: (S, frames): block (s, f) takes the s-th slice of frame f's scan.
+__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp, CommonRef cr, double max_pixel_dist, int S, PairRec* __restrict__ pairs, uint32_t* __restrict__ hard,
+                                                                  uint32_t* __restrict__ counts, int pair_cap, int hard_cap) {
+    const int f = blockIdx.y;
+    const FrameHdr& h = dp.frames[f];
+    const uint32_t P = h.P;
+    const uint32_t per = (((P + (uint32_t)S - 1u) / (uint32_t)S) + 63u) & ~63u;
+    const uint32_t begin = blockIdx.x * per, end = min(P, begin + per);
+    const float4* p4 = dp.pts4 + h.pt_base;
+    const uint32_t* gcs = dp.coarse_start + h.coarse_base;
+    const float2* guv = dp.kp_uv + h.kp_base;
+    uint32_t* cnt = counts + (size_t)f * kCountStride;
+    PairRec* out = pairs + (size_t)f * (size_t)pair_cap;
+    uint32_t* hout = hard + (size_t)f * (size_t)hard_cap;
+    const int gw = (int)h.gw, gh = (int)h.gh, gwc = (int)h.gwc;
+    const double fx = h.fx, cx = h.cx, cy = h.cy, W = h.W, H = h.H;
+    for (uint32_t pos = begin + threadIdx.x; pos < end; pos += kPairsThreads) {
+        const float4 pv = p4[pos];
+        const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+        const double x0 = ((cr.R[0] * x + cr.R[1] * y) + cr.R[2] * z) + cr.t[0];
+        const double y0 = ((cr.R[3] * x + cr.R[4] * y) + cr.R[5] * z) + cr.t[1];
+        const double z0 = ((cr.R[6] * x + cr.R[7] * y) + cr.R[8] * z) + cr.t[2];
+        const double ax = fabs(x0), ay = fabs(y0), az = fabs(z0);
+        const double round_off = 1e-13 * ((ax + ay) + az) + 1e-13;   // of q_0 itself and of the candidates' own q_b (a few ulps of |q|)
+        const double dx = ((cr.rho[0] * ax + cr.rho[1] * ay) + cr.rho[2] * az) + cr.tau[0] + round_off;
+        const double dy = ((cr.rho[3] * ax + cr.rho[4] * ay) + cr.rho[5] * az) + cr.tau[1] + round_off;
+        const double dz = ((cr.rho[6] * ax + cr.rho[7] * ay) + cr.rho[8] * az) + cr.tau[2] + round_off;
+        if (!(z0 == z0) || z0 < -dz) continue;   // NaN: fails every candidate's own depth test; z0 < -dz: behind every candidate's camera
+        bool is_hard = false;
+        double u0 = 0, v0 = 0, r = 0;
+        if (!(z0 > 2.0 * dz)) {
+            // depth not bounded away from zero: z_b in (0, z0 + dz]. Far enough to the side, every candidate still sees it outside
+            const double zmax = z0 + dz;
+            const bool out_u = fx * (ax - dx) > zmax * (fmax(cx, W - cx) + 1.0), out_v = fx * (ay - dy) > zmax * (fmax(cy, H - cy) + 1.0);
+            if (out_u || out_v) continue;
+            is_hard = true;
+        } else {
+            const double den = z0 * (z0 - dz);
+            const double Du = fx * (dx * z0 + ax * dz) / den, Dv = fx * (dy * z0 + ay * dz) / den;
+            u0 = fx * x0 / z0 + cx; v0 = fx * y0 / z0 + cy;
+            if (u0 + Du < -1.0 || u0 - Du >= W + 1.0 || v0 + Dv < -1.0 || v0 - Dv >= H + 1.0) continue;   // inside the image for no candidate
+            r = max_pixel_dist + sqrt(Du * Du + Dv * Dv) + 0.02;
+            if (!(r <= 64.0)) is_hard = true;   // a window this wide is cheaper as one exact projection per candidate
+        }
+        if (is_hard) {
+            const uint32_t slot = atomicAdd(&cnt[1], 1u);
+            if (slot < (uint32_t)hard_cap) hout[slot] = pos; else cnt[2] = 1u;
+            continue;
+        }
+        // keypoints within r of (u0, v0): the coarse CSR of the keypoint grid (record e of the grid IS keypoint e)
+        const int x0c = grid_cell((float)(u0 - r) - 0.01f, gw) >> kCoarseShift, x1c = grid_cell((float)(u0 + r) + 0.01f, gw) >> kCoarseShift;
+        const int y0c = grid_cell((float)(v0 - r) - 0.01f, gh) >> kCoarseShift, y1c = grid_cell((float)(v0 + r) + 0.01f, gh) >> kCoarseShift;
+        const double r2 = r * r;
+        for (int yy = y0c; yy <= y1c; ++yy) {
+            const uint32_t e0 = gcs[yy * gwc + x0c], e1 = gcs[yy * gwc + x1c + 1];
+            for (uint32_t e = e0; e < e1; ++e) {
+                const float2 kv = guv[e];
+                const double du = (double)kv.x - u0, dv = (double)kv.y - v0;
+                if (du * du + dv * dv <= r2) {
+                    const uint32_t slot = atomicAdd(&cnt[0], 1u);
+                    if (slot < (uint32_t)pair_cap) { PairRec pr; pr.x = pv.x; pr.y = pv.y; pr.z = pv.z; pr.idx = __float_as_uint(pv.w); pr.u = kv.x; pr.v = kv.y; pr.k = e; pr.pad = 0u; out[slot] = pr; }
+                    else cnt[2] = 1u;
+                }
+            }
+        }
+    }
+}
+
+// exact association of one scan point against the keypoint grid in GLOBAL memory (hard points, overflow rescans): grid_match
+// with the coarse CSR read through L2. PASS 1: ds_min_u64 on the keypoint's best d^2; PASS 2: ties -> lowest original index.
+template <int PASS>
+__device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* __restrict__ gcs, double u, double v, uint32_t pos) {
+    const float uf = (float)u, vf = (float)v;
+    const int x0 = grid_cell(uf - c.margin, c.gw) >> kCoarseShift, x1 = grid_cell(uf + c.margin, c.gw) >> kCoarseShift;
+    const int y0 = grid_cell(vf - c.margin, c.gh) >> kCoarseShift, y1 = grid_cell(vf + c.margin, c.gh) >> kCoarseShift;
+    for (int yy = y0; yy <= y1; ++yy) {
+        const uint32_t e0 = gcs[yy * c.gwc + x0], e1 = gcs[yy * c.gwc + x1 + 1];
+        for (uint32_t e = e0; e < e1; ++e) {
+            const float4 rec = c.crec[e];
+            if (fabsf(rec.x - uf) > c.margin || fabsf(rec.y - vf) > c.margin) continue;
+            const double du = (double)rec.x - u, dv = (double)rec.y - v;
+            const double d2 = du * du + dv * dv;
+            if (d2 <= c.gate2) {
+                const uint32_t k = __float_as_uint(rec.z);
+                if (PASS == 1) atomicMin(&c.best_d2[k], d2bits(d2));
+                else if (c.best_d2[k] == d2bits(d2)) atomicMin(&c.best_idx[k], c.perm[pos]);
+            }
+        }
+    }
+}
+
+// iba_assoc2_kernel: one workgroup per (keyframe, candidate), as iba_assoc_kernel, with the first half replaced by the exact
+// f64 test of the batch's common pairs (K1 + K2 + K3 of the reference: TransformPointCloud pointcloud.h:82-86, the projection
+// and FOV test iba_global.cpp:68-81, the 1-NN within max_pixel_dist :86-95) streamed from the list iba_pairs_kernel left.
+// LDS: 16 B per keypoint (best d^2, best index, flags) + the relative poses: ~33 KB at 2000 keypoints.
+constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; more are re-evaluated)
+__global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
+                                                              const double* __restrict__ he, uint4* __restrict__ flist, float4* __restrict__ fmp, uint32_t* __restrict__ fcount,
+                                                              uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hard,
+                                                              const uint32_t* __restrict__ counts, int pair_cap, int hard_cap) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    KArgsC* ka = (KArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)ka_by_value;
+#define dp (ka->dp)
+#define prm (ka->prm)
+#define lay (ka->lay)
+    const int tid = threadIdx.x;
+    const int nf = dp.n_frames;
+    const int per_xcd = (nf + 7) / 8;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int f = xcd + 8 * (jj / B), b = jj % B;
+    if (f >= nf || jj / B >= per_xcd) return;
+    const FrameHdr& h = dp.frames[f];
+    const Cand& cd = cands[b];
+    double* part = frame_partials + ((size_t)b * nrec + f) * kPartialStride;
+
+    unsigned long long* s_best_d2 = (unsigned long long*)(smem + lay.off_best_d2);
+    uint32_t* s_best_idx = (uint32_t*)(smem + lay.off_best_idx);
+    uint32_t* s_kfl = (uint32_t*)(smem + lay.off_kfl);
+    double* s_red = (double*)(smem + lay.off_red);
+    double* s_rel = s_red + kWaves * 4;
+    uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 once the winners are known
+    const uint32_t K = h.K, P = h.P;
+    const uint32_t ut = (uint32_t)tid;
+
+    // ---- the counts of this frame's common lists, the first pairs of this thread, the tables ----
+    const uint32_t* cnt = counts + (size_t)f * kCountStride;
+    const bool overflow = cnt[2] != 0u;   // a list did not hold everything: every point again, exactly (speed only)
+    const uint32_t npair = overflow ? 0u : min(cnt[0], (uint32_t)pair_cap), nhard = overflow ? 0u : min(cnt[1], (uint32_t)hard_cap);
+    const float4* prq = (const float4*)(pairs + (size_t)f * (size_t)pair_cap);   // two 16-byte halves per record
+    {
+        const uint32_t* gfl = dp.kp_fl + h.kp_base;
+        double rv = 0.0;
+        if (ut < h.n_slots * 12u) rv = dp.slots[h.slot_base + ut / 12].rel[ut % 12];
+        for (uint32_t i = ut; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kfl[i] = gfl[i]; }
+        if (ut < h.n_slots * 12u) s_rel[ut] = rv;
+    }
+    const int dbg = want >> 8;
+    const bool refit = (want & 4) != 0;
+    FrameCtx c;
+    c.xs = dp.xs + h.pt_base; c.ys = dp.ys + h.pt_base; c.zs = dp.zs + h.pt_base;
+    c.nodes = nullptr; c.bitmap = nullptr; c.best_d2 = s_best_d2; c.best_idx = s_best_idx;
+    c.cstart = nullptr; c.gwc = (int)h.gwc; c.crec = dp.crec + h.kp_base;
+    c.perm = dp.perm + h.pt_base;
+    c.p4 = dp.pts4 + h.pt_base;
+    c.gw = (int)h.gw; c.gh = (int)h.gh; c.margin = (float)prm.grid_margin; c.gate2 = prm.gate2;
+    c.fx = h.fx; c.cx = h.cx; c.cy = h.cy; c.W = h.W; c.H = h.H;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = cd.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.t[i] = cd.t[i];
+    const uint32_t* gcs = dp.coarse_start + h.coarse_base;
+    __syncthreads();
+    if (dbg == 1) return;
+
+    // ---- pass 1: exact f64 projection + FOV test and exact d^2 of every common pair, ds_min_u64 on the keypoint's best ----
+    auto eval_pair = [&](uint32_t i, uint32_t& k, uint32_t& idx) -> unsigned long long {
+        const float4 a = prq[2 * (size_t)i], q = prq[2 * (size_t)i + 1];
+        double u, v;
+        k = kNone; idx = __float_as_uint(a.w);
+        if (project_uv(c, a.x, a.y, a.z, u, v)) {
+            const double du = (double)q.x - u, dv = (double)q.y - v;
+            const double d2 = du * du + dv * dv;
+            if (d2 <= c.gate2) { k = __float_as_uint(q.z); return d2bits(d2); }
+        }
+        return 0ull;
+    };
+    uint32_t rk[kPairRegs], ri[kPairRegs]; unsigned long long rb[kPairRegs];
+#pragma unroll
+    for (int j = 0; j < kPairRegs; ++j) {
+        rk[j] = kNone; ri[j] = 0u; rb[j] = 0ull;
+        const uint32_t i = ut + (uint32_t)j * kThreads;
+        if (i < npair) { rb[j] = eval_pair(i, rk[j], ri[j]); if (rk[j] != kNone) atomicMin(&s_best_d2[rk[j]], rb[j]); }
+    }
+    for (uint32_t i = ut + (uint32_t)kPairRegs * kThreads; i < npair; i += kThreads) {
+        uint32_t k, idx;
+        const unsigned long long bits = eval_pair(i, k, idx);
+        if (k != kNone) atomicMin(&s_best_d2[k], bits);
+    }
+    for (uint32_t i = ut; i < nhard; i += kThreads) {
+        const uint32_t pos = hard[(size_t)f * (size_t)hard_cap + i];
+        double u, v;
+        if (project_pos<true>(c, pos, u, v)) grid_match_g<1>(c, gcs, u, v, pos);
+    }
+    if (overflow)
+        for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<1>(c, gcs, u, v, pos); }
+    __syncthreads();
+    if (dbg == 4) return;
+    // ---- pass 2: the winner of each keypoint records its original index; exact ties -> lowest index ----
+#pragma unroll
+    for (int j = 0; j < kPairRegs; ++j)
+        if (rk[j] != kNone && s_best_d2[rk[j]] == rb[j]) atomicMin(&s_best_idx[rk[j]], ri[j]);
+    for (uint32_t i = ut + (uint32_t)kPairRegs * kThreads; i < npair; i += kThreads) {
+        uint32_t k, idx;
+        const unsigned long long bits = eval_pair(i, k, idx);
+        if (k != kNone && s_best_d2[k] == bits) atomicMin(&s_best_idx[k], idx);
+    }
+    for (uint32_t i = ut; i < nhard; i += kThreads) {
+        const uint32_t pos = hard[(size_t)f * (size_t)hard_cap + i];
+        double u, v;
+        if (project_pos<true>(c, pos, u, v)) grid_match_g<2>(c, gcs, u, v, pos);
+    }
+    if (overflow)
+        for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<2>(c, gcs, u, v, pos); }
+    __syncthreads();
+    if (dbg == 5) return;
+    assoc_tail(ka, h, cd, c, s_best_idx, s_kfl, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fmp, fcount, lcount, flist_stride);
+#undef dp
+#undef prm
+#undef lay
 }
 
 // ---- one lane's exact 1-NN search of a query pair in the implicit balanced kd-tree: a = the association path's MapPoint query,

@@ -1,0 +1,122 @@
+"""The 2d-3d association of a batch of nearby candidates shares ONE pair search per keyframe (iba_pairs_kernel +
+iba_assoc2_kernel); a lone candidate or a wide batch searches per candidate (iba_assoc_kernel). Both must give the SAME BITS —
+a candidate's result may not depend on what else is in the batch — and both must equal the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _handle(pkg, prob, p, mode):
+    old = os.environ.get("IBA_COMMON_PAIRS")
+    os.environ["IBA_COMMON_PAIRS"] = str(mode)
+    try:
+        return pkg.IbaHandle(prob, p)
+    finally:
+        if old is None:
+            del os.environ["IBA_COMMON_PAIRS"]
+        else:
+            os.environ["IBA_COMMON_PAIRS"] = old
+
+
+def _same_bits(pkg, h0, h1, xs, want_path):
+    c0, n0 = h0.eval_full(xs)
+    p0 = h0.debug_last_partials(min(len(xs), 64))
+    assert h0.last_path == 0
+    c1, n1 = h1.eval_full(xs)
+    p1 = h1.debug_last_partials(min(len(xs), 64))
+    assert h1.last_path == want_path
+    assert np.array_equal(p0, p1), np.argwhere(p0 != p1)[:5]
+    for a, b in zip(c0, c1):
+        assert a.as_dict() == b.as_dict()
+    for a, b in zip(n0, n1):
+        assert np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.cost == b.cost and a.counts() == b.counts()
+    a0, a1 = h0.eval_cost(xs), h1.eval_cost(xs)
+    for a, b in zip(a0, a1):
+        assert a.as_dict() == b.as_dict()
+
+
+def test_shared_search_gives_the_same_bits(pkg, synth, abi, scene_small):
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    h0, h1, h2 = _handle(pkg, prob, p, 0), _handle(pkg, prob, p, 1), _handle(pkg, prob, p, 2)
+    rng = np.random.default_rng(11)
+    tight = synth.perturb(meta["x_gt"], rng, n=64)
+    _same_bits(pkg, h0, h1, tight, 1)
+    _same_bits(pkg, h0, h1, tight[:4], 1)
+    _same_bits(pkg, h0, h1, tight[:3], 0)                       # below the batch threshold: per-candidate search
+    # ten times the spread: still shared by default? the nominal spread decides; forced sharing (mode 2) must agree anyway
+    wide10 = synth.perturb(meta["x_gt"], rng, rot=5e-3, trans=5e-2, scale_rel=1e-2, n=16)
+    _same_bits(pkg, h0, h2, wide10, 1)
+    # as wide as the reference's whole search box (+-0.1 rad, +-0.3 m): windows of tens of pixels, hard points, list overflows
+    box = meta["x_gt"][None, :] + rng.uniform(-1, 1, (12, 7)) * np.array([0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0])
+    _same_bits(pkg, h0, h2, box, 1)
+    _same_bits(pkg, h0, h1, box, 0)                             # the default falls back for such a batch
+    # the frozen problem and the callers are untouched by the mode
+    for h in (h0, h1):
+        h.build_problem(tight[1])
+    for a, b in zip(h0.eval_factors(tight[:5]), h1.eval_factors(tight[:5])):
+        assert np.array_equal(a.H_np(), b.H_np()) and a.cost == b.cost
+    # plane_cache = 0 runs on the same association
+    q = abi.reference_yaml_params(plane_cache=0)
+    h0.set_params(q)
+    h1.set_params(q)
+    _same_bits(pkg, h0, h1, tight[:8], 1)
+    for h in (h0, h1, h2):
+        h.close()
+
+
+def test_shared_search_against_the_oracle(pkg, synth, abi, ob):
+    """not only equal to the other kernel: equal to the CPU restatement (correspondence-derived counters exact, sums 1e-10)"""
+    prob, meta = synth.make_scene(n_frames=8, pts_per_frame=6000, n_keypoints=1500, seed=21)
+    p = abi.reference_yaml_params()
+    h = _handle(pkg, prob, p, 2)
+    o = ob.Oracle(prob)
+    rng = np.random.default_rng(5)
+    for xs in (synth.perturb(meta["x_gt"], rng, n=6), synth.perturb(meta["x_gt"], rng, rot=8e-3, trans=6e-2, scale_rel=2e-2, n=6)):
+        g = h.eval_cost(xs)
+        assert h.last_path == 1
+        r = o.eval_cost(p, xs)
+        for a, b in zip(g, r):
+            assert (a.n_corr, a.cnt_3d_2d, a.valid_cnt_3d_2d, a.cnt_3d_3d, a.valid_cnt_3d_3d, a.frames_used) == (b.n_corr, b.cnt_3d_2d, b.valid_cnt_3d_2d, b.cnt_3d_3d, b.valid_cnt_3d_3d, b.frames_used)
+            assert abs(a.f1 - b.f1) <= 1e-10 * abs(b.f1) and abs(a.f2 - b.f2) <= 1e-10 * abs(b.f2)
+        gn, rn = h.eval_normal(xs), o.eval_normal(p, xs)
+        for a, b in zip(gn, rn):
+            assert a.counts() == b.counts()
+            assert np.max(np.abs(a.H_np() - b.H_np())) <= 1e-9 * np.max(np.abs(b.H_np()))
+    h.close()
+
+
+def test_points_at_the_camera_plane_and_tiny_lists(pkg, synth, abi, ob):
+    """Scan points whose depth cannot be bounded away from zero over the batch go through the hard list (exact per candidate);
+    with the lists squeezed to a few entries every frame overflows and every candidate rescans. Both equal the per-candidate path."""
+    prob, meta = synth.make_scene(n_frames=5, pts_per_frame=3000, n_keypoints=800, seed=31, new_mappoints=100, scan_kp=150)
+    a = {k: v.copy() for k, v in prob.arrays.items()}
+    pts = a["pts_xyz"].reshape(-1, 3)
+    # 300 points per frame moved onto the camera plane, in front of the lens: LiDAR x ~ 0 is camera z ~ 0 for the KITTI-like extrinsic
+    R, t, _ = synth.sim3_exp(meta["x_gt"])
+    rng = np.random.default_rng(3)
+    for f in range(5):
+        qc = np.stack([rng.uniform(-0.02, 0.02, 300), rng.uniform(-0.01, 0.01, 300), rng.uniform(-0.02, 0.03, 300)], 1)   # camera frame, metres
+        pts[3000 * f:3000 * f + 300] = ((qc - t) @ R).astype(np.float32)
+    prob2 = abi.Problem(**a)
+    p = abi.reference_yaml_params()
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(9), n=8)
+    h0, h2 = _handle(pkg, prob2, p, 0), _handle(pkg, prob2, p, 2)
+    _same_bits(pkg, h0, h2, xs, 1)
+    o = ob.Oracle(prob2)
+    for a_, b_ in zip(h2.eval_cost(xs), o.eval_cost(p, xs)):
+        assert (a_.n_corr, a_.cnt_3d_2d, a_.cnt_3d_3d) == (b_.n_corr, b_.cnt_3d_2d, b_.cnt_3d_3d)
+    h2.close()
+    old = os.environ.get("IBA_DEBUG_PAIR_CAP")
+    os.environ["IBA_DEBUG_PAIR_CAP"] = "64"
+    try:
+        h3 = _handle(pkg, prob2, p, 2)
+    finally:
+        if old is None:
+            del os.environ["IBA_DEBUG_PAIR_CAP"]
+    _same_bits(pkg, h0, h3, xs, 1)
+    h3.close()
+    h0.close()
