@@ -81,7 +81,7 @@ struct iba_handle {
     LdsLayout alay2{};                    // LDS plan of iba_assoc2_kernel
     DevBuf<PairRec> d_pairs;              // n_frames x pair_cap
     DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
-    int pair_cap = 0, hard_cap = 0, pairs_slices = 8;
+    int pair_cap = 0, hard_cap = 0, pairs_slices = 1;   // pairs_slices: scan points per thread of iba_pairs_kernel (IBA_PAIRS_SLICES)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
     int common_min_batch = 4;             // IBA_COMMON_MIN_BATCH
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
@@ -189,15 +189,16 @@ bool layout_assoc(iba_handle* h, LdsLayout& L) {
     const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;
     L = LdsLayout{};
     uint32_t off = 0;
-    L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
-    L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
+    const uint32_t Kp = (std::max(h->maxK, 1u) + 3u) & ~3u;   // per-keypoint tables hold a multiple of 4 entries: the tail reads them 16 bytes at a time
+    L.off_best_d2 = off; off += 8u * Kp;
+    L.off_best_idx = off; off += 4u * Kp;
     off = align_up(off, 8); L.off_nodes = off;
     off = align_up(off, 16); L.off_red = off; off += red_bytes;
     L.off_vis = off; L.vis_words = 2u * kWaves * ((h->maxPpad / (uint32_t)kChunk + kThreads) / kThreads) + 2u;
     off += 4u * L.vis_words + 2u * (h->maxPpad / (uint32_t)kChunk + 2u);
     off = align_up(off, 4); L.off_cstart = off; off += 2u * std::max(h->maxCoarse, 1u);
-    off = align_up(off, 16); L.off_kuv = off; off += 8u * std::max(h->maxK, 1u);
-    L.off_kfl = off; off += 4u * std::max(h->maxK, 1u);
+    off = align_up(off, 16); L.off_kuv = off; off += 8u * Kp;
+    L.off_kfl = off; off += 4u * Kp;
     off = align_up(off, 16);
     const uint32_t bm_bytes = align_up(4u * std::max(h->maxBitmapWords, 1u), 16u);
     if (off + bm_bytes + 4u * 512u > kLdsBytes) return false;
@@ -238,9 +239,10 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;
     L = LdsLayout{};
     uint32_t off = 0;
-    L.off_best_d2 = off; off += 8u * std::max(h->maxK, 1u);
-    L.off_best_idx = off; off += 4u * std::max(h->maxK, 1u);
-    L.off_kfl = off; off += 4u * std::max(h->maxK, 1u);
+    const uint32_t Kp = (std::max(h->maxK, 1u) + 3u) & ~3u;
+    L.off_best_d2 = off; off += 8u * Kp;
+    L.off_best_idx = off; off += 4u * Kp;
+    L.off_kfl = off; off += 4u * Kp;
     off = align_up(off, 16); L.off_red = off; off += red_bytes;
     L.total = align_up(off, 16);
     return L.total <= kLdsBytes;
@@ -431,8 +433,12 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     h->last_path = common ? 1 : 0;
     if (common) {
         HIP_TRY(h, hipMemsetAsync(h->d_pcounts.p, 0, sizeof(uint32_t) * (size_t)nf * kCountStride, st));
-        hipLaunchKernelGGL(iba_pairs_kernel, dim3(h->pairs_slices, nf), dim3(kPairsThreads), 0, st, dp, cref, h->params.max_pixel_dist, h->pairs_slices, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p,
-                           h->pair_cap, h->hard_cap);
+        {   // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
+            const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
+            const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
+            hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, dp, cref, h->params.max_pixel_dist, kuv_off,
+                               h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
+        }
         HIP_TRY(h, hipGetLastError());
         hipLaunchKernelGGL(iba_assoc2_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                            h->d_frame_partials.p, nrec, h->d_he.p, fl, fm, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
@@ -716,7 +722,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
     if (!layout_assoc(h, h->alay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
-    if (!layout_assoc2(h, h->alay2)) h->common_mode = 0;
+    if (!layout_assoc2(h, h->alay2) || 8u * (uint32_t)kPairStage + 160u + 2u * std::max(h->maxCoarse, 1u) + 8u * std::max(h->maxK, 1u) > kLdsBytes) h->common_mode = 0;
     if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
     { NNLayout probe; if (!layout_nn(h, probe)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel"); } }
     h->lstride = std::max(1u, std::min(h->maxK, h->maxKw));
@@ -757,6 +763,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel
     if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     const void* nfns[9] = {(const void*)iba_nn_kernel<1, 0>, (const void*)iba_nn_kernel<2, 0>, (const void*)iba_nn_kernel<3, 0>, (const void*)iba_nn_kernel<1, 1>, (const void*)iba_nn_kernel<2, 1>, (const void*)iba_nn_kernel<3, 1>,
                            (const void*)iba_nn_kernel<1, 2>, (const void*)iba_nn_kernel<2, 2>, (const void*)iba_nn_kernel<3, 2>};

@@ -782,30 +782,57 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
     const float4* p4 = dp.pts4 + h.pt_base;
     const PlaneRec* planes = prm.plane_cache ? dp.plane_local + h.pt_base
                                              : dp.scratch_local + (size_t)(per_cand ? dp.scratch_slot_base + b : 0) * (size_t)dp.n_pt_total + h.pt_base;
+    // A list entry carries up to two residual blocks — the IBA_PlaneFactor of its keypoint (.y) and the 3d-3d factor of its
+    // MapPoint (.z) — and about half of the entries have each: a lane per ENTRY left half of the wave idle in either body.
+    // The entries are therefore split into two dense queues as they are read (64 at a time, one ballot each), and each body
+    // runs on full waves of its own kind: 64 plane factors, then 64 3d-3d factors, whenever a queue holds that many, the
+    // remainders at the end. Which lane adds which block is fixed by the list alone: the sums stay bitwise reproducible.
+    constexpr uint32_t kQ = 128u;   // ring capacity: at most 63 waiting + 64 new
+    __shared__ uint2 s_qa[kFactorThreads / 64][kQ], s_qb[kFactorThreads / 64][kQ];   // (keypoint, scan point) of a plane factor / (keypoint, point | kind) of a 3d-3d factor
+    uint2* qa = s_qa[wave]; uint2* qb = s_qb[wave];
+    uint32_t ha = 0u, ta = 0u, hb = 0u, tb = 0u;   // ring heads / tails (wave-uniform)
+    auto plane_batch = [&](uint32_t cnt) {   // the first min(cnt, 64) plane factors of the queue
+        if ((uint32_t)lane < cnt) {
+            const uint2 q = qa[(ha + (uint32_t)lane) & (kQ - 1u)];
+            const PlaneRec& rec = planes[q.y];
+            const float4 pt = p4[q.y];
+            const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, n0[3] = {rec.nx, rec.ny, rec.nz};
+            const float2 uv = dp.kp_uv[h.kp_base + q.x];
+            plane_factor_accum(c, h, dp, prm, q.x, h.K, (double)uv.x, (double)uv.y, p0, n0, A, s_rel);
+        }
+        ha += min(cnt, 64u);
+    };
+    auto p2x_batch = [&](uint32_t cnt) {
+        if ((uint32_t)lane < cnt) {
+            const uint2 q = qb[(hb + (uint32_t)lane) & (kQ - 1u)];
+            const uint32_t pos3 = q.y & 0x7FFFFFFFu;
+            const float4 pt3 = p4[pos3], mp3 = dp.kp_mp[h.kp_base + q.x];
+            const PlaneRec& r3 = planes[pos3];
+            const double Q[3] = {(double)pt3.x, (double)pt3.y, (double)pt3.z}, nn[3] = {r3.nx, r3.ny, r3.nz};
+            p2x_factor_accum(c, h, prm, mp3, Q, nn, (q.y >> 31) != 0, A);
+        }
+        hb += min(cnt, 64u);
+    };
+    auto lds_order = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
     uint4 e_n = make_uint4(0u, kNone, kNone, 0u);
     if ((uint32_t)tid < n) e_n = fl[tid];
-    for (uint32_t i = tid; i < n; i += kFactorThreads) {
+    for (uint32_t i0 = 0; i0 < n; i0 += kFactorThreads) {
+        const uint32_t i = i0 + (uint32_t)tid;
         const uint4 e = e_n;
-        if (i + kFactorThreads < n) e_n = fl[i + kFactorThreads];   // the next entry is in flight during this one's arithmetic
-        const uint32_t k = e.x;
-        // the gathers of both blocks of the entry are issued together
-        const bool has3 = e.z != kNone;
-        const uint32_t pos3 = e.z & 0x7FFFFFFFu;
-        float4 pt3 = make_float4(0.f, 0.f, 0.f, 0.f), mp3 = pt3; double n3x = 0, n3y = 0, n3z = 0;
-        if (has3) { pt3 = p4[pos3]; mp3 = dp.kp_mp[h.kp_base + k]; const PlaneRec& r3 = planes[pos3]; n3x = r3.nx; n3y = r3.ny; n3z = r3.nz; }
-        if (e.y != kNone) {
-            const PlaneRec& rec = planes[e.y];
-            const float4 pt = p4[e.y];
-            const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, n0[3] = {rec.nx, rec.ny, rec.nz};
-            const float2 uv = dp.kp_uv[h.kp_base + k];
-            plane_factor_accum(c, h, dp, prm, k, h.K, (double)uv.x, (double)uv.y, p0, n0, A, s_rel);
-        }
-        if (has3) {
-            const bool is_plane = (e.z >> 31) != 0;
-            const double Q[3] = {(double)pt3.x, (double)pt3.y, (double)pt3.z}, nn[3] = {n3x, n3y, n3z};
-            p2x_factor_accum(c, h, prm, mp3, Q, nn, is_plane, A);
-        }
+        e_n = make_uint4(0u, kNone, kNone, 0u);
+        if (i + kFactorThreads < n) e_n = fl[i + kFactorThreads];   // the next entries are in flight during this round's arithmetic
+        const bool hp = i < n && e.y != kNone, h3 = i < n && e.z != kNone;
+        const unsigned long long bp = __ballot(hp), b3 = __ballot(h3), lt = (1ull << lane) - 1ull;
+        if (hp) qa[(ta + (uint32_t)__popcll(bp & lt)) & (kQ - 1u)] = make_uint2(e.x, e.y);
+        if (h3) qb[(tb + (uint32_t)__popcll(b3 & lt)) & (kQ - 1u)] = make_uint2(e.x, e.z);
+        ta += (uint32_t)__popcll(bp); tb += (uint32_t)__popcll(b3);
+        lds_order();
+        if (ta - ha >= 64u) plane_batch(64u);
+        if (tb - hb >= 64u) p2x_batch(64u);
+        lds_order();   // the slots just read may be rewritten by the next round
     }
+    if (ta - ha) plane_batch(ta - ha);
+    if (tb - hb) p2x_batch(tb - hb);
     // fixed-order reduction through LDS: every lane parks its 41 sums (two halves of <= 21 through an 11 KB transposing
     // buffer), then lane v adds the 64 lanes' values of sum v in lane order. (The DPP butterfly this replaces cost 12 moves
     // and 6 adds per 64-bit sum: 1.5 k instructions per block, a quarter of the kernel.)

@@ -91,66 +91,61 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
 
     const double s = cd.s;
     uint32_t n3 = 0;
-
-    // ---- phase 3: corrset.size() and the sizes of the work list, one contiguous range of keypoints per wave ----
-    // (the list is in keypoint order; two barriers in all: counts -> prefix -> entries)
-    const uint32_t kw = ((K + (uint32_t)kWaves * 64u - 1u) / ((uint32_t)kWaves * 64u)) * 64u;   // keypoints per wave, a multiple of 64
-    const uint32_t kbeg = (uint32_t)wave * kw;
-    uint32_t n_corr = 0u, cntC = 0u, cntA = 0u;
-    {
-        uint32_t nv = 0u, nc = 0u, na = 0u;
-        for (uint32_t k = kbeg + (uint32_t)lane; k < kbeg + kw; k += 64u) {
-            const bool valid = k < K && s_best_idx[k] != kNone;
-            const int w = valid ? (int)s_kfl[k] : 0;
-            nv += (uint32_t)__popcll(__ballot(valid));
-            nc += (uint32_t)__popcll(__ballot(w != 0));
-            na += (uint32_t)__popcll(__ballot((w & 3) == 3));
-        }
-        uint32_t* s_cnt3 = (uint32_t*)s_red;   // 3 counts per wave (the reduction slab is not in use yet)
-        if (lane == 0) { s_cnt3[wave * 3] = nv; s_cnt3[wave * 3 + 1] = nc; s_cnt3[wave * 3 + 2] = na; }
-        __syncthreads();
-        for (int w = 0; w < kWaves; ++w) {
-            n_corr += s_cnt3[w * 3];
-            if (w < wave) { cntC += s_cnt3[w * 3 + 1]; cntA += s_cnt3[w * 3 + 2]; }
+    // ---- phase 3: corrset.size() and the work list in keypoint order, in one pass: every thread owns a run of q consecutive
+    //      keypoints (q = 4 up to 2048 keypoints: one 16-byte LDS read each of the winners and of the flag words), counts its
+    //      valid / cost-list / association-list keypoints, an inclusive DPP scan of the packed counts gives its place in the
+    //      wave, the waves' totals go through LDS (the one barrier), and the entries are written. Work list = keypoints with a
+    //      correspondence that can own a term: a MapPoint and/or a covisible match for the cost (iba_global.cpp:225, 295-300),
+    //      both for a residual block (iba_local.cpp:213, 259-260); entry = k | w << 16 (bits 16,17: MapPoint / covisible-match
+    //      flags). (Round 2 counted with three ballots per 64 keypoints and walked the keypoints a second time for the entries:
+    //      2.3e7 of the kernel's 8.1e7 vector instructions at the bench shape, and as many scalar ones.) ----
+    const uint32_t q = ((K + (uint32_t)kThreads * 4u - 1u) / ((uint32_t)kThreads * 4u)) * 4u;   // keypoints per thread: a multiple of 4
+    const uint32_t k0 = (uint32_t)tid * q;
+    uint32_t n_corr = 0u;
+    unsigned long long mine = 0ull;   // valid | cost-list << 16 | association-list << 32 of this thread's run (K < 65535: each fits 16 bits, so do the block totals)
+    for (uint32_t g = 0; g < q && k0 + g < K; g += 4u) {
+        const uint4 bi = *(const uint4*)(s_best_idx + k0 + g), fl4 = *(const uint4*)(s_kfl + k0 + g);
+        const uint32_t bv[4] = {bi.x, bi.y, bi.z, bi.w}, fv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
+            const uint32_t w = valid ? fv[j] : 0u;
+            mine += (valid ? 1ull : 0ull) | (w != 0u ? 1ull << 16 : 0ull) | ((w & 3u) == 3u ? 1ull << 32 : 0ull);
         }
     }
+    const unsigned long long incl = wave_sum_u64(mine);   // inclusive prefix over the lanes of the wave (the total in lane 63)
+    unsigned long long* s_cnt = (unsigned long long*)s_red;   // one total per wave (the reduction slab is not in use yet)
+    if (lane == 63) s_cnt[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0ull, total = 0ull;
+    for (int w = 0; w < kWaves; ++w) { const unsigned long long t = s_cnt[w]; total += t; if (w < wave) before += t; }
+    n_corr = (uint32_t)(total & 0xffffull);
     const bool usedA = (want & 1) && !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
     const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
     const PlaneRec* planes_local = dp.plane_local + h.pt_base;
     uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
     float4* fm = fmp + ((size_t)b * nf + f) * (size_t)flist_stride;   // the MapPoint of every entry, for the search kernel
     uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
-    // ---- work list: keypoints with a correspondence that can own a term: a MapPoint and/or a covisible match for the
-    //      cost (iba_global.cpp:225, 295-300), both for a residual block (iba_local.cpp:213, 259-260); entry = k | w << 16
-    //      (bits 16,17: MapPoint / covisible-match flags) ----
     {
-        uint32_t* s_cnt3 = (uint32_t*)s_red;
-        uint32_t at = usedC ? cntC : (usedA ? cntA : 0u);   // entries of the waves before this one
-        for (int w = 0; w < kWaves; ++w) n3 += usedC ? s_cnt3[w * 3 + 1] : (usedA ? s_cnt3[w * 3 + 2] : 0u);
-        for (uint32_t k0 = kbeg + (uint32_t)lane; k0 < kbeg + kw; k0 += 256u) {   // four steps at a time: their gathers are in flight together
-            uint32_t ip[4]; int ww[4];
+        const int sh = usedC ? 16 : 32;   // which of the two lists this evaluation builds
+        n3 = (usedC || usedA) ? (uint32_t)((total >> sh) & 0xffffull) : 0u;
+        uint32_t at = (uint32_t)(((before + (incl - mine)) >> sh) & 0xffffull);   // entries of the threads before this one
+        if (usedC || usedA)
+            for (uint32_t g = 0; g < q && k0 + g < K; g += 4u) {
+                const uint4 bi = *(const uint4*)(s_best_idx + k0 + g), fl4 = *(const uint4*)(s_kfl + k0 + g);
+                const uint32_t bv[4] = {bi.x, bi.y, bi.z, bi.w}, fv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+                uint32_t ip[4]; bool wk[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t k = k0 + 64u * (uint32_t)j;
-                const bool valid = k < kbeg + kw && k < K && s_best_idx[k] != kNone;
-                const int w = valid ? (int)s_kfl[k] : 0;
-                const bool wantk = (usedC && w != 0) || (usedA && (w & 3) == 3);
-                ww[j] = wantk ? (w & 3) | 4 : 0;
-                ip[j] = wantk ? inv_perm[s_best_idx[k]] : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t k = k0 + 64u * (uint32_t)j;
-                const bool wantk = ww[j] != 0;
-                const unsigned long long bal = __ballot(wantk);
-                if (wantk) {
-                    const uint32_t i = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                    s_list[i] = k | (((uint32_t)ww[j] & 3u) << 16);   // the slot mask is read from s_kfl where it is needed
-                    s_pos[i] = ip[j];
+                for (int j = 0; j < 4; ++j) {   // the four gathers are in flight together
+                    const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
+                    const uint32_t w = valid ? fv[j] : 0u;
+                    wk[j] = usedC ? w != 0u : (w & 3u) == 3u;
+                    ip[j] = wk[j] ? inv_perm[bv[j]] : 0u;
                 }
-                at += (uint32_t)__popcll(bal);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (wk[j]) { s_list[at] = (k0 + g + (uint32_t)j) | ((fv[j] & 3u) << 16); s_pos[at] = ip[j]; ++at; }   // the slot mask is read from s_kfl where it is needed
             }
-        }
     }
     __syncthreads();
     if (dbg == 6) return;
@@ -613,27 +608,51 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 // ------------------------------------------------------------------------------------------------------------------
 struct CommonRef { double R[9], t[3], rho[9], tau[3]; };
 struct PairRec { float x, y, z; uint32_t idx; float u, v; uint32_t k, pad; };   // scan point (+ original index), keypoint (+ id): 32 B, streamed
-constexpr int kPairsThreads = 256;
-constexpr int kCountStride = 4;   // per frame: pairs, hard points, overflow flag, spare
+constexpr int kPairsThreads = 1024;
+constexpr int kCountStride = 32;   // u32 per frame (one 128-byte line: the frames' counters do not share a line): pairs, hard points, overflow flag
+constexpr int kPairStage = 2048;   // (point, keypoint) hits a block parks in LDS before ONE global reservation writes them out
 
-// grid: (S, frames): block (s, f) takes the s-th slice of frame f's scan.
-__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp, CommonRef cr, double max_pixel_dist, int S, PairRec* __restrict__ pairs, uint32_t* __restrict__ hard,
+// grid: (ceil(max P / kPairsThreads), frames); one scan point per thread. The keypoint grid of the frame (coarse CSR + the
+// keypoints' (u, v)) sits in LDS, so a thread's walk costs LDS round trips, not L2 ones; the hits of a block are parked in LDS
+// and written out behind one atomic reservation per block.
+__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp, CommonRef cr, double max_pixel_dist, uint32_t lds_kuv_off, PairRec* __restrict__ pairs, uint32_t* __restrict__ hard,
                                                                   uint32_t* __restrict__ counts, int pair_cap, int hard_cap) {
+    extern __shared__ __align__(16) unsigned char smem[];
     const int f = blockIdx.y;
     const FrameHdr& h = dp.frames[f];
-    const uint32_t P = h.P;
-    const uint32_t per = (((P + (uint32_t)S - 1u) / (uint32_t)S) + 63u) & ~63u;
-    const uint32_t begin = blockIdx.x * per, end = min(P, begin + per);
+    const uint32_t P = h.P, K = h.K;
+    const uint32_t begin = blockIdx.x * (uint32_t)kPairsThreads;
+    if (begin >= P) return;
+    uint2* s_hit = (uint2*)smem;                                   // [kPairStage] (tree position, keypoint)
+    uint32_t* s_n = (uint32_t*)(smem + 8u * kPairStage);            // [0] hits parked, [1] base of the block's global reservation, [4..] one flag per wave
+    uint16_t* s_cstart = (uint16_t*)(smem + 8u * kPairStage + 128u);
+    float2* s_kuv = (float2*)(smem + lds_kuv_off);
     const float4* p4 = dp.pts4 + h.pt_base;
-    const uint32_t* gcs = dp.coarse_start + h.coarse_base;
     const float2* guv = dp.kp_uv + h.kp_base;
     uint32_t* cnt = counts + (size_t)f * kCountStride;
     PairRec* out = pairs + (size_t)f * (size_t)pair_cap;
     uint32_t* hout = hard + (size_t)f * (size_t)hard_cap;
     const int gw = (int)h.gw, gh = (int)h.gh, gwc = (int)h.gwc;
     const double fx = h.fx, cx = h.cx, cy = h.cy, W = h.W, H = h.H;
-    for (uint32_t pos = begin + threadIdx.x; pos < end; pos += kPairsThreads) {
-        const float4 pv = p4[pos];
+    const uint32_t pos = begin + threadIdx.x;
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos < P) pv = p4[pos];
+    // the frame's keypoint grid is fetched into registers now and parked in LDS only if some point of the block needs it: a block
+    // of 1024 consecutive tree positions is a compact piece of the scene, and most pieces lie outside every candidate's image
+    const uint32_t* gcs = dp.coarse_start + h.coarse_base;
+    const uint32_t ncs = h.gwc * h.ghc + 1u;
+    uint32_t cs_r[2]; float2 uv_r[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t i = threadIdx.x + (uint32_t)j * kPairsThreads;
+        cs_r[j] = i < ncs ? gcs[i] : 0u;
+        uv_r[j] = i < K ? guv[i] : make_float2(0.f, 0.f);
+    }
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0u;
+    // ---- the point under the reference candidate, the batch's bound on its motion, its search window ----
+    int kind = 0;   // 0: nothing to do, 1: walk the grid, 2: hard point
+    double u0 = 0, v0 = 0, r = 0;
+    if (pos < P) {
         const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
         const double x0 = ((cr.R[0] * x + cr.R[1] * y) + cr.R[2] * z) + cr.t[0];
         const double y0 = ((cr.R[3] * x + cr.R[4] * y) + cr.R[5] * z) + cr.t[1];
@@ -643,44 +662,81 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
         const double dx = ((cr.rho[0] * ax + cr.rho[1] * ay) + cr.rho[2] * az) + cr.tau[0] + round_off;
         const double dy = ((cr.rho[3] * ax + cr.rho[4] * ay) + cr.rho[5] * az) + cr.tau[1] + round_off;
         const double dz = ((cr.rho[6] * ax + cr.rho[7] * ay) + cr.rho[8] * az) + cr.tau[2] + round_off;
-        if (!(z0 == z0) || z0 < -dz) continue;   // NaN: fails every candidate's own depth test; z0 < -dz: behind every candidate's camera
-        bool is_hard = false;
-        double u0 = 0, v0 = 0, r = 0;
-        if (!(z0 > 2.0 * dz)) {
+        if (!(z0 == z0) || z0 < -dz) kind = 0;   // NaN: fails every candidate's own depth test; z0 < -dz: behind every candidate's camera
+        else if (!(z0 > 2.0 * dz)) {
             // depth not bounded away from zero: z_b in (0, z0 + dz]. Far enough to the side, every candidate still sees it outside
             const double zmax = z0 + dz;
             const bool out_u = fx * (ax - dx) > zmax * (fmax(cx, W - cx) + 1.0), out_v = fx * (ay - dy) > zmax * (fmax(cy, H - cy) + 1.0);
-            if (out_u || out_v) continue;
-            is_hard = true;
+            kind = (out_u || out_v) ? 0 : 2;
         } else {
             const double den = z0 * (z0 - dz);
             const double Du = fx * (dx * z0 + ax * dz) / den, Dv = fx * (dy * z0 + ay * dz) / den;
             u0 = fx * x0 / z0 + cx; v0 = fx * y0 / z0 + cy;
-            if (u0 + Du < -1.0 || u0 - Du >= W + 1.0 || v0 + Dv < -1.0 || v0 - Dv >= H + 1.0) continue;   // inside the image for no candidate
-            r = max_pixel_dist + sqrt(Du * Du + Dv * Dv) + 0.02;
-            if (!(r <= 64.0)) is_hard = true;   // a window this wide is cheaper as one exact projection per candidate
+            if (u0 + Du < -1.0 || u0 - Du >= W + 1.0 || v0 + Dv < -1.0 || v0 - Dv >= H + 1.0) kind = 0;   // inside the image for no candidate
+            else {
+                r = max_pixel_dist + sqrt(Du * Du + Dv * Dv) + 0.02;
+                kind = (r <= 64.0) ? 1 : 2;   // a window wider than that is cheaper as one exact projection per candidate
+            }
         }
-        if (is_hard) {
-            const uint32_t slot = atomicAdd(&cnt[1], 1u);
-            if (slot < (uint32_t)hard_cap) hout[slot] = pos; else cnt[2] = 1u;
-            continue;
-        }
+    }
+    if (kind == 2) {
+        const uint32_t slot = atomicAdd(&cnt[1], 1u);
+        if (slot < (uint32_t)hard_cap) hout[slot] = pos; else cnt[2] = 1u;
+    }
+    {   // does any point of the block walk the grid? (one flag per wave; hipcc's __syncthreads_or would add static LDS of its own)
+        const unsigned long long any = __ballot(kind == 1);
+        if ((threadIdx.x & 63) == 0) s_n[4 + (threadIdx.x >> 6)] = any != 0ull ? 1u : 0u;
+        __syncthreads();
+        uint32_t walk = 0u;
+#pragma unroll
+        for (int w = 0; w < kPairsThreads / 64; ++w) walk |= s_n[4 + w];
+        if (!walk) return;   // no point of this block can meet a keypoint under any candidate
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t i = threadIdx.x + (uint32_t)j * kPairsThreads;
+        if (i < ncs) s_cstart[i] = (uint16_t)cs_r[j];
+        if (i < K) s_kuv[i] = uv_r[j];
+    }
+    for (uint32_t i = threadIdx.x + 2u * kPairsThreads; i < ncs; i += kPairsThreads) s_cstart[i] = (uint16_t)gcs[i];
+    for (uint32_t i = threadIdx.x + 2u * kPairsThreads; i < K; i += kPairsThreads) s_kuv[i] = guv[i];
+    __syncthreads();
+    if (kind == 1) {
         // keypoints within r of (u0, v0): the coarse CSR of the keypoint grid (record e of the grid IS keypoint e)
         const int x0c = grid_cell((float)(u0 - r) - 0.01f, gw) >> kCoarseShift, x1c = grid_cell((float)(u0 + r) + 0.01f, gw) >> kCoarseShift;
         const int y0c = grid_cell((float)(v0 - r) - 0.01f, gh) >> kCoarseShift, y1c = grid_cell((float)(v0 + r) + 0.01f, gh) >> kCoarseShift;
         const double r2 = r * r;
         for (int yy = y0c; yy <= y1c; ++yy) {
-            const uint32_t e0 = gcs[yy * gwc + x0c], e1 = gcs[yy * gwc + x1c + 1];
+            const uint32_t e0 = s_cstart[yy * gwc + x0c], e1 = s_cstart[yy * gwc + x1c + 1];
             for (uint32_t e = e0; e < e1; ++e) {
-                const float2 kv = guv[e];
+                const float2 kv = s_kuv[e];
                 const double du = (double)kv.x - u0, dv = (double)kv.y - v0;
                 if (du * du + dv * dv <= r2) {
-                    const uint32_t slot = atomicAdd(&cnt[0], 1u);
-                    if (slot < (uint32_t)pair_cap) { PairRec pr; pr.x = pv.x; pr.y = pv.y; pr.z = pv.z; pr.idx = __float_as_uint(pv.w); pr.u = kv.x; pr.v = kv.y; pr.k = e; pr.pad = 0u; out[slot] = pr; }
-                    else cnt[2] = 1u;
+                    const uint32_t slot = atomicAdd(&s_n[0], 1u);
+                    if (slot < (uint32_t)kPairStage) s_hit[slot] = make_uint2(pos, e);
+                    else {   // the stage is full (a dense frame): straight to the list
+                        const uint32_t g = atomicAdd(&cnt[0], 1u);
+                        if (g < (uint32_t)pair_cap) { PairRec pr; pr.x = pv.x; pr.y = pv.y; pr.z = pv.z; pr.idx = __float_as_uint(pv.w); pr.u = kv.x; pr.v = kv.y; pr.k = e; pr.pad = 0u; out[g] = pr; }
+                        else cnt[2] = 1u;
+                    }
                 }
             }
         }
+    }
+    __syncthreads();
+    const uint32_t n = min(s_n[0], (uint32_t)kPairStage);
+    if (n == 0u) return;
+    if (threadIdx.x == 0) s_n[1] = atomicAdd(&cnt[0], n);
+    __syncthreads();
+    const uint32_t base = s_n[1];
+    for (uint32_t i = threadIdx.x; i < n; i += kPairsThreads) {
+        const uint2 hit = s_hit[i];
+        const uint32_t g = base + i;
+        if (g < (uint32_t)pair_cap) {
+            const float4 q = p4[hit.x]; const float2 kv = s_kuv[hit.y];
+            PairRec pr; pr.x = q.x; pr.y = q.y; pr.z = q.z; pr.idx = __float_as_uint(q.w); pr.u = kv.x; pr.v = kv.y; pr.k = hit.y; pr.pad = 0u;
+            out[g] = pr;
+        } else cnt[2] = 1u;
     }
 }
 

@@ -20,12 +20,12 @@ for k in "1 2 3 4 5 6 7 0".split():
     acc = defaultdict(list)
     for fn in glob.glob("gpurun_out/%s/c%s/**/*counter_collection.csv" % (T, k), recursive=True):
         for r in csv.DictReader(open(fn)):
-            if "iba_assoc_kernel" in r["Kernel_Name"]:
+            if "iba_assoc" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     t = None
     for fn in glob.glob("gpurun_out/%s/c%s/st/**/*kernel_stats.csv" % (T, k), recursive=True):
         for r in csv.DictReader(open(fn)):
-            if "iba_assoc_kernel" in r["Name"]:
+            if "iba_assoc" in r["Name"]:
                 t = float(r["AverageNs"]) / 1e3
     print("dbg=%s  time_us=%s  " % (k, "%.1f" % t if t else "?") + "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(acc.items())))
 PY
