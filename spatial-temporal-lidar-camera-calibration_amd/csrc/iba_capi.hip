@@ -81,6 +81,7 @@ struct iba_handle {
     LdsLayout alay2{};                    // LDS plan of iba_assoc2_kernel
     DevBuf<PairRec> d_pairs;              // n_frames x pair_cap
     DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
+    unsigned pairs_epoch = 0;             // which of the two counter sets the next call uses
     int pair_cap = 0, hard_cap = 0, pairs_slices = 1;   // pairs_slices: scan points per thread of iba_pairs_kernel (IBA_PAIRS_SLICES)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
     int common_min_batch = 4;             // IBA_COMMON_MIN_BATCH
@@ -432,16 +433,18 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     const bool common = h->common_mode > 0 && !frozen && B >= h->common_min_batch && h->d_pairs.p && h->last_hc && common_ref(h, h->last_hc, B, cref);
     h->last_path = common ? 1 : 0;
     if (common) {
-        HIP_TRY(h, hipMemsetAsync(h->d_pcounts.p, 0, sizeof(uint32_t) * (size_t)nf * kCountStride, st));
+        uint32_t* cnt_now = h->d_pcounts.p + (size_t)(h->pairs_epoch & 1) * (size_t)nf * kCountStride;
+        uint32_t* cnt_next = h->d_pcounts.p + (size_t)((h->pairs_epoch + 1) & 1) * (size_t)nf * kCountStride;
+        ++h->pairs_epoch;
         {   // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
             const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
             const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
             hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, dp, cref, h->params.max_pixel_dist, kuv_off,
-                               h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
+                               h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
         }
         HIP_TRY(h, hipGetLastError());
         hipLaunchKernelGGL(iba_assoc2_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                           h->d_frame_partials.p, nrec, h->d_he.p, fl, fm, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
+                           h->d_frame_partials.p, nrec, h->d_he.p, fl, fm, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
     } else
     hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                        h->d_frame_partials.p, nrec, (uint32_t*)nullptr, h->d_he.p, fl, fm, fc, lc, (int)h->lstride);
@@ -751,7 +754,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         if (const char* e = std::getenv("IBA_DEBUG_PAIR_CAP")) { h->pair_cap = std::max(1, std::atoi(e)); h->hard_cap = std::max(1, std::atoi(e) / 8); }   // tests: force the overflow path
         if ((er = h->d_pairs.alloc((size_t)std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
         if ((er = h->d_hard.alloc((size_t)std::max(nf, 1) * h->hard_cap)) != hipSuccess) return bail("alloc hard list", er);
-        if ((er = h->d_pcounts.alloc((size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("alloc pair counts", er);
+        if ((er = h->d_pcounts.alloc(2 * (size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("alloc pair counts", er);   // two sets, used in turn
+        if ((er = hipMemset(h->d_pcounts.p, 0, sizeof(uint32_t) * 2 * (size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("clear pair counts", er);
     }
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
     if ((er = h->d_he.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1))) != hipSuccess) return bail("alloc he", er);

@@ -616,12 +616,14 @@ constexpr int kPairStage = 2048;   // (point, keypoint) hits a block parks in LD
 // keypoints' (u, v)) sits in LDS, so a thread's walk costs LDS round trips, not L2 ones; the hits of a block are parked in LDS
 // and written out behind one atomic reservation per block.
 __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp, CommonRef cr, double max_pixel_dist, uint32_t lds_kuv_off, PairRec* __restrict__ pairs, uint32_t* __restrict__ hard,
-                                                                  uint32_t* __restrict__ counts, int pair_cap, int hard_cap) {
+                                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ counts_next, int pair_cap, int hard_cap) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int f = blockIdx.y;
     const FrameHdr& h = dp.frames[f];
     const uint32_t P = h.P, K = h.K;
     const uint32_t begin = blockIdx.x * (uint32_t)kPairsThreads;
+    // the counters of the NEXT call's lists are cleared here (two sets, used in turn: no memset between the kernels of a call)
+    if (blockIdx.x == 0 && threadIdx.x < 4) counts_next[(size_t)f * kCountStride + threadIdx.x] = 0u;
     if (begin >= P) return;
     uint2* s_hit = (uint2*)smem;                                   // [kPairStage] (tree position, keypoint)
     uint32_t* s_n = (uint32_t*)(smem + 8u * kPairStage);            // [0] hits parked, [1] base of the block's global reservation, [4..] one flag per wave
@@ -635,6 +637,37 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
     const int gw = (int)h.gw, gh = (int)h.gh, gwc = (int)h.gwc;
     const double fx = h.fx, cx = h.cx, cy = h.cy, W = h.W, H = h.H;
     const uint32_t pos = begin + threadIdx.x;
+    // ---- the block's culling chunks (static AABBs of kChunk consecutive tree positions) against every candidate's frustum: a
+    //      block of 1024 consecutive tree positions is a compact piece of the scene, and most pieces are seen by no candidate.
+    //      For a point p of a box with centre c and half extent e: q_b(p)_i lies within m_i = (|R_0| e)_i + delta_i of q_0(c)_i,
+    //      delta from the batch bound at |q_0(c)| + |R_0| e. The piece is invisible when it is behind the camera (z + m_z <= 0) or
+    //      wholly beyond one image border: u >= W <=> fx x + (cx - W) z >= 0 (z > 0), u < 0 <=> fx x + cx z < 0, v alike. ----
+    constexpr uint32_t kBlkChunks = (uint32_t)kPairsThreads / (uint32_t)kChunk;
+    bool chunk_vis = false;
+    if (threadIdx.x < kBlkChunks) {
+        const uint32_t ch = begin / (uint32_t)kChunk + threadIdx.x;
+        if (ch * (uint32_t)kChunk < P) {
+            const float4* bx = (const float4*)(dp.chunk_box + 8 * (h.box_base + ch));
+            const float4 lo = bx[0], hi = bx[1];
+            const double c3[3] = {0.5 * ((double)lo.x + (double)hi.x), 0.5 * ((double)lo.y + (double)hi.y), 0.5 * ((double)lo.z + (double)hi.z)};
+            const double e3[3] = {0.5 * ((double)hi.x - (double)lo.x), 0.5 * ((double)hi.y - (double)lo.y), 0.5 * ((double)hi.z - (double)lo.z)};
+            double qc[3], ex[3], m[3];
+            for (int i = 0; i < 3; ++i) {
+                qc[i] = ((cr.R[i * 3] * c3[0] + cr.R[i * 3 + 1] * c3[1]) + cr.R[i * 3 + 2] * c3[2]) + cr.t[i];
+                ex[i] = (fabs(cr.R[i * 3]) * e3[0] + fabs(cr.R[i * 3 + 1]) * e3[1]) + fabs(cr.R[i * 3 + 2]) * e3[2];
+            }
+            const double a3[3] = {fabs(qc[0]) + ex[0], fabs(qc[1]) + ex[1], fabs(qc[2]) + ex[2]};
+            for (int i = 0; i < 3; ++i)
+                m[i] = (ex[i] + ((cr.rho[i * 3] * a3[0] + cr.rho[i * 3 + 1] * a3[1]) + cr.rho[i * 3 + 2] * a3[2]) + cr.tau[i]) * (1.0 + 1e-9) + 1e-9 * ((a3[0] + a3[1]) + a3[2]) + 1e-9;
+            const double zhi = qc[2] + m[2];
+            const bool behind = zhi <= 0.0;
+            const bool right = fx * (qc[0] - m[0]) + (cx - W) * zhi >= 1e-6 * (fx * a3[0] + W * a3[2]);
+            const bool left = fx * (qc[0] + m[0]) + cx * zhi < -1e-6 * (fx * a3[0] + W * a3[2]);
+            const bool below = fx * (qc[1] - m[1]) + (cy - H) * zhi >= 1e-6 * (fx * a3[1] + H * a3[2]);
+            const bool above = fx * (qc[1] + m[1]) + cy * zhi < -1e-6 * (fx * a3[1] + H * a3[2]);
+            chunk_vis = !(behind || right || left || below || above);   // a NaN box (empty chunk) compares false everywhere: kept, harmless
+        }
+    }
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pos < P) pv = p4[pos];
     // the frame's keypoint grid is fetched into registers now and parked in LDS only if some point of the block needs it: a block
@@ -649,6 +682,12 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
         uv_r[j] = i < K ? guv[i] : make_float2(0.f, 0.f);
     }
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0u;
+    if (threadIdx.x < 64) {   // wave 0 holds the chunk tests
+        const unsigned long long anyc = __ballot(chunk_vis);
+        if (threadIdx.x == 0) s_n[3] = anyc != 0ull ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_n[3]) return;   // no candidate sees any point of this block
     // ---- the point under the reference candidate, the batch's bound on its motion, its search window ----
     int kind = 0;   // 0: nothing to do, 1: walk the grid, 2: hard point
     double u0 = 0, v0 = 0, r = 0;
