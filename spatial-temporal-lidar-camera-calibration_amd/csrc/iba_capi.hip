@@ -81,9 +81,13 @@ struct iba_handle {
     LdsLayout alay2{};                    // LDS plan of iba_assoc2_kernel
     DevBuf<PairRec> d_pairs;              // n_frames x pair_cap
     DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
+    DevBuf<uint32_t> mpk;                 // per frame: keypoints that own a MapPoint
+    uint32_t max_mpk = 0;
+    DevBuf<float4> d_nnset; DevBuf<uint32_t> d_nnset_cnt;   // neighbour candidates of a batch: n_frames x maxK x kSetM points, n_frames x maxK counts
     unsigned pairs_epoch = 0;             // which of the two counter sets the next call uses
     int pair_cap = 0, hard_cap = 0, pairs_slices = 1;   // pairs_slices: scan points per thread of iba_pairs_kernel (IBA_PAIRS_SLICES)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
+    bool nn_sets = true;                  // IBA_NN_SETS=0: every lane searches the tree even in a tight batch (diagnostic)
     int common_min_batch = 4;             // IBA_COMMON_MIN_BATCH
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
     double max_fx = 0.0;
@@ -130,6 +134,7 @@ struct iba_handle {
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
+        dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u);
         return dp;
     }
 };
@@ -231,6 +236,7 @@ bool layout_nn(const iba_handle* h, NNLayout& L) {
     off = align_up(off, 16); L.off_misc = off; off += 128u;
     off = align_up(off, 16); L.off_cd = off; off += 8u * (uint32_t)kCdDoubles * (uint32_t)kMaxGroup;
     off = align_up(off, 16); L.off_res = off; off += 8u * kSliceW * (uint32_t)kMaxGroup;
+    L.off_ovf = off; off += 4u * kSliceW * (uint32_t)kMaxGroup;   // work entries left to the tree search when the batch's neighbour sets are in use
     L.total = off;
     return L.total <= kLdsBytes;
 }
@@ -253,7 +259,7 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
 // nearest the batch mean, rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i, both inflated for their own
 // rounding. Returns false when the batch is too wide for common pairs to pay (nominal projection spread above max_px at a
 // point 12 m out, 10 m deep), in which case every candidate searches for itself (iba_assoc_kernel).
-bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
+bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr, NNRef& nr) {
     double mean[12] = {0};
     for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].R[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].t[i]; }
     for (double& m : mean) m /= (double)B;
@@ -279,6 +285,15 @@ bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
             for (int q = 0; q < 3; ++q) { const double e = std::fabs(A[r * 3 + q] - (r == q ? 1.0 : 0.0)); if (!(e <= 4.0)) return false; cr.rho[r * 3 + q] = std::max(cr.rho[r * 3 + q], e); }
         }
     }
+    // the MapPoint queries of the batch around the reference's (see iba_nnset_kernel): q_b = (s_b Ri_b) m + ti_b
+    for (int i = 0; i < 9; ++i) { nr.M0[i] = c0.s * c0.Ri[i]; nr.D[i] = 0; }
+    for (int i = 0; i < 3; ++i) { nr.ti0[i] = c0.ti[i]; nr.d[i] = 0; }
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < 9; ++i) { const double e = std::fabs(hc[b].s * hc[b].Ri[i] - nr.M0[i]); if (!(e <= 1e30)) return false; nr.D[i] = std::max(nr.D[i], e); }
+        for (int i = 0; i < 3; ++i) { const double e = std::fabs(hc[b].ti[i] - nr.ti0[i]); if (!(e <= 1e30)) return false; nr.d[i] = std::max(nr.d[i], e); }
+    }
+    for (int i = 0; i < 9; ++i) nr.D[i] = nr.D[i] * (1.0 + 1e-9) + 1e-15;
+    for (int i = 0; i < 3; ++i) nr.d[i] = nr.d[i] * (1.0 + 1e-9) + 1e-15;
     double rho_row = 0, tau_max = 0;
     for (int r = 0; r < 3; ++r) { rho_row = std::max(rho_row, cr.rho[r * 3] + cr.rho[r * 3 + 1] + cr.rho[r * 3 + 2]); tau_max = std::max(tau_max, cr.tau[r]); }
     for (int i = 0; i < 9; ++i) cr.rho[i] = cr.rho[i] * (1.0 + 1e-9) + 1e-15;
@@ -429,8 +444,8 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     // 2d-3d association: a batch of nearby candidates shares ONE search for the (scan point, keypoint) pairs per keyframe
     // (iba_pairs_kernel) and every candidate runs the exact test on that list (iba_assoc2_kernel); a lone candidate, a small or a
     // wide batch searches per candidate (iba_assoc_kernel). Same results either way, bit for bit.
-    CommonRef cref;
-    const bool common = h->common_mode > 0 && !frozen && B >= h->common_min_batch && h->d_pairs.p && h->last_hc && common_ref(h, h->last_hc, B, cref);
+    CommonRef cref; NNRef nref;
+    const bool common = h->common_mode > 0 && !frozen && B >= h->common_min_batch && h->d_pairs.p && h->last_hc && common_ref(h, h->last_hc, B, cref, nref);
     h->last_path = common ? 1 : 0;
     if (common) {
         uint32_t* cnt_now = h->d_pcounts.p + (size_t)(h->pairs_epoch & 1) * (size_t)nf * kCountStride;
@@ -459,11 +474,18 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         const dim3 grid(8 * per_xcd * ngroups * NS), block(kNNThreads);
         const NNArgs na{dp, h->dprm, nl};
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
+        // a batch of nearby candidates: the tree is searched once per MapPoint keypoint for the whole batch (iba_nnset_kernel)
+        const bool sets = common && h->d_nnset.p && h->max_mpk > 0 && h->nn_sets;
+        const float4* nnset = sets ? h->d_nnset.p : nullptr; const uint32_t* nnset_cnt = sets ? h->d_nnset_cnt.p : nullptr;
+        if (sets) {
+            hipLaunchKernelGGL(iba_nnset_kernel, dim3((h->max_mpk + kNNThreads - 1) / kNNThreads, nf), dim3(kNNThreads), nl.total, st, NNSetArgs{dp, nref, nl}, h->d_nnset.p, h->d_nnset_cnt.p);
+            HIP_TRY(h, hipGetLastError());
+        }
         auto launch_nn = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
-            if (wA && wC) hipLaunchKernelGGL((iba_nn_kernel<3, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p);
-            else if (wA) hipLaunchKernelGGL((iba_nn_kernel<1, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p);
-            else hipLaunchKernelGGL((iba_nn_kernel<2, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p);
+            if (wA && wC) hipLaunchKernelGGL((iba_nn_kernel<3, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, nnset, nnset_cnt);
+            else if (wA) hipLaunchKernelGGL((iba_nn_kernel<1, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, nnset, nnset_cnt);
+            else hipLaunchKernelGGL((iba_nn_kernel<2, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, nnset, nnset_cnt);
         };
         if (refit) launch_nn(std::integral_constant<int, kRefitSearch>{}); else launch_nn(std::integral_constant<int, 0>{});
         HIP_TRY(h, hipGetLastError());
@@ -525,7 +547,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_nnset.release(); h->d_nnset_cnt.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -705,6 +727,13 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     std::vector<uint32_t> kp_fl(kp_base);
     bool crec_ok = true;
     for (size_t k = 0; k < (size_t)kp_base; ++k) kp_fl[k] = (uint32_t)(int)kp_mp[k].w;
+    std::vector<uint32_t> mpk;   // per frame: the keypoints that own a MapPoint (the only ones a 1-NN search is ever run for)
+    for (int lf = 0; lf < nf; ++lf) {
+        hdr[lf].mpk_base = mpk.size();
+        for (uint32_t k = 0; k < hdr[lf].K; ++k) if (kp_fl[hdr[lf].kp_base + k] & 1u) mpk.push_back(k);
+        hdr[lf].n_mpk = (uint32_t)(mpk.size() - hdr[lf].mpk_base);
+        h->max_mpk = std::max(h->max_mpk, hdr[lf].n_mpk);
+    }
     for (int lf = 0; lf < nf; ++lf) {
         uint32_t cnt = 0;
         for (uint32_t k = 0; k < hdr[lf].K; ++k) { uint32_t idb; std::memcpy(&idb, &crec[hdr[lf].kp_base + k].z, 4); crec_ok = crec_ok && idb == k; }
@@ -721,6 +750,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
     if (const char* e = std::getenv("IBA_COMMON_PAIRS")) h->common_mode = std::atoi(e);
+    if (const char* e = std::getenv("IBA_NN_SETS")) h->nn_sets = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
@@ -734,7 +764,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
 #define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
     UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes); UP(chunk_box, chunk_box); UP(pts4, pts4);
-    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(kp_fl, kp_fl); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv);
+    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(kp_fl, kp_fl); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv); UP(mpk, mpk);
 #undef UP
     hipError_t er;
     if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);
@@ -755,6 +785,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         if ((er = h->d_pairs.alloc((size_t)std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
         if ((er = h->d_hard.alloc((size_t)std::max(nf, 1) * h->hard_cap)) != hipSuccess) return bail("alloc hard list", er);
         if ((er = h->d_pcounts.alloc(2 * (size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("alloc pair counts", er);   // two sets, used in turn
+        if ((er = h->d_nnset.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kSetM)) != hipSuccess) return bail("alloc neighbour sets", er);
+        if ((er = h->d_nnset_cnt.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u))) != hipSuccess) return bail("alloc neighbour set counts", er);
         if ((er = hipMemset(h->d_pcounts.p, 0, sizeof(uint32_t) * 2 * (size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("clear pair counts", er);
     }
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
@@ -769,6 +801,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    if ((er = hipFuncSetAttribute((const void*)iba_nnset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     const void* nfns[9] = {(const void*)iba_nn_kernel<1, 0>, (const void*)iba_nn_kernel<2, 0>, (const void*)iba_nn_kernel<3, 0>, (const void*)iba_nn_kernel<1, 1>, (const void*)iba_nn_kernel<2, 1>, (const void*)iba_nn_kernel<3, 1>,
                            (const void*)iba_nn_kernel<1, 2>, (const void*)iba_nn_kernel<2, 2>, (const void*)iba_nn_kernel<3, 2>};
     for (const void* fn : nfns)

@@ -47,6 +47,8 @@ struct DevProblem {
     PlaneRec* scratch_cost; PlaneRec* scratch_local;
     int64_t n_pt_total;
     int32_t scratch_slot_base;
+    const uint32_t* mpk;       // per frame: the keypoints that own a MapPoint (FrameHdr::mpk_base, n_mpk)
+    uint32_t max_k;            // largest keypoint count of a frame: row pitch of the per-(frame, keypoint) tables
 };
 
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames

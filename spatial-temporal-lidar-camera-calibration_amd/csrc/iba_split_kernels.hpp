@@ -38,7 +38,7 @@ constexpr int kNNPartial = 8;   // doubles per (candidate, nn record): sum3d, cn
 constexpr int kMaxGroup = kNNThreads / 32 < 16 ? kNNThreads / 32 : 16;   // candidates per block (32 threads each in the final sums)
 
 struct NNLayout {   // byte offsets into the dynamic LDS of iba_nn_kernel
-    uint32_t off_nodes, off_res, off_misc, off_cd, total;
+    uint32_t off_nodes, off_res, off_misc, off_cd, off_ovf, total;
 };
 constexpr int kCdDoubles = 14;   // per candidate in LDS: s, Ri[9], ti[3], (s32, pad) = doubles 12..25 of Cand
 #ifndef IBA_NN_WAVES
@@ -1088,6 +1088,126 @@ __global__ __launch_bounds__(256) void iba_nn_probe_kernel(DevProblem dp, int fr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Neighbour candidates of a BATCH of nearby candidates.
+//
+// The 1-NN search of iba_nn_kernel answers, per (MapPoint, candidate): which scan point is nearest to the MapPoint moved into
+// the LiDAR frame by this candidate (iba_global.cpp:231-234, 116-122; iba_local.cpp:238-239, 282-290). The MapPoint is the
+// keypoint's, not the candidate's: over a batch of nearby candidates its queries q_b = s_b Ri_b m + ti_b (m = the MapPoint in the
+// camera frame) lie within sigma = |D |m| + d| of the reference candidate's q_0, with D_ij = max_b |s_b Ri_b - s_0 Ri_0|_ij and
+// d_i = max_b |ti_b - ti_0|_i from the host. If p_0 is q_0's nearest scan point at distance d_0, candidate b's nearest point p_b
+// has |q_b - p_b| <= |q_b - p_0| <= d_0 + sigma, hence |q_0 - p_b| <= d_0 + 2 sigma: every candidate's nearest point (and every
+// point tied with it) lies in the ball of radius d_0 + 2 sigma around q_0. That ball holds one or two scan points at the bench
+// shape. So the tree is searched ONCE per MapPoint keypoint of a keyframe for the whole batch — exact 1-NN of q_0, then the
+// points of the ball, at most kSetM of them — and iba_nn_kernel picks each candidate's nearest among them with its own exact
+// f64 distances (same expressions, same tie rule: same bits as its tree search). A ball with more points sends its lanes
+// back to the tree.
+// ------------------------------------------------------------------------------------------------------------------
+struct NNRef { double M0[9], ti0[3], D[9], d[3]; };   // s_0 Ri_0, ti_0 of the reference candidate; the batch's spread around it
+constexpr int kSetM = 8;
+constexpr uint32_t kSetOverflow = 0xFFFFFFFFu;
+struct NNSetArgs { DevProblem dp; NNRef nr; NNLayout lay; };
+// grid: (ceil(max MapPoint keypoints of a frame / kNNThreads), frames); one lane per MapPoint keypoint
+__global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, float4* __restrict__ nnset, uint32_t* __restrict__ nnset_cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const DevProblem& dp = a.dp;
+    const int f = blockIdx.y;
+    const FrameHdr& h = dp.frames[f];
+    if (blockIdx.x * (uint32_t)kNNThreads >= h.n_mpk) return;
+    TreeNode* s_nodes = (TreeNode*)(smem + a.lay.off_nodes);
+    const uint32_t P = h.P, D = h.depth;
+    for (uint32_t i = threadIdx.x; i < (1u << D) - 1u; i += kNNThreads) s_nodes[i] = dp.nodes[h.node_base + i];
+    __syncthreads();
+    const uint32_t j = blockIdx.x * (uint32_t)kNNThreads + threadIdx.x;
+    if (j >= h.n_mpk) return;
+    const uint32_t k = dp.mpk[h.mpk_base + j];
+    const size_t row = (size_t)f * dp.max_k + k;
+    if (P == 0) { nnset_cnt[row] = 0u; return; }
+    const float4* p4 = dp.pts4 + h.pt_base;
+    const uint32_t* perm_g = dp.perm + h.pt_base;
+    const float4 mp = dp.kp_mp[h.kp_base + k];
+    const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+    const double m0 = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
+    const double m1 = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
+    const double m2 = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
+    const NNRef& nr = a.nr;
+    IBA_LANE_NN_DECL;
+    actA = true; actC = false;
+    ax = ((nr.M0[0] * m0 + nr.M0[1] * m1) + nr.M0[2] * m2) + nr.ti0[0];
+    ay = ((nr.M0[3] * m0 + nr.M0[4] * m1) + nr.M0[5] * m2) + nr.ti0[1];
+    az = ((nr.M0[6] * m0 + nr.M0[7] * m1) + nr.M0[8] * m2) + nr.ti0[2];
+    const double am0 = fabs(m0), am1 = fabs(m1), am2 = fabs(m2);
+    // the batch's queries (both float / double islands of the reference: they differ by the rounding of one float product,
+    // < 1e-6 of |q|) lie within sigma of (ax, ay, az)
+    const double aq = (fabs(ax) + fabs(ay)) + fabs(az);
+    const double g0 = ((nr.D[0] * am0 + nr.D[1] * am1) + nr.D[2] * am2) + nr.d[0];
+    const double g1 = ((nr.D[3] * am0 + nr.D[4] * am1) + nr.D[5] * am2) + nr.d[1];
+    const double g2 = ((nr.D[6] * am0 + nr.D[7] * am1) + nr.D[8] * am2) + nr.d[2];
+    const double sigma = sqrt((g0 * g0 + g1 * g1) + g2 * g2) * (1.0 + 1e-9) + 2e-6 * aq + 1e-6;
+    if (!(sigma == sigma) || !(aq == aq)) { nnset_cnt[row] = kSetOverflow; return; }   // no bound: the lanes search the tree
+    lane_nn_begin(IBA_LANE_NN_PASS);
+    do { lane_nn_visit<1>(IBA_LANE_NN_PASS, s_nodes, p4, perm_g, P, D); } while (go >= 0);
+    // ---- the ball: every scan point within d_0 + 2 sigma of the reference query, by the same register-path traversal with a
+    //      FIXED bound (float arithmetic, every test inflated so that it can only add points) ----
+    const double Rb = sqrt(bestA) + 2.0 * sigma;
+    const float Rf = (float)Rb * 1.000001f + 1e-4f + 2e-6f * (float)aq;   // covers float(o), the float d^2 and the plane bounds
+    const float R2f = Rf * Rf * 1.000001f;
+    uint32_t cnt = 0u;
+    float4* out = nnset + row * (size_t)kSetM;
+    side = 0u; done = 0u; node = 0u; go = -1;
+    const uint32_t first_leaf = (1u << D) - 1u;
+    do {
+        int start = 0;
+        if (go >= 0) {
+            const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
+            done |= 1u << go; side ^= 1u << go;
+            node = 2u * anc + 1u + ((side >> go) & 1u);
+            start = go + 1;
+        }
+        {
+            const uint32_t keep = (1u << start) - 1u;
+            side &= keep; done &= keep;
+            uint32_t n1 = node + 1u;
+#pragma unroll
+            for (int L = 0; L < kPathMax; ++L) {
+                if (L >= (int)D) break;
+                if (L >= start) {
+                    const TreeNode n = s_nodes[n1 - 1u];
+                    const float dd = (n.dim == 0 ? o0 : (n.dim == 1 ? o1 : o2)) - n.split;
+                    const uint32_t r = (~__float_as_uint(dd)) >> 31;
+                    pd2[L] = dd * dd * 0.999999f;   // <= the squared distance from o to the splitting plane
+                    side |= r << L;
+                    n1 = (n1 << 1) | r;
+                }
+            }
+            node = n1 - 1u;
+        }
+        const uint32_t lj = node - first_leaf;
+        const uint32_t lo = (uint32_t)(((uint64_t)lj * P) >> D), hi = (uint32_t)(((uint64_t)(lj + 1) * P) >> D);
+        for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {   // eight loads in flight per step
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t iu = i0 + (uint32_t)u; v[u] = p4[iu < hi ? iu : hi - 1u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + (uint32_t)u;
+                const float dx = o0 - v[u].x, dy = o1 - v[u].y, dz = o2 - v[u].z;
+                if (i < hi && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= R2f) {
+                    if (cnt < (uint32_t)kSetM) out[cnt] = make_float4(v[u].x, v[u].y, v[u].z, __uint_as_float(i));
+                    ++cnt;
+                }
+            }
+        }
+        uint32_t cnd = 0u;
+#pragma unroll
+        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= R2f ? 1u : 0u) << L;
+        cnd &= ~done & ((1u << D) - 1u);
+        done |= ~cnd;
+        go = cnd ? 31 - __clz((int)cnd) : -1;
+    } while (go >= 0 && cnt <= (uint32_t)kSetM);
+    nnset_cnt[row] = cnt <= (uint32_t)kSetM ? cnt : kSetOverflow;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // iba_nn_kernel<WHICH>. WHICH bit 0: association-path queries present, bit 1: cost-path queries.
 // grid: 8 * ceil(n_frames/8) * NG * NS blocks (NG = ceil(B / CG) candidate groups, NS keypoint slices) of kNNThreads.
 //
@@ -1107,8 +1227,11 @@ __global__ __launch_bounds__(256) void iba_nn_probe_kernel(DevProblem dp, int fr
 template <int WHICH, int REFIT>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_NN_WAVES, IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
                                                                                                   double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist, const float4* __restrict__ fmp,
-                                                                                                  const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit) {
+                                                                                                  const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit,
+                                                                                                  const float4* __restrict__ nnset, const uint32_t* __restrict__ nnset_cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // nnset != nullptr: the batch's neighbour candidates (iba_nnset_kernel): a lane whose keypoint has a set picks its nearest
+    // points from it instead of searching the tree.
     // kRefitSearch = the searches only (neighbour and query offset of every entry -> flist.z / frefit), kRefitSums = the fixed-order
     // sums over the distances the fit kernel left in frefit
     constexpr int refit = REFIT;
@@ -1191,13 +1314,114 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
         __syncthreads();
         if (dbg == 2) return;
 
-        // ---- the searches: persistent lanes, refilled from the work list ----
+        // ---- the searches ----
         if (refit != kRefitSums) {
             bool have = false;
             uint32_t w = 0u;   // the lane's work entry: candidate w % CG of the group, list position i_lo + w / CG
             IBA_LANE_NN_DECL;
+            auto entry_at = [&](uint32_t wn) -> size_t { return ((size_t)((uint32_t)(g * CG) + (wn & ((1u << cg_shift) - 1u))) * nf + f) * (size_t)flist_stride + (i_lo + (wn >> cg_shift)); };
+            // the two MapPoint -> LiDAR-frame queries of an entry under candidate cc (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
+            auto make_queries = [&](uint32_t cc, const uint4& e, const float4& mp) {
+                actC = (WHICH & 2) && (e.w & kFlagC);
+                actA = (WHICH & 1) && (e.w & kFlagA);
+                const double* cdl = s_cd + cc * kCdDoubles;
+                struct { double s, Ri[9], ti[3]; float s32; } cd;
+                cd.s = cdl[0];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) cd.Ri[q] = cdl[1 + q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) cd.ti[q] = cdl[10 + q];
+                cd.s32 = *(const float*)(cdl + 13);
+                const double s = cd.s;
+                ax = NAN; ay = NAN; az = NAN; qx = NAN; qy = NAN; qz = NAN;
+                if (actA) {
+                    const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+                    const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
+                    const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
+                    const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
+                    const double sx = mx * s, sy = my * s, sz = mz * s;
+                    ax = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
+                    ay = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
+                    az = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
+                }
+                if (actC) {
+                    const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
+                    const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;       // CV_32F product (:232)
+                    const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
+                    const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
+                    const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
+                    const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
+                    qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
+                    qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
+                    qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+                }
+            };
+            // the finished searches of entry wn: the association's neighbour (+ kind), the cost distance. cpt: the cost path's
+            // neighbour when the caller already holds its coordinates (a set lane), else it is fetched
+            auto finish = [&](uint32_t wn, const float4* cpt) {
+                const size_t at = entry_at(wn);
+                if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2)) {   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
+                    bool state = false;   // refit: settled by the fit kernel
+                    if (!refit) { const PlaneRec r2 = planes_local[bposA]; state = local_neigh_ok(prm, r2) && local_plane_ok(prm, r2); }   // pointcloud.h:699-717
+                    flist[at].z = bposA | (state ? 0x80000000u : 0u);
+                }
+                double res = NAN;
+                if ((WHICH & 2) && actC) {
+                    const float4 pv = cpt ? *cpt : p4[bposC];
+                    const double ex = (double)pv.x - qx, ey = (double)pv.y - qy, ez = (double)pv.z - qz;
+                    if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
+                    else {
+                        PlaneRec rec; rec.k = 0;
+                        if (prm.use_plane) rec = planes_cost[bposC];   // the whole record in one round trip
+                        res = cost_res(prm, prm.use_plane != 0, rec, ex, ey, ez);
+                    }
+                }
+                if ((WHICH & 2) && !refit) s_res[wn - c0] = res;
+            };
+            uint32_t* s_ovf = (uint32_t*)(smem + lay.off_ovf);   // work entries whose keypoint has no usable set: searched in the tree below
+            uint32_t c_end = c1;                                 // entries the persistent loop hands out
+            if (nnset) {
+                // ---- a batch of nearby candidates: the neighbour candidates of every MapPoint keypoint are there (iba_nnset_kernel).
+                //      One pass, no claiming: thread t takes the entries t, t + T, ...; per entry one dependent chain of three loads
+                //      (entry -> set -> plane records), the next entry's first load in flight meanwhile ----
+                if (tid == 0) s_ctr[1] = 0u;
+                __syncthreads();
+                uint4 e_n = make_uint4(0u, 0u, 0u, 0u); float4 mp_n = make_float4(0.f, 0.f, 0.f, 0.f);
+                auto fetch = [&](uint32_t wn) {
+                    e_n = make_uint4(0u, 0u, 0u, 0u);
+                    const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
+                    if (wn < c1 && il < s_n[cc]) { const size_t at = entry_at(wn); e_n = flist[at]; mp_n = fmp[at]; }
+                };
+                fetch((uint32_t)tid);
+                for (uint32_t wn = (uint32_t)tid; wn < c1; wn += (uint32_t)T) {
+                    const uint4 e = e_n; const float4 mp = mp_n;
+                    fetch(wn + (uint32_t)T);
+                    if (!(e.w & kWantMask)) continue;
+                    const size_t srow = (size_t)f * dp.max_k + e.x;
+                    const float4* sp = nnset + srow * (size_t)kSetM;
+                    const uint32_t sc = nnset_cnt[srow];
+                    const float4 p0 = sp[0], p1 = sp[1];   // nearly every set holds one or two points: fetched with the count
+                    if (sc == kSetOverflow || sc == 0u) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; continue; }
+                    make_queries(wn & ((1u << cg_shift) - 1u), e, mp);
+                    bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
+                    float4 cbest = p0;
+                    for (uint32_t si = 0; si < sc; ++si) {
+                        const float4 pv = si == 0u ? p0 : (si == 1u ? p1 : sp[si]);
+                        const uint32_t pi = __float_as_uint(pv.w);
+                        const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+                        if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, pi, perm_g); }
+                        if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; const uint32_t was = bposC; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, pi, perm_g); if (bposC != was) cbest = pv; }
+                    }
+                    if (dbg != 5) finish(wn, &cbest);
+                }
+                __syncthreads();
+                c_end = s_ctr[1];
+                if (tid == 0) *s_ctr = 0u;
+                __syncthreads();
+            }
+            // ---- persistent lanes, refilled from the work list (all of it, or what the sets left over) ----
             bool exhausted = false;   // wave-uniform: the work list has been handed out
-            for (;;) {
+            if (c_end != 0u) for (;;) {
                 // ---- refill: idle lanes claim the next entries (one LDS atomic per wave) ----
                 const unsigned long long idle = __ballot(!have);
                 if (idle != 0ull && !exhausted) {
@@ -1205,52 +1429,17 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                     uint32_t base = 0u;
                     if (lane == 0) base = atomicAdd(s_ctr, nidle);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    exhausted = base + nidle >= c1;
+                    exhausted = base + nidle >= c_end;
                     if (!have) {
-                        const uint32_t wn = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        const uint32_t wq = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        const uint32_t wn = nnset ? (wq < c_end ? s_ovf[wq] : c1) : wq;
                         const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
                         uint4 e = make_uint4(0u, 0u, 0u, 0u);
                         float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (wn < c1 && il < s_n[cc]) {
-                            const size_t at = ((size_t)((uint32_t)(g * CG) + cc) * nf + f) * (size_t)flist_stride + il;
-                            e = flist[at]; mp = fmp[at];
-                        }
+                        if (wn < c1 && il < s_n[cc]) { const size_t at = entry_at(wn); e = flist[at]; mp = fmp[at]; }
                         if (e.w & kWantMask) {
                             w = wn;
-                            actC = (WHICH & 2) && (e.w & kFlagC);
-                            actA = (WHICH & 1) && (e.w & kFlagA);
-                            // the two MapPoint -> LiDAR-frame queries (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
-                            const double* cdl = s_cd + cc * kCdDoubles;
-                            struct { double s, Ri[9], ti[3]; float s32; } cd;
-                            cd.s = cdl[0];
-#pragma unroll
-                            for (int q = 0; q < 9; ++q) cd.Ri[q] = cdl[1 + q];
-#pragma unroll
-                            for (int q = 0; q < 3; ++q) cd.ti[q] = cdl[10 + q];
-                            cd.s32 = *(const float*)(cdl + 13);
-                            const double s = cd.s;
-                            ax = NAN; ay = NAN; az = NAN; qx = NAN; qy = NAN; qz = NAN;
-                            if (actA) {
-                                const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
-                                const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
-                                const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
-                                const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
-                                const double sx = mx * s, sy = my * s, sz = mz * s;
-                                ax = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
-                                ay = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
-                                az = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
-                            }
-                            if (actC) {
-                                const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
-                                const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;       // CV_32F product (:232)
-                                const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
-                                const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
-                                const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
-                                const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
-                                qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
-                                qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
-                                qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
-                            }
+                            make_queries(cc, e, mp);
                             lane_nn_begin(IBA_LANE_NN_PASS);
                             have = true;
                         }
@@ -1260,27 +1449,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                 if (have && dbg == 4) { have = false; continue; }
                 if (have) lane_nn_visit<WHICH>(IBA_LANE_NN_PASS, s_nodes, p4, perm_g, P, D);
                 if (have && go < 0) {
-                    // ---- the finished searches of this entry ----
-                    if (dbg != 5) {
-                    const size_t at = ((size_t)((uint32_t)(g * CG) + (w & ((1u << cg_shift) - 1u))) * nf + f) * (size_t)flist_stride + (i_lo + (w >> cg_shift));
-                    if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2)) {   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
-                        bool state = false;   // refit: settled by the fit kernel
-                        if (!refit) { const PlaneRec r2 = planes_local[bposA]; state = local_neigh_ok(prm, r2) && local_plane_ok(prm, r2); }   // pointcloud.h:699-717
-                        flist[at].z = bposA | (state ? 0x80000000u : 0u);
-                    }
-                    double res = NAN;
-                    if ((WHICH & 2) && actC) {
-                        const float4 pv = p4[bposC];
-                        const double ex = (double)pv.x - qx, ey = (double)pv.y - qy, ez = (double)pv.z - qz;
-                        if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
-                        else {
-                            PlaneRec rec; rec.k = 0;
-                            if (prm.use_plane) rec = planes_cost[bposC];   // the whole record in one round trip
-                            res = cost_res(prm, prm.use_plane != 0, rec, ex, ey, ez);
-                        }
-                    }
-                    if ((WHICH & 2) && !refit) s_res[w - c0] = res;
-                    }
+                    if (dbg != 5) finish(w, nullptr);
                     have = false;
                 }
             }

@@ -77,6 +77,8 @@ struct FrameHdr {
     double Tl_next[12];
     int32_t he_valid;     // global frame index < F-1
     int32_t global_frame;
+    uint64_t mpk_base;    // offset into mpk[]: the keypoints of this frame that own a MapPoint (internal ids, ascending)
+    uint32_t n_mpk, pad_mpk;
 };
 
 struct SlotHdr {
