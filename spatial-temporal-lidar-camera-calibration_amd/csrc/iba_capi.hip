@@ -76,6 +76,8 @@ struct iba_handle {
     int nn_ns = 1;                        // search blocks per (frame, candidate group): ceil(maxKw / kSliceW)
     DevBuf<double> d_nn_partials;         // IBA_MAX_BATCH * n_frames * kMaxSlices * kNNPartial
     hipEvent_t ev_mid = nullptr;
+    hipStream_t stream2 = nullptr;        // the batch's neighbour sets are built beside the association kernels (fork / join around iba_nnset_kernel)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float last_assoc_ms = 0.f, last_nn_ms = 0.f;
     // common pairs of a batch of nearby candidates (iba_pairs_kernel + iba_assoc2_kernel)
     LdsLayout alay2{};                    // LDS plan of iba_assoc2_kernel
@@ -83,10 +85,13 @@ struct iba_handle {
     DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
     DevBuf<uint32_t> mpk;                 // per frame: keypoints that own a MapPoint
     uint32_t max_mpk = 0;
-    DevBuf<float4> d_nnset; DevBuf<uint32_t> d_nnset_cnt;   // neighbour candidates of a batch: n_frames x maxK x kSetM points, n_frames x maxK counts
+    DevBuf<SetPt> d_nnset; DevBuf<uint32_t> d_nnset_cnt;   // neighbour candidates of a batch: n_frames x maxK x kSetM points, n_frames x maxK counts
     unsigned pairs_epoch = 0;             // which of the two counter sets the next call uses
     int pair_cap = 0, hard_cap = 0, pairs_slices = 1;   // pairs_slices: scan points per thread of iba_pairs_kernel (IBA_PAIRS_SLICES)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
+    int set_visits = kSetMaxVisits, set_leaves = kSetMaxLeaves;   // IBA_SET_VISITS / IBA_SET_LEAVES (diagnostic)
+    bool set_serial = false;              // IBA_SET_SERIAL=1: the set kernel on the evaluation's own stream (diagnostic)
+    int nn_sets_min_batch = 24;           // IBA_NN_SETS_MIN_BATCH: below it the set kernel (a fixed ~0.15 ms beside the association) is not hidden
     bool nn_sets = true;                  // IBA_NN_SETS=0: every lane searches the tree even in a tight batch (diagnostic)
     int common_min_batch = 4;             // IBA_COMMON_MIN_BATCH
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
@@ -447,6 +452,20 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     CommonRef cref; NNRef nref;
     const bool common = h->common_mode > 0 && !frozen && B >= h->common_min_batch && h->d_pairs.p && h->last_hc && common_ref(h, h->last_hc, B, cref, nref);
     h->last_path = common ? 1 : 0;
+    // a batch of nearby candidates: the tree is searched once per MapPoint keypoint for the whole batch (iba_nnset_kernel). The
+    // kernel depends on the candidates alone and keeps one or two waves per SIMD busy: it runs on a second stream beside the
+    // association kernels (fork here, join before the search kernel)
+    const bool sets = common && h->d_nnset.p && h->max_mpk > 0 && h->nn_sets && B >= h->nn_sets_min_batch && ((want & 1) || h->dprm.use_3d3d);
+    auto launch_sets = [&]() -> iba_status {
+        NNLayout nls; layout_nn(h, nls);
+        const uint32_t lds = 8u * std::max(h->maxNodes, 1u);   // the tree nodes only
+        hipStream_t ss = h->set_serial ? st : h->stream2;
+        if (!h->set_serial) { HIP_TRY(h, hipEventRecord(h->ev_fork, st)); HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
+        hipLaunchKernelGGL(iba_nnset_kernel, dim3((h->max_mpk + kNNThreads - 1) / kNNThreads, nf), dim3(kNNThreads), lds, ss, NNSetArgs{dp, h->dprm, nref, nls, h->set_visits, h->set_leaves}, h->d_nnset.p, h->d_nnset_cnt.p);
+        HIP_TRY(h, hipGetLastError());
+        if (!h->set_serial) HIP_TRY(h, hipEventRecord(h->ev_join, h->stream2));
+        return IBA_OK;
+    };
     if (common) {
         uint32_t* cnt_now = h->d_pcounts.p + (size_t)(h->pairs_epoch & 1) * (size_t)nf * kCountStride;
         uint32_t* cnt_next = h->d_pcounts.p + (size_t)((h->pairs_epoch + 1) & 1) * (size_t)nf * kCountStride;
@@ -458,6 +477,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
                                h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
         }
         HIP_TRY(h, hipGetLastError());
+        if (sets) { const iba_status ss = launch_sets(); if (ss != IBA_OK) return ss; }   // beside iba_assoc2_kernel (it starts when the pairs kernel has finished)
         hipLaunchKernelGGL(iba_assoc2_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                            h->d_frame_partials.p, nrec, h->d_he.p, fl, fm, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
     } else
@@ -474,18 +494,13 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         const dim3 grid(8 * per_xcd * ngroups * NS), block(kNNThreads);
         const NNArgs na{dp, h->dprm, nl};
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
-        // a batch of nearby candidates: the tree is searched once per MapPoint keypoint for the whole batch (iba_nnset_kernel)
-        const bool sets = common && h->d_nnset.p && h->max_mpk > 0 && h->nn_sets;
-        const float4* nnset = sets ? h->d_nnset.p : nullptr; const uint32_t* nnset_cnt = sets ? h->d_nnset_cnt.p : nullptr;
-        if (sets) {
-            hipLaunchKernelGGL(iba_nnset_kernel, dim3((h->max_mpk + kNNThreads - 1) / kNNThreads, nf), dim3(kNNThreads), nl.total, st, NNSetArgs{dp, nref, nl}, h->d_nnset.p, h->d_nnset_cnt.p);
-            HIP_TRY(h, hipGetLastError());
-        }
+        const SetPt* nnset = sets ? h->d_nnset.p : nullptr; const uint32_t* nnset_cnt = sets ? h->d_nnset_cnt.p : nullptr;
+        if (sets && !h->set_serial) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));   // join: the neighbour sets built beside the association kernel
         auto launch_nn = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
-            if (wA && wC) hipLaunchKernelGGL((iba_nn_kernel<3, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, nnset, nnset_cnt);
-            else if (wA) hipLaunchKernelGGL((iba_nn_kernel<1, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, nnset, nnset_cnt);
-            else hipLaunchKernelGGL((iba_nn_kernel<2, MODE>), grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, nnset, nnset_cnt);
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, nnset, nnset_cnt); };
+            if (sets && MODE != kRefitSums) { if (wA && wC) go(iba_nn_kernel<3, MODE, 1>); else if (wA) go(iba_nn_kernel<1, MODE, 1>); else go(iba_nn_kernel<2, MODE, 1>); }
+            else { if (wA && wC) go(iba_nn_kernel<3, MODE, 0>); else if (wA) go(iba_nn_kernel<1, MODE, 0>); else go(iba_nn_kernel<2, MODE, 0>); }
         };
         if (refit) launch_nn(std::integral_constant<int, kRefitSearch>{}); else launch_nn(std::integral_constant<int, 0>{});
         HIP_TRY(h, hipGetLastError());
@@ -549,6 +564,9 @@ void iba_destroy(iba_handle* h) {
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
     h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_nnset.release(); h->d_nnset_cnt.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
@@ -751,6 +769,10 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
     if (const char* e = std::getenv("IBA_COMMON_PAIRS")) h->common_mode = std::atoi(e);
     if (const char* e = std::getenv("IBA_NN_SETS")) h->nn_sets = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IBA_SET_VISITS")) h->set_visits = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IBA_SET_LEAVES")) h->set_leaves = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IBA_SET_SERIAL")) h->set_serial = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IBA_NN_SETS_MIN_BATCH")) h->nn_sets_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
@@ -778,6 +800,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
     if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
     if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
+    if ((er = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
+    if ((er = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)) != hipSuccess || (er = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     if (h->common_mode > 0) {   // common lists of one batch: (scan point, keypoint) pairs and hard points per frame
         h->pair_cap = (int)std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, 4u * h->maxK));
         h->hard_cap = 1024;
@@ -802,8 +826,10 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if ((er = hipFuncSetAttribute((const void*)iba_nnset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
-    const void* nfns[9] = {(const void*)iba_nn_kernel<1, 0>, (const void*)iba_nn_kernel<2, 0>, (const void*)iba_nn_kernel<3, 0>, (const void*)iba_nn_kernel<1, 1>, (const void*)iba_nn_kernel<2, 1>, (const void*)iba_nn_kernel<3, 1>,
-                           (const void*)iba_nn_kernel<1, 2>, (const void*)iba_nn_kernel<2, 2>, (const void*)iba_nn_kernel<3, 2>};
+    const void* nfns[15] = {(const void*)iba_nn_kernel<1, 0, 0>, (const void*)iba_nn_kernel<2, 0, 0>, (const void*)iba_nn_kernel<3, 0, 0>, (const void*)iba_nn_kernel<1, 1, 0>, (const void*)iba_nn_kernel<2, 1, 0>,
+                            (const void*)iba_nn_kernel<3, 1, 0>, (const void*)iba_nn_kernel<1, 2, 0>, (const void*)iba_nn_kernel<2, 2, 0>, (const void*)iba_nn_kernel<3, 2, 0>,
+                            (const void*)iba_nn_kernel<1, 0, 1>, (const void*)iba_nn_kernel<2, 0, 1>, (const void*)iba_nn_kernel<3, 0, 1>, (const void*)iba_nn_kernel<1, 1, 1>, (const void*)iba_nn_kernel<2, 1, 1>,
+                            (const void*)iba_nn_kernel<3, 1, 1>};
     for (const void* fn : nfns)
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
 

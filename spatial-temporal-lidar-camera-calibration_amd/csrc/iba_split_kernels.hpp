@@ -1103,13 +1103,21 @@ __global__ __launch_bounds__(256) void iba_nn_probe_kernel(DevProblem dp, int fr
 // back to the tree.
 // ------------------------------------------------------------------------------------------------------------------
 struct NNRef { double M0[9], ti0[3], D[9], d[3]; };   // s_0 Ri_0, ti_0 of the reference candidate; the batch's spread around it
-constexpr int kSetM = 8;
+constexpr int kSetM = 8;              // points a set holds
+constexpr int kSetMaxLeaves = 6;      // leaves the ball of a set may touch before the keypoint is left to the per-candidate tree search
+constexpr int kSetMaxVisits = 6;      // leaf visits the reference query's own 1-NN search may take
 constexpr uint32_t kSetOverflow = 0xFFFFFFFFu;
-struct NNSetArgs { DevProblem dp; NNRef nr; NNLayout lay; };
+// a neighbour candidate: the scan point, and (plane_cache = 1) what the memoised planes at it say — the lane that picks it needs
+// no further gather: flags bit 0 = the local plane is valid (pointcloud.h:699-717), bit 1 = the cost term is point-to-plane
+// (iba_global.cpp:136-148) with normal n
+struct SetPt { float x, y, z; uint32_t pos; double nx, ny, nz; uint32_t flags, pad; };   // 48 B
+static_assert(sizeof(SetPt) == 48, "SetPt is read as three 16-byte pieces");
+struct NNSetArgs { DevProblem dp; DevParams prm; NNRef nr; NNLayout lay; int max_visits, max_leaves; };
 // grid: (ceil(max MapPoint keypoints of a frame / kNNThreads), frames); one lane per MapPoint keypoint
-__global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, float4* __restrict__ nnset, uint32_t* __restrict__ nnset_cnt) {
+__global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, SetPt* __restrict__ nnset, uint32_t* __restrict__ nnset_cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevProblem& dp = a.dp;
+    const DevParams& prm = a.prm;
     const int f = blockIdx.y;
     const FrameHdr& h = dp.frames[f];
     if (blockIdx.x * (uint32_t)kNNThreads >= h.n_mpk) return;
@@ -1121,40 +1129,67 @@ __global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, floa
     if (j >= h.n_mpk) return;
     const uint32_t k = dp.mpk[h.mpk_base + j];
     const size_t row = (size_t)f * dp.max_k + k;
-    if (P == 0) { nnset_cnt[row] = 0u; return; }
+    if (P == 0) { nnset_cnt[row] = kSetOverflow; return; }
     const float4* p4 = dp.pts4 + h.pt_base;
-    const uint32_t* perm_g = dp.perm + h.pt_base;
     const float4 mp = dp.kp_mp[h.kp_base + k];
     const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
     const double m0 = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
     const double m1 = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
     const double m2 = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
     const NNRef& nr = a.nr;
-    IBA_LANE_NN_DECL;
-    actA = true; actC = false;
-    ax = ((nr.M0[0] * m0 + nr.M0[1] * m1) + nr.M0[2] * m2) + nr.ti0[0];
-    ay = ((nr.M0[3] * m0 + nr.M0[4] * m1) + nr.M0[5] * m2) + nr.ti0[1];
-    az = ((nr.M0[6] * m0 + nr.M0[7] * m1) + nr.M0[8] * m2) + nr.ti0[2];
+    const double rx = ((nr.M0[0] * m0 + nr.M0[1] * m1) + nr.M0[2] * m2) + nr.ti0[0];
+    const double ry = ((nr.M0[3] * m0 + nr.M0[4] * m1) + nr.M0[5] * m2) + nr.ti0[1];
+    const double rz = ((nr.M0[6] * m0 + nr.M0[7] * m1) + nr.M0[8] * m2) + nr.ti0[2];
     const double am0 = fabs(m0), am1 = fabs(m1), am2 = fabs(m2);
     // the batch's queries (both float / double islands of the reference: they differ by the rounding of one float product,
-    // < 1e-6 of |q|) lie within sigma of (ax, ay, az)
-    const double aq = (fabs(ax) + fabs(ay)) + fabs(az);
+    // < 1e-6 of |q|) lie within sigma of the reference query r
+    const double aq = (fabs(rx) + fabs(ry)) + fabs(rz);
     const double g0 = ((nr.D[0] * am0 + nr.D[1] * am1) + nr.D[2] * am2) + nr.d[0];
     const double g1 = ((nr.D[3] * am0 + nr.D[4] * am1) + nr.D[5] * am2) + nr.d[1];
     const double g2 = ((nr.D[6] * am0 + nr.D[7] * am1) + nr.D[8] * am2) + nr.d[2];
     const double sigma = sqrt((g0 * g0 + g1 * g1) + g2 * g2) * (1.0 + 1e-9) + 2e-6 * aq + 1e-6;
-    if (!(sigma == sigma) || !(aq == aq)) { nnset_cnt[row] = kSetOverflow; return; }   // no bound: the lanes search the tree
-    lane_nn_begin(IBA_LANE_NN_PASS);
-    do { lane_nn_visit<1>(IBA_LANE_NN_PASS, s_nodes, p4, perm_g, P, D); } while (go >= 0);
-    // ---- the ball: every scan point within d_0 + 2 sigma of the reference query, by the same register-path traversal with a
-    //      FIXED bound (float arithmetic, every test inflated so that it can only add points) ----
-    const double Rb = sqrt(bestA) + 2.0 * sigma;
-    const float Rf = (float)Rb * 1.000001f + 1e-4f + 2e-6f * (float)aq;   // covers float(o), the float d^2 and the plane bounds
-    const float R2f = Rf * Rf * 1.000001f;
-    uint32_t cnt = 0u;
-    float4* out = nnset + row * (size_t)kSetM;
-    side = 0u; done = 0u; node = 0u; go = -1;
+    if (!(sigma == sigma) || !(aq <= 1e30)) { nnset_cnt[row] = kSetOverflow; return; }   // no bound: the lanes search the tree
+    // ---- exact nearest point of the reference query: the per-lane search of iba_nn_kernel, given up after kSetMaxVisits leaves
+    //      (a MapPoint far from the scan: the ball would be large anyway; its lanes search for themselves) ----
+    const uint32_t* perm_g = dp.perm + h.pt_base;
+    float dup2;
+    {
+        IBA_LANE_NN_DECL;
+        actA = true; actC = false; ax = rx; ay = ry; az = rz;
+        lane_nn_begin(IBA_LANE_NN_PASS);
+        int visits = 0;
+        do { lane_nn_visit<1>(IBA_LANE_NN_PASS, s_nodes, p4, perm_g, P, D); } while (go >= 0 && ++visits < a.max_visits);
+        if (go >= 0 || !(bestA < INFINITY)) { nnset_cnt[row] = kSetOverflow; return; }
+        dup2 = (float)bestA * 1.000001f;
+    }
+    const float o0 = (float)rx, o1 = (float)ry, o2 = (float)rz;
+    const float slop = 1e-4f + 2e-6f * (float)aq;   // float(o), the float differences and products: far below a millimetre
     const uint32_t first_leaf = (1u << D) - 1u;
+    // ---- the ball: every scan point within d_0 + 2 sigma of the reference query; register-path traversal with a FIXED bound,
+    //      float arithmetic, every test inflated so that it can only add points ----
+    const float Rf = (sqrtf(dup2) * 1.000001f + slop) + 2.0f * (float)sigma * 1.000001f + slop;
+    const float R2f = Rf * Rf * 1.000001f;
+    uint32_t cnt = 0u, leaves = 0u;
+    SetPt* out = nnset + row * (size_t)kSetM;
+    const PlaneRec* planes_cost = dp.plane_cost + h.pt_base;
+    const PlaneRec* planes_local = dp.plane_local + h.pt_base;
+    // a point of the ball -> the set, with what the memoised planes say at it (plane_cache = 1; with refitted planes the fit kernels decide)
+    auto emit = [&](const float4& v, uint32_t pos, uint32_t slot) {
+        SetPt sp; sp.x = v.x; sp.y = v.y; sp.z = v.z; sp.pos = pos; sp.nx = 0; sp.ny = 0; sp.nz = 0; sp.flags = 0u; sp.pad = 0u;
+        if (prm.plane_cache) {
+            const PlaneRec rl = planes_local[pos];
+            sp.flags = (local_neigh_ok(prm, rl) && local_plane_ok(prm, rl)) ? 1u : 0u;
+            if (prm.use_plane) {
+                const PlaneRec rc = planes_cost[pos];
+                if (!(rc.far_d2 < prm.min_diff_dist2) && !(rc.k < prm.norm_min_pts) && !(rc.reg_sum / (double)(rc.k - 1) > prm.norm_reg_threshold)) { sp.flags |= 2u; sp.nx = rc.nx; sp.ny = rc.ny; sp.nz = rc.nz; }
+            }
+        }
+        out[slot] = sp;
+    };
+    float pd2[kPathMax];
+#pragma unroll
+    for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
+    uint32_t side = 0u, done = 0u, node = 0u; int go = -1;
     do {
         int start = 0;
         if (go >= 0) {
@@ -1174,13 +1209,15 @@ __global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, floa
                     const TreeNode n = s_nodes[n1 - 1u];
                     const float dd = (n.dim == 0 ? o0 : (n.dim == 1 ? o1 : o2)) - n.split;
                     const uint32_t r = (~__float_as_uint(dd)) >> 31;
-                    pd2[L] = dd * dd * 0.999999f;   // <= the squared distance from o to the splitting plane
+                    const float ad = fmaxf(fabsf(dd) - slop, 0.f);
+                    pd2[L] = ad * ad * 0.999999f;   // <= the squared distance from the query to the splitting plane
                     side |= r << L;
                     n1 = (n1 << 1) | r;
                 }
             }
             node = n1 - 1u;
         }
+        ++leaves;
         const uint32_t lj = node - first_leaf;
         const uint32_t lo = (uint32_t)(((uint64_t)lj * P) >> D), hi = (uint32_t)(((uint64_t)(lj + 1) * P) >> D);
         for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {   // eight loads in flight per step
@@ -1191,10 +1228,7 @@ __global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, floa
             for (int u = 0; u < 8; ++u) {
                 const uint32_t i = i0 + (uint32_t)u;
                 const float dx = o0 - v[u].x, dy = o1 - v[u].y, dz = o2 - v[u].z;
-                if (i < hi && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= R2f) {
-                    if (cnt < (uint32_t)kSetM) out[cnt] = make_float4(v[u].x, v[u].y, v[u].z, __uint_as_float(i));
-                    ++cnt;
-                }
+                if (i < hi && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= R2f) { if (cnt < (uint32_t)kSetM) emit(v[u], i, cnt); ++cnt; }
             }
         }
         uint32_t cnd = 0u;
@@ -1203,8 +1237,9 @@ __global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, floa
         cnd &= ~done & ((1u << D) - 1u);
         done |= ~cnd;
         go = cnd ? 31 - __clz((int)cnd) : -1;
-    } while (go >= 0 && cnt <= (uint32_t)kSetM);
-    nnset_cnt[row] = cnt <= (uint32_t)kSetM ? cnt : kSetOverflow;
+    } while (go >= 0 && cnt <= (uint32_t)kSetM && leaves < (uint32_t)a.max_leaves);
+    if (go >= 0 || cnt > (uint32_t)kSetM || cnt == 0u) { nnset_cnt[row] = kSetOverflow; return; }
+    nnset_cnt[row] = cnt;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1224,11 +1259,13 @@ __global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, floa
 // which lane ran which search does not matter, so the sums are bitwise reproducible. One record of kNNPartial doubles per
 // (candidate, frame, slice).
 // ------------------------------------------------------------------------------------------------------------------
-template <int WHICH, int REFIT>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_NN_WAVES, IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
+// SETS 1: the batch's neighbour sets are in use (nnset != nullptr); compiled for 4 waves per SIMD — what its LDS allows anyway — so that the
+// direct pass keeps two entries' loads in registers
+template <int WHICH, int REFIT, int SETS>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS ? 4 : IBA_NN_WAVES, SETS ? 4 : IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
                                                                                                   double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist, const float4* __restrict__ fmp,
                                                                                                   const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit,
-                                                                                                  const float4* __restrict__ nnset, const uint32_t* __restrict__ nnset_cnt) {
+                                                                                                  const SetPt* __restrict__ nnset, const uint32_t* __restrict__ nnset_cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
     // nnset != nullptr: the batch's neighbour candidates (iba_nnset_kernel): a lane whose keypoint has a set picks its nearest
     // points from it instead of searching the tree.
@@ -1278,7 +1315,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
     const uint32_t nnodes = (1u << D) - 1u;
     uint32_t my_n = 0u;
     if (tid < cands_here) my_n = lcount[(size_t)(g * CG + tid) * nf + f];
-    for (uint32_t i = tid; i < nnodes; i += T) s_nodes[i] = dp.nodes[h.node_base + i];
+    if (!SETS) for (uint32_t i = tid; i < nnodes; i += T) s_nodes[i] = dp.nodes[h.node_base + i];   // with the batch's neighbour sets the tree is staged only if a lane needs it
     if (tid < kMaxGroup) s_n[tid] = my_n;
     if (tid < cands_here * kCdDoubles) s_cd[tid] = ((const double*)&cands[g * CG + tid / kCdDoubles])[12 + tid % kCdDoubles];
     __syncthreads();
@@ -1356,21 +1393,28 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                     qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
                 }
             };
-            // the finished searches of entry wn: the association's neighbour (+ kind), the cost distance. cpt: the cost path's
-            // neighbour when the caller already holds its coordinates (a set lane), else it is fetched
-            auto finish = [&](uint32_t wn, const float4* cpt) {
+            // the finished searches of entry wn: the association's neighbour (+ kind), the cost distance. From the tree search
+            // the plane records are fetched here; a set lane brings them along (sa / sc: the set entries of its two neighbours)
+            auto finish = [&](uint32_t wn, const SetPt* sa, const SetPt* sc) {
                 const size_t at = entry_at(wn);
                 if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2)) {   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
                     bool state = false;   // refit: settled by the fit kernel
-                    if (!refit) { const PlaneRec r2 = planes_local[bposA]; state = local_neigh_ok(prm, r2) && local_plane_ok(prm, r2); }   // pointcloud.h:699-717
+                    if (!refit) {
+                        if (sa) state = (sa->flags & 1u) != 0u;
+                        else { const PlaneRec r2 = planes_local[bposA]; state = local_neigh_ok(prm, r2) && local_plane_ok(prm, r2); }   // pointcloud.h:699-717
+                    }
                     flist[at].z = bposA | (state ? 0x80000000u : 0u);
                 }
                 double res = NAN;
                 if ((WHICH & 2) && actC) {
-                    const float4 pv = cpt ? *cpt : p4[bposC];
-                    const double ex = (double)pv.x - qx, ey = (double)pv.y - qy, ez = (double)pv.z - qz;
+                    float px, py, pz;
+                    if (sc) { px = sc->x; py = sc->y; pz = sc->z; } else { const float4 pv = p4[bposC]; px = pv.x; py = pv.y; pz = pv.z; }
+                    const double ex = (double)px - qx, ey = (double)py - qy, ez = (double)pz - qz;
                     if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
-                    else {
+                    else if (sc) {   // cost_res with the plane's verdict already taken (iba_nnset_kernel): the same expressions
+                        const double dist = (sc->flags & 2u) ? fabs(ex * sc->nx + ey * sc->ny + ez * sc->nz) : sqrt((ex * ex + ey * ey) + ez * ez);
+                        res = (sc->flags & 2u) ? dist : -dist;
+                    } else {
                         PlaneRec rec; rec.k = 0;
                         if (prm.use_plane) rec = planes_cost[bposC];   // the whole record in one round trip
                         res = cost_res(prm, prm.use_plane != 0, rec, ex, ey, ez);
@@ -1380,43 +1424,49 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
             };
             uint32_t* s_ovf = (uint32_t*)(smem + lay.off_ovf);   // work entries whose keypoint has no usable set: searched in the tree below
             uint32_t c_end = c1;                                 // entries the persistent loop hands out
-            if (nnset) {
+            if (SETS) {
                 // ---- a batch of nearby candidates: the neighbour candidates of every MapPoint keypoint are there (iba_nnset_kernel).
                 //      One pass, no claiming: thread t takes the entries t, t + T, ...; per entry one dependent chain of three loads
                 //      (entry -> set -> plane records), the next entry's first load in flight meanwhile ----
                 if (tid == 0) s_ctr[1] = 0u;
                 __syncthreads();
-                uint4 e_n = make_uint4(0u, 0u, 0u, 0u); float4 mp_n = make_float4(0.f, 0.f, 0.f, 0.f);
-                auto fetch = [&](uint32_t wn) {
-                    e_n = make_uint4(0u, 0u, 0u, 0u);
+                // two entries per step: their loads are issued stage by stage (entries, then sets), so a thread's four entries cost
+                // four dependent round trips instead of eight
+                auto fetch = [&](uint32_t wn, uint4& e, float4& mp) {
+                    e = make_uint4(0u, 0u, 0u, 0u); mp = make_float4(0.f, 0.f, 0.f, 0.f);
                     const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
-                    if (wn < c1 && il < s_n[cc]) { const size_t at = entry_at(wn); e_n = flist[at]; mp_n = fmp[at]; }
+                    if (wn < c1 && il < s_n[cc]) { const size_t at = entry_at(wn); e = flist[at]; mp = fmp[at]; }
                 };
-                fetch((uint32_t)tid);
-                for (uint32_t wn = (uint32_t)tid; wn < c1; wn += (uint32_t)T) {
-                    const uint4 e = e_n; const float4 mp = mp_n;
-                    fetch(wn + (uint32_t)T);
-                    if (!(e.w & kWantMask)) continue;
-                    const size_t srow = (size_t)f * dp.max_k + e.x;
-                    const float4* sp = nnset + srow * (size_t)kSetM;
-                    const uint32_t sc = nnset_cnt[srow];
-                    const float4 p0 = sp[0], p1 = sp[1];   // nearly every set holds one or two points: fetched with the count
-                    if (sc == kSetOverflow || sc == 0u) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; continue; }
+                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, uint32_t sc, const SetPt& p0, const SetPt& p1, const SetPt* sp) {
+                    if (sc == kSetOverflow || sc == 0u) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; return; }
                     make_queries(wn & ((1u << cg_shift) - 1u), e, mp);
                     bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
-                    float4 cbest = p0;
+                    SetPt abest = p0, cbest = p0;
                     for (uint32_t si = 0; si < sc; ++si) {
-                        const float4 pv = si == 0u ? p0 : (si == 1u ? p1 : sp[si]);
-                        const uint32_t pi = __float_as_uint(pv.w);
+                        const SetPt pv = si == 0u ? p0 : (si == 1u ? p1 : sp[si]);
                         const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
-                        if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, pi, perm_g); }
-                        if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; const uint32_t was = bposC; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, pi, perm_g); if (bposC != was) cbest = pv; }
+                        if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; const uint32_t was = bposA; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposA != was) abest = pv; }
+                        if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; const uint32_t was = bposC; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposC != was) cbest = pv; }
                     }
-                    if (dbg != 5) finish(wn, &cbest);
+                    if (dbg != 5) finish(wn, &abest, &cbest);
+                };
+                for (uint32_t wn = (uint32_t)tid; wn < c1; wn += 2u * (uint32_t)T) {
+                    uint4 e0, e1; float4 mq0, mq1;
+                    fetch(wn, e0, mq0); fetch(wn + (uint32_t)T, e1, mq1);
+                    const bool w0 = (e0.w & kWantMask) != 0u, w1 = (e1.w & kWantMask) != 0u;
+                    const size_t r0 = (size_t)f * dp.max_k + (w0 ? e0.x : 0u), r1 = (size_t)f * dp.max_k + (w1 ? e1.x : 0u);
+                    const SetPt* sp0 = nnset + r0 * (size_t)kSetM; const SetPt* sp1 = nnset + r1 * (size_t)kSetM;
+                    uint32_t sc0 = 0u, sc1 = 0u; SetPt a0, a1, b0, b1;
+                    a0.flags = a1.flags = b0.flags = b1.flags = 0u;
+                    if (w0) { sc0 = nnset_cnt[r0]; a0 = sp0[0]; a1 = sp0[1]; }   // nearly every set holds one or two points: fetched with the count
+                    if (w1) { sc1 = nnset_cnt[r1]; b0 = sp1[0]; b1 = sp1[1]; }
+                    if (w0) pick(wn, e0, mq0, sc0, a0, a1, sp0);
+                    if (w1) pick(wn + (uint32_t)T, e1, mq1, sc1, b0, b1, sp1);
                 }
                 __syncthreads();
                 c_end = s_ctr[1];
                 if (tid == 0) *s_ctr = 0u;
+                if (c_end != 0u) for (uint32_t i = tid; i < nnodes; i += T) s_nodes[i] = dp.nodes[h.node_base + i];   // some lanes search the tree after all
                 __syncthreads();
             }
             // ---- persistent lanes, refilled from the work list (all of it, or what the sets left over) ----
@@ -1432,7 +1482,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                     exhausted = base + nidle >= c_end;
                     if (!have) {
                         const uint32_t wq = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                        const uint32_t wn = nnset ? (wq < c_end ? s_ovf[wq] : c1) : wq;
+                        const uint32_t wn = SETS ? (wq < c_end ? s_ovf[wq] : c1) : wq;
                         const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
                         uint4 e = make_uint4(0u, 0u, 0u, 0u);
                         float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1449,7 +1499,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
                 if (have && dbg == 4) { have = false; continue; }
                 if (have) lane_nn_visit<WHICH>(IBA_LANE_NN_PASS, s_nodes, p4, perm_g, P, D);
                 if (have && go < 0) {
-                    if (dbg != 5) finish(w, nullptr);
+                    if (dbg != 5) finish(w, nullptr, nullptr);
                     have = false;
                 }
             }
