@@ -265,6 +265,10 @@ iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
  * (a batch of >= 4 nearby candidates), 0 = every candidate searched for itself. The results are the same bits either way.
  * Environment (read at iba_create): IBA_COMMON_PAIRS=0 never share, 2 share whenever the bound allows; IBA_COMMON_MAX_PX. */
 int32_t iba_debug_last_path(const iba_handle* h);
+/* debug: how often the anchored neighbour lists (the 1-NN search memoised around an anchor extrinsic that follows the
+ * optimiser's candidates; IBA_NN_SETS=0 disables them, IBA_ANCHOR_REACH sets the drift in metres that moves the anchor) have
+ * been built on this handle. Results do not depend on the anchor: every lane certifies its pick or searches the tree. */
+int32_t iba_debug_anchor_builds(const iba_handle* h);
 /* debug: exact 1-NN (nanoflann semantics with the lowest-index tie rule, iba_global.cpp:116-122) of n LiDAR-frame query
  * points in the scan of local frame `frame`, run through the search kernel's own kd search, one lane per query: original point
  * index and exact squared distance. mode 1: as the association path's query alone; 2: as the cost path's alone; 3 / 4: both paths

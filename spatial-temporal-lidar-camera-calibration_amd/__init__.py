@@ -265,6 +265,11 @@ class IbaHandle:
         self.lib.iba_debug_last_path.argtypes = [C.c_void_p]
         return int(self.lib.iba_debug_last_path(self.h))
 
+    @property
+    def anchor_builds(self):
+        self.lib.iba_debug_anchor_builds.argtypes = [C.c_void_p]
+        return int(self.lib.iba_debug_anchor_builds(self.h))
+
     def set_timing(self, on=True):
         self._chk(self.lib.iba_set_timing(self.h, C.c_int32(1 if on else 0)))
 

@@ -76,8 +76,6 @@ struct iba_handle {
     int nn_ns = 1;                        // search blocks per (frame, candidate group): ceil(maxKw / kSliceW)
     DevBuf<double> d_nn_partials;         // IBA_MAX_BATCH * n_frames * kMaxSlices * kNNPartial
     hipEvent_t ev_mid = nullptr;
-    hipStream_t stream2 = nullptr;        // the batch's neighbour sets are built beside the association kernels (fork / join around iba_nnset_kernel)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float last_assoc_ms = 0.f, last_nn_ms = 0.f;
     // common pairs of a batch of nearby candidates (iba_pairs_kernel + iba_assoc2_kernel)
     LdsLayout alay2{};                    // LDS plan of iba_assoc2_kernel
@@ -85,14 +83,14 @@ struct iba_handle {
     DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
     DevBuf<uint32_t> mpk;                 // per frame: keypoints that own a MapPoint
     uint32_t max_mpk = 0;
-    DevBuf<SetPt> d_nnset; DevBuf<uint32_t> d_nnset_cnt;   // neighbour candidates of a batch: n_frames x maxK x kSetM points, n_frames x maxK counts
+    DevBuf<SetPt> d_anchor;               // anchored neighbour lists: n_frames x maxK rows of kAnchorRow 48-byte pieces
+    bool anchor_valid = false; AnchorRef anchor_ref{}; int calls_since_anchor = 0;
+    double anchor_reach = 0.06;           // IBA_ANCHOR_REACH (m): a batch whose reference candidate moves a nominal MapPoint further than this from the anchor's query gets a new anchor
+    int anchor_builds = 0;
     unsigned pairs_epoch = 0;             // which of the two counter sets the next call uses
     int pair_cap = 0, hard_cap = 0, pairs_slices = 1;   // pairs_slices: scan points per thread of iba_pairs_kernel (IBA_PAIRS_SLICES)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
-    int set_visits = kSetMaxVisits, set_leaves = kSetMaxLeaves;   // IBA_SET_VISITS / IBA_SET_LEAVES (diagnostic)
-    bool set_serial = false;              // IBA_SET_SERIAL=1: the set kernel on the evaluation's own stream (diagnostic)
-    int nn_sets_min_batch = 24;           // IBA_NN_SETS_MIN_BATCH: below it the set kernel (a fixed ~0.15 ms beside the association) is not hidden
-    bool nn_sets = true;                  // IBA_NN_SETS=0: every lane searches the tree even in a tight batch (diagnostic)
+    bool nn_sets = true;                  // IBA_NN_SETS=0: no anchored neighbour lists, every lane searches the tree (diagnostic)
     int common_min_batch = 4;             // IBA_COMMON_MIN_BATCH
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
     double max_fx = 0.0;
@@ -264,7 +262,7 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
 // nearest the batch mean, rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i, both inflated for their own
 // rounding. Returns false when the batch is too wide for common pairs to pay (nominal projection spread above max_px at a
 // point 12 m out, 10 m deep), in which case every candidate searches for itself (iba_assoc_kernel).
-bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr, NNRef& nr) {
+bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
     double mean[12] = {0};
     for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].R[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].t[i]; }
     for (double& m : mean) m /= (double)B;
@@ -290,15 +288,6 @@ bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr, NNRef
             for (int q = 0; q < 3; ++q) { const double e = std::fabs(A[r * 3 + q] - (r == q ? 1.0 : 0.0)); if (!(e <= 4.0)) return false; cr.rho[r * 3 + q] = std::max(cr.rho[r * 3 + q], e); }
         }
     }
-    // the MapPoint queries of the batch around the reference's (see iba_nnset_kernel): q_b = (s_b Ri_b) m + ti_b
-    for (int i = 0; i < 9; ++i) { nr.M0[i] = c0.s * c0.Ri[i]; nr.D[i] = 0; }
-    for (int i = 0; i < 3; ++i) { nr.ti0[i] = c0.ti[i]; nr.d[i] = 0; }
-    for (int b = 0; b < B; ++b) {
-        for (int i = 0; i < 9; ++i) { const double e = std::fabs(hc[b].s * hc[b].Ri[i] - nr.M0[i]); if (!(e <= 1e30)) return false; nr.D[i] = std::max(nr.D[i], e); }
-        for (int i = 0; i < 3; ++i) { const double e = std::fabs(hc[b].ti[i] - nr.ti0[i]); if (!(e <= 1e30)) return false; nr.d[i] = std::max(nr.d[i], e); }
-    }
-    for (int i = 0; i < 9; ++i) nr.D[i] = nr.D[i] * (1.0 + 1e-9) + 1e-15;
-    for (int i = 0; i < 3; ++i) nr.d[i] = nr.d[i] * (1.0 + 1e-9) + 1e-15;
     double rho_row = 0, tau_max = 0;
     for (int r = 0; r < 3; ++r) { rho_row = std::max(rho_row, cr.rho[r * 3] + cr.rho[r * 3 + 1] + cr.rho[r * 3 + 2]); tau_max = std::max(tau_max, cr.tau[r]); }
     for (int i = 0; i < 9; ++i) cr.rho[i] = cr.rho[i] * (1.0 + 1e-9) + 1e-15;
@@ -449,23 +438,50 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     // 2d-3d association: a batch of nearby candidates shares ONE search for the (scan point, keypoint) pairs per keyframe
     // (iba_pairs_kernel) and every candidate runs the exact test on that list (iba_assoc2_kernel); a lone candidate, a small or a
     // wide batch searches per candidate (iba_assoc_kernel). Same results either way, bit for bit.
-    CommonRef cref; NNRef nref;
-    const bool common = h->common_mode > 0 && !frozen && B >= h->common_min_batch && h->d_pairs.p && h->last_hc && common_ref(h, h->last_hc, B, cref, nref);
+    CommonRef cref;
+    const bool common = h->common_mode > 0 && !frozen && B >= h->common_min_batch && h->d_pairs.p && h->last_hc && common_ref(h, h->last_hc, B, cref);
     h->last_path = common ? 1 : 0;
-    // a batch of nearby candidates: the tree is searched once per MapPoint keypoint for the whole batch (iba_nnset_kernel). The
-    // kernel depends on the candidates alone and keeps one or two waves per SIMD busy: it runs on a second stream beside the
-    // association kernels (fork here, join before the search kernel)
-    const bool sets = common && h->d_nnset.p && h->max_mpk > 0 && h->nn_sets && B >= h->nn_sets_min_batch && ((want & 1) || h->dprm.use_3d3d);
-    auto launch_sets = [&]() -> iba_status {
-        NNLayout nls; layout_nn(h, nls);
-        const uint32_t lds = 8u * std::max(h->maxNodes, 1u);   // the tree nodes only
-        hipStream_t ss = h->set_serial ? st : h->stream2;
-        if (!h->set_serial) { HIP_TRY(h, hipEventRecord(h->ev_fork, st)); HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
-        hipLaunchKernelGGL(iba_nnset_kernel, dim3((h->max_mpk + kNNThreads - 1) / kNNThreads, nf), dim3(kNNThreads), lds, ss, NNSetArgs{dp, h->dprm, nref, nls, h->set_visits, h->set_leaves}, h->d_nnset.p, h->d_nnset_cnt.p);
-        HIP_TRY(h, hipGetLastError());
-        if (!h->set_serial) HIP_TRY(h, hipEventRecord(h->ev_join, h->stream2));
-        return IBA_OK;
-    };
+    // Anchored neighbour lists (iba_anchor_kernel): the scan points nearest to every MapPoint's query under an ANCHOR extrinsic,
+    // built once and reused by every evaluation whose candidates stay near the anchor (each lane certifies its own pick, or
+    // searches the tree). The anchor follows the optimiser: when the candidate of this call that is nearest the batch mean has
+    // moved a nominal MapPoint (30 m out) further than anchor_reach from the anchor's query, the lists are rebuilt around it —
+    // at most every fourth call, so that a wide exploratory phase does not rebuild for nothing.
+    bool sets = false;
+    const bool search_wanted = (want & 1) || h->dprm.use_3d3d;
+    if (h->nn_sets && h->d_anchor.p && h->max_mpk > 0 && search_wanted && h->last_hc) {
+        const Cand* hc = h->last_hc;
+        int ref = 0;
+        if (B > 1) {
+            double mean[12] = {0};
+            for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].s * hc[b].Ri[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].ti[i]; }
+            double best = INFINITY;
+            for (int b = 0; b < B; ++b) {
+                double dd = 0;
+                for (int i = 0; i < 9; ++i) dd = std::max(dd, 30.0 * std::fabs(hc[b].s * hc[b].Ri[i] - mean[i] / B));
+                for (int i = 0; i < 3; ++i) dd = std::max(dd, std::fabs(hc[b].ti[i] - mean[9 + i] / B));
+                if (dd < best) { best = dd; ref = b; }
+            }
+        }
+        auto drift = [&](const Cand& c) {   // how far a nominal MapPoint's query moves between the anchor and c (row-sum bound)
+            double worst = 0;
+            for (int r = 0; r < 3; ++r) {
+                double v = std::fabs(c.ti[r] - h->anchor_ref.t[r]);
+                for (int q = 0; q < 3; ++q) v += 30.0 * std::fabs(c.s * c.Ri[r * 3 + q] - h->anchor_ref.M[r * 3 + q]);
+                worst = std::max(worst, v);
+            }
+            return worst;
+        };
+        ++h->calls_since_anchor;
+        const double far = h->anchor_valid ? drift(hc[ref]) : INFINITY;
+        if (!(far <= h->anchor_reach) && (!h->anchor_valid || h->calls_since_anchor >= 4) && std::isfinite(hc[ref].s)) {
+            for (int i = 0; i < 9; ++i) h->anchor_ref.M[i] = hc[ref].s * hc[ref].Ri[i];
+            for (int i = 0; i < 3; ++i) h->anchor_ref.t[i] = hc[ref].ti[i];
+            hipLaunchKernelGGL(iba_anchor_kernel, dim3((h->max_mpk + kNNThreads - 1) / kNNThreads, nf), dim3(kNNThreads), 8u * std::max(h->maxNodes, 1u), st, AnchorArgs{dp, h->dprm, h->anchor_ref}, h->d_anchor.p);
+            HIP_TRY(h, hipGetLastError());
+            h->anchor_valid = true; h->calls_since_anchor = 0; ++h->anchor_builds;
+            sets = true;
+        } else sets = h->anchor_valid && far <= 4.0 * h->anchor_reach;   // further out the certificates fail anyway: plain search kernel
+    }
     if (common) {
         uint32_t* cnt_now = h->d_pcounts.p + (size_t)(h->pairs_epoch & 1) * (size_t)nf * kCountStride;
         uint32_t* cnt_next = h->d_pcounts.p + (size_t)((h->pairs_epoch + 1) & 1) * (size_t)nf * kCountStride;
@@ -477,7 +493,6 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
                                h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
         }
         HIP_TRY(h, hipGetLastError());
-        if (sets) { const iba_status ss = launch_sets(); if (ss != IBA_OK) return ss; }   // beside iba_assoc2_kernel (it starts when the pairs kernel has finished)
         hipLaunchKernelGGL(iba_assoc2_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                            h->d_frame_partials.p, nrec, h->d_he.p, fl, fm, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
     } else
@@ -494,11 +509,10 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         const dim3 grid(8 * per_xcd * ngroups * NS), block(kNNThreads);
         const NNArgs na{dp, h->dprm, nl};
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
-        const SetPt* nnset = sets ? h->d_nnset.p : nullptr; const uint32_t* nnset_cnt = sets ? h->d_nnset_cnt.p : nullptr;
-        if (sets && !h->set_serial) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));   // join: the neighbour sets built beside the association kernel
+        const SetPt* anchor = sets ? h->d_anchor.p : nullptr;
         auto launch_nn = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
-            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, nnset, nnset_cnt); };
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, anchor); };
             if (sets && MODE != kRefitSums) { if (wA && wC) go(iba_nn_kernel<3, MODE, 1>); else if (wA) go(iba_nn_kernel<1, MODE, 1>); else go(iba_nn_kernel<2, MODE, 1>); }
             else { if (wA && wC) go(iba_nn_kernel<3, MODE, 0>); else if (wA) go(iba_nn_kernel<1, MODE, 0>); else go(iba_nn_kernel<2, MODE, 0>); }
         };
@@ -562,11 +576,8 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_nnset.release(); h->d_nnset_cnt.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_anchor.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
@@ -769,10 +780,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
     if (const char* e = std::getenv("IBA_COMMON_PAIRS")) h->common_mode = std::atoi(e);
     if (const char* e = std::getenv("IBA_NN_SETS")) h->nn_sets = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IBA_SET_VISITS")) h->set_visits = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("IBA_SET_LEAVES")) h->set_leaves = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("IBA_SET_SERIAL")) h->set_serial = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IBA_NN_SETS_MIN_BATCH")) h->nn_sets_min_batch = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IBA_ANCHOR_REACH")) h->anchor_reach = std::atof(e);
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
@@ -800,8 +808,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
     if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
     if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
-    if ((er = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
-    if ((er = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)) != hipSuccess || (er = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
+    if (h->nn_sets && h->max_mpk > 0 && (er = h->d_anchor.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kAnchorRow)) != hipSuccess) return bail("alloc anchored neighbour lists", er);
     if (h->common_mode > 0) {   // common lists of one batch: (scan point, keypoint) pairs and hard points per frame
         h->pair_cap = (int)std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, 4u * h->maxK));
         h->hard_cap = 1024;
@@ -809,8 +816,6 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         if ((er = h->d_pairs.alloc((size_t)std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
         if ((er = h->d_hard.alloc((size_t)std::max(nf, 1) * h->hard_cap)) != hipSuccess) return bail("alloc hard list", er);
         if ((er = h->d_pcounts.alloc(2 * (size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("alloc pair counts", er);   // two sets, used in turn
-        if ((er = h->d_nnset.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kSetM)) != hipSuccess) return bail("alloc neighbour sets", er);
-        if ((er = h->d_nnset_cnt.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u))) != hipSuccess) return bail("alloc neighbour set counts", er);
         if ((er = hipMemset(h->d_pcounts.p, 0, sizeof(uint32_t) * 2 * (size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("clear pair counts", er);
     }
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
@@ -825,7 +830,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
-    if ((er = hipFuncSetAttribute((const void*)iba_nnset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    if ((er = hipFuncSetAttribute((const void*)iba_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     const void* nfns[15] = {(const void*)iba_nn_kernel<1, 0, 0>, (const void*)iba_nn_kernel<2, 0, 0>, (const void*)iba_nn_kernel<3, 0, 0>, (const void*)iba_nn_kernel<1, 1, 0>, (const void*)iba_nn_kernel<2, 1, 0>,
                             (const void*)iba_nn_kernel<3, 1, 0>, (const void*)iba_nn_kernel<1, 2, 0>, (const void*)iba_nn_kernel<2, 2, 0>, (const void*)iba_nn_kernel<3, 2, 0>,
                             (const void*)iba_nn_kernel<1, 0, 1>, (const void*)iba_nn_kernel<2, 0, 1>, (const void*)iba_nn_kernel<3, 0, 1>, (const void*)iba_nn_kernel<1, 1, 1>, (const void*)iba_nn_kernel<2, 1, 1>,
@@ -857,6 +862,7 @@ iba_status iba_set_params(iba_handle* h, const iba_params* p) {
     if (p->max_pixel_dist != h->params.max_pixel_dist) return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist is baked into the keypoint grid: recreate the handle");
     HIP_TRY(h, hipSetDevice(h->device));
     h->params = *p; to_dev_params(*p, h->dprm); h->frozen_valid = false;
+    h->anchor_valid = false;   // the lists carry the planes' verdicts under the old parameters
     return compute_plane_cache(h);
 }
 
@@ -986,6 +992,9 @@ iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
 
 // debug: 1 when the last evaluation chain shared the 2d-3d pair search over the batch (iba_pairs_kernel + iba_assoc2_kernel)
 int32_t iba_debug_last_path(const iba_handle* h) { return h ? h->last_path : -1; }
+
+// debug: how many times the anchored neighbour lists have been (re)built on this handle
+int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }
 
 // debug: exact 1-NN of n LiDAR-frame queries in the scan of a local frame, through the frame kernels' own search
 iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n, int32_t mode, uint32_t* out_idx, double* out_d2) {

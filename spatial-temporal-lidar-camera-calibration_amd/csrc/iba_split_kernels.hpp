@@ -1088,104 +1088,69 @@ __global__ __launch_bounds__(256) void iba_nn_probe_kernel(DevProblem dp, int fr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Neighbour candidates of a BATCH of nearby candidates.
+// Anchored neighbour lists: the 1-NN search memoised around an anchor extrinsic.
 //
-// The 1-NN search of iba_nn_kernel answers, per (MapPoint, candidate): which scan point is nearest to the MapPoint moved into
-// the LiDAR frame by this candidate (iba_global.cpp:231-234, 116-122; iba_local.cpp:238-239, 282-290). The MapPoint is the
-// keypoint's, not the candidate's: over a batch of nearby candidates its queries q_b = s_b Ri_b m + ti_b (m = the MapPoint in the
-// camera frame) lie within sigma = |D |m| + d| of the reference candidate's q_0, with D_ij = max_b |s_b Ri_b - s_0 Ri_0|_ij and
-// d_i = max_b |ti_b - ti_0|_i from the host. If p_0 is q_0's nearest scan point at distance d_0, candidate b's nearest point p_b
-// has |q_b - p_b| <= |q_b - p_0| <= d_0 + sigma, hence |q_0 - p_b| <= d_0 + 2 sigma: every candidate's nearest point (and every
-// point tied with it) lies in the ball of radius d_0 + 2 sigma around q_0. That ball holds one or two scan points at the bench
-// shape. So the tree is searched ONCE per MapPoint keypoint of a keyframe for the whole batch — exact 1-NN of q_0, then the
-// points of the ball, at most kSetM of them — and iba_nn_kernel picks each candidate's nearest among them with its own exact
-// f64 distances (same expressions, same tie rule: same bits as its tree search). A ball with more points sends its lanes
-// back to the tree.
+// The 1-NN search of iba_nn_kernel answers, per (MapPoint, candidate): which scan point is nearest to the MapPoint moved into the
+// LiDAR frame by this candidate (iba_global.cpp:231-234, 116-122; iba_local.cpp:238-239, 282-290). The MapPoint is the keypoint's,
+// not the candidate's, and an optimiser's candidates stay near each other: under candidate b the query q_b = s_b Ri_b m + ti_b
+// (m = the MapPoint in the camera frame) lies S = |q_b - q_a| from the query q_a of an ANCHOR extrinsic a. Let p_1 .. p_M be the
+// M scan points nearest to q_a (distances d_1 <= .. <= d_M, exact). The nearest point p of q_b has |q_b - p| <= |q_b - p_1| <=
+// d_1 + S, hence |q_a - p| <= d_1 + 2 S: if d_1 + 2 S < d_M (or the scan has fewer than M points), every nearest point of q_b —
+// and every point tied with it — is among the listed points within d_1 + 2 S of q_a. A lane of iba_nn_kernel evaluates its own
+// S from its own exact queries, checks that certificate, and picks its nearest point among those few entries with the search's own
+// f64 expressions and tie rule: the same bits as the tree search, which remains the path of every lane whose certificate fails.
+// The lists are built once per anchor (iba_anchor_kernel: exact kNN(M) per MapPoint keypoint) and rebuilt when the candidates
+// have drifted away from it (host, run_split); each entry carries what the memoised planes say at its point, so a lane that
+// picks it needs no further gather. At the bench shape a candidate 0.5 mrad / 5 mm / 0.1 % from the anchor has S ~ 4 cm against
+// d_M ~ 30 cm: one or two entries qualify, and no lane searches the tree.
 // ------------------------------------------------------------------------------------------------------------------
-struct NNRef { double M0[9], ti0[3], D[9], d[3]; };   // s_0 Ri_0, ti_0 of the reference candidate; the batch's spread around it
-constexpr int kSetM = 8;              // points a set holds
-constexpr int kSetMaxLeaves = 6;      // leaves the ball of a set may touch before the keypoint is left to the per-candidate tree search
-constexpr int kSetMaxVisits = 6;      // leaf visits the reference query's own 1-NN search may take
-constexpr uint32_t kSetOverflow = 0xFFFFFFFFu;
-// a neighbour candidate: the scan point, and (plane_cache = 1) what the memoised planes at it say — the lane that picks it needs
-// no further gather: flags bit 0 = the local plane is valid (pointcloud.h:699-717), bit 1 = the cost term is point-to-plane
-// (iba_global.cpp:136-148) with normal n
-struct SetPt { float x, y, z; uint32_t pos; double nx, ny, nz; uint32_t flags, pad; };   // 48 B
-static_assert(sizeof(SetPt) == 48, "SetPt is read as three 16-byte pieces");
-struct NNSetArgs { DevProblem dp; DevParams prm; NNRef nr; NNLayout lay; int max_visits, max_leaves; };
-// grid: (ceil(max MapPoint keypoints of a frame / kNNThreads), frames); one lane per MapPoint keypoint
-__global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, SetPt* __restrict__ nnset, uint32_t* __restrict__ nnset_cnt) {
+constexpr int kSetM = 8;              // neighbours a list holds
+// a listed neighbour: the scan point, a float lower bound of its distance to the anchor query, and (plane_cache = 1) what the
+// memoised planes at it say: flags bit 0 = the local plane is valid (pointcloud.h:699-717), bit 1 = the cost term is
+// point-to-plane (iba_global.cpp:136-148) with normal n
+struct SetPt { float x, y, z; uint32_t pos; double nx, ny, nz; uint32_t flags; float da_lo; };   // 48 B
+struct AnchorHdr { double qa[3]; double d1, dM; uint32_t count, pad; };                         // 48 B: anchor query, nearest / farthest listed distance
+static_assert(sizeof(SetPt) == 48 && sizeof(AnchorHdr) == 48, "anchor rows are read as 16-byte pieces");
+constexpr size_t kAnchorRow = 1 + kSetM;   // 48-byte pieces per (frame, keypoint) row: header, then the entries
+struct AnchorRef { double M[9], t[3]; };   // s_a Ri_a, ti_a of the anchor extrinsic: q_a = M m + t
+struct AnchorArgs { DevProblem dp; DevParams prm; AnchorRef ar; };
+// grid: (ceil(max MapPoint keypoints of a frame / kNNThreads), frames); one lane per MapPoint keypoint; dynamic LDS: the tree nodes
+__global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, SetPt* __restrict__ rows) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevProblem& dp = a.dp;
     const DevParams& prm = a.prm;
     const int f = blockIdx.y;
     const FrameHdr& h = dp.frames[f];
     if (blockIdx.x * (uint32_t)kNNThreads >= h.n_mpk) return;
-    TreeNode* s_nodes = (TreeNode*)(smem + a.lay.off_nodes);
+    TreeNode* s_nodes = (TreeNode*)smem;
     const uint32_t P = h.P, D = h.depth;
     for (uint32_t i = threadIdx.x; i < (1u << D) - 1u; i += kNNThreads) s_nodes[i] = dp.nodes[h.node_base + i];
     __syncthreads();
     const uint32_t j = blockIdx.x * (uint32_t)kNNThreads + threadIdx.x;
     if (j >= h.n_mpk) return;
     const uint32_t k = dp.mpk[h.mpk_base + j];
-    const size_t row = (size_t)f * dp.max_k + k;
-    if (P == 0) { nnset_cnt[row] = kSetOverflow; return; }
+    SetPt* row = rows + ((size_t)f * dp.max_k + k) * kAnchorRow;
+    AnchorHdr hd;
     const float4* p4 = dp.pts4 + h.pt_base;
     const float4 mp = dp.kp_mp[h.kp_base + k];
     const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
     const double m0 = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
     const double m1 = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
     const double m2 = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
-    const NNRef& nr = a.nr;
-    const double rx = ((nr.M0[0] * m0 + nr.M0[1] * m1) + nr.M0[2] * m2) + nr.ti0[0];
-    const double ry = ((nr.M0[3] * m0 + nr.M0[4] * m1) + nr.M0[5] * m2) + nr.ti0[1];
-    const double rz = ((nr.M0[6] * m0 + nr.M0[7] * m1) + nr.M0[8] * m2) + nr.ti0[2];
-    const double am0 = fabs(m0), am1 = fabs(m1), am2 = fabs(m2);
-    // the batch's queries (both float / double islands of the reference: they differ by the rounding of one float product,
-    // < 1e-6 of |q|) lie within sigma of the reference query r
-    const double aq = (fabs(rx) + fabs(ry)) + fabs(rz);
-    const double g0 = ((nr.D[0] * am0 + nr.D[1] * am1) + nr.D[2] * am2) + nr.d[0];
-    const double g1 = ((nr.D[3] * am0 + nr.D[4] * am1) + nr.D[5] * am2) + nr.d[1];
-    const double g2 = ((nr.D[6] * am0 + nr.D[7] * am1) + nr.D[8] * am2) + nr.d[2];
-    const double sigma = sqrt((g0 * g0 + g1 * g1) + g2 * g2) * (1.0 + 1e-9) + 2e-6 * aq + 1e-6;
-    if (!(sigma == sigma) || !(aq <= 1e30)) { nnset_cnt[row] = kSetOverflow; return; }   // no bound: the lanes search the tree
-    // ---- exact nearest point of the reference query: the per-lane search of iba_nn_kernel, given up after kSetMaxVisits leaves
-    //      (a MapPoint far from the scan: the ball would be large anyway; its lanes search for themselves) ----
-    const uint32_t* perm_g = dp.perm + h.pt_base;
-    float dup2;
-    {
-        IBA_LANE_NN_DECL;
-        actA = true; actC = false; ax = rx; ay = ry; az = rz;
-        lane_nn_begin(IBA_LANE_NN_PASS);
-        int visits = 0;
-        do { lane_nn_visit<1>(IBA_LANE_NN_PASS, s_nodes, p4, perm_g, P, D); } while (go >= 0 && ++visits < a.max_visits);
-        if (go >= 0 || !(bestA < INFINITY)) { nnset_cnt[row] = kSetOverflow; return; }
-        dup2 = (float)bestA * 1.000001f;
-    }
-    const float o0 = (float)rx, o1 = (float)ry, o2 = (float)rz;
-    const float slop = 1e-4f + 2e-6f * (float)aq;   // float(o), the float differences and products: far below a millimetre
+    const double qx = ((a.ar.M[0] * m0 + a.ar.M[1] * m1) + a.ar.M[2] * m2) + a.ar.t[0];
+    const double qy = ((a.ar.M[3] * m0 + a.ar.M[4] * m1) + a.ar.M[5] * m2) + a.ar.t[1];
+    const double qz = ((a.ar.M[6] * m0 + a.ar.M[7] * m1) + a.ar.M[8] * m2) + a.ar.t[2];
+    hd.qa[0] = qx; hd.qa[1] = qy; hd.qa[2] = qz; hd.d1 = 0; hd.dM = 0; hd.count = 0u; hd.pad = 0u;
+    const double aq = (fabs(qx) + fabs(qy)) + fabs(qz);
+    if (P == 0 || !(aq <= 1e30)) { hd.count = 0u; hd.dM = -1.0; *(AnchorHdr*)row = hd; return; }   // dM < 0: no certificate, the lanes search the tree
+    // ---- exact kNN(M): the M smallest (d^2, tree position) in registers, kept sorted by an unrolled insertion; register-path
+    //      traversal with float lower bounds of the plane distances against the current M-th distance ----
+    double bd[kSetM]; uint32_t bp[kSetM];
+#pragma unroll
+    for (int i = 0; i < kSetM; ++i) { bd[i] = INFINITY; bp[i] = kNone; }
+    const float o0 = (float)qx, o1 = (float)qy, o2 = (float)qz;
+    const float slop = 1e-4f + 2e-6f * (float)aq;   // float(o) and the float plane differences: far below a millimetre
     const uint32_t first_leaf = (1u << D) - 1u;
-    // ---- the ball: every scan point within d_0 + 2 sigma of the reference query; register-path traversal with a FIXED bound,
-    //      float arithmetic, every test inflated so that it can only add points ----
-    const float Rf = (sqrtf(dup2) * 1.000001f + slop) + 2.0f * (float)sigma * 1.000001f + slop;
-    const float R2f = Rf * Rf * 1.000001f;
-    uint32_t cnt = 0u, leaves = 0u;
-    SetPt* out = nnset + row * (size_t)kSetM;
-    const PlaneRec* planes_cost = dp.plane_cost + h.pt_base;
-    const PlaneRec* planes_local = dp.plane_local + h.pt_base;
-    // a point of the ball -> the set, with what the memoised planes say at it (plane_cache = 1; with refitted planes the fit kernels decide)
-    auto emit = [&](const float4& v, uint32_t pos, uint32_t slot) {
-        SetPt sp; sp.x = v.x; sp.y = v.y; sp.z = v.z; sp.pos = pos; sp.nx = 0; sp.ny = 0; sp.nz = 0; sp.flags = 0u; sp.pad = 0u;
-        if (prm.plane_cache) {
-            const PlaneRec rl = planes_local[pos];
-            sp.flags = (local_neigh_ok(prm, rl) && local_plane_ok(prm, rl)) ? 1u : 0u;
-            if (prm.use_plane) {
-                const PlaneRec rc = planes_cost[pos];
-                if (!(rc.far_d2 < prm.min_diff_dist2) && !(rc.k < prm.norm_min_pts) && !(rc.reg_sum / (double)(rc.k - 1) > prm.norm_reg_threshold)) { sp.flags |= 2u; sp.nx = rc.nx; sp.ny = rc.ny; sp.nz = rc.nz; }
-            }
-        }
-        out[slot] = sp;
-    };
     float pd2[kPathMax];
 #pragma unroll
     for (int L = 0; L < kPathMax; ++L) pd2[L] = INFINITY;
@@ -1217,7 +1182,6 @@ __global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, SetP
             }
             node = n1 - 1u;
         }
-        ++leaves;
         const uint32_t lj = node - first_leaf;
         const uint32_t lo = (uint32_t)(((uint64_t)lj * P) >> D), hi = (uint32_t)(((uint64_t)(lj + 1) * P) >> D);
         for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {   // eight loads in flight per step
@@ -1227,19 +1191,54 @@ __global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, SetP
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t i = i0 + (uint32_t)u;
-                const float dx = o0 - v[u].x, dy = o1 - v[u].y, dz = o2 - v[u].z;
-                if (i < hi && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= R2f) { if (cnt < (uint32_t)kSetM) emit(v[u], i, cnt); ++cnt; }
+                const double dx = qx - (double)v[u].x, dy = qy - (double)v[u].y, dz = qz - (double)v[u].z;
+                double d2 = (dx * dx + dy * dy) + dz * dz;
+                uint32_t pi = i;
+                if (i < hi && d2 < bd[kSetM - 1]) {   // insert: a strictly closer point only (ties at the M-th distance stay out; the certificate is strict)
+#pragma unroll
+                    for (int t = 0; t < kSetM; ++t) {
+                        const bool lt = d2 < bd[t] || (d2 == bd[t] && pi < bp[t]);
+                        const double td = lt ? bd[t] : d2; const uint32_t tp = lt ? bp[t] : pi;
+                        bd[t] = lt ? d2 : bd[t]; bp[t] = lt ? pi : bp[t];
+                        d2 = td; pi = tp;
+                    }
+                }
             }
         }
+        const float bound = bd[kSetM - 1] < INFINITY ? (float)bd[kSetM - 1] * 1.000001f + 1e-30f : INFINITY;
         uint32_t cnd = 0u;
 #pragma unroll
-        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= R2f ? 1u : 0u) << L;
+        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= bound ? 1u : 0u) << L;
         cnd &= ~done & ((1u << D) - 1u);
         done |= ~cnd;
         go = cnd ? 31 - __clz((int)cnd) : -1;
-    } while (go >= 0 && cnt <= (uint32_t)kSetM && leaves < (uint32_t)a.max_leaves);
-    if (go >= 0 || cnt > (uint32_t)kSetM || cnt == 0u) { nnset_cnt[row] = kSetOverflow; return; }
-    nnset_cnt[row] = cnt;
+    } while (go >= 0);
+    const PlaneRec* planes_cost = dp.plane_cost + h.pt_base;
+    const PlaneRec* planes_local = dp.plane_local + h.pt_base;
+    uint32_t cnt = 0u;
+#pragma unroll
+    for (int i = 0; i < kSetM; ++i) {
+        if (bp[i] == kNone) continue;
+        const float4 v = p4[bp[i]];
+        SetPt sp; sp.x = v.x; sp.y = v.y; sp.z = v.z; sp.pos = bp[i]; sp.nx = 0; sp.ny = 0; sp.nz = 0; sp.flags = 0u;
+        const float dl = (float)sqrt(bd[i]);
+        sp.da_lo = fmaxf(dl * 0.999999f - 1e-30f, 0.f);   // <= the exact distance
+        if (prm.plane_cache) {   // with refitted planes the fit kernels decide
+            const PlaneRec rl = planes_local[bp[i]];
+            sp.flags = (local_neigh_ok(prm, rl) && local_plane_ok(prm, rl)) ? 1u : 0u;
+            if (prm.use_plane) {
+                const PlaneRec rc = planes_cost[bp[i]];
+                if (!(rc.far_d2 < prm.min_diff_dist2) && !(rc.k < prm.norm_min_pts) && !(rc.reg_sum / (double)(rc.k - 1) > prm.norm_reg_threshold)) { sp.flags |= 2u; sp.nx = rc.nx; sp.ny = rc.ny; sp.nz = rc.nz; }
+            }
+        }
+        row[1 + i] = sp;
+        if (i == 0) hd.d1 = sqrt(bd[0]);
+        hd.dM = sqrt(bd[i]);
+        ++cnt;
+    }
+    hd.count = cnt;
+    if (cnt < (uint32_t)kSetM) hd.dM = INFINITY;   // the whole scan is listed: every radius is certified
+    *(AnchorHdr*)row = hd;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1259,16 +1258,16 @@ __global__ __launch_bounds__(kNNThreads) void iba_nnset_kernel(NNSetArgs a, SetP
 // which lane ran which search does not matter, so the sums are bitwise reproducible. One record of kNNPartial doubles per
 // (candidate, frame, slice).
 // ------------------------------------------------------------------------------------------------------------------
-// SETS 1: the batch's neighbour sets are in use (nnset != nullptr); compiled for 4 waves per SIMD — what its LDS allows anyway — so that the
+// SETS 1: the anchored neighbour lists are in use (anchor != nullptr); compiled for 4 waves per SIMD — what its LDS allows anyway — so that the
 // direct pass keeps two entries' loads in registers
 template <int WHICH, int REFIT, int SETS>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS ? 4 : IBA_NN_WAVES, SETS ? 4 : IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
                                                                                                   double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist, const float4* __restrict__ fmp,
                                                                                                   const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit,
-                                                                                                  const SetPt* __restrict__ nnset, const uint32_t* __restrict__ nnset_cnt) {
+                                                                                                  const SetPt* __restrict__ anchor) {
     extern __shared__ __align__(16) unsigned char smem[];
-    // nnset != nullptr: the batch's neighbour candidates (iba_nnset_kernel): a lane whose keypoint has a set picks its nearest
-    // points from it instead of searching the tree.
+    // SETS: the anchored neighbour lists (iba_anchor_kernel): a lane whose certificate holds picks its nearest points from its
+    // keypoint's list instead of searching the tree.
     // kRefitSearch = the searches only (neighbour and query offset of every entry -> flist.z / frefit), kRefitSums = the fixed-order
     // sums over the distances the fit kernel left in frefit
     constexpr int refit = REFIT;
@@ -1411,7 +1410,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     if (sc) { px = sc->x; py = sc->y; pz = sc->z; } else { const float4 pv = p4[bposC]; px = pv.x; py = pv.y; pz = pv.z; }
                     const double ex = (double)px - qx, ey = (double)py - qy, ez = (double)pz - qz;
                     if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
-                    else if (sc) {   // cost_res with the plane's verdict already taken (iba_nnset_kernel): the same expressions
+                    else if (sc) {   // cost_res with the plane's verdict already taken (iba_anchor_kernel): the same expressions
                         const double dist = (sc->flags & 2u) ? fabs(ex * sc->nx + ey * sc->ny + ez * sc->nz) : sqrt((ex * ex + ey * ey) + ez * ez);
                         res = (sc->flags & 2u) ? dist : -dist;
                     } else {
@@ -1425,25 +1424,34 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
             uint32_t* s_ovf = (uint32_t*)(smem + lay.off_ovf);   // work entries whose keypoint has no usable set: searched in the tree below
             uint32_t c_end = c1;                                 // entries the persistent loop hands out
             if (SETS) {
-                // ---- a batch of nearby candidates: the neighbour candidates of every MapPoint keypoint are there (iba_nnset_kernel).
+                // ---- the anchored neighbour lists of the MapPoint keypoints are there (iba_anchor_kernel).
                 //      One pass, no claiming: thread t takes the entries t, t + T, ...; per entry one dependent chain of three loads
                 //      (entry -> set -> plane records), the next entry's first load in flight meanwhile ----
                 if (tid == 0) s_ctr[1] = 0u;
                 __syncthreads();
-                // two entries per step: their loads are issued stage by stage (entries, then sets), so a thread's four entries cost
-                // four dependent round trips instead of eight
+                // two entries per step: their loads are issued stage by stage (entries, then list rows), so a thread's four entries
+                // cost four dependent round trips instead of eight
                 auto fetch = [&](uint32_t wn, uint4& e, float4& mp) {
                     e = make_uint4(0u, 0u, 0u, 0u); mp = make_float4(0.f, 0.f, 0.f, 0.f);
                     const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
                     if (wn < c1 && il < s_n[cc]) { const size_t at = entry_at(wn); e = flist[at]; mp = fmp[at]; }
                 };
-                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, uint32_t sc, const SetPt& p0, const SetPt& p1, const SetPt* sp) {
-                    if (sc == kSetOverflow || sc == 0u) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; return; }
+                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, const AnchorHdr& hd, const SetPt& p0, const SetPt& p1, const SetPt* sp) {
                     make_queries(wn & ((1u << cg_shift) - 1u), e, mp);
+                    // the certificate: this candidate's queries are S from the anchor's; its nearest points lie within d_1 + 2 S of the
+                    // anchor query, and the list is complete out to d_M (exclusive)
+                    double S2 = 0.0;
+                    if ((WHICH & 1) && actA) { const double dx = ax - hd.qa[0], dy = ay - hd.qa[1], dz = az - hd.qa[2]; S2 = (dx * dx + dy * dy) + dz * dz; }
+                    if ((WHICH & 2) && actC) { const double dx = qx - hd.qa[0], dy = qy - hd.qa[1], dz = qz - hd.qa[2]; S2 = fmax(S2, (dx * dx + dy * dy) + dz * dz); }
+                    const double radius = (hd.d1 + 2.0 * sqrt(S2)) * (1.0 + 1e-12) + 1e-12;
+                    if (!(radius < hd.dM) || hd.count == 0u) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; return; }   // (NaN queries fail here too)
                     bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
                     SetPt abest = p0, cbest = p0;
-                    for (uint32_t si = 0; si < sc; ++si) {
-                        const SetPt pv = si == 0u ? p0 : (si == 1u ? p1 : sp[si]);
+                    const float rf = (float)radius * 1.000001f + 1e-30f;   // >= radius
+                    for (uint32_t si = 0; si < hd.count; ++si) {
+                        if (si >= 2u && !(sp[1 + si].da_lo <= rf)) break;   // the list is sorted by distance to the anchor query: nothing further qualifies
+                        const SetPt pv = si == 0u ? p0 : (si == 1u ? p1 : sp[1 + si]);
+                        if (!(pv.da_lo <= rf)) break;
                         const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
                         if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; const uint32_t was = bposA; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposA != was) abest = pv; }
                         if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; const uint32_t was = bposC; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposC != was) cbest = pv; }
@@ -1454,14 +1462,15 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     uint4 e0, e1; float4 mq0, mq1;
                     fetch(wn, e0, mq0); fetch(wn + (uint32_t)T, e1, mq1);
                     const bool w0 = (e0.w & kWantMask) != 0u, w1 = (e1.w & kWantMask) != 0u;
-                    const size_t r0 = (size_t)f * dp.max_k + (w0 ? e0.x : 0u), r1 = (size_t)f * dp.max_k + (w1 ? e1.x : 0u);
-                    const SetPt* sp0 = nnset + r0 * (size_t)kSetM; const SetPt* sp1 = nnset + r1 * (size_t)kSetM;
-                    uint32_t sc0 = 0u, sc1 = 0u; SetPt a0, a1, b0, b1;
+                    const SetPt* sp0 = anchor + ((size_t)f * dp.max_k + (w0 ? e0.x : 0u)) * kAnchorRow;
+                    const SetPt* sp1 = anchor + ((size_t)f * dp.max_k + (w1 ? e1.x : 0u)) * kAnchorRow;
+                    AnchorHdr h0, h1; SetPt a0, a1, b0, b1;
+                    h0.count = h1.count = 0u; h0.dM = h1.dM = -1.0; h0.d1 = h1.d1 = 0.0;
                     a0.flags = a1.flags = b0.flags = b1.flags = 0u;
-                    if (w0) { sc0 = nnset_cnt[r0]; a0 = sp0[0]; a1 = sp0[1]; }   // nearly every set holds one or two points: fetched with the count
-                    if (w1) { sc1 = nnset_cnt[r1]; b0 = sp1[0]; b1 = sp1[1]; }
-                    if (w0) pick(wn, e0, mq0, sc0, a0, a1, sp0);
-                    if (w1) pick(wn + (uint32_t)T, e1, mq1, sc1, b0, b1, sp1);
+                    if (w0) { h0 = *(const AnchorHdr*)sp0; a0 = sp0[1]; a1 = sp0[2]; }   // one or two entries qualify nearly always: fetched with the header
+                    if (w1) { h1 = *(const AnchorHdr*)sp1; b0 = sp1[1]; b1 = sp1[2]; }
+                    if (w0) pick(wn, e0, mq0, h0, a0, a1, sp0);
+                    if (w1) pick(wn + (uint32_t)T, e1, mq1, h1, b0, b1, sp1);
                 }
                 __syncthreads();
                 c_end = s_ctr[1];

@@ -10,15 +10,18 @@ pytestmark = pytest.mark.gpu
 
 
 def _handle(pkg, prob, p, mode):
-    old = os.environ.get("IBA_COMMON_PAIRS")
+    """mode 0: every candidate searches for itself — 2d-3d pairs AND the 3-D nearest neighbours (no anchored lists)"""
+    old = {k: os.environ.get(k) for k in ("IBA_COMMON_PAIRS", "IBA_NN_SETS")}
     os.environ["IBA_COMMON_PAIRS"] = str(mode)
+    os.environ["IBA_NN_SETS"] = "0" if mode == 0 else "1"
     try:
         return pkg.IbaHandle(prob, p)
     finally:
-        if old is None:
-            del os.environ["IBA_COMMON_PAIRS"]
-        else:
-            os.environ["IBA_COMMON_PAIRS"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 def _same_bits(pkg, h0, h1, xs, want_path):
@@ -120,3 +123,45 @@ def test_points_at_the_camera_plane_and_tiny_lists(pkg, synth, abi, ob):
     _same_bits(pkg, h0, h3, xs, 1)
     h3.close()
     h0.close()
+
+
+def test_anchored_neighbour_lists_follow_the_candidates(pkg, synth, abi, scene_small):
+    """The 1-NN search is memoised around an anchor extrinsic (iba_anchor_kernel): lanes certify their pick from the anchor's
+    neighbour lists or search the tree. Near the anchor, far from it (certificates fail), after the anchor has moved, with one
+    candidate or many, after a parameter change: always the bits of the handle that searches the tree for every lane."""
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    h0, h1 = _handle(pkg, prob, p, 0), _handle(pkg, prob, p, 1)
+    rng = np.random.default_rng(3)
+    x1 = meta["x_gt"]
+    x2 = x1 + np.array([0.004, -0.003, 0.002, 0.05, -0.04, 0.03, 0.3])   # ~30 cm of query motion: outside every list's reach
+
+    def same(xs):
+        c0, n0 = h0.eval_full(xs)
+        c1, n1 = h1.eval_full(xs)
+        for a, b in zip(c0, c1):
+            assert a.as_dict() == b.as_dict()
+        for a, b in zip(n0, n1):
+            assert np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.cost == b.cost and a.counts() == b.counts()
+
+    assert h1.anchor_builds == 0
+    same(x1[None, :])                                            # one candidate (BALoss::eval_x): the anchor is built here
+    assert h1.anchor_builds == 1 and h0.anchor_builds == 0
+    same(synth.perturb(x1, rng, n=9))                            # near the anchor: certified picks
+    same(synth.perturb(x1, rng, rot=3e-3, trans=3e-2, scale_rel=6e-3, n=9))   # a spread of ~20 cm: some certify, some search
+    assert h1.anchor_builds == 1
+    same(synth.perturb(x2, rng, n=5))                            # far away: no certificate holds (and no rebuild yet: hysteresis)
+    assert h1.anchor_builds == 1
+    for _ in range(4):
+        same(synth.perturb(x2, rng, n=5))
+    assert h1.anchor_builds == 2                                 # the anchor has followed the candidates
+    same(synth.perturb(x2, rng, n=40))
+    q = abi.reference_yaml_params()
+    q.norm_reg_threshold *= 0.5                                  # the lists carry the planes' verdicts: a parameter change rebuilds them
+    q.local_norm_reg_threshold *= 2.0
+    h0.set_params(q)
+    h1.set_params(q)
+    same(synth.perturb(x2, rng, n=6))
+    assert h1.anchor_builds == 3
+    h0.close()
+    h1.close()
