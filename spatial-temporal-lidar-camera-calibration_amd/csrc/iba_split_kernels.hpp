@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 // ------------------------------------------------------------------------------------------------------------------
 struct CommonRef { double R[9], t[3], rho[9], tau[3]; };
 struct PairRec { float x, y, z; uint32_t idx; float u, v; uint32_t k, pad; };   // scan point (+ original index), keypoint (+ id): 32 B, streamed
-constexpr int kPairsThreads = 1024;
+constexpr int kPairsThreads = 512;    // measured at the bench shape: 1024 threads 50 us, 512 threads 39 us, 256 threads 58 us per batch
 constexpr int kCountStride = 32;   // u32 per frame (one 128-byte line: the frames' counters do not share a line): pairs, hard points, overflow flag
 constexpr int kPairStage = 2048;   // (point, keypoint) hits a block parks in LDS before ONE global reservation writes them out
 
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
     const double fx = h.fx, cx = h.cx, cy = h.cy, W = h.W, H = h.H;
     const uint32_t pos = begin + threadIdx.x;
     // ---- the block's culling chunks (static AABBs of kChunk consecutive tree positions) against every candidate's frustum: a
-    //      block of 1024 consecutive tree positions is a compact piece of the scene, and most pieces are seen by no candidate.
+    //      block of kPairsThreads consecutive tree positions is a compact piece of the scene, and most pieces are seen by no candidate.
     //      For a point p of a box with centre c and half extent e: q_b(p)_i lies within m_i = (|R_0| e)_i + delta_i of q_0(c)_i,
     //      delta from the batch bound at |q_0(c)| + |R_0| e. The piece is invisible when it is behind the camera (z + m_z <= 0) or
     //      wholly beyond one image border: u >= W <=> fx x + (cx - W) z >= 0 (z > 0), u < 0 <=> fx x + cx z < 0, v alike. ----
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pos < P) pv = p4[pos];
     // the frame's keypoint grid is fetched into registers now and parked in LDS only if some point of the block needs it: a block
-    // of 1024 consecutive tree positions is a compact piece of the scene, and most pieces lie outside every candidate's image
+    // of consecutive tree positions is a compact piece of the scene, and most pieces lie outside every candidate's image
     const uint32_t* gcs = dp.coarse_start + h.coarse_base;
     const uint32_t ncs = h.gwc * h.ghc + 1u;
     uint32_t cs_r[2]; float2 uv_r[2];
