@@ -810,7 +810,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
     if (h->nn_sets && h->max_mpk > 0 && (er = h->d_anchor.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kAnchorRow)) != hipSuccess) return bail("alloc anchored neighbour lists", er);
     if (h->common_mode > 0) {   // common lists of one batch: (scan point, keypoint) pairs and hard points per frame
-        h->pair_cap = (int)std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, 4u * h->maxK));
+        // the pairs of a batch grow with the scan density (points per pixel) and with the batch's spread: 4 per keypoint serve 10 k-point
+        // scans, a full KITTI scan (120 k points) needs ~8 (r03: 14 k pairs per keyframe at the bench spread). A full list only costs speed.
+        h->pair_cap = (int)std::min<uint32_t>(65536u, std::max<uint32_t>(std::max<uint32_t>(2048u, 4u * h->maxK), h->maxP / 4u));
         h->hard_cap = 1024;
         if (const char* e = std::getenv("IBA_DEBUG_PAIR_CAP")) { h->pair_cap = std::max(1, std::atoi(e)); h->hard_cap = std::max(1, std::atoi(e) / 8); }   // tests: force the overflow path
         if ((er = h->d_pairs.alloc((size_t)std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
