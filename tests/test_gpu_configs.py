@@ -108,14 +108,51 @@ def test_c3_three_trajectories_four_shards(pkg, synth, abi, c2):
         assert abs(a.f1 - b.f1) <= 1e-12 * b.f1 and abs(a.f2 - b.f2) <= 1e-12 * b.f2
 
 
+def test_c4_full_size_eight_shards(pkg, synth, abi, c2):
+    """C4 whole: 2000 keyframes x 10 k points (20 M points) on ONE device, then as the 8 frame ranges of an 8-GPU node: the
+    partial blocks of the ranges add up to the unsharded block — counters bit for bit, sums to 1e-13 — and, the scene being ten
+    copies of C2's trajectory, every counter is ten times C2's (a checksum of checksums). Four candidates: the batch shares its
+    pair search, the neighbour lists are anchored."""
+    prob, meta = synth.tile_scene(*c2, 10)
+    assert prob.n_frames == 2000 and prob.n_points == 20_000_000
+    p = abi.reference_yaml_params()
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(12), n=4)
+    whole = pkg.IbaHandle(prob, p)
+    full = _partials(pkg, whole, xs, "full")
+    assert whole.last_path == 1
+    whole.close()
+    acc = np.zeros_like(full)
+    for r in range(8):
+        a, b = pkg.shard_frames(prob.n_frames, 8, r, np.diff(prob.arrays["pt_offset"].astype(np.int64)))
+        hs = pkg.IbaHandle(prob, p, frame_begin=a, frame_end=b)
+        acc += _partials(pkg, hs, xs, "full")
+        hs.close()
+    cw, cs = pkg.finalize_cost(p, full), pkg.finalize_cost(p, acc)
+    nw, ns = pkg.finalize_normal(p, full), pkg.finalize_normal(p, acc)
+    for a, b in zip(cw, cs):
+        _cmp_cost(b, a, rel=1e-13)
+    for a, b in zip(nw, ns):
+        assert a.counts() == b.counts()
+        assert np.allclose(a.H_np(), b.H_np(), rtol=1e-13, atol=1e-13 * np.abs(a.H_np()).max())
+        assert np.allclose(a.b_np(), b.b_np(), rtol=1e-13, atol=1e-13 * np.abs(a.b_np()).max())
+        assert abs(a.cost - b.cost) <= 1e-13 * abs(a.cost)
+    one = pkg.IbaHandle(c2[0], p)
+    c1 = one.eval_cost(xs)
+    one.close()
+    for a, b in zip(cw, c1):
+        assert a.n_corr == 10 * b.n_corr and a.cnt_3d_3d == 10 * b.cnt_3d_3d and a.cnt_3d_2d == 10 * b.cnt_3d_2d and a.frames_used == 10 * b.frames_used
+        assert abs(a.f1 - b.f1) <= 1e-12 * b.f1 and abs(a.f2 - b.f2) <= 1e-12 * b.f2
+
+
 def test_kitti_sized_scans(pkg, synth, abi, ob):
     """Raw KITTI scans are ~120 k points (~60 k with PointCloudOnlyPositiveX): deeper kd-trees (D = 12), candidate queues and
     work lists several times longer than at the bench shape. Cost tuple and normal equations vs the oracle."""
     prob, meta = synth.make_scene(n_frames=3, pts_per_frame=60000, seed=8)   # depth-capped tree: 30 points per leaf
     p = abi.reference_yaml_params()
     h = pkg.IbaHandle(prob, p)
-    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(8), n=2)])
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(8), n=4)])   # five candidates: the batch shares its pair search
     cost, nrm = h.eval_full(xs)
+    assert h.last_path == 1
     orc = ob.Oracle(prob)
     oc, on = orc.eval_cost(p, xs), orc.eval_normal(p, xs)
     for a, b in zip(cost, oc):
