@@ -129,6 +129,7 @@ struct iba_handle {
     std::vector<FrameHdr> h_frames;
     std::vector<uint64_t> h_kp_off;       // local frame -> kp offset (K+1)
     std::vector<uint32_t> h_kp_ext;       // internal (Morton) keypoint id -> reference keypoint id
+    std::vector<float> h_kp_uv;           // (u, v) of every keypoint in internal order: the reject bitmap is rebuilt from it when max_pixel_dist changes
 
     DevProblem dev_problem() const {
         DevProblem dp{};
@@ -457,16 +458,17 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
             double best = INFINITY;
             for (int b = 0; b < B; ++b) {
                 double dd = 0;
-                for (int i = 0; i < 9; ++i) dd = std::max(dd, 30.0 * std::fabs(hc[b].s * hc[b].Ri[i] - mean[i] / B));
+                for (int i = 0; i < 9; ++i) dd = std::max(dd, 3.0 * std::fabs(hc[b].s * hc[b].Ri[i] - mean[i] / B));
                 for (int i = 0; i < 3; ++i) dd = std::max(dd, std::fabs(hc[b].ti[i] - mean[9 + i] / B));
                 if (dd < best) { best = dd; ref = b; }
             }
         }
-        auto drift = [&](const Cand& c) {   // how far a nominal MapPoint's query moves between the anchor and c (row-sum bound)
+        auto drift = [&](const Cand& c) {   // how far the query of a MapPoint 30 m out moves between the anchor and c (row-sum bound; |m| = 30 m / scale)
+            const double nominal = 30.0 / std::max(std::fabs(c.s), 1e-12);
             double worst = 0;
             for (int r = 0; r < 3; ++r) {
                 double v = std::fabs(c.ti[r] - h->anchor_ref.t[r]);
-                for (int q = 0; q < 3; ++q) v += 30.0 * std::fabs(c.s * c.Ri[r * 3 + q] - h->anchor_ref.M[r * 3 + q]);
+                for (int q = 0; q < 3; ++q) v += nominal * std::fabs(c.s * c.Ri[r * 3 + q] - h->anchor_ref.M[r * 3 + q]) / std::sqrt(3.0);
                 worst = std::max(worst, v);
             }
             return worst;
@@ -624,7 +626,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         const uint64_t P = d->pt_offset[f + 1] - d->pt_offset[f], K = d->kp_offset[f + 1] - d->kp_offset[f];
         if (P >= (1ull << 22) || K >= 65535ull) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan (>= 2^22 points) or keypoint count (>= 65535) too large"); }
         const uint64_t ns = d->covis_offset[f + 1] - d->covis_offset[f];
-        if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 22 covisible keyframes per frame"); }
+        if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 30 covisible keyframes per frame"); }
         h->max_slots = std::max<uint32_t>(h->max_slots, (uint32_t)ns);
     }
 
@@ -703,6 +705,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     std::vector<uint32_t> coarse_start(coarse_base), bitmap(bm_base);
     std::vector<float2> match_uv(match_base, float2{qnan, qnan});
     std::vector<SlotHdr> slots(slot_base);
+    std::vector<uint32_t> kp_fl(kp_base, 0u);   // flag word of every keypoint (see the match loop)
     std::atomic<bool> bad_match(false);
     parallel_for(nf, [&](int lf) {
         const int f = frame_begin + lf; const FrameHdr& x = hdr[lf]; const FrameBuild& b = fb[lf];
@@ -748,14 +751,13 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
                 const int kr = d->match_kp_ref[m], kc = d->match_kp_covis[m];
                 if (kr < 0 || (uint32_t)kr >= x.K || kc < 0 || (uint64_t)kc >= cK) { bad_match = true; continue; }
                 match_uv[x.match_base + (uint64_t)sl * x.K + b.kp_inv[kr]] = float2{d->kp_uv[2 * (ck0 + kc)], d->kp_uv[2 * (ck0 + kc) + 1]};
-                // w = 1 (owns a MapPoint) | 2 (matched in >= 1 covisible KF) | per-slot match bits << 2  (<= 12 bits: exact in float)
-                kp_mp[x.kp_base + b.kp_inv[kr]].w = (float)(((int)kp_mp[x.kp_base + b.kp_inv[kr]].w) | 2 | (4 << sl));
+                // flag word = 1 (owns a MapPoint) | 2 (matched in >= 1 covisible KF) | per-slot match bits << 2 (up to 30 slots)
+                kp_fl[x.kp_base + b.kp_inv[kr]] |= 2u | (4u << sl);
             }
         }
     });
-    std::vector<uint32_t> kp_fl(kp_base);
     bool crec_ok = true;
-    for (size_t k = 0; k < (size_t)kp_base; ++k) kp_fl[k] = (uint32_t)(int)kp_mp[k].w;
+    for (size_t k = 0; k < (size_t)kp_base; ++k) { if (kp_mp[k].w != 0.f) kp_fl[k] |= 1u; kp_mp[k].w = (float)(kp_fl[k] & 3u); }
     std::vector<uint32_t> mpk;   // per frame: the keypoints that own a MapPoint (the only ones a 1-NN search is ever run for)
     for (int lf = 0; lf < nf; ++lf) {
         hdr[lf].mpk_base = mpk.size();
@@ -766,7 +768,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     for (int lf = 0; lf < nf; ++lf) {
         uint32_t cnt = 0;
         for (uint32_t k = 0; k < hdr[lf].K; ++k) { uint32_t idb; std::memcpy(&idb, &crec[hdr[lf].kp_base + k].z, 4); crec_ok = crec_ok && idb == k; }
-        for (uint32_t k = 0; k < hdr[lf].K; ++k) cnt += kp_mp[hdr[lf].kp_base + k].w != 0.f ? 1u : 0u;
+        for (uint32_t k = 0; k < hdr[lf].K; ++k) cnt += kp_fl[hdr[lf].kp_base + k] != 0u ? 1u : 0u;
         h->maxKw = std::max(h->maxKw, cnt);
     }
     fb.clear(); fb.shrink_to_fit();
@@ -794,6 +796,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
 #define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
     UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes); UP(chunk_box, chunk_box); UP(pts4, pts4);
+    h->h_kp_uv.resize(2 * (size_t)kp_base);
+    for (size_t k = 0; k < (size_t)kp_base; ++k) { h->h_kp_uv[2 * k] = kp_uv[k].x; h->h_kp_uv[2 * k + 1] = kp_uv[k].y; }
     UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(kp_fl, kp_fl); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv); UP(mpk, mpk);
 #undef UP
     hipError_t er;
@@ -861,8 +865,24 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
 iba_status iba_set_params(iba_handle* h, const iba_params* p) {
     if (!h || !p) return IBA_ERR_INVALID_ARG;
     iba_status s = check_params(h, *p); if (s != IBA_OK) return s;
-    if (p->max_pixel_dist != h->params.max_pixel_dist) return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist is baked into the keypoint grid: recreate the handle");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (p->max_pixel_dist != h->params.max_pixel_dist && h->bitmap.n) {
+        // the 1-bit reject bitmap of the per-candidate association is the keypoints dilated by max_pixel_dist (+ the float slack):
+        // rebuilt here from the host copy of the keypoints. The coarse CSR and the grid dimensions do not depend on it.
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::vector<uint32_t> bm(h->bitmap.n, 0u);
+        std::atomic<bool> bad(false);
+        const double margin = p->max_pixel_dist + 0.45;
+        parallel_for(h->n_frames, [&](int lf) {
+            const FrameHdr& x = h->h_frames[lf];
+            KpGrid g;
+            build_kp_grid(h->h_kp_uv.data() + 2 * x.kp_base, x.K, x.W, x.H, margin, g);
+            if (g.gw != x.gw || g.gh != x.gh || x.bitmap_base + g.bitmap.size() > bm.size()) { bad = true; return; }
+            std::copy(g.bitmap.begin(), g.bitmap.end(), bm.begin() + x.bitmap_base);
+        });
+        if (bad) return fail(h, IBA_ERR_STATE, "internal: keypoint grid changed shape");
+        HIP_TRY(h, hipMemcpy(h->bitmap.p, bm.data(), sizeof(uint32_t) * bm.size(), hipMemcpyHostToDevice));
+    }
     h->params = *p; to_dev_params(*p, h->dprm); h->frozen_valid = false;
     h->anchor_valid = false;   // the lists carry the planes' verdicts under the old parameters
     return compute_plane_cache(h);

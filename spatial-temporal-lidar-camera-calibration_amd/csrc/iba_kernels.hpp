@@ -35,7 +35,7 @@ struct DevProblem {
     const float* chunk_box;    // [chunk][8]: min xyz, -, max xyz, - of kChunk consecutive tree positions (NaN padding ignored)
     const TreeNode* nodes;
     const float2* kp_uv;
-    const float4* kp_mp;       // MapPoint world position (x,y,z); w = 1*(owns a MapPoint) + 2*(matched in >= 1 covisible KF)
+    const float4* kp_mp;       // MapPoint world position (x,y,z); w = 1*(owns a MapPoint) + 2*(matched in >= 1 covisible KF) (the full flag word is kp_fl)
     const uint32_t* kp_fl;     // the same flag word (w) as an integer, for kernels that keep it in LDS
     const uint32_t* coarse_start; const float4* crec; const uint32_t* bitmap;   // keypoint grid (see iba_build.hpp)
     const float2* match_uv;    // [slot][K] matched covisible keypoint, NaN = no match
@@ -657,9 +657,9 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
     }
     const double P0x = Cxz * Z0, P0y = Cyz * Z0, P0z = Z0;
     int nconv = 0;
-    // only the covisible slots whose match bit is set in the keypoint flags (kp_mp.w >> 2), in slot order; the next
+    // only the covisible slots whose match bit is set in the keypoint flags (kp_fl >> 2), in slot order; the next
     // match is in flight during the arithmetic of the current one
-    uint32_t mask = ((uint32_t)(int)dp.kp_mp[h.kp_base + k].w >> 2) & ((1u << kMaxCovis) - 1u);
+    uint32_t mask = (dp.kp_fl[h.kp_base + k] >> 2) & ((1u << kMaxCovis) - 1u);
     const float2* mrow = dp.match_uv + h.match_base + k;
     float2 mnext = mask ? mrow[(size_t)(__ffs((int)mask) - 1) * K] : make_float2(0.f, 0.f);
     while (mask) {

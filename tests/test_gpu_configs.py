@@ -24,7 +24,7 @@ def _cmp_cost(g, o, rel=1e-10):
         assert getattr(g, k) == getattr(o, k), (k, getattr(g, k), getattr(o, k))
     for k in ("f1", "f2"):
         assert abs(getattr(g, k) - getattr(o, k)) <= rel * max(abs(getattr(o, k)), 1e-300), k
-    assert abs(g.C - o.C) <= 1e-12 + 1e-9 * abs(o.C)
+    assert abs(g.C - o.C) <= 1e-10 * abs(o.C) + 1e-15
 
 
 def test_c1_point_to_pixel_only(pkg, synth, abi, ob):

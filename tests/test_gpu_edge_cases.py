@@ -13,7 +13,7 @@ def _cmp(g, o):
     for k in ("f1", "f2"):
         a, b = getattr(g, k), getattr(o, k)
         assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-10 * abs(b), (k, a, b)
-    assert (np.isnan(g.C) and np.isnan(o.C)) or abs(g.C - o.C) <= 1e-12 + 1e-9 * abs(o.C)
+    assert (np.isnan(g.C) and np.isnan(o.C)) or abs(g.C - o.C) <= 1e-10 * abs(o.C) + 1e-15
 
 
 def _cmpn(g, o):

@@ -45,7 +45,7 @@ def cmp_cost(g, o, rel=1e-10):
         assert getattr(g, k) == getattr(o, k), (k, getattr(g, k), getattr(o, k))
     for k in ("f1", "f2"):
         assert abs(getattr(g, k) - getattr(o, k)) <= rel * max(abs(getattr(o, k)), 1e-300), k
-    assert (np.isnan(g.C) and np.isnan(o.C)) or abs(g.C - o.C) <= 1e-12 + 1e-9 * abs(o.C)   # device acos / tan vs glibc
+    assert (np.isnan(g.C) and np.isnan(o.C)) or abs(g.C - o.C) <= 1e-10 * abs(o.C) + 1e-15   # device acos / tan vs glibc: measured 5e-12 over 1500 random scenes (tools/soak_parity.py, r03)
 
 
 def cmp_normal(g, o):
@@ -66,7 +66,7 @@ def test_golden_fixture_replayed_on_the_gpu(pkg, abi):
         assert [getattr(cost[b], k) for k in INT] == list(z["cost_i"][b])
         for j, k in enumerate(("f1", "f2")):
             assert abs(getattr(cost[b], k) - z["cost_f"][b, j]) <= 1e-10 * abs(z["cost_f"][b, j])
-        assert (np.isnan(cost[b].C) and np.isnan(z["cost_f"][b, 2])) or abs(cost[b].C - z["cost_f"][b, 2]) <= 1e-12 + 1e-9 * abs(z["cost_f"][b, 2])
+        assert (np.isnan(cost[b].C) and np.isnan(z["cost_f"][b, 2])) or abs(cost[b].C - z["cost_f"][b, 2]) <= 1e-10 * abs(z["cost_f"][b, 2]) + 1e-15
         c = nrm[b].counts()
         assert [c[k] for k in ("n_factor_3d2d", "n_factor_p2pl", "n_factor_p2pt", "n_residuals", "frames_used", "n_corr")] == list(z["normal_i"][b])
         per_entry(nrm[b].H_np(), z["normal_H"][b])

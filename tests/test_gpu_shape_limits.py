@@ -84,3 +84,41 @@ def test_more_than_sixty_four_candidates_per_call(pkg, synth, abi, scene_small):
     for a, b in zip(nrm, nr):
         assert np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.counts() == b.counts()
     h.close()
+
+
+def test_twenty_eight_covisible_keyframes(pkg, synth, abi, ob):
+    """GetCovisiblesByWeightSafe (iba_global.cpp:259) is unbounded; the flag word holds one match bit per covisible keyframe:
+    30 of them since round 3 (22 before)."""
+    prob, meta = synth.make_scene(n_frames=32, pts_per_frame=2500, n_keypoints=700, seed=43, n_covis=28, new_mappoints=120, scan_kp=160)
+    assert int(np.diff(prob.arrays["covis_offset"].astype(np.int64)).max()) == 28
+    p = abi.reference_yaml_params()
+    h, o = pkg.IbaHandle(prob, p), ob.Oracle(prob)
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(43), n=4)])
+    cost, nrm = _check(h, o, p, xs)
+    assert cost[0].cnt_3d_2d > 3 * cost[0].n_corr
+    h.close()
+
+
+def test_max_pixel_dist_changes_on_a_live_handle(pkg, synth, abi, ob):
+    """max_pixel_dist used to be baked into the handle (the reject bitmap of the association is the keypoints dilated by it);
+    iba_set_params now rebuilds the bitmap. Both association kernels, against the oracle, for a tighter and a wider gate."""
+    prob, meta = synth.make_scene(n_frames=6, pts_per_frame=5000, n_keypoints=1200, seed=44)
+    p = abi.reference_yaml_params()
+    h, o = pkg.IbaHandle(prob, p), ob.Oracle(prob)
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(44), n=5)])
+    base, _ = _check(h, o, p, xs)
+    seen = {base[0].n_corr}
+    for mpd in (0.7, 3.5, 1.5):
+        q = abi.reference_yaml_params()
+        q.max_pixel_dist = mpd
+        h.set_params(q)
+        for sel in (xs, xs[:2]):     # six candidates share their pair search, two search per candidate
+            cost, _ = _check(h, o, q, sel)
+        seen.add(cost[0].n_corr)
+        for f in (0, 5):
+            gk, gp = h.correspondences(xs[1], f)
+            ok, op = o.correspondences(q, xs[1], f)
+            assert np.array_equal(gk, ok) and np.array_equal(gp, op)
+    assert len(seen) == 3          # the gate did change the correspondence sets
+    assert cost[0].n_corr == base[0].n_corr
+    h.close()

@@ -1,5 +1,5 @@
 """Randomised parity soak (GPU box): many seeded scenes of random shape and random candidates, GPU path vs the CPU oracle.
-Counters must be equal, cost floats within 1e-9; H (normal equations) within 1e-6 of its largest entry — the fixed scenes of
+Counters must be equal, cost floats (f1, f2, C) within 1e-10; H (normal equations) within 1e-6 of its largest entry — the fixed scenes of
 tests/ hold 1e-9, but over thousands of random scenes a near-degenerate plane block (viewing ray almost in the plane: Z0 =
 num / den with a tiny den) amplifies the last-bit differences between the kernel's chain rule and the oracle's dual numbers;
 the worst case seen is printed (7e-8 in 7000 scenes at the reference's parameters, identical with and without FMA contraction;
@@ -70,7 +70,7 @@ for sc in range(n_scenes):
                 if getattr(g, k) != getattr(oc[b], k): msgs.append((b, k, getattr(g, k), getattr(oc[b], k)))
             for k in ("f1", "f2", "C"):
                 a, r = getattr(g, k), getattr(oc[b], k)
-                if not ((np.isnan(a) and np.isnan(r)) or a == r or abs(a - r) <= 1e-9 * abs(r) + 1e-12): msgs.append((b, k, a, r))
+                if not ((np.isnan(a) and np.isnan(r)) or a == r or abs(a - r) <= 1e-10 * abs(r) + 1e-15): msgs.append((b, k, a, r))
                 if k == "C" and np.isfinite(a) and np.isfinite(r) and r != 0: worst_c = max(worst_c, abs(a - r) / abs(r))
         if nfm[b].counts() != on[b].counts(): msgs.append((b, "normal counts", nfm[b].counts(), on[b].counts()))
         Ho = on[b].H_np()
@@ -94,7 +94,6 @@ for sc in range(n_scenes):
     if not (np.array_equal(gk, ok_) and np.array_equal(gp, op_)): msgs.append(("corr", fsel, len(gk), len(ok_)))
     # new parameters on the live handle (plane memo rebuilt / dropped as needed), same candidates
     p2 = random_params(rng)
-    p2.max_pixel_dist = p.max_pixel_dist   # baked into the keypoint grid: iba_set_params refuses to change it (checked by the tests)
     h.set_params(p2)
     cf2, nf2 = h.eval_full(xs); oc2 = o.eval_cost(p2, xs); on2 = o.eval_normal(p2, xs)
     for b in range(len(xs)):
@@ -102,7 +101,7 @@ for sc in range(n_scenes):
             if getattr(cf2[b], k) != getattr(oc2[b], k): msgs.append((b, "after set_params", k, getattr(cf2[b], k), getattr(oc2[b], k)))
         for k in ("f1", "f2", "C"):
             a, r = getattr(cf2[b], k), getattr(oc2[b], k)
-            if not ((np.isnan(a) and np.isnan(r)) or a == r or abs(a - r) <= 1e-9 * abs(r) + 1e-12): msgs.append((b, "after set_params", k, a, r))
+            if not ((np.isnan(a) and np.isnan(r)) or a == r or abs(a - r) <= 1e-10 * abs(r) + 1e-15): msgs.append((b, "after set_params", k, a, r))
         if nf2[b].counts() != on2[b].counts(): msgs.append((b, "after set_params normal counts"))
     h.close()
     tag = "ok " if not msgs else "BAD"
