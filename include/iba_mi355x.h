@@ -235,7 +235,8 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
  * Multi-GPU building blocks (frames shard across ranks; one sum all-reduce per evaluation).
  * iba_eval_*_partial writes this rank's partial sums for B candidates into DEVICE memory
  * `d_partials` (B * iba_partial_stride() doubles, counters carried as doubles) on HIP stream
- * `stream` (a hipStream_t passed as void*; NULL = the handle's own stream) without synchronising.
+ * `stream` (a hipStream_t passed as void*; NULL = the handle's own NON-BLOCKING stream, NOT the legacy default stream: a caller whose
+ * other work — the all-reduce, copies — sits on the default stream must pass a stream of its own) without synchronising.
  * After the caller has summed the partial blocks over ranks (ncclAllReduce, sum, f64),
  * iba_finalize_* turns HOST copies of the summed blocks into the outputs above.
  */

@@ -95,6 +95,7 @@ struct iba_handle {
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
+    const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
     int last_path = 0;                    // 1: the last evaluation chain used the common pairs
 
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
@@ -123,6 +124,8 @@ struct iba_handle {
     int nrec = 0;                         // partial records per candidate = n_frames + nfb
     Cand* h_cands = nullptr;              // pinned, kRing * IBA_MAX_BATCH
     double* h_partials = nullptr;         // pinned
+    double* h_partials_dev = nullptr;     // the same buffer as the kernels see it: the last kernel of a chain writes the sums there (no D2H copy)
+    Cand* h_cands_dev = nullptr;          // the pinned candidate ring as the fetch kernel sees it
     hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
     bool ring_used[kRing] = {false, false, false, false};
     int ring_next = 0;
@@ -343,19 +346,45 @@ iba_status ensure_scratch(iba_handle* h) {
 }
 
 // stages B candidates into a pinned ring slot and enqueues the H2D copy; returns the device pointer. The block is computed
-// from x here, or copied from `pre` when the caller (iba_group) has already computed it for all its devices.
-iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr) {
+// from x here, or copied from `pre` when the caller (iba_group) has already computed it for all its devices. jets = 0: the
+// values only (cost evaluations never read the derivatives); jets = 2: the values now, the derivatives later (finish_jets:
+// the host differentiates the exponentials while the GPU runs the association and search kernels on the values).
+iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1) {
     const int slot = h->ring_next; h->ring_next = (h->ring_next + 1) % kRing;
     if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
     Cand* hc = h->h_cands + (size_t)slot * IBA_MAX_BATCH;
-    if (pre) std::memcpy(hc, pre, sizeof(Cand) * (size_t)B);
-    else for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
     Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
     h->last_hc = hc;
-    HIP_TRY(h, hipMemcpyAsync(dc, hc, sizeof(Cand) * B, hipMemcpyHostToDevice, st));
+    h->jets_x = nullptr;
+    if (pre) { std::memcpy(hc, pre, sizeof(Cand) * (size_t)B); jets = 1; }
+    else if (jets == 1) for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
+    else for (int b = 0; b < B; ++b) make_cand_values(x + 7 * b, hc[b]);
+    // the block crosses PCIe by a kernel that reads the pinned ring (a copy-engine transfer of these 70 KB costs ~15 us of latency
+    // at the head of every evaluation; a strided copy of the value halves alone was slower still)
+    {
+        const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)B / 16);
+        hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)(h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH), (uint4*)dc, n16);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (jets == 2) { h->jets_x = x; h->jets_B = B; h->jets_slot = slot; }
     HIP_TRY(h, hipEventRecord(h->ring_ev[slot], st));
     h->ring_used[slot] = true;
     *d_out = dc;
+    return IBA_OK;
+}
+// the derivative half of the staged candidates: computed and uploaded now (before the factor kernel is enqueued)
+iba_status finish_jets(iba_handle* h, hipStream_t st) {
+    if (!h->jets_x) return IBA_OK;
+    Cand* hc = h->h_cands + (size_t)h->jets_slot * IBA_MAX_BATCH;
+    Cand* dc = h->d_cands.p + (size_t)h->jets_slot * IBA_MAX_BATCH;
+    for (int b = 0; b < h->jets_B; ++b) make_cand_jets(h->jets_x + 7 * b, hc[b]);
+    {   // the whole block again, now complete: stream-ordered behind the kernels that read the values
+        const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)h->jets_B / 16);
+        hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)(h->h_cands_dev + (size_t)h->jets_slot * IBA_MAX_BATCH), (uint4*)dc, n16);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipEventRecord(h->ring_ev[h->jets_slot], st));   // the slot is busy until this copy has been read
+    h->jets_x = nullptr;
     return IBA_OK;
 }
 
@@ -529,7 +558,10 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         }
     }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    if (factors) { iba_status s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, nf, st); if (s != IBA_OK) return s; }
+    if (factors) {
+        iba_status s = finish_jets(h, st); if (s != IBA_OK) return s;   // the GPU has been busy with the values since stage_cands
+        s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, nf, st); if (s != IBA_OK) return s;
+    }
     hipLaunchKernelGGL(iba_reduce2_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, search ? h->d_nn_partials.p : (const double*)nullptr, nn_nrec, d_partials);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
@@ -547,7 +579,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
     if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0); if (s != IBA_OK) return s;   // the cost tuple never reads the derivatives
     return run_split(h, dc, B, 2, false, false, d_partials, st);
 }
 
@@ -829,6 +861,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
     if ((er = hipHostMalloc((void**)&h->h_cands, sizeof(Cand) * kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("hipHostMalloc", er);
     if ((er = hipHostMalloc((void**)&h->h_partials, sizeof(double) * IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("hipHostMalloc", er);
+    if ((er = hipHostGetDevicePointer((void**)&h->h_partials_dev, h->h_partials, 0)) != hipSuccess || (er = hipHostGetDevicePointer((void**)&h->h_cands_dev, h->h_cands, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", er);
     if ((er = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
@@ -939,8 +972,7 @@ iba_status iba_eval_cost_partial(iba_handle* h, const double* x, int32_t B, void
 iba_status iba_eval_cost(iba_handle* h, const double* x, int32_t B, iba_cost_out* out) {
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(B, [&](int b0, int Bc) {
-        iba_status s = eval_cost_partial_impl(h, x + 7 * b0, Bc, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * Bc * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+        iba_status s = eval_cost_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;   // the sums land in pinned host memory: no copy behind the last kernel
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_cost(&h->params, h->h_partials, Bc, out + b0);
@@ -1061,7 +1093,7 @@ static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 1, false, true, d_partials, st);
 }
 
@@ -1073,8 +1105,7 @@ iba_status iba_eval_normal_partial(iba_handle* h, const double* x, int32_t B, vo
 iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(B, [&](int b0, int Bc) {
-        iba_status s = eval_normal_partial_impl(h, x + 7 * b0, Bc, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * Bc * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+        iba_status s = eval_normal_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_normal(&h->params, h->h_partials, Bc, out + b0);
@@ -1088,7 +1119,7 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 3, false, true, d_partials, st);
 }
 
@@ -1100,8 +1131,7 @@ iba_status iba_eval_full_partial(iba_handle* h, const double* x, int32_t B, void
 iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal) {
     if (!h || !cost || !normal || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(B, [&](int b0, int Bc) {
-        iba_status s = eval_full_partial_impl(h, x + 7 * b0, Bc, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * Bc * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+        iba_status s = eval_full_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         s = iba_finalize_cost(&h->params, h->h_partials, Bc, cost + b0); if (s != IBA_OK) return s;
         return iba_finalize_normal(&h->params, h->h_partials, Bc, normal + b0);
@@ -1113,8 +1143,7 @@ static iba_status build_problem_impl(iba_handle* h, const double* x, const Cand*
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc, pre); if (s != IBA_OK) return s;
-    s = run_split(h, dc, 1, 1, true, false, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-    HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+    s = run_split(h, dc, 1, 1, true, false, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->frozen_frames = (int32_t)h->h_partials[P_FRAMES_N]; h->frozen_ncorr = (int32_t)h->h_partials[P_NCORR_N]; h->frozen_valid = true;
     return IBA_OK;
@@ -1147,8 +1176,7 @@ iba_status iba_eval_factors_partial(iba_handle* h, const double* x, int32_t B, v
 iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(B, [&](int b0, int Bc) {
-        iba_status s = eval_factors_partial_impl(h, x + 7 * b0, Bc, h->d_partials.p, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, hipMemcpyAsync(h->h_partials, h->d_partials.p, sizeof(double) * Bc * kPartialStride, hipMemcpyDeviceToHost, h->stream));
+        iba_status s = eval_factors_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_normal(&h->params, h->h_partials, Bc, out + b0);
@@ -1383,7 +1411,7 @@ iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double*
 
 // ---- library-internal interface of iba_group (iba_internal.hpp) ----
 namespace iba {
-void make_cands_host(const double* x, int B, Cand* out) { for (int b = 0; b < B; ++b) make_cand(x + 7 * b, out[b]); }
+void make_cands_host(const double* x, int B, Cand* out, bool jets) { for (int b = 0; b < B; ++b) { make_cand_values(x + 7 * b, out[b]); if (jets) make_cand_jets(x + 7 * b, out[b]); } }
 iba_status eval_partial_cands(iba_handle* h, const Cand* hc, int B, EvalKind kind, double* d_partials, hipStream_t st) {
     if (!h || !hc || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     if (!st) st = h->stream;

@@ -187,7 +187,7 @@ void shard(const iba_problem_desc* d, int n, std::vector<int32_t>& b, std::vecto
 // g->h_part. Per device, on its own thread: pinned copy of the candidate block, kernels, ONE collective, stream drained.
 iba_status eval_chunk(iba_group* g, const double* x, int Bc, EvalKind kind) {
     const auto t0 = std::chrono::steady_clock::now();
-    make_cands_host(x, Bc, g->cands.data());
+    make_cands_host(x, Bc, g->cands.data(), kind != kEvalCost);
     const size_t bytes = sizeof(double) * (size_t)Bc * g->stride;
     iba_status s = run_all(g, [g, Bc, kind, bytes](int i) -> iba_status {
         W_IBA(g, i, eval_partial_cands(g->h[i], g->cands.data(), Bc, kind, g->d_part[i], g->st[i]));

@@ -12,7 +12,7 @@ namespace iba {
 enum EvalKind { kEvalCost = 0, kEvalNormal = 1, kEvalFull = 2, kEvalFactors = 3 };
 
 // Cand block of B candidates x (7 doubles each): g2o_tools.h:105-140, 149-183 on the host
-void make_cands_host(const double* x, int B, Cand* out);
+void make_cands_host(const double* x, int B, Cand* out, bool jets = true);   // jets = false: the values only (cost evaluations)
 // launch chain of one chunk (B <= IBA_MAX_BATCH) on `st` from a ready candidate block (host memory, copied into the handle's
 // pinned ring before the call returns); no synchronisation
 iba_status eval_partial_cands(iba_handle* h, const Cand* host_cands, int B, EvalKind kind, double* d_partials, hipStream_t st);

@@ -1132,6 +1132,12 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce_kernel(const double
     }
 }
 
+// copies n16 16-byte words (pinned host memory -> device): the candidate block of an evaluation
+__global__ void iba_fetch_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 // writes two host-known values into their slots of B partial blocks (frozen-problem counts)
 __global__ void iba_set_slots_kernel(double* __restrict__ partials, int B, int slot_a, double va, int slot_b, double vb) {
     const int b = threadIdx.x;

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 PKG = "spatial-temporal-lidar-camera-calibration_amd"
 
+# torch first: its wheel bundles its own ROCm libraries (libamdhip64, librccl, librocm_smi64). Loaded first, they are the one HIP
+# runtime of the process and the library's own dependency resolves to them (same SONAME); loaded second, behind /opt/rocm's copies,
+# the process runs torch on a runtime it was not built for — a torch stream handed to the C-ABI then aborts inside libamdhip64
+# (seen in round 3). bench.py imports torch first for the same reason; INTEGRATION.md says so for integrators.
+try:
+    import torch  # noqa: F401
+except Exception:   # the CPU tier runs without it too
+    torch = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

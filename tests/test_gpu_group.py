@@ -55,10 +55,16 @@ def test_partial_block_summed_by_torch_rccl(pkg, synth, abi, scene_small):
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         h = pkg.IbaHandle(prob, p)
-        d = torch.zeros(len(xs) * pkg.partial_stride(), dtype=torch.float64, device="cuda:0")
-        h.eval_full_partial(xs, d.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        dist.all_reduce(d)
-        part = d.cpu().numpy()
+        # an explicit stream: torch's default stream has the handle 0, which the C-ABI reads as "the handle's own stream".
+        # (kept alive until the handle is closed: the handle's ring events have been recorded on it)
+        ts = torch.cuda.Stream()
+        with torch.cuda.stream(ts):
+            d = torch.zeros(len(xs) * pkg.partial_stride(), dtype=torch.float64, device="cuda:0")
+            st = torch.cuda.current_stream().cuda_stream
+            assert st != 0
+            h.eval_full_partial(xs, d.data_ptr(), st)
+            dist.all_reduce(d)
+            part = d.cpu().numpy()
         cost, nrm = pkg.finalize_cost(p, part), pkg.finalize_normal(p, part)
         c1, n1 = h.eval_full(xs)
         for a, b in zip(c1, cost):
@@ -88,12 +94,15 @@ def test_comm_allreduce_entry_point(pkg, synth, abi, scene_small):
     assert L.iba_comm_count(comm[0]) == 1
     h = pkg.IbaHandle(prob, p)
     stride = pkg.partial_stride()
-    d = torch.full((len(xs) * stride,), float("nan"), dtype=torch.float64, device="cuda:0")
-    st = torch.cuda.current_stream().cuda_stream
-    h.eval_full_partial(xs, d.data_ptr(), st)
-    assert L.iba_comm_allreduce(comm[0], C.c_void_p(d.data_ptr()), C.c_int32(len(xs)), C.c_void_p(st)) == 0
-    torch.cuda.synchronize()
-    part = d.cpu().numpy()
+    ts = torch.cuda.Stream()   # an explicit stream (torch's default stream is the handle 0 = "the handle's own stream" to the C-ABI)
+    with torch.cuda.stream(ts):
+        d = torch.full((len(xs) * stride,), float("nan"), dtype=torch.float64, device="cuda:0")
+        st = ts.cuda_stream
+        assert st != 0
+        h.eval_full_partial(xs, d.data_ptr(), st)
+        assert L.iba_comm_allreduce(comm[0], C.c_void_p(d.data_ptr()), C.c_int32(len(xs)), C.c_void_p(st)) == 0
+        ts.synchronize()
+        part = d.cpu().numpy()
     cost, nrm = pkg.finalize_cost(p, part), pkg.finalize_normal(p, part)
     c1, n1 = h.eval_full(xs)
     for a, b in zip(c1, cost):

@@ -6,10 +6,10 @@
 static void on_abort(int sig) {
     void* bt[64];
     int n = backtrace(bt, 64);
-    const char msg[] = "\n==== abort_bt: C stack at SIGABRT ====\n";
+    const char msg[] = "\n==== abort_bt: C stack at the fatal signal ====\n";
     (void)!write(2, msg, sizeof(msg) - 1);
     backtrace_symbols_fd(bt, n, 2);
     signal(sig, SIG_DFL);
     raise(sig);
 }
-__attribute__((constructor)) static void install(void) { signal(SIGABRT, on_abort); }
+__attribute__((constructor)) static void install(void) { signal(SIGABRT, on_abort); signal(SIGSEGV, on_abort); signal(SIGBUS, on_abort); }
