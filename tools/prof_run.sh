@@ -4,7 +4,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-T=${1:-r02}
+T=${1:-r03}
 mkdir -p gpurun_out/$T
 BENCH="python3 bench.py --steps 15 --warmup 2 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/stats -o stats -- $BENCH > gpurun_out/$T/bench_under_rocprof.json 2> gpurun_out/$T/rocprof_stats.log

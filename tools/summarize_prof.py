@@ -35,7 +35,7 @@ for r in rows:
     avg_us[short(r["Name"])] = float(r["AverageNs"]) / 1e3
     lines.append("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
 fetch, write, insts, cyc, mfma = counters("fetch"), counters("write"), counters("insts"), counters("cycles"), counters("mfma")
-kernels = [k for k in avg_us if k.startswith(("iba_assoc_kernel", "iba_nn_kernel", "iba_factor", "iba_reduce2", "iba_he_kernel", "iba_frame_kernel"))]
+kernels = [k for k in avg_us if k.startswith(("iba_assoc", "iba_pairs", "iba_nn_kernel", "iba_anchor", "iba_factor", "iba_reduce2", "iba_he_kernel", "iba_fetch"))]
 lines += ["", "## counters per launch (separate --pmc passes on the same command; KiB -> bytes, FETCH_SIZE x2 on gfx950)", "",
           "| kernel | HBM read MB (x2) | HBM write MB | SQ_INSTS_VALU | SQ_INSTS_SALU | SQ_INSTS_LDS | SQ_INSTS_VMEM | VALU-active share of SIMD cycles | SQ_WAIT_ANY / SQ_WAVE_CYCLES | MFMA F64 insts |", "|---|---|---|---|---|---|---|---|---|---|"]
 tot_hbm = 0.0; act = 0.0; gui = 0.0
@@ -46,7 +46,7 @@ for k in kernels:
     wait = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else float("nan")
     lines.append("| %s | %.2f | %.2f | %.3g | %.3g | %.3g | %.3g | %.2f | %.2f | %.3g |" % (k, f / 1e6, w / 1e6, i.get("SQ_INSTS_VALU", 0), i.get("SQ_INSTS_SALU", 0), i.get("SQ_INSTS_LDS", 0),
                                                                                         i.get("SQ_INSTS_VMEM", 0), share, wait, m.get("SQ_INSTS_VALU_MFMA_F64", 0)))
-    if k.startswith(("iba_assoc_kernel", "iba_nn_kernel")):
+    if k.startswith(("iba_assoc", "iba_pairs", "iba_nn_kernel")):
         tot_hbm += f + w; act += 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0); gui += c.get("GRBM_GUI_ACTIVE", 0.0) / 8
 bench_line = None
 try:
@@ -63,11 +63,11 @@ dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "spatial-temp
 cfg = (bench_line or {}).get("config", {})
 pmc = {"round": tag, "git_head": head + ("+uncommitted kernel changes" if dirty else ""), "source_stamp": hsh.hexdigest()[:16], "taken_on": time.strftime("%Y-%m-%d"),
        "frames": cfg.get("frames_this_rank"), "pts": cfg.get("points_per_frame"), "batch": cfg.get("candidates_per_step"),
-       "kernels": "iba_assoc_kernel + iba_nn_kernel", "hbm_bytes_per_launch": tot_hbm, "valu_issue_frac": act / (N_SIMD * gui) if gui else None,
+       "kernels": "iba_pairs_kernel + iba_assoc2_kernel + iba_nn_kernel", "hbm_bytes_per_launch": tot_hbm, "valu_issue_frac": act / (N_SIMD * gui) if gui else None,
        "counters": "FETCH_SIZE x2 + WRITE_SIZE (KiB); 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
        "note": "one rocprofv3 --pmc pass per counter list on `python3 bench.py --steps 15 --warmup 2 --no-cpu-baseline --no-extras`; mean per launch"}
 json.dump(pmc, open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
-lines += ["", "assoc + search kernels per launch: HBM %.1f MB, VALU-active share of the SIMD cycles %.2f  (source stamp %s, head %s)" % (tot_hbm / 1e6, pmc["valu_issue_frac"] or float("nan"), pmc["source_stamp"], pmc["git_head"])]
+lines += ["", "association (pairs + assoc2) + search kernels per launch: HBM %.1f MB, VALU-active share of the SIMD cycles %.2f  (source stamp %s, head %s)" % (tot_hbm / 1e6, pmc["valu_issue_frac"] or float("nan"), pmc["source_stamp"], pmc["git_head"])]
 if bench_line:
     lines += ["", "bench line under rocprofv3 (kernel trace): value %.0f evals/s, ms_per_step %.3f, roofline %s" % (bench_line["value"], bench_line["ms_per_step"], json.dumps({k: bench_line["roofline"][k] for k in ("achieved", "frac", "launch_ms", "kernel_ms")}))]
 open(os.path.join(out_dir, "%s_rocprof_summary.md" % tag), "w").write("\n".join(lines) + "\n")
