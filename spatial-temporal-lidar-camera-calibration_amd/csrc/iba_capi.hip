@@ -83,7 +83,7 @@ struct iba_handle {
     DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
     DevBuf<uint32_t> mpk;                 // per frame: keypoints that own a MapPoint
     uint32_t max_mpk = 0;
-    DevBuf<SetPt> d_anchor;               // anchored neighbour lists: n_frames x maxK rows of kAnchorRow 48-byte pieces
+    DevBuf<SetPt> d_anchor;               // anchored neighbour lists: n_frames x maxK rows of kAnchorRowBytes (512) bytes
     bool anchor_valid = false; AnchorRef anchor_ref{}; int calls_since_anchor = 0;
     double anchor_reach = 0.06;           // IBA_ANCHOR_REACH (m): a batch whose reference candidate moves a nominal MapPoint further than this from the anchor's query gets a new anchor
     int anchor_builds = 0;
@@ -844,7 +844,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
     if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
     if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
-    if (h->nn_sets && h->max_mpk > 0 && (er = h->d_anchor.alloc((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kAnchorRow)) != hipSuccess) return bail("alloc anchored neighbour lists", er);
+    if (h->nn_sets && h->max_mpk > 0 && (er = h->d_anchor.alloc(((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kAnchorRowBytes + sizeof(SetPt) - 1) / sizeof(SetPt) + 1)) != hipSuccess) return bail("alloc anchored neighbour lists", er);
     if (h->common_mode > 0) {   // common lists of one batch: (scan point, keypoint) pairs and hard points per frame
         // the pairs of a batch grow with the scan density (points per pixel) and with the batch's spread: 4 per keypoint serve 10 k-point
         // scans, a full KITTI scan (120 k points) needs ~8 (r03: 14 k pairs per keyframe at the bench spread). A full list only costs speed.

@@ -1109,9 +1109,16 @@ constexpr int kSetM = 8;              // neighbours a list holds
 // memoised planes at it say: flags bit 0 = the local plane is valid (pointcloud.h:699-717), bit 1 = the cost term is
 // point-to-plane (iba_global.cpp:136-148) with normal n
 struct SetPt { float x, y, z; uint32_t pos; double nx, ny, nz; uint32_t flags; float da_lo; };   // 48 B
-struct AnchorHdr { double qa[3]; double d1, dM; uint32_t count, pad; };                         // 48 B: anchor query, nearest / farthest listed distance
+struct AnchorHdr { double qa[3]; double d1, dM; uint32_t count; float da1_lo; };                // 48 B: anchor query, nearest / farthest listed distance, count, lower bound of the second neighbour's distance
 static_assert(sizeof(SetPt) == 48 && sizeof(AnchorHdr) == 48, "anchor rows are read as 16-byte pieces");
-constexpr size_t kAnchorRow = 1 + kSetM;   // 48-byte pieces per (frame, keypoint) row: header, then the entries
+// A (frame, keypoint) row is 512 bytes, 128-byte aligned: header and nearest neighbour share the FIRST 128-byte line (96 bytes:
+// what nearly every lane needs, and all a lane fetches up front); the neighbours 1..7 follow from byte 128. (As nine
+// consecutive 48-byte pieces a lane's header + two neighbours straddled 2.6 lines on average, and the lines, not the bytes, are
+// what the L2 moves.)
+constexpr size_t kAnchorRowBytes = 512;
+__host__ __device__ inline const unsigned char* anchor_row(const void* base, size_t row) { return (const unsigned char*)base + row * kAnchorRowBytes; }
+__device__ __forceinline__ const AnchorHdr* anchor_hdr(const unsigned char* r) { return (const AnchorHdr*)r; }
+__device__ __forceinline__ const SetPt* anchor_pt(const unsigned char* r, uint32_t i) { return (const SetPt*)(r + (i == 0u ? 48u : 128u + (i - 1u) * 48u)); }
 struct AnchorRef { double M[9], t[3]; };   // s_a Ri_a, ti_a of the anchor extrinsic: q_a = M m + t
 struct AnchorArgs { DevProblem dp; DevParams prm; AnchorRef ar; };
 // grid: (ceil(max MapPoint keypoints of a frame / kNNThreads), frames); one lane per MapPoint keypoint; dynamic LDS: the tree nodes
@@ -1129,7 +1136,7 @@ __global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, Se
     const uint32_t j = blockIdx.x * (uint32_t)kNNThreads + threadIdx.x;
     if (j >= h.n_mpk) return;
     const uint32_t k = dp.mpk[h.mpk_base + j];
-    SetPt* row = rows + ((size_t)f * dp.max_k + k) * kAnchorRow;
+    unsigned char* row = (unsigned char*)anchor_row(rows, (size_t)f * dp.max_k + k);
     AnchorHdr hd;
     const float4* p4 = dp.pts4 + h.pt_base;
     const float4 mp = dp.kp_mp[h.kp_base + k];
@@ -1140,7 +1147,7 @@ __global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, Se
     const double qx = ((a.ar.M[0] * m0 + a.ar.M[1] * m1) + a.ar.M[2] * m2) + a.ar.t[0];
     const double qy = ((a.ar.M[3] * m0 + a.ar.M[4] * m1) + a.ar.M[5] * m2) + a.ar.t[1];
     const double qz = ((a.ar.M[6] * m0 + a.ar.M[7] * m1) + a.ar.M[8] * m2) + a.ar.t[2];
-    hd.qa[0] = qx; hd.qa[1] = qy; hd.qa[2] = qz; hd.d1 = 0; hd.dM = 0; hd.count = 0u; hd.pad = 0u;
+    hd.qa[0] = qx; hd.qa[1] = qy; hd.qa[2] = qz; hd.d1 = 0; hd.dM = 0; hd.count = 0u; hd.da1_lo = INFINITY;
     const double aq = (fabs(qx) + fabs(qy)) + fabs(qz);
     if (P == 0 || !(aq <= 1e30)) { hd.count = 0u; hd.dM = -1.0; *(AnchorHdr*)row = hd; return; }   // dM < 0: no certificate, the lanes search the tree
     // ---- exact kNN(M): the M smallest (d^2, tree position) in registers, kept sorted by an unrolled insertion; register-path
@@ -1231,8 +1238,9 @@ __global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, Se
                 if (!(rc.far_d2 < prm.min_diff_dist2) && !(rc.k < prm.norm_min_pts) && !(rc.reg_sum / (double)(rc.k - 1) > prm.norm_reg_threshold)) { sp.flags |= 2u; sp.nx = rc.nx; sp.ny = rc.ny; sp.nz = rc.nz; }
             }
         }
-        row[1 + i] = sp;
+        *(SetPt*)anchor_pt(row, (uint32_t)i) = sp;
         if (i == 0) hd.d1 = sqrt(bd[0]);
+        if (i == 1) hd.da1_lo = sp.da_lo;
         hd.dM = sqrt(bd[i]);
         ++cnt;
     }
@@ -1436,7 +1444,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
                     if (wn < c1 && il < s_n[cc]) { const size_t at = entry_at(wn); e = flist[at]; mp = fmp[at]; }
                 };
-                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, const AnchorHdr& hd, const SetPt& p0, const SetPt& p1, const SetPt* sp) {
+                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, const AnchorHdr& hd, const SetPt& p0, const unsigned char* row) {
                     make_queries(wn & ((1u << cg_shift) - 1u), e, mp);
                     // the certificate: this candidate's queries are S from the anchor's; its nearest points lie within d_1 + 2 S of the
                     // anchor query, and the list is complete out to d_M (exclusive)
@@ -1449,9 +1457,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     SetPt abest = p0, cbest = p0;
                     const float rf = (float)radius * 1.000001f + 1e-30f;   // >= radius
                     for (uint32_t si = 0; si < hd.count; ++si) {
-                        if (si >= 2u && !(sp[1 + si].da_lo <= rf)) break;   // the list is sorted by distance to the anchor query: nothing further qualifies
-                        const SetPt pv = si == 0u ? p0 : (si == 1u ? p1 : sp[1 + si]);
-                        if (!(pv.da_lo <= rf)) break;
+                        if (si == 1u && !(hd.da1_lo <= rf)) break;   // the second neighbour cannot qualify: its line is not even fetched (the usual case)
+                        const SetPt pv = si == 0u ? p0 : *anchor_pt(row, si);
+                        if (!(pv.da_lo <= rf)) break;            // the list is sorted by distance to the anchor query: nothing further qualifies
                         const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
                         if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; const uint32_t was = bposA; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposA != was) abest = pv; }
                         if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; const uint32_t was = bposC; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposC != was) cbest = pv; }
@@ -1462,15 +1470,15 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     uint4 e0, e1; float4 mq0, mq1;
                     fetch(wn, e0, mq0); fetch(wn + (uint32_t)T, e1, mq1);
                     const bool w0 = (e0.w & kWantMask) != 0u, w1 = (e1.w & kWantMask) != 0u;
-                    const SetPt* sp0 = anchor + ((size_t)f * dp.max_k + (w0 ? e0.x : 0u)) * kAnchorRow;
-                    const SetPt* sp1 = anchor + ((size_t)f * dp.max_k + (w1 ? e1.x : 0u)) * kAnchorRow;
-                    AnchorHdr h0, h1; SetPt a0, a1, b0, b1;
-                    h0.count = h1.count = 0u; h0.dM = h1.dM = -1.0; h0.d1 = h1.d1 = 0.0;
-                    a0.flags = a1.flags = b0.flags = b1.flags = 0u;
-                    if (w0) { h0 = *(const AnchorHdr*)sp0; a0 = sp0[1]; a1 = sp0[2]; }   // one or two entries qualify nearly always: fetched with the header
-                    if (w1) { h1 = *(const AnchorHdr*)sp1; b0 = sp1[1]; b1 = sp1[2]; }
-                    if (w0) pick(wn, e0, mq0, h0, a0, a1, sp0);
-                    if (w1) pick(wn + (uint32_t)T, e1, mq1, h1, b0, b1, sp1);
+                    const unsigned char* r0 = anchor_row(anchor, (size_t)f * dp.max_k + (w0 ? e0.x : 0u));
+                    const unsigned char* r1 = anchor_row(anchor, (size_t)f * dp.max_k + (w1 ? e1.x : 0u));
+                    AnchorHdr h0, h1; SetPt a0, b0;
+                    h0.count = h1.count = 0u; h0.dM = h1.dM = -1.0; h0.d1 = h1.d1 = 0.0; h0.da1_lo = h1.da1_lo = INFINITY;
+                    a0.flags = b0.flags = 0u;
+                    if (w0) { h0 = *anchor_hdr(r0); a0 = *anchor_pt(r0, 0u); }   // header + nearest neighbour: ONE 128-byte line, all that most lanes need
+                    if (w1) { h1 = *anchor_hdr(r1); b0 = *anchor_pt(r1, 0u); }
+                    if (w0) pick(wn, e0, mq0, h0, a0, r0);
+                    if (w1) pick(wn + (uint32_t)T, e1, mq1, h1, b0, r1);
                 }
                 __syncthreads();
                 c_end = s_ctr[1];
