@@ -320,6 +320,25 @@ def main():
             a, n, r = phases()
             sweep[str(b)] = {"wall_ms": wall * 1e3, "assoc_ms": a, "nn_ms": n, "factor_sums_ms": r, "evals_per_s": units * b / wall}
         extras["batch_sweep"] = sweep
+        # (1b) the same sweep for the entry points the reference's callers use alone: the cost tuple (BALoss::eval_x / NOMAD's poll
+        # block: iba_eval_cost) and the frozen problem's normal equations (one LM step of iba_local: iba_eval_factors)
+        h.build_problem(xs_all[0][0])
+        sweep2 = {}
+        for b in (1, 8, 14, 64):
+            xb = xs_all[1][:b]
+            row = {}
+            for name, fn in (("cost", h.eval_cost), ("frozen_factors", h.eval_factors)):
+                for _ in range(3):
+                    fn(xb)
+                ts = []
+                for _ in range(50):
+                    t0 = time.perf_counter()
+                    fn(xb)
+                    ts.append(time.perf_counter() - t0)
+                row[name + "_wall_ms"] = float(np.median(ts)) * 1e3
+                row[name + "_evals_per_s"] = units * b / float(np.median(ts))
+            sweep2[str(b)] = row
+        extras["batch_sweep_cost_and_factors"] = sweep2
         # (2) a batch as wide as the reference's search box (iba_calib_global.yml:39-40: +-0.1 rad, +-0.3 m, +-1 on the scale)
         xw = meta["x_gt"][None, :] + np.random.default_rng(7).uniform(-1, 1, (B, 7)) * np.array([0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0])
         for _ in range(2):

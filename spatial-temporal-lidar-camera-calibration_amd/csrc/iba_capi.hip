@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -90,6 +91,7 @@ struct iba_handle {
     unsigned pairs_epoch = 0;             // which of the two counter sets the next call uses
     int pair_cap = 0, hard_cap = 0, pairs_slices = 1;   // pairs_slices: scan points per thread of iba_pairs_kernel (IBA_PAIRS_SLICES)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
+    bool spin_wait = true;                // IBA_SPIN_WAIT=0: blocking waits only
     bool nn_sets = true;                  // IBA_NN_SETS=0: no anchored neighbour lists, every lane searches the tree (diagnostic)
     int common_min_batch = 4;             // IBA_COMMON_MIN_BATCH
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
@@ -386,6 +388,22 @@ iba_status finish_jets(iba_handle* h, hipStream_t st) {
     HIP_TRY(h, hipEventRecord(h->ring_ev[h->jets_slot], st));   // the slot is busy until this copy has been read
     h->jets_x = nullptr;
     return IBA_OK;
+}
+
+// End of an evaluation: the host polls the stream (hipStreamQuery) for up to 2 ms before it falls back to the blocking
+// wait — an evaluation takes 0.1 .. 0.6 ms and the blocking wait's wake-up costs 10-20 us of it (IBA_SPIN_WAIT=0: always block).
+hipError_t wait_stream(iba_handle* h, hipStream_t st) {
+    if (h->spin_wait) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int polls = 0;
+        for (;;) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            if ((++polls & 15) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    return hipStreamSynchronize(st);
 }
 
 iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
@@ -814,6 +832,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
     if (const char* e = std::getenv("IBA_COMMON_PAIRS")) h->common_mode = std::atoi(e);
     if (const char* e = std::getenv("IBA_NN_SETS")) h->nn_sets = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IBA_SPIN_WAIT")) h->spin_wait = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_ANCHOR_REACH")) h->anchor_reach = std::atof(e);
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
@@ -973,7 +992,7 @@ iba_status iba_eval_cost(iba_handle* h, const double* x, int32_t B, iba_cost_out
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(B, [&](int b0, int Bc) {
         iba_status s = eval_cost_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;   // the sums land in pinned host memory: no copy behind the last kernel
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, wait_stream(h, h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_cost(&h->params, h->h_partials, Bc, out + b0);
     });
@@ -1106,7 +1125,7 @@ iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(B, [&](int b0, int Bc) {
         iba_status s = eval_normal_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, wait_stream(h, h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_normal(&h->params, h->h_partials, Bc, out + b0);
     });
@@ -1132,7 +1151,7 @@ iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out
     if (!h || !cost || !normal || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(B, [&](int b0, int Bc) {
         iba_status s = eval_full_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, wait_stream(h, h->stream));
         s = iba_finalize_cost(&h->params, h->h_partials, Bc, cost + b0); if (s != IBA_OK) return s;
         return iba_finalize_normal(&h->params, h->h_partials, Bc, normal + b0);
     });
@@ -1177,7 +1196,7 @@ iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_norma
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(B, [&](int b0, int Bc) {
         iba_status s = eval_factors_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, wait_stream(h, h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_normal(&h->params, h->h_partials, Bc, out + b0);
     });
