@@ -337,6 +337,7 @@ const char* iba_group_last_error(const iba_group* g); /* g may be NULL for creat
 int32_t iba_group_size(const iba_group* g);
 int32_t iba_group_comm_ranks(const iba_group* g);     /* ncclCommCount of the group's communicator; 0 with IBA_GROUP_REDUCE_HOST */
 double iba_group_last_issue_us(const iba_group* g);   /* host wall time of the last chunk: candidate block, hand-over to the device threads, wait */
+double iba_group_last_enqueue_us(const iba_group* g); /* of which: until the last device's launch chain + collective were enqueued (host issue time) */
 iba_status iba_group_frame_range(const iba_group* g, int32_t rank, int32_t* frame_begin, int32_t* frame_end);
 iba_status iba_group_set_params(iba_group* g, const iba_params* params);
 iba_status iba_group_eval_cost(iba_group* g, const double* x, int32_t B, iba_cost_out* out);

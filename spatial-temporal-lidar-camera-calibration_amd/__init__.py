@@ -318,6 +318,13 @@ class IbaGroup:
     def last_issue_us(self):
         return float(self.lib.iba_group_last_issue_us(self.g))
 
+    @property
+    def last_enqueue_us(self):
+        """host time until the last device's launch chain and collective of the last call were enqueued"""
+        self.lib.iba_group_last_enqueue_us.restype = C.c_double
+        self.lib.iba_group_last_enqueue_us.argtypes = [C.c_void_p]
+        return float(self.lib.iba_group_last_enqueue_us(self.g))
+
     def set_params(self, params):
         self.params = copy_params(params)
         self._chk(self.lib.iba_group_set_params(self.g, C.byref(self.params)))

@@ -98,6 +98,7 @@ struct iba_handle {
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
+    const Cand* jets_src = nullptr; const std::atomic<int>* jets_flag = nullptr;   // ... or is being computed by the group's calling thread: the block to copy once *jets_flag is set
     int last_path = 0;                    // 1: the last evaluation chain used the common pairs
 
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
@@ -351,14 +352,18 @@ iba_status ensure_scratch(iba_handle* h) {
 // from x here, or copied from `pre` when the caller (iba_group) has already computed it for all its devices. jets = 0: the
 // values only (cost evaluations never read the derivatives); jets = 2: the values now, the derivatives later (finish_jets:
 // the host differentiates the exponentials while the GPU runs the association and search kernels on the values).
-iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1) {
+iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1, const std::atomic<int>* pre_flag = nullptr) {
     const int slot = h->ring_next; h->ring_next = (h->ring_next + 1) % kRing;
     if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
     Cand* hc = h->h_cands + (size_t)slot * IBA_MAX_BATCH;
     Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
     h->last_hc = hc;
-    h->jets_x = nullptr;
-    if (pre) { std::memcpy(hc, pre, sizeof(Cand) * (size_t)B); jets = 1; }
+    h->jets_x = nullptr; h->jets_src = nullptr; h->jets_flag = nullptr;
+    if (pre) {   // the group's block: complete, or (pre_flag) with the derivative half still being computed by the calling thread
+        std::memcpy(hc, pre, sizeof(Cand) * (size_t)B);
+        if (pre_flag && jets == 2) { h->jets_src = pre; h->jets_flag = pre_flag; h->jets_B = B; h->jets_slot = slot; }
+        jets = 1;
+    }
     else if (jets == 1) for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
     else for (int b = 0; b < B; ++b) make_cand_values(x + 7 * b, hc[b]);
     // the block crosses PCIe by a kernel that reads the pinned ring (a copy-engine transfer of these 70 KB costs ~15 us of latency
@@ -376,9 +381,14 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
 }
 // the derivative half of the staged candidates: computed and uploaded now (before the factor kernel is enqueued)
 iba_status finish_jets(iba_handle* h, hipStream_t st) {
-    if (!h->jets_x) return IBA_OK;
+    if (!h->jets_x && !h->jets_src) return IBA_OK;
     Cand* hc = h->h_cands + (size_t)h->jets_slot * IBA_MAX_BATCH;
     Cand* dc = h->d_cands.p + (size_t)h->jets_slot * IBA_MAX_BATCH;
+    if (h->jets_src) {   // the group's calling thread has been differentiating while this device's kernels ran on the values
+        while (h->jets_flag->load(std::memory_order_acquire) == 0) { /* microseconds */ }
+        std::memcpy(hc, h->jets_src, sizeof(Cand) * (size_t)h->jets_B);
+        h->jets_src = nullptr; h->jets_flag = nullptr;
+    } else
     for (int b = 0; b < h->jets_B; ++b) make_cand_jets(h->jets_x + 7 * b, hc[b]);
     {   // the whole block again, now complete: stream-ordered behind the kernels that read the values
         const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)h->jets_B / 16);
@@ -1107,12 +1117,12 @@ iba_status iba_finalize_normal(const iba_params* p, const double* part, int32_t 
     return IBA_OK;
 }
 
-static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr) {
+static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr, const std::atomic<int>* pre_flag = nullptr) {
     if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 1, false, true, d_partials, st);
 }
 
@@ -1133,12 +1143,12 @@ iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal
 
 // BAError tuple AND re-associated normal equations of the same candidates from ONE pass over the scans:
 // the two paths share projection + 2d-3d association (iba_global.cpp:55-96 = iba_local.cpp:17-58).
-static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr) {
+static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr, const std::atomic<int>* pre_flag = nullptr) {
     if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 3, false, true, d_partials, st);
 }
 
@@ -1430,14 +1440,15 @@ iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double*
 
 // ---- library-internal interface of iba_group (iba_internal.hpp) ----
 namespace iba {
+void make_cands_jets_host(const double* x, int B, Cand* out) { for (int b = 0; b < B; ++b) make_cand_jets(x + 7 * b, out[b]); }
 void make_cands_host(const double* x, int B, Cand* out, bool jets) { for (int b = 0; b < B; ++b) { make_cand_values(x + 7 * b, out[b]); if (jets) make_cand_jets(x + 7 * b, out[b]); } }
-iba_status eval_partial_cands(iba_handle* h, const Cand* hc, int B, EvalKind kind, double* d_partials, hipStream_t st) {
+iba_status eval_partial_cands(iba_handle* h, const Cand* hc, int B, EvalKind kind, double* d_partials, hipStream_t st, const std::atomic<int>* jets_ready) {
     if (!h || !hc || !d_partials) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     if (!st) st = h->stream;
     switch (kind) {
         case kEvalCost: return eval_cost_partial_impl(h, nullptr, B, d_partials, st, hc);
-        case kEvalNormal: return eval_normal_partial_impl(h, nullptr, B, d_partials, st, hc);
-        case kEvalFull: return eval_full_partial_impl(h, nullptr, B, d_partials, st, hc);
+        case kEvalNormal: return eval_normal_partial_impl(h, nullptr, B, d_partials, st, hc, jets_ready);
+        case kEvalFull: return eval_full_partial_impl(h, nullptr, B, d_partials, st, hc, jets_ready);
         case kEvalFactors: return eval_factors_partial_impl(h, nullptr, B, d_partials, st, hc);
     }
     return fail(h, IBA_ERR_INVALID_ARG, "bad evaluation kind");

@@ -88,6 +88,8 @@ struct iba_group {
     std::vector<hipStream_t> st;
     std::vector<double*> d_part;          // per device: IBA_MAX_BATCH x stride doubles
     std::vector<double*> h_parts;         // per device, pinned (host reduction); h_part = h_parts[0] otherwise
+    std::vector<double*> h_parts_dev;     // the same blocks as the devices address them: with the host reduction the last kernel of a
+                                          // device's chain writes its sums there (no copy behind it)
     std::vector<int32_t> f_begin, f_end;
     double* h_part = nullptr;             // the summed block, host
     std::vector<double> h_sum;            // host reduction: the sum in rank order
@@ -96,6 +98,8 @@ struct iba_group {
     int stride = 64;
     std::string err;
     double last_issue_us = 0.0;           // host time of the last chunk: candidate block + hand-over to the workers + wait
+    double last_enqueue_us = 0.0;         // of which: until the LAST device's launch chain and collective were enqueued (the host issue time)
+    std::vector<double> enq_us;           // per worker
     // ---- one worker thread per device ----
     std::vector<std::thread> workers;
     std::vector<iba_status> wstatus;
@@ -106,6 +110,7 @@ struct iba_group {
     std::atomic<uint64_t> gen{0};
     std::atomic<int> pending{0};
     std::atomic<bool> quit{false};
+    std::atomic<int> jets_ready{0};       // the derivative half of `cands` is complete (set by the calling thread while the workers' kernels run)
 };
 
 namespace {
@@ -142,12 +147,14 @@ void worker_main(iba_group* g, int i) {
     }
 }
 
-// runs fn(i) on every device's worker, concurrently; the first failure is reported
-iba_status run_all(iba_group* g, std::function<iba_status(int)> fn) {
+// runs fn(i) on every device's worker, concurrently (and `meanwhile`, if any, on the calling thread once the workers are off);
+// the first failure is reported
+iba_status run_all(iba_group* g, std::function<iba_status(int)> fn, const std::function<void()>& meanwhile = nullptr) {
     g->job = std::move(fn);
     g->pending.store(g->n, std::memory_order_release);
     { std::lock_guard<std::mutex> lk(g->mu); g->gen.fetch_add(1, std::memory_order_acq_rel); }
     g->cv_job.notify_all();
+    if (meanwhile) meanwhile();
     auto t0 = std::chrono::steady_clock::now();
     int polls = 0;
     while (g->pending.load(std::memory_order_acquire) != 0) {
@@ -160,6 +167,19 @@ iba_status run_all(iba_group* g, std::function<iba_status(int)> fn) {
     for (int i = 0; i < g->n; ++i)
         if (g->wstatus[i] != IBA_OK) return gfail(g, g->wstatus[i], std::string("device ") + std::to_string(g->dev[i]) + ": " + g->werr[i]);
     return IBA_OK;
+}
+
+// the worker polls its stream for up to 2 ms before it blocks (the rule of the single handle's wait_stream)
+hipError_t poll_stream(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int polls = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return hipSuccess;
+        if (q != hipErrorNotReady) return q;
+        if ((++polls & 15) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    return hipStreamSynchronize(st);
 }
 
 iba_status wfail(iba_group* g, int i, iba_status s, const std::string& m) { g->werr[i] = m; return s; }
@@ -187,20 +207,28 @@ void shard(const iba_problem_desc* d, int n, std::vector<int32_t>& b, std::vecto
 // g->h_part. Per device, on its own thread: pinned copy of the candidate block, kernels, ONE collective, stream drained.
 iba_status eval_chunk(iba_group* g, const double* x, int Bc, EvalKind kind) {
     const auto t0 = std::chrono::steady_clock::now();
-    make_cands_host(x, Bc, g->cands.data(), kind != kEvalCost);
+    // the values first (6 us for 64 candidates): the devices start on them; the derivatives (38 us, read by the factor kernel alone)
+    // are computed on this thread while the workers issue and the kernels run
+    const bool late_jets = kind == kEvalNormal || kind == kEvalFull;
+    make_cands_host(x, Bc, g->cands.data(), kind == kEvalFactors);
+    g->jets_ready.store(0, std::memory_order_release);
     const size_t bytes = sizeof(double) * (size_t)Bc * g->stride;
-    iba_status s = run_all(g, [g, Bc, kind, bytes](int i) -> iba_status {
-        W_IBA(g, i, eval_partial_cands(g->h[i], g->cands.data(), Bc, kind, g->d_part[i], g->st[i]));
-        if (g->host_reduce) W_HIP(g, i, hipMemcpyAsync(g->h_parts[i], g->d_part[i], bytes, hipMemcpyDeviceToHost, g->st[i]));
-        else {
+    iba_status s = run_all(g, [g, Bc, kind, bytes, t0, late_jets](int i) -> iba_status {
+        W_IBA(g, i, eval_partial_cands(g->h[i], g->cands.data(), Bc, kind, g->host_reduce ? g->h_parts_dev[i] : g->d_part[i], g->st[i], late_jets ? &g->jets_ready : nullptr));
+        if (!g->host_reduce) {
             const ncclResult_t r = rccl().AllReduce(g->d_part[i], g->d_part[i], (size_t)Bc * g->stride, ncclDouble, ncclSum, g->comm[i], g->st[i]);
             if (r != ncclSuccess) return wfail(g, i, IBA_ERR_HIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(r));
             if (i == 0) W_HIP(g, i, hipMemcpyAsync(g->h_parts[0], g->d_part[0], bytes, hipMemcpyDeviceToHost, g->st[0]));
         }
-        W_HIP(g, i, hipStreamSynchronize(g->st[i]));
+        g->enq_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();   // everything of this device is enqueued
+        W_HIP(g, i, poll_stream(g->st[i]));
         return IBA_OK;
+    }, [g, x, Bc, late_jets]() {
+        if (late_jets) make_cands_jets_host(x, Bc, g->cands.data());
+        g->jets_ready.store(1, std::memory_order_release);   // always: a worker may be waiting on it
     });
     if (s != IBA_OK) return s;
+    g->last_enqueue_us = *std::max_element(g->enq_us.begin(), g->enq_us.end());
     if (g->host_reduce && g->n > 1) {   // rank order: bitwise reproducible whatever the timing
         const size_t m = (size_t)Bc * g->stride;
         for (size_t k = 0; k < m; ++k) { double a = g->h_parts[0][k]; for (int i = 1; i < g->n; ++i) a += g->h_parts[i][k]; g->h_sum[k] = a; }
@@ -262,8 +290,8 @@ iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* p
     iba_group* g = new iba_group;
     g->n = n_devices; g->params = *params; g->stride = iba_partial_stride(); g->host_reduce = host_reduce;
     g->dev.assign(devices, devices + n_devices);
-    g->h.assign(n_devices, nullptr); g->comm.assign(n_devices, nullptr); g->st.assign(n_devices, nullptr); g->d_part.assign(n_devices, nullptr); g->h_parts.assign(n_devices, nullptr);
-    g->wstatus.assign(n_devices, IBA_OK); g->werr.assign(n_devices, "");
+    g->h.assign(n_devices, nullptr); g->comm.assign(n_devices, nullptr); g->st.assign(n_devices, nullptr); g->d_part.assign(n_devices, nullptr); g->h_parts.assign(n_devices, nullptr); g->h_parts_dev.assign(n_devices, nullptr);
+    g->wstatus.assign(n_devices, IBA_OK); g->werr.assign(n_devices, ""); g->enq_us.assign(n_devices, 0.0);
     g->cands.resize(IBA_MAX_BATCH); g->h_sum.resize((size_t)IBA_MAX_BATCH * g->stride);
     shard(desc, n_devices, g->f_begin, g->f_end);
     for (int i = 0; i < n_devices; ++i) g->workers.emplace_back(worker_main, g, i);
@@ -274,7 +302,8 @@ iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* p
         W_HIP(g, i, hipSetDevice(g->dev[i]));
         W_HIP(g, i, hipStreamCreateWithFlags(&g->st[i], hipStreamNonBlocking));
         W_HIP(g, i, hipMalloc((void**)&g->d_part[i], sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride));
-        W_HIP(g, i, hipHostMalloc((void**)&g->h_parts[i], sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride));
+        W_HIP(g, i, hipHostMalloc((void**)&g->h_parts[i], sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride, hipHostMallocMapped));
+        W_HIP(g, i, hipHostGetDevicePointer((void**)&g->h_parts_dev[i], g->h_parts[i], 0));
         W_IBA(g, i, reserve_batch(g->h[i], IBA_MAX_BATCH));   // no allocation inside an evaluation (several threads are inside HIP then)
         return IBA_OK;
     });
@@ -300,6 +329,7 @@ int32_t iba_group_comm_ranks(const iba_group* g) {   // what RCCL itself says ab
 }
 
 double iba_group_last_issue_us(const iba_group* g) { return g ? g->last_issue_us : 0.0; }
+double iba_group_last_enqueue_us(const iba_group* g) { return g ? g->last_enqueue_us : 0.0; }
 
 iba_status iba_group_set_params(iba_group* g, const iba_params* p) {
     if (!g || !p) return IBA_ERR_INVALID_ARG;

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "../../include/iba_mi355x.h"
 #include "iba_types.hpp"
 
@@ -15,7 +17,10 @@ enum EvalKind { kEvalCost = 0, kEvalNormal = 1, kEvalFull = 2, kEvalFactors = 3 
 void make_cands_host(const double* x, int B, Cand* out, bool jets = true);   // jets = false: the values only (cost evaluations)
 // launch chain of one chunk (B <= IBA_MAX_BATCH) on `st` from a ready candidate block (host memory, copied into the handle's
 // pinned ring before the call returns); no synchronisation
-iba_status eval_partial_cands(iba_handle* h, const Cand* host_cands, int B, EvalKind kind, double* d_partials, hipStream_t st);
+// jets_ready != nullptr (kEvalNormal / kEvalFull): the derivative half of host_cands is still being computed by the caller; the chain
+// starts on the values and copies the block again, before the factor kernel, once *jets_ready is set
+iba_status eval_partial_cands(iba_handle* h, const Cand* host_cands, int B, EvalKind kind, double* d_partials, hipStream_t st, const std::atomic<int>* jets_ready = nullptr);
+void make_cands_jets_host(const double* x, int B, Cand* out);   // the derivative half alone
 // iba_build_problem from a ready candidate (synchronises the handle's stream: the frozen counts are read back)
 iba_status build_problem_cands(iba_handle* h, const Cand* host_cand);
 // work buffers for batches of up to B candidates, so that no evaluation allocates
