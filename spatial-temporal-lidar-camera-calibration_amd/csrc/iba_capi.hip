@@ -93,11 +93,12 @@ struct iba_handle {
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
     bool spin_wait = true;                // IBA_SPIN_WAIT=0: blocking waits only
     bool nn_sets = true;                  // IBA_NN_SETS=0: no anchored neighbour lists, every lane searches the tree (diagnostic)
-    int common_min_batch = 4;             // IBA_COMMON_MIN_BATCH
+    int common_min_batch = 1;             // IBA_COMMON_MIN_BATCH
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
+    bool he_staged = false;               // the hand-eye terms of the staged candidates were computed by the staging launch
     const Cand* jets_src = nullptr; const std::atomic<int>* jets_flag = nullptr;   // ... or is being computed by the group's calling thread: the block to copy once *jets_flag is set
     int last_path = 0;                    // 1: the last evaluation chain used the common pairs
 
@@ -352,7 +353,7 @@ iba_status ensure_scratch(iba_handle* h) {
 // from x here, or copied from `pre` when the caller (iba_group) has already computed it for all its devices. jets = 0: the
 // values only (cost evaluations never read the derivatives); jets = 2: the values now, the derivatives later (finish_jets:
 // the host differentiates the exponentials while the GPU runs the association and search kernels on the values).
-iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1, const std::atomic<int>* pre_flag = nullptr) {
+iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1, const std::atomic<int>* pre_flag = nullptr, bool with_he = false) {
     const int slot = h->ring_next; h->ring_next = (h->ring_next + 1) % kRing;
     if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
     Cand* hc = h->h_cands + (size_t)slot * IBA_MAX_BATCH;
@@ -370,7 +371,12 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     // at the head of every evaluation; a strided copy of the value halves alone was slower still)
     {
         const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)B / 16);
-        hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)(h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH), (uint4*)dc, n16);
+        const Cand* src = h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH;
+        h->he_staged = with_he && h->n_frames > 0;
+        if (h->he_staged) {   // K7 rides in the same launch (one kernel less at the head of every cost evaluation)
+            const uint32_t n_fetch = (n16 + 255) / 256;
+            hipLaunchKernelGGL(iba_fetch_he_kernel, dim3(n_fetch + (uint32_t)((B * h->n_frames + 31) / 32)), dim3(64), 0, st, (const uint4*)src, (uint4*)dc, n16, n_fetch, h->dev_problem(), src, B, h->d_he.p);
+        } else hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)src, (uint4*)dc, n16);
         HIP_TRY(h, hipGetLastError());
     }
     if (jets == 2) { h->jets_x = x; h->jets_B = B; h->jets_slot = slot; }
@@ -473,8 +479,8 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev0, st)); HIP_TRY(h, hipEventRecord(h->ev_mid, st)); HIP_TRY(h, hipEventRecord(h->ev1, st)); HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
         return IBA_OK;
     }
-    if (want & 2) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
-        hipLaunchKernelGGL(iba_he_kernel, dim3((B * nf + 63) / 64), dim3(64), 0, st, dp, dc, B, h->d_he.p);
+    if ((want & 2) && !h->he_staged) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
+        hipLaunchKernelGGL(iba_he_kernel, dim3((B * nf + 31) / 32), dim3(64), 0, st, dp, dc, B, h->d_he.p);
         HIP_TRY(h, hipGetLastError());
     }
     const int per_xcd = (nf + 7) / 8;
@@ -607,7 +613,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
     if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0); if (s != IBA_OK) return s;   // the cost tuple never reads the derivatives
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0, nullptr, true); if (s != IBA_OK) return s;   // the cost tuple never reads the derivatives
     return run_split(h, dc, B, 2, false, false, d_partials, st);
 }
 
@@ -1148,7 +1154,7 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, true); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 3, false, true, d_partials, st);
 }
 

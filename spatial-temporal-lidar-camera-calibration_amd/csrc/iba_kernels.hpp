@@ -557,31 +557,49 @@ __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm
 
 // K7: hand-eye consistency term of every (candidate, frame) pair (iba_global.cpp:264-276); one lane each.
 // The frame kernel adds he[b][f] only for frames that pass the corrset test.
-__global__ __launch_bounds__(64) void iba_he_kernel(DevProblem dp, const Cand* __restrict__ cands, int B, double* __restrict__ he) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= B * dp.n_frames) return;
-    const int b = i / dp.n_frames, f = i % dp.n_frames;
-    const FrameHdr& h = dp.frames[f];
-    const Cand& cd = cands[b];
-    double val = 0.0;
-    if (h.he_valid) {
-        double C1R[9], C1t[3], C2R[9], C2t[3];
+// Two lanes per (candidate, frame): the even lane takes log(T_cl Tl), the odd one log(Tc T_cl) — the two halves of the term are
+// independent chains of ~1000 dependent f64 instructions each, and a small batch has more lanes than work.
+__device__ __forceinline__ double he_term(const FrameHdr& h, const Cand& cd, const int which, const bool live) {
+    double l[6] = {0, 0, 0, 0, 0, 0};
+    if (live && h.he_valid) {
+        double CR[9], Ct[3];
         const double* Tl = h.Tl_next; const double* Tc = h.Tc_next;
         for (int r = 0; r < 3; ++r) {
-            for (int cc = 0; cc < 3; ++cc) {
-                C1R[r * 3 + cc] = (cd.R[r * 3 + 0] * Tl[0 * 4 + cc] + cd.R[r * 3 + 1] * Tl[1 * 4 + cc]) + cd.R[r * 3 + 2] * Tl[2 * 4 + cc];
-                C2R[r * 3 + cc] = (Tc[r * 4 + 0] * cd.R[0 * 3 + cc] + Tc[r * 4 + 1] * cd.R[1 * 3 + cc]) + Tc[r * 4 + 2] * cd.R[2 * 3 + cc];
-            }
-            C1t[r] = ((cd.R[r * 3 + 0] * Tl[3] + cd.R[r * 3 + 1] * Tl[7]) + cd.R[r * 3 + 2] * Tl[11]) + cd.t[r];
-            C2t[r] = ((Tc[r * 4 + 0] * cd.t[0] + Tc[r * 4 + 1] * cd.t[1]) + Tc[r * 4 + 2] * cd.t[2]) + Tc[r * 4 + 3] * cd.s;
+            for (int cc = 0; cc < 3; ++cc)
+                CR[r * 3 + cc] = which == 0 ? (cd.R[r * 3 + 0] * Tl[0 * 4 + cc] + cd.R[r * 3 + 1] * Tl[1 * 4 + cc]) + cd.R[r * 3 + 2] * Tl[2 * 4 + cc]
+                                            : (Tc[r * 4 + 0] * cd.R[0 * 3 + cc] + Tc[r * 4 + 1] * cd.R[1 * 3 + cc]) + Tc[r * 4 + 2] * cd.R[2 * 3 + cc];
+            Ct[r] = which == 0 ? ((cd.R[r * 3 + 0] * Tl[3] + cd.R[r * 3 + 1] * Tl[7]) + cd.R[r * 3 + 2] * Tl[11]) + cd.t[r]
+                               : ((Tc[r * 4 + 0] * cd.t[0] + Tc[r * 4 + 1] * cd.t[1]) + Tc[r * 4 + 2] * cd.t[2]) + Tc[r * 4 + 3] * cd.s;
         }
-        double l1[6], l2[6];
-        dev_se3log(C1R, C1t, l1); dev_se3log(C2R, C2t, l2);
-        double ss = 0;
-        for (int k = 0; k < 6; ++k) ss += (l1[k] - l2[k]) * (l1[k] - l2[k]);
-        val = sqrt(ss);
+        dev_se3log(CR, Ct, l);
     }
-    he[i] = val;
+    double ss = 0;
+    for (int k = 0; k < 6; ++k) {   // the even lane holds l1, its neighbour l2
+        const double other = __shfl_xor(l[k], 1);
+        ss += (l[k] - other) * (l[k] - other);
+    }
+    return sqrt(ss);
+}
+__global__ __launch_bounds__(64) void iba_he_kernel(DevProblem dp, const Cand* __restrict__ cands, int B, double* __restrict__ he) {
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 1);
+    const bool live = i < B * dp.n_frames;
+    const int ii = live ? i : 0;
+    const double v = he_term(dp.frames[ii % dp.n_frames], cands[ii / dp.n_frames], threadIdx.x & 1, live);
+    if (live && !(threadIdx.x & 1)) he[i] = v;
+}
+// the head of an evaluation in one launch: blocks [0, n_fetch) copy the candidate block (iba_fetch_kernel), the others compute
+// K7 from the candidates where they lie in pinned host memory (13 doubles per lane, two distinct candidates per wave at most)
+__global__ __launch_bounds__(64) void iba_fetch_he_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, uint32_t n_fetch,
+                                                          DevProblem dp, const Cand* __restrict__ cands_host, int B, double* __restrict__ he) {
+    if (blockIdx.x < n_fetch) {
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < min(n16, (blockIdx.x + 1u) * 256u); i += 64u) dst[i] = src[i];
+        return;
+    }
+    const int i = (int)(blockIdx.x - n_fetch) * 32 + (int)(threadIdx.x >> 1);
+    const bool live = i < B * dp.n_frames;
+    const int ii = live ? i : 0;
+    const double v = he_term(dp.frames[ii % dp.n_frames], cands_host[ii / dp.n_frames], threadIdx.x & 1, live);
+    if (live && !(threadIdx.x & 1)) he[i] = v;
 }
 
 // grid: 8 * ceil(n_frames/8) * B blocks of kThreads. Block i runs on XCD i%8 (round-robin dispatch), so

@@ -49,7 +49,8 @@ def test_shared_search_gives_the_same_bits(pkg, synth, abi, scene_small):
     tight = synth.perturb(meta["x_gt"], rng, n=64)
     _same_bits(pkg, h0, h1, tight, 1)
     _same_bits(pkg, h0, h1, tight[:4], 1)
-    _same_bits(pkg, h0, h1, tight[:3], 0)                       # below the batch threshold: per-candidate search
+    _same_bits(pkg, h0, h1, tight[:3], 1)
+    _same_bits(pkg, h0, h1, tight[:1], 1)                       # a single candidate too (zero spread: the tightest lists)
     # ten times the spread: still shared by default? the nominal spread decides; forced sharing (mode 2) must agree anyway
     wide10 = synth.perturb(meta["x_gt"], rng, rot=5e-3, trans=5e-2, scale_rel=1e-2, n=16)
     _same_bits(pkg, h0, h2, wide10, 1)
