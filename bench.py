@@ -155,6 +155,7 @@ def main():
     rng = np.random.default_rng(0)
     xs_all = [synth.perturb(meta["x_gt"], rng, n=B) for _ in range(4)]   # x0 +- seeded perturbations (0.5 mrad / 5 mm / 0.1 %)
     d_part = torch.zeros(B * stride, dtype=torch.float64, device=dev)
+    h_part = torch.zeros(B * stride, dtype=torch.float64).pin_memory()
 
     import ctypes as C
     lean_out = {}
@@ -178,12 +179,24 @@ def main():
             return grp.eval_full(xs)
         if not use_dist:   # one GPU: the C entry point does it all (launch chain, D2H of the 64-double blocks, host finalisation)
             return eval_full_lean(xs)
+        # one process per GPU: the partial entry point enqueues on this process's stream and returns; ONE sum all-reduce of the
+        # 64-double blocks (RCCL over xGMI); the block lands in pinned memory; the host finalises into arrays kept between calls
         st = torch.cuda.current_stream().cuda_stream
-        h.eval_full_partial(xs, d_part.data_ptr(), st)   # cost tuple + normal equations from one pass over the scans
-        if use_dist:   # frames shard across ranks: ONE sum all-reduce of the partial blocks (RCCL over xGMI)
-            dist.all_reduce(d_part)
-        pc = d_part[: len(xs) * stride].cpu().numpy()
-        return pkg.finalize_cost(params, pc), pkg.finalize_normal(params, pc)
+        n = len(xs)
+        xs = np.ascontiguousarray(xs, np.float64)
+        st_ = h.lib.iba_eval_full_partial(h.h, xs.ctypes.data_as(C.c_void_p), C.c_int32(n), C.c_void_p(d_part.data_ptr()), C.c_void_p(st))
+        if st_ != 0:
+            raise pkg.IbaError(st_, h.lib.iba_last_error(h.h).decode())
+        dist.all_reduce(d_part)
+        h_part[: n * stride].copy_(d_part[: n * stride], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        if n not in lean_out:
+            lean_out[n] = ((pkg.IbaCostOut * n)(), (pkg.IbaNormalOut * n)())
+        cost, nrm = lean_out[n]
+        if h.lib.iba_finalize_cost(C.byref(params), C.c_void_p(h_part.data_ptr()), C.c_int32(n), cost) != 0 or \
+           h.lib.iba_finalize_normal(C.byref(params), C.c_void_p(h_part.data_ptr()), C.c_int32(n), nrm) != 0:
+            raise pkg.IbaError(-1, "iba_finalize_*")
+        return cost, nrm
 
     def sync():
         if use_dist:

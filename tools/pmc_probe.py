@@ -9,5 +9,5 @@ prob, meta = synth.make_scene(n_frames=200, pts_per_frame=10000, seed=0)
 h = pkg.IbaHandle(prob, abi.reference_yaml_params())
 xs = synth.perturb(meta["x_gt"], np.random.default_rng(0), n=64)
 mode = sys.argv[1] if len(sys.argv) > 1 else "cost"
-for _ in range(3):
+for _ in range(int(os.environ.get("PMC_PROBE_ITERS", "3"))):
     (h.eval_cost if mode == "cost" else h.eval_full)(xs)
