@@ -266,6 +266,12 @@ class IbaHandle:
         return int(self.lib.iba_debug_last_path(self.h))
 
     @property
+    def nn_left_to_tree(self):
+        self.lib.iba_debug_nn_left_to_tree.restype = C.c_double
+        self.lib.iba_debug_nn_left_to_tree.argtypes = [C.c_void_p]
+        return float(self.lib.iba_debug_nn_left_to_tree(self.h))
+
+    @property
     def anchor_builds(self):
         self.lib.iba_debug_anchor_builds.argtypes = [C.c_void_p]
         return int(self.lib.iba_debug_anchor_builds(self.h))

@@ -98,6 +98,7 @@ struct iba_handle {
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
+    int last_nn_nrec = 0, last_nn_B = 0;   // shape of the search kernel's records of the last evaluation (iba_debug_nn_left_to_tree)
     bool he_staged = false;               // the hand-eye terms of the staged candidates were computed by the staging launch
     const Cand* jets_src = nullptr; const std::atomic<int>* jets_flag = nullptr;   // ... or is being computed by the group's calling thread: the block to copy once *jets_flag is set
     int last_path = 0;                    // 1: the last evaluation chain used the common pairs
@@ -577,6 +578,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         const SetPt* anchor = sets ? h->d_anchor.p : nullptr;
         auto launch_nn = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
+            h->last_nn_nrec = nn_nrec; h->last_nn_B = B;
             auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, anchor); };
             if (sets && MODE != kRefitSums) { if (wA && wC) go(iba_nn_kernel<3, MODE, 1>); else if (wA) go(iba_nn_kernel<1, MODE, 1>); else go(iba_nn_kernel<2, MODE, 1>); }
             else { if (wA && wC) go(iba_nn_kernel<3, MODE, 0>); else if (wA) go(iba_nn_kernel<1, MODE, 0>); else go(iba_nn_kernel<2, MODE, 0>); }
@@ -1083,6 +1085,15 @@ iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
 int32_t iba_debug_last_path(const iba_handle* h) { return h ? h->last_path : -1; }
 
 // debug: how many times the anchored neighbour lists have been (re)built on this handle
+// entries of the last evaluation (all candidates) that the anchored neighbour lists left to the tree search (-1: no search ran)
+double iba_debug_nn_left_to_tree(iba_handle* h) {
+    if (!h || h->last_nn_nrec <= 0) return -1.0;
+    std::vector<double> v((size_t)h->last_nn_B * h->last_nn_nrec * kNNPartial);
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1.0;
+    if (hipMemcpy(v.data(), h->d_nn_partials.p, v.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    double t = 0; for (size_t i = 5; i < v.size(); i += kNNPartial) t += v[i];
+    return t;
+}
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }
 
 // debug: exact 1-NN of n LiDAR-frame queries in the scan of a local frame, through the frame kernels' own search

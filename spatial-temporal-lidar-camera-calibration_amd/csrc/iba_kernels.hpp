@@ -240,7 +240,7 @@ __device__ __forceinline__ void fit_insert(double d2q, uint32_t base, double (&e
     for (int s = 0; s < SLOTS; ++s) { ed[s] = nd[s]; ep[s] = np[s]; }
 }
 
-constexpr int kFitPathMax = 12;   // >= the builder's depth cap (kMaxTreeDepth = 11)
+constexpr int kFitPathMax = ((kMaxTreeDepth + 3) / 4) * 4;   // >= the builder's depth cap (kMaxTreeDepth = 11)
 constexpr int kFitListStride(int slots) { return 16 * slots + 1; }   // words per list in LDS (odd: lane-per-fit reads are conflict-free)
 template <int SLOTS> struct FitLds {
     uint32_t list[64][kFitListStride(SLOTS)];   // tree positions of the kept neighbours, nearest first
@@ -544,7 +544,7 @@ __device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v
     return hit;
 }
 
-constexpr int kPathMax = 12;   // levels of the search path whose plane bounds are kept in registers (the builder caps D at kMaxTreeDepth = 11)
+constexpr int kPathMax = ((kMaxTreeDepth + 3) / 4) * 4;   // levels of the search path whose plane bounds are kept in registers (the builder caps D at kMaxTreeDepth = 11)
 static_assert(kPathMax % 4 == 0 && kPathMax >= kMaxTreeDepth, "register path must cover the depth cap");
 // a closer point, or an equally close one with a lower original index, replaces the best so far
 __device__ __forceinline__ void nn_merge(double& best, uint32_t& bpos, double od, uint32_t op, const uint32_t* __restrict__ perm_g) {

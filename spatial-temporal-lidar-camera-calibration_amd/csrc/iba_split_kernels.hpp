@@ -1343,6 +1343,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
 
     // per-thread partial sums of the final (fixed-order) pass: thread t sums entries of candidate t / 32
     double fin_sum = 0.0; uint32_t fin_c = 0, fin_v = 0, fin_pl = 0, fin_pt = 0;
+    uint32_t left_to_tree = 0u;   // diagnostic (record slot 5): entries of this block the anchored lists could not settle
 
     {
         const uint32_t c0 = 0u, c1 = W;
@@ -1451,11 +1452,16 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     double S2 = 0.0;
                     if ((WHICH & 1) && actA) { const double dx = ax - hd.qa[0], dy = ay - hd.qa[1], dz = az - hd.qa[2]; S2 = (dx * dx + dy * dy) + dz * dz; }
                     if ((WHICH & 2) && actC) { const double dx = qx - hd.qa[0], dy = qy - hd.qa[1], dz = qz - hd.qa[2]; S2 = fmax(S2, (dx * dx + dy * dy) + dz * dz); }
-                    const double radius = (hd.d1 + 2.0 * sqrt(S2)) * (1.0 + 1e-12) + 1e-12;
-                    if (!(radius < hd.dM) || hd.count == 0u) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; return; }   // (NaN queries fail here too)
+                    const double S = sqrt(S2);
+                    const double radius = (hd.d1 + 2.0 * S) * (1.0 + 1e-12) + 1e-12;
+                    const bool quick = radius < hd.dM;   // (NaN queries fail both tests)
+                    // Second chance, from the whole row: with r = the distance to the nearest LISTED point, every point within r of this
+                    // query is within r + S of the anchor's; if that is inside d_M they are all listed and the nearest listed point is the
+                    // nearest point. (Dense scans: d_M shrinks with the point spacing, S does not.)
+                    if ((!quick && !(S < hd.dM)) || hd.count == 0u) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; return; }
                     bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
                     SetPt abest = p0, cbest = p0;
-                    const float rf = (float)radius * 1.000001f + 1e-30f;   // >= radius
+                    const float rf = quick ? (float)radius * 1.000001f + 1e-30f : INFINITY;   // >= radius
                     for (uint32_t si = 0; si < hd.count; ++si) {
                         if (si == 1u && !(hd.da1_lo <= rf)) break;   // the second neighbour cannot qualify: its line is not even fetched (the usual case)
                         const SetPt pv = si == 0u ? p0 : *anchor_pt(row, si);
@@ -1463,6 +1469,12 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                         const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
                         if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; const uint32_t was = bposA; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposA != was) abest = pv; }
                         if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; const uint32_t was = bposC; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposC != was) cbest = pv; }
+                    }
+                    if (!quick) {
+                        double r2 = 0.0;
+                        if ((WHICH & 1) && actA) r2 = bestA;
+                        if ((WHICH & 2) && actC) r2 = fmax(r2, bestC);
+                        if (!((sqrt(r2) + S) * (1.0 + 1e-12) + 1e-12 < hd.dM)) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; return; }
                     }
                     if (dbg != 5) finish(wn, &abest, &cbest);
                 };
@@ -1482,6 +1494,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                 }
                 __syncthreads();
                 c_end = s_ctr[1];
+                left_to_tree = c_end;
                 if (tid == 0) *s_ctr = 0u;
                 if (c_end != 0u) for (uint32_t i = tid; i < nnodes; i += T) s_nodes[i] = dp.nodes[h.node_base + i];   // some lanes search the tree after all
                 __syncthreads();
@@ -1555,6 +1568,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
             else if (q == 2) out = (double)(cnt >> 32);
             else if (q == 3) out = (double)(cnt2 & 0xffffffffull);
             else if (q == 4) out = (double)(cnt2 >> 32);
+            else if (q == 5 && cc == 0) out = (double)left_to_tree;
             nn_partials[((size_t)(g * CG + cc) * nn_nrec + (size_t)f * NS + sl) * kNNPartial + q] = out;
         }
     }

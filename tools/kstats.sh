@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 T=${1:-kstats}
 mkdir -p gpurun_out/$T
 export PMC_PROBE_ITERS=${ITERS:-30}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/st -o st -- python3 tools/pmc_probe.py full > /dev/null 2> gpurun_out/$T/log.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/st -o st -- python3 ${PROBE:-tools/pmc_probe.py} ${PROBE_ARG:-full} > /dev/null 2> gpurun_out/$T/log.txt
 python3 - <<'PY' $T
 import csv, glob, sys
 for fn in glob.glob("gpurun_out/%s/st/**/*kernel_stats.csv" % sys.argv[1], recursive=True):
