@@ -263,6 +263,7 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     L.off_best_idx = off; off += 4u * Kp;
     L.off_kfl = off; off += 4u * Kp;
     off = align_up(off, 16); L.off_red = off; off += red_bytes;
+    off = align_up(off, 16); L.off_pair = off; off += 2u * (uint32_t)kPairNote;   // possible winners beyond the register window
     L.total = align_up(off, 16);
     return L.total <= kLdsBytes;
 }

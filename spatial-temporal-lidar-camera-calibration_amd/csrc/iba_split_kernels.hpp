@@ -806,7 +806,8 @@ __device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* 
 // f64 test of the batch's common pairs (K1 + K2 + K3 of the reference: TransformPointCloud pointcloud.h:82-86, the projection
 // and FOV test iba_global.cpp:68-81, the 1-NN within max_pixel_dist :86-95) streamed from the list iba_pairs_kernel left.
 // LDS: 16 B per keypoint (best d^2, best index, flags) + the relative poses: ~33 KB at 2000 keypoints.
-constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; more are re-evaluated)
+constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
+constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
 __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
                                                               const double* __restrict__ he, uint4* __restrict__ flist, float4* __restrict__ fmp, uint32_t* __restrict__ fcount,
                                                               uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hard,
@@ -833,6 +834,8 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
     double* s_red = (double*)(smem + lay.off_red);
     double* s_rel = s_red + kWaves * 4;
     uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 once the winners are known
+    uint32_t* s_qn = (uint32_t*)(s_rel + kMaxCovis * 12) + kWaves;   // [0]: pairs noted for the tie pass
+    uint16_t* s_q = (uint16_t*)(smem + lay.off_pair);                // their numbers (pair lists hold at most 65 536 records)
     const uint32_t K = h.K, P = h.P;
     const uint32_t ut = (uint32_t)tid;
 
@@ -847,6 +850,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
         if (ut < h.n_slots * 12u) rv = dp.slots[h.slot_base + ut / 12].rel[ut % 12];
         for (uint32_t i = ut; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kfl[i] = gfl[i]; }
         if (ut < h.n_slots * 12u) s_rel[ut] = rv;
+        if (tid == 0) s_qn[0] = 0u;
     }
     const int dbg = want >> 8;
     const bool refit = (want & 4) != 0;
@@ -885,10 +889,27 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
         const uint32_t i = ut + (uint32_t)j * kThreads;
         if (i < npair) { rb[j] = eval_pair(i, rk[j], ri[j]); if (rk[j] != kNone) atomicMin(&s_best_d2[rk[j]], rb[j]); }
     }
-    for (uint32_t i = ut + (uint32_t)kPairRegs * kThreads; i < npair; i += kThreads) {
-        uint32_t k, idx;
-        const unsigned long long bits = eval_pair(i, k, idx);
-        if (k != kNone) atomicMin(&s_best_d2[k], bits);
+    // pairs beyond the register window (a dense scan: 9 k pairs per keyframe at 120 k points): one that is at most the keypoint's best
+    // so far MAY be the winner and is noted for the tie pass (a keypoint sees ~1.3 such pairs); the others cannot win any more
+    {
+        const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+        for (uint32_t i0 = (uint32_t)kPairRegs * kThreads; i0 < npair; i0 += kThreads) {   // block-uniform trip count
+            const uint32_t i = i0 + ut;
+            bool note = false;
+            if (i < npair) {
+                uint32_t k, idx;
+                const unsigned long long bits = eval_pair(i, k, idx);
+                if (k != kNone) note = bits <= atomicMin(&s_best_d2[k], bits);
+            }
+            const unsigned long long bal = __ballot(note);
+            if (bal != 0ull) {
+                uint32_t base = 0u;
+                if ((tid & 63) == 0) base = atomicAdd(&s_qn[0], (uint32_t)__popcll(bal));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t slot = base + (uint32_t)__popcll(bal & lt);
+                if (note && slot < (uint32_t)kPairNote) s_q[slot] = (uint16_t)i;
+            }
+        }
     }
     for (uint32_t i = ut; i < nhard; i += kThreads) {
         const uint32_t pos = hard[(size_t)f * (size_t)hard_cap + i];
@@ -903,10 +924,21 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
 #pragma unroll
     for (int j = 0; j < kPairRegs; ++j)
         if (rk[j] != kNone && s_best_d2[rk[j]] == rb[j]) atomicMin(&s_best_idx[rk[j]], ri[j]);
-    for (uint32_t i = ut + (uint32_t)kPairRegs * kThreads; i < npair; i += kThreads) {
-        uint32_t k, idx;
-        const unsigned long long bits = eval_pair(i, k, idx);
-        if (k != kNone && s_best_d2[k] == bits) atomicMin(&s_best_idx[k], idx);
+    {
+        const uint32_t nq = s_qn[0];
+        if (nq <= (uint32_t)kPairNote) {   // the noted pairs alone
+            for (uint32_t t = ut; t < nq; t += kThreads) {
+                uint32_t k, idx;
+                const unsigned long long bits = eval_pair((uint32_t)s_q[t], k, idx);
+                if (k != kNone && s_best_d2[k] == bits) atomicMin(&s_best_idx[k], idx);
+            }
+        } else {   // more than the note list holds: every pair beyond the window again
+            for (uint32_t i = ut + (uint32_t)kPairRegs * kThreads; i < npair; i += kThreads) {
+                uint32_t k, idx;
+                const unsigned long long bits = eval_pair(i, k, idx);
+                if (k != kNone && s_best_d2[k] == bits) atomicMin(&s_best_idx[k], idx);
+            }
+        }
     }
     for (uint32_t i = ut; i < nhard; i += kThreads) {
         const uint32_t pos = hard[(size_t)f * (size_t)hard_cap + i];

@@ -7,8 +7,8 @@ mkdir -p gpurun_out/$T
 for k in ${CUTS:-1 2 3 4 5 6 7 0}; do
   export IBA_ASSOC_DBG=$k
   d=gpurun_out/$T/c$k; mkdir -p $d
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $d -o pmc -- python3 tools/pmc_probe.py full > /dev/null 2> $d/log.txt
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d/st -o st -- python3 tools/pmc_probe.py full > /dev/null 2>> $d/log.txt
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $d -o pmc -- python3 ${PROBE:-tools/pmc_probe.py} ${PROBE_ARG:-full} > /dev/null 2> $d/log.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d/st -o st -- python3 ${PROBE:-tools/pmc_probe.py} ${PROBE_ARG:-full} > /dev/null 2>> $d/log.txt
 done
 unset IBA_ASSOC_DBG
 python3 - <<'PY' $T > gpurun_out/$T/cuts.txt
