@@ -1093,6 +1093,12 @@ double iba_debug_nn_left_to_tree(iba_handle* h) {
     if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1.0;
     if (hipMemcpy(v.data(), h->d_nn_partials.p, v.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
     double t = 0; for (size_t i = 5; i < v.size(); i += kNNPartial) t += v[i];
+    if (std::getenv("IBA_DEBUG_LEFT_HIST")) {   // blocks by the number of entries they searched in the tree
+        const int edges[] = {0, 1, 9, 17, 33, 65, 129, 257, 1 << 30};
+        int hist[8] = {0};
+        for (size_t i = 5; i < v.size(); i += kNNPartial) for (int k = 0; k < 8; ++k) if (v[i] >= edges[k] && v[i] < edges[k + 1]) ++hist[k];
+        std::fprintf(stderr, "left-over entries per block: 0:%d 1-8:%d 9-16:%d 17-32:%d 33-64:%d 65-128:%d 129-256:%d more:%d\n", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+    }
     return t;
 }
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }

@@ -1086,6 +1086,141 @@ __device__ __forceinline__ void lane_nn_visit(IBA_LANE_NN_PARAMS, const TreeNode
     }
 }
 
+// ---- the same search run by a GROUP of G lanes (8 .. 64, a whole wave) for one query pair: every lane carries the same state and walks the same path, the points
+//      of a leaf are spread over the lanes (one coalesced load instead of a lane's 59 dependent gathers at 120 k points per scan) and
+//      the leaf's minimum, runner-up and arg-min are combined across the wave exactly as the sequential scan defines them (arg-min =
+//      lowest position among the minima, runner-up = second smallest of the multiset). The exact confirmations merge through
+//      nn_merge, whose outcome (least d^2, ties to the lowest original index) does not depend on the order. For the handful of
+//      entries per block that the anchored lists leave over: their searches, not their number, set the block's run time. ----
+// (minimum over the G consecutive lanes of a group, G a power of two: a lane's partners are in its own group, which branches as one)
+__device__ __forceinline__ float group_min_f32(float v, const int G) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) if (o < G) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v, const int G) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) if (o < G) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ __forceinline__ double group_min_f64(double v, const int G) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) if (o < G) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+template <int WHICH>
+__device__ __forceinline__ void wave_nn_visit(IBA_LANE_NN_PARAMS, const int lane, const int G, const TreeNode* s_nodes, const float4* __restrict__ p4, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D) {
+    const uint32_t first_leaf = (1u << D) - 1u;
+    auto lower_bound = [delc](float d) { const float a = fmaxf(fmaf(fabsf(d), 0.999999f, -delc), 0.f); return a * a; };
+    int start = 0;
+    if (go >= 0) {   // enter the far child at level go
+        const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
+        done |= 1u << go; side ^= 1u << go;
+        node = 2u * anc + 1u + ((side >> go) & 1u);
+        start = go + 1;
+    }
+    {
+        const uint32_t keep = (1u << start) - 1u;
+        side &= keep; done &= keep;
+        uint32_t n1 = node + 1u;
+#pragma unroll
+        for (int L = 0; L < kPathMax; ++L) {
+            if (L >= (int)D) break;
+            if (L >= start) {
+                const TreeNode n = s_nodes[n1 - 1u];
+                const float d = (n.dim == 0 ? o0 : (n.dim == 1 ? o1 : o2)) - n.split;
+                const uint32_t r = (~__float_as_uint(d)) >> 31;
+                pd2[L] = lower_bound(d);
+                side |= r << L;
+                n1 = (n1 << 1) | r;
+            }
+        }
+        node = n1 - 1u;
+    }
+    {
+        const uint32_t j = node - first_leaf;
+        const uint32_t lo = (uint32_t)(((uint64_t)j * P) >> D), hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D);
+        auto err_of = [e_lin, e_const](float u) { return fmaf(1.001f * e_lin, __builtin_amdgcn_sqrtf(3.f * u), fmaf(1.5e-6f, u, e_const)); };
+        // this lane's share of the leaf, then the wave's (m1, m2, mi) of the whole leaf
+        float l1 = INFINITY, l2 = INFINITY; uint32_t li = kNone;
+        for (uint32_t i0 = lo + (uint32_t)lane; i0 < hi; i0 += 4u * (uint32_t)G) {   // four loads in flight per lane (a small group scans 15 points per lane)
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t iu = i0 + (uint32_t)u * (uint32_t)G; v[u] = p4[iu < hi ? iu : hi - 1u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * (uint32_t)G;
+                const float dx = o0 - v[u].x, dy = o1 - v[u].y, dz = o2 - v[u].z;
+                float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                uu = i < hi ? uu : INFINITY;
+                li = uu < l1 ? i : li;
+                l2 = __builtin_amdgcn_fmed3f(l1, l2, uu);
+                l1 = vmin(l1, uu);
+            }
+        }
+        const float m1 = group_min_f32(l1, G);
+        const uint32_t mi = group_min_u32(l1 == m1 ? li : kNone, G);
+        const float m2 = group_min_f32((li == mi && mi != kNone) ? l2 : l1, G);
+        const float mono = 4.f * e_lin * e_lin;
+        const float thi = m1 + err_of(m1);
+        bool single = m2 >= mono && m2 - err_of(m2) > thi;
+        const float bnear = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+        const float bmax = fmaf(fabsf(bnear), 1.2e-7f, bnear);
+        const bool skip = m1 >= mono && m1 - err_of(m1) > bmax;
+#ifdef IBA_LEAF_FORCE_SINGLE
+        single = true;
+#endif
+        if (mi != kNone && !skip) {
+            if (single) {
+                const float4 pv = p4[mi];
+                const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+                if (WHICH & 1) { const double dx = ax - x, dy = ay - y, dz = az - z; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, mi, perm_g); }
+                if (WHICH & 2) { const double dx = qx - x, dy = qy - y, dz = qz - z; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, mi, perm_g); }
+            } else {
+                double lbA = INFINITY, lbC = INFINITY; uint32_t lpA = kNone, lpC = kNone;
+                for (uint32_t i0 = lo + (uint32_t)lane; i0 < hi; i0 += 4u * (uint32_t)G) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const uint32_t iu = i0 + (uint32_t)u * (uint32_t)G; v[u] = p4[iu < hi ? iu : hi - 1u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t i = i0 + (uint32_t)u * (uint32_t)G;
+                        const float4 pv = v[u];
+                        const float dx = o0 - pv.x, dy = o1 - pv.y, dz = o2 - pv.z;
+                        const float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        if (i < hi && uu - err_of(uu) <= thi) {
+                            const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+                            if (WHICH & 1) { const double ex = ax - x, ey = ay - y, ez = az - z; nn_merge(lbA, lpA, (ex * ex + ey * ey) + ez * ez, i, perm_g); }
+                            if (WHICH & 2) { const double ex = qx - x, ey = qy - y, ez = qz - z; nn_merge(lbC, lpC, (ex * ex + ey * ey) + ez * ez, i, perm_g); }
+                        }
+                    }
+                }
+                if (WHICH & 1) {
+                    const double g = group_min_f64(lbA, G);
+                    const uint32_t key = group_min_u32((lbA == g && lpA != kNone) ? perm_g[lpA] : kNone, G);
+                    const uint32_t pw = group_min_u32((lbA == g && lpA != kNone && perm_g[lpA] == key) ? lpA : kNone, G);
+                    if (pw != kNone) nn_merge(bestA, bposA, g, pw, perm_g);
+                }
+                if (WHICH & 2) {
+                    const double g = group_min_f64(lbC, G);
+                    const uint32_t key = group_min_u32((lbC == g && lpC != kNone) ? perm_g[lpC] : kNone, G);
+                    const uint32_t pw = group_min_u32((lbC == g && lpC != kNone && perm_g[lpC] == key) ? lpC : kNone, G);
+                    if (pw != kNone) nn_merge(bestC, bposC, g, pw, perm_g);
+                }
+            }
+        }
+    }
+    {   // deepest level whose far side may still be within reach of either query
+        const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+        uint32_t cnd = 0u;
+#pragma unroll
+        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= bestf ? 1u : 0u) << L;
+        cnd &= ~done & ((1u << D) - 1u);
+        done |= ~cnd;
+        go = cnd ? 31 - __clz((int)cnd) : -1;
+    }
+}
+
 // diagnostic (iba_debug_nn): the search of iba_nn_kernel on caller-supplied LiDAR-frame queries, one lane per query, run to its
 // end. mode 1: the query is the association path's (a) alone; 2: the cost path's (c) alone; 3 / 4: both paths are searched
 // together, the query as a (3) or as c (4), its partner 1e-7 beside it as the reference's two float/double islands are.
@@ -1136,6 +1271,7 @@ __global__ __launch_bounds__(256) void iba_nn_probe_kernel(DevProblem dp, int fr
 // picks it needs no further gather. At the bench shape a candidate 0.5 mrad / 5 mm / 0.1 % from the anchor has S ~ 4 cm against
 // d_M ~ 30 cm: one or two entries qualify, and no lane searches the tree.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int kCoopMax = kNNThreads / 2; // entries the lists left over that a block searches with a group of 2 .. 64 lanes each (more: one lane each)
 constexpr int kSetM = 8;              // neighbours a list holds
 // a listed neighbour: the scan point, a float lower bound of its distance to the anchor query, and (plane_cache = 1) what the
 // memoised planes at it say: flags bit 0 = the local plane is valid (pointcloud.h:699-717), bit 1 = the cost term is
@@ -1460,9 +1596,15 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                         res = cost_res(prm, prm.use_plane != 0, rec, ex, ey, ez);
                     }
                 }
-                if ((WHICH & 2) && !refit) s_res[wn - c0] = res;
+                if (WHICH & 2) s_res[wn - c0] = res;   // (NaN when the planes are refitted: the sums come from the fit kernel's distances; a left-over entry's seed is cleared either way)
             };
             uint32_t* s_ovf = (uint32_t*)(smem + lay.off_ovf);   // work entries whose keypoint has no usable set: searched in the tree below
+            // the first bound of a left-over entry's search: its nearest listed points (their positions wait in the entry's result slot)
+            auto seed = [&](uint32_t wn) {
+                const uint2 sd = ((const uint2*)s_res)[wn - c0];
+                if ((WHICH & 1) && actA && sd.x != kNone) { const float4 pv = p4[sd.x]; const double dx = ax - (double)pv.x, dy = ay - (double)pv.y, dz = az - (double)pv.z; bestA = (dx * dx + dy * dy) + dz * dz; bposA = sd.x; }
+                if ((WHICH & 2) && actC && sd.y != kNone) { const float4 pv = p4[sd.y]; const double dx = qx - (double)pv.x, dy = qy - (double)pv.y, dz = qz - (double)pv.z; bestC = (dx * dx + dy * dy) + dz * dz; bposC = sd.y; }
+            };
             uint32_t c_end = c1;                                 // entries the persistent loop hands out
             if (SETS) {
                 // ---- the anchored neighbour lists of the MapPoint keypoints are there (iba_anchor_kernel).
@@ -1489,8 +1631,11 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     const bool quick = radius < hd.dM;   // (NaN queries fail both tests)
                     // Second chance, from the whole row: with r = the distance to the nearest LISTED point, every point within r of this
                     // query is within r + S of the anchor's; if that is inside d_M they are all listed and the nearest listed point is the
-                    // nearest point. (Dense scans: d_M shrinks with the point spacing, S does not.)
-                    if ((!quick && !(S < hd.dM)) || hd.count == 0u) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; return; }
+                    // nearest point. (Dense scans: d_M shrinks with the point spacing, S does not.) An entry that fails this too goes to
+                    // the tree search WITH its nearest listed points as the first bound: a query far from the scan (a MapPoint 2 m in front
+                    // of a wall) otherwise opens every leaf within its first, poor, bound.
+                    auto leave = [&](uint32_t pa, uint32_t pc) { ((uint2*)s_res)[wn - c0] = make_uint2(pa, pc); s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; };
+                    if (hd.count == 0u) { leave(kNone, kNone); return; }
                     bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
                     SetPt abest = p0, cbest = p0;
                     const float rf = quick ? (float)radius * 1.000001f + 1e-30f : INFINITY;   // >= radius
@@ -1506,7 +1651,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                         double r2 = 0.0;
                         if ((WHICH & 1) && actA) r2 = bestA;
                         if ((WHICH & 2) && actC) r2 = fmax(r2, bestC);
-                        if (!((sqrt(r2) + S) * (1.0 + 1e-12) + 1e-12 < hd.dM)) { s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; return; }
+                        if (!((sqrt(r2) + S) * (1.0 + 1e-12) + 1e-12 < hd.dM)) { leave(bposA, bposC); return; }   // (NaN queries end here, unseeded)
                     }
                     if (dbg != 5) finish(wn, &abest, &cbest);
                 };
@@ -1531,9 +1676,26 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                 if (c_end != 0u) for (uint32_t i = tid; i < nnodes; i += T) s_nodes[i] = dp.nodes[h.node_base + i];   // some lanes search the tree after all
                 __syncthreads();
             }
+            // ---- a few entries left over by the lists: a group of lanes each — a whole wave when there are at most 8, 8 lanes when
+            //      there are 64, 2 when there are 256 (their searches would otherwise run one lane each while 500 lanes of the block wait for the slowest) ----
+            const bool coop = SETS && c_end != 0u && c_end <= (uint32_t)kCoopMax;
+            if (coop && dbg != 4) {
+                int G = 64; while ((uint32_t)(T / G) < c_end) G >>= 1;   // the largest group that takes all of them in one round
+                for (uint32_t q = (uint32_t)tid / (uint32_t)G; q < c_end; q += (uint32_t)(T / G)) {
+                    const uint32_t wn = s_ovf[q];
+                    const uint32_t cc = wn & ((1u << cg_shift) - 1u);
+                    const size_t at = entry_at(wn);
+                    const uint4 e = flist[at]; const float4 mp = fmp[at];   // (an entry is queued only if it exists and wants a search)
+                    make_queries(cc, e, mp);
+                    lane_nn_begin(IBA_LANE_NN_PASS);
+                    seed(wn);
+                    do wave_nn_visit<WHICH>(IBA_LANE_NN_PASS, tid & (G - 1), G, s_nodes, p4, perm_g, P, D); while (go >= 0);
+                    if (dbg != 5) finish(wn, nullptr, nullptr);   // every lane of the group writes the same values
+                }
+            }
             // ---- persistent lanes, refilled from the work list (all of it, or what the sets left over) ----
             bool exhausted = false;   // wave-uniform: the work list has been handed out
-            if (c_end != 0u) for (;;) {
+            if (c_end != 0u && !coop) for (;;) {
                 // ---- refill: idle lanes claim the next entries (one LDS atomic per wave) ----
                 const unsigned long long idle = __ballot(!have);
                 if (idle != 0ull && !exhausted) {
@@ -1553,6 +1715,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                             w = wn;
                             make_queries(cc, e, mp);
                             lane_nn_begin(IBA_LANE_NN_PASS);
+                            if (SETS) seed(wn);
                             have = true;
                         }
                     }

@@ -166,3 +166,21 @@ def test_anchored_neighbour_lists_follow_the_candidates(pkg, synth, abi, scene_s
     assert h1.anchor_builds == 3
     h0.close()
     h1.close()
+
+
+def test_dense_scans_leftover_entries_and_long_pair_lists(pkg, synth, abi):
+    """120 k points per scan (the reference's scan size): the 8-neighbour lists are complete only out to a few centimetres, so a few
+    per cent of the entries fail their certificate and are searched in the tree — by whole waves when a block has only a handful
+    (wave_nn_visit) — and a keyframe's pair list outgrows the association kernel's register window (noted pairs). Same bits as the
+    per-candidate search without lists, for a batch and for a single candidate."""
+    prob, meta = synth.make_scene(n_frames=3, pts_per_frame=120000, seed=5)
+    p = abi.reference_yaml_params()
+    h0, h1 = _handle(pkg, prob, p, 0), _handle(pkg, prob, p, 1)
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(2), n=24)
+    h1.eval_full(xs[:1])                     # the anchor is built around the first call's candidate
+    _same_bits(pkg, h0, h1, xs, 1)
+    left = h1.nn_left_to_tree
+    assert left > 0, "no entry was left to the tree search: the scene no longer exercises that path"
+    _same_bits(pkg, h0, h1, xs[:8], 1)
+    _same_bits(pkg, h0, h1, xs[5:6], 1)
+    h0.close(); h1.close()
