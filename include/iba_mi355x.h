@@ -273,6 +273,8 @@ int32_t iba_debug_anchor_builds(const iba_handle* h);
 /* diagnostic: list entries of the last evaluation (all candidates) that the anchored neighbour lists could not settle and the
  * tree search took over; -1 when no search ran */
 double iba_debug_nn_left_to_tree(iba_handle* h);
+/* diagnostic: mean number of (scan point, keypoint) pairs per keyframe that the last shared pair search listed; -1: none ran */
+double iba_debug_mean_pairs(iba_handle* h);
 /* debug: exact 1-NN (nanoflann semantics with the lowest-index tie rule, iba_global.cpp:116-122) of n LiDAR-frame query
  * points in the scan of local frame `frame`, run through the search kernel's own kd search, one lane per query: original point
  * index and exact squared distance. mode 1: as the association path's query alone; 2: as the cost path's alone; 3 / 4: both paths

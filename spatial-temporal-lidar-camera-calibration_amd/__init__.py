@@ -266,6 +266,12 @@ class IbaHandle:
         return int(self.lib.iba_debug_last_path(self.h))
 
     @property
+    def mean_pairs(self):
+        self.lib.iba_debug_mean_pairs.restype = C.c_double
+        self.lib.iba_debug_mean_pairs.argtypes = [C.c_void_p]
+        return float(self.lib.iba_debug_mean_pairs(self.h))
+
+    @property
     def nn_left_to_tree(self):
         self.lib.iba_debug_nn_left_to_tree.restype = C.c_double
         self.lib.iba_debug_nn_left_to_tree.argtypes = [C.c_void_p]

@@ -93,10 +93,12 @@ struct iba_handle {
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
     bool spin_wait = true;                // IBA_SPIN_WAIT=0: blocking waits only
     bool nn_sets = true;                  // IBA_NN_SETS=0: no anchored neighbour lists, every lane searches the tree (diagnostic)
+    int pair_bound = 1;                   // IBA_PAIR_BOUND: 0 = the pair search bounds the batch's motion entrywise only (diagnostic)
     int common_min_batch = 1;             // IBA_COMMON_MIN_BATCH
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
+    CommonRef cref; bool cref_ok = false; // the staged batch's reference candidate and spread (common_ref at staging time: it also fills Cand::rel)
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
     int last_nn_nrec = 0, last_nn_B = 0;   // shape of the search kernel's records of the last evaluation (iba_debug_nn_left_to_tree)
     bool he_staged = false;               // the hand-eye terms of the staged candidates were computed by the staging launch
@@ -272,7 +274,7 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
 // nearest the batch mean, rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i, both inflated for their own
 // rounding. Returns false when the batch is too wide for common pairs to pay (nominal projection spread above max_px at a
 // point 12 m out, 10 m deep), in which case every candidate searches for itself (iba_assoc_kernel).
-bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
+bool common_ref(const iba_handle* h, Cand* hc, int B, CommonRef& cr) {
     double mean[12] = {0};
     for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].R[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].t[i]; }
     for (double& m : mean) m /= (double)B;
@@ -295,7 +297,8 @@ bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
             const double a = hc[b].t[r] - ((A[r * 3] * c0.t[0] + A[r * 3 + 1] * c0.t[1]) + A[r * 3 + 2] * c0.t[2]);
             if (!(std::fabs(a) <= 1e30)) return false;
             cr.tau[r] = std::max(cr.tau[r], std::fabs(a));
-            for (int q = 0; q < 3; ++q) { const double e = std::fabs(A[r * 3 + q] - (r == q ? 1.0 : 0.0)); if (!(e <= 4.0)) return false; cr.rho[r * 3 + q] = std::max(cr.rho[r * 3 + q], e); }
+            hc[b].rel[9 + r] = a;
+            for (int q = 0; q < 3; ++q) { const double m = A[r * 3 + q] - (r == q ? 1.0 : 0.0), e = std::fabs(m); if (!(e <= 4.0)) return false; cr.rho[r * 3 + q] = std::max(cr.rho[r * 3 + q], e); hc[b].rel[r * 3 + q] = m; }
         }
     }
     double rho_row = 0, tau_max = 0;
@@ -369,6 +372,7 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     }
     else if (jets == 1) for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
     else for (int b = 0; b < B; ++b) make_cand_values(x + 7 * b, hc[b]);
+    h->cref_ok = h->common_mode > 0 && B >= h->common_min_batch && h->d_pairs.p && common_ref(h, hc, B, h->cref);
     // the block crosses PCIe by a kernel that reads the pinned ring (a copy-engine transfer of these 70 KB costs ~15 us of latency
     // at the head of every evaluation; a strided copy of the value halves alone was slower still)
     {
@@ -394,7 +398,8 @@ iba_status finish_jets(iba_handle* h, hipStream_t st) {
     Cand* dc = h->d_cands.p + (size_t)h->jets_slot * IBA_MAX_BATCH;
     if (h->jets_src) {   // the group's calling thread has been differentiating while this device's kernels ran on the values
         while (h->jets_flag->load(std::memory_order_acquire) == 0) { /* microseconds */ }
-        std::memcpy(hc, h->jets_src, sizeof(Cand) * (size_t)h->jets_B);
+        for (int b = 0; b < h->jets_B; ++b)   // the derivative half alone: the values (and Cand::rel, which is this handle's own) stay as staged
+            std::memcpy((char*)&hc[b] + offsetof(Cand, dR), (const char*)&h->jets_src[b] + offsetof(Cand, dR), offsetof(Cand, rel) - offsetof(Cand, dR));
         h->jets_src = nullptr; h->jets_flag = nullptr;
     } else
     for (int b = 0; b < h->jets_B; ++b) make_cand_jets(h->jets_x + 7 * b, hc[b]);
@@ -504,8 +509,8 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     // 2d-3d association: a batch of nearby candidates shares ONE search for the (scan point, keypoint) pairs per keyframe
     // (iba_pairs_kernel) and every candidate runs the exact test on that list (iba_assoc2_kernel); a lone candidate, a small or a
     // wide batch searches per candidate (iba_assoc_kernel). Same results either way, bit for bit.
-    CommonRef cref;
-    const bool common = h->common_mode > 0 && !frozen && B >= h->common_min_batch && h->d_pairs.p && h->last_hc && common_ref(h, h->last_hc, B, cref);
+    const CommonRef& cref = h->cref;
+    const bool common = !frozen && h->last_hc && h->cref_ok;
     h->last_path = common ? 1 : 0;
     // Anchored neighbour lists (iba_anchor_kernel): the scan points nearest to every MapPoint's query under an ANCHOR extrinsic,
     // built once and reused by every evaluation whose candidates stay near the anchor (each lane certifies its own pick, or
@@ -556,7 +561,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         {   // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
             const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
             const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
-            hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, dp, cref, h->params.max_pixel_dist, kuv_off,
+            hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, dp, cref, h->params.max_pixel_dist, kuv_off, dc, h->pair_bound ? B : 0,
                                h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
         }
         HIP_TRY(h, hipGetLastError());
@@ -853,6 +858,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_NN_SETS")) h->nn_sets = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_SPIN_WAIT")) h->spin_wait = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_ANCHOR_REACH")) h->anchor_reach = std::atof(e);
+    if (const char* e = std::getenv("IBA_PAIR_BOUND")) h->pair_bound = std::atoi(e);
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
@@ -1100,6 +1106,15 @@ double iba_debug_nn_left_to_tree(iba_handle* h) {
         std::fprintf(stderr, "left-over entries per block: 0:%d 1-8:%d 9-16:%d 17-32:%d 33-64:%d 65-128:%d 129-256:%d more:%d\n", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
     }
     return t;
+}
+// mean length of the keyframes' common pair lists of the last evaluation that shared the pair search (-1: none has)
+double iba_debug_mean_pairs(iba_handle* h) {
+    if (!h || !h->d_pcounts.p || h->pairs_epoch == 0 || h->n_frames == 0) return -1.0;
+    std::vector<uint32_t> v((size_t)h->n_frames * kCountStride);
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1.0;
+    if (hipMemcpy(v.data(), h->d_pcounts.p + (size_t)((h->pairs_epoch - 1) & 1) * (size_t)h->n_frames * kCountStride, v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    double t = 0; for (int f = 0; f < h->n_frames; ++f) t += v[(size_t)f * kCountStride];
+    return t / h->n_frames;
 }
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }
 

@@ -615,7 +615,8 @@ constexpr int kPairStage = 2048;   // (point, keypoint) hits a block parks in LD
 // grid: (ceil(max P / kPairsThreads), frames); one scan point per thread. The keypoint grid of the frame (coarse CSR + the
 // keypoints' (u, v)) sits in LDS, so a thread's walk costs LDS round trips, not L2 ones; the hits of a block are parked in LDS
 // and written out behind one atomic reservation per block.
-__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp, CommonRef cr, double max_pixel_dist, uint32_t lds_kuv_off, PairRec* __restrict__ pairs, uint32_t* __restrict__ hard,
+__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp, CommonRef cr, double max_pixel_dist, uint32_t lds_kuv_off, const Cand* __restrict__ cands, int B,
+                                                                  PairRec* __restrict__ pairs, uint32_t* __restrict__ hard,
                                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ counts_next, int pair_cap, int hard_cap) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int f = blockIdx.y;
@@ -644,11 +645,13 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
     //      wholly beyond one image border: u >= W <=> fx x + (cx - W) z >= 0 (z > 0), u < 0 <=> fx x + cx z < 0, v alike. ----
     constexpr uint32_t kBlkChunks = (uint32_t)kPairsThreads / (uint32_t)kChunk;
     bool chunk_vis = false;
+    float4 blo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), bhi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);   // this lane's chunk box (lanes < kBlkChunks)
     if (threadIdx.x < kBlkChunks) {
         const uint32_t ch = begin / (uint32_t)kChunk + threadIdx.x;
         if (ch * (uint32_t)kChunk < P) {
             const float4* bx = (const float4*)(dp.chunk_box + 8 * (h.box_base + ch));
             const float4 lo = bx[0], hi = bx[1];
+            blo = lo; bhi = hi;
             const double c3[3] = {0.5 * ((double)lo.x + (double)hi.x), 0.5 * ((double)lo.y + (double)hi.y), 0.5 * ((double)lo.z + (double)hi.z)};
             const double e3[3] = {0.5 * ((double)hi.x - (double)lo.x), 0.5 * ((double)hi.y - (double)lo.y), 0.5 * ((double)hi.z - (double)lo.z)};
             double qc[3], ex[3], m[3];
@@ -688,6 +691,49 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
     }
     __syncthreads();
     if (!s_n[3]) return;   // no candidate sees any point of this block
+    // ---- how far the candidates move the points of THIS block (512 consecutive tree positions: a box with centre c and half extent
+    //      e in the LiDAR frame, qc = R_0 c + t_0, ex = |R_0| e under the reference): candidate b moves q_0 by M_b q_0 + a_b
+    //      (Cand::rel), so |q_b - q_0|_i <= |(M_b qc + a_b)_i| + sum_j |M_b|_ij ex_j for every point of the box. Wave 0: lane b
+    //      evaluates candidate b, the maximum per axis goes to LDS (as floats rounded up). The entrywise bound below (rho, tau: every
+    //      term maximised over the batch on its own) is about twice as wide for a batch of random perturbations; the smaller of
+    //      the two is used. ----
+    float* s_delta = (float*)(s_n + 16);
+    if (threadIdx.x < 64) {
+        float l[3] = {blo.x, blo.y, blo.z}, u[3] = {bhi.x, bhi.y, bhi.z};   // union of the block's chunk boxes (a NaN box of an empty chunk drops out of fminf / fmaxf)
+#pragma unroll
+        for (int o = 1; o < (int)kBlkChunks; o <<= 1)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { l[i] = fminf(l[i], __shfl_xor(l[i], o)); u[i] = fmaxf(u[i], __shfl_xor(u[i], o)); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { l[i] = __shfl(l[i], 0); u[i] = __shfl(u[i], 0); }
+        const double c3[3] = {0.5 * ((double)l[0] + (double)u[0]), 0.5 * ((double)l[1] + (double)u[1]), 0.5 * ((double)l[2] + (double)u[2])};
+        const double e3[3] = {0.5 * ((double)u[0] - (double)l[0]), 0.5 * ((double)u[1] - (double)l[1]), 0.5 * ((double)u[2] - (double)l[2])};
+        double qc[3], ex[3];
+        for (int i = 0; i < 3; ++i) {
+            qc[i] = ((cr.R[i * 3] * c3[0] + cr.R[i * 3 + 1] * c3[1]) + cr.R[i * 3 + 2] * c3[2]) + cr.t[i];
+            ex[i] = ((fabs(cr.R[i * 3]) * e3[0] + fabs(cr.R[i * 3 + 1]) * e3[1]) + fabs(cr.R[i * 3 + 2]) * e3[2]) * (1.0 + 1e-9) + 1e-9 * ((fabs(c3[0]) + fabs(c3[1])) + fabs(c3[2])) + 1e-12;   // (+ the rounding of qc itself)
+        }
+        const double scale = (fabs(qc[0]) + fabs(qc[1])) + fabs(qc[2]) + (ex[0] + ex[1]) + ex[2];
+        float m[3] = {0.f, 0.f, 0.f};
+        const int b = (int)threadIdx.x;
+        if (b < B) {
+            const double* rl = cands[b].rel;
+            for (int i = 0; i < 3; ++i) {
+                const double mi = (fabs(((rl[i * 3] * qc[0] + rl[i * 3 + 1] * qc[1]) + rl[i * 3 + 2] * qc[2]) + rl[9 + i]) + ((fabs(rl[i * 3]) * ex[0] + fabs(rl[i * 3 + 1]) * ex[1]) + fabs(rl[i * 3 + 2]) * ex[2])) * (1.0 + 1e-9) + 1e-12 * scale + 1e-13;
+                m[i] = (float)mi * 1.0000002f + 1e-30f;   // >= mi (NaN stays NaN)
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const float other = __shfl_xor(m[i], o); m[i] = (m[i] != m[i] || other != other) ? __builtin_nanf("") : fmaxf(m[i], other); }
+        if (threadIdx.x == 0) {   // NaN (an empty block's box, a NaN candidate): the entrywise bound alone
+            const bool on = B > 0;   // (B = 0: the entrywise bound alone, IBA_PAIR_BOUND=0)
+            s_delta[0] = on && m[0] == m[0] ? m[0] : INFINITY; s_delta[1] = on && m[1] == m[1] ? m[1] : INFINITY; s_delta[2] = on && m[2] == m[2] ? m[2] : INFINITY;
+        }
+    }
+    __syncthreads();
+    const double wdx = (double)s_delta[0], wdy = (double)s_delta[1], wdz = (double)s_delta[2];
     // ---- the point under the reference candidate, the batch's bound on its motion, its search window ----
     int kind = 0;   // 0: nothing to do, 1: walk the grid, 2: hard point
     double u0 = 0, v0 = 0, r = 0;
@@ -698,9 +744,9 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
         const double z0 = ((cr.R[6] * x + cr.R[7] * y) + cr.R[8] * z) + cr.t[2];
         const double ax = fabs(x0), ay = fabs(y0), az = fabs(z0);
         const double round_off = 1e-13 * ((ax + ay) + az) + 1e-13;   // of q_0 itself and of the candidates' own q_b (a few ulps of |q|)
-        const double dx = ((cr.rho[0] * ax + cr.rho[1] * ay) + cr.rho[2] * az) + cr.tau[0] + round_off;
-        const double dy = ((cr.rho[3] * ax + cr.rho[4] * ay) + cr.rho[5] * az) + cr.tau[1] + round_off;
-        const double dz = ((cr.rho[6] * ax + cr.rho[7] * ay) + cr.rho[8] * az) + cr.tau[2] + round_off;
+        const double dx = fmin(((cr.rho[0] * ax + cr.rho[1] * ay) + cr.rho[2] * az) + cr.tau[0], wdx) + round_off;
+        const double dy = fmin(((cr.rho[3] * ax + cr.rho[4] * ay) + cr.rho[5] * az) + cr.tau[1], wdy) + round_off;
+        const double dz = fmin(((cr.rho[6] * ax + cr.rho[7] * ay) + cr.rho[8] * az) + cr.tau[2], wdz) + round_off;
         if (!(z0 == z0) || z0 < -dz) kind = 0;   // NaN: fails every candidate's own depth test; z0 < -dz: behind every candidate's camera
         else if (!(z0 > 2.0 * dz)) {
             // depth not bounded away from zero: z_b in (0, z0 + dz]. Far enough to the side, every candidate still sees it outside

@@ -16,4 +16,5 @@ ts = []
 for _ in range(n):
     t0 = time.perf_counter(); c, _n = h.eval_full(xs); ts.append(time.perf_counter() - t0)
 print("kitti shape %d KF: %.3f ms per call, n_corr %.0f, cnt_3d_3d %.0f, anchor builds %d" % (kf, np.median(ts) * 1e3, np.mean([a.n_corr for a in c]), np.mean([a.cnt_3d_3d for a in c]), h.anchor_builds), flush=True)
+print("pairs per keyframe: %.0f" % h.mean_pairs, flush=True)
 print("entries left to the tree search: %.0f of ~%.0f wanted (all candidates)" % (h.nn_left_to_tree, sum(a.cnt_3d_3d for a in c)), flush=True)
