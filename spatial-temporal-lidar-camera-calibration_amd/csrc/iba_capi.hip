@@ -112,6 +112,7 @@ struct iba_handle {
     DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
     DevBuf<PlaneRec> plane_cost, plane_local;
+    DevBuf<uint8_t> plane_ok;             // the association's verdicts on plane_local per scan point (iba_verdict_kernel), rebuilt with every parameter set
     DevBuf<double4> d_frefit;   // plane_cache = 0: per list entry, query offset + neighbour of the cost path between the search and the fit kernel
     DevBuf<PlaneRec> scratch_cost, scratch_local;   // plane_cache = 0: (scratch_cap + 1) x n_pt_total records
     int scratch_cap = -1; bool scratch_local_aliases = false; int64_t n_pt_total = 0;
@@ -146,7 +147,7 @@ struct iba_handle {
         dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p; dp.chunk_box = chunk_box.p; dp.pts4 = pts4.p;
         dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.kp_fl = kp_fl.p; dp.coarse_start = coarse_start.p; dp.crec = crec.p;
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
-        dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
+        dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.plane_ok = plane_ok.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
         dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u);
         return dp;
@@ -333,6 +334,12 @@ iba_status compute_plane_cache(iba_handle* h) {
         if (!h->plane_local.p) HIP_TRY(h, h->plane_local.alloc(h->plane_cost.n));
         HIP_TRY(h, run(r2l, p.neigh_max_pts, h->plane_local.p));
         h->plane_local_r2 = r2l; h->plane_local_max = p.neigh_max_pts;
+    }
+    if (h->plane_cost.n) {   // the thresholds of the two verdicts are parameters too: every call of this function rebuilds them
+        if (!h->plane_ok.p) HIP_TRY(h, h->plane_ok.alloc(h->plane_cost.n));
+        hipLaunchKernelGGL(iba_verdict_kernel, dim3((unsigned)((h->plane_cost.n + 255) / 256)), dim3(256), 0, h->stream, h->plane_local_aliases_cost ? h->plane_cost.p : h->plane_local.p, h->dprm, h->plane_ok.p, h->plane_cost.n);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     return IBA_OK;
 }
@@ -652,7 +659,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_anchor.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_anchor.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);

@@ -41,6 +41,7 @@ struct DevProblem {
     const float2* match_uv;    // [slot][K] matched covisible keypoint, NaN = no match
     const PlaneRec* plane_cost;   // x-independent plane records (norm_radius / norm_max_pts)
     const PlaneRec* plane_local;  // (neigh_radius / neigh_max_pts)
+    const uint8_t* plane_ok;      // what the association asks of plane_local, per scan point: bit 0 ComputeLocalNeighbor is valid, bit 1 the plane passes (iba_verdict_kernel; nullptr when the planes are refitted)
     int32_t n_frames;
     int64_t n_kp_total;
     // plane_cache = 0: per-candidate plane records refitted inside every evaluation (slot 0 = frozen problem)

@@ -122,7 +122,6 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     n_corr = (uint32_t)(total & 0xffffull);
     const bool usedA = (want & 1) && !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
     const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
-    const PlaneRec* planes_local = dp.plane_local + h.pt_base;
     uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
     float4* fm = fmp + ((size_t)b * nf + f) * (size_t)flist_stride;   // the MapPoint of every entry, for the search kernel
     uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
@@ -158,11 +157,10 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
         if (usedA && ((e >> 16) & 3u) == 3u) {
             const uint32_t pos = s_pos[i];
             if (refit) { ax_ = pos; flags |= kFlagA; }
-            else {
-                const PlaneRec rec = planes_local[pos];
-                const bool neigh_ok = local_neigh_ok(prm, rec);                     // pointcloud.h:752
-                if (neigh_ok && local_plane_ok(prm, rec)) ax_ = pos;               // bvalid_plane (:231)
-                if (neigh_ok) flags |= kFlagA;   // no 3d-3d block either otherwise (the `continue` at :209-211)
+            else {   // the two verdicts of the memoised local plane at the matched point: one byte instead of the 48-byte record
+                const uint32_t v = dp.plane_ok[h.pt_base + pos];
+                if ((v & 3u) == 3u) ax_ = pos;      // ComputeLocalNeighbor valid (pointcloud.h:752) and bvalid_plane (iba_local.cpp:231)
+                if (v & 1u) flags |= kFlagA;        // no 3d-3d block either otherwise (the `continue` at :209-211)
             }
         }
         if (usedC && prm.use_3d3d && ((e >> 16) & 1u)) flags |= kFlagC;
@@ -1919,6 +1917,16 @@ __global__ __launch_bounds__(64) void iba_fit_kernel(DevProblem dp, DevParams pr
 // sums the per-frame records of each candidate in a fixed order, plus the search kernel's own (narrow) records.
 // grid: B blocks of kReduceThreads threads: 16 record groups x 64 slots for the wide records; 128 record lanes x 8 slots
 // for the narrow ones.
+// the association's two questions to the memoised local plane of every scan point (local_neigh_ok / local_plane_ok), answered once per
+// parameter set: the tail of the association kernels gathers one byte per matched point
+__global__ __launch_bounds__(256) void iba_verdict_kernel(const PlaneRec* __restrict__ planes_local, DevParams prm, uint8_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const PlaneRec rec = planes_local[i];
+    const bool neigh_ok = local_neigh_ok(prm, rec);
+    out[i] = (uint8_t)((neigh_ok ? 1u : 0u) | (neigh_ok && local_plane_ok(prm, rec) ? 2u : 0u));
+}
+
 __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, const double* __restrict__ nn_partials, int nn_nrec,
                                                                      double* __restrict__ out) {
     constexpr int NG = kReduceThreads / kPartialStride;
