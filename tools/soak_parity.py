@@ -43,7 +43,7 @@ t0 = time.time()
 for sc in range(n_scenes):
     seed = seed0 + sc
     rng = np.random.default_rng(seed)
-    nf = int(rng.integers(1, 5)); pts = int(rng.choice([300, 900, 2500, 6000, 14000, 40000])); kp = int(rng.choice([150, 600, 2000, 3000]))
+    nf = int(rng.integers(1, 5)); pts = int(rng.choice([300, 900, 2500, 6000, 14000, 40000, 120000], p=[0.17, 0.17, 0.17, 0.17, 0.14, 0.12, 0.06])); kp = int(rng.choice([150, 600, 2000, 3000]))
     prob, meta = synth.make_scene(n_frames=nf, pts_per_frame=pts, n_keypoints=kp, seed=seed)
     if rng.random() < 0.4:   # ragged frames: truncated scans down to a handful of points, or none at all
         a = {k: v.copy() for k, v in prob.arrays.items()}
@@ -80,6 +80,14 @@ for sc in range(n_scenes):
             if dev > 1e-6: msgs.append((b, "H", dev))
             m = np.abs(Ho) > 1e-6 * np.max(np.abs(Ho))
             worst_entry = max(worst_entry, float(np.max(np.abs(nfm[b].H_np() - Ho)[m] / np.abs(Ho)[m])))
+    # the candidates drift a little between calls (the anchored neighbour lists of the first call serve the next ones)
+    xs_d = xs + rng.normal(size=xs.shape) * np.array([1, 1, 1, 5, 5, 5, 2]) * scale * float(rng.choice([0.05, 0.3, 1.0]))
+    for b, (g, r) in enumerate(zip(h.eval_cost(xs_d), o.eval_cost(p, xs_d))):
+        for k in INT:
+            if getattr(g, k) != getattr(r, k): msgs.append((b, "drifted", k, getattr(g, k), getattr(r, k)))
+        for k in ("f1", "f2"):
+            a, rr = getattr(g, k), getattr(r, k)
+            if not ((np.isnan(a) and np.isnan(rr)) or a == rr or abs(a - rr) <= 1e-10 * abs(rr) + 1e-15): msgs.append((b, "drifted", k, a, rr))
     # frozen problem (BuildProblem at xs[0], residual blocks at the other candidates) and the raw correspondence set of a frame
     h.build_problem(xs[0]); o.build_problem(p, xs[0])
     for b, (gf, of) in enumerate(zip(h.eval_factors(xs), o.eval_factors(p, xs))):
