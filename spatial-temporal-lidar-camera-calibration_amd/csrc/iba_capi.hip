@@ -372,6 +372,7 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
     h->last_hc = hc;
     h->jets_x = nullptr; h->jets_src = nullptr; h->jets_flag = nullptr;
+    if (!pre && jets == 2 && B <= 4) jets = 1;   // a few candidates: their derivatives cost the host less (0.6 us each) than the second fetch of the block
     if (pre) {   // the group's block: complete, or (pre_flag) with the derivative half still being computed by the calling thread
         std::memcpy(hc, pre, sizeof(Cand) * (size_t)B);
         if (pre_flag && jets == 2) { h->jets_src = pre; h->jets_flag = pre_flag; h->jets_B = B; h->jets_slot = slot; }
@@ -568,7 +569,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         {   // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
             const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
             const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
-            hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, dp, cref, h->params.max_pixel_dist, kuv_off, dc, h->pair_bound ? B : 0,
+            hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, dp, cref, h->params.max_pixel_dist, kuv_off, dc, (h->pair_bound && B > 1) ? B : 0,
                                h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
         }
         HIP_TRY(h, hipGetLastError());

@@ -696,42 +696,44 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
     //      term maximised over the batch on its own) is about twice as wide for a batch of random perturbations; the smaller of
     //      the two is used. ----
     float* s_delta = (float*)(s_n + 16);
-    if (threadIdx.x < 64) {
-        float l[3] = {blo.x, blo.y, blo.z}, u[3] = {bhi.x, bhi.y, bhi.z};   // union of the block's chunk boxes (a NaN box of an empty chunk drops out of fminf / fmaxf)
+    double wdx = INFINITY, wdy = INFINITY, wdz = INFINITY;
+    if (B > 0) {   // (B = 0: a lone candidate — the entrywise bound is zero but for rounding — or IBA_PAIR_BOUND=0)
+        if (threadIdx.x < 64) {
+            float l[3] = {blo.x, blo.y, blo.z}, u[3] = {bhi.x, bhi.y, bhi.z};   // union of the block's chunk boxes (a NaN box of an empty chunk drops out of fminf / fmaxf)
 #pragma unroll
-        for (int o = 1; o < (int)kBlkChunks; o <<= 1)
+            for (int o = 1; o < (int)kBlkChunks; o <<= 1)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { l[i] = fminf(l[i], __shfl_xor(l[i], o)); u[i] = fmaxf(u[i], __shfl_xor(u[i], o)); }
+                for (int i = 0; i < 3; ++i) { l[i] = fminf(l[i], __shfl_xor(l[i], o)); u[i] = fmaxf(u[i], __shfl_xor(u[i], o)); }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { l[i] = __shfl(l[i], 0); u[i] = __shfl(u[i], 0); }
-        const double c3[3] = {0.5 * ((double)l[0] + (double)u[0]), 0.5 * ((double)l[1] + (double)u[1]), 0.5 * ((double)l[2] + (double)u[2])};
-        const double e3[3] = {0.5 * ((double)u[0] - (double)l[0]), 0.5 * ((double)u[1] - (double)l[1]), 0.5 * ((double)u[2] - (double)l[2])};
-        double qc[3], ex[3];
-        for (int i = 0; i < 3; ++i) {
-            qc[i] = ((cr.R[i * 3] * c3[0] + cr.R[i * 3 + 1] * c3[1]) + cr.R[i * 3 + 2] * c3[2]) + cr.t[i];
-            ex[i] = ((fabs(cr.R[i * 3]) * e3[0] + fabs(cr.R[i * 3 + 1]) * e3[1]) + fabs(cr.R[i * 3 + 2]) * e3[2]) * (1.0 + 1e-9) + 1e-9 * ((fabs(c3[0]) + fabs(c3[1])) + fabs(c3[2])) + 1e-12;   // (+ the rounding of qc itself)
-        }
-        const double scale = (fabs(qc[0]) + fabs(qc[1])) + fabs(qc[2]) + (ex[0] + ex[1]) + ex[2];
-        float m[3] = {0.f, 0.f, 0.f};
-        const int b = (int)threadIdx.x;
-        if (b < B) {
-            const double* rl = cands[b].rel;
+            for (int i = 0; i < 3; ++i) { l[i] = __shfl(l[i], 0); u[i] = __shfl(u[i], 0); }
+            const double c3[3] = {0.5 * ((double)l[0] + (double)u[0]), 0.5 * ((double)l[1] + (double)u[1]), 0.5 * ((double)l[2] + (double)u[2])};
+            const double e3[3] = {0.5 * ((double)u[0] - (double)l[0]), 0.5 * ((double)u[1] - (double)l[1]), 0.5 * ((double)u[2] - (double)l[2])};
+            double qc[3], ex[3];
             for (int i = 0; i < 3; ++i) {
-                const double mi = (fabs(((rl[i * 3] * qc[0] + rl[i * 3 + 1] * qc[1]) + rl[i * 3 + 2] * qc[2]) + rl[9 + i]) + ((fabs(rl[i * 3]) * ex[0] + fabs(rl[i * 3 + 1]) * ex[1]) + fabs(rl[i * 3 + 2]) * ex[2])) * (1.0 + 1e-9) + 1e-12 * scale + 1e-13;
-                m[i] = (float)mi * 1.0000002f + 1e-30f;   // >= mi (NaN stays NaN)
+                qc[i] = ((cr.R[i * 3] * c3[0] + cr.R[i * 3 + 1] * c3[1]) + cr.R[i * 3 + 2] * c3[2]) + cr.t[i];
+                ex[i] = ((fabs(cr.R[i * 3]) * e3[0] + fabs(cr.R[i * 3 + 1]) * e3[1]) + fabs(cr.R[i * 3 + 2]) * e3[2]) * (1.0 + 1e-9) + 1e-9 * ((fabs(c3[0]) + fabs(c3[1])) + fabs(c3[2])) + 1e-12;   // (+ the rounding of qc itself)
+            }
+            const double scale = (fabs(qc[0]) + fabs(qc[1])) + fabs(qc[2]) + (ex[0] + ex[1]) + ex[2];
+            float m[3] = {0.f, 0.f, 0.f};
+            const int b = (int)threadIdx.x;
+            if (b < B) {
+                const double* rl = cands[b].rel;
+                for (int i = 0; i < 3; ++i) {
+                    const double mi = (fabs(((rl[i * 3] * qc[0] + rl[i * 3 + 1] * qc[1]) + rl[i * 3 + 2] * qc[2]) + rl[9 + i]) + ((fabs(rl[i * 3]) * ex[0] + fabs(rl[i * 3 + 1]) * ex[1]) + fabs(rl[i * 3 + 2]) * ex[2])) * (1.0 + 1e-9) + 1e-12 * scale + 1e-13;
+                    m[i] = (float)mi * 1.0000002f + 1e-30f;   // >= mi (NaN stays NaN)
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const float other = __shfl_xor(m[i], o); m[i] = (m[i] != m[i] || other != other) ? __builtin_nanf("") : fmaxf(m[i], other); }
+            if (threadIdx.x == 0) {   // NaN (an empty block's box, a NaN candidate): the entrywise bound alone
+                s_delta[0] = m[0] == m[0] ? m[0] : INFINITY; s_delta[1] = m[1] == m[1] ? m[1] : INFINITY; s_delta[2] = m[2] == m[2] ? m[2] : INFINITY;
             }
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { const float other = __shfl_xor(m[i], o); m[i] = (m[i] != m[i] || other != other) ? __builtin_nanf("") : fmaxf(m[i], other); }
-        if (threadIdx.x == 0) {   // NaN (an empty block's box, a NaN candidate): the entrywise bound alone
-            const bool on = B > 0;   // (B = 0: the entrywise bound alone, IBA_PAIR_BOUND=0)
-            s_delta[0] = on && m[0] == m[0] ? m[0] : INFINITY; s_delta[1] = on && m[1] == m[1] ? m[1] : INFINITY; s_delta[2] = on && m[2] == m[2] ? m[2] : INFINITY;
-        }
+        __syncthreads();
+        wdx = (double)s_delta[0]; wdy = (double)s_delta[1]; wdz = (double)s_delta[2];
     }
-    __syncthreads();
-    const double wdx = (double)s_delta[0], wdy = (double)s_delta[1], wdz = (double)s_delta[2];
     // ---- the point under the reference candidate, the batch's bound on its motion, its search window ----
     int kind = 0;   // 0: nothing to do, 1: walk the grid, 2: hard point
     double u0 = 0, v0 = 0, r = 0;
