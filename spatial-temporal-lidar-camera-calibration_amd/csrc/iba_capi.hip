@@ -71,7 +71,6 @@ struct iba_handle {
     int nn_cg_max = 8;                    // candidates per search block (power of two <= kMaxGroup)
     bool nn_cg_fixed = false;             // IBA_NN_CG given: no adaptation to the batch size
     DevBuf<uint32_t> d_lcount, d_lcount_frozen;   // work-list length per (candidate, frame)
-    DevBuf<float4> d_fmp, d_fmp_frozen;   // MapPoint of every work-list entry
     uint32_t max_slots = 0;               // covisible keyframes of the busiest frame
     uint32_t lstride = 1;                 // entries per (candidate, frame) row of the lists: no list is longer than maxKw
     int nn_ns = 1;                        // search blocks per (frame, candidate group): ceil(maxKw / kSliceW)
@@ -455,9 +454,8 @@ iba_status ensure_lists(iba_handle* h, int B, hipStream_t st) {
     if (h->assoc_cap >= B && (h->params.plane_cache || h->d_frefit.p)) return IBA_OK;
     B = std::max(B, h->assoc_cap);
     HIP_TRY(h, hipStreamSynchronize(st)); HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->d_flist.release(); h->d_fcount.release(); h->d_lcount.release(); h->d_fmp.release();
+    h->d_flist.release(); h->d_fcount.release(); h->d_lcount.release();
     HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
-    HIP_TRY(h, h->d_fmp.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
     HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
     HIP_TRY(h, h->d_lcount.alloc((size_t)B * std::max(h->n_frames, 1)));
     h->d_frefit.release();
@@ -478,7 +476,6 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     uint32_t* lc = frozen ? h->d_lcount_frozen.p : h->d_lcount.p;
     const DevProblem dp = h->dev_problem();
     const int nrec = factors ? h->nrec : nf;
-    float4* fm = frozen ? h->d_fmp_frozen.p : h->d_fmp.p;
     // candidates per search block: a power of two; list positions are cut into slices of a fixed width
     // candidates per search block: 8 fill a wave with neighbours that walk the same leaves, but a small batch then leaves the GPU
     // short of blocks and every block waits for its slowest search: fewer per block below 24 candidates (measured at 200 keyframes:
@@ -574,10 +571,10 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         }
         HIP_TRY(h, hipGetLastError());
         hipLaunchKernelGGL(iba_assoc2_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                           h->d_frame_partials.p, nrec, h->d_he.p, fl, fm, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
+                           h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
     } else
     hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                       h->d_frame_partials.p, nrec, (uint32_t*)nullptr, h->d_he.p, fl, fm, fc, lc, (int)h->lstride);
+                       h->d_frame_partials.p, nrec, (uint32_t*)nullptr, h->d_he.p, fl, fc, lc, (int)h->lstride);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_mid, st));
     if (refit && (want & 1)) {
@@ -593,7 +590,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         auto launch_nn = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             h->last_nn_nrec = nn_nrec; h->last_nn_B = B;
-            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, fm, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, anchor); };
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, anchor); };
             if (sets && MODE != kRefitSums) { if (wA && wC) go(iba_nn_kernel<3, MODE, 1>); else if (wA) go(iba_nn_kernel<1, MODE, 1>); else go(iba_nn_kernel<2, MODE, 1>); }
             else { if (wA && wC) go(iba_nn_kernel<3, MODE, 0>); else if (wA) go(iba_nn_kernel<1, MODE, 0>); else go(iba_nn_kernel<2, MODE, 0>); }
         };
@@ -660,7 +657,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_fmp.release(); h->d_fmp_frozen.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_anchor.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_anchor.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -891,7 +888,6 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(h->nrec, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
     if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
     if ((er = h->d_flist_frozen.alloc((size_t)std::max(nf, 1) * h->lstride)) != hipSuccess) return bail("alloc flist", er);
-    if ((er = h->d_fmp_frozen.alloc((size_t)std::max(nf, 1) * h->lstride)) != hipSuccess) return bail("alloc fmp", er);
     if ((er = h->d_fcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc fcount", er);
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
     if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
@@ -1054,7 +1050,7 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
     {
         hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * ((h->n_frames + 7) / 8)), dim3(kThreads), h->alay.total, h->stream, KArgs{h->dev_problem(), h->dprm, h->alay}, dc, 1, 0,
-                           h->d_frame_partials.p, h->n_frames, h->d_corr.p, h->d_he.p, h->d_flist_frozen.p, h->d_fmp_frozen.p, h->d_fcount_frozen.p, h->d_lcount_frozen.p, (int)h->lstride);
+                           h->d_frame_partials.p, h->n_frames, h->d_corr.p, h->d_he.p, h->d_flist_frozen.p, h->d_fcount_frozen.p, h->d_lcount_frozen.p, (int)h->lstride);
         HIP_TRY(h, hipGetLastError());
     }
     const uint64_t k0 = h->h_kp_off[lf], K = h->h_kp_off[lf + 1] - k0;

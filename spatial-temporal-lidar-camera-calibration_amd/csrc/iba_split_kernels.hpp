@@ -81,12 +81,11 @@ template <class PRM> __device__ __forceinline__ double cost_res(const PRM& prm, 
 typedef __attribute__((address_space(4))) const KArgs KArgsC;
 __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, const uint32_t* s_best_idx, const uint32_t* s_kfl, uint32_t* s_list,
                                            double* s_red, const double* s_rel, const uint32_t K, const int want, const int dbg, const bool refit, const int b, const int f, const int nf,
-                                           double* __restrict__ part, const double* __restrict__ he, uint4* __restrict__ flist, float4* __restrict__ fmp,
+                                           double* __restrict__ part, const double* __restrict__ he, uint4* __restrict__ flist,
                                            uint32_t* __restrict__ fcount, uint32_t* __restrict__ lcount, const int flist_stride) {
 #define dp (ka->dp)
 #define prm (ka->prm)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float4* kp_mp = dp.kp_mp + h.kp_base;
     const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
 
     const double s = cd.s;
@@ -123,7 +122,6 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     const bool usedA = (want & 1) && !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
     const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
     uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
-    float4* fm = fmp + ((size_t)b * nf + f) * (size_t)flist_stride;   // the MapPoint of every entry, for the search kernel
     uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
     {
         const int sh = usedC ? 16 : 32;   // which of the two lists this evaluation builds
@@ -165,7 +163,6 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
         }
         if (usedC && prm.use_3d3d && ((e >> 16) & 1u)) flags |= kFlagC;
         fl[i] = make_uint4(k, ax_, kNone, flags);   // .z (the 3d-3d block) is filled in by iba_nn_kernel
-        if (flags) fm[i] = kp_mp[k];
     }
     if (dbg == 7) return;
     // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328): only the slots whose match bit is set
@@ -244,7 +241,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
 #endif
 __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want,
                                                              double* __restrict__ frame_partials, int nrec, uint32_t* __restrict__ corr_out,
-                                                             const double* __restrict__ he, uint4* __restrict__ flist, float4* __restrict__ fmp, uint32_t* __restrict__ fcount,
+                                                             const double* __restrict__ he, uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
                                                              uint32_t* __restrict__ lcount, int flist_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
     KArgsC* ka = (KArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // see iba_frame_kernel: parameter blocks are read where they are used
@@ -575,7 +572,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 
     if (dbg == 5) return;
     IBA_RELOAD();
-    assoc_tail(ka, h, cd, c, s_best_idx, s_kfl, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fmp, fcount, lcount, flist_stride);
+    assoc_tail(ka, h, cd, c, s_best_idx, s_kfl, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
 #undef dp
 #undef prm
 #undef lay
@@ -855,7 +852,7 @@ __device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* 
 constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
 constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
 __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
-                                                              const double* __restrict__ he, uint4* __restrict__ flist, float4* __restrict__ fmp, uint32_t* __restrict__ fcount,
+                                                              const double* __restrict__ he, uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
                                                               uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hard,
                                                               const uint32_t* __restrict__ counts, int pair_cap, int hard_cap) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -995,7 +992,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
         for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<2>(c, gcs, u, v, pos); }
     __syncthreads();
     if (dbg == 5) return;
-    assoc_tail(ka, h, cd, c, s_best_idx, s_kfl, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fmp, fcount, lcount, flist_stride);
+    assoc_tail(ka, h, cd, c, s_best_idx, s_kfl, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
 #undef dp
 #undef prm
 #undef lay
@@ -1484,7 +1481,7 @@ __global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, Se
 // direct pass keeps two entries' loads in registers
 template <int WHICH, int REFIT, int SETS>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS ? 4 : IBA_NN_WAVES, SETS ? 4 : IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
-                                                                                                  double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist, const float4* __restrict__ fmp,
+                                                                                                  double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist,
                                                                                                   const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit,
                                                                                                   const SetPt* __restrict__ anchor) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1551,6 +1548,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
     const uint32_t W = (i_hi - i_lo) << cg_shift;   // <= kSliceW * kMaxGroup result slots
 
     const float4* p4 = dp.pts4 + h.pt_base;
+    const float4* kmp = dp.kp_mp + h.kp_base;   // the MapPoint of a list entry's keypoint (shared by the candidates: L2)
     const uint32_t* perm_g = dp.perm + h.pt_base;
     const PlaneRec* planes_cost = dp.plane_cost + h.pt_base;
     const PlaneRec* planes_local = dp.plane_local + h.pt_base;
@@ -1663,7 +1661,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                 auto fetch = [&](uint32_t wn, uint4& e, float4& mp) {
                     e = make_uint4(0u, 0u, 0u, 0u); mp = make_float4(0.f, 0.f, 0.f, 0.f);
                     const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
-                    if (wn < c1 && il < s_n[cc]) { const size_t at = entry_at(wn); e = flist[at]; mp = fmp[at]; }
+                    if (wn < c1 && il < s_n[cc]) { e = flist[entry_at(wn)]; if (e.w & kWantMask) mp = kmp[e.x]; }
                 };
                 auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, const AnchorHdr& hd, const SetPt& p0, const unsigned char* row) {
                     make_queries(wn & ((1u << cg_shift) - 1u), e, mp);
@@ -1731,7 +1729,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     const uint32_t wn = s_ovf[q];
                     const uint32_t cc = wn & ((1u << cg_shift) - 1u);
                     const size_t at = entry_at(wn);
-                    const uint4 e = flist[at]; const float4 mp = fmp[at];   // (an entry is queued only if it exists and wants a search)
+                    const uint4 e = flist[at]; const float4 mp = kmp[e.x];   // (an entry is queued only if it exists and wants a search)
                     make_queries(cc, e, mp);
                     lane_nn_begin(IBA_LANE_NN_PASS);
                     seed(wn);
@@ -1756,7 +1754,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                         const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
                         uint4 e = make_uint4(0u, 0u, 0u, 0u);
                         float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (wn < c1 && il < s_n[cc]) { const size_t at = entry_at(wn); e = flist[at]; mp = fmp[at]; }
+                        if (wn < c1 && il < s_n[cc]) { e = flist[entry_at(wn)]; if (e.w & kWantMask) mp = kmp[e.x]; }
                         if (e.w & kWantMask) {
                             w = wn;
                             make_queries(cc, e, mp);
