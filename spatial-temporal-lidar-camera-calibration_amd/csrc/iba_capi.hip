@@ -134,6 +134,10 @@ struct iba_handle {
     double* h_partials_dev = nullptr;     // the same buffer as the kernels see it: the last kernel of a chain writes the sums there (no D2H copy)
     Cand* h_cands_dev = nullptr;          // the pinned candidate ring as the fetch kernel sees it
     hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    // The staging launch of a cost evaluation (candidates -> device, hand-eye terms) runs on a stream of its own beside the pair search,
+    // which needs neither: ev_entry orders it behind the caller's stream, the slot's ring event brings the caller's stream back
+    // before the first kernel that reads the candidates (IBA_SIDE_STREAM=0: one stream, staging first).
+    hipStream_t side = nullptr; hipEvent_t ev_entry = nullptr; int side_on = 1; int head_slot = -1; bool head_deferred = false; int head_B = 0;
     bool ring_used[kRing] = {false, false, false, false};
     int ring_next = 0;
     std::vector<FrameHdr> h_frames;
@@ -274,7 +278,7 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
 // nearest the batch mean, rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i, both inflated for their own
 // rounding. Returns false when the batch is too wide for common pairs to pay (nominal projection spread above max_px at a
 // point 12 m out, 10 m deep), in which case every candidate searches for itself (iba_assoc_kernel).
-bool common_ref(const iba_handle* h, Cand* hc, int B, CommonRef& cr) {
+bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
     double mean[12] = {0};
     for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].R[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].t[i]; }
     for (double& m : mean) m /= (double)B;
@@ -297,8 +301,8 @@ bool common_ref(const iba_handle* h, Cand* hc, int B, CommonRef& cr) {
             const double a = hc[b].t[r] - ((A[r * 3] * c0.t[0] + A[r * 3 + 1] * c0.t[1]) + A[r * 3 + 2] * c0.t[2]);
             if (!(std::fabs(a) <= 1e30)) return false;
             cr.tau[r] = std::max(cr.tau[r], std::fabs(a));
-            hc[b].rel[9 + r] = a;
-            for (int q = 0; q < 3; ++q) { const double m = A[r * 3 + q] - (r == q ? 1.0 : 0.0), e = std::fabs(m); if (!(e <= 4.0)) return false; cr.rho[r * 3 + q] = std::max(cr.rho[r * 3 + q], e); hc[b].rel[r * 3 + q] = m; }
+            cr.rel[b][9 + r] = (float)a;
+            for (int q = 0; q < 3; ++q) { const double m = A[r * 3 + q] - (r == q ? 1.0 : 0.0), e = std::fabs(m); if (!(e <= 4.0)) return false; cr.rho[r * 3 + q] = std::max(cr.rho[r * 3 + q], e); cr.rel[b][r * 3 + q] = (float)m; }
         }
     }
     double rho_row = 0, tau_max = 0;
@@ -386,14 +390,19 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
         const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)B / 16);
         const Cand* src = h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH;
         h->he_staged = with_he && h->n_frames > 0;
-        if (h->he_staged) {   // K7 rides in the same launch (one kernel less at the head of every cost evaluation)
-            const uint32_t n_fetch = (n16 + 255) / 256;
-            hipLaunchKernelGGL(iba_fetch_he_kernel, dim3(n_fetch + (uint32_t)((B * h->n_frames + 31) / 32)), dim3(64), 0, st, (const uint4*)src, (uint4*)dc, n16, n_fetch, h->dev_problem(), src, B, h->d_he.p);
-        } else hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)src, (uint4*)dc, n16);
-        HIP_TRY(h, hipGetLastError());
+        h->head_slot = -1; h->head_deferred = false;
+        if (h->he_staged && h->side_on && h->side) {   // launched by run_split, on the side stream, right behind the pair search (launch_head)
+            h->head_deferred = true; h->head_slot = slot; h->head_B = B;
+        } else {
+            if (h->he_staged) {   // K7 rides in the same launch (one kernel less at the head of every cost evaluation)
+                const uint32_t n_fetch = (n16 + 255) / 256;
+                hipLaunchKernelGGL(iba_fetch_he_kernel, dim3(n_fetch + (uint32_t)((B * h->n_frames + 31) / 32)), dim3(64), 0, st, (const uint4*)src, (uint4*)dc, n16, n_fetch, h->dev_problem(), src, B, h->d_he.p);
+            } else hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)src, (uint4*)dc, n16);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipEventRecord(h->ring_ev[slot], st));
+        }
     }
     if (jets == 2) { h->jets_x = x; h->jets_B = B; h->jets_slot = slot; }
-    HIP_TRY(h, hipEventRecord(h->ring_ev[slot], st));
     h->ring_used[slot] = true;
     *d_out = dc;
     return IBA_OK;
@@ -405,8 +414,8 @@ iba_status finish_jets(iba_handle* h, hipStream_t st) {
     Cand* dc = h->d_cands.p + (size_t)h->jets_slot * IBA_MAX_BATCH;
     if (h->jets_src) {   // the group's calling thread has been differentiating while this device's kernels ran on the values
         while (h->jets_flag->load(std::memory_order_acquire) == 0) { /* microseconds */ }
-        for (int b = 0; b < h->jets_B; ++b)   // the derivative half alone: the values (and Cand::rel, which is this handle's own) stay as staged
-            std::memcpy((char*)&hc[b] + offsetof(Cand, dR), (const char*)&h->jets_src[b] + offsetof(Cand, dR), offsetof(Cand, rel) - offsetof(Cand, dR));
+        for (int b = 0; b < h->jets_B; ++b)   // the derivative half alone: the values stay as staged
+            std::memcpy((char*)&hc[b] + offsetof(Cand, dR), (const char*)&h->jets_src[b] + offsetof(Cand, dR), sizeof(Cand) - offsetof(Cand, dR));
         h->jets_src = nullptr; h->jets_flag = nullptr;
     } else
     for (int b = 0; b < h->jets_B; ++b) make_cand_jets(h->jets_x + 7 * b, hc[b]);
@@ -434,6 +443,32 @@ hipError_t wait_stream(iba_handle* h, hipStream_t st) {
         }
     }
     return hipStreamSynchronize(st);
+}
+
+// The staging launch of a cost evaluation on the side stream. mark_entry() is called BEFORE the pair search is enqueued on the
+// caller's stream (the side stream is ordered behind what the caller's stream held at that moment, not behind the pair search),
+// launch_head() right after it, join_head() before the first kernel that reads the candidates or the hand-eye terms.
+iba_status mark_entry(iba_handle* h, hipStream_t st) {
+    if (h->head_deferred) HIP_TRY(h, hipEventRecord(h->ev_entry, st));
+    return IBA_OK;
+}
+iba_status launch_head(iba_handle* h) {
+    if (!h->head_deferred) return IBA_OK;
+    h->head_deferred = false;
+    const int slot = h->head_slot, B = h->head_B;
+    const Cand* src = h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH;
+    Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
+    const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)B / 16), n_fetch = (n16 + 255) / 256;
+    HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_entry, 0));
+    hipLaunchKernelGGL(iba_fetch_he_kernel, dim3(n_fetch + (uint32_t)((B * h->n_frames + 31) / 32)), dim3(64), 0, h->side, (const uint4*)src, (uint4*)dc, n16, n_fetch, h->dev_problem(), src, B, h->d_he.p);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->side));
+    return IBA_OK;
+}
+iba_status join_head(iba_handle* h, hipStream_t st) {
+    if (h->head_deferred) { iba_status s = mark_entry(h, st); if (s != IBA_OK) return s; s = launch_head(h); if (s != IBA_OK) return s; }
+    if (h->head_slot >= 0) { HIP_TRY(h, hipStreamWaitEvent(st, h->ring_ev[h->head_slot], 0)); h->head_slot = -1; }
+    return IBA_OK;
 }
 
 iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
@@ -487,6 +522,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     NNLayout nl;
     if (!layout_nn(h, nl)) return fail(h, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel");
     if (nf == 0) {
+        { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }
         HIP_TRY(h, hipMemsetAsync(d_partials, 0, sizeof(double) * (size_t)B * kPartialStride, st));
         if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev0, st)); HIP_TRY(h, hipEventRecord(h->ev_mid, st)); HIP_TRY(h, hipEventRecord(h->ev1, st)); HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
         return IBA_OK;
@@ -517,6 +553,21 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     const CommonRef& cref = h->cref;
     const bool common = !frozen && h->last_hc && h->cref_ok;
     h->last_path = common ? 1 : 0;
+    // the pair search reads nothing the staging launch produces: it goes first, the staging launch runs beside it on the side stream
+    uint32_t* cnt_now = nullptr;
+    { iba_status ms = mark_entry(h, st); if (ms != IBA_OK) return ms; }
+    if (common) {
+        cnt_now = h->d_pcounts.p + (size_t)(h->pairs_epoch & 1) * (size_t)nf * kCountStride;
+        uint32_t* cnt_next = h->d_pcounts.p + (size_t)((h->pairs_epoch + 1) & 1) * (size_t)nf * kCountStride;
+        ++h->pairs_epoch;
+        // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
+        const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
+        const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
+        hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, PairsArgs{dp, cref}, h->params.max_pixel_dist, kuv_off, (h->pair_bound && B > 1) ? B : 0,
+                           h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
+        HIP_TRY(h, hipGetLastError());
+    }
+    { iba_status ls = launch_head(h); if (ls != IBA_OK) return ls; }
     // Anchored neighbour lists (iba_anchor_kernel): the scan points nearest to every MapPoint's query under an ANCHOR extrinsic,
     // built once and reused by every evaluation whose candidates stay near the anchor (each lane certifies its own pick, or
     // searches the tree). The anchor follows the optimiser: when the candidate of this call that is nearest the batch mean has
@@ -560,21 +611,14 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         } else sets = h->anchor_valid && far <= 4.0 * h->anchor_reach;   // further out the certificates fail anyway: plain search kernel
     }
     if (common) {
-        uint32_t* cnt_now = h->d_pcounts.p + (size_t)(h->pairs_epoch & 1) * (size_t)nf * kCountStride;
-        uint32_t* cnt_next = h->d_pcounts.p + (size_t)((h->pairs_epoch + 1) & 1) * (size_t)nf * kCountStride;
-        ++h->pairs_epoch;
-        {   // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
-            const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
-            const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
-            hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, dp, cref, h->params.max_pixel_dist, kuv_off, dc, (h->pair_bound && B > 1) ? B : 0,
-                               h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
-        }
-        HIP_TRY(h, hipGetLastError());
+        { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }   // the candidates and the hand-eye terms: first read here
         hipLaunchKernelGGL(iba_assoc2_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                            h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
-    } else
+    } else {
+    { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }
     hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                        h->d_frame_partials.p, nrec, (uint32_t*)nullptr, h->d_he.p, fl, fc, lc, (int)h->lstride);
+    }
     HIP_TRY(h, hipGetLastError());
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_mid, st));
     if (refit && (want & 1)) {
@@ -609,7 +653,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         iba_status s = finish_jets(h, st); if (s != IBA_OK) return s;   // the GPU has been busy with the values since stage_cands
         s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, nf, st); if (s != IBA_OK) return s;
     }
-    hipLaunchKernelGGL(iba_reduce2_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, search ? h->d_nn_partials.p : (const double*)nullptr, nn_nrec, d_partials);
+    hipLaunchKernelGGL(iba_reduce2_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, search ? h->d_nn_partials.p : (const double*)nullptr, nn_nrec, d_partials);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
     return IBA_OK;
@@ -662,6 +706,8 @@ void iba_destroy(iba_handle* h) {
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
+    if (h->ev_entry) (void)hipEventDestroy(h->ev_entry);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -911,6 +957,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = hipHostMalloc((void**)&h->h_partials, sizeof(double) * IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("hipHostMalloc", er);
     if ((er = hipHostGetDevicePointer((void**)&h->h_partials_dev, h->h_partials, 0)) != hipSuccess || (er = hipHostGetDevicePointer((void**)&h->h_cands_dev, h->h_cands, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", er);
     if ((er = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
+    if ((er = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
+    if ((er = hipEventCreateWithFlags(&h->ev_entry, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
+    if (const char* e = std::getenv("IBA_SIDE_STREAM")) h->side_on = std::atoi(e);
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel

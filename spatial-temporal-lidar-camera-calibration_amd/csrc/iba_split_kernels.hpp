@@ -601,7 +601,12 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 // Every decision of a candidate (visibility, d^2 <= gate^2, nearest point, ties) is still made by its own exact f64
 // arithmetic in iba_assoc2_kernel, in the reference's expression order: the pair list only has to be a superset.
 // ------------------------------------------------------------------------------------------------------------------
-struct CommonRef { double R[9], t[3], rho[9], tau[3]; };
+// rel[b] = (M_b row-major, a_b) as floats: candidate b relative to the reference, q_b = q_0 + M_b q_0 + a_b with M_b = R_b R_0^T - I,
+// a_b = t_b - R_b R_0^T t_0 (the pair search bounds a block's motion over the batch by the candidates' own motions). The whole
+// struct travels in the kernel arguments: the pair search depends on nothing the staging launch produces and runs beside it.
+struct CommonRef { double R[9], t[3], rho[9], tau[3]; float rel[IBA_MAX_BATCH][12]; };
+struct PairsArgs { DevProblem dp; CommonRef cr; };
+static_assert(sizeof(PairsArgs) + 96 <= 4096, "the pair search's arguments must fit the 4 KB kernel argument segment");
 struct PairRec { float x, y, z; uint32_t idx; float u, v; uint32_t k, pad; };   // scan point (+ original index), keypoint (+ id): 32 B, streamed
 constexpr int kPairsThreads = 512;    // measured at the bench shape: 1024 threads 50 us, 512 threads 39 us, 256 threads 58 us per batch
 constexpr int kCountStride = 32;   // u32 per frame (one 128-byte line: the frames' counters do not share a line): pairs, hard points, overflow flag
@@ -610,10 +615,13 @@ constexpr int kPairStage = 2048;   // (point, keypoint) hits a block parks in LD
 // grid: (ceil(max P / kPairsThreads), frames); one scan point per thread. The keypoint grid of the frame (coarse CSR + the
 // keypoints' (u, v)) sits in LDS, so a thread's walk costs LDS round trips, not L2 ones; the hits of a block are parked in LDS
 // and written out behind one atomic reservation per block.
-__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp, CommonRef cr, double max_pixel_dist, uint32_t lds_kuv_off, const Cand* __restrict__ cands, int B,
+__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_by_value, double max_pixel_dist, uint32_t lds_kuv_off, int B,
                                                                   PairRec* __restrict__ pairs, uint32_t* __restrict__ hard,
                                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ counts_next, int pair_cap, int hard_cap) {
     extern __shared__ __align__(16) unsigned char smem[];
+    typedef __attribute__((address_space(4))) const PairsArgs PairsArgsC;
+    PairsArgsC* pa = (PairsArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // (the argument block is read in place: rel[] is indexed per lane)
+    const DevProblem& dp = pa_by_value.dp; const CommonRef& cr = pa_by_value.cr;
     const int f = blockIdx.y;
     const FrameHdr& h = dp.frames[f];
     const uint32_t P = h.P, K = h.K;
@@ -714,9 +722,14 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(DevProblem dp,
             float m[3] = {0.f, 0.f, 0.f};
             const int b = (int)threadIdx.x;
             if (b < B) {
-                const double* rl = cands[b].rel;
+                double rl[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) rl[i] = (double)pa->cr.rel[b][i];
                 for (int i = 0; i < 3; ++i) {
-                    const double mi = (fabs(((rl[i * 3] * qc[0] + rl[i * 3 + 1] * qc[1]) + rl[i * 3 + 2] * qc[2]) + rl[9 + i]) + ((fabs(rl[i * 3]) * ex[0] + fabs(rl[i * 3 + 1]) * ex[1]) + fabs(rl[i * 3 + 2]) * ex[2])) * (1.0 + 1e-9) + 1e-12 * scale + 1e-13;
+                    // (the entries are floats of the host's doubles: each is off by at most 2^-24 of itself, which the last term covers)
+                    const double lin = (fabs(rl[i * 3]) * (fabs(qc[0]) + ex[0]) + fabs(rl[i * 3 + 1]) * (fabs(qc[1]) + ex[1])) + fabs(rl[i * 3 + 2]) * (fabs(qc[2]) + ex[2]);
+                    const double mi = (fabs(((rl[i * 3] * qc[0] + rl[i * 3 + 1] * qc[1]) + rl[i * 3 + 2] * qc[2]) + rl[9 + i]) + ((fabs(rl[i * 3]) * ex[0] + fabs(rl[i * 3 + 1]) * ex[1]) + fabs(rl[i * 3 + 2]) * ex[2])) * (1.0 + 1e-9) + 1e-12 * scale + 1e-13
+                                      + 6.1e-8 * (lin + fabs(rl[9 + i]));
                     m[i] = (float)mi * 1.0000002f + 1e-30f;   // >= mi (NaN stays NaN)
                 }
             }
@@ -1927,7 +1940,7 @@ __global__ __launch_bounds__(256) void iba_verdict_kernel(const PlaneRec* __rest
     out[i] = (uint8_t)((neigh_ok ? 1u : 0u) | (neigh_ok && local_plane_ok(prm, rec) ? 2u : 0u));
 }
 
-__global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, const double* __restrict__ nn_partials, int nn_nrec,
+__global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, int nfr, const double* __restrict__ nn_partials, int nn_nrec,
                                                                      double* __restrict__ out) {
     constexpr int NG = kReduceThreads / kPartialStride;
     constexpr int NL = kReduceThreads / kNNPartial;
@@ -1935,15 +1948,23 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
     __shared__ double s2[NL][kNNPartial];
     const int b = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
     const double* src = frame_partials + (size_t)b * nrec * kPartialStride;
-    const int per = (nrec + NG - 1) / NG, f0 = g * per, f1 = min(nrec, f0 + per);
-    double x = 0;
-    int f = f0;
-    for (; f + 4 <= f1; f += 4) {
-        const double v0 = src[(size_t)f * kPartialStride + i], v1 = src[(size_t)(f + 1) * kPartialStride + i];
-        const double v2 = src[(size_t)(f + 2) * kPartialStride + i], v3 = src[(size_t)(f + 3) * kPartialStride + i];
-        x = (((x + v0) + v1) + v2) + v3;
-    }
-    for (; f < f1; ++f) x += src[(size_t)f * kPartialStride + i];
+    // the first nfr records are the association's (one per frame), the others — when the evaluation has them — the factor kernel's:
+    // a group sums the same frame range of either half, so that a slot only one half fills (every cost slot, every H / b slot) gets
+    // the same bits whether or not the other half exists (iba_eval_cost = the cost tuple of iba_eval_full, bit for bit)
+    const int per = (nfr + NG - 1) / NG, f0 = g * per, f1 = min(nfr, f0 + per);
+    auto range_sum = [&](const double* base, int lo, int hi) {
+        double x = 0;
+        int f = lo;
+        for (; f + 4 <= hi; f += 4) {
+            const double v0 = base[(size_t)f * kPartialStride + i], v1 = base[(size_t)(f + 1) * kPartialStride + i];
+            const double v2 = base[(size_t)(f + 2) * kPartialStride + i], v3 = base[(size_t)(f + 3) * kPartialStride + i];
+            x = (((x + v0) + v1) + v2) + v3;
+        }
+        for (; f < hi; ++f) x += base[(size_t)f * kPartialStride + i];
+        return x;
+    };
+    double x = range_sum(src, f0, f1);
+    if (nrec > nfr) x += range_sum(src + (size_t)nfr * kPartialStride, f0, min(f1, nrec - nfr));
     s[g][i] = x;
     if (nn_partials) {   // record lane rl sums the records rl, rl + NL, ... of slot q
         const int q = threadIdx.x & (kNNPartial - 1), rl = threadIdx.x / kNNPartial;

@@ -107,9 +107,6 @@ struct Cand {
     double Rlc[9], tlc[3];    // SE3Exp(-x[0:6])  (IBACalib2.hpp:573-577)
     double dRlc[3][9];
     double dtlc[6][3];
-    // this candidate relative to the reference candidate of its batch (common_ref): q_b = q_0 + M q_0 + a with M = R_b R_0^T - I,
-    // a = t_b - R_b R_0^T t_0; the pair search bounds a piece of the scan's motion over the batch by the candidates' own motions
-    double rel[12];
 };
 
 struct DevParams {

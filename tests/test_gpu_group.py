@@ -281,3 +281,37 @@ def test_shard_without_any_keypoint(pkg, synth, abi, ob):
         assert a.counts() == b.counts()
         assert np.max(np.abs(a.H_np() - b.H_np())) <= 1e-9 * np.max(np.abs(b.H_np()))
     g.close()
+
+
+def test_back_to_back_partial_calls_on_a_caller_stream(pkg, synth, abi, scene_small):
+    """Several iba_eval_full_partial / iba_eval_cost_partial calls enqueued on the caller's stream without a host wait between
+    them (what a pipelined caller does): the staging launch of call n + 1 runs on the handle's side stream and must stay behind
+    everything call n reads (candidate ring slot, hand-eye terms); every block equals the synchronous result bit for bit."""
+    import torch
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    rng = np.random.default_rng(11)
+    sets = [synth.perturb(meta["x_gt"], rng, n=n) for n in (7, 1, 16, 3, 16, 7, 2, 9)]
+    h = pkg.IbaHandle(prob, p)
+    ts = torch.cuda.Stream()
+    stride = pkg.partial_stride()
+    with torch.cuda.stream(ts):
+        st = torch.cuda.current_stream().cuda_stream
+        outs = [torch.zeros(len(x) * stride, dtype=torch.float64, device="cuda:0") for x in sets]
+        for rep in range(3):
+            for i, (x, d) in enumerate(zip(sets, outs)):
+                if (i + rep) % 3 == 2:
+                    h.eval_cost_partial(x, d.data_ptr(), st)
+                else:
+                    h.eval_full_partial(x, d.data_ptr(), st)
+        ts.synchronize()
+        parts = [d.cpu().numpy() for d in outs]
+    for i, (x, part) in enumerate(zip(sets, parts)):
+        cost = pkg.finalize_cost(p, part)
+        c1, n1 = h.eval_full(x)
+        for a, b in zip(c1, cost):
+            assert a.as_dict() == b.as_dict(), i
+        if (i + 2) % 3 != 2:   # the last repetition of this set was a full evaluation: the normal equations are in the block too
+            for a, b in zip(n1, pkg.finalize_normal(p, part)):
+                assert np.array_equal(a.H_np(), b.H_np()) and a.counts() == b.counts(), i
+    h.close()
