@@ -251,7 +251,11 @@ iba_status iba_finalize_normal(const iba_params* params, const double* partials,
 /* The frozen problem's residual blocks, as a partial block (the Jacobian-path half of the LM caller on several GPUs). */
 iba_status iba_eval_factors_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream);
 /* Calls on one handle must be issued in order, on one stream at a time: the handle's work buffers (candidate ring, lists,
- * records) are reused from call to call and are ordered by that stream only. */
+ * records) are reused from call to call and are ordered by that stream only.
+ * A cost evaluation also uses a second stream that belongs to the handle: its staging launch (candidates -> device, hand-eye terms)
+ * and the later copy of the candidates' derivatives run there, beside the pair search / the search kernel on `stream`. That stream
+ * is ordered behind everything `stream` held when the call was made and `stream` waits for it before the first kernel that reads
+ * its results, so a caller sees one stream's ordering (IBA_SIDE_STREAM=0 in the environment: everything on `stream`). */
 
 /* Introspection for benchmarks: device-side duration of the last evaluation's dominant kernel
  * measured with HIP events on the launch stream (ms), and the frame-kernel launch shape. */

@@ -138,6 +138,7 @@ struct iba_handle {
     // which needs neither: ev_entry orders it behind the caller's stream, the slot's ring event brings the caller's stream back
     // before the first kernel that reads the candidates (IBA_SIDE_STREAM=0: one stream, staging first).
     hipStream_t side = nullptr; hipEvent_t ev_entry = nullptr; int side_on = 1; int head_slot = -1; bool head_deferred = false; int head_B = 0;
+    bool side_in_use = false;             // this call's staging launch ran on the side stream (which is therefore ordered behind the caller's earlier work)
     bool ring_used[kRing] = {false, false, false, false};
     int ring_next = 0;
     std::vector<FrameHdr> h_frames;
@@ -390,9 +391,9 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
         const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)B / 16);
         const Cand* src = h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH;
         h->he_staged = with_he && h->n_frames > 0;
-        h->head_slot = -1; h->head_deferred = false;
+        h->head_slot = -1; h->head_deferred = false; h->side_in_use = false;
         if (h->he_staged && h->side_on && h->side) {   // launched by run_split, on the side stream, right behind the pair search (launch_head)
-            h->head_deferred = true; h->head_slot = slot; h->head_B = B;
+            h->head_deferred = true; h->head_slot = slot; h->head_B = B; h->side_in_use = true;
         } else {
             if (h->he_staged) {   // K7 rides in the same launch (one kernel less at the head of every cost evaluation)
                 const uint32_t n_fetch = (n16 + 255) / 256;
@@ -419,12 +420,17 @@ iba_status finish_jets(iba_handle* h, hipStream_t st) {
         h->jets_src = nullptr; h->jets_flag = nullptr;
     } else
     for (int b = 0; b < h->jets_B; ++b) make_cand_jets(h->jets_x + 7 * b, hc[b]);
-    {   // the whole block again, now complete: stream-ordered behind the kernels that read the values
-        const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)h->jets_B / 16);
-        hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)(h->h_cands_dev + (size_t)h->jets_slot * IBA_MAX_BATCH), (uint4*)dc, n16);
+    {   // the derivative half alone (the kernels in flight read the value half). When this call's staging launch went to the side
+        // stream, so does this copy — it then runs beside the search kernel instead of between it and the factor kernel — and the
+        // caller's stream waits for it; otherwise it is stream-ordered where it stands.
+        static_assert(offsetof(Cand, dR) % 16 == 0 && sizeof(Cand) % 16 == 0, "the halves of a Cand are copied as 16-byte words");
+        const uint32_t w0 = (uint32_t)(offsetof(Cand, dR) / 16), w1 = (uint32_t)(sizeof(Cand) / 16), n = (uint32_t)h->jets_B * (w1 - w0);
+        hipStream_t cs = h->side_in_use ? h->side : st;
+        hipLaunchKernelGGL(iba_fetch_jets_kernel, dim3((n + 255) / 256), dim3(256), 0, cs, (const uint4*)(h->h_cands_dev + (size_t)h->jets_slot * IBA_MAX_BATCH), (uint4*)dc, (uint32_t)h->jets_B, w0, w1, w1);
         HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ring_ev[h->jets_slot], cs));   // the slot is busy until this copy has been read
+        if (h->side_in_use) HIP_TRY(h, hipStreamWaitEvent(st, h->ring_ev[h->jets_slot], 0));
     }
-    HIP_TRY(h, hipEventRecord(h->ring_ev[h->jets_slot], st));   // the slot is busy until this copy has been read
     h->jets_x = nullptr;
     return IBA_OK;
 }

@@ -1157,6 +1157,15 @@ __global__ void iba_fetch_kernel(const uint4* __restrict__ src, uint4* __restric
     if (i < n16) dst[i] = src[i];
 }
 
+// the derivative half of B candidates (16-byte words [w0, w1) of every Cand): pinned host memory -> device, beside the kernels that are
+// still reading the value half
+__global__ void iba_fetch_jets_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t B, uint32_t w0, uint32_t w1, uint32_t wcand) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, per = w1 - w0;
+    if (i >= B * per) return;
+    const uint32_t w = (i / per) * wcand + w0 + i % per;
+    dst[w] = src[w];
+}
+
 // writes two host-known values into their slots of B partial blocks (frozen-problem counts)
 __global__ void iba_set_slots_kernel(double* __restrict__ partials, int B, int slot_a, double va, int slot_b, double vb) {
     const int b = threadIdx.x;
