@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle", type=int, default=150, help="untimed steps BEFORE the warmup steps: a 10 ms timed region on a GPU that has only just left idle measures the clock ramp (config.untimed_steps_before_warmup)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--pts", type=int, default=PTS_PER_FRAME)
@@ -203,6 +204,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(args.settle):
+        out = step(i)
     for i in range(args.warmup):
         out = step(i)
     sync()
@@ -273,6 +276,7 @@ def main():
             "mean_n_corr": float(np.mean([c.n_corr for c in out[0]])), "mean_cnt_3d_3d": float(np.mean([c.cnt_3d_3d for c in out[0]])),
             "mean_factors": float(np.mean([n.n_factor_3d2d + n.n_factor_p2pl + n.n_factor_p2pt for n in out[1]])),
             "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of %d doubles per call" % (n_gpus, B * stride),
+            "untimed_steps_before_warmup": args.settle,
             "launch": launch, "rccl_ranks": rccl_ranks,
             "unit_definition": ("weak scaling: 1 eval = one candidate x against %d keyframes / %.1fM points (+ normal equations); at N GPUs a candidate covers N x %d "
                                 "keyframes = N units, value = units/s over all ranks" % (args.frames, args.frames * args.pts / 1e6, args.frames)) if args.scaling == "weak" else
