@@ -274,6 +274,9 @@ int32_t iba_debug_last_path(const iba_handle* h);
  * optimiser's candidates; IBA_NN_SETS=0 disables them, IBA_ANCHOR_REACH sets the drift in metres that moves the anchor) have
  * been built on this handle. Results do not depend on the anchor: every lane certifies its pick or searches the tree. */
 int32_t iba_debug_anchor_builds(const iba_handle* h);
+/* diagnostic: how many times the shared pair search has run on this handle (an evaluation whose batch stays inside the bound of
+ * the lists an earlier call built reuses them: IBA_PAIR_MEMO, default on) */
+int32_t iba_debug_pairs_builds(const iba_handle* h);
 /* diagnostic: list entries of the last evaluation (all candidates) that the anchored neighbour lists could not settle and the
  * tree search took over; -1 when no search ran */
 double iba_debug_nn_left_to_tree(iba_handle* h);

@@ -266,6 +266,11 @@ class IbaHandle:
         return int(self.lib.iba_debug_last_path(self.h))
 
     @property
+    def pairs_builds(self):
+        self.lib.iba_debug_pairs_builds.argtypes = [C.c_void_p]
+        return int(self.lib.iba_debug_pairs_builds(self.h))
+
+    @property
     def mean_pairs(self):
         self.lib.iba_debug_mean_pairs.restype = C.c_double
         self.lib.iba_debug_mean_pairs.argtypes = [C.c_void_p]

@@ -97,7 +97,10 @@ struct iba_handle {
     double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
-    CommonRef cref; bool cref_ok = false; // the staged batch's reference candidate and spread (common_ref at staging time: it also fills Cand::rel)
+    CommonRef cref; bool cref_ok = false; // reference candidate and bound of the pair lists this call uses (plan_pairs at staging time)
+    bool pairs_valid = false, pairs_reuse = false;   // the device holds lists built for cref; this call reuses them (no pair search)
+    int pair_memo = 1; double pair_infl = 1.25, pair_rho_floor = 1e-4, pair_tau_floor = 1e-3;   // IBA_PAIR_MEMO, IBA_PAIR_INFL
+    int pairs_builds = 0; int pair_memo_max_b = 32; bool memo_this_call = false;   // IBA_PAIR_MEMO_MAX_B
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
     int last_nn_nrec = 0, last_nn_B = 0;   // shape of the search kernel's records of the last evaluation (iba_debug_nn_left_to_tree)
     bool he_staged = false;               // the hand-eye terms of the staged candidates were computed by the staging launch
@@ -279,7 +282,51 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
 // nearest the batch mean, rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i, both inflated for their own
 // rounding. Returns false when the batch is too wide for common pairs to pay (nominal projection spread above max_px at a
 // point 12 m out, 10 m deep), in which case every candidate searches for itself (iba_assoc_kernel).
-bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
+// rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i of a batch around a reference (R_0, t_0), inflated for their own
+// rounding; rel (optional): the candidates' own (M_b, a_b) as floats. false: a NaN / absurd candidate, no bound.
+static bool batch_spread(const Cand* hc, int B, const double* R0, const double* t0, double* rho, double* tau, float (*rel)[12]) {
+    for (int i = 0; i < 9; ++i) rho[i] = 0;
+    for (int i = 0; i < 3; ++i) tau[i] = 0;
+    for (int b = 0; b < B; ++b) {
+        double A[9];
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) A[r * 3 + q] = (hc[b].R[r * 3] * R0[q * 3] + hc[b].R[r * 3 + 1] * R0[q * 3 + 1]) + hc[b].R[r * 3 + 2] * R0[q * 3 + 2];   // R_b R_0^T
+        for (int r = 0; r < 3; ++r) {
+            const double a = hc[b].t[r] - ((A[r * 3] * t0[0] + A[r * 3 + 1] * t0[1]) + A[r * 3 + 2] * t0[2]);
+            if (!(std::fabs(a) <= 1e30)) return false;
+            tau[r] = std::max(tau[r], std::fabs(a));
+            if (rel) rel[b][9 + r] = (float)a;
+            for (int q = 0; q < 3; ++q) { const double m = A[r * 3 + q] - (r == q ? 1.0 : 0.0), e = std::fabs(m); if (!(e <= 4.0)) return false; rho[r * 3 + q] = std::max(rho[r * 3 + q], e); if (rel) rel[b][r * 3 + q] = (float)m; }
+        }
+    }
+    for (int i = 0; i < 9; ++i) rho[i] = rho[i] * (1.0 + 1e-9) + 1e-15;
+    for (int i = 0; i < 3; ++i) tau[i] = tau[i] * (1.0 + 1e-9) + 1e-15;
+    return true;
+}
+
+// The pair lists of a batch (see iba_pairs_kernel) and their REUSE: a list built around a reference candidate with the entrywise
+// bound (rho, tau) holds every (scan point, keypoint) pair that any candidate within that bound of the reference can match — not
+// only the batch it was built for. With IBA_PAIR_MEMO (default) the bound of a new list is the batch's own times pair_infl plus
+// a floor, the candidates' own per-block bound is left out (it is specific to the batch), and the next calls whose batches stay
+// inside the built bound skip the pair search altogether: an optimiser's late polls and line searches hover around one point.
+// Sets h->cref (reference + bound of the lists that this call will use), h->pairs_reuse. false: no shared search for this batch
+// (a NaN candidate; a batch wider than common_max_px of nominal projection spread, at a point 12 m out, 10 m deep).
+bool plan_pairs(iba_handle* h, const Cand* hc, int B) {
+    h->pairs_reuse = false;
+    CommonRef& cr = h->cref;
+    // (a big batch keeps its own, tight lists: the pair search is a fixed ~40 us per call, longer lists cost every candidate)
+    const bool memo = h->pair_memo && B <= h->pair_memo_max_b;
+    h->memo_this_call = memo;
+    if (memo && h->pairs_valid) {
+        double rho[9], tau[3];
+        if (batch_spread(hc, B, cr.R, cr.t, rho, tau, nullptr)) {
+            bool fits = true;
+            for (int i = 0; i < 9; ++i) fits = fits && rho[i] <= cr.rho[i];
+            for (int i = 0; i < 3; ++i) fits = fits && tau[i] <= cr.tau[i];
+            if (fits) { h->pairs_reuse = true; return true; }
+        }
+    }
+    h->pairs_valid = false;   // cr is rewritten: the lists on the device no longer belong to it
     double mean[12] = {0};
     for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].R[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].t[i]; }
     for (double& m : mean) m /= (double)B;
@@ -291,25 +338,14 @@ bool common_ref(const iba_handle* h, const Cand* hc, int B, CommonRef& cr) {
         if (d < best) { best = d; ref = b; }
     }
     if (!(best < INFINITY)) return false;   // a NaN candidate: no bound
-    const Cand& c0 = hc[ref];
-    std::memcpy(cr.R, c0.R, sizeof(cr.R)); std::memcpy(cr.t, c0.t, sizeof(cr.t));
-    for (int i = 0; i < 9; ++i) cr.rho[i] = 0; for (int i = 0; i < 3; ++i) cr.tau[i] = 0;
-    for (int b = 0; b < B; ++b) {
-        double A[9];
-        for (int r = 0; r < 3; ++r)
-            for (int q = 0; q < 3; ++q) A[r * 3 + q] = (hc[b].R[r * 3] * c0.R[q * 3] + hc[b].R[r * 3 + 1] * c0.R[q * 3 + 1]) + hc[b].R[r * 3 + 2] * c0.R[q * 3 + 2];   // R_b R_0^T
-        for (int r = 0; r < 3; ++r) {
-            const double a = hc[b].t[r] - ((A[r * 3] * c0.t[0] + A[r * 3 + 1] * c0.t[1]) + A[r * 3 + 2] * c0.t[2]);
-            if (!(std::fabs(a) <= 1e30)) return false;
-            cr.tau[r] = std::max(cr.tau[r], std::fabs(a));
-            cr.rel[b][9 + r] = (float)a;
-            for (int q = 0; q < 3; ++q) { const double m = A[r * 3 + q] - (r == q ? 1.0 : 0.0), e = std::fabs(m); if (!(e <= 4.0)) return false; cr.rho[r * 3 + q] = std::max(cr.rho[r * 3 + q], e); cr.rel[b][r * 3 + q] = (float)m; }
-        }
+    std::memcpy(cr.R, hc[ref].R, sizeof(cr.R)); std::memcpy(cr.t, hc[ref].t, sizeof(cr.t));
+    if (!batch_spread(hc, B, cr.R, cr.t, cr.rho, cr.tau, cr.rel)) return false;
+    if (memo) {
+        for (int i = 0; i < 9; ++i) cr.rho[i] = cr.rho[i] * h->pair_infl + h->pair_rho_floor;
+        for (int i = 0; i < 3; ++i) cr.tau[i] = cr.tau[i] * h->pair_infl + h->pair_tau_floor;
     }
     double rho_row = 0, tau_max = 0;
     for (int r = 0; r < 3; ++r) { rho_row = std::max(rho_row, cr.rho[r * 3] + cr.rho[r * 3 + 1] + cr.rho[r * 3 + 2]); tau_max = std::max(tau_max, cr.tau[r]); }
-    for (int i = 0; i < 9; ++i) cr.rho[i] = cr.rho[i] * (1.0 + 1e-9) + 1e-15;
-    for (int i = 0; i < 3; ++i) cr.tau[i] = cr.tau[i] * (1.0 + 1e-9) + 1e-15;
     if (h->common_mode >= 2) return true;
     const double nominal_px = h->max_fx * (rho_row * 12.0 + tau_max) * 1.8 / 10.0;
     return nominal_px <= h->common_max_px;
@@ -369,7 +405,7 @@ iba_status ensure_scratch(iba_handle* h) {
 // from x here, or copied from `pre` when the caller (iba_group) has already computed it for all its devices. jets = 0: the
 // values only (cost evaluations never read the derivatives); jets = 2: the values now, the derivatives later (finish_jets:
 // the host differentiates the exponentials while the GPU runs the association and search kernels on the values).
-iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1, const std::atomic<int>* pre_flag = nullptr, bool with_he = false) {
+iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1, const std::atomic<int>* pre_flag = nullptr, bool with_he = false, bool plan = false) {
     const int slot = h->ring_next; h->ring_next = (h->ring_next + 1) % kRing;
     if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
     Cand* hc = h->h_cands + (size_t)slot * IBA_MAX_BATCH;
@@ -384,7 +420,7 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     }
     else if (jets == 1) for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
     else for (int b = 0; b < B; ++b) make_cand_values(x + 7 * b, hc[b]);
-    h->cref_ok = h->common_mode > 0 && B >= h->common_min_batch && h->d_pairs.p && common_ref(h, hc, B, h->cref);
+    h->cref_ok = plan && h->common_mode > 0 && B >= h->common_min_batch && h->d_pairs.p && plan_pairs(h, hc, B);
     // the block crosses PCIe by a kernel that reads the pinned ring (a copy-engine transfer of these 70 KB costs ~15 us of latency
     // at the head of every evaluation; a strided copy of the value halves alone was slower still)
     {
@@ -562,16 +598,19 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     // the pair search reads nothing the staging launch produces: it goes first, the staging launch runs beside it on the side stream
     uint32_t* cnt_now = nullptr;
     { iba_status ms = mark_entry(h, st); if (ms != IBA_OK) return ms; }
-    if (common) {
+    if (common && h->pairs_reuse) cnt_now = h->d_pcounts.p + (size_t)((h->pairs_epoch - 1) & 1) * (size_t)nf * kCountStride;   // the lists of an earlier call cover this batch
+    else if (common) {
         cnt_now = h->d_pcounts.p + (size_t)(h->pairs_epoch & 1) * (size_t)nf * kCountStride;
         uint32_t* cnt_next = h->d_pcounts.p + (size_t)((h->pairs_epoch + 1) & 1) * (size_t)nf * kCountStride;
         ++h->pairs_epoch;
         // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
         const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
         const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
-        hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, PairsArgs{dp, cref}, h->params.max_pixel_dist, kuv_off, (h->pair_bound && B > 1) ? B : 0,
-                           h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
+        // (lists that later batches may reuse are bounded entrywise only: the candidates' own per-block bound is this batch's)
+        hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, PairsArgs{dp, cref}, h->params.max_pixel_dist, kuv_off,
+                           (h->pair_bound && B > 1 && !h->memo_this_call) ? B : 0, h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
         HIP_TRY(h, hipGetLastError());
+        h->pairs_valid = h->memo_this_call; ++h->pairs_builds;
     }
     { iba_status ls = launch_head(h); if (ls != IBA_OK) return ls; }
     // Anchored neighbour lists (iba_anchor_kernel): the scan points nearest to every MapPoint's query under an ANCHOR extrinsic,
@@ -676,7 +715,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
     if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0, nullptr, true); if (s != IBA_OK) return s;   // the cost tuple never reads the derivatives
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0, nullptr, true, true); if (s != IBA_OK) return s;   // the cost tuple never reads the derivatives
     return run_split(h, dc, B, 2, false, false, d_partials, st);
 }
 
@@ -916,6 +955,9 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_SPIN_WAIT")) h->spin_wait = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_ANCHOR_REACH")) h->anchor_reach = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIR_BOUND")) h->pair_bound = std::atoi(e);
+    if (const char* e = std::getenv("IBA_PAIR_MEMO")) h->pair_memo = std::atoi(e);
+    if (const char* e = std::getenv("IBA_PAIR_INFL")) h->pair_infl = std::max(1.0, std::atof(e));
+    if (const char* e = std::getenv("IBA_PAIR_MEMO_MAX_B")) h->pair_memo_max_b = std::atoi(e);
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
@@ -1021,6 +1063,7 @@ iba_status iba_set_params(iba_handle* h, const iba_params* p) {
     }
     h->params = *p; to_dev_params(*p, h->dprm); h->frozen_valid = false;
     h->anchor_valid = false;   // the lists carry the planes' verdicts under the old parameters
+    h->pairs_valid = false;    // the pair lists were cut for the old max_pixel_dist
     return compute_plane_cache(h);
 }
 
@@ -1175,6 +1218,7 @@ double iba_debug_mean_pairs(iba_handle* h) {
     double t = 0; for (int f = 0; f < h->n_frames; ++f) t += v[(size_t)f * kCountStride];
     return t / h->n_frames;
 }
+int32_t iba_debug_pairs_builds(const iba_handle* h) { return h ? h->pairs_builds : -1; }
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }
 
 // debug: exact 1-NN of n LiDAR-frame queries in the scan of a local frame, through the frame kernels' own search
@@ -1220,7 +1264,7 @@ static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, false, true); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 1, false, true, d_partials, st);
 }
 
@@ -1246,7 +1290,7 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, true); if (s != IBA_OK) return s;
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, true, true); if (s != IBA_OK) return s;
     return run_split(h, dc, B, 3, false, true, d_partials, st);
 }
 

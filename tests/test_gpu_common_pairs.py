@@ -184,3 +184,51 @@ def test_dense_scans_leftover_entries_and_long_pair_lists(pkg, synth, abi):
     _same_bits(pkg, h0, h1, xs[:8], 1)
     _same_bits(pkg, h0, h1, xs[5:6], 1)
     h0.close(); h1.close()
+
+
+def test_pair_lists_are_reused_while_the_batches_stay_inside_their_bound(pkg, synth, abi, scene_small):
+    """The pair lists of a call are built for an inflated bound around its reference candidate and serve the following calls whose
+    batches stay inside it (an optimiser's late polls, a line search): fewer pair searches than calls, and not one bit of any result
+    differs from a handle that searches on every call, nor from the per-candidate path."""
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    old = os.environ.get("IBA_PAIR_MEMO")
+    os.environ["IBA_PAIR_MEMO"] = "0"
+    try:
+        h_every = _handle(pkg, prob, p, 1)
+    finally:
+        if old is None:
+            del os.environ["IBA_PAIR_MEMO"]
+        else:
+            os.environ["IBA_PAIR_MEMO"] = old
+    h_memo, h_single = _handle(pkg, prob, p, 1), _handle(pkg, prob, p, 0)
+    rng = np.random.default_rng(17)
+    centre = meta["x_gt"].copy()
+    calls = 0
+    for step in range(14):
+        n = int(rng.choice([1, 3, 8, 14]))
+        scale = 1.0 if step < 3 else 0.35   # a few wide polls, then the mesh shrinks
+        xs = synth.perturb(centre, rng, rot=3e-4 * scale, trans=3e-3 * scale, scale_rel=1e-3 * scale, n=n)
+        centre = xs[0] if step % 4 == 3 else centre   # the incumbent moves now and then
+        for fn in ("eval_cost", "eval_full"):
+            a, b, c = getattr(h_memo, fn)(xs), getattr(h_every, fn)(xs), getattr(h_single, fn)(xs)
+            calls += 1
+            assert h_memo.last_path == 1 and h_every.last_path == 1 and h_single.last_path == 0
+            ca, cb, cc = (a, b, c) if fn == "eval_cost" else (a[0], b[0], c[0])
+            for u, v, w in zip(ca, cb, cc):
+                assert u.as_dict() == v.as_dict() == w.as_dict(), (step, fn)
+            if fn == "eval_full":
+                for u, v, w in zip(a[1], b[1], c[1]):
+                    assert np.array_equal(u.H_np(), v.H_np()) and np.array_equal(u.H_np(), w.H_np()) and u.counts() == v.counts() == w.counts()
+    assert h_every.pairs_builds == calls
+    assert h_memo.pairs_builds < calls // 2, (h_memo.pairs_builds, calls)
+    # new parameters: the lists are cut again
+    p2 = abi.reference_yaml_params(); p2.max_pixel_dist = 2.5
+    before = h_memo.pairs_builds
+    h_memo.set_params(p2); h_single.set_params(p2)
+    xs = synth.perturb(centre, rng, rot=1e-4, trans=1e-3, scale_rel=1e-4, n=5)
+    for u, w in zip(h_memo.eval_cost(xs), h_single.eval_cost(xs)):
+        assert u.as_dict() == w.as_dict()
+    assert h_memo.pairs_builds == before + 1
+    for hh in (h_memo, h_every, h_single):
+        hh.close()
