@@ -94,7 +94,7 @@ struct iba_handle {
     bool nn_sets = true;                  // IBA_NN_SETS=0: no anchored neighbour lists, every lane searches the tree (diagnostic)
     int pair_bound = 1;                   // IBA_PAIR_BOUND: 0 = the pair search bounds the batch's motion entrywise only (diagnostic)
     int common_min_batch = 1;             // IBA_COMMON_MIN_BATCH
-    double common_max_px = 12.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
+    double common_max_px = 20.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
     CommonRef cref; bool cref_ok = false; // reference candidate and bound of the pair lists this call uses (plan_pairs at staging time)
