@@ -100,7 +100,7 @@ struct iba_handle {
     CommonRef cref; bool cref_ok = false; // reference candidate and bound of the pair lists this call uses (plan_pairs at staging time)
     bool pairs_valid = false, pairs_reuse = false;   // the device holds lists built for cref; this call reuses them (no pair search)
     int pair_memo = 1; double pair_infl = 1.25, pair_rho_floor = 1e-4, pair_tau_floor = 1e-3;   // IBA_PAIR_MEMO, IBA_PAIR_INFL
-    int pairs_builds = 0; int pair_memo_max_b = 32; bool memo_this_call = false;   // IBA_PAIR_MEMO_MAX_B
+    int pairs_builds = 0; int pair_memo_max_b = 40; bool memo_this_call = false;   // IBA_PAIR_MEMO_MAX_B
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
     int last_nn_nrec = 0, last_nn_B = 0;   // shape of the search kernel's records of the last evaluation (iba_debug_nn_left_to_tree)
     bool he_staged = false;               // the hand-eye terms of the staged candidates were computed by the staging launch
