@@ -267,8 +267,11 @@ iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_ke
 /* debug: host copy of the summed partial blocks of the last iba_eval_* call */
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
 /* debug: which 2d-3d association ran in the last evaluation chain: 1 = the batch shared one pair search per keyframe
- * (a batch of >= 4 nearby candidates), 0 = every candidate searched for itself. The results are the same bits either way.
- * Environment (read at iba_create): IBA_COMMON_PAIRS=0 never share, 2 share whenever the bound allows; IBA_COMMON_MAX_PX. */
+ * (any batch, a single candidate included, whose nominal projection spread stays under IBA_COMMON_MAX_PX = 20 px), 0 = every
+ * candidate searched for itself. The results are the same bits either way.
+ * Environment (read at iba_create): IBA_COMMON_PAIRS=0 never share, 2 share whenever the bound allows; IBA_COMMON_MAX_PX;
+ * IBA_PAIR_MEMO=0 no reuse of pair lists across calls, IBA_PAIR_MEMO_MAX_B (40) the largest batch that reuses, IBA_PAIR_INFL (1.25)
+ * the inflation of a reusable list's bound; IBA_SIDE_STREAM=0 one stream only; IBA_SPIN_WAIT=0 blocking waits. */
 int32_t iba_debug_last_path(const iba_handle* h);
 /* debug: how often the anchored neighbour lists (the 1-NN search memoised around an anchor extrinsic that follows the
  * optimiser's candidates; IBA_NN_SETS=0 disables them, IBA_ANCHOR_REACH sets the drift in metres that moves the anchor) have
