@@ -100,7 +100,7 @@ struct iba_handle {
     CommonRef cref; bool cref_ok = false; // reference candidate and bound of the pair lists this call uses (plan_pairs at staging time)
     bool pairs_valid = false, pairs_reuse = false;   // the device holds lists built for cref; this call reuses them (no pair search)
     int pair_memo = 1; double pair_infl = 1.25, pair_rho_floor = 1e-4, pair_tau_floor = 1e-3;   // IBA_PAIR_MEMO, IBA_PAIR_INFL
-    int pairs_builds = 0; int pair_memo_max_b = 40; bool memo_this_call = false;   // IBA_PAIR_MEMO_MAX_B
+    int pairs_builds = 0; int pair_memo_max_b = 40; double pair_memo_max_px = 8.0; bool memo_this_call = false;   // IBA_PAIR_MEMO_MAX_B
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
     int last_nn_nrec = 0, last_nn_B = 0;   // shape of the search kernel's records of the last evaluation (iba_debug_nn_left_to_tree)
     bool he_staged = false;               // the hand-eye terms of the staged candidates were computed by the staging launch
@@ -340,15 +340,19 @@ bool plan_pairs(iba_handle* h, const Cand* hc, int B) {
     if (!(best < INFINITY)) return false;   // a NaN candidate: no bound
     std::memcpy(cr.R, hc[ref].R, sizeof(cr.R)); std::memcpy(cr.t, hc[ref].t, sizeof(cr.t));
     if (!batch_spread(hc, B, cr.R, cr.t, cr.rho, cr.tau, cr.rel)) return false;
-    if (memo) {
+    auto nominal_px = [&]() {
+        double rho_row = 0, tau_max = 0;
+        for (int r = 0; r < 3; ++r) { rho_row = std::max(rho_row, cr.rho[r * 3] + cr.rho[r * 3 + 1] + cr.rho[r * 3 + 2]); tau_max = std::max(tau_max, cr.tau[r]); }
+        return h->max_fx * (rho_row * 12.0 + tau_max) * 1.8 / 10.0;
+    };
+    // a reusable (inflated, entrywise-bounded) list only for a tight batch: a list grows with the square of its window, and at
+    // 16 px of nominal spread the inflated one overflows its capacity where the batch's own fits (tools/wide_probe.py)
+    if (memo && nominal_px() <= h->pair_memo_max_px) {
         for (int i = 0; i < 9; ++i) cr.rho[i] = cr.rho[i] * h->pair_infl + h->pair_rho_floor;
         for (int i = 0; i < 3; ++i) cr.tau[i] = cr.tau[i] * h->pair_infl + h->pair_tau_floor;
-    }
-    double rho_row = 0, tau_max = 0;
-    for (int r = 0; r < 3; ++r) { rho_row = std::max(rho_row, cr.rho[r * 3] + cr.rho[r * 3 + 1] + cr.rho[r * 3 + 2]); tau_max = std::max(tau_max, cr.tau[r]); }
+    } else h->memo_this_call = false;
     if (h->common_mode >= 2) return true;
-    const double nominal_px = h->max_fx * (rho_row * 12.0 + tau_max) * 1.8 / 10.0;
-    return nominal_px <= h->common_max_px;
+    return nominal_px() <= h->common_max_px;
 }
 
 iba_status ensure_scratch(iba_handle* h);
