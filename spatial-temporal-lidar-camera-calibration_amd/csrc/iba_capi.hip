@@ -79,6 +79,7 @@ struct iba_handle {
     float last_assoc_ms = 0.f, last_nn_ms = 0.f;
     // common pairs of a batch of nearby candidates (iba_pairs_kernel + iba_assoc2_kernel)
     LdsLayout alay2{};                    // LDS plan of iba_assoc2_kernel
+    int assoc2_flreg_on = 1;              // IBA_ASSOC2_FLREG
     DevBuf<PairRec> d_pairs;              // n_frames x pair_cap
     DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
     DevBuf<uint32_t> mpk;                 // per frame: keypoints that own a MapPoint
@@ -263,6 +264,8 @@ bool layout_nn(const iba_handle* h, NNLayout& L) {
     return L.total <= kLdsBytes;
 }
 
+// iba_assoc2_kernel<true>: at most four keypoints per thread, their flags in registers (IBA_ASSOC2_FLREG=0: always through LDS)
+bool assoc2_flreg(const iba_handle* h) { return h->assoc2_flreg_on && h->maxK <= 4u * (uint32_t)kThreads; }
 // LDS plan of iba_assoc2_kernel: best d^2, best index and flag word per keypoint, the reduction slab
 bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;
@@ -271,7 +274,7 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     const uint32_t Kp = (std::max(h->maxK, 1u) + 3u) & ~3u;
     L.off_best_d2 = off; off += 8u * Kp;
     L.off_best_idx = off; off += 4u * Kp;
-    L.off_kfl = off; off += 4u * Kp;
+    L.off_kfl = off; if (!assoc2_flreg(h)) off += 4u * Kp;   // (the register variant keeps no LDS copy of the flags)
     off = align_up(off, 16); L.off_red = off; off += red_bytes;
     off = align_up(off, 16); L.off_pair = off; off += 2u * (uint32_t)kPairNote;   // possible winners beyond the register window
     L.total = align_up(off, 16);
@@ -661,8 +664,12 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     }
     if (common) {
         { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }   // the candidates and the hand-eye terms: first read here
-        hipLaunchKernelGGL(iba_assoc2_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                           h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
+        if (assoc2_flreg(h))
+            hipLaunchKernelGGL(iba_assoc2_kernel<true>, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                               h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
+        else
+            hipLaunchKernelGGL(iba_assoc2_kernel<false>, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                               h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
     } else {
     { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }
     hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
@@ -959,6 +966,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_SPIN_WAIT")) h->spin_wait = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_ANCHOR_REACH")) h->anchor_reach = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIR_BOUND")) h->pair_bound = std::atoi(e);
+    if (const char* e = std::getenv("IBA_ASSOC2_FLREG")) h->assoc2_flreg_on = std::atoi(e);
     if (const char* e = std::getenv("IBA_PAIR_MEMO")) h->pair_memo = std::atoi(e);
     if (const char* e = std::getenv("IBA_PAIR_INFL")) h->pair_infl = std::max(1.0, std::atof(e));
     if (const char* e = std::getenv("IBA_PAIR_MEMO_MAX_B")) h->pair_memo_max_b = std::atoi(e);
@@ -1017,7 +1025,8 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     // > 64 KB of dynamic LDS must be opted into per kernel
     if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
-    if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if ((er = hipFuncSetAttribute((const void*)iba_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     const void* nfns[15] = {(const void*)iba_nn_kernel<1, 0, 0>, (const void*)iba_nn_kernel<2, 0, 0>, (const void*)iba_nn_kernel<3, 0, 0>, (const void*)iba_nn_kernel<1, 1, 0>, (const void*)iba_nn_kernel<2, 1, 0>,
                             (const void*)iba_nn_kernel<3, 1, 0>, (const void*)iba_nn_kernel<1, 2, 0>, (const void*)iba_nn_kernel<2, 2, 0>, (const void*)iba_nn_kernel<3, 2, 0>,

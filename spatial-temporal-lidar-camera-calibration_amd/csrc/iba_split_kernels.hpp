@@ -79,7 +79,11 @@ template <class PRM> __device__ __forceinline__ double cost_res(const PRM& prm, 
 // One function, one order of every sum: which kernel ran the first half cannot be told from the results.
 // ------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(4))) const KArgs KArgsC;
-__device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, const uint32_t* s_best_idx, const uint32_t* s_kfl, uint32_t* s_list,
+// FLREG (at most 2048 keypoints per frame: four per thread): the thread's four flag words arrive in registers (rf, loaded from global
+// memory at the start of the kernel) instead of through an LDS copy of the frame's flags, the winners read in the counting pass stay
+// in registers for the list pass, and the covisible-slot mask of a list entry is parked next to it (s_msk, over the winners' array).
+template <bool FLREG>
+__device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, uint32_t* s_best_idx, const uint32_t* s_kfl, const uint4 rf, uint32_t* s_list,
                                            double* s_red, const double* s_rel, const uint32_t K, const int want, const int dbg, const bool refit, const int b, const int f, const int nf,
                                            double* __restrict__ part, const double* __restrict__ he, uint4* __restrict__ flist,
                                            uint32_t* __restrict__ fcount, uint32_t* __restrict__ lcount, const int flist_stride) {
@@ -102,8 +106,10 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     const uint32_t k0 = (uint32_t)tid * q;
     uint32_t n_corr = 0u;
     unsigned long long mine = 0ull;   // valid | cost-list << 16 | association-list << 32 of this thread's run (K < 65535: each fits 16 bits, so do the block totals)
+    uint4 bi_keep = make_uint4(kNone, kNone, kNone, kNone);
     for (uint32_t g = 0; g < q && k0 + g < K; g += 4u) {
-        const uint4 bi = *(const uint4*)(s_best_idx + k0 + g), fl4 = *(const uint4*)(s_kfl + k0 + g);
+        const uint4 bi = *(const uint4*)(s_best_idx + k0 + g), fl4 = FLREG ? rf : *(const uint4*)(s_kfl + k0 + g);
+        if (FLREG) bi_keep = bi;
         const uint32_t bv[4] = {bi.x, bi.y, bi.z, bi.w}, fv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -123,13 +129,14 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
     uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
     uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
+    uint32_t* s_msk = s_best_idx;        // FLREG: per list item its covisible-slot mask (the winners were read before the barrier above)
     {
         const int sh = usedC ? 16 : 32;   // which of the two lists this evaluation builds
         n3 = (usedC || usedA) ? (uint32_t)((total >> sh) & 0xffffull) : 0u;
         uint32_t at = (uint32_t)(((before + (incl - mine)) >> sh) & 0xffffull);   // entries of the threads before this one
         if (usedC || usedA)
             for (uint32_t g = 0; g < q && k0 + g < K; g += 4u) {
-                const uint4 bi = *(const uint4*)(s_best_idx + k0 + g), fl4 = *(const uint4*)(s_kfl + k0 + g);
+                const uint4 bi = FLREG ? bi_keep : *(const uint4*)(s_best_idx + k0 + g), fl4 = FLREG ? rf : *(const uint4*)(s_kfl + k0 + g);
                 const uint32_t bv[4] = {bi.x, bi.y, bi.z, bi.w}, fv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
                 uint32_t ip[4]; bool wk[4];
 #pragma unroll
@@ -141,7 +148,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (wk[j]) { s_list[at] = (k0 + g + (uint32_t)j) | ((fv[j] & 3u) << 16); s_pos[at] = ip[j]; ++at; }   // the slot mask is read from s_kfl where it is needed
+                    if (wk[j]) { s_list[at] = (k0 + g + (uint32_t)j) | ((fv[j] & 3u) << 16); s_pos[at] = ip[j]; if (FLREG) s_msk[at] = fv[j] >> 2; ++at; }   // (not FLREG: the slot mask is read from s_kfl where it is needed)
             }
     }
     __syncthreads();
@@ -169,7 +176,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     if (usedC) {
         for (uint32_t i = tid; i < n3; i += kThreads) {
             const uint32_t k = s_list[i] & 0xffffu, pos = s_pos[i];
-            uint32_t mask = s_kfl[k] >> 2;
+            uint32_t mask = FLREG ? s_msk[i] : s_kfl[k] >> 2;
             if (!mask) continue;
             float xf_, yf_, zf_; load_pt<true>(c, pos, xf_, yf_, zf_);
             const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 
     if (dbg == 5) return;
     IBA_RELOAD();
-    assoc_tail(ka, h, cd, c, s_best_idx, s_kfl, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
+    assoc_tail<false>(ka, h, cd, c, s_best_idx, s_kfl, make_uint4(0u, 0u, 0u, 0u), s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
 #undef dp
 #undef prm
 #undef lay
@@ -864,6 +871,7 @@ __device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* 
 // LDS: 16 B per keypoint (best d^2, best index, flags) + the relative poses: ~33 KB at 2000 keypoints.
 constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
 constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
+template <bool FLREG>   // FLREG: the frame's keypoint flags never go through LDS (at most 2048 keypoints per frame; see assoc_tail)
 __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
                                                               const double* __restrict__ he, uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
                                                               uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hard,
@@ -897,6 +905,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
 
     // ---- the counts of this frame's common lists, the first pairs of this thread, the tables ----
     const uint32_t* cnt = counts + (size_t)f * kCountStride;
+    uint4 rf = make_uint4(0u, 0u, 0u, 0u);
     const bool overflow = cnt[2] != 0u;   // a list did not hold everything: every point again, exactly (speed only)
     const uint32_t npair = overflow ? 0u : min(cnt[0], (uint32_t)pair_cap), nhard = overflow ? 0u : min(cnt[1], (uint32_t)hard_cap);
     const float4* prq = (const float4*)(pairs + (size_t)f * (size_t)pair_cap);   // two 16-byte halves per record
@@ -904,6 +913,11 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
         const uint32_t* gfl = dp.kp_fl + h.kp_base;
         double rv = 0.0;
         if (ut < h.n_slots * 12u) rv = dp.slots[h.slot_base + ut / 12].rel[ut % 12];
+        if (FLREG) {   // this thread's four flag words: in flight until the tail
+            const uint32_t k4 = ut * 4u;
+            rf.x = k4 < K ? gfl[k4] : 0u; rf.y = k4 + 1u < K ? gfl[k4 + 1u] : 0u; rf.z = k4 + 2u < K ? gfl[k4 + 2u] : 0u; rf.w = k4 + 3u < K ? gfl[k4 + 3u] : 0u;
+            for (uint32_t i = ut; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; }
+        } else
         for (uint32_t i = ut; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kfl[i] = gfl[i]; }
         if (ut < h.n_slots * 12u) s_rel[ut] = rv;
         if (tid == 0) s_qn[0] = 0u;
@@ -1005,7 +1019,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
         for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<2>(c, gcs, u, v, pos); }
     __syncthreads();
     if (dbg == 5) return;
-    assoc_tail(ka, h, cd, c, s_best_idx, s_kfl, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
+    assoc_tail<FLREG>(ka, h, cd, c, s_best_idx, s_kfl, rf, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
 #undef dp
 #undef prm
 #undef lay
