@@ -5,10 +5,11 @@ BOTH the BAError tuple (iba_global.cpp:169-344) AND the Gauss-Newton normal equa
 at x (iba_local.cpp:145-323 + IBACalib2.hpp factors). Frames shard across GPUs; one sum all-reduce of the partial blocks per
 call (RCCL over xGMI).
 
-  --scaling weak   (default) every GPU holds configs[1]'s shape — 200 keyframes x 10 k points — so the map grows with the
-                   GPU count (configs[2], [3]); one unit of work = one candidate against ONE GPU's 200 keyframes, and
-                   value = units / s over all ranks (N units per candidate at N GPUs).
-  --scaling strong the 200-keyframe / 2 M-point problem of the metric itself split N ways; value = candidates / s.
+  --scaling strong (default) the 200-keyframe / 2 M-point problem of the metric itself (BASELINE.json: "2M pts x 200 KF @1/2/4/8
+                   GPU") split N ways; value = candidates / s of THAT problem, whatever the GPU count.
+  --scaling weak   every GPU holds configs[1]'s shape — 200 keyframes x 10 k points — so the map grows with the GPU count
+                   (configs[2], [3]: N x 200 keyframes); value = candidates / s of that N-times-larger problem (NOT multiplied
+                   by N: the record says how many keyframes a candidate covered).
 """
 import argparse
 import hashlib
@@ -50,7 +51,7 @@ def source_stamp():
     return hsh.hexdigest()[:16]
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -59,7 +60,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--pts", type=int, default=PTS_PER_FRAME)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plane-cache", type=int, default=1, help="1 = memoise the x-independent local-plane fits (default), 0 = refit inside every evaluation")
     ap.add_argument("--no-extras", action="store_true", help="timed region and roofline only (profiling runs)")
@@ -67,7 +68,19 @@ def main():
                     help="how N GPUs are driven: ranks = one process per GPU over torch.distributed / RCCL (what the driver's torchrun line gives; "
                          "without WORLD_SIZE in the environment bench.py starts the N ranks itself), group = ONE process, iba_group_* with one issuing "
                          "thread and one RCCL communicator per device; auto = ranks")
-    args = ap.parse_args()
+    return ap
+
+
+def job_value(evals, seconds, n_gpus, scaling):
+    """The record's `value`: candidates evaluated against EVERY keyframe of the job per second — the whole-job aggregate. Never
+    multiplied by the GPU count: in strong scaling the job is BASELINE's 200-keyframe problem at every N, in weak scaling it is
+    N x 200 keyframes and the record says so (config.total_frames)."""
+    assert scaling in ("strong", "weak") and n_gpus >= 1
+    return evals / seconds
+
+
+def main():
+    args = build_parser().parse_args()
 
     # ---- how many GPUs, really: --gpus is the contract, WORLD_SIZE what a launcher gave us; they must agree ----
     env_world = os.environ.get("WORLD_SIZE")
@@ -225,6 +238,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stage("timed steps done")
+    # the timed region is ~10 ms at the default 20 steps: four more regions of the same K steps (AFTER the one the record's value
+    # comes from) give its spread — a regression of a few per cent is otherwise inside the noise of one region
+    region_rates = [B * args.steps / dt]
+    for _ in range(4):
+        sync()
+        t0r = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i)
+        sync()
+        dtr = time.perf_counter() - t0r
+        if use_dist:
+            tr_ = torch.tensor([dtr], dtype=torch.float64, device=dev)
+            dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+            dtr = float(tr_.item())
+        region_rates.append(B * args.steps / dtr)
 
     # ---- dominant kernels, timed with HIP events on their launch stream ----
     L = pkg.load_library()
@@ -249,8 +277,8 @@ def main():
     achieved = B * per_eval / (pair_ms * 1e-3) / 1e9
 
     evals = B * args.steps
-    units = n_gpus if args.scaling == "weak" else 1
-    value = units * evals / dt
+    units = 1            # one unit = one candidate against every keyframe of the job (never multiplied by the GPU count)
+    value = job_value(evals, dt, n_gpus, args.scaling)
     if group_mode:
         launch, rccl_ranks = "group: one process, iba_group_* (one issuing thread + one RCCL communicator per device)", grp.comm_ranks
     elif use_dist:
@@ -273,7 +301,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": ("configs[1]-shaped synthetic street scene %s: %d keyframes x %d pts (%.1fM pts), %d keypoints/KF, IBACalib cost (3d-2d + 3d-3d plane + hand-eye) "
-                         "+ iba_local normal equations per candidate") % ("per GPU" if args.scaling == "weak" else "split over the GPUs", args.frames, args.pts, args.frames * args.pts / 1e6, KEYPOINTS),
+                         "+ iba_local normal equations per candidate") % ("per GPU (the job holds N x this)" if (args.scaling == "weak" and n_gpus > 1) else "split over the GPUs", args.frames, args.pts, args.frames * args.pts / 1e6, KEYPOINTS),
             "frames_this_rank": f1 - f0, "points_per_frame": args.pts, "keypoints_per_frame": KEYPOINTS,
             "candidates_per_step": B, "total_frames": prob.n_frames, "total_points": prob.n_points,
             "candidate_spread": "x_gt + N(0, 0.5 mrad), N(0, 5 mm), N(0, 0.1 %) per component (see extras.wide_candidates for a MADS-box-wide batch)",
@@ -283,39 +311,51 @@ def main():
             "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of %d doubles per call" % (n_gpus, B * stride),
             "untimed_steps_before_warmup": args.settle,
             "launch": launch, "rccl_ranks": rccl_ranks,
-            "unit_definition": ("weak scaling: 1 eval = one candidate x against %d keyframes / %.1fM points (+ normal equations); at N GPUs a candidate covers N x %d "
-                                "keyframes = N units, value = units/s over all ranks" % (args.frames, args.frames * args.pts / 1e6, args.frames)) if args.scaling == "weak" else
-                               "strong scaling: 1 eval = one candidate x against the whole %d-keyframe problem, whatever the GPU count" % args.frames,
-            "candidates_per_s_of_the_sharded_problem": evals / dt,
+            "unit_definition": ("weak scaling: 1 eval = one candidate x against ALL %d keyframes of the job (%d per GPU), cost tuple + normal equations; "
+                                "value = candidates/s, not multiplied by the GPU count" % (prob.n_frames, args.frames)) if args.scaling == "weak" else
+                               "strong scaling: 1 eval = one candidate x against the whole %d-keyframe / %.1fM-point problem (cost tuple + normal equations), whatever the GPU count" % (args.frames, args.frames * args.pts / 1e6),
         },
         "roofline": {
-            # what the counters say (profiles/r03*): the association and search kernels are bound by vector-instruction issue and
-            # the latency of dependent gathers, not by HBM. `achieved` is the REFERENCE formulation's algorithmic bytes (SURVEY
-            # 8(d): every candidate streams every scan and gathers 31 points per MapPoint) over these kernels' time — an effective
-            # rate. The kernels do not move those bytes: the planes are memoised (plane_cache), a batch shares one 2d-3d pair
-            # search per keyframe, the 1-NN search is memoised around an anchor extrinsic; so the figure can exceed the HBM peak.
-            # `frac_like_for_like` is the same ratio with the planes fitted inside every evaluation (plane_cache = 0), the
-            # formulation the bytes were counted for; `traffic` / `issue_frac` are measured (counter passes, stamped).
-            "bound": "issue", "kernel": "association (iba_pairs_kernel + iba_assoc2_kernel) + search (iba_nn_kernel)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "issue_frac": None, "frac_like_for_like": None,
-            "achieved_is": "algorithmic bytes of SURVEY 8(d) x candidates per launch / (association + search kernel time); an effective rate against the uncached, unbatched formulation",
-            "algorithmic_bytes_per_eval": per_eval, "evals_per_launch": B, "launch_ms": pair_ms, "shared_pair_search": bool(h.last_path),
+            # PHYSICAL figures only (round 3's `frac` was an effective rate against the reference's formulation and exceeded 1):
+            #   achieved = HBM bytes the dominant kernels really moved per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes,
+            #              profiles/pmc_latest.json, stamped with the kernel sources' hash) / their launch time measured HERE with HIP
+            #              events on the launch stream;  hbm_frac = achieved / 8 TB/s.
+            #   frac     = the fraction of the roof that BINDS these kernels: vector-instruction issue (bound "issue"): the share of
+            #              SIMD cycles that issue a VALU instruction (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)).
+            # The old effective figure lives on under effective_vs_reference_formulation (it is not a roofline fraction).
+            "bound": "issue", "kernel": "association (iba_pairs_kernel + iba_assoc2_kernel) + search (iba_nn_kernel)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None, "hbm_frac": None, "traffic": None, "issue_frac": None,
+            "launch_ms": pair_ms, "evals_per_launch": B, "shared_pair_search": bool(h.last_path),
             "kernel_ms": {"association (pairs + assoc2)": assoc_ms, "iba_nn_kernel": nn_ms, "factor + sums": rest_ms},
+            "effective_vs_reference_formulation": {
+                "what": "algorithmic bytes of SURVEY 8(d) (every candidate streams every scan, gathers 31 points per MapPoint) x candidates per launch / (association + search kernel time): "
+                        "an effective rate against the uncached, unbatched formulation. The kernels do not move those bytes (planes memoised, one pair search per batch, 1-NN memoised around an anchor), "
+                        "so it may exceed the HBM peak; like_for_like = the same ratio with the planes fitted inside every evaluation (plane_cache = 0), over the whole step",
+                "algorithmic_bytes_per_eval": per_eval, "effective_GBs": achieved, "ratio_to_hbm_peak": achieved / HBM_PEAK_GBS, "like_for_like": None},
         },
     }
-    # measured HBM traffic and VALU issue share of the same launch shape, from the committed counter passes — only when they
-    # were taken on these kernel sources (tools/prof_run.sh stamps them)
+    # measured HBM traffic and VALU issue share of the same launch shape from the committed counter passes (tools/prof_run.sh +
+    # tools/summarize_prof.py stamp them with the kernel sources' hash). Counters taken on OTHER sources of the same shape are
+    # still quoted, flagged pmc_stale (a physical figure of a nearby kernel version beats none); another shape is not quoted.
     pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_file):
         try:
             pmc = json.load(open(pmc_file))
             same_shape = (pmc.get("frames"), pmc.get("pts"), pmc.get("batch")) == (f1 - f0, args.pts, B)
-            if pmc.get("source_stamp") == source_stamp() and same_shape:
-                res["roofline"]["traffic"] = pmc.get("hbm_bytes_per_launch")
-                res["roofline"]["issue_frac"] = pmc.get("valu_issue_frac")
-                res["roofline"]["pmc_provenance"] = {k: pmc.get(k) for k in ("git_head", "source_stamp", "taken_on", "counters")}
+            if same_shape:
+                rf = res["roofline"]
+                rf["traffic"] = pmc.get("hbm_bytes_per_launch")
+                rf["issue_frac"] = pmc.get("valu_issue_frac")
+                rf["achieved"] = rf["traffic"] / (pair_ms * 1e-3) / 1e9
+                rf["hbm_frac"] = rf["achieved"] / HBM_PEAK_GBS
+                rf["frac"] = rf["issue_frac"]
+                rf["pmc_stale"] = pmc.get("source_stamp") != source_stamp()
+                if pmc.get("hbm_bytes_per_step"):
+                    rf["whole_step"] = {"hbm_bytes": pmc["hbm_bytes_per_step"], "hbm_frac": pmc["hbm_bytes_per_step"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                        "issue_frac": pmc.get("valu_issue_frac_step")}
+                rf["pmc_provenance"] = {k: pmc.get(k) for k in ("round", "git_head", "source_stamp", "taken_on", "counters")}
             else:
-                res["roofline"]["pmc_provenance"] = "profiles/pmc_latest.json is from other sources or another shape: not quoted"
+                res["roofline"]["pmc_provenance"] = "profiles/pmc_latest.json was taken on another launch shape (%s frames x %s pts x %s candidates): not quoted" % (pmc.get("frames"), pmc.get("pts"), pmc.get("batch"))
         except Exception:
             pass
 
@@ -325,6 +365,8 @@ def main():
         stage("extras are measured in the default launch mode: skipped with --launch group")
     if not args.no_extras and not group_mode:
         extras = {}
+        extras["timed_region_repeats"] = {"regions": len(region_rates), "steps_each": args.steps, "evals_per_s": region_rates, "min": float(np.min(region_rates)), "median": float(np.median(region_rates)),
+                                          "max": float(np.max(region_rates)), "note": "region 0 is the record's value; the others follow it back to back"}
         st = torch.cuda.current_stream().cuda_stream
         # (1) batch-size sweep: wall and device time per call (NOMAD polls 8..14 points, the BAError shim calls B = 1)
         sweep = {}
@@ -374,6 +416,45 @@ def main():
         a, n, r = phases()
         extras["wide_candidates"] = {"spread": "uniform over the yml search box around x_gt", "evals_per_s": units * B / tw, "ms_per_step": tw * 1e3, "assoc_ms": a, "nn_ms": n,
                                      "factor_sums_ms": r, "mean_n_corr": float(np.mean([c.n_corr for c in ow[0]]))}
+        # (2b) strong-scaling prediction on ONE GPU: the frame shard a rank of a 2 / 4 / 8-GPU job holds (100 / 50 / 25 keyframes of the
+        # 200), timed as bench.py's step (B = 64, host finalisation) and with a pipelined batch of 64 N candidates (the partial entry
+        # point enqueues the 64-candidate chunks back to back without a host round trip in between: what keeps a small shard's GPU
+        # full). Speed-up = time of the 200-keyframe handle / time of the shard at the same candidates; the all-reduce of 64 x 64
+        # doubles is not in it (latency-bound, ~20-40 us over xGMI).
+        if world == 1 and args.scaling == "strong" and args.frames >= 64:
+            emu = {}
+            t_full = {}
+            for nsh in (1, 2, 4, 8):
+                fe = args.frames // nsh
+                hs = h if nsh == 1 else pkg.IbaHandle(prob, params, device=local_rank, frame_begin=0, frame_end=fe)
+                row = {"frames": fe}
+                for mult in (1, nsh) if nsh > 1 else (1, 2, 4, 8):
+                    Bm = B * mult
+                    xm = np.vstack([xs_all[i % len(xs_all)] for i in range(mult)])
+                    dm = torch.zeros(Bm * stride, dtype=torch.float64, device=dev)
+                    hm = torch.zeros(Bm * stride, dtype=torch.float64).pin_memory()
+
+                    def one():
+                        hs.eval_full_partial(xm, dm.data_ptr(), st)
+                        hm.copy_(dm, non_blocking=True)
+                        torch.cuda.current_stream().synchronize()
+                    for _ in range(5):
+                        one()
+                    ts = []
+                    for _ in range(15):
+                        t0 = time.perf_counter(); one(); ts.append(time.perf_counter() - t0)
+                    tmed = float(np.median(ts))
+                    row["B%d" % Bm] = {"ms_per_call": tmed * 1e3, "candidates_per_s_this_shard": Bm / tmed}
+                    if nsh == 1:
+                        t_full[Bm] = tmed
+                emu[str(nsh)] = row
+                if nsh > 1:
+                    hs.close()
+            for nsh in (2, 4, 8):
+                r_ = emu[str(nsh)]
+                r_["predicted_speedup_same_batch_64"] = t_full[B] / (r_["B%d" % B]["ms_per_call"] * 1e-3)
+                r_["predicted_speedup_batch_64N"] = (r_["B%d" % (B * nsh)]["candidates_per_s_this_shard"]) / (B / t_full[B])
+            extras["strong_shard_emulation"] = emu
         # (3) same workload with the local planes refitted inside every evaluation, as the reference does
         other = abi.reference_yaml_params(plane_cache=1 - args.plane_cache)
         h.set_params(other)
@@ -395,7 +476,7 @@ def main():
             t_other = float(t.item())
         res["value_plane_refit" if args.plane_cache else "value_plane_cache"] = units * B * nrep / t_other
         if args.plane_cache:   # the like-for-like roofline figure: what the reference computes per evaluation, over the whole step's time
-            res["roofline"]["frac_like_for_like"] = (B * nrep * per_eval / t_other / 1e9) / HBM_PEAK_GBS
+            res["roofline"]["effective_vs_reference_formulation"]["like_for_like"] = (B * nrep * per_eval / t_other / 1e9) / HBM_PEAK_GBS
         h.set_params(params)
         # (3b) the plane memo itself: what a change of a plane parameter costs (every scan point of this rank refitted)
         moved = abi.reference_yaml_params(plane_cache=1)
@@ -433,7 +514,7 @@ def main():
                 "keyframes": kf, "points_per_scan": 120000, "ms_per_step": tk * 1e3, "evals_per_s_at_this_size": B / tk,
                 "evals_per_s_scaled_to_200_keyframes": B / tk * kf / 200.0,
                 "kernel_ms": {"association (pairs + assoc2)": pa.value, "iba_nn_kernel": pn.value, "factor + sums": pr.value},
-                "algorithmic_bytes_per_eval": per_eval_k, "frac": (B * per_eval_k / ((pa.value + pn.value) * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_eval": per_eval_k, "effective_vs_reference_formulation_ratio_to_hbm_peak": (B * per_eval_k / ((pa.value + pn.value) * 1e-3) / 1e9) / HBM_PEAK_GBS,
                 "mean_n_corr": float(np.mean([c.n_corr for c in ck])), "shared_pair_search": bool(hb.last_path)}
             hb.close()
             del big
@@ -464,7 +545,7 @@ def main():
             # start as far off as a hand-eye initialiser may be inside the reference's search box, then the LM polish
             xg0 = meta["x_gt"] + np.array([0.009, -0.006, 0.005, 0.06, -0.04, 0.05, 0.4])
             t0 = time.perf_counter()
-            xg, mr = h.calibrate_mads(xg0, max_bb_eval=100000)
+            xg, mr, mtr, mbs = h.calibrate_mads(xg0, record=True, max_bb_eval=100000)
             t_mads = time.perf_counter() - t0
             xl, lr2 = h.calibrate_lm(xg, max_outer_iterations=10)
             t_all = time.perf_counter() - t0
@@ -477,6 +558,38 @@ def main():
                                         "mads_f": mr.f, "mads_seconds": t_mads, "total_seconds": t_all,
                                         "note": "reference budget: 5000 NOMAD evaluations on one CPU thread (iba_calib_global.yml:42) at ~2 evals/s"}
             res["_lm_check_start"] = [float(v) for v in xg]
+            # (5b) what an optimiser really gets: the recorded black-box calls of that MADS run (every x, every batch boundary)
+            # replayed through iba_eval_bbo on a FRESH handle, every cross-call mechanism live and inside the clock (pair searches,
+            # pair-list reuse, anchor rebuilds, clustering of multi-centre batches): evaluations/s over the whole trace and the
+            # share of calls / time per association path
+            hr = pkg.IbaHandle(prob, params, device=local_rank)
+            mo = pkg.mads_options(xg0)
+            Lr = hr.lib
+            Lr.iba_debug_last_path.argtypes = [C.c_void_p]
+            bbo_buf = (pkg.IbaBbo * pkg.IBA_MAX_BATCH)()
+            xr = np.ascontiguousarray(mtr[:, :7])
+            at = 0
+            t_by_path, n_by_path, e_by_path = {}, {}, {}
+            t0 = time.perf_counter()
+            for nb_ in mbs:
+                nb_ = int(nb_)
+                t1 = time.perf_counter()
+                st_ = Lr.iba_eval_bbo(hr.h, C.c_void_p(xr[at:at + nb_].ctypes.data), C.c_int32(nb_), C.c_double(mo.he_threshold), C.c_double(mo.valid_rate), bbo_buf)
+                t2 = time.perf_counter()
+                if st_ != 0:
+                    raise pkg.IbaError(st_, Lr.iba_last_error(hr.h).decode())
+                pth = int(Lr.iba_debug_last_path(hr.h))
+                t_by_path[pth] = t_by_path.get(pth, 0.0) + (t2 - t1); n_by_path[pth] = n_by_path.get(pth, 0) + 1; e_by_path[pth] = e_by_path.get(pth, 0) + nb_
+                at += nb_
+            t_rep = time.perf_counter() - t0
+            names = {0: "per-candidate association (iba_assoc_kernel)", 1: "one shared pair search", 2: "clustered: one pair search per tight group"}
+            extras["mads_trace_replay"] = {
+                "evaluations": int(at), "batches": int(len(mbs)), "mean_batch": float(np.mean(mbs)), "seconds": t_rep, "evals_per_s": at / t_rep,
+                "by_path": {names.get(k, str(k)): {"batches": n_by_path[k], "evaluations": e_by_path[k], "seconds": t_by_path[k], "evals_per_s": e_by_path[k] / t_by_path[k]} for k in sorted(t_by_path)},
+                "anchor_builds": hr.anchor_builds, "pair_searches": hr.pairs_builds,
+                "what": "cost tuple only (iba_eval_bbo = what BALoss::eval_x returns, iba_global.cpp:377-396); compare config.candidate_spread of the headline: "
+                        "this is the optimiser's own sequence of batches from 11.8 mrad / 8.7 cm / 4x scale off down to the minimum mesh"}
+            hr.close()
             # (6) ORB-only extrinsic BA on a planted edge list of the C2 scale: 200 keyframes x 600 observations
             import ba_scene
             ba = importlib.import_module(PKG + ".ba")

@@ -5,41 +5,61 @@
 // format iba_func writes (:457, :466-468).
 //
 //   iba_func <FrameId.yml> <lidar_poses.txt> <velodyne_dir> <KeyFrames_dir> <Map.yml> <sim3_list.txt> <out.txt> [precision=6] [device=0]
+//   iba_func --config <config.yml> [device=0]     the reference's own call: ONE argument, its yaml-cpp config file (iba_func.cpp:356-406:
+//                                                 io.BaseDir/VOIdFile/LOFile/PointCloudDir/init_sim3/res_file/precision, orb.KeyFrameDir/MapFile,
+//                                                 runtime.*), read by iba_run_config_* (csrc/iba_config.cpp)
 //
 // Differences from the reference, on purpose: candidates are evaluated 64 per launch; a trailing newline in the list does
 // not produce the junk record the reference's `while (ifs.peek() != EOF)` loop appends (its 7 extractions fail and leave
-// the record uninitialised). Parameters are config/calib/00/iba_calib_global.yml's (iba_default_params + the yml's overrides).
+// the record uninitialised). Without --config the parameters are config/calib/00/iba_calib_global.yml's (iba_default_params + the yml's overrides).
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include "iba_mi355x.h"
 
 int main(int argc, char** argv) {
-    if (argc < 8) { std::fprintf(stderr, "usage: %s FrameId.yml lidar_poses velodyne_dir KeyFrames_dir Map.yml sim3_list out [precision] [device]\n", argv[0]); return 2; }
-    const int precision = argc > 8 ? std::atoi(argv[8]) : 6, device = argc > 9 ? std::atoi(argv[9]) : 0;
-    iba_dataset_paths paths = {argv[1], argv[2], argv[3], argv[4], argv[5], /*skip*/ 1, /*only_positive_x*/ 0, /*num_best_covis*/ 3, /*min_covis_weight*/ 100};
+    const bool from_config = argc >= 3 && std::string(argv[1]) == "--config";
+    if (!from_config && argc < 8) { std::fprintf(stderr, "usage: %s FrameId.yml lidar_poses velodyne_dir KeyFrames_dir Map.yml sim3_list out [precision] [device]\n       %s --config config.yml [device]\n", argv[0], argv[0]); return 2; }
+    int precision = 6, device = 0;
+    iba_dataset_paths paths;
+    iba_params prm;
+    std::string list_file, out_file;
+    iba_run_config* cfg = nullptr;
+    if (from_config) {
+        if (iba_run_config_load(argv[2], &cfg) != IBA_OK || iba_run_config_paths(cfg, 0, &paths) != IBA_OK || iba_run_config_params(cfg, 0, &prm) != IBA_OK) {
+            std::fprintf(stderr, "config: %s\n", iba_run_config_last_error()); return 1;
+        }
+        const char* in = iba_run_config_get(cfg, "io.init_sim3"); const char* res = iba_run_config_get(cfg, "io.res_file"); const char* pr = iba_run_config_get(cfg, "io.precision");
+        if (!in || !res || !pr) { std::fprintf(stderr, "config: io.init_sim3 / io.res_file / io.precision missing (iba_func.cpp:401-403)\n"); return 1; }
+        list_file = in; out_file = res; precision = std::atoi(pr);   // (used as given, not joined with BaseDir: iba_func.cpp:401-402)
+        device = argc > 3 ? std::atoi(argv[3]) : 0;
+    } else {
+        precision = argc > 8 ? std::atoi(argv[8]) : 6; device = argc > 9 ? std::atoi(argv[9]) : 0;
+        paths = iba_dataset_paths{argv[1], argv[2], argv[3], argv[4], argv[5], /*skip*/ 1, /*only_positive_x*/ 0, /*num_best_covis*/ 3, /*min_covis_weight*/ 100};
+        iba_default_params(&prm);
+        prm.corr_3d_3d_threshold = 10.0; prm.norm_reg_threshold = 0.02; prm.min_diff_dist = 0.2;   // iba_calib_global.yml:26-34
+        list_file = argv[6]; out_file = argv[7];
+    }
     iba_dataset* ds = nullptr;
     if (iba_dataset_load(&paths, &ds) != IBA_OK) { std::fprintf(stderr, "iba_dataset_load: %s\n", iba_io_last_error()); return 1; }
-    iba_params prm;
-    iba_default_params(&prm);
-    prm.corr_3d_3d_threshold = 10.0; prm.norm_reg_threshold = 0.02; prm.min_diff_dist = 0.2;   // iba_calib_global.yml:26-34
     iba_handle* h = nullptr;
     const iba_problem_desc* desc = iba_dataset_desc(ds);
     if (iba_create(desc, &prm, device, 0, desc->n_frames, &h) != IBA_OK) { std::fprintf(stderr, "iba_create: %s\n", iba_last_error(nullptr)); return 1; }
     std::vector<double> xs;   // ReadSim3List: whitespace-separated numbers, 7 per record
     {
-        std::ifstream ifs(argv[6]);
-        if (!ifs) { std::fprintf(stderr, "Cannot open file: %s\n", argv[6]); return 1; }
+        std::ifstream ifs(list_file);
+        if (!ifs) { std::fprintf(stderr, "Cannot open file: %s\n", list_file.c_str()); return 1; }
         double v;
         while (ifs >> v) xs.push_back(v);
         xs.resize(xs.size() / 7 * 7);
     }
     const size_t n = xs.size() / 7;
-    std::ofstream ofs(argv[7]);
+    std::ofstream ofs(out_file);
     ofs << std::setprecision(precision);
     std::vector<iba_cost_out> out(IBA_MAX_BATCH);
     for (size_t i0 = 0; i0 < n; i0 += IBA_MAX_BATCH) {
@@ -56,5 +76,6 @@ int main(int argc, char** argv) {
     ofs.close();
     iba_destroy(h);
     iba_dataset_free(ds);
+    iba_run_config_free(cfg);
     return 0;
 }

@@ -272,7 +272,12 @@ iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
  * Environment (read at iba_create): IBA_COMMON_PAIRS=0 never share, 2 share whenever the bound allows; IBA_COMMON_MAX_PX;
  * IBA_PAIR_MEMO=0 no reuse of pair lists across calls, IBA_PAIR_MEMO_MAX_B (40) the largest batch that reuses, IBA_PAIR_INFL (1.25)
  * the inflation of a reusable list's bound; IBA_SIDE_STREAM=0 one stream only; IBA_SPIN_WAIT=0 blocking waits. */
-int32_t iba_debug_last_path(const iba_handle* h);
+int32_t iba_debug_last_path(const iba_handle* h);   /* 2: the batch was clustered into several tight groups with one pair search each */
+/* The planner behind that decision on B <= IBA_MAX_BATCH candidates, host only (no GPU): a batch whose nominal projection spread
+ * (at a point 12 m out, 10 m deep, focal length max_fx) exceeds max_px is clustered into at most max_groups (<= 4) groups, accepted
+ * when every group is within max_px. group_of[B] (may be NULL) receives each candidate's group, group_px[4] (may be NULL) the
+ * groups' nominal spreads, *n_groups 1 (one shared search), 2..4 (clustered) or 0 (wide everywhere: every candidate for itself). */
+iba_status iba_debug_plan_groups(const double* x, int32_t B, double max_fx, double max_px, int32_t max_groups, int32_t* group_of, double* group_px, int32_t* n_groups);
 /* debug: how often the anchored neighbour lists (the 1-NN search memoised around an anchor extrinsic that follows the
  * optimiser's candidates; IBA_NN_SETS=0 disables them, IBA_ANCHOR_REACH sets the drift in metres that moves the anchor) have
  * been built on this handle. Results do not depend on the anchor: every lane certifies its pick or searches the tree. */
@@ -329,6 +334,11 @@ iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_o
 /* the same two calls with the sequence of black-box evaluations recorded: `trace` receives up to `cap` rows of 8 doubles
  * (x[7], f) in evaluation order, *n_trace the number of evaluations (tests diff the sequence against oracle/mads.py) */
 iba_status iba_calibrate_mads_trace(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace);
+/* ... and with the black-box CALLS recorded as well: batch_sizes receives up to cap_batches call sizes in order (they split the
+ * rows of `trace` into the batches iba_eval_bbo was given), *n_batches their number. bench.py replays such a record through
+ * iba_eval_bbo (extras.mads_trace_replay). */
+iba_status iba_calibrate_mads_record(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace,
+                                     int32_t* batch_sizes, int32_t cap_batches, int32_t* n_batches);
 iba_status iba_mads_selftest_trace(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace);
 
 /*
@@ -405,6 +415,36 @@ void iba_dataset_free(iba_dataset* d);
 /* message of the last failing iba_dataset_* / iba_read_* / iba_write_* call on this thread */
 const char* iba_io_last_error(void);
 
+/*
+ * The reference's RUN CONFIGURATION (config/calib/NN/iba_calib_global.yml and its iba_func / iba_local siblings): what main()
+ * reads with yaml-cpp — the maps io / orb / runtime (iba_global.cpp:412-471, iba_func.cpp:356-406, iba_local.cpp:325-378) — turned
+ * into this header's structs, so that a run on the reference pipeline's artefacts takes the reference's own config file.
+ * csrc/iba_config.cpp; host only. A missing key is an error (IBA_ERR_IO), as yaml-cpp's .as<T>() throws.
+ */
+typedef struct iba_run_config iba_run_config;
+iba_status iba_run_config_load(const char* yaml_file, iba_run_config** out);
+void iba_run_config_free(iba_run_config* c);
+const char* iba_run_config_last_error(void);   /* of the last failing iba_run_config_* call on this thread */
+/* iba_default_params + the file's runtime keys. local_stage = 0: IBAGlobalParams as iba_global / iba_func fill it
+ * (iba_global.cpp:436-459); 1: IBALocalParams as iba_local fills it (iba_local.cpp:358-377). */
+iba_status iba_run_config_params(const iba_run_config* c, int32_t local_stage, iba_params* out);
+/* The dataset files as main() derives them: BaseDir (+ '/') + VOIdFile / LOFile, PointCloudDir, orb.KeyFrameDir, orb.MapFile,
+ * num_best_covis, min_covis_weight. local_stage = 0 ignores PointCloudskip / PointCloudOnlyPositiveX exactly as iba_global does
+ * (it reads them and then calls readPointCloud without them, iba_global.cpp:450-451 vs :494); 1 passes them (iba_local.cpp:394).
+ * The strings belong to `c` and live until iba_run_config_free. */
+iba_status iba_run_config_paths(iba_run_config* c, int32_t local_stage, iba_dataset_paths* out);
+/* The NOMAD set-up of the global stage (iba_global.cpp: lb / ub added to x0 :530-533, init_frame, min_mesh, max_bbeval, he_threshold, valid_rate, seed,
+ * use_vns) on top of iba_default_mads_options(x0). */
+iba_status iba_run_config_mads(const iba_run_config* c, const double* x0, iba_mads_options* out);
+/* any entry as text, "section.key" ("io.init_sim3", "runtime.direction_type"; sequences as "[a, b]"); NULL when absent */
+const char* iba_run_config_get(const iba_run_config* c, const char* dotted_key);
+/* BaseDir (+ '/') + io.<io_key> ("init_sim3", "gt_sim3", "ResFile", "VOFile"); NULL when absent; valid until the next call with the same key */
+const char* iba_run_config_path(const iba_run_config* c, const char* io_key);
+
+/* The numbers of one TOP-LEVEL entry of a cv::FileStorage YAML file ("%YAML:1.0": KeyFrames/NNNNNN.yml, Map.yml, ORB-SLAM2 settings
+ * such as config/orb_ori/KITTI00-02.yaml, whose Camera.fx.. become KeyFrame::fx..): a scalar, a flow sequence or the data of an
+ * !!opencv-matrix node, through the reader iba_dataset_load uses. *n_out = how many there are; at most cap are written. */
+iba_status iba_read_cv_yaml_numbers(const char* file, const char* key, double* out, int32_t cap, int32_t* n_out);
 /* readPointCloud for .bin (io_tools.h:142-196): XYZI float32 records; with skip > 1 the reference advances its counter
  * by `skip` but reads CONSECUTIVE records, i.e. it keeps the first floor((n - skip) / skip) + 1 points — reproduced.
  * *xyz is malloc'ed (release with iba_io_free). */

@@ -181,20 +181,26 @@ class IbaHandle:
         self._chk(self.lib.iba_calibrate_lm(self.h, _p(x0), C.byref(o), C.byref(r)))
         return np.array(r.x[:]), r
 
-    def calibrate_mads(self, x0, trace=False, **opts):
+    def calibrate_mads(self, x0, trace=False, record=False, **opts):
         """Global stage: batch-aware MADS on BALoss::eval_x's objective + 3 progressive-barrier constraints
         (the caller the reference gets from NOMAD, iba_global.cpp:551-602). opts override iba_default_mads_options;
-        lb/ub given as 7-vectors are ABSOLUTE bounds. trace=True also returns the evaluated points (rows of x[7], f)."""
+        lb/ub given as 7-vectors are ABSOLUTE bounds. trace=True also returns the evaluated points (rows of x[7], f);
+        record=True returns them together with the size of every black-box call (the batches iba_eval_bbo was given)."""
         x0 = np.ascontiguousarray(x0, np.float64)
         o = mads_options(x0, **opts)
         r = IbaMadsResult()
-        if not trace:
+        if not trace and not record:
             self._chk(self.lib.iba_calibrate_mads(self.h, _p(x0), C.byref(o), C.byref(r)))
             return np.array(r.x[:]), r
-        tr = np.zeros((int(o.max_bb_eval), 8))
+        tr = np.zeros((int(o.max_bb_eval) + IBA_MAX_BATCH, 8))   # (the last batch may overshoot the budget by less than one batch)
         n = C.c_int32(0)
-        self._chk(self.lib.iba_calibrate_mads_trace(self.h, _p(x0), C.byref(o), C.byref(r), _p(tr), C.c_int32(len(tr)), C.byref(n)))
-        return np.array(r.x[:]), r, tr[: n.value]
+        if not record:
+            self._chk(self.lib.iba_calibrate_mads_trace(self.h, _p(x0), C.byref(o), C.byref(r), _p(tr), C.c_int32(len(tr)), C.byref(n)))
+            return np.array(r.x[:]), r, tr[: min(n.value, len(tr))]
+        bs = np.zeros(len(tr), np.int32)
+        nb = C.c_int32(0)
+        self._chk(self.lib.iba_calibrate_mads_record(self.h, _p(x0), C.byref(o), C.byref(r), _p(tr), C.c_int32(len(tr)), C.byref(n), _p(bs), C.c_int32(len(bs)), C.byref(nb)))
+        return np.array(r.x[:]), r, tr[: min(n.value, len(tr))], bs[: min(nb.value, len(bs))].copy()
 
     def build_problem(self, x):
         x = np.ascontiguousarray(x, np.float64)

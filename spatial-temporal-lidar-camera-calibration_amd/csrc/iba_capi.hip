@@ -22,6 +22,7 @@
 #include "iba_kernels.hpp"
 #include "iba_lm.hpp"
 #include "iba_mads.hpp"
+#include "iba_mads_glue.hpp"
 #include "iba_split_kernels.hpp"
 #include "iba_types.hpp"
 
@@ -88,7 +89,15 @@ struct iba_handle {
     bool anchor_valid = false; AnchorRef anchor_ref{}; int calls_since_anchor = 0;
     double anchor_reach = 0.06;           // IBA_ANCHOR_REACH (m): a batch whose reference candidate moves a nominal MapPoint further than this from the anchor's query gets a new anchor
     int anchor_builds = 0;
-    unsigned pairs_epoch = 0;             // which of the two counter sets the next call uses
+    // list slots of the common pairs: each holds the pair lists of ONE group of candidates (reference + bound) and may outlive the call
+    struct PairSlot { GroupRef ref{}; bool valid = false; unsigned epoch = 0; unsigned long long last_use = 0; };
+    PairSlot pslot[kMaxPairGroups];
+    unsigned long long pair_clock = 0;
+    PairsPlan pplan{}; int n_build = 0;   // this call's pair search: the groups that need new lists
+    Assoc2Map amap{};                     // this call's candidate -> slot map and the slots' current counter sets
+    int n_groups = 0;                     // groups of this call's batch (1: the whole batch shares one search)
+    int max_groups = kMaxPairGroups;      // IBA_PAIR_GROUPS: 1 = no clustering of wide batches (round 3's behaviour)
+    int last_mean_pairs_slot = -1;
     int pair_cap = 0, hard_cap = 0, pairs_slices = 1;   // pairs_slices: scan points per thread of iba_pairs_kernel (IBA_PAIRS_SLICES)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
     bool spin_wait = true;                // IBA_SPIN_WAIT=0: blocking waits only
@@ -98,10 +107,9 @@ struct iba_handle {
     double common_max_px = 20.0;          // IBA_COMMON_MAX_PX: nominal spread of the batch's projections beyond which every candidate searches for itself
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
-    CommonRef cref; bool cref_ok = false; // reference candidate and bound of the pair lists this call uses (plan_pairs at staging time)
-    bool pairs_valid = false, pairs_reuse = false;   // the device holds lists built for cref; this call reuses them (no pair search)
+    bool cref_ok = false;                 // this call's batch shares pair searches (plan_pairs at staging time)
     int pair_memo = 1; double pair_infl = 1.25, pair_rho_floor = 1e-4, pair_tau_floor = 1e-3;   // IBA_PAIR_MEMO, IBA_PAIR_INFL
-    int pairs_builds = 0; int pair_memo_max_b = 40; double pair_memo_max_px = 8.0; bool memo_this_call = false;   // IBA_PAIR_MEMO_MAX_B
+    int pairs_builds = 0; int pair_memo_max_b = 40; double pair_memo_max_px = 8.0;   // IBA_PAIR_MEMO_MAX_B
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
     int last_nn_nrec = 0, last_nn_B = 0;   // shape of the search kernel's records of the last evaluation (iba_debug_nn_left_to_tree)
     bool he_staged = false;               // the hand-eye terms of the staged candidates were computed by the staging launch
@@ -281,81 +289,103 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     return L.total <= kLdsBytes;
 }
 
-// The reference candidate of a batch and the spread of the batch around it (see iba_pairs_kernel): reference = the candidate
-// nearest the batch mean, rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i, both inflated for their own
-// rounding. Returns false when the batch is too wide for common pairs to pay (nominal projection spread above max_px at a
-// point 12 m out, 10 m deep), in which case every candidate searches for itself (iba_assoc_kernel).
-// rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i of a batch around a reference (R_0, t_0), inflated for their own
-// rounding; rel (optional): the candidates' own (M_b, a_b) as floats. false: a NaN / absurd candidate, no bound.
-static bool batch_spread(const Cand* hc, int B, const double* R0, const double* t0, double* rho, double* tau, float (*rel)[12]) {
-    for (int i = 0; i < 9; ++i) rho[i] = 0;
-    for (int i = 0; i < 3; ++i) tau[i] = 0;
-    for (int b = 0; b < B; ++b) {
-        double A[9];
-        for (int r = 0; r < 3; ++r)
-            for (int q = 0; q < 3; ++q) A[r * 3 + q] = (hc[b].R[r * 3] * R0[q * 3] + hc[b].R[r * 3 + 1] * R0[q * 3 + 1]) + hc[b].R[r * 3 + 2] * R0[q * 3 + 2];   // R_b R_0^T
-        for (int r = 0; r < 3; ++r) {
-            const double a = hc[b].t[r] - ((A[r * 3] * t0[0] + A[r * 3 + 1] * t0[1]) + A[r * 3 + 2] * t0[2]);
-            if (!(std::fabs(a) <= 1e30)) return false;
-            tau[r] = std::max(tau[r], std::fabs(a));
-            if (rel) rel[b][9 + r] = (float)a;
-            for (int q = 0; q < 3; ++q) { const double m = A[r * 3 + q] - (r == q ? 1.0 : 0.0), e = std::fabs(m); if (!(e <= 4.0)) return false; rho[r * 3 + q] = std::max(rho[r * 3 + q], e); if (rel) rel[b][r * 3 + q] = (float)m; }
-        }
-    }
-    for (int i = 0; i < 9; ++i) rho[i] = rho[i] * (1.0 + 1e-9) + 1e-15;
-    for (int i = 0; i < 3; ++i) tau[i] = tau[i] * (1.0 + 1e-9) + 1e-15;
-    return true;
-}
-
-// The pair lists of a batch (see iba_pairs_kernel) and their REUSE: a list built around a reference candidate with the entrywise
-// bound (rho, tau) holds every (scan point, keypoint) pair that any candidate within that bound of the reference can match — not
-// only the batch it was built for. With IBA_PAIR_MEMO (default) the bound of a new list is the batch's own times pair_infl plus
-// a floor, the candidates' own per-block bound is left out (it is specific to the batch), and the next calls whose batches stay
-// inside the built bound skip the pair search altogether: an optimiser's late polls and line searches hover around one point.
-// Sets h->cref (reference + bound of the lists that this call will use), h->pairs_reuse. false: no shared search for this batch
-// (a NaN candidate; a batch wider than common_max_px of nominal projection spread, at a point 12 m out, 10 m deep).
-bool plan_pairs(iba_handle* h, const Cand* hc, int B) {
-    h->pairs_reuse = false;
-    CommonRef& cr = h->cref;
-    // (a big batch keeps its own, tight lists: the pair search is a fixed ~40 us per call, longer lists cost every candidate)
-    const bool memo = h->pair_memo && B <= h->pair_memo_max_b;
-    h->memo_this_call = memo;
-    if (memo && h->pairs_valid) {
+// The pair lists of a batch (see iba_pairs_kernel), their REUSE and the GROUPS of a wide batch. A list built around a reference
+// candidate with the entrywise bound (rho, tau) holds every (scan point, keypoint) pair that any candidate within that bound of the
+// reference can match — not only the candidates it was built for. The handle has kMaxPairGroups list slots. Planning a call:
+//   1. the whole batch against the valid slots: inside the bound of one -> no pair search at all (an optimiser's late polls and
+//      line searches hover around one point);
+//   2. the whole batch as one group when its nominal projection spread (at a point 12 m out, 10 m deep) is at most common_max_px;
+//   3. otherwise greedy clustering (farthest-point seeds, nearest seed wins) into up to max_groups groups, accepted when EVERY
+//      group is that tight: a MADS batch is two polls, around the feasible and the infeasible incumbent, each tight, far apart;
+//      each group is matched against the valid slots like a batch of its own, or gets new lists in the least recently used slot;
+//   4. otherwise (a batch wide everywhere) every candidate searches for itself (iba_assoc_kernel): returns false.
+// With IBA_PAIR_MEMO (default) the bound of a small (<= pair_memo_max_b), tight (<= pair_memo_max_px) group's new lists is its own
+// times pair_infl plus a floor and the candidates' own per-block bound is left out (it is specific to the batch): such a slot
+// stays valid for later calls. Sets h->pplan / h->n_build (the pair search of this call), h->amap, h->n_groups.
+// is every member of the group inside the bound of a valid slot? (-1: no)
+static int covering_slot(const iba_handle* h, const Cand* hc, const GroupPick& g) {
+    Cand tmp[IBA_MAX_BATCH];
+    for (int j = 0; j < g.n; ++j) { std::memcpy(tmp[j].R, hc[g.idx[j]].R, sizeof(tmp[j].R)); std::memcpy(tmp[j].t, hc[g.idx[j]].t, sizeof(tmp[j].t)); }
+    for (int sl = 0; sl < kMaxPairGroups; ++sl) {
+        const iba_handle::PairSlot& ps = h->pslot[sl];
+        if (!ps.valid) continue;
         double rho[9], tau[3];
-        if (batch_spread(hc, B, cr.R, cr.t, rho, tau, nullptr)) {
-            bool fits = true;
-            for (int i = 0; i < 9; ++i) fits = fits && rho[i] <= cr.rho[i];
-            for (int i = 0; i < 3; ++i) fits = fits && tau[i] <= cr.tau[i];
-            if (fits) { h->pairs_reuse = true; return true; }
+        if (!batch_spread(tmp, g.n, ps.ref.R, ps.ref.t, rho, tau, nullptr)) continue;
+        bool fits = true;
+        for (int i = 0; i < 9; ++i) fits = fits && rho[i] <= ps.ref.rho[i];
+        for (int i = 0; i < 3; ++i) fits = fits && tau[i] <= ps.ref.tau[i];
+        if (fits) return sl;
+    }
+    return -1;
+}
+inline bool plan_pairs(iba_handle* h, const Cand* hc, int B) {
+    h->n_build = 0; h->n_groups = 0;
+    const size_t set_words = (size_t)std::max(h->n_frames, 1) * kCountStride;
+    auto cnt_off = [&](int sl, unsigned e) { return (uint32_t)(((size_t)sl * 2 + (e & 1u)) * set_words); };
+    static thread_local GroupPick gp[kMaxPairGroups];
+    int ng = 1;
+    gp[0].n = B; for (int b = 0; b < B; ++b) gp[0].idx[b] = b;
+    const bool memo_whole = h->pair_memo && B <= h->pair_memo_max_b;
+    int whole_slot = -1;
+    if (memo_whole && (whole_slot = covering_slot(h, hc, gp[0])) >= 0) {
+        // (1) the lists of an earlier call cover this batch
+        h->pslot[whole_slot].last_use = ++h->pair_clock;
+        for (int b = 0; b < B; ++b) h->amap.slot[b] = (uint8_t)whole_slot;
+        for (int sl = 0; sl < kMaxPairGroups; ++sl) h->amap.cnt_off[sl] = cnt_off(sl, h->pslot[sl].epoch - 1u);
+        h->n_groups = 1; h->last_mean_pairs_slot = whole_slot;
+        return true;
+    }
+    if (!pick_group(h->max_fx, hc, gp[0])) return false;
+    const double max_px = h->common_mode >= 2 ? INFINITY : h->common_max_px;
+    if (gp[0].px > max_px) {
+        // (3) cluster (iba_pair_plan.hpp)
+        ng = cluster_batch(h->max_fx, hc, B, max_px, h->max_groups, gp);
+        if (ng == 0) return false;   // (4) wide everywhere
+    }
+    // (2) / (3): every group reuses a covering slot or gets new lists in the least recently used slot this call does not use
+    bool taken[kMaxPairGroups] = {false, false, false, false};
+    int slot_of[kMaxPairGroups];
+    for (int g = 0; g < ng; ++g) {
+        slot_of[g] = -1;
+        if (ng > 1 && h->pair_memo && gp[g].n <= h->pair_memo_max_b) { const int sl = covering_slot(h, hc, gp[g]); if (sl >= 0 && !taken[sl]) slot_of[g] = sl; }   // (a single group was tried above)
+        if (slot_of[g] >= 0) taken[slot_of[g]] = true;
+    }
+    int rel_at = 0;
+    for (int g = 0; g < ng; ++g) {
+        int sl = slot_of[g];
+        if (sl < 0) {
+            unsigned long long oldest = ~0ull;
+            for (int c = 0; c < kMaxPairGroups; ++c) {
+                if (taken[c]) continue;
+                const unsigned long long age = h->pslot[c].valid ? h->pslot[c].last_use : 0ull;
+                if (age < oldest) { oldest = age; sl = c; }
+            }
+            taken[sl] = true; slot_of[g] = sl;
+            iba_handle::PairSlot& ps = h->pslot[sl];
+            // a reusable (inflated, entrywise-bounded) list only for a small tight group: a list grows with the square of its window,
+            // and at 16 px of nominal spread the inflated one overflows its capacity where the group's own fits (tools/wide_probe.py)
+            const bool memo = h->pair_memo && gp[g].n <= h->pair_memo_max_b && gp[g].px <= h->pair_memo_max_px;
+            if (memo) {
+                for (int i = 0; i < 9; ++i) gp[g].gr.rho[i] = gp[g].gr.rho[i] * h->pair_infl + h->pair_rho_floor;
+                for (int i = 0; i < 3; ++i) gp[g].gr.tau[i] = gp[g].gr.tau[i] * h->pair_infl + h->pair_tau_floor;
+            }
+            const int k = h->n_build++;
+            PairsPlan& pl = h->pplan;
+            pl.g[k] = gp[g].gr; pl.slot[k] = (uint8_t)sl;
+            pl.cnt_off[k] = cnt_off(sl, ps.epoch); pl.next_off[k] = cnt_off(sl, ps.epoch + 1u);
+            ++ps.epoch;
+            // (lists that later calls may reuse are bounded entrywise only: the candidates' own per-block bound is this batch's)
+            const bool own = h->pair_bound && gp[g].n > 1 && !memo;
+            pl.first[k] = (uint8_t)rel_at; pl.count[k] = (uint8_t)(own ? gp[g].n : 0);
+            if (own) { std::memcpy(pl.rel[rel_at], gp[g].rel, sizeof(float) * 12 * (size_t)gp[g].n); rel_at += gp[g].n; }
+            ps.ref = gp[g].gr; ps.valid = memo;
         }
+        h->pslot[sl].last_use = ++h->pair_clock;
+        for (int j = 0; j < gp[g].n; ++j) h->amap.slot[gp[g].idx[j]] = (uint8_t)sl;
     }
-    h->pairs_valid = false;   // cr is rewritten: the lists on the device no longer belong to it
-    double mean[12] = {0};
-    for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].R[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].t[i]; }
-    for (double& m : mean) m /= (double)B;
-    int ref = 0; double best = INFINITY;
-    for (int b = 0; b < B; ++b) {
-        double d = 0;
-        for (int i = 0; i < 9; ++i) d = std::max(d, 12.0 * std::fabs(hc[b].R[i] - mean[i]));
-        for (int i = 0; i < 3; ++i) d = std::max(d, std::fabs(hc[b].t[i] - mean[9 + i]));
-        if (d < best) { best = d; ref = b; }
-    }
-    if (!(best < INFINITY)) return false;   // a NaN candidate: no bound
-    std::memcpy(cr.R, hc[ref].R, sizeof(cr.R)); std::memcpy(cr.t, hc[ref].t, sizeof(cr.t));
-    if (!batch_spread(hc, B, cr.R, cr.t, cr.rho, cr.tau, cr.rel)) return false;
-    auto nominal_px = [&]() {
-        double rho_row = 0, tau_max = 0;
-        for (int r = 0; r < 3; ++r) { rho_row = std::max(rho_row, cr.rho[r * 3] + cr.rho[r * 3 + 1] + cr.rho[r * 3 + 2]); tau_max = std::max(tau_max, cr.tau[r]); }
-        return h->max_fx * (rho_row * 12.0 + tau_max) * 1.8 / 10.0;
-    };
-    // a reusable (inflated, entrywise-bounded) list only for a tight batch: a list grows with the square of its window, and at
-    // 16 px of nominal spread the inflated one overflows its capacity where the batch's own fits (tools/wide_probe.py)
-    if (memo && nominal_px() <= h->pair_memo_max_px) {
-        for (int i = 0; i < 9; ++i) cr.rho[i] = cr.rho[i] * h->pair_infl + h->pair_rho_floor;
-        for (int i = 0; i < 3; ++i) cr.tau[i] = cr.tau[i] * h->pair_infl + h->pair_tau_floor;
-    } else h->memo_this_call = false;
-    if (h->common_mode >= 2) return true;
-    return nominal_px() <= h->common_max_px;
+    for (int sl = 0; sl < kMaxPairGroups; ++sl) h->amap.cnt_off[sl] = cnt_off(sl, h->pslot[sl].epoch - 1u);
+    h->n_groups = ng; h->last_mean_pairs_slot = slot_of[0];
+    return true;
 }
 
 iba_status ensure_scratch(iba_handle* h);
@@ -421,8 +451,13 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     h->jets_x = nullptr; h->jets_src = nullptr; h->jets_flag = nullptr;
     if (!pre && jets == 2 && B <= 4) jets = 1;   // a few candidates: their derivatives cost the host less (0.6 us each) than the second fetch of the block
     if (pre) {   // the group's block: complete, or (pre_flag) with the derivative half still being computed by the calling thread
-        std::memcpy(hc, pre, sizeof(Cand) * (size_t)B);
-        if (pre_flag && jets == 2) { h->jets_src = pre; h->jets_flag = pre_flag; h->jets_B = B; h->jets_slot = slot; }
+        if (pre_flag && jets == 2) {
+            // the calling thread is writing the derivative half of `pre` right now: only the value half is read here (the other is
+            // copied by finish_jets once *pre_flag is set). The stale derivative words of the ring slot that the staging fetch carries
+            // along are overwritten on the device by finish_jets' own fetch, stream-ordered before the factor kernel.
+            for (int b = 0; b < B; ++b) std::memcpy((void*)&hc[b], (const void*)&pre[b], offsetof(Cand, dR));
+            h->jets_src = pre; h->jets_flag = pre_flag; h->jets_B = B; h->jets_slot = slot;
+        } else std::memcpy(hc, pre, sizeof(Cand) * (size_t)B);
         jets = 1;
     }
     else if (jets == 1) for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
@@ -599,25 +634,19 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     // 2d-3d association: a batch of nearby candidates shares ONE search for the (scan point, keypoint) pairs per keyframe
     // (iba_pairs_kernel) and every candidate runs the exact test on that list (iba_assoc2_kernel); a lone candidate, a small or a
     // wide batch searches per candidate (iba_assoc_kernel). Same results either way, bit for bit.
-    const CommonRef& cref = h->cref;
     const bool common = !frozen && h->last_hc && h->cref_ok;
-    h->last_path = common ? 1 : 0;
+    h->last_path = common ? (h->n_groups > 1 ? 2 : 1) : 0;
     // the pair search reads nothing the staging launch produces: it goes first, the staging launch runs beside it on the side stream
-    uint32_t* cnt_now = nullptr;
     { iba_status ms = mark_entry(h, st); if (ms != IBA_OK) return ms; }
-    if (common && h->pairs_reuse) cnt_now = h->d_pcounts.p + (size_t)((h->pairs_epoch - 1) & 1) * (size_t)nf * kCountStride;   // the lists of an earlier call cover this batch
-    else if (common) {
-        cnt_now = h->d_pcounts.p + (size_t)(h->pairs_epoch & 1) * (size_t)nf * kCountStride;
-        uint32_t* cnt_next = h->d_pcounts.p + (size_t)((h->pairs_epoch + 1) & 1) * (size_t)nf * kCountStride;
-        ++h->pairs_epoch;
+    if (common && h->n_build > 0) {   // (n_build == 0: the lists of earlier calls cover every group of this batch)
         // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
         const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
         const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
-        // (lists that later batches may reuse are bounded entrywise only: the candidates' own per-block bound is this batch's)
-        hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf), dim3(kPairsThreads), lds, st, PairsArgs{dp, cref}, h->params.max_pixel_dist, kuv_off,
-                           (h->pair_bound && B > 1 && !h->memo_this_call) ? B : 0, h->d_pairs.p, h->d_hard.p, cnt_now, cnt_next, h->pair_cap, h->hard_cap);
+        const PairsProblem pp{dp.frames, dp.pts4, dp.chunk_box, dp.kp_uv, dp.coarse_start};
+        hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf, h->n_build), dim3(kPairsThreads), lds, st, PairsArgs{pp, h->pplan}, h->params.max_pixel_dist, kuv_off,
+                           nf, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
         HIP_TRY(h, hipGetLastError());
-        h->pairs_valid = h->memo_this_call; ++h->pairs_builds;
+        h->pairs_builds += h->n_build;
     }
     { iba_status ls = launch_head(h); if (ls != IBA_OK) return ls; }
     // Anchored neighbour lists (iba_anchor_kernel): the scan points nearest to every MapPoint's query under an ANCHOR extrinsic,
@@ -665,11 +694,11 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     if (common) {
         { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }   // the candidates and the hand-eye terms: first read here
         if (assoc2_flreg(h))
-            hipLaunchKernelGGL(iba_assoc2_kernel<true>, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                               h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
+            hipLaunchKernelGGL(iba_assoc2_kernel<true>, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                               h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
         else
-            hipLaunchKernelGGL(iba_assoc2_kernel<false>, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, KArgs{dp, h->dprm, h->alay2}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                               h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, cnt_now, h->pair_cap, h->hard_cap);
+            hipLaunchKernelGGL(iba_assoc2_kernel<false>, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                               h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
     } else {
     { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }
     hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
@@ -734,20 +763,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
 
 extern "C" {
 
-iba_status iba_default_params(iba_params* p) {
-    if (!p) return IBA_ERR_INVALID_ARG;
-    std::memset(p, 0, sizeof(*p));
-    p->max_pixel_dist = 1.5; p->num_min_corr_cost = 30; p->corr_3d_2d_threshold = 40.; p->corr_3d_3d_threshold = 5.;
-    p->norm_max_pts = 30; p->norm_min_pts = 5; p->norm_radius = 0.6; p->norm_reg_threshold = 0.04; p->min_diff_dist = 0.01;
-    p->err_weight[0] = 1.0; p->err_weight[1] = 1.0; p->use_plane = 1;
-    p->num_min_corr = 30; p->max_3d_dist = 1.0; p->neigh_radius = 0.6; p->neigh_max_pts = 30; p->neigh_min_pts = 5;
-    p->local_min_diff_dist = 0.2; p->local_norm_reg_threshold = 0.001; p->robust_kernel_delta = 2.98; p->robust_kernel_3ddelta = 1.0;
-    p->plane_cache = 1;
-    return IBA_OK;
-}
-
 const char* iba_last_error(const iba_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
-int32_t iba_partial_stride(void) { return kPartialStride; }
 int64_t iba_num_points(const iba_handle* h) { return h ? h->n_points : 0; }
 int64_t iba_num_keypoints(const iba_handle* h) { return h ? h->n_keypoints : 0; }
 
@@ -973,6 +989,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IBA_PAIR_GROUPS")) h->max_groups = std::max(1, std::min(kMaxPairGroups, std::atoi(e)));
     if (!layout_assoc(h, h->alay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
     if (!layout_assoc2(h, h->alay2) || 8u * (uint32_t)kPairStage + 160u + 2u * std::max(h->maxCoarse, 1u) + 8u * std::max(h->maxK, 1u) > kLdsBytes) h->common_mode = 0;
     if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
@@ -1005,10 +1022,11 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
         h->pair_cap = (int)std::min<uint32_t>(65536u, std::max<uint32_t>(std::max<uint32_t>(2048u, 4u * h->maxK), h->maxP / 4u));
         h->hard_cap = 1024;
         if (const char* e = std::getenv("IBA_DEBUG_PAIR_CAP")) { h->pair_cap = std::max(1, std::atoi(e)); h->hard_cap = std::max(1, std::atoi(e) / 8); }   // tests: force the overflow path
-        if ((er = h->d_pairs.alloc((size_t)std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
-        if ((er = h->d_hard.alloc((size_t)std::max(nf, 1) * h->hard_cap)) != hipSuccess) return bail("alloc hard list", er);
-        if ((er = h->d_pcounts.alloc(2 * (size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("alloc pair counts", er);   // two sets, used in turn
-        if ((er = hipMemset(h->d_pcounts.p, 0, sizeof(uint32_t) * 2 * (size_t)std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("clear pair counts", er);
+        // kMaxPairGroups list slots (one group of candidates each); two counter sets per slot, used in turn (the pair search clears the set of the slot's NEXT build)
+        if ((er = h->d_pairs.alloc((size_t)kMaxPairGroups * std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
+        if ((er = h->d_hard.alloc((size_t)kMaxPairGroups * std::max(nf, 1) * h->hard_cap)) != hipSuccess) return bail("alloc hard list", er);
+        if ((er = h->d_pcounts.alloc(2 * (size_t)kMaxPairGroups * std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("alloc pair counts", er);
+        if ((er = hipMemset(h->d_pcounts.p, 0, sizeof(uint32_t) * 2 * (size_t)kMaxPairGroups * std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("clear pair counts", er);
     }
     if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
     if ((er = h->d_he.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1))) != hipSuccess) return bail("alloc he", er);
@@ -1076,7 +1094,7 @@ iba_status iba_set_params(iba_handle* h, const iba_params* p) {
     }
     h->params = *p; to_dev_params(*p, h->dprm); h->frozen_valid = false;
     h->anchor_valid = false;   // the lists carry the planes' verdicts under the old parameters
-    h->pairs_valid = false;    // the pair lists were cut for the old max_pixel_dist
+    for (auto& ps : h->pslot) ps.valid = false;    // the pair lists were cut for the old max_pixel_dist
     return compute_plane_cache(h);
 }
 
@@ -1102,24 +1120,6 @@ iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_ke
     if (assoc_kernel_ms) *assoc_kernel_ms = h->last_assoc_ms;
     if (nn_kernel_ms) *nn_kernel_ms = h->last_nn_ms;
     if (rest_ms) *rest_ms = tot - fk;
-    return IBA_OK;
-}
-
-iba_status iba_finalize_cost(const iba_params* p, const double* part, int32_t B, iba_cost_out* out) {
-    if (!p || !part || !out || B < 1) return IBA_ERR_INVALID_ARG;
-    for (int b = 0; b < B; ++b) {
-        const double* q = part + (size_t)b * kPartialStride; iba_cost_out& o = out[b];
-        o.valid_cnt_3d_2d = (int32_t)q[P_VALID_3D2D]; o.cnt_3d_2d = (int32_t)q[P_CNT_3D2D];
-        o.cnt_3d_3d = (int32_t)q[P_CNT_3D3D]; o.valid_cnt_3d_3d = (int32_t)q[P_VALID_3D3D];
-        o.valid_pl_3d_3d = (int32_t)q[P_VALID_PL]; o.valid_pt_3d_3d = (int32_t)q[P_VALID_PT];
-        o.frames_used = (int32_t)q[P_FRAMES]; o.n_corr = (int32_t)q[P_NCORR];
-        // iba_global.cpp:330-338
-        if (o.valid_cnt_3d_2d == 0 && p->err_weight[0] > 1e-10) o.f1 = std::numeric_limits<double>::max();
-        else o.f1 = q[P_SUM_3D2D] / (double)o.valid_cnt_3d_2d;
-        if (o.valid_cnt_3d_3d == 0 && p->err_weight[1] > 1e-10) o.f2 = std::numeric_limits<double>::max();
-        else o.f2 = (p->err_weight[1] <= 1e-10 ? 0.0 : q[P_SUM_3D3D]) / (double)o.valid_cnt_3d_3d;
-        o.C = q[P_HE_SUM] / q[P_HE_CNT];
-    }
     return IBA_OK;
 }
 
@@ -1224,10 +1224,10 @@ double iba_debug_nn_left_to_tree(iba_handle* h) {
 }
 // mean length of the keyframes' common pair lists of the last evaluation that shared the pair search (-1: none has)
 double iba_debug_mean_pairs(iba_handle* h) {
-    if (!h || !h->d_pcounts.p || h->pairs_epoch == 0 || h->n_frames == 0) return -1.0;
+    if (!h || !h->d_pcounts.p || h->last_mean_pairs_slot < 0 || h->n_frames == 0) return -1.0;
     std::vector<uint32_t> v((size_t)h->n_frames * kCountStride);
     if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1.0;
-    if (hipMemcpy(v.data(), h->d_pcounts.p + (size_t)((h->pairs_epoch - 1) & 1) * (size_t)h->n_frames * kCountStride, v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    if (hipMemcpy(v.data(), h->d_pcounts.p + h->amap.cnt_off[h->last_mean_pairs_slot], v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
     double t = 0; for (int f = 0; f < h->n_frames; ++f) t += v[(size_t)f * kCountStride];
     return t / h->n_frames;
 }
@@ -1253,22 +1253,6 @@ iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n
     if (er == hipSuccess) er = hipMemcpy(out_d2, dd.p, sizeof(double) * n, hipMemcpyDeviceToHost);
     dq.release(); dd.release(); di.release();
     if (er != hipSuccess) return fail(h, IBA_ERR_HIP, hipGetErrorString(er));
-    return IBA_OK;
-}
-
-// ---- Jacobian path ----
-iba_status iba_finalize_normal(const iba_params* p, const double* part, int32_t B, iba_normal_out* out) {
-    if (!p || !part || !out || B < 1) return IBA_ERR_INVALID_ARG;
-    for (int b = 0; b < B; ++b) {
-        const double* q = part + (size_t)b * kPartialStride; iba_normal_out& o = out[b];
-        int at = 0;
-        for (int i = 0; i < 7; ++i)
-            for (int j = i; j < 7; ++j) { o.H[i * 7 + j] = q[P_H0 + at]; o.H[j * 7 + i] = q[P_H0 + at]; ++at; }
-        for (int i = 0; i < 7; ++i) o.b[i] = q[P_B0 + i];
-        o.cost = q[P_COST]; o.chi2 = q[P_CHI2];
-        o.n_factor_3d2d = (int32_t)q[P_NF_3D2D]; o.n_factor_p2pl = (int32_t)q[P_NF_P2PL]; o.n_factor_p2pt = (int32_t)q[P_NF_P2PT];
-        o.n_residuals = (int32_t)q[P_NRES]; o.frames_used = (int32_t)q[P_FRAMES_N]; o.n_corr = (int32_t)q[P_NCORR_N];
-    }
     return IBA_OK;
 }
 
@@ -1367,47 +1351,11 @@ iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_norma
     });
 }
 
-// ---- one 8-row residual block standing for the whole frozen problem (Ceres / g2o adaptors) ----
-// [J | r] = upper Cholesky factor of M = [[H, b], [b^T, 2 cost]]: J^T J = H, J^T r = b, |r|^2 = 2 cost. M is positive
-// semi-definite: it is a sum over residual blocks of w [J_k | r_k]^T [J_k | r_k] plus (rho_k - w_k s_k) >= 0 on the last
-// diagonal entry (Huber: rho(s) - rho'(s) s = a (sqrt(s) - a) > 0 beyond the kink). A pivot that is not positive relative to
-// its column (rank-deficient H: no factor constrains that direction) leaves a zero row.
-iba_status iba_whiten_normal(const iba_normal_out* n, double r[8], double J[56]) {
-    if (!n || !r || !J) return IBA_ERR_INVALID_ARG;
-    double M[64];
-    for (int i = 0; i < 7; ++i) { for (int j = 0; j < 7; ++j) M[i * 8 + j] = n->H[i * 7 + j]; M[i * 8 + 7] = n->b[i]; M[7 * 8 + i] = n->b[i]; }
-    M[63] = 2.0 * n->cost;
-    double R[64]; std::memset(R, 0, sizeof(R));   // upper triangular, R^T R = M
-    for (int i = 0; i < 8; ++i) {
-        double d = M[i * 8 + i];
-        for (int k = 0; k < i; ++k) d -= R[k * 8 + i] * R[k * 8 + i];
-        if (!(d > 1e-14 * std::fabs(M[i * 8 + i])) || !(d > 0)) continue;   // zero row
-        const double rii = std::sqrt(d);
-        R[i * 8 + i] = rii;
-        for (int j = i + 1; j < 8; ++j) {
-            double v = M[i * 8 + j];
-            for (int k = 0; k < i; ++k) v -= R[k * 8 + i] * R[k * 8 + j];
-            R[i * 8 + j] = v / rii;
-        }
-    }
-    for (int i = 0; i < 8; ++i) { for (int j = 0; j < 7; ++j) J[i * 7 + j] = R[i * 8 + j]; r[i] = R[i * 8 + 7]; }
-    return IBA_OK;
-}
-
 iba_status iba_eval_whitened(iba_handle* h, const double* x, double r[8], double J[56]) {
     if (!h || !x || !r || !J) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     iba_normal_out n;
     iba_status s = iba_eval_factors(h, x, 1, &n); if (s != IBA_OK) return s;
     return iba_whiten_normal(&n, r, J);
-}
-
-iba_status iba_default_lm_options(iba_lm_options* o) {
-    if (!o) return IBA_ERR_INVALID_ARG;
-    const LmOptions d;
-    o->max_outer_iterations = d.max_outer_iterations; o->max_inner_iterations = d.max_inner_iterations; o->min_diff = d.min_diff;
-    o->function_tolerance = d.function_tolerance; o->gradient_tolerance = d.gradient_tolerance; o->parameter_tolerance = d.parameter_tolerance;
-    o->initial_trust_region_radius = d.initial_trust_region_radius;
-    return IBA_OK;
 }
 
 iba_status iba_calibrate_lm(iba_handle* h, const double* x0, const iba_lm_options* opt, iba_lm_result* res) {
@@ -1435,38 +1383,8 @@ iba_status iba_calibrate_lm(iba_handle* h, const double* x0, const iba_lm_option
     return IBA_OK;
 }
 
-// ---- global stage caller (csrc/iba_mads.hpp) ----
-iba_status iba_default_mads_options(const double* x0, iba_mads_options* o) {
-    if (!x0 || !o) return IBA_ERR_INVALID_ARG;
-    static const double lb[7] = {-0.1, -0.1, -0.1, -0.3, -0.3, -0.3, -1.0}, ub[7] = {0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0};   // iba_calib_global.yml:39-40
-    o->max_bb_eval = 5000;
-    for (int i = 0; i < 7; ++i) { o->lb[i] = x0[i] + lb[i]; o->ub[i] = x0[i] + ub[i]; o->init_frame[i] = 0.5; }
-    o->min_mesh = 1e-6; o->he_threshold = 0.094; o->valid_rate = 0.95; o->seed = 0; o->bases_per_poll = 2; o->speculative = 1; o->vns_max_idle = 6;
-    return IBA_OK;
-}
-static void to_mads(const iba_mads_options* opt, MadsOptions& o) {
-    o.max_bb_eval = opt->max_bb_eval; o.min_mesh = opt->min_mesh; o.seed = opt->seed;
-    o.bases_per_poll = std::max(1, std::min(4, opt->bases_per_poll)); o.speculative = opt->speculative != 0; o.max_batch = IBA_MAX_BATCH; o.vns_max_idle = std::max(0, opt->vns_max_idle);
-    for (int i = 0; i < 7; ++i) { o.lb[i] = opt->lb[i]; o.ub[i] = opt->ub[i]; o.init_frame[i] = opt->init_frame[i]; }
-}
-static void from_mads(const MadsResult& r, iba_mads_result* res) {
-    std::memcpy(res->x, r.best.x, sizeof(res->x));
-    res->f = r.best.f; res->c1 = r.best.c[0]; res->c2 = r.best.c[1]; res->c3 = r.best.c[2];
-    res->feasible = r.feasible; res->evaluations = r.evaluations; res->iterations = r.iterations; res->batches = r.batches;
-    res->cache_hits = r.cache_hits; res->restarts = r.restarts; res->stop_reason = r.stop_reason;
-}
-static bool mads_options_ok(const iba_mads_options* opt) {
-    if (!opt || opt->max_bb_eval < 1 || !(opt->min_mesh > 0)) return false;
-    for (int i = 0; i < 7; ++i) if (!(opt->lb[i] <= opt->ub[i]) || !(opt->init_frame[i] > 0)) return false;
-    return true;
-}
-// copies the recorded evaluations (8 doubles each: x, f) into the caller's buffer; *n = how many there were
-static void hand_over_trace(const std::vector<double>& tr, double* trace, int32_t cap, int32_t* n) {
-    const int32_t have = (int32_t)(tr.size() / 8);
-    if (n) *n = have;
-    if (trace && cap > 0) std::memcpy(trace, tr.data(), sizeof(double) * 8 * (size_t)std::min(have, cap));
-}
-iba_status iba_calibrate_mads_trace(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace) {
+iba_status iba_calibrate_mads_record(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace,
+                                     int32_t* batch_sizes, int32_t cap_batches, int32_t* n_batches) {
     if (!h || !x0 || !res) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     iba_mads_options dflt;
     if (!opt) { iba_default_mads_options(x0, &dflt); opt = &dflt; }
@@ -1474,6 +1392,8 @@ iba_status iba_calibrate_mads_trace(iba_handle* h, const double* x0, const iba_m
     MadsOptions o; to_mads(opt, o);
     std::vector<double> tr;
     if (trace || n_trace) o.trace = &tr;
+    std::vector<int> bs;
+    if (batch_sizes || n_batches) o.batch_sizes = &bs;
     iba_status st = IBA_OK;
     MadsResult r;
     const bool ok = mads_minimize(x0, o, [&](const double* X, int B, MadsPoint* out) {
@@ -1486,45 +1406,16 @@ iba_status iba_calibrate_mads_trace(iba_handle* h, const double* x0, const iba_m
     if (!ok) return st == IBA_OK ? IBA_ERR_STATE : st;
     from_mads(r, res);
     hand_over_trace(tr, trace, cap, n_trace);
+    if (n_batches) *n_batches = (int32_t)bs.size();
+    if (batch_sizes && cap_batches > 0) std::memcpy(batch_sizes, bs.data(), sizeof(int32_t) * (size_t)std::min<int32_t>((int32_t)bs.size(), cap_batches));
     return IBA_OK;
+}
+iba_status iba_calibrate_mads_trace(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace) {
+    return iba_calibrate_mads_record(h, x0, opt, res, trace, cap, n_trace, nullptr, 0, nullptr);
 }
 iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res) {
     return iba_calibrate_mads_trace(h, x0, opt, res, nullptr, 0, nullptr);
 }
-iba_status iba_mads_selftest_trace(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace) {
-    if (!x0 || !res || !mads_options_ok(opt) || problem < 0 || problem > 3) return IBA_ERR_INVALID_ARG;
-    MadsOptions o; to_mads(opt, o);
-    std::vector<double> tr;
-    if (trace || n_trace) o.trace = &tr;
-    static const double a[7] = {0.3, -0.2, 0.1, 0.25, -0.15, 0.05, 9.5};
-    MadsResult r;
-    mads_minimize(x0, o, [&](const double* X, int B, MadsPoint* out) {
-        for (int b = 0; b < B; ++b) {
-            const double* x = X + 7 * b;
-            double f = 0, c0 = -1, c1 = -1, c2 = -1;
-            if (problem == 0) { for (int i = 0; i < 7; ++i) f += (1.0 + i) * (x[i] - a[i]) * (x[i] - a[i]); }
-            else if (problem == 1) { f = (x[0] - 1.0) * (x[0] - 1.0); for (int i = 1; i < 7; ++i) f += (x[i] - a[i]) * (x[i] - a[i]); c0 = x[0] - 0.5; }
-            else if (problem == 3) {   // many narrow local basins (period 0.08) under a shallow bowl: the global one is at a
-                const double two_pi = 6.283185307179586;
-                for (int i = 0; i < 7; ++i) { const double d = x[i] - a[i] - 0.0123 * (i + 1); f += 2.0 * d * d + 0.3 * (1.0 - std::cos(two_pi * d / 0.08)); }
-            }
-            else {
-                double m = 0, s1 = 0;
-                for (int i = 0; i < 7; ++i) { const double d = std::fabs(x[i] - a[i]); m = std::max(m, d); s1 += d; }
-                f = m + 0.1 * s1; c0 = 0.2 - x[1]; c1 = x[3] + x[4] - 0.05;   // optimum on both constraint boundaries
-            }
-            out[b].f = f; out[b].c[0] = c0; out[b].c[1] = c1; out[b].c[2] = c2;
-        }
-        return true;
-    }, r);
-    from_mads(r, res);
-    hand_over_trace(tr, trace, cap, n_trace);
-    return IBA_OK;
-}
-iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res) {
-    return iba_mads_selftest_trace(problem, x0, opt, res, nullptr, 0, nullptr);
-}
-
 iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double* J, int32_t* block_id, int32_t* block_kind, int64_t* n_rows) {
     if (!h || !x || !n_rows) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     if (!h->frozen_valid) return fail(h, IBA_ERR_STATE, "iba_eval_residuals called before iba_build_problem");

@@ -34,6 +34,7 @@
 #include "iba_internal.hpp"
 #include "iba_lm.hpp"
 #include "iba_mads.hpp"
+#include "iba_workers.hpp"
 
 using namespace iba;
 
@@ -47,6 +48,7 @@ struct Rccl {
     ncclResult_t (*GetVersion)(int*) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional: frees a communicator whose collective can no longer complete
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -69,6 +71,7 @@ Rccl& rccl() {
         IBA_SYM(GetVersion, "ncclGetVersion") IBA_SYM(CommInitAll, "ncclCommInitAll") IBA_SYM(CommDestroy, "ncclCommDestroy") IBA_SYM(CommCount, "ncclCommCount")
         IBA_SYM(AllReduce, "ncclAllReduce") IBA_SYM(GetErrorString, "ncclGetErrorString")
 #undef IBA_SYM
+        R.CommAbort = (decltype(R.CommAbort))dlsym(lib, "ncclCommAbort");
         Dl_info info;
         if (dladdr((void*)R.AllReduce, &info) && info.dli_fname) R.path = info.dli_fname;
         (void)R.GetVersion(&R.runtime_version);
@@ -100,17 +103,16 @@ struct iba_group {
     double last_issue_us = 0.0;           // host time of the last chunk: candidate block + hand-over to the workers + wait
     double last_enqueue_us = 0.0;         // of which: until the LAST device's launch chain and collective were enqueued (the host issue time)
     std::vector<double> enq_us;           // per worker
-    // ---- one worker thread per device ----
-    std::vector<std::thread> workers;
-    std::vector<iba_status> wstatus;
-    std::vector<std::string> werr;
-    std::function<iba_status(int)> job;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
-    std::atomic<uint64_t> gen{0};
-    std::atomic<int> pending{0};
-    std::atomic<bool> quit{false};
+    // ---- one worker thread per device (iba_workers.hpp) ----
+    WorkerPool pool;
     std::atomic<int> jets_ready{0};       // the derivative half of `cands` is complete (set by the calling thread while the workers' kernels run)
+    // failure handling: a worker that fails BEFORE the collective is seen by its peers at the barrier between launch chain and
+    // collective (nobody enters the all-reduce); a failure AFTER it (the collective did not enqueue on one rank, the bounded wait
+    // ran out) raises the pool's abort flag: every worker abandons its wait, aborts its communicator and the group is `broken`
+    // (every later call fails at once with IBA_ERR_STATE; destroy does not wait for the streams).
+    std::atomic<bool> broken{false};
+    double wait_timeout_ms = 20000.0;     // IBA_GROUP_TIMEOUT_MS: bound of a worker's wait for its stream (a collective that never completes)
+    int debug_fail_rank = -1, debug_fail_phase = 1; bool debug_fail_armed = false;   // IBA_DEBUG_FAIL_RANK / _PHASE: one injected failure (tests)
 };
 
 namespace {
@@ -118,71 +120,35 @@ thread_local std::string g_group_create_error;
 
 iba_status gfail(iba_group* g, iba_status s, const std::string& m) { if (g) g->err = m; else g_group_create_error = m; return s; }
 
-inline void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#else
-    std::this_thread::yield();
-#endif
-}
-constexpr auto kSpinFor = std::chrono::microseconds(200);
-
-void worker_main(iba_group* g, int i) {
-    (void)hipSetDevice(g->dev[i]);   // once: every HIP call of this thread targets its device
-    uint64_t seen = 0;
-    for (;;) {
-        auto t0 = std::chrono::steady_clock::now();
-        int polls = 0;
-        while (g->gen.load(std::memory_order_acquire) == seen && !g->quit.load(std::memory_order_acquire)) {
-            cpu_relax();
-            if ((++polls & 63) == 0 && std::chrono::steady_clock::now() - t0 > kSpinFor) {
-                std::unique_lock<std::mutex> lk(g->mu);
-                g->cv_job.wait(lk, [&]() { return g->gen.load(std::memory_order_acquire) != seen || g->quit.load(std::memory_order_acquire); });
-            }
-        }
-        if (g->quit.load(std::memory_order_acquire) && g->gen.load(std::memory_order_acquire) == seen) return;
-        seen = g->gen.load(std::memory_order_acquire);
-        g->wstatus[i] = g->job(i);
-        if (g->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(g->mu); g->cv_done.notify_all(); }
-    }
-}
-
 // runs fn(i) on every device's worker, concurrently (and `meanwhile`, if any, on the calling thread once the workers are off);
 // the first failure is reported
 iba_status run_all(iba_group* g, std::function<iba_status(int)> fn, const std::function<void()>& meanwhile = nullptr) {
-    g->job = std::move(fn);
-    g->pending.store(g->n, std::memory_order_release);
-    { std::lock_guard<std::mutex> lk(g->mu); g->gen.fetch_add(1, std::memory_order_acq_rel); }
-    g->cv_job.notify_all();
-    if (meanwhile) meanwhile();
-    auto t0 = std::chrono::steady_clock::now();
-    int polls = 0;
-    while (g->pending.load(std::memory_order_acquire) != 0) {
-        cpu_relax();
-        if ((++polls & 63) == 0 && std::chrono::steady_clock::now() - t0 > kSpinFor) {
-            std::unique_lock<std::mutex> lk(g->mu);
-            g->cv_done.wait(lk, [&]() { return g->pending.load(std::memory_order_acquire) == 0; });
-        }
-    }
-    for (int i = 0; i < g->n; ++i)
-        if (g->wstatus[i] != IBA_OK) return gfail(g, g->wstatus[i], std::string("device ") + std::to_string(g->dev[i]) + ": " + g->werr[i]);
+    const int bad = g->pool.run_all(std::move(fn), meanwhile);
+    if (bad >= 0) return gfail(g, g->pool.status_of(bad), std::string("device ") + std::to_string(g->dev[bad]) + ": " + g->pool.error_of(bad));
     return IBA_OK;
 }
 
-// the worker polls its stream for up to 2 ms before it blocks (the rule of the single handle's wait_stream)
-hipError_t poll_stream(hipStream_t st) {
+// The worker polls its stream (the rule of the single handle's wait_stream) — and never blocks inside the runtime: a collective
+// whose peer never arrives would keep hipStreamSynchronize forever. Past 2 ms the poll yields between queries; it gives up when a
+// peer has raised the abort flag or when the bound (IBA_GROUP_TIMEOUT_MS, default 20 s) has run out. 1: done, 0: abandoned.
+int poll_stream(iba_group* g, hipStream_t st, hipError_t* err) {
     const auto t0 = std::chrono::steady_clock::now();
     int polls = 0;
+    *err = hipSuccess;
     for (;;) {
         const hipError_t q = hipStreamQuery(st);
-        if (q == hipSuccess) return hipSuccess;
-        if (q != hipErrorNotReady) return q;
-        if ((++polls & 15) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        if (q == hipSuccess) return 1;
+        if (q != hipErrorNotReady) { *err = q; return 1; }
+        if ((++polls & 15) == 0) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (g->pool.aborted()) return 0;
+            if (ms > g->wait_timeout_ms) { g->pool.raise_abort(); return 0; }
+            if (ms > 2.0) std::this_thread::yield();
+        }
     }
-    return hipStreamSynchronize(st);
 }
 
-iba_status wfail(iba_group* g, int i, iba_status s, const std::string& m) { g->werr[i] = m; return s; }
+iba_status wfail(iba_group* g, int i, iba_status s, const std::string& m, bool secondary = false) { return g->pool.fail(i, s, m, secondary); }
 #define W_HIP(g, i, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return wfail(g, i, IBA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
 #define W_IBA(g, i, expr) do { iba_status _s = (expr); if (_s != IBA_OK) return wfail(g, i, _s, iba_last_error((g)->h[i])); } while (0)
 
@@ -213,20 +179,45 @@ iba_status eval_chunk(iba_group* g, const double* x, int Bc, EvalKind kind) {
     make_cands_host(x, Bc, g->cands.data(), kind == kEvalFactors);
     g->jets_ready.store(0, std::memory_order_release);
     const size_t bytes = sizeof(double) * (size_t)Bc * g->stride;
+    if (g->broken.load(std::memory_order_acquire)) return gfail(g, IBA_ERR_STATE, "the group is broken: an earlier call abandoned a collective (destroy the group)");
     iba_status s = run_all(g, [g, Bc, kind, bytes, t0, late_jets](int i) -> iba_status {
-        W_IBA(g, i, eval_partial_cands(g->h[i], g->cands.data(), Bc, kind, g->host_reduce ? g->h_parts_dev[i] : g->d_part[i], g->st[i], late_jets ? &g->jets_ready : nullptr));
+        // phase 1: this device's launch chain. Whatever happens here, the worker goes on to the barrier: its peers must learn of a
+        // failure BEFORE any of them enters the collective.
+        iba_status mine = eval_partial_cands(g->h[i], g->cands.data(), Bc, kind, g->host_reduce ? g->h_parts_dev[i] : g->d_part[i], g->st[i], late_jets ? &g->jets_ready : nullptr);
+        if (mine != IBA_OK) (void)wfail(g, i, mine, iba_last_error(g->h[i]));
+        if (g->debug_fail_armed && g->debug_fail_rank == i && g->debug_fail_phase == 1 && mine == IBA_OK) mine = wfail(g, i, IBA_ERR_STATE, "injected failure before the collective (IBA_DEBUG_FAIL_RANK)");
+        const bool all_ok = g->pool.meet(i, mine == IBA_OK);
+        if (!all_ok) {   // nobody enters the collective: drain what this device has enqueued and report
+            (void)hipStreamSynchronize(g->st[i]);
+            return mine != IBA_OK ? mine : wfail(g, i, IBA_ERR_STATE, "another device of the group failed before the collective; this device's launch chain was drained", true);
+        }
+        // phase 2: the one collective of the call
         if (!g->host_reduce) {
-            const ncclResult_t r = rccl().AllReduce(g->d_part[i], g->d_part[i], (size_t)Bc * g->stride, ncclDouble, ncclSum, g->comm[i], g->st[i]);
-            if (r != ncclSuccess) return wfail(g, i, IBA_ERR_HIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(r));
+            ncclResult_t r = ncclSuccess;
+            if (g->debug_fail_armed && g->debug_fail_rank == i && g->debug_fail_phase == 2) r = ncclInternalError;   // (injected: this rank never enqueues its all-reduce)
+            else r = rccl().AllReduce(g->d_part[i], g->d_part[i], (size_t)Bc * g->stride, ncclDouble, ncclSum, g->comm[i], g->st[i]);
+            if (r != ncclSuccess) {
+                g->pool.raise_abort();   // the peers are (or will be) waiting for a collective that cannot complete
+                if (rccl().CommAbort && g->comm[i]) { (void)rccl().CommAbort(g->comm[i]); g->comm[i] = nullptr; }
+                g->broken.store(true, std::memory_order_release);
+                return wfail(g, i, IBA_ERR_HIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(r));
+            }
             if (i == 0) W_HIP(g, i, hipMemcpyAsync(g->h_parts[0], g->d_part[0], bytes, hipMemcpyDeviceToHost, g->st[0]));
         }
         g->enq_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();   // everything of this device is enqueued
-        W_HIP(g, i, poll_stream(g->st[i]));
+        hipError_t qe = hipSuccess;
+        if (!poll_stream(g, g->st[i], &qe)) {   // abandoned: a peer failed after the barrier, or the bounded wait ran out
+            if (!g->host_reduce && rccl().CommAbort && g->comm[i]) { (void)rccl().CommAbort(g->comm[i]); g->comm[i] = nullptr; }
+            g->broken.store(true, std::memory_order_release);
+            return wfail(g, i, IBA_ERR_STATE, "the collective of this call was abandoned (a peer failed or the wait ran out): the communicator was aborted", true);
+        }
+        if (qe != hipSuccess) return wfail(g, i, IBA_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(qe));
         return IBA_OK;
     }, [g, x, Bc, late_jets]() {
         if (late_jets) make_cands_jets_host(x, Bc, g->cands.data());
         g->jets_ready.store(1, std::memory_order_release);   // always: a worker may be waiting on it
     });
+    g->debug_fail_armed = false;   // one injected failure per arming
     if (s != IBA_OK) return s;
     g->last_enqueue_us = *std::max_element(g->enq_us.begin(), g->enq_us.end());
     if (g->host_reduce && g->n > 1) {   // rank order: bitwise reproducible whatever the timing
@@ -238,12 +229,7 @@ iba_status eval_chunk(iba_group* g, const double* x, int Bc, EvalKind kind) {
     return IBA_OK;
 }
 
-void stop_workers(iba_group* g) {
-    { std::lock_guard<std::mutex> lk(g->mu); g->quit.store(true, std::memory_order_release); }
-    g->cv_job.notify_all();
-    for (auto& t : g->workers) if (t.joinable()) t.join();
-    g->workers.clear();
-}
+void stop_workers(iba_group* g) { g->pool.stop(); }
 }  // namespace
 
 extern "C" {
@@ -259,15 +245,16 @@ iba_status iba_group_frame_range(const iba_group* g, int32_t rank, int32_t* fram
 
 void iba_group_destroy(iba_group* g) {
     if (!g) return;
-    if (!g->workers.empty()) {
+    if (g->pool.size() > 0) {
         // every device's teardown on its own thread (and device)
         (void)run_all(g, [g](int i) -> iba_status {
-            if (g->st[i]) (void)hipStreamSynchronize(g->st[i]);
-            if (g->comm[i]) (void)rccl().CommDestroy(g->comm[i]);
+            const bool broken = g->broken.load(std::memory_order_acquire);   // a stream of a broken group may hold a collective that never completes
+            if (g->st[i] && !broken) (void)hipStreamSynchronize(g->st[i]);
+            if (g->comm[i]) { if (broken && rccl().CommAbort) (void)rccl().CommAbort(g->comm[i]); else (void)rccl().CommDestroy(g->comm[i]); }
             if (g->h[i]) iba_destroy(g->h[i]);
             if (g->d_part[i]) (void)hipFree(g->d_part[i]);
             if (g->h_parts[i]) (void)hipHostFree(g->h_parts[i]);
-            if (g->st[i]) (void)hipStreamDestroy(g->st[i]);
+            if (g->st[i] && !broken) (void)hipStreamDestroy(g->st[i]);
             return IBA_OK;
         });
         stop_workers(g);
@@ -291,10 +278,12 @@ iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* p
     g->n = n_devices; g->params = *params; g->stride = iba_partial_stride(); g->host_reduce = host_reduce;
     g->dev.assign(devices, devices + n_devices);
     g->h.assign(n_devices, nullptr); g->comm.assign(n_devices, nullptr); g->st.assign(n_devices, nullptr); g->d_part.assign(n_devices, nullptr); g->h_parts.assign(n_devices, nullptr); g->h_parts_dev.assign(n_devices, nullptr);
-    g->wstatus.assign(n_devices, IBA_OK); g->werr.assign(n_devices, ""); g->enq_us.assign(n_devices, 0.0);
+    g->enq_us.assign(n_devices, 0.0);
+    if (const char* e = std::getenv("IBA_GROUP_TIMEOUT_MS")) g->wait_timeout_ms = std::max(1.0, std::atof(e));
+    if (const char* e = std::getenv("IBA_DEBUG_FAIL_RANK")) { g->debug_fail_rank = std::atoi(e); g->debug_fail_armed = true; if (const char* ph = std::getenv("IBA_DEBUG_FAIL_PHASE")) g->debug_fail_phase = std::atoi(ph); }
     g->cands.resize(IBA_MAX_BATCH); g->h_sum.resize((size_t)IBA_MAX_BATCH * g->stride);
     shard(desc, n_devices, g->f_begin, g->f_end);
-    for (int i = 0; i < n_devices; ++i) g->workers.emplace_back(worker_main, g, i);
+    g->pool.start(n_devices, [g](int i) { (void)hipSetDevice(g->dev[i]); });   // once: every HIP call of a worker targets its device
     // the handles (static index builds, uploads, plane memo) are created concurrently, one per worker
     iba_status s = run_all(g, [g, desc, params](int i) -> iba_status {
         const iba_status cs = iba_create(desc, params, g->dev[i], g->f_begin[i], g->f_end[i], &g->h[i]);

@@ -337,6 +337,23 @@ extern "C" {
 const char* iba_io_last_error(void) { return g_io_err.c_str(); }
 void iba_io_free(void* p) { std::free(p); }
 
+// the numbers of one top-level entry of a cv::FileStorage YAML file (the dialect of KeyFrames/NNNNNN.yml, Map.yml and of ORB-SLAM2's
+// settings files such as config/orb_ori/KITTI00-02.yaml): a scalar, a flow sequence, or the data of an !!opencv-matrix node
+iba_status iba_read_cv_yaml_numbers(const char* file, const char* key, double* out, int32_t cap, int32_t* n_out) {
+    if (!file || !key || !n_out) return io_fail(IBA_ERR_INVALID_ARG, "null argument");
+    CvYaml y;
+    if (!y.load(file)) return io_fail(IBA_ERR_IO, std::string("Cannot open file: ") + file);
+    const int line = y.find(0, y.size(), 0, key);
+    if (line < 0) return io_fail(IBA_ERR_IO, std::string(file) + ": no top-level entry '" + key + "'");
+    std::vector<double> v;
+    int rows = 0, cols = 0;
+    if (!y.numbers(line, v) && !y.matrix(line, rows, cols, v)) return io_fail(IBA_ERR_IO, std::string(file) + ": entry '" + key + "' is not numeric");
+    if (rows > 0) { std::vector<double> m; if (y.matrix(line, rows, cols, m)) v = m; }
+    *n_out = (int32_t)v.size();
+    for (int32_t i = 0; i < (int32_t)v.size() && i < cap && out; ++i) out[i] = v[(size_t)i];
+    return IBA_OK;
+}
+
 iba_status iba_read_kitti_bin(const char* file, int32_t skip, int32_t only_positive_x, float** xyz, int64_t* n_points) {
     if (!file || !xyz || !n_points) return io_fail(IBA_ERR_INVALID_ARG, "null argument");
     std::vector<float> v;
@@ -345,7 +362,7 @@ iba_status iba_read_kitti_bin(const char* file, int32_t skip, int32_t only_posit
     *n_points = (int64_t)(v.size() / 3);
     *xyz = (float*)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(float));
     if (!*xyz) return io_fail(IBA_ERR_IO, "out of memory");
-    std::memcpy(*xyz, v.data(), v.size() * sizeof(float));
+    if (!v.empty()) std::memcpy(*xyz, v.data(), v.size() * sizeof(float));   // (memcpy from a null pointer is undefined even for 0 bytes: found by the UBSan build)
     return IBA_OK;
 }
 
@@ -358,7 +375,7 @@ iba_status iba_read_pose_list(const char* file, double** poses12, int64_t* n_pos
     *n_poses = (int64_t)n;
     *poses12 = (double*)std::malloc(std::max<size_t>(12 * n, 1) * sizeof(double));
     if (!*poses12) return io_fail(IBA_ERR_IO, "out of memory");
-    std::memcpy(*poses12, v.data(), 12 * n * sizeof(double));
+    if (n) std::memcpy(*poses12, v.data(), 12 * n * sizeof(double));
     return IBA_OK;
 }
 

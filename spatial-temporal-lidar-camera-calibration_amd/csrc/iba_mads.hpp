@@ -43,6 +43,7 @@ struct MadsOptions {
     double vns_amplitude = 0.5;
     int vns_mesh_index = 0;                         // mesh index a restarted descent begins with
     std::vector<double>* trace = nullptr;           // optional: every point handed to the black box, in order, as 8 doubles (x, f)
+    std::vector<int>* batch_sizes = nullptr;        // optional: the size of every black-box call, in order (the rows of `trace` split into calls)
 };
 struct MadsPoint { double x[kMadsN]; double f, c[3], h; };
 struct MadsResult {
@@ -106,6 +107,7 @@ inline bool mads_minimize(const double* x0, const MadsOptions& o, EvalBatch eval
             for (int b = 0; b < B; ++b) std::memcpy(&X[(size_t)b * n], trial[todo[s + b]].x, sizeof(double) * n);
             if (!eval(X.data(), B, out.data())) return false;
             ++res.batches;
+            if (o.batch_sizes) o.batch_sizes->push_back(B);
             for (int b = 0; b < B; ++b) {
                 MadsPoint& p = trial[todo[s + b]];
                 p.f = out[b].f; std::memcpy(p.c, out[b].c, sizeof(p.c));

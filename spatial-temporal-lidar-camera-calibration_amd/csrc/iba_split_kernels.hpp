@@ -22,6 +22,7 @@
 // that recomputed the queries. Splitting also frees the association kernel from the search's registers and LDS.
 #pragma once
 #include "iba_kernels.hpp"
+#include "iba_pair_plan.hpp"
 
 namespace iba {
 
@@ -611,9 +612,31 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 // rel[b] = (M_b row-major, a_b) as floats: candidate b relative to the reference, q_b = q_0 + M_b q_0 + a_b with M_b = R_b R_0^T - I,
 // a_b = t_b - R_b R_0^T t_0 (the pair search bounds a block's motion over the batch by the candidates' own motions). The whole
 // struct travels in the kernel arguments: the pair search depends on nothing the staging launch produces and runs beside it.
-struct CommonRef { double R[9], t[3], rho[9], tau[3]; float rel[IBA_MAX_BATCH][12]; };
-struct PairsArgs { DevProblem dp; CommonRef cr; };
+//
+// GROUPS (round 4). A batch need not be tight as a whole: an optimiser's batch is typically two polls — around its feasible and
+// its infeasible incumbent (iba_mads.hpp) — each tight once the mesh has shrunk, far from each other (tools/mads_trace_stats.py:
+// 376 of 1276 batches of a calibration, half of its time). The host clusters the candidates into at most kMaxPairGroups groups
+// (plan_pairs), every group has its own reference + bound (GroupRef) and its own pair lists in one of kMaxPairGroups list SLOTS
+// of the handle; ONE launch of the pair search builds the lists of every group that needs new ones (blockIdx.z), and a
+// candidate's association block reads the slot of its group (Assoc2Map). A slot whose lists were built with an inflated bound
+// stays valid for later calls (the reuse of round 3, now per slot: both poll centres keep theirs).
+// (kMaxPairGroups, GroupRef: iba_pair_plan.hpp, shared with the host-only planner)
+// what the pair search reads of the problem (the whole DevProblem would not fit the kernel argument segment beside four groups)
+struct PairsProblem { const FrameHdr* frames; const float4* pts4; const float* chunk_box; const float2* kp_uv; const uint32_t* coarse_start; };
+struct PairsPlan {
+    GroupRef g[kMaxPairGroups];                  // the groups whose lists this launch builds (blockIdx.z)
+    float rel[IBA_MAX_BATCH][12];                // the candidates' own motions relative to their group's reference, the rows of a group consecutive
+    uint32_t cnt_off[kMaxPairGroups];            // per built group: offset (u32) of the counter set its lists use ...
+    uint32_t next_off[kMaxPairGroups];           // ... and of the set cleared for the slot's next build
+    uint8_t first[kMaxPairGroups], count[kMaxPairGroups];   // rows of rel[] of the group; count 0: entrywise bound only (a lone candidate, a reusable list)
+    uint8_t slot[kMaxPairGroups];                // the list slot the group's lists go to
+    uint8_t pad[4];
+};
+struct PairsArgs { PairsProblem dp; PairsPlan pl; };
 static_assert(sizeof(PairsArgs) + 96 <= 4096, "the pair search's arguments must fit the 4 KB kernel argument segment");
+// which list slot a candidate's association block reads, and where the slots' current counters are
+struct Assoc2Map { uint32_t cnt_off[kMaxPairGroups]; uint8_t slot[IBA_MAX_BATCH]; };
+struct K2Args { KArgs k; Assoc2Map m; };   // first argument of iba_assoc2_kernel: read in place through the kernarg segment pointer
 struct PairRec { float x, y, z; uint32_t idx; float u, v; uint32_t k, pad; };   // scan point (+ original index), keypoint (+ id): 32 B, streamed
 constexpr int kPairsThreads = 512;    // measured at the bench shape: 1024 threads 50 us, 512 threads 39 us, 256 threads 58 us per batch
 constexpr int kCountStride = 32;   // u32 per frame (one 128-byte line: the frames' counters do not share a line): pairs, hard points, overflow flag
@@ -622,13 +645,25 @@ constexpr int kPairStage = 2048;   // (point, keypoint) hits a block parks in LD
 // grid: (ceil(max P / kPairsThreads), frames); one scan point per thread. The keypoint grid of the frame (coarse CSR + the
 // keypoints' (u, v)) sits in LDS, so a thread's walk costs LDS round trips, not L2 ones; the hits of a block are parked in LDS
 // and written out behind one atomic reservation per block.
-__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_by_value, double max_pixel_dist, uint32_t lds_kuv_off, int B,
-                                                                  PairRec* __restrict__ pairs, uint32_t* __restrict__ hard,
-                                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ counts_next, int pair_cap, int hard_cap) {
+__global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_by_value, double max_pixel_dist, uint32_t lds_kuv_off, int n_frames,
+                                                                  PairRec* __restrict__ pairs_all, uint32_t* __restrict__ hard_all,
+                                                                  uint32_t* __restrict__ counts_all, int pair_cap, int hard_cap) {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef __attribute__((address_space(4))) const PairsArgs PairsArgsC;
-    PairsArgsC* pa = (PairsArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // (the argument block is read in place: rel[] is indexed per lane)
-    const DevProblem& dp = pa_by_value.dp; const CommonRef& cr = pa_by_value.cr;
+    PairsArgsC* pa = (PairsArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // (the argument block is read in place: the group is indexed per block, rel[] per lane)
+    (void)pa_by_value;
+    const PairsProblem dp{pa->dp.frames, pa->dp.pts4, pa->dp.chunk_box, pa->dp.kp_uv, pa->dp.coarse_start};
+    const int grp = blockIdx.z;                    // which of the plan's groups this block searches for
+    GroupRef cr;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { cr.R[i] = pa->pl.g[grp].R[i]; cr.rho[i] = pa->pl.g[grp].rho[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { cr.t[i] = pa->pl.g[grp].t[i]; cr.tau[i] = pa->pl.g[grp].tau[i]; }
+    const int B = (int)pa->pl.count[grp], rel0 = (int)pa->pl.first[grp];
+    const size_t slot = (size_t)pa->pl.slot[grp];
+    PairRec* pairs = pairs_all + slot * (size_t)n_frames * (size_t)pair_cap;
+    uint32_t* hard = hard_all + slot * (size_t)n_frames * (size_t)hard_cap;
+    uint32_t* counts = counts_all + pa->pl.cnt_off[grp]; uint32_t* counts_next = counts_all + pa->pl.next_off[grp];
     const int f = blockIdx.y;
     const FrameHdr& h = dp.frames[f];
     const uint32_t P = h.P, K = h.K;
@@ -731,7 +766,7 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
             if (b < B) {
                 double rl[12];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) rl[i] = (double)pa->cr.rel[b][i];
+                for (int i = 0; i < 12; ++i) rl[i] = (double)pa->pl.rel[rel0 + b][i];
                 for (int i = 0; i < 3; ++i) {
                     // (the entries are floats of the host's doubles: each is off by at most 2^-24 of itself, which the last term covers)
                     const double lin = (fabs(rl[i * 3]) * (fabs(qc[0]) + ex[0]) + fabs(rl[i * 3 + 1]) * (fabs(qc[1]) + ex[1])) + fabs(rl[i * 3 + 2]) * (fabs(qc[2]) + ex[2]);
@@ -872,12 +907,14 @@ __device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* 
 constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
 constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
 template <bool FLREG>   // FLREG: the frame's keypoint flags never go through LDS (at most 2048 keypoints per frame; see assoc_tail)
-__global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
+__global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
                                                               const double* __restrict__ he, uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
-                                                              uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hard,
-                                                              const uint32_t* __restrict__ counts, int pair_cap, int hard_cap) {
+                                                              uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs_all, const uint32_t* __restrict__ hard_all,
+                                                              const uint32_t* __restrict__ counts_all, int pair_cap, int hard_cap) {
     extern __shared__ __align__(16) unsigned char smem[];
-    KArgsC* ka = (KArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef __attribute__((address_space(4))) const K2Args K2ArgsC;
+    K2ArgsC* ka2 = (K2ArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
+    KArgsC* ka = &ka2->k;
     (void)ka_by_value;
 #define dp (ka->dp)
 #define prm (ka->prm)
@@ -891,6 +928,11 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(KArgs ka_by_value,
     const FrameHdr& h = dp.frames[f];
     const Cand& cd = cands[b];
     double* part = frame_partials + ((size_t)b * nrec + f) * kPartialStride;
+    // the lists of this candidate's group: one of the handle's list slots
+    const uint32_t lslot = (uint32_t)ka2->m.slot[b];
+    const PairRec* pairs = pairs_all + (size_t)lslot * (size_t)nf * (size_t)pair_cap;
+    const uint32_t* hard = hard_all + (size_t)lslot * (size_t)nf * (size_t)hard_cap;
+    const uint32_t* counts = counts_all + ka2->m.cnt_off[lslot];
 
     unsigned long long* s_best_d2 = (unsigned long long*)(smem + lay.off_best_d2);
     uint32_t* s_best_idx = (uint32_t*)(smem + lay.off_best_idx);

@@ -202,3 +202,69 @@ def handeye_lineprocess(Ta, Tb, rigid0, scale0, inner_iterations=10, mu0=64.0, d
     if st != 0:
         raise IbaError(st, "iba_handeye_lineprocess")
     return r.reshape(3, 4), s.value
+
+
+def read_cv_yaml_numbers(path, key):
+    """The numbers of one top-level entry of a cv::FileStorage YAML file through the reader iba_dataset_load uses."""
+    L = _lib()
+    L.iba_read_cv_yaml_numbers.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32)]
+    n = C.c_int32(0)
+    _chk(L, L.iba_read_cv_yaml_numbers(str(path).encode(), key.encode(), None, 0, C.byref(n)))
+    out = np.zeros(max(n.value, 1))
+    _chk(L, L.iba_read_cv_yaml_numbers(str(path).encode(), key.encode(), _dp(out), n.value, C.byref(n)))
+    return out[: n.value]
+
+
+class RunConfig:
+    """The reference's run configuration file (config/calib/NN/iba_calib_global.yml and its iba_func / iba_local siblings) as the
+    C-ABI's structs: iba_run_config_* (csrc/iba_config.cpp; what main() reads with yaml-cpp, iba_global.cpp:412-471)."""
+
+    def __init__(self, path):
+        from .abi import IbaMadsOptions, IbaParams
+        self._P, self._M = IbaParams, IbaMadsOptions
+        self.L = L = load_library()
+        L.iba_run_config_last_error.restype = C.c_char_p
+        L.iba_run_config_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.iba_run_config_free.argtypes = [C.c_void_p]
+        L.iba_run_config_get.restype = C.c_char_p
+        L.iba_run_config_get.argtypes = [C.c_void_p, C.c_char_p]
+        L.iba_run_config_path.restype = C.c_char_p
+        L.iba_run_config_path.argtypes = [C.c_void_p, C.c_char_p]
+        L.iba_run_config_params.argtypes = [C.c_void_p, C.c_int32, C.POINTER(IbaParams)]
+        L.iba_run_config_paths.argtypes = [C.c_void_p, C.c_int32, C.POINTER(IbaDatasetPaths)]
+        L.iba_run_config_mads.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(IbaMadsOptions)]
+        self.h = C.c_void_p()
+        self._chk(L.iba_run_config_load(str(path).encode(), C.byref(self.h)))
+
+    def _chk(self, st):
+        if st != 0:
+            raise IbaError(st, (self.L.iba_run_config_last_error() or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.L.iba_run_config_free(self.h)
+            self.h = C.c_void_p()
+
+    def get(self, dotted_key):
+        v = self.L.iba_run_config_get(self.h, dotted_key.encode())
+        return None if v is None else v.decode()
+
+    def path(self, io_key):
+        v = self.L.iba_run_config_path(self.h, io_key.encode())
+        return None if v is None else v.decode()
+
+    def params(self, local_stage=False):
+        p = self._P()
+        self._chk(self.L.iba_run_config_params(self.h, 1 if local_stage else 0, C.byref(p)))
+        return p
+
+    def paths(self, local_stage=False):
+        d = IbaDatasetPaths()
+        self._chk(self.L.iba_run_config_paths(self.h, 1 if local_stage else 0, C.byref(d)))
+        return {k: (getattr(d, k).decode() if isinstance(getattr(d, k), bytes) else getattr(d, k)) for k, _ in IbaDatasetPaths._fields_}
+
+    def mads(self, x0):
+        x0 = np.ascontiguousarray(x0, np.float64)
+        o = self._M()
+        self._chk(self.L.iba_run_config_mads(self.h, _dp(x0), C.byref(o)))
+        return o

@@ -33,3 +33,17 @@ def test_gpus_flag_must_agree_with_the_launcher():
     assert r.returncode != 0
     r = _run(["--gpus", "2", "--launch", "group"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "one process for all GPUs" in r.stderr
+
+
+def test_default_is_the_metrics_own_problem_and_value_is_never_multiplied_by_the_gpu_count():
+    """BASELINE.json's metric is the 2 M-point x 200-keyframe problem at 1 / 2 / 4 / 8 GPUs: strong scaling. Round 3's bench.py
+    defaulted to weak scaling and multiplied candidates/s by N."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.build_parser().parse_args(["--gpus", "8"])
+    assert a.scaling == "strong" and a.frames == 200 and a.pts == 10000 and a.batch == 64
+    for scaling in ("strong", "weak"):
+        for n in (1, 2, 8):
+            assert bench.job_value(64 * 20, 0.01, n, scaling) == 64 * 20 / 0.01
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "units * evals" not in src and "n_gpus * evals" not in src

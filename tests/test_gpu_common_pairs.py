@@ -30,7 +30,7 @@ def _same_bits(pkg, h0, h1, xs, want_path):
     assert h0.last_path == 0
     c1, n1 = h1.eval_full(xs)
     p1 = h1.debug_last_partials(min(len(xs), 64))
-    assert h1.last_path == want_path
+    assert h1.last_path in (want_path if isinstance(want_path, tuple) else (want_path,)), h1.last_path
     assert np.array_equal(p0, p1), np.argwhere(p0 != p1)[:5]
     for a, b in zip(c0, c1):
         assert a.as_dict() == b.as_dict()
@@ -57,7 +57,7 @@ def test_shared_search_gives_the_same_bits(pkg, synth, abi, scene_small):
     # as wide as the reference's whole search box (+-0.1 rad, +-0.3 m): windows of tens of pixels, hard points, list overflows
     box = meta["x_gt"][None, :] + rng.uniform(-1, 1, (12, 7)) * np.array([0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0])
     _same_bits(pkg, h0, h2, box, 1)
-    _same_bits(pkg, h0, h1, box, 0)                             # the default falls back for such a batch
+    _same_bits(pkg, h0, h1, box, (0, 2))                        # the default falls back for such a batch (or finds tight groups in it)
     # the frozen problem and the callers are untouched by the mode
     for h in (h0, h1):
         h.build_problem(tight[1])
@@ -232,3 +232,60 @@ def test_pair_lists_are_reused_while_the_batches_stay_inside_their_bound(pkg, sy
     assert h_memo.pairs_builds == before + 1
     for hh in (h_memo, h_every, h_single):
         hh.close()
+
+
+def test_a_batch_of_several_tight_groups_shares_one_search_per_group(pkg, synth, abi, ob, scene_small):
+    """An optimiser's batch is usually two polls — around its feasible and its infeasible incumbent (iba_mads.hpp) — each tight, far
+    from each other: wide as a whole, so round 3 sent it to the per-candidate kernels. The planner clusters such a batch into at
+    most four groups with one pair list each (path 2). Same bits as the handle where every candidate searches for itself, whatever
+    the grouping, the order of the candidates, the number of groups; lists are reused per group across calls; equal to the oracle."""
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    h0, h1 = _handle(pkg, prob, p, 0), _handle(pkg, prob, p, 1)
+    rng = np.random.default_rng(23)
+    c1 = meta["x_gt"]
+    c2 = c1 + np.array([0.02, -0.015, 0.01, 0.1, -0.08, 0.06, 0.2])      # tens of pixels away
+    c3 = c1 + np.array([-0.03, 0.01, 0.02, -0.15, 0.05, -0.1, -0.3])
+    c4 = c1 + np.array([0.01, 0.03, -0.02, 0.05, 0.12, 0.1, 0.5])
+    two = np.vstack([synth.perturb(c1, rng, n=28), synth.perturb(c2, rng, n=29)])
+    _same_bits(pkg, h0, h1, two, 2)
+    _same_bits(pkg, h0, h1, two[rng.permutation(len(two))], 2)           # interleaved: the map candidate -> list slot is per candidate
+    three = np.vstack([synth.perturb(c1, rng, n=20), synth.perturb(c2, rng, n=1), synth.perturb(c3, rng, n=30)])   # a singleton group
+    _same_bits(pkg, h0, h1, three, 2)
+    four = np.vstack([synth.perturb(c, rng, rot=8e-4, trans=8e-3, scale_rel=1e-2, n=16) for c in (c1, c2, c3, c4)])  # four looser groups (7-10 px each), 64 candidates
+    _same_bits(pkg, h0, h1, four, 2)
+    five = np.vstack([four[:50], synth.perturb(c1 + 0.05, rng, n=5)])    # a fifth centre: more groups than slots -> every candidate for itself
+    _same_bits(pkg, h0, h1, five, (0, 2))
+    # against the oracle
+    o = ob.Oracle(prob)
+    g, r = h1.eval_cost(two[20:36]), o.eval_cost(p, two[20:36])
+    assert h1.last_path == 2
+    for a, b in zip(g, r):
+        assert (a.n_corr, a.cnt_3d_2d, a.valid_cnt_3d_2d, a.cnt_3d_3d, a.valid_cnt_3d_3d, a.frames_used) == (b.n_corr, b.cnt_3d_2d, b.valid_cnt_3d_2d, b.cnt_3d_3d, b.valid_cnt_3d_3d, b.frames_used)
+        assert abs(a.f1 - b.f1) <= 1e-10 * abs(b.f1) and abs(a.f2 - b.f2) <= 1e-10 * abs(b.f2)
+    # a drifting two-centre sequence (the late polls of a mesh search): both centres keep their lists across calls
+    before, calls = h1.pairs_builds, 0
+    a1, a2 = c1.copy(), c2.copy()
+    for step in range(10):
+        xs = np.vstack([synth.perturb(a1, rng, rot=1e-4, trans=1e-3, scale_rel=3e-4, n=14), synth.perturb(a2, rng, rot=1e-4, trans=1e-3, scale_rel=3e-4, n=15)])
+        if step % 3 == 2:
+            a1 = xs[0]
+        u, w = h1.eval_cost(xs), h0.eval_cost(xs)
+        assert h1.last_path == 2
+        calls += 1
+        for x_, y_ in zip(u, w):
+            assert x_.as_dict() == y_.as_dict(), step
+    assert h1.pairs_builds - before < calls, (h1.pairs_builds - before, calls)   # (two searches per call without reuse)
+    # one group of the two alone, then the other: single-group calls find the slots the clustered calls left
+    n0 = h1.pairs_builds
+    for x_, y_ in zip(h1.eval_cost(synth.perturb(a2, rng, rot=5e-5, trans=5e-4, scale_rel=1e-4, n=6)), h0.eval_cost(synth.perturb(a2, np.random.default_rng(1), rot=5e-5, trans=5e-4, scale_rel=1e-4, n=6))):
+        pass
+    xs = synth.perturb(a2, rng, rot=5e-5, trans=5e-4, scale_rel=1e-4, n=6)
+    for x_, y_ in zip(h1.eval_cost(xs), h0.eval_cost(xs)):
+        assert x_.as_dict() == y_.as_dict()
+    assert h1.last_path == 1
+    # plane_cache = 0 runs on the same association
+    q = abi.reference_yaml_params(plane_cache=0)
+    h0.set_params(q); h1.set_params(q)
+    _same_bits(pkg, h0, h1, two[18:40], 2)
+    h0.close(); h1.close()

@@ -315,3 +315,68 @@ def test_back_to_back_partial_calls_on_a_caller_stream(pkg, synth, abi, scene_sm
             for a, b in zip(n1, pkg.finalize_normal(p, part)):
                 assert np.array_equal(a.H_np(), b.H_np()) and a.counts() == b.counts(), i
     h.close()
+
+
+def _group_with_env(pkg, prob, p, env, **kw):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return pkg.IbaGroup(prob, p, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_a_failing_device_is_an_error_not_a_hang(pkg, synth, abi, scene_small):
+    """Round 3: a worker whose launch chain failed returned before its all-reduce while its peers sat in theirs forever
+    (ADVICE r3). Now every worker meets its peers at a barrier between launch chain and collective: a failure
+    before it (injected with IBA_DEBUG_FAIL_RANK on one of two shards) makes the call return an error within a second, nobody
+    enters the collective, and the NEXT call on the same group works and gives the single-device bits. A failure at the
+    collective itself (IBA_DEBUG_FAIL_PHASE=2: the rank never enqueues its all-reduce; one-rank RCCL group on this box) aborts
+    the communicator: the call returns an error, the group is broken (every later call fails at once), destroy does not hang."""
+    import time
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(8), n=6)
+    h = pkg.IbaHandle(prob, p)
+    want = h.eval_cost(xs)
+    # (1) two host-reduced shards on this device, shard 1 fails before the collective phase
+    g = _group_with_env(pkg, prob, p, {"IBA_DEBUG_FAIL_RANK": "1", "IBA_DEBUG_FAIL_PHASE": "1"}, devices=(0, 0), host_reduce=True)
+    t0 = time.perf_counter()
+    with pytest.raises(pkg.IbaError) as ei:
+        g.eval_cost(xs)
+    assert time.perf_counter() - t0 < 1.0
+    assert "injected failure" in str(ei.value)
+    got = g.eval_cost(xs)                                              # the injection was one-shot: the group is intact
+    for a, b in zip(want, got):
+        assert (a.n_corr, a.cnt_3d_2d, a.valid_cnt_3d_2d, a.cnt_3d_3d, a.valid_cnt_3d_3d) == (b.n_corr, b.cnt_3d_2d, b.valid_cnt_3d_2d, b.cnt_3d_3d, b.valid_cnt_3d_3d)
+        assert abs(a.f1 - b.f1) <= 1e-12 * abs(a.f1)
+    g.close()
+    # (2) the same with RCCL (one rank): fails before the collective, the next call works
+    g = _group_with_env(pkg, prob, p, {"IBA_DEBUG_FAIL_RANK": "0", "IBA_DEBUG_FAIL_PHASE": "1"}, devices=(0,))
+    t0 = time.perf_counter()
+    with pytest.raises(pkg.IbaError):
+        g.eval_full(xs)
+    assert time.perf_counter() - t0 < 1.0
+    for a, b in zip(want, g.eval_cost(xs)):
+        assert a.as_dict() == b.as_dict()
+    g.close()
+    # (3) the collective itself fails on a rank: communicator aborted, group broken, no hang anywhere
+    g = _group_with_env(pkg, prob, p, {"IBA_DEBUG_FAIL_RANK": "0", "IBA_DEBUG_FAIL_PHASE": "2"}, devices=(0,))
+    t0 = time.perf_counter()
+    with pytest.raises(pkg.IbaError) as ei:
+        g.eval_cost(xs)
+    assert time.perf_counter() - t0 < 1.0 and "ncclAllReduce" in str(ei.value)
+    with pytest.raises(pkg.IbaError) as ei:
+        g.eval_cost(xs)
+    assert "broken" in str(ei.value)
+    t0 = time.perf_counter()
+    g.close()
+    assert time.perf_counter() - t0 < 5.0
+    for a, b in zip(want, h.eval_cost(xs)):                           # the device and the single handle are unharmed
+        assert a.as_dict() == b.as_dict()
+    h.close()

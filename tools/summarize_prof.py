@@ -39,6 +39,7 @@ kernels = [k for k in avg_us if k.startswith(("iba_assoc", "iba_pairs", "iba_nn_
 lines += ["", "## counters per launch (separate --pmc passes on the same command; KiB -> bytes, FETCH_SIZE x2 on gfx950)", "",
           "| kernel | HBM read MB (x2) | HBM write MB | SQ_INSTS_VALU | SQ_INSTS_SALU | SQ_INSTS_LDS | SQ_INSTS_VMEM | VALU-active share of SIMD cycles | SQ_WAIT_ANY / SQ_WAVE_CYCLES | MFMA F64 insts |", "|---|---|---|---|---|---|---|---|---|---|"]
 tot_hbm = 0.0; act = 0.0; gui = 0.0
+step_hbm = 0.0; step_act = 0.0; step_gui = 0.0; per_kernel = {}
 for k in kernels:
     f = 2 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024; w = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
     i, c, m = insts.get(k, {}), cyc.get(k, {}), mfma.get(k, {})
@@ -48,6 +49,9 @@ for k in kernels:
                                                                                         i.get("SQ_INSTS_VMEM", 0), share, wait, m.get("SQ_INSTS_VALU_MFMA_F64", 0)))
     if k.startswith(("iba_assoc", "iba_pairs", "iba_nn_kernel")):
         tot_hbm += f + w; act += 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0); gui += c.get("GRBM_GUI_ACTIVE", 0.0) / 8
+    if not k.startswith("iba_anchor"):   # every kernel of a step (the anchor lists are built once, outside the timed steps)
+        step_hbm += f + w; step_act += 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0); step_gui += c.get("GRBM_GUI_ACTIVE", 0.0) / 8
+    per_kernel[k] = {"avg_us": avg_us.get(k), "hbm_read_bytes": f, "hbm_write_bytes": w, "valu_active_share": share, "wait_any_share": wait, "insts_valu": i.get("SQ_INSTS_VALU", 0)}
 bench_line = None
 try:
     bench_line = json.loads([l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][-1])
@@ -64,6 +68,7 @@ cfg = (bench_line or {}).get("config", {})
 pmc = {"round": tag, "git_head": head + ("+uncommitted kernel changes" if dirty else ""), "source_stamp": hsh.hexdigest()[:16], "taken_on": time.strftime("%Y-%m-%d"),
        "frames": cfg.get("frames_this_rank"), "pts": cfg.get("points_per_frame"), "batch": cfg.get("candidates_per_step"),
        "kernels": "iba_pairs_kernel + iba_assoc2_kernel + iba_nn_kernel", "hbm_bytes_per_launch": tot_hbm, "valu_issue_frac": act / (N_SIMD * gui) if gui else None,
+       "hbm_bytes_per_step": step_hbm, "valu_issue_frac_step": step_act / (N_SIMD * step_gui) if step_gui else None, "per_kernel": per_kernel,
        "counters": "FETCH_SIZE x2 + WRITE_SIZE (KiB); 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
        "note": "one rocprofv3 --pmc pass per counter list on `python3 bench.py --steps 15 --warmup 2 --no-cpu-baseline --no-extras`; mean per launch"}
 json.dump(pmc, open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
