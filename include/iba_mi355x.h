@@ -71,7 +71,7 @@ typedef struct iba_problem_desc {
     const float* Tcw; /* [F*12] */
 
     /* pKF->GetBestCovisibilityKeyFramesSafe(num_best_covis) (or ByWeight), iba_global.cpp:254-258.
-     * One "slot" per (reference KF, covisible KF) pair; at most 22 per reference KF. */
+     * One "slot" per (reference KF, covisible KF) pair; at most 30 per reference KF. */
     const uint64_t* covis_offset; /* [F+1] slots of frame f are covis_offset[f]..covis_offset[f+1] */
     const int32_t* covis_frame;   /* [S] frame index of the covisible KF */
     /* pKFConv->GetPose() * InvRefCVPose evaluated in CV_32F (iba_global.cpp:280), top 3 rows
@@ -172,6 +172,30 @@ iba_status iba_default_params(iba_params* p); /* IBAGlobalParams / IBALocalParam
  * are resolved at creation time); only owned frames are uploaded and evaluated. */
 iba_status iba_create(const iba_problem_desc* desc, const iba_params* params, int device,
                       int32_t frame_begin, int32_t frame_end, iba_handle** out);
+/*
+ * Engine options of a handle (no reference counterpart: none of them changes a result bit, they steer how the work is shared
+ * between candidates and calls). Fill with iba_default_create_options, change fields, pass to iba_create_ex; iba_create uses the
+ * defaults. The IBA_* environment variables of earlier rounds are still read at creation as DEBUG overrides of these fields
+ * (process-global, for A/B runs without recompiling a caller); an integrator sets the struct.
+ */
+typedef struct iba_create_options {
+    int32_t struct_size;          /* sizeof(iba_create_options) of the caller: the struct may grow at its end */
+    int32_t common_pairs;         /* 2d-3d pair search shared by a batch: 0 never, 1 when the batch (or each of its groups) is tight [default], 2 always */
+    double common_max_px;         /* nominal projection spread (px) up to which candidates share one pair search [20] */
+    int32_t max_pair_groups;      /* a wider batch is clustered into up to this many tight groups, 1..4 [4]; 1 = no clustering */
+    int32_t pair_memo;            /* pair lists built for an inflated bound and reused by later calls that stay inside it [1] */
+    int32_t pair_memo_max_batch;  /* largest batch (group) whose lists are built reusable [40] */
+    double pair_inflation;        /* inflation of a reusable list's bound [1.25] */
+    int32_t anchored_lists;       /* 3-D 1-NN memoised around an anchor extrinsic that follows the candidates [1] */
+    double anchor_reach;          /* drift (m) of a MapPoint query 30 m out that moves the anchor [0.06] */
+    int32_t side_stream;          /* staging launch / derivative copy on a second stream of the handle [1] */
+    int32_t spin_wait;            /* the host polls the stream at the end of a call instead of blocking [1] */
+    int32_t factor_mfma;          /* normal-equation sums on the matrix cores (v_mfma_f64_16x16x4; measured slower) [0] */
+    int32_t pair_list_capacity;   /* entries per keyframe of a pair list; 0 = automatic. A full list only costs speed [0] */
+} iba_create_options;
+iba_status iba_default_create_options(iba_create_options* o);
+iba_status iba_create_ex(const iba_problem_desc* desc, const iba_params* params, int device,
+                         int32_t frame_begin, int32_t frame_end, const iba_create_options* options, iba_handle** out);
 void iba_destroy(iba_handle* h);
 iba_status iba_set_params(iba_handle* h, const iba_params* params);
 const char* iba_last_error(const iba_handle* h); /* never NULL; h may be NULL for creation errors */

@@ -157,6 +157,25 @@ class Oracle:
             lib().oracle_eval_residuals(C.c_void_p(self.h), _p(x), _p(r), _p(J), _p(bid), _p(kind), _p(fk), C.byref(n))
         return r, J, bid, kind, fk
 
+    def block_conditioning(self, x):
+        """per residual block of the frozen problem, at x: how far the block's quotients are from cancelling (1 = well-conditioned,
+        -> 0 = a plane factor whose viewing ray lies in its plane / whose reprojection depth vanishes)"""
+        x = np.ascontiguousarray(x, np.float64)
+        n = C.c_int64(0)
+        lib().oracle_block_conditioning(C.c_void_p(self.h), _p(x), None, C.byref(n))
+        c = np.ones(max(n.value, 1))
+        if n.value:
+            lib().oracle_block_conditioning(C.c_void_p(self.h), _p(x), _p(c), C.byref(n))
+        return c[: n.value]
+
+    def plane_edge20(self, factor_index, x):
+        """IBAPlaneEdge (the g2o twin of IBA_PlaneFactor, IBACalib.hpp:103-140): the block's residuals zero-padded to 20, J 20 x 7"""
+        x = np.ascontiguousarray(x, np.float64)
+        e = np.zeros(20)
+        J = np.zeros((20, 7))
+        st = lib().oracle_eval_plane_edge20(C.c_void_p(self.h), C.c_int64(factor_index), _p(x), _p(e), _p(J))
+        return (e, J) if st == 0 else None
+
     def plane_at(self, frame, pt_idx, radius, max_pts):
         k = C.c_int32(0)
         far = C.c_double(0)

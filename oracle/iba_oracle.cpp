@@ -585,6 +585,40 @@ int oracle_eval_plane_edge20(void* h, int64_t factor_index, const double* x, dou
     eval_factor(f, x, err20, J20x7);
     return 0;
 }
+// How well-conditioned each residual block of the frozen problem is at x, as a number in (0, 1]: for an IBA_PlaneFactor the two
+// quotients of IBACalib2.hpp:163-183 are differences of products divided by a sum that may cancel —
+//   Z0 = (n_c . p_c) / den, den = Cxz n_cx + Cyz n_cy + n_cz   -> |den| / (|Cxz n_cx| + |Cyz n_cy| + |n_cz|)   (the viewing ray lies in the plane: 0)
+//   u = fx P1x / P1z + cx                                       -> |P1z| / (|R20 X0| + |R21 Y0| + |R22 Z0| + |s t_z|) per covisible keyframe
+// the smallest of them; 1 for the 3d-3d blocks (no quotient). Two double evaluations of such a block (the device's chain rule, the
+// Dual<7> arithmetic here) may differ by about eps / cond relative to the block's scale: the parity tests use it to tell
+// conditioning from defects (tools/soak_parity.py, tests/test_gpu_conditioning.py).
+int oracle_block_conditioning(void* h, const double* x, double* cond, int64_t* n_blocks) {
+    Oracle& O = *(Oracle*)h;
+    *n_blocks = (int64_t)O.factors.size();
+    if (!cond) return 0;
+    M3d Rcl; V3d tcl; double s;
+    Sim3Exp<double>(x, Rcl, tcl, s);
+    int64_t at = 0;
+    for (auto const& f : O.factors) {
+        double c = 1.0;
+        if (f.kind == 0) {
+            const V3d p0c = mul(Rcl, f.p0) + tcl, n0c = mul(Rcl, f.n0);
+            const double Cxz = (f.u0 - f.cx) / f.fx, Cyz = (f.v0 - f.cy) / f.fy;
+            const double den = Cxz * n0c.x + Cyz * n0c.y + n0c.z, mag = std::fabs(Cxz * n0c.x) + std::fabs(Cyz * n0c.y) + std::fabs(n0c.z);
+            c = mag > 0 ? std::fabs(den) / mag : 0.0;
+            const double Z0 = dot(n0c, p0c) / den, X0 = Cxz * Z0, Y0 = Cyz * Z0;
+            for (size_t i = 0; i < f.u1.size(); ++i) {
+                const M3d& R = f.R[i];
+                const double tz = f.t[i].z * s;
+                const double z = R.m[6] * X0 + R.m[7] * Y0 + R.m[8] * Z0 + tz, zm = std::fabs(R.m[6] * X0) + std::fabs(R.m[7] * Y0) + std::fabs(R.m[8] * Z0) + std::fabs(tz);
+                c = std::min(c, zm > 0 ? std::fabs(z) / zm : 0.0);
+            }
+            if (!(c == c)) c = 0.0;
+        }
+        cond[at++] = c;
+    }
+    return 0;
+}
 // x-independent local plane record at one scan point (for the GPU plane-cache parity test)
 int oracle_plane_at(void* h, int frame, uint32_t pt_idx, double radius, int max_pts, int32_t* k_out, double* far_d2, double* normal3, double* reg_err_sum) {
     Oracle& O = *(Oracle*)h; const Frame& f = O.frames[frame];

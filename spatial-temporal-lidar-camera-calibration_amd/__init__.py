@@ -14,7 +14,7 @@ import subprocess
 
 import numpy as np
 
-from .abi import (IBA_MAX_BATCH, IbaLmOptions, IbaLmResult, IbaMadsOptions, IbaMadsResult, IbaBbo, IbaCostOut, IbaNormalOut, IbaParams, IbaProblemDesc, Problem, copy_params,
+from .abi import (IBA_MAX_BATCH, IbaCreateOptions, IbaLmOptions, IbaLmResult, IbaMadsOptions, IbaMadsResult, IbaBbo, IbaCostOut, IbaNormalOut, IbaParams, IbaProblemDesc, Problem, copy_params,
                   reference_yaml_params)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -53,6 +53,7 @@ def load_library():
         L.iba_last_error.restype = C.c_char_p
         L.iba_last_error.argtypes = [C.c_void_p]
         L.iba_create.argtypes = [C.POINTER(IbaProblemDesc), C.POINTER(IbaParams), C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.iba_create_ex.argtypes = [C.POINTER(IbaProblemDesc), C.POINTER(IbaParams), C.c_int, C.c_int32, C.c_int32, C.POINTER(IbaCreateOptions), C.POINTER(C.c_void_p)]
         L.iba_destroy.argtypes = [C.c_void_p]
         L.iba_num_points.restype = C.c_int64
         L.iba_num_points.argtypes = [C.c_void_p]
@@ -75,6 +76,17 @@ def default_params():
     p = IbaParams()
     load_library().iba_default_params(C.byref(p))
     return p
+
+
+def create_options(**fields):
+    """iba_default_create_options with fields overridden (engine options: none changes a result bit)"""
+    o = IbaCreateOptions()
+    load_library().iba_default_create_options(C.byref(o))
+    for k, v in fields.items():
+        if k not in dict(IbaCreateOptions._fields_):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
 
 
 def partial_stride():
@@ -104,7 +116,8 @@ def finalize_normal(params, partials):
 class IbaHandle:
     """iba_handle wrapper. One evaluation at a time per handle (as BALoss::eval_x)."""
 
-    def __init__(self, problem, params=None, device=0, frame_begin=0, frame_end=None):
+    def __init__(self, problem, params=None, device=0, frame_begin=0, frame_end=None, options=None):
+        """options: an IbaCreateOptions (create_options(...)) or a dict of its fields; None = the defaults (iba_create)"""
         self.lib = load_library()
         self.problem = problem
         self.params = copy_params(params) if params is not None else default_params()
@@ -112,7 +125,11 @@ class IbaHandle:
         self.h = C.c_void_p(None)
         fe = problem.n_frames if frame_end is None else frame_end
         self.frame_begin, self.frame_end = frame_begin, fe
-        st = self.lib.iba_create(C.byref(self._desc), C.byref(self.params), C.c_int(device), C.c_int32(frame_begin), C.c_int32(fe), C.byref(self.h))
+        if options is None:
+            st = self.lib.iba_create(C.byref(self._desc), C.byref(self.params), C.c_int(device), C.c_int32(frame_begin), C.c_int32(fe), C.byref(self.h))
+        else:
+            self.options = create_options(**options) if isinstance(options, dict) else options
+            st = self.lib.iba_create_ex(C.byref(self._desc), C.byref(self.params), C.c_int(device), C.c_int32(frame_begin), C.c_int32(fe), C.byref(self.options), C.byref(self.h))
         if st != 0:
             raise IbaError(st, self.lib.iba_last_error(None).decode())
 

@@ -57,6 +57,12 @@ class IbaParams(C.Structure):
     ]
 
 
+class IbaCreateOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("common_pairs", C.c_int32), ("common_max_px", C.c_double), ("max_pair_groups", C.c_int32), ("pair_memo", C.c_int32),
+                ("pair_memo_max_batch", C.c_int32), ("pair_inflation", C.c_double), ("anchored_lists", C.c_int32), ("anchor_reach", C.c_double), ("side_stream", C.c_int32),
+                ("spin_wait", C.c_int32), ("factor_mfma", C.c_int32), ("pair_list_capacity", C.c_int32)]
+
+
 class IbaCostOut(C.Structure):
     _fields_ = [
         ("f1", C.c_double),

@@ -788,7 +788,21 @@ void iba_destroy(iba_handle* h) {
 }
 
 iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int device, int32_t frame_begin, int32_t frame_end, iba_handle** out) {
+    return iba_create_ex(d, params, device, frame_begin, frame_end, nullptr, out);
+}
+
+iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, int device, int32_t frame_begin, int32_t frame_end, const iba_create_options* user_opt, iba_handle** out) {
     g_create_error.clear();
+    iba_create_options opt;
+    iba_default_create_options(&opt);
+    if (user_opt) {   // (a caller compiled against an older, shorter struct: the fields it does not know keep their defaults)
+        if (user_opt->struct_size < (int32_t)(2 * sizeof(int32_t)) || user_opt->struct_size > (int32_t)sizeof(opt)) return fail(nullptr, IBA_ERR_INVALID_ARG, "iba_create_options.struct_size is not set (use iba_default_create_options)");
+        std::memcpy(&opt, user_opt, (size_t)user_opt->struct_size);
+        opt.struct_size = (int32_t)sizeof(opt);
+        if (opt.common_pairs < 0 || opt.common_pairs > 2 || opt.max_pair_groups < 1 || opt.max_pair_groups > kMaxPairGroups || !(opt.common_max_px >= 0) || !(opt.pair_inflation >= 1.0) ||
+            !(opt.anchor_reach >= 0) || opt.pair_list_capacity < 0 || opt.pair_memo_max_batch < 0)
+            return fail(nullptr, IBA_ERR_INVALID_ARG, "iba_create_options: a field is out of range");
+    }
     if (!d || !params || !out) return fail(nullptr, IBA_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
     const int F = d->n_frames;
@@ -973,6 +987,10 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (!crec_ok) { delete h; return fail(nullptr, IBA_ERR_STATE, "internal: keypoint grid records are not in keypoint order"); }
 
     // ---- LDS plans ----
+    // the options struct first, then the environment as a debug override (process-global: for A/B runs of an unmodified caller)
+    h->common_mode = opt.common_pairs; h->common_max_px = opt.common_max_px; h->max_groups = opt.max_pair_groups; h->pair_memo = opt.pair_memo;
+    h->pair_memo_max_b = opt.pair_memo_max_batch; h->pair_infl = opt.pair_inflation; h->nn_sets = opt.anchored_lists != 0; h->anchor_reach = opt.anchor_reach;
+    h->side_on = opt.side_stream; h->spin_wait = opt.spin_wait != 0; h->factor_valu = opt.factor_mfma == 0;
     if (const char* e = std::getenv("IBA_NN_CG")) { h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e))); h->nn_cg_fixed = true; }
     if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
@@ -990,6 +1008,7 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_PAIR_GROUPS")) h->max_groups = std::max(1, std::min(kMaxPairGroups, std::atoi(e)));
+    if (const char* e = std::getenv("IBA_SIDE_STREAM")) h->side_on = std::atoi(e);
     if (!layout_assoc(h, h->alay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
     if (!layout_assoc2(h, h->alay2) || 8u * (uint32_t)kPairStage + 160u + 2u * std::max(h->maxCoarse, 1u) + 8u * std::max(h->maxK, 1u) > kLdsBytes) h->common_mode = 0;
     if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
@@ -1015,13 +1034,19 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
     if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
     if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
-    if (h->nn_sets && h->max_mpk > 0 && (er = h->d_anchor.alloc(((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kAnchorRowBytes + sizeof(SetPt) - 1) / sizeof(SetPt) + 1)) != hipSuccess) return bail("alloc anchored neighbour lists", er);
+    if (h->nn_sets && h->max_mpk > 0) {
+        // 512 B per (frame, keypoint): 205 MB at 200 x 2000 keypoints, linear in the keyframes. The lists are an
+        // optional memo: when the allocation fails the handle runs without them (every lane searches the tree), it does not fail.
+        if (h->d_anchor.alloc(((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kAnchorRowBytes + sizeof(SetPt) - 1) / sizeof(SetPt) + 1) != hipSuccess) { (void)hipGetLastError(); h->d_anchor.p = nullptr; h->d_anchor.n = 0; h->nn_sets = false; }
+    }
     if (h->common_mode > 0) {   // common lists of one batch: (scan point, keypoint) pairs and hard points per frame
         // the pairs of a batch grow with the scan density (points per pixel) and with the batch's spread: 4 per keypoint serve 10 k-point
         // scans, a full KITTI scan (120 k points) needs ~8 (r03: 14 k pairs per keyframe at the bench spread). A full list only costs speed.
         h->pair_cap = (int)std::min<uint32_t>(65536u, std::max<uint32_t>(std::max<uint32_t>(2048u, 4u * h->maxK), h->maxP / 4u));
         h->hard_cap = 1024;
+        if (opt.pair_list_capacity > 0) { h->pair_cap = opt.pair_list_capacity; h->hard_cap = std::max(1, opt.pair_list_capacity / 8); }
         if (const char* e = std::getenv("IBA_DEBUG_PAIR_CAP")) { h->pair_cap = std::max(1, std::atoi(e)); h->hard_cap = std::max(1, std::atoi(e) / 8); }   // tests: force the overflow path
+        h->pair_cap = std::min(h->pair_cap, 65536);   // (iba_assoc2_kernel notes pair numbers as u16)
         // kMaxPairGroups list slots (one group of candidates each); two counter sets per slot, used in turn (the pair search clears the set of the slot's NEXT build)
         if ((er = h->d_pairs.alloc((size_t)kMaxPairGroups * std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
         if ((er = h->d_hard.alloc((size_t)kMaxPairGroups * std::max(nf, 1) * h->hard_cap)) != hipSuccess) return bail("alloc hard list", er);
@@ -1037,7 +1062,6 @@ iba_status iba_create(const iba_problem_desc* d, const iba_params* params, int d
     if ((er = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
     if ((er = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
     if ((er = hipEventCreateWithFlags(&h->ev_entry, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
-    if (const char* e = std::getenv("IBA_SIDE_STREAM")) h->side_on = std::atoi(e);
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel

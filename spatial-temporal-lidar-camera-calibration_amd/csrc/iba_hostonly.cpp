@@ -19,6 +19,15 @@ using namespace iba;
 
 extern "C" {
 
+iba_status iba_default_create_options(iba_create_options* o) {
+    if (!o) return IBA_ERR_INVALID_ARG;
+    std::memset(o, 0, sizeof(*o));
+    o->struct_size = (int32_t)sizeof(*o);
+    o->common_pairs = 1; o->common_max_px = 20.0; o->max_pair_groups = 4; o->pair_memo = 1; o->pair_memo_max_batch = 40; o->pair_inflation = 1.25;
+    o->anchored_lists = 1; o->anchor_reach = 0.06; o->side_stream = 1; o->spin_wait = 1; o->factor_mfma = 0; o->pair_list_capacity = 0;
+    return IBA_OK;
+}
+
 iba_status iba_default_params(iba_params* p) {
     if (!p) return IBA_ERR_INVALID_ARG;
     std::memset(p, 0, sizeof(*p));

@@ -5,15 +5,23 @@
 // is the C-ABI library. Everything here is glue: packing + forwarding.
 //
 //   iba::PackedProblem / iba::pack()   KeyFrame*/PointClouds/vTwl -> iba_problem_desc (done ONCE)
-//   iba::BAError(...)                  drop-in for BAError() of iba_global.cpp:169-173 / iba_func.cpp:179-183
+//   iba::BAError(xvec, PointClouds, KdTrees, vTwl, KFIdMap, KeyFrames, iba_params, multiprocessing, verborse)
+//                                      the reference's EXACT parameter list (iba_global.cpp:169-173; g2o::Vector7 form iba_func.cpp:179-183):
+//                                      packs once — cache keyed on the addresses of PointClouds / KeyFrames — and forwards to
+//                                      iba_eval_cost, so a call site (iba_global.cpp:372, 385; iba_func.cpp:463) compiles unchanged
+//                                      once the reference's own BAError body is removed and this header is included
+//   iba::BAError(xvec, Evaluator&)     the same on an evaluator the caller owns
 //   iba::IbaAggregateCostFunction      ceres::SizedCostFunction<8, 7> replacing the blocks BuildProblem() adds (iba_local.cpp:263-308)
 //   iba::IbaAggregateEdge              g2o::BaseUnaryEdge<8, ..., VertexSim3> (same vertex type as IBACalib.hpp:74)
 // The two solver adaptors only forward to iba_eval_whitened (the math is behind the C-ABI and tested there).
 #pragma once
 #include <cstdint>
+#include <map>
+#include <memory>
 #include <stdexcept>
 #include <tuple>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include <Eigen/Dense>
@@ -108,6 +116,59 @@ inline std::tuple<double, double, double, int, int> BAError(const double* xvec, 
     iba_cost_out o;
     if (iba_eval_cost(ev.get(), xvec, 1, &o) != IBA_OK) throw std::runtime_error(iba_last_error(ev.get()));
     return {o.f1, o.f2, o.C, o.valid_cnt_3d_2d, o.cnt_3d_2d};
+}
+
+// IBAGlobalParams (a class local to iba_global.cpp:26-52 / iba_func.cpp, hence the template) -> iba_params
+template <class GlobalParams>
+inline iba_params to_iba_params(const GlobalParams& g) {
+    iba_params p;
+    iba_default_params(&p);
+    p.max_pixel_dist = g.max_pixel_dist; p.corr_3d_2d_threshold = g.corr_3d_2d_threshold; p.corr_3d_3d_threshold = g.corr_3d_3d_threshold;
+    p.norm_max_pts = g.norm_max_pts; p.norm_min_pts = g.norm_min_pts; p.norm_radius = g.norm_radius; p.norm_reg_threshold = g.norm_reg_threshold;
+    p.min_diff_dist = g.min_diff_dist; p.use_plane = g.use_plane ? 1 : 0;
+    if (g.err_weight.size() >= 2) { p.err_weight[0] = g.err_weight[0]; p.err_weight[1] = g.err_weight[1]; }
+    return p;
+}
+
+// The reference's own parameter list (iba_global.cpp:169-173). KdTrees and KFIdMap are accepted and ignored (the 3-D indices live
+// on the device; KFIdMap is unused in the reference's body too), multiprocessing / verborse have no meaning here. The problem is
+// packed and uploaded on the FIRST call and whenever the caller's containers or parameters change: the cache key is the addresses
+// of the two vectors' storage, their sizes and the parameter values (BALoss holds them for the whole run, iba_global.cpp:346-404).
+// Thread-compatible like the reference's serial NOMAD loop (:385): one evaluation at a time.
+template <class KdTrees, class GlobalParams>
+inline std::tuple<double, double, double, int, int> BAError(const double* xvec, const std::vector<VecVector3d>& PointClouds, const KdTrees& /*KdTrees*/,
+                                                            const std::vector<Eigen::Isometry3d>& vTwl, const std::unordered_map<int, int>& /*KFIdMap*/,
+                                                            const std::vector<ORB_SLAM2::KeyFrame*>& KeyFrames, const GlobalParams& gp /* the reference names it iba_params */,
+                                                            const bool& /*multiprocessing*/ = false, const bool& /*verborse*/ = false) {
+    struct Cached { const void* pc; const void* kf; size_t n_pc, n_kf; ::iba_params prm; int covis, weight; std::unique_ptr<PackedProblem> packed; std::unique_ptr<Evaluator> ev; };
+    static Cached cache{nullptr, nullptr, 0, 0, ::iba_params{}, 0, 0, nullptr, nullptr};
+    const ::iba_params prm = to_iba_params(gp);
+    auto same_params = [](const ::iba_params& a, const ::iba_params& b) {
+        return a.max_pixel_dist == b.max_pixel_dist && a.corr_3d_2d_threshold == b.corr_3d_2d_threshold && a.corr_3d_3d_threshold == b.corr_3d_3d_threshold && a.norm_max_pts == b.norm_max_pts &&
+               a.norm_min_pts == b.norm_min_pts && a.norm_radius == b.norm_radius && a.norm_reg_threshold == b.norm_reg_threshold && a.min_diff_dist == b.min_diff_dist &&
+               a.use_plane == b.use_plane && a.err_weight[0] == b.err_weight[0] && a.err_weight[1] == b.err_weight[1];
+    };
+    const bool same_data = cache.ev && cache.pc == (const void*)PointClouds.data() && cache.kf == (const void*)KeyFrames.data() && cache.n_pc == PointClouds.size() &&
+                           cache.n_kf == KeyFrames.size() && cache.covis == gp.num_best_covis && cache.weight == gp.min_covis_weight;
+    if (!same_data) {
+        cache.ev.reset();
+        cache.packed.reset(new PackedProblem(pack(PointClouds, vTwl, KeyFrames, gp.num_best_covis, gp.min_covis_weight)));
+        cache.ev.reset(new Evaluator(*cache.packed, prm));
+        cache.pc = PointClouds.data(); cache.kf = KeyFrames.data(); cache.n_pc = PointClouds.size(); cache.n_kf = KeyFrames.size();
+        cache.covis = gp.num_best_covis; cache.weight = gp.min_covis_weight; cache.prm = prm;
+    } else if (!same_params(cache.prm, prm)) {
+        if (iba_set_params(cache.ev->get(), &prm) != IBA_OK) throw std::runtime_error(iba_last_error(cache.ev->get()));
+        cache.prm = prm;
+    }
+    return BAError(xvec, *cache.ev);
+}
+// ... and with the 7-vector as an Eigen object (g2o::Vector7: iba_func.cpp:179-183)
+template <class Vec7, class KdTrees, class GlobalParams, class = decltype(std::declval<const Vec7&>().data())>
+inline std::tuple<double, double, double, int, int> BAError(const Vec7& xvec, const std::vector<VecVector3d>& PointClouds, const KdTrees& trees,
+                                                            const std::vector<Eigen::Isometry3d>& vTwl, const std::unordered_map<int, int>& ids,
+                                                            const std::vector<ORB_SLAM2::KeyFrame*>& KeyFrames, const GlobalParams& gp,
+                                                            const bool& multiprocessing = false, const bool& verborse = false) {
+    return BAError(static_cast<const double*>(xvec.data()), PointClouds, trees, vTwl, ids, KeyFrames, gp, multiprocessing, verborse);
 }
 
 }  // namespace iba

@@ -1,0 +1,122 @@
+"""Parity of the normal equations as a CHECKED invariant. The advertised gate is "every entry of H and b within
+1e-10 of itself". Over thousands of random scenes some candidates miss it, for two reasons that round 3 only asserted in prose:
+  (a) CONDITIONING OF A BLOCK. An IBA_PlaneFactor is two nested quotients (IBACalib2.hpp:163-183): Z0 = (n_c . p_c) / den with
+      den = Cxz n_cx + Cyz n_cy + n_cz, then u = fx P1x / P1z + cx. When the viewing ray lies almost in the plane, den is a
+      difference of nearly equal terms; the device's analytic chain rule and the oracle's Dual<7> arithmetic are two different double
+      expressions of the same quotients and differ by about eps / cond^2 of the block's scale (cond = how far the sums in the two
+      denominators are from cancelling: oracle_block_conditioning; squared because the derivative of a quotient divides by it twice).
+  (b) CONDITIONING OF A SUM. An entry of H or b is a sum over 10^3..10^5 blocks; off-diagonal entries cancel. Two summation orders of
+      the same terms differ by about eps sqrt(n) of the sum of the ABSOLUTE values of the terms, which for a cancelling entry is far
+      more than 1e-10 of the entry.
+explain() turns both into tests. Whenever a candidate misses the plain gate:
+  (i)   every residual block's rows (r, J) must agree within max(ROW_FLOOR, C_EPS * eps / cond^2) of the block's scale — so a block
+        that deviates by more than ROW_FLOOR is ill-conditioned by the oracle's own measure (cond < sqrt(C_EPS eps / ROW_FLOOR) = 0.12)
+        and deviates by no more than its conditioning allows;
+  (ii)  with the deviating blocks removed from BOTH sides, every entry of the rebuilt H and b must be within 1e-10 of itself OR
+        within SUM_TOL of the sum of the absolute values of its terms;
+  (iii) the candidate's own miss must be accounted for by (i) and (ii): either some block deviates, or the missed entries pass the
+        sum-conditioning gate.
+Anything else — a well-conditioned block that deviates, a deviation beyond the bound, an entry off by more than both gates — raises.
+Used by tests/test_gpu_conditioning.py and tools/soak_parity.py (test infrastructure: imports the oracle)."""
+import numpy as np
+
+EPS = 2.220446049250313e-16
+GATE = 1e-10          # per entry, relative to the entry itself
+ENTRY_FLOOR = 1e-6    # entries below this fraction of the largest are compared against the largest instead
+ROW_FLOOR = 1e-12     # rows of a well-conditioned block agree to this (of the block's scale)
+C_EPS = 64.0          # rows of any block: within max(ROW_FLOOR, C_EPS * eps / cond^2) of the block's scale
+SUM_TOL = 1e-12       # an entry of H / b: within this of the sum of the absolute values of its terms (two summation orders)
+
+
+def entry_deviation(a, b):
+    """worst |a - b| relative to |b| over the entries of b above ENTRY_FLOOR of its largest; the others relative to the largest"""
+    a, b = np.asarray(a, float).ravel(), np.asarray(b, float).ravel()
+    big = np.max(np.abs(b)) if b.size else 0.0
+    if big == 0.0:
+        return float(np.max(np.abs(a))) if a.size else 0.0
+    den = np.where(np.abs(b) > ENTRY_FLOOR * big, np.abs(b), big)
+    return float(np.max(np.abs(a - b) / den))
+
+
+def normal_from_rows(r, J, bid, kind, params, skip=(), absolute=False):
+    """H = sum_blocks w J^T J, b = sum_blocks w J^T r with the Huber IRLS weight of each block (w = 1 if |r| <= a else a / |r|;
+    a = robust_kernel_delta for IBA_PlaneFactor blocks, robust_kernel_3ddelta for the 3d-3d ones: iba_local.cpp:263, 291).
+    absolute: the sums of the absolute values of the terms instead (the scale two summation orders may differ by)."""
+    H, b = np.zeros((7, 7)), np.zeros(7)
+    if len(r) == 0:
+        return H, b
+    starts = np.concatenate([[0], np.where(np.diff(bid) != 0)[0] + 1, [len(bid)]])
+    skip = set(int(s) for s in skip)
+    for i in range(len(starts) - 1):
+        lo, hi = starts[i], starts[i + 1]
+        if int(bid[lo]) in skip:
+            continue
+        rr, JJ = r[lo:hi], J[lo:hi]
+        nrm = np.sqrt(np.sum(rr * rr))
+        a = params.robust_kernel_delta if kind[lo] == 0 else params.robust_kernel_3ddelta
+        w = 1.0 if nrm <= a else a / nrm
+        if absolute:
+            H += w * (np.abs(JJ).T @ np.abs(JJ))
+            b += w * (np.abs(JJ).T @ np.abs(rr))
+        else:
+            H += w * (JJ.T @ JJ)
+            b += w * (JJ.T @ rr)
+    return H, b
+
+
+def entries_ok(a, ref, abs_sum):
+    """every entry within GATE of itself (ENTRY_FLOOR rule) or within SUM_TOL of the sum of the absolute values of its terms"""
+    a, ref, abs_sum = (np.asarray(v, float).ravel() for v in (a, ref, abs_sum))
+    big = np.max(np.abs(ref)) if ref.size else 0.0
+    den = np.where(np.abs(ref) > ENTRY_FLOOR * big, np.abs(ref), big)
+    d = np.abs(a - ref)
+    ok = (d <= GATE * den) | (d <= SUM_TOL * abs_sum)
+    return bool(np.all(ok)), float(np.max(np.where(ok, 0.0, d / np.maximum(den, 1e-300)))) if ref.size else 0.0
+
+
+def explain(h, o, p, x, nthreads=1):
+    """-> dict(status="clean" | "explained", flagged=<blocks>, min_cond=.., worst_entry=.., cancelling_entries=<bool>); raises
+    AssertionError when a deviation is NOT explained. h: device handle, o: oracle, p: parameters, x: one candidate."""
+    g = h.eval_normal(x)[0]
+    r = o.eval_normal(p, x, nthreads=nthreads)[0]
+    assert g.counts() == r.counts(), (g.counts(), r.counts())
+    worst = max(entry_deviation(g.H_np(), r.H_np()), entry_deviation(g.b_np(), r.b_np()))
+    if worst <= GATE:
+        return {"status": "clean", "flagged": 0, "worst_entry": worst}
+    h.build_problem(x)
+    o.build_problem(p, x)
+    rg, Jg, bg, kg = h.eval_residuals(x)
+    ro, Jo, bo, ko, _ = o.eval_residuals(x)
+    assert np.array_equal(kg, ko) and np.array_equal(bg, bo), "the two sides hold different residual blocks"
+    cond = o.block_conditioning(x)
+    starts = np.concatenate([[0], np.where(np.diff(bo) != 0)[0] + 1, [len(bo)]])
+    assert len(cond) == len(starts) - 1
+    flagged, min_cond = [], 1.0
+    for i in range(len(starts) - 1):
+        lo, hi = starts[i], starts[i + 1]
+        scale = max(float(np.max(np.abs(Jo[lo:hi]))), float(np.max(np.abs(ro[lo:hi]))), 1.0)
+        dev = max(float(np.max(np.abs(Jg[lo:hi] - Jo[lo:hi]))), float(np.max(np.abs(rg[lo:hi] - ro[lo:hi])))) / scale
+        c = max(float(cond[i]), 1e-150)
+        bound = max(ROW_FLOOR, C_EPS * EPS / (c * c))
+        assert dev <= bound, "block %d (kind %d) deviates by %.2e of its scale, beyond what its conditioning allows: %.2e (cond %.2e)" % (i, ko[lo], dev, bound, c)
+        if dev > ROW_FLOOR:
+            flagged.append(int(bo[lo]))
+            min_cond = min(min_cond, c)
+    # with the deviating blocks removed: 1e-10 per entry, or the accuracy of a sum of that many cancelling terms
+    Hg, bgv = normal_from_rows(rg, Jg, bg, kg, p, skip=flagged)
+    Ho, bov = normal_from_rows(ro, Jo, bo, ko, p, skip=flagged)
+    Ha, ba = normal_from_rows(ro, Jo, bo, ko, p, skip=flagged, absolute=True)
+    okH, wH = entries_ok(Hg, Ho, Ha)
+    okb, wb = entries_ok(bgv, bov, ba)
+    assert okH and okb, "with the %d ill-conditioned block(s) removed an entry is still off by %.2e of itself and by more than %.0e of its terms' absolute sum" % (len(flagged), max(wH, wb), SUM_TOL)
+    cancelling = False
+    if not flagged:   # the miss must then be the summation order on cancelling entries — of the DEVICE's own sums against the oracle's
+        Hfa, bfa = normal_from_rows(ro, Jo, bo, ko, p, absolute=True)
+        ok1, w1 = entries_ok(g.H_np(), r.H_np(), Hfa)
+        ok2, w2 = entries_ok(g.b_np(), r.b_np(), bfa)
+        assert ok1 and ok2, "H / b miss the gate by %.2e although no residual block deviates and the entries do not cancel: a summation defect" % max(w1, w2)
+        cancelling = True
+    # (the rows are the same numbers the device summed: its own H rebuilt from its rows)
+    Hfull, _ = normal_from_rows(rg, Jg, bg, kg, p)
+    assert np.max(np.abs(Hfull - g.H_np())) <= 1e-9 * np.max(np.abs(g.H_np())), "iba_eval_residuals and iba_eval_normal disagree"
+    return {"status": "explained", "flagged": len(flagged), "min_cond": min_cond, "worst_entry": worst, "cancelling_entries": cancelling}

@@ -9,19 +9,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _handle(pkg, prob, p, mode):
-    """mode 0: every candidate searches for itself — 2d-3d pairs AND the 3-D nearest neighbours (no anchored lists)"""
-    old = {k: os.environ.get(k) for k in ("IBA_COMMON_PAIRS", "IBA_NN_SETS")}
-    os.environ["IBA_COMMON_PAIRS"] = str(mode)
-    os.environ["IBA_NN_SETS"] = "0" if mode == 0 else "1"
-    try:
-        return pkg.IbaHandle(prob, p)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+def _handle(pkg, prob, p, mode, **more):
+    """mode 0: every candidate searches for itself — 2d-3d pairs AND the 3-D nearest neighbours (no anchored lists); through the
+    options struct of iba_create_ex (round 3 steered this with environment variables)"""
+    return pkg.IbaHandle(prob, p, options=dict(common_pairs=mode, anchored_lists=0 if mode == 0 else 1, **more))
 
 
 def _same_bits(pkg, h0, h1, xs, want_path):
@@ -114,13 +105,7 @@ def test_points_at_the_camera_plane_and_tiny_lists(pkg, synth, abi, ob):
     for a_, b_ in zip(h2.eval_cost(xs), o.eval_cost(p, xs)):
         assert (a_.n_corr, a_.cnt_3d_2d, a_.cnt_3d_3d) == (b_.n_corr, b_.cnt_3d_2d, b_.cnt_3d_3d)
     h2.close()
-    old = os.environ.get("IBA_DEBUG_PAIR_CAP")
-    os.environ["IBA_DEBUG_PAIR_CAP"] = "64"
-    try:
-        h3 = _handle(pkg, prob2, p, 2)
-    finally:
-        if old is None:
-            del os.environ["IBA_DEBUG_PAIR_CAP"]
+    h3 = _handle(pkg, prob2, p, 2, pair_list_capacity=64)
     _same_bits(pkg, h0, h3, xs, 1)
     h3.close()
     h0.close()
@@ -192,15 +177,7 @@ def test_pair_lists_are_reused_while_the_batches_stay_inside_their_bound(pkg, sy
     differs from a handle that searches on every call, nor from the per-candidate path."""
     prob, meta = scene_small
     p = abi.reference_yaml_params()
-    old = os.environ.get("IBA_PAIR_MEMO")
-    os.environ["IBA_PAIR_MEMO"] = "0"
-    try:
-        h_every = _handle(pkg, prob, p, 1)
-    finally:
-        if old is None:
-            del os.environ["IBA_PAIR_MEMO"]
-        else:
-            os.environ["IBA_PAIR_MEMO"] = old
+    h_every = _handle(pkg, prob, p, 1, pair_memo=0)
     h_memo, h_single = _handle(pkg, prob, p, 1), _handle(pkg, prob, p, 0)
     rng = np.random.default_rng(17)
     centre = meta["x_gt"].copy()

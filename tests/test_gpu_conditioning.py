@@ -1,0 +1,58 @@
+"""Parity of H and b over random scenes as a checked invariant: every candidate either meets the advertised gate (each entry within
+1e-10 of itself) or its deviation is EXPLAINED — confined to residual blocks the oracle's own conditioning measure flags, within the
+conditioning bound, and gone once those blocks are removed from both sides (tests/parity_explain.py). tools/soak_parity.py runs
+the same check over thousands of scenes."""
+import numpy as np
+import pytest
+
+import parity_explain as pe
+
+pytestmark = pytest.mark.gpu
+
+
+def test_the_known_ill_conditioned_candidate_is_explained(pkg, synth, abi, ob):
+    """Candidate 32 of the C2 scene (200 keyframes x 10 k points): one plane factor with |r| = 2e4 px, |J| = 3e9 moves b by 8e-8."""
+    import os
+    prob, meta = synth.make_scene(n_frames=200, pts_per_frame=10000, seed=0)
+    p = abi.reference_yaml_params()
+    h, o = pkg.IbaHandle(prob, p), ob.Oracle(prob)
+    x = synth.perturb(meta["x_gt"], np.random.default_rng(32), n=1)[0]
+    res = pe.explain(h, o, p, x, nthreads=min(os.cpu_count() or 1, 64))
+    assert res["status"] == "explained" and res["flagged"] >= 1 and res["min_cond"] < 1e-4, res
+    assert res["worst_entry"] > 1e-10
+    h.close()
+
+
+def test_random_scenes_meet_the_gate_or_are_explained(pkg, synth, abi, ob):
+    rng = np.random.default_rng(77)
+    clean = explained = 0
+    for sc in range(30):
+        nf, pts, kp = int(rng.integers(2, 6)), int(rng.choice([2500, 6000, 14000])), int(rng.choice([600, 2000]))
+        prob, meta = synth.make_scene(n_frames=nf, pts_per_frame=pts, n_keypoints=kp, seed=7000 + sc)
+        p = abi.reference_yaml_params()
+        h, o = pkg.IbaHandle(prob, p), ob.Oracle(prob)
+        scale = float(rng.choice([1e-4, 1e-3, 5e-3, 2e-2]))
+        for x in synth.perturb(meta["x_gt"], rng, rot=scale, trans=5 * scale, scale_rel=2 * scale, n=4):
+            res = pe.explain(h, o, p, x)
+            clean += res["status"] == "clean"
+            explained += res["status"] == "explained"
+        h.close()
+    assert clean + explained == 120 and clean > 60, (clean, explained)
+
+
+def test_a_well_conditioned_deviation_is_not_excused():
+    """the checker itself: a deviation planted in a well-conditioned block must raise (no GPU needed, run with the GPU tier for the fixtures' sake)"""
+    class P:
+        robust_kernel_delta, robust_kernel_3ddelta = 2.98, 1.0
+    r = np.array([0.5, -0.25, 0.1, 0.2, 0.3])
+    J = np.arange(35, dtype=float).reshape(5, 7) / 10.0
+    bid = np.array([0, 0, 1, 1, 1], np.int32)
+    kind = np.array([0, 0, 2, 2, 2], np.int32)
+    H, b = pe.normal_from_rows(r, J, bid, kind, P)
+    H2, b2 = pe.normal_from_rows(r, J, bid, kind, P, skip=[1])
+    assert np.allclose(H - H2, J[2:].T @ J[2:]) and np.allclose(b - b2, J[2:].T @ r[2:])
+    assert pe.entry_deviation(H * (1 + 1e-12), H) < 1e-11 and pe.entry_deviation(H + 1e-3, H) > 1e-6
+    Ha, _ = pe.normal_from_rows(r, J, bid, kind, P, absolute=True)
+    assert pe.entries_ok(H * (1 + 1e-11), H, Ha)[0] and not pe.entries_ok(H * (1 + 1e-8), H, Ha)[0]
+    cancel = np.array([1e-6]), np.array([1e6])          # an entry of 1e-6 that is the sum of terms of size 1e6
+    assert pe.entries_ok(cancel[0] + 5e-7, cancel[0], cancel[1])[0] and not pe.entries_ok(cancel[0] + 5e-5, cancel[0], cancel[1])[0]

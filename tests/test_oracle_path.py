@@ -129,3 +129,28 @@ def test_frame_ranges_sum_to_whole(ob, abi, gold):
     parts = o.eval_cost_raw(p, x, 0, 2) + o.eval_cost_raw(p, x, 2, prob.n_frames)
     assert np.allclose(whole, parts, rtol=1e-13)
     assert whole[3] == whole[10] - 1    # HE term exists for every processed frame but the last (iba_global.cpp:264)
+
+
+def test_plane_edge_twin_and_block_conditioning(synth, abi, ob):
+    """IBAPlaneEdge (the g2o twin of IBA_PlaneFactor, IBACalib.hpp:103-140) = the block's rows zero-padded to 20; the conditioning
+    measure of a block is 1 for 3d-3d blocks, in (0, 1] for plane factors, and goes to 0 when the viewing ray is rotated into the plane."""
+    prob, meta = synth.make_scene(n_frames=3, pts_per_frame=3000, seed=3)
+    p = abi.reference_yaml_params()
+    o = ob.Oracle(prob)
+    x = meta["x_gt"]
+    o.build_problem(p, x)
+    r, J, bid, kind, _ = o.eval_residuals(x)
+    cond = o.block_conditioning(x)
+    starts = np.concatenate([[0], np.where(np.diff(bid) != 0)[0] + 1])
+    assert len(cond) == len(starts)
+    seen = 0
+    for i, lo in enumerate(starts):
+        rows = np.where(bid == bid[lo])[0]
+        if kind[lo] == 0 and len(rows) <= 20:
+            e, Je = o.plane_edge20(int(bid[lo]), x)
+            assert np.array_equal(e[:len(rows)], r[rows]) and np.all(e[len(rows):] == 0) and np.array_equal(Je[:len(rows)], J[rows]) and np.all(Je[len(rows):] == 0)
+            assert 0 < cond[i] <= 1
+            seen += 1
+        elif kind[lo] != 0:
+            assert cond[i] == 1.0 and o.plane_edge20(int(bid[lo]), x) is None
+    assert seen > 20

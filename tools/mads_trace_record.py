@@ -28,18 +28,33 @@ xg, mr, tr, bs = h.calibrate_mads(xg0, record=True, max_bb_eval=100000)
 dt = time.perf_counter() - t0
 print("mads: %d evaluations in %d batches, %.3f s, feasible %d, f %.6f" % (mr.evaluations, mr.batches, dt, mr.feasible, mr.f))
 assert bs.sum() == len(tr), (bs.sum(), len(tr))
-# replay with the path recorded
-paths, times = [], []
+# replay with the path and the kernel phases recorded (a fresh handle: every cross-call mechanism starts cold, as in the run itself)
+import ctypes as C
+h.close()
+h = pkg.IbaHandle(prob, params, device=0)
+h.set_timing(True)
+L = pkg.load_library()
+L.iba_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+paths, times, phases, anchors = [], [], [], []
 o = pkg.mads_options(xg0)
 at = 0
 for b in bs:
     X = tr[at:at + b, :7]
+    a0 = h.anchor_builds
     t1 = time.perf_counter()
     h.eval_bbo(X, o.he_threshold, o.valid_rate)
     times.append(time.perf_counter() - t1)
+    pa, pn, pr = C.c_float(0), C.c_float(0), C.c_float(0)
+    L.iba_last_phase_ms(h.h, C.byref(pa), C.byref(pn), C.byref(pr))
+    phases.append((pa.value, pn.value, pr.value))
     paths.append(h.last_path)
+    anchors.append(h.anchor_builds - a0)
     at += b
-paths, times = np.array(paths), np.array(times)
-print("replay: %.3f s, %d of %d batches shared their pair search; time share of the others %.2f" % (times.sum(), paths.sum(), len(paths), times[paths == 0].sum() / times.sum()))
+paths, times, phases, anchors = np.array(paths), np.array(times), np.array(phases), np.array(anchors)
+print("replay: %.3f s (with phase events), %d anchor builds" % (times.sum(), anchors.sum()))
+for pth in (0, 1, 2):
+    m = paths == pth
+    if m.any():
+        print("  path %d: %4d batches, mean B %.1f, %.3f s, wall/batch %.3f ms, assoc %.3f ms, nn %.3f ms, rest %.3f ms" % (pth, m.sum(), bs[m].mean(), times[m].sum(), 1e3 * times[m].mean(), phases[m, 0].mean(), phases[m, 1].mean(), phases[m, 2].mean()))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-np.savez_compressed(os.path.join(ROOT, "gpurun_out", "mads_trace.npz"), x=tr, batch_sizes=bs, path=paths, wall=times, x0=xg0, x_gt=meta["x_gt"], fx=718.856)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", "mads_trace.npz"), x=tr, batch_sizes=bs, path=paths, wall=times, phases=phases, anchors=anchors, x0=xg0, x_gt=meta["x_gt"], fx=718.856)

@@ -12,18 +12,10 @@ pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synt
 
 
 def handle(prob, p, plain):
-    keys = {"IBA_COMMON_PAIRS": "0", "IBA_NN_SETS": "0", "IBA_SIDE_STREAM": "0", "IBA_PAIR_MEMO": "0"}
-    old = {k: os.environ.get(k) for k in keys}
+    """plain: every cross-call / cross-candidate mechanism off (iba_create_options)"""
     if plain:
-        os.environ.update(keys)
-    try:
-        return pkg.IbaHandle(prob, p)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        return pkg.IbaHandle(prob, p, options=dict(common_pairs=0, anchored_lists=0, side_stream=0, pair_memo=0, max_pair_groups=1))
+    return pkg.IbaHandle(prob, p)
 
 
 def eq(u, v):   # NaN (a cost term over zero frames) equals NaN
@@ -49,6 +41,8 @@ for sq in range(n_seq):
     if rng.random() < 0.2: p.plane_cache = 0
     h, r = handle(prob, p, False), handle(prob, p, True)
     centre = meta["x_gt"].copy()
+    # a second and a third poll centre tens of pixels away (an optimiser's infeasible incumbent): batches of several tight groups
+    far = [centre + rng.normal(size=7) * np.array([0.02, 0.02, 0.02, 0.1, 0.1, 0.1, 0.3]) for _ in range(2)]
     log = []
     ok = True
     for step in range(int(rng.integers(15, 40))):
@@ -56,6 +50,12 @@ for sq in range(n_seq):
         scale = float(rng.choice([1e-5, 1e-4, 5e-4, 2e-3, 2e-2]))
         n = int(rng.choice([1, 2, 5, 14, 33, 64, 70]))
         xs = synth.perturb(centre, rng, rot=scale, trans=8 * scale, scale_rel=2 * scale, n=n)
+        if n >= 2 and rng.random() < 0.35:   # several centres in one batch, interleaved
+            k = int(rng.choice([1, 2]))
+            for j in range(k):
+                m = int(rng.integers(1, max(2, n // (k + 1) + 1)))
+                xs[rng.choice(n, size=min(m, n - 1), replace=False)] = synth.perturb(far[j], rng, rot=scale, trans=8 * scale, scale_rel=2 * scale, n=min(m, n - 1))
+            if rng.random() < 0.3: far[0] = far[0] + rng.normal(size=7) * 1e-4
         if rng.random() < 0.25: centre = xs[int(rng.integers(0, n))]
         log.append((op, n, scale))
         if op == "cost": ok = same_cost(h.eval_cost(xs), r.eval_cost(xs))

@@ -1,10 +1,11 @@
 """Randomised parity soak (GPU box): many seeded scenes of random shape and random candidates, GPU path vs the CPU oracle.
-Counters must be equal, cost floats (f1, f2, C) within 1e-10; H (normal equations) within 1e-6 of its largest entry — the fixed scenes of
-tests/ hold 1e-9, but over thousands of random scenes a near-degenerate plane block (viewing ray almost in the plane: Z0 =
-num / den with a tiny den) amplifies the last-bit differences between the kernel's chain rule and the oracle's dual numbers;
-the worst case seen is printed (7e-8 in 7000 scenes at the reference's parameters, identical with and without FMA contraction;
-5e-7 in 2000 scenes with randomised parameters, in frozen-problem evaluations far from the point the problem was built at). Not part of the test
-suite (minutes).
+Counters must be equal, cost floats (f1, f2, C) within 1e-10. H and b: every entry within 1e-10 of itself (entries below 1e-6 of the
+largest: of the largest) — OR the candidate's deviation must be EXPLAINED (tests/parity_explain.py, round 4): confined to residual
+blocks that the oracle's conditioning measure flags (a plane factor whose viewing ray lies almost in its plane: Z0 = num / den with a
+cancelling den), within eps / cond^2 of the block's scale, and gone when those blocks are removed from both sides (the remaining
+entries within 1e-10 of themselves or within 1e-12 of the sum of the absolute values of their terms: cancelling off-diagonal sums). A deviation that is
+not explained fails the scene. The summary line says how many candidates were above the gate and how many blocks explained them.
+Not part of the test suite (minutes); tests/test_gpu_conditioning.py runs the same check on 30 scenes.
 usage: python tools/soak_parity.py [n_scenes] [first_seed]"""
 import importlib, os, sys, time
 import numpy as np
@@ -14,6 +15,8 @@ pkg = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd")
 synth = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.synth")
 abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi")
 from oracle import binding as ob
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import parity_explain as pe
 ob.lib()
 def random_params(rng):
     p = abi.reference_yaml_params()
@@ -36,6 +39,8 @@ n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 INT = ("valid_cnt_3d_2d", "cnt_3d_2d", "cnt_3d_3d", "valid_cnt_3d_3d", "valid_pl_3d_3d", "valid_pt_3d_3d", "frames_used", "n_corr")
 bad = 0
+above_gate = explained_blocks = cancelling = 0   # candidates whose H / b missed the 1e-10 gate; ill-conditioned blocks that explained them
+worst_cond = 1.0
 worst_h = 0.0
 worst_entry = 0.0   # per-entry relative deviation over the entries above 1e-6 of the largest
 worst_c = 0.0       # hand-eye term C: device acos / tan through a cancelling log difference vs glibc
@@ -77,9 +82,16 @@ for sc in range(n_scenes):
         if np.max(np.abs(Ho)) > 0:
             dev = float(np.max(np.abs(nfm[b].H_np() - Ho)) / np.max(np.abs(Ho)))
             worst_h = max(worst_h, dev)
-            if dev > 1e-6: msgs.append((b, "H", dev))
-            m = np.abs(Ho) > 1e-6 * np.max(np.abs(Ho))
-            worst_entry = max(worst_entry, float(np.max(np.abs(nfm[b].H_np() - Ho)[m] / np.abs(Ho)[m])))
+            e_dev = max(pe.entry_deviation(nfm[b].H_np(), Ho), pe.entry_deviation(nfm[b].b_np(), on[b].b_np()))
+            worst_entry = max(worst_entry, e_dev)
+            if e_dev > pe.GATE:   # above the advertised gate: it must be conditioning, and only conditioning
+                above_gate += 1
+                try:
+                    res = pe.explain(h, o, p, xs[b])
+                    if res["status"] == "explained":
+                        explained_blocks += res["flagged"]; worst_cond = min(worst_cond, res["min_cond"]); cancelling += bool(res["cancelling_entries"])
+                except AssertionError as ex:
+                    msgs.append((b, "H/b not explained", e_dev, str(ex)[:200]))
     # the candidates drift a little between calls (the anchored neighbour lists of the first call serve the next ones)
     xs_d = xs + rng.normal(size=xs.shape) * np.array([1, 1, 1, 5, 5, 5, 2]) * scale * float(rng.choice([0.05, 0.3, 1.0]))
     for b, (g, r) in enumerate(zip(h.eval_cost(xs_d), o.eval_cost(p, xs_d))):
@@ -96,7 +108,7 @@ for sc in range(n_scenes):
         if np.max(np.abs(Ho)) > 0:
             dev = float(np.max(np.abs(gf.H_np() - Ho)) / np.max(np.abs(Ho)))
             worst_h = max(worst_h, dev)
-            if dev > 1e-6: msgs.append((b, "frozen H", dev))
+            if dev > 1e-6: msgs.append((b, "frozen H", dev))   # (the frozen problem far from its linearisation point: blocks the re-association would have dropped; row-level check in tests)
     fsel = int(rng.integers(0, nf))
     gk, gp = h.correspondences(xs[0], fsel); ok_, op_ = o.correspondences(p, xs[0], fsel)
     if not (np.array_equal(gk, ok_) and np.array_equal(gp, op_)): msgs.append(("corr", fsel, len(gk), len(ok_)))
@@ -115,5 +127,6 @@ for sc in range(n_scenes):
     tag = "ok " if not msgs else "BAD"
     bad += bool(msgs)
     print(f"{tag} seed {seed}: F={nf} P={pts} K={kp} B={len(xs)} pert={scale:g} plane={p.use_plane} w1={p.err_weight[1]:g} cache={p.plane_cache} n_corr={[c.n_corr for c in oc][:3]}", msgs[:3], flush=True)
-print(f"{n_scenes - bad}/{n_scenes} scenes in parity, worst deviation of H relative to its largest entry {worst_h:.2e}, per entry (entries > 1e-6 of the largest, re-associated evaluations) {worst_entry:.2e}, worst relative deviation of C {worst_c:.2e}, {time.time() - t0:.0f} s")
+print(f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the 1e-10 per-entry gate, all explained: {explained_blocks} ill-conditioned block(s) (smallest conditioning measure {worst_cond:.1e}), {cancelling} candidate(s) by cancelling sums alone" if not bad else f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the gate, NOT all explained")
+print(f"worst deviation of H relative to its largest entry {worst_h:.2e}, per entry (re-associated evaluations) {worst_entry:.2e}, worst relative deviation of C {worst_c:.2e}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
