@@ -320,6 +320,14 @@ double iba_debug_mean_pairs(iba_handle* h);
  * searched together as the kernel does, the query as the first (3) or the second (4) with its partner 1e-7 beside it.
  * For parity tests of the search itself. */
 iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q_xyz, int32_t n, int32_t mode, uint32_t* out_idx, double* out_d2);
+/* debug: the memoised local plane (plane_cache = 1) at scan point `point` (ORIGINAL index) of owned frame `frame`: which = 0 the cost
+ * path's planes (norm_radius / norm_max_pts), 1 the association / Jacobian path's (neigh_radius / neigh_max_pts). With plane_cache = 0
+ * only which = 1 after iba_build_problem: the plane the frozen problem's residual blocks read (fitted where a block needed one; other
+ * points hold stale records). out5 = unit normal
+ * (3), sum of |(p_i - c) . n|, squared distance of the farthest kept neighbour; *k = kept neighbours. The parity tests substitute this
+ * normal into the oracle's residual block: the device fits planes with its own libm, and an ill-conditioned block amplifies the
+ * last-bit difference of the two normals (tests/parity_explain.py). */
+iba_status iba_debug_plane(iba_handle* h, int32_t frame, uint32_t point, int32_t which, double out5[5], int32_t* k);
 int64_t iba_num_points(const iba_handle* h);
 int64_t iba_num_keypoints(const iba_handle* h);
 

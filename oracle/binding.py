@@ -168,6 +168,63 @@ class Oracle:
             lib().oracle_block_conditioning(C.c_void_p(self.h), _p(x), _p(c), C.byref(n))
         return c[: n.value]
 
+    def block_forward_error(self, x):
+        """per residual block of the frozen problem, at x: the forward error of the oracle's own double evaluation, measured against
+        the same formulas in long double, relative to the block's scale (two correct double evaluations agree no better than this)"""
+        x = np.ascontiguousarray(x, np.float64)
+        n = C.c_int64(0)
+        lib().oracle_block_forward_error(C.c_void_p(self.h), _p(x), None, C.byref(n))
+        e = np.zeros(max(n.value, 1))
+        if n.value:
+            lib().oracle_block_forward_error(C.c_void_p(self.h), _p(x), _p(e), C.byref(n))
+        return e[: n.value]
+
+    def block_sensitivity(self, x):
+        """per residual block of the frozen problem, at x: how far its long-double rows move (relative to the block's scale) when x moves
+        by one unit in the last place — what two correct double evaluations that derive R, t, dR, dt from x on their own may differ by"""
+        x = np.ascontiguousarray(x, np.float64)
+        n = C.c_int64(0)
+        lib().oracle_block_sensitivity(C.c_void_p(self.h), _p(x), None, C.byref(n))
+        e = np.zeros(max(n.value, 1))
+        if n.value:
+            lib().oracle_block_sensitivity(C.c_void_p(self.h), _p(x), _p(e), C.byref(n))
+        return e[: n.value]
+
+    def block_input_sensitivity(self, x):
+        """per residual block (plane factors; 0 for the others): the largest relative change of its rows, in the device kernel's operation
+        order, when every derived input (R, t, dR, dt, n0) moves by one unit in the last place (8 random sign draws)"""
+        x = np.ascontiguousarray(x, np.float64)
+        n = C.c_int64(0)
+        lib().oracle_block_input_sensitivity(C.c_void_p(self.h), _p(x), None, C.byref(n))
+        e = np.zeros(max(n.value, 1))
+        if n.value:
+            lib().oracle_block_input_sensitivity(C.c_void_p(self.h), _p(x), _p(e), C.byref(n))
+        return e[: n.value]
+
+    def block_three_ways(self, block, x, rows, variant=0):
+        """(Dual<7> double, long double rounded, the device kernel's operation order in double) rows x 8 (r, J) of a plane-factor block; None for other kinds"""
+        x = np.ascontiguousarray(x, np.float64)
+        o0, o1, o2 = np.zeros((rows, 8)), np.zeros((rows, 8)), np.zeros((rows, 8))
+        if lib().oracle_block_three_ways(C.c_void_p(self.h), C.c_int64(block), _p(x), C.c_int(variant), _p(o0), _p(o1), _p(o2)) != 0:
+            return None
+        return o0, o1, o2
+
+    def block_normal(self, block):
+        """(plane normal, the scan point it was fitted at, frame) of a residual block of the frozen problem; None for a point-to-point block"""
+        n, q, f = np.zeros(3), np.zeros(3), C.c_int32(0)
+        if lib().oracle_block_normal(C.c_void_p(self.h), C.c_int64(block), _p(n), _p(q), C.byref(f)) != 0:
+            return None
+        return n, q, f.value
+
+    def block_rows_with_normal(self, block, x, normal, rows):
+        """(r, J, forward error) of one block of the frozen problem at x with `normal` in place of its own plane normal"""
+        x = np.ascontiguousarray(x, np.float64)
+        n = np.ascontiguousarray(normal, np.float64)
+        r, J, e = np.zeros(rows), np.zeros((rows, 7)), C.c_double(0)
+        st = lib().oracle_block_rows_with_normal(C.c_void_p(self.h), C.c_int64(block), _p(x), _p(n), _p(r), _p(J), C.byref(e))
+        assert st == 0
+        return r, J, e.value
+
     def plane_edge20(self, factor_index, x):
         """IBAPlaneEdge (the g2o twin of IBA_PlaneFactor, IBACalib.hpp:103-140): the block's residuals zero-padded to 20, J 20 x 7"""
         x = np.ascontiguousarray(x, np.float64)

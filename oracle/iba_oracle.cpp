@@ -619,6 +619,218 @@ int oracle_block_conditioning(void* h, const double* x, double* cond, int64_t* n
     }
     return 0;
 }
+// The FORWARD ERROR of this file's own double evaluation of every residual block of the frozen problem at x, measured against the
+// same formulas in long double (DualL<7>, 64-bit mantissa): max over the block's rows of |r, J (double) - r, J (long double)|
+// divided by the block's scale max(|J|, |r|, 1). Two correct double evaluations of a block (the device's analytic chain rule and the
+// Dual<7> arithmetic here) cannot be expected to agree better than a small multiple of this: the parity tests bound the device's
+// deviation by it (tests/parity_explain.py), instead of by a tolerance picked to make them pass.
+// The block's SENSITIVITY to its inputs' last bits: how far its long-double rows move, relative to the block's scale, when x is moved by
+// one unit in the last place per component (four sign patterns, the largest). The device derives R, t and their derivatives from x
+// with its own (Jet<6>) arithmetic, this file with Dual<7>: each is the exact result for an x a few ulps away, so two correct
+// evaluations of an ill-conditioned block may differ by a small multiple of this however accurate each of them is internally —
+// the forward error of ONE evaluation (above) is a single draw of the same quantity and can come out small by luck.
+static double block_sensitivity(const Factor& f, const double* x) {
+    using L7 = DualL<7>;
+    const int rows = f.rows();
+    std::vector<L7> e0(rows), e1(rows);
+    L7 xl[7]; for (int i = 0; i < 7; ++i) xl[i] = L7(x[i], i);
+    if (f.kind == 0) eval_plane_factor<L7>(f, xl, e0.data()); else eval_p2x_factor<L7>(f, xl, e0.data());
+    long double scale = 1.0L;
+    for (int i = 0; i < rows; ++i) { scale = std::max(scale, fabsl(e0[i].a)); for (int c = 0; c < 7; ++c) scale = std::max(scale, fabsl(e0[i].v[c])); }
+    long double worst = 0.0L;
+    for (int pat = 0; pat < 4; ++pat) {
+        for (int i = 0; i < 7; ++i) {
+            const int sgn = ((pat == 0) || (pat == 1 && (i & 1)) || (pat == 2 && (i % 3 == 0)) || (pat == 3 && i < 3)) ? 1 : -1;
+            xl[i] = L7(x[i], i); xl[i].a = (long double)x[i] * (1.0L + (long double)sgn * 0x1p-52L);
+        }
+        if (f.kind == 0) eval_plane_factor<L7>(f, xl, e1.data()); else eval_p2x_factor<L7>(f, xl, e1.data());
+        for (int i = 0; i < rows; ++i) {
+            worst = std::max(worst, fabsl(e1[i].a - e0[i].a));
+            for (int c = 0; c < 7; ++c) worst = std::max(worst, fabsl(e1[i].v[c] - e0[i].v[c]));
+        }
+    }
+    const long double sres = worst / scale;
+    return (sres == sres) ? (double)sres : 1.0;
+}
+int oracle_block_sensitivity(void* h, const double* x, double* sens, int64_t* n_blocks) {
+    Oracle& O = *(Oracle*)h;
+    *n_blocks = (int64_t)O.factors.size();
+    if (!sens) return 0;
+    int64_t at = 0;
+    for (auto const& f : O.factors) sens[at++] = block_sensitivity(f, x);
+    return 0;
+}
+int oracle_block_forward_error(void* h, const double* x, double* err, int64_t* n_blocks) {
+    Oracle& O = *(Oracle*)h;
+    *n_blocks = (int64_t)O.factors.size();
+    if (!err) return 0;
+    using D7 = Dual<7>; using L7 = DualL<7>;
+    D7 xd[7]; L7 xl[7];
+    for (int i = 0; i < 7; ++i) { xd[i] = D7(x[i], i); xl[i] = L7(x[i], i); }
+    int64_t at = 0;
+    for (auto const& f : O.factors) {
+        const int rows = f.rows();
+        std::vector<D7> ed(rows); std::vector<L7> el(rows);
+        if (f.kind == 0) { eval_plane_factor<D7>(f, xd, ed.data()); eval_plane_factor<L7>(f, xl, el.data()); }
+        else { eval_p2x_factor<D7>(f, xd, ed.data()); eval_p2x_factor<L7>(f, xl, el.data()); }
+        long double scale = 1.0L, dev = 0.0L;
+        for (int i = 0; i < rows; ++i) {
+            scale = std::max(scale, fabsl(el[i].a)); dev = std::max(dev, fabsl((long double)ed[i].a - el[i].a));
+            for (int c = 0; c < 7; ++c) { scale = std::max(scale, fabsl(el[i].v[c])); dev = std::max(dev, fabsl((long double)ed[i].v[c] - el[i].v[c])); }
+        }
+        const long double e = dev / scale;
+        err[at++] = (e == e) ? (double)e : 1.0;   // NaN (a degenerate block): "no accuracy at all"
+    }
+    return 0;
+}
+// The analytic chain rule of an IBA_PlaneFactor block in the device kernel's operation order (plane_factor_core, csrc/iba_kernels.hpp),
+// in double, from explicit inputs: R, t and their derivatives (dR[k] for k < 3, dt[k] for k < 6), the scale s, the plane normal n0.
+// variant: how the cancelling factor (ax - xz az) is formed: 0 as the kernel does, 1 from the exact identity (ax tz - az tx) / P1z.
+// out: rows x 8 doubles (r, J[7]).
+static void plane_block_kernel_order(const Factor& f, const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], double s, const double* n0, int variant, double* out) {
+    const double p0[3] = {f.p0.x, f.p0.y, f.p0.z};
+    double p0c[3], n0c[3];
+    for (int r = 0; r < 3; ++r) { p0c[r] = ((R[r * 3] * p0[0] + R[r * 3 + 1] * p0[1]) + R[r * 3 + 2] * p0[2]) + t[r]; n0c[r] = (R[r * 3] * n0[0] + R[r * 3 + 1] * n0[1]) + R[r * 3 + 2] * n0[2]; }
+    const double Cxz = (f.u0 - f.cx) / f.fx, Cyz = (f.v0 - f.cy) / f.fy;
+    const double num = (n0c[0] * p0c[0] + n0c[1] * p0c[1]) + n0c[2] * p0c[2];
+    const double den = (Cxz * n0c[0] + Cyz * n0c[1]) + n0c[2];
+    const double Z0 = num / den, iden = 1.0 / den;
+    double z6[6];
+    for (int kk = 0; kk < 6; ++kk) {
+        double dpv[3], dnv[3] = {0, 0, 0};
+        for (int r = 0; r < 3; ++r) {
+            dpv[r] = dt[kk][r];
+            if (kk < 3) { dpv[r] += (dR[kk][r * 3] * p0[0] + dR[kk][r * 3 + 1] * p0[1]) + dR[kk][r * 3 + 2] * p0[2]; dnv[r] = (dR[kk][r * 3] * n0[0] + dR[kk][r * 3 + 1] * n0[1]) + dR[kk][r * 3 + 2] * n0[2]; }
+        }
+        const double dnum = ((dnv[0] * p0c[0] + dnv[1] * p0c[1]) + dnv[2] * p0c[2]) + ((n0c[0] * dpv[0] + n0c[1] * dpv[1]) + n0c[2] * dpv[2]);
+        const double dden = (Cxz * dnv[0] + Cyz * dnv[1]) + dnv[2];
+        z6[kk] = (dnum - Z0 * dden) * iden;
+    }
+    const double P0x = Cxz * Z0, P0y = Cyz * Z0, P0z = Z0;
+    for (size_t i = 0; i < f.u1.size(); ++i) {
+        const double* rel = f.R[i].m;
+        const double t3[3] = {f.t[i].x, f.t[i].y, f.t[i].z};
+        const double tx = t3[0] * s, ty = t3[1] * s, tz = t3[2] * s;
+        const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx, P1y = ((rel[3] * P0x + rel[4] * P0y) + rel[5] * P0z) + ty, P1z = ((rel[6] * P0x + rel[7] * P0y) + rel[8] * P0z) + tz;
+        const double ru = (f.fx * P1x / P1z + f.cx) - f.u1[i], rv = (f.fy * P1y / P1z + f.cy) - f.v1[i];
+        const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[3] * Cxz + rel[4] * Cyz) + rel[5], az = (rel[6] * Cxz + rel[7] * Cyz) + rel[8];
+        const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
+        double cu, cv;
+        if (variant == 0) { cu = ax - xz * az; cv = ay - yz * az; }
+        else { cu = (ax * tz - az * tx) * iz; cv = (ay * tz - az * ty) * iz; }   // P1 = Z0 a + s t  =>  ax - (P1x / P1z) az = (ax tz - az tx) / P1z exactly
+        const double gu = f.fx * iz * cu, gv = f.fy * iz * cv;
+        const double hu = f.fx * iz * (t3[0] - xz * t3[2]), hv = f.fy * iz * (t3[1] - yz * t3[2]);
+        double* o0 = out + 8 * (2 * i); double* o1 = out + 8 * (2 * i + 1);
+        o0[0] = ru; o1[0] = rv;
+        for (int k = 0; k < 6; ++k) { o0[1 + k] = gu * z6[k]; o1[1 + k] = gv * z6[k]; }
+        o0[7] = hu; o1[7] = hv;
+    }
+}
+struct CandInputs { double R[9], t[3], dR[6][9], dt[6][3]; };
+static CandInputs cand_inputs_of(const double* x) {   // R, t and their derivatives from the duals of Sim3Exp (the device's host math computes them with Jet<6>)
+    using D7 = Dual<7>;
+    D7 xd[7]; for (int i = 0; i < 7; ++i) xd[i] = D7(x[i], i);
+    M3<D7> Rd; V3<D7> td; D7 sd;
+    Sim3Exp<D7>(xd, Rd, td, sd);
+    CandInputs c;
+    for (int i = 0; i < 9; ++i) { c.R[i] = Rd.m[i].a; for (int k = 0; k < 6; ++k) c.dR[k][i] = Rd.m[i].v[k]; }
+    for (int i = 0; i < 3; ++i) { c.t[i] = td[i].a; for (int k = 0; k < 6; ++k) c.dt[k][i] = td[i].v[k]; }
+    return c;
+}
+// One IBA_PlaneFactor block of the frozen problem evaluated THREE ways at x (investigation tool for the parity tests): out[0] = the
+// Dual<7> arithmetic of this file (double), out[1] = the same in long double rounded to double, out[2] = the kernel's operation order
+// in double (plane_block_kernel_order). Each out[i] holds rows x 8 doubles: r, J[7].
+int oracle_block_three_ways(void* h, int64_t block, const double* x, int variant, double* out0, double* out1, double* out2) {
+    Oracle& O = *(Oracle*)h;
+    if (block < 0 || block >= (int64_t)O.factors.size() || O.factors[block].kind != 0) return 1;
+    const Factor& f = O.factors[block];
+    using D7 = Dual<7>; using L7 = DualL<7>;
+    D7 xd[7]; L7 xl[7];
+    for (int i = 0; i < 7; ++i) { xd[i] = D7(x[i], i); xl[i] = L7(x[i], i); }
+    const int rows = f.rows();
+    std::vector<D7> ed(rows); std::vector<L7> el(rows);
+    eval_plane_factor<D7>(f, xd, ed.data()); eval_plane_factor<L7>(f, xl, el.data());
+    for (int i = 0; i < rows; ++i) { out0[8 * i] = ed[i].a; out1[8 * i] = (double)el[i].a; for (int c = 0; c < 7; ++c) { out0[8 * i + 1 + c] = ed[i].v[c]; out1[8 * i + 1 + c] = (double)el[i].v[c]; } }
+    const CandInputs c = cand_inputs_of(x);
+    const double n0[3] = {f.n0.x, f.n0.y, f.n0.z};
+    plane_block_kernel_order(f, c.R, c.t, c.dR, c.dt, x[6], n0, variant, out2);
+    return 0;
+}
+// INPUT SENSITIVITY of a plane-factor block: the device and this file each derive R, t and their derivatives from x with their own
+// dual arithmetic (Jet<6> / Dual<7>: tools/device_vs_simulation.py finds the two bit-identical on some candidates and a last bit apart
+// on others) and each fit the plane with their own libm; both then run the SAME formulas (device == plane_block_kernel_order bit for
+// bit when the inputs are equal). How far apart two such evaluations may be is therefore a property of the block: the largest change
+// of its rows, relative to the block's scale, when every derived input (entries of R, t, dR, dt, n0) moves by one unit in the last
+// place, signs drawn at random, eight draws. A block whose viewing ray lies almost in its plane amplifies exactly these last bits.
+static double plane_block_input_sensitivity(const Factor& f, const double* x) {
+    if (f.kind != 0) return 0.0;
+    const int rows = f.rows();
+    const CandInputs c0 = cand_inputs_of(x);
+    const double n0[3] = {f.n0.x, f.n0.y, f.n0.z};
+    std::vector<double> base((size_t)rows * 8), pert((size_t)rows * 8);
+    plane_block_kernel_order(f, c0.R, c0.t, c0.dR, c0.dt, x[6], n0, 0, base.data());
+    double scale = 1.0;
+    for (double v : base) scale = std::max(scale, std::fabs(v));
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)rows;
+    auto flip = [&](double v) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return v * (1.0 + ((st >> 33) & 1ull ? 0x1p-52 : -0x1p-52)); };
+    double worst = 0.0;
+    for (int draw = 0; draw < 8; ++draw) {
+        CandInputs c = c0; double n[3];
+        for (double& v : c.R) v = flip(v);
+        for (double& v : c.t) v = flip(v);
+        for (int k = 0; k < 6; ++k) { for (double& v : c.dR[k]) v = flip(v); for (double& v : c.dt[k]) v = flip(v); }
+        for (int i = 0; i < 3; ++i) n[i] = flip(n0[i]);
+        plane_block_kernel_order(f, c.R, c.t, c.dR, c.dt, x[6], n, 0, pert.data());
+        for (size_t i = 0; i < base.size(); ++i) { const double d = std::fabs(pert[i] - base[i]); if (d > worst || d != d) worst = (d == d) ? d : scale; }
+    }
+    return worst / scale;
+}
+int oracle_block_input_sensitivity(void* h, const double* x, double* sens, int64_t* n_blocks) {
+    Oracle& O = *(Oracle*)h;
+    *n_blocks = (int64_t)O.factors.size();
+    if (!sens) return 0;
+    int64_t at = 0;
+    for (auto const& f : O.factors) sens[at++] = plane_block_input_sensitivity(f, x);
+    return 0;
+}
+// The plane normal a residual block of the frozen problem carries (kind 0: n0 of IBA_PlaneFactor, kind 1: n of Point2Plane_Factor), and
+// the block's rows with ANOTHER normal substituted: the device fits its planes with its own libm (acos / cos of the closed-form
+// eigen-solver), so its normal differs from this file's in the last bits, and an ill-conditioned block amplifies exactly that input
+// difference. With the device's normal substituted here the two evaluations see the same inputs (tests/parity_explain.py).
+int oracle_block_normal(void* h, int64_t block, double n[3], double point[3], int32_t* frame) {   // + the scan point the plane was fitted at
+    Oracle& O = *(Oracle*)h;
+    if (block < 0 || block >= (int64_t)O.factors.size()) return 1;
+    const Factor& f = O.factors[block];
+    if (f.kind == 2) return 1;
+    const V3d& v = f.kind == 0 ? f.n0 : f.n;
+    const V3d& q = f.kind == 0 ? f.p0 : f.Q;
+    n[0] = v.x; n[1] = v.y; n[2] = v.z;
+    point[0] = q.x; point[1] = q.y; point[2] = q.z;
+    *frame = f.frame;
+    return 0;
+}
+int oracle_block_rows_with_normal(void* h, int64_t block, const double* x, const double n[3], double* r, double* J, double* fwd_err) {
+    Oracle& O = *(Oracle*)h;
+    if (block < 0 || block >= (int64_t)O.factors.size()) return 1;
+    Factor f = O.factors[block];
+    if (f.kind == 2) return 1;
+    (f.kind == 0 ? f.n0 : f.n) = V3d{n[0], n[1], n[2]};
+    eval_factor(f, x, r, J);
+    if (fwd_err) {   // the forward error of THIS evaluation (double against long double), relative to the block's scale
+        using L7 = DualL<7>;
+        L7 xl[7]; for (int i = 0; i < 7; ++i) xl[i] = L7(x[i], i);
+        const int rows = f.rows();
+        std::vector<L7> el(rows);
+        if (f.kind == 0) eval_plane_factor<L7>(f, xl, el.data()); else eval_p2x_factor<L7>(f, xl, el.data());
+        long double scale = 1.0L, dev = 0.0L;
+        for (int i = 0; i < rows; ++i) {
+            scale = std::max(scale, fabsl(el[i].a)); dev = std::max(dev, fabsl((long double)r[i] - el[i].a));
+            for (int c = 0; c < 7; ++c) { scale = std::max(scale, fabsl(el[i].v[c])); dev = std::max(dev, fabsl((long double)J[i * 7 + c] - el[i].v[c])); }
+        }
+        *fwd_err = std::max(std::max((double)(dev / scale), block_sensitivity(f, x)), plane_block_input_sensitivity(f, x));   // the yardstick of this evaluation: its forward error or the block's sensitivities, the largest
+    }
+    return 0;
+}
 // x-independent local plane record at one scan point (for the GPU plane-cache parity test)
 int oracle_plane_at(void* h, int frame, uint32_t pt_idx, double radius, int max_pts, int32_t* k_out, double* far_d2, double* normal3, double* reg_err_sum) {
     Oracle& O = *(Oracle*)h; const Frame& f = O.frames[frame];

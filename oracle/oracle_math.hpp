@@ -48,6 +48,31 @@ inline double sqrt(double x) { return std::sqrt(x); }
 inline double cos(double x) { return std::cos(x); }
 inline double sin(double x) { return std::sin(x); }
 inline double pow(double x, double p) { return std::pow(x, p); }
+// The same dual numbers in `long double` (x87 80-bit: 64-bit mantissa): NOT a restatement of anything in the reference — a
+// higher-precision evaluation of the same formulas, used to MEASURE the forward error of the double evaluation of a residual block
+// (oracle_block_forward_error: how far two correct double evaluations of an ill-conditioned block may be from each other).
+template <int N>
+struct DualL {
+    long double a;
+    long double v[N];
+    DualL() : a(0) { for (int i = 0; i < N; ++i) v[i] = 0; }
+    DualL(double s) : a(s) { for (int i = 0; i < N; ++i) v[i] = 0; }  // NOLINT
+    DualL(long double s) : a(s) { for (int i = 0; i < N; ++i) v[i] = 0; }  // NOLINT
+    DualL(double s, int k) : a(s) { for (int i = 0; i < N; ++i) v[i] = 0; v[k] = 1.0L; }
+};
+template <int N> inline DualL<N> operator+(const DualL<N>& f, const DualL<N>& g) { DualL<N> h; h.a = f.a + g.a; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] + g.v[i]; return h; }
+template <int N> inline DualL<N> operator-(const DualL<N>& f, const DualL<N>& g) { DualL<N> h; h.a = f.a - g.a; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] - g.v[i]; return h; }
+template <int N> inline DualL<N> operator-(const DualL<N>& f) { DualL<N> h; h.a = -f.a; for (int i = 0; i < N; ++i) h.v[i] = -f.v[i]; return h; }
+template <int N> inline DualL<N> operator*(const DualL<N>& f, const DualL<N>& g) { DualL<N> h; h.a = f.a * g.a; for (int i = 0; i < N; ++i) h.v[i] = f.a * g.v[i] + f.v[i] * g.a; return h; }
+template <int N> inline DualL<N> operator/(const DualL<N>& f, const DualL<N>& g) {
+    DualL<N> h; const long double gi = 1.0L / g.a; const long double fg = f.a * gi; h.a = fg;
+    for (int i = 0; i < N; ++i) h.v[i] = (f.v[i] - fg * g.v[i]) * gi;
+    return h; }
+template <int N> inline bool operator<(const DualL<N>& f, const DualL<N>& g) { return f.a < g.a; }
+template <int N> inline DualL<N> sqrt(const DualL<N>& f) { DualL<N> h; const long double t = sqrtl(f.a); const long double ti = 1.0L / (2.0L * t); h.a = t; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * ti; return h; }
+template <int N> inline DualL<N> cos(const DualL<N>& f) { DualL<N> h; h.a = cosl(f.a); const long double s = -sinl(f.a); for (int i = 0; i < N; ++i) h.v[i] = s * f.v[i]; return h; }
+template <int N> inline DualL<N> sin(const DualL<N>& f) { DualL<N> h; h.a = sinl(f.a); const long double c = cosl(f.a); for (int i = 0; i < N; ++i) h.v[i] = c * f.v[i]; return h; }
+template <int N> inline DualL<N> pow(const DualL<N>& f, double p) { DualL<N> h; h.a = powl(f.a, (long double)p); const long double t = (long double)p * powl(f.a, (long double)p - 1.0L); for (int i = 0; i < N; ++i) h.v[i] = t * f.v[i]; return h; }
 template <class T> inline double scalar_of(const T& x) { return x.a; }
 template <> inline double scalar_of<double>(const double& x) { return x; }
 

@@ -265,6 +265,13 @@ class IbaHandle:
                                         idx.ctypes.data_as(C.POINTER(C.c_uint32)), _p(d2)))
         return idx, d2
 
+    def debug_plane(self, frame, point, which=1):
+        """(normal[3], reg_sum, far_d2, k) of the memoised local plane at ORIGINAL scan point index `point` of `frame` (which: 0 cost path, 1 local)"""
+        out = np.zeros(5)
+        k = C.c_int32(0)
+        self._chk(self.lib.iba_debug_plane(self.h, C.c_int32(frame), C.c_uint32(int(point)), C.c_int32(which), _p(out), C.byref(k)))
+        return out[:3].copy(), float(out[3]), float(out[4]), k.value
+
     def eval_cost_partial(self, x, d_partials_ptr, stream_ptr=None):
         x = self._x(x)
         self._chk(self.lib.iba_eval_cost_partial(self.h, _p(x), C.c_int32(len(x)), C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))

@@ -86,7 +86,10 @@ struct iba_handle {
     DevBuf<uint32_t> mpk;                 // per frame: keypoints that own a MapPoint
     uint32_t max_mpk = 0;
     DevBuf<SetPt> d_anchor;               // anchored neighbour lists: n_frames x maxK rows of kAnchorRowBytes (512) bytes
-    bool anchor_valid = false; AnchorRef anchor_ref{}; int calls_since_anchor = 0;
+    // up to kAnchorSets anchors (an optimiser polls around two incumbents, the feasible and the infeasible one): each with its own set of lists
+    bool anchor_valid[kAnchorSets] = {false, false}; AnchorRef anchor_ref[kAnchorSets]{}; int calls_since_anchor[kAnchorSets] = {0, 0}; unsigned long long anchor_used[kAnchorSets] = {0, 0};
+    unsigned long long anchor_clock = 0; size_t anchor_set_elems = 0;
+    uint8_t anchor_sel[IBA_MAX_BATCH] = {0};   // this call: the set each candidate reads (255: none)
     double anchor_reach = 0.06;           // IBA_ANCHOR_REACH (m): a batch whose reference candidate moves a nominal MapPoint further than this from the anchor's query gets a new anchor
     int anchor_builds = 0;
     // list slots of the common pairs: each holds the pair lists of ONE group of candidates (reference + bound) and may outlive the call
@@ -108,6 +111,7 @@ struct iba_handle {
     double max_fx = 0.0;
     const Cand* last_hc = nullptr;        // host copy of the candidate block staged last (pinned ring)
     bool cref_ok = false;                 // this call's batch shares pair searches (plan_pairs at staging time)
+    bool plan_wide = false;               // ... or was found wide everywhere (an exploratory poll: every candidate for itself)
     int pair_memo = 1; double pair_infl = 1.25, pair_rho_floor = 1e-4, pair_tau_floor = 1e-3;   // IBA_PAIR_MEMO, IBA_PAIR_INFL
     int pairs_builds = 0; int pair_memo_max_b = 40; double pair_memo_max_px = 8.0;   // IBA_PAIR_MEMO_MAX_B
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
@@ -462,7 +466,9 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     }
     else if (jets == 1) for (int b = 0; b < B; ++b) make_cand(x + 7 * b, hc[b]);
     else for (int b = 0; b < B; ++b) make_cand_values(x + 7 * b, hc[b]);
-    h->cref_ok = plan && h->common_mode > 0 && B >= h->common_min_batch && h->d_pairs.p && plan_pairs(h, hc, B);
+    const bool planned = plan && h->common_mode > 0 && B >= h->common_min_batch && h->d_pairs.p;
+    h->cref_ok = planned && plan_pairs(h, hc, B);
+    h->plan_wide = planned && !h->cref_ok;   // the planner looked at this batch and found it wide everywhere
     // the block crosses PCIe by a kernel that reads the pinned ring (a copy-engine transfer of these 70 KB costs ~15 us of latency
     // at the head of every evaluation; a strided copy of the value halves alone was slower still)
     {
@@ -658,38 +664,75 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     const bool search_wanted = (want & 1) || h->dprm.use_3d3d;
     if (h->nn_sets && h->d_anchor.p && h->max_mpk > 0 && search_wanted && h->last_hc) {
         const Cand* hc = h->last_hc;
-        int ref = 0;
-        if (B > 1) {
-            double mean[12] = {0};
-            for (int b = 0; b < B; ++b) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].s * hc[b].Ri[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].ti[i]; }
-            double best = INFINITY;
-            for (int b = 0; b < B; ++b) {
-                double dd = 0;
-                for (int i = 0; i < 9; ++i) dd = std::max(dd, 3.0 * std::fabs(hc[b].s * hc[b].Ri[i] - mean[i] / B));
-                for (int i = 0; i < 3; ++i) dd = std::max(dd, std::fabs(hc[b].ti[i] - mean[9 + i] / B));
-                if (dd < best) { best = dd; ref = b; }
-            }
-        }
-        auto drift = [&](const Cand& c) {   // how far the query of a MapPoint 30 m out moves between the anchor and c (row-sum bound; |m| = 30 m / scale)
+        auto drift = [&](const Cand& c, const AnchorRef& ar) {   // how far the query of a MapPoint 30 m out moves between an anchor and c (row-sum bound; |m| = 30 m / scale)
             const double nominal = 30.0 / std::max(std::fabs(c.s), 1e-12);
             double worst = 0;
             for (int r = 0; r < 3; ++r) {
-                double v = std::fabs(c.ti[r] - h->anchor_ref.t[r]);
-                for (int q = 0; q < 3; ++q) v += nominal * std::fabs(c.s * c.Ri[r * 3 + q] - h->anchor_ref.M[r * 3 + q]) / std::sqrt(3.0);
+                double v = std::fabs(c.ti[r] - ar.t[r]);
+                for (int q = 0; q < 3; ++q) v += nominal * std::fabs(c.s * c.Ri[r * 3 + q] - ar.M[r * 3 + q]) / std::sqrt(3.0);
                 worst = std::max(worst, v);
             }
             return worst;
         };
-        ++h->calls_since_anchor;
-        const double far = h->anchor_valid ? drift(hc[ref]) : INFINITY;
-        if (!(far <= h->anchor_reach) && (!h->anchor_valid || h->calls_since_anchor >= 4) && std::isfinite(hc[ref].s)) {
-            for (int i = 0; i < 9; ++i) h->anchor_ref.M[i] = hc[ref].s * hc[ref].Ri[i];
-            for (int i = 0; i < 3; ++i) h->anchor_ref.t[i] = hc[ref].ti[i];
-            hipLaunchKernelGGL(iba_anchor_kernel, dim3((h->max_mpk + kNNThreads - 1) / kNNThreads, nf), dim3(kNNThreads), 8u * std::max(h->maxNodes, 1u), st, AnchorArgs{dp, h->dprm, h->anchor_ref}, h->d_anchor.p);
-            HIP_TRY(h, hipGetLastError());
-            h->anchor_valid = true; h->calls_since_anchor = 0; ++h->anchor_builds;
-            sets = true;
-        } else sets = h->anchor_valid && far <= 4.0 * h->anchor_reach;   // further out the certificates fail anyway: plain search kernel
+        // the poll centres of this batch: the groups of the pair-search plan (one per incumbent) — or the whole batch; of each, the member
+        // nearest the group's mean query transform
+        int grp_of[IBA_MAX_BATCH], n_grp = 1;
+        for (int b = 0; b < B; ++b) grp_of[b] = 0;
+        if (common && h->n_groups > 1) {
+            int slot_grp[kMaxPairGroups] = {-1, -1, -1, -1}; n_grp = 0;
+            for (int b = 0; b < B; ++b) { int& g = slot_grp[h->amap.slot[b]]; if (g < 0) g = n_grp++; grp_of[b] = g; }
+        }
+        int ref_of[kMaxPairGroups], size_of[kMaxPairGroups];
+        for (int g = 0; g < n_grp; ++g) {
+            double mean[12] = {0}; int n = 0;
+            for (int b = 0; b < B; ++b) if (grp_of[b] == g) { for (int i = 0; i < 9; ++i) mean[i] += hc[b].s * hc[b].Ri[i]; for (int i = 0; i < 3; ++i) mean[9 + i] += hc[b].ti[i]; ++n; }
+            double best = INFINITY; int ref = -1;
+            for (int b = 0; b < B; ++b) if (grp_of[b] == g) {
+                double dd = 0;
+                for (int i = 0; i < 9; ++i) dd = std::max(dd, 3.0 * std::fabs(hc[b].s * hc[b].Ri[i] - mean[i] / n));
+                for (int i = 0; i < 3; ++i) dd = std::max(dd, std::fabs(hc[b].ti[i] - mean[9 + i] / n));
+                if (ref < 0 || dd < best) { best = dd; ref = b; }
+            }
+            ref_of[g] = ref; size_of[g] = n;
+        }
+        for (int a = 0; a < kAnchorSets; ++a) ++h->calls_since_anchor[a];
+        // The anchors follow the optimiser: a centre none of whose anchors is within anchor_reach gets new lists — in a free set at once,
+        // else in the least recently used set no centre of THIS batch sits on, and then at most every fourth call of that set (a wide
+        // exploratory phase does not rebuild for nothing). At most one build per call: the biggest centre first.
+        bool in_use[kAnchorSets] = {false, false};
+        int want_build = -1;
+        for (int g = 0; g < n_grp; ++g) {
+            double near = INFINITY; int na = -1;
+            for (int a = 0; a < kAnchorSets; ++a) if (h->anchor_valid[a]) { const double d = drift(hc[ref_of[g]], h->anchor_ref[a]); if (d < near) { near = d; na = a; } }
+            if (na >= 0 && near <= h->anchor_reach) in_use[na] = true;
+            else if (std::isfinite(hc[ref_of[g]].s) && (want_build < 0 || size_of[g] > size_of[want_build])) want_build = g;
+        }
+        // (a batch that is wide everywhere — tens of pixels between any two candidates — is an exploratory poll: lists around its
+        //  centre would serve one or two of its candidates; 216 -> fewer builds of 0.16 ms in a recorded calibration)
+        if (want_build >= 0 && !h->plan_wide) {
+            int slot = -1;
+            for (int a = 0; a < kAnchorSets && slot < 0; ++a) if (!h->anchor_valid[a]) slot = a;
+            if (slot < 0) {
+                unsigned long long oldest = ~0ull;
+                for (int a = 0; a < kAnchorSets; ++a) if (!in_use[a] && h->calls_since_anchor[a] >= 4 && h->anchor_used[a] < oldest) { oldest = h->anchor_used[a]; slot = a; }
+            }
+            if (slot >= 0) {
+                const Cand& c = hc[ref_of[want_build]];
+                AnchorRef& ar = h->anchor_ref[slot];
+                for (int i = 0; i < 9; ++i) ar.M[i] = c.s * c.Ri[i];
+                for (int i = 0; i < 3; ++i) ar.t[i] = c.ti[i];
+                hipLaunchKernelGGL(iba_anchor_kernel, dim3((h->max_mpk + kNNThreads - 1) / kNNThreads, nf), dim3(kNNThreads), 8u * std::max(h->maxNodes, 1u), st, AnchorArgs{dp, h->dprm, ar}, h->d_anchor.p + (size_t)slot * h->anchor_set_elems);
+                HIP_TRY(h, hipGetLastError());
+                h->anchor_valid[slot] = true; h->calls_since_anchor[slot] = 0; ++h->anchor_builds;
+            }
+        }
+        // every candidate reads the set of the anchor nearest to it — further than 4 x anchor_reach the certificates fail anyway: none
+        for (int b = 0; b < B; ++b) {
+            double near = INFINITY; int na = 255;
+            for (int a = 0; a < kAnchorSets; ++a) if (h->anchor_valid[a]) { const double d = drift(hc[b], h->anchor_ref[a]); if (d < near) { near = d; na = a; } }
+            h->anchor_sel[b] = (uint8_t)((na != 255 && near <= 4.0 * h->anchor_reach) ? na : 255);
+            if (h->anchor_sel[b] != 255) { sets = true; h->anchor_used[na] = ++h->anchor_clock; }
+        }
     }
     if (common) {
         { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }   // the candidates and the hand-eye terms: first read here
@@ -713,7 +756,8 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     }
     if (search) {
         const dim3 grid(8 * per_xcd * ngroups * NS), block(kNNThreads);
-        const NNArgs na{dp, h->dprm, nl};
+        NNArgs na{dp, h->dprm, nl, (unsigned long long)(h->anchor_set_elems * sizeof(SetPt)), {0}};
+        std::memcpy(na.anchor_sel, h->anchor_sel, sizeof(na.anchor_sel));
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
         const SetPt* anchor = sets ? h->d_anchor.p : nullptr;
         auto launch_nn = [&](auto mode_tag) {
@@ -1037,7 +1081,8 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (h->nn_sets && h->max_mpk > 0) {
         // 512 B per (frame, keypoint): 205 MB at 200 x 2000 keypoints, linear in the keyframes. The lists are an
         // optional memo: when the allocation fails the handle runs without them (every lane searches the tree), it does not fail.
-        if (h->d_anchor.alloc(((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kAnchorRowBytes + sizeof(SetPt) - 1) / sizeof(SetPt) + 1) != hipSuccess) { (void)hipGetLastError(); h->d_anchor.p = nullptr; h->d_anchor.n = 0; h->nn_sets = false; }
+        h->anchor_set_elems = (((size_t)std::max(nf, 1) * std::max(h->maxK, 1u) * kAnchorRowBytes + sizeof(SetPt) - 1) / sizeof(SetPt) + 1 + 7) / 8 * 8;   // (a multiple of 384 B: every set starts 128-byte aligned)
+        if (h->d_anchor.alloc((size_t)kAnchorSets * h->anchor_set_elems) != hipSuccess) { (void)hipGetLastError(); h->d_anchor.p = nullptr; h->d_anchor.n = 0; h->nn_sets = false; }
     }
     if (h->common_mode > 0) {   // common lists of one batch: (scan point, keypoint) pairs and hard points per frame
         // the pairs of a batch grow with the scan density (points per pixel) and with the batch's spread: 4 per keypoint serve 10 k-point
@@ -1117,7 +1162,7 @@ iba_status iba_set_params(iba_handle* h, const iba_params* p) {
         HIP_TRY(h, hipMemcpy(h->bitmap.p, bm.data(), sizeof(uint32_t) * bm.size(), hipMemcpyHostToDevice));
     }
     h->params = *p; to_dev_params(*p, h->dprm); h->frozen_valid = false;
-    h->anchor_valid = false;   // the lists carry the planes' verdicts under the old parameters
+    for (bool& v : h->anchor_valid) v = false;   // the lists carry the planes' verdicts under the old parameters
     for (auto& ps : h->pslot) ps.valid = false;    // the pair lists were cut for the old max_pixel_dist
     return compute_plane_cache(h);
 }
@@ -1199,6 +1244,26 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     int n = 0;
     for (auto const& pr : pairs) { if (n < cap && kp_idx && pt_idx) { kp_idx[n] = pr.first; pt_idx[n] = pr.second; } ++n; }
     *n_out = n;
+    return IBA_OK;
+}
+
+iba_status iba_debug_plane(iba_handle* h, int32_t frame, uint32_t point, int32_t which, double out5[5], int32_t* k) {
+    if (!h || !out5 || !k) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
+    const int lf = frame - h->frame_begin;
+    if (lf < 0 || lf >= h->n_frames || point >= h->h_frames[lf].P) return fail(h, IBA_ERR_INVALID_ARG, "frame / point out of range");
+    // plane_cache = 0: the planes are fitted per evaluation; slot 0 of the scratch records holds those of the FROZEN problem
+    // (iba_build_problem), the ones iba_eval_residuals / iba_eval_factors read — only the local planes (which = 1) exist there
+    if (!h->params.plane_cache && (which != 1 || !h->frozen_valid || !h->scratch_cost.p)) return fail(h, IBA_ERR_STATE, "plane_cache = 0: only the local planes of a frozen problem (which = 1 after iba_build_problem)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const FrameHdr& fh = h->h_frames[lf];
+    uint32_t pos = 0;
+    HIP_TRY(h, hipMemcpy(&pos, h->inv_perm.p + fh.pt_base + point, sizeof(pos), hipMemcpyDeviceToHost));
+    const PlaneRec* src = !h->params.plane_cache ? (h->scratch_local_aliases ? h->scratch_cost.p : h->scratch_local.p)
+                        : (which == 0 || h->plane_local_aliases_cost) ? h->plane_cost.p : h->plane_local.p;
+    PlaneRec rec;
+    HIP_TRY(h, hipMemcpy(&rec, src + fh.pt_base + pos, sizeof(rec), hipMemcpyDeviceToHost));
+    out5[0] = rec.nx; out5[1] = rec.ny; out5[2] = rec.nz; out5[3] = rec.reg_sum; out5[4] = rec.far_d2; *k = rec.k;
     return IBA_OK;
 }
 

@@ -48,7 +48,14 @@ constexpr int kCdDoubles = 14;   // per candidate in LDS: s, Ri[9], ti[3], (s32,
 #ifndef IBA_NN_LEAF_BATCH
 #define IBA_NN_LEAF_BATCH 4   /* points of a leaf scan whose loads are in flight together */
 #endif
-struct NNArgs { DevProblem dp; DevParams prm; NNLayout lay; };
+constexpr int kAnchorSets = 2;      // anchored neighbour lists are kept around up to this many anchor extrinsics (an optimiser polls around two incumbents)
+struct NNArgs {
+    DevProblem dp; DevParams prm; NNLayout lay;
+    // which set of anchored neighbour lists each candidate of the batch reads (255: none — its lanes search the tree), and the
+    // distance in bytes between two sets
+    unsigned long long anchor_set_bytes;
+    uint8_t anchor_sel[IBA_MAX_BATCH];
+};
 
 // list entry flags (uint4.w) written by iba_assoc_kernel
 constexpr uint32_t kFlagC = 1u;   // cost-path 1-NN wanted (keypoint owns a MapPoint, frame counts for BAError, 3d-3d enabled)
@@ -170,7 +177,11 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
             }
         }
         if (usedC && prm.use_3d3d && ((e >> 16) & 1u)) flags |= kFlagC;
-        fl[i] = make_uint4(k, ax_, kNone, flags);   // .z (the 3d-3d block) is filled in by iba_nn_kernel
+        // (.z, the 3d-3d block, is filled in by iba_nn_kernel. Round 4 measured the 16-byte entry against 8 bytes — the store skipped
+        //  altogether: 2 us of 186; 8 bytes + a 4-byte array for the search kernel's pick: search + 7 us, factors + 8 us (two loads per
+        //  entry instead of one); one packed 8-byte word: search + 10 us (spills at its 128-VGPR cap), factors + 3 us, association
+        //  unchanged. These kernels do not wait for HBM: tools/experiments/r04_list_entry_8_bytes.patch.)
+        fl[i] = make_uint4(k, ax_, kNone, flags);
     }
     if (dbg == 7) return;
     // K6: 3d-2d covisible reprojection residuals (iba_global.cpp:291-328): only the slots whose match bit is set
@@ -1604,6 +1615,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
     if (tid < cands_here) my_n = lcount[(size_t)(g * CG + tid) * nf + f];
     if (!SETS) for (uint32_t i = tid; i < nnodes; i += T) s_nodes[i] = dp.nodes[h.node_base + i];   // with the batch's neighbour sets the tree is staged only if a lane needs it
     if (tid < kMaxGroup) s_n[tid] = my_n;
+    uint32_t* s_sel = s_ctr + 4;                             // [kMaxGroup] anchor set of each candidate of the group (255: none)
+    if (SETS && tid < kMaxGroup) s_sel[tid] = tid < cands_here ? (uint32_t)ka->anchor_sel[g * CG + tid] : 255u;
     if (tid < cands_here * kCdDoubles) s_cd[tid] = ((const double*)&cands[g * CG + tid / kCdDoubles])[12 + tid % kCdDoubles];
     __syncthreads();
     if (dbg == 1) return;
@@ -1772,13 +1785,15 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     uint4 e0, e1; float4 mq0, mq1;
                     fetch(wn, e0, mq0); fetch(wn + (uint32_t)T, e1, mq1);
                     const bool w0 = (e0.w & kWantMask) != 0u, w1 = (e1.w & kWantMask) != 0u;
-                    const unsigned char* r0 = anchor_row(anchor, (size_t)f * dp.max_k + (w0 ? e0.x : 0u));
-                    const unsigned char* r1 = anchor_row(anchor, (size_t)f * dp.max_k + (w1 ? e1.x : 0u));
+                    // the lists this lane's candidate reads: the set built around the anchor nearest to it (255: none is near — straight to the tree search)
+                    const uint32_t sel0 = s_sel[wn & ((1u << cg_shift) - 1u)], sel1 = s_sel[(wn + (uint32_t)T) & ((1u << cg_shift) - 1u)];
+                    const unsigned char* r0 = anchor_row((const unsigned char*)anchor + (size_t)(sel0 != 255u ? sel0 : 0u) * ka->anchor_set_bytes, (size_t)f * dp.max_k + (w0 ? e0.x : 0u));
+                    const unsigned char* r1 = anchor_row((const unsigned char*)anchor + (size_t)(sel1 != 255u ? sel1 : 0u) * ka->anchor_set_bytes, (size_t)f * dp.max_k + (w1 ? e1.x : 0u));
                     AnchorHdr h0, h1; SetPt a0, b0;
                     h0.count = h1.count = 0u; h0.dM = h1.dM = -1.0; h0.d1 = h1.d1 = 0.0; h0.da1_lo = h1.da1_lo = INFINITY;
                     a0.flags = b0.flags = 0u;
-                    if (w0) { h0 = *anchor_hdr(r0); a0 = *anchor_pt(r0, 0u); }   // header + nearest neighbour: ONE 128-byte line, all that most lanes need
-                    if (w1) { h1 = *anchor_hdr(r1); b0 = *anchor_pt(r1, 0u); }
+                    if (w0 && sel0 != 255u) { h0 = *anchor_hdr(r0); a0 = *anchor_pt(r0, 0u); }   // header + nearest neighbour: ONE 128-byte line, all that most lanes need
+                    if (w1 && sel1 != 255u) { h1 = *anchor_hdr(r1); b0 = *anchor_pt(r1, 0u); }
                     if (w0) pick(wn, e0, mq0, h0, a0, r0);
                     if (w1) pick(wn + (uint32_t)T, e1, mq1, h1, b0, r1);
                 }

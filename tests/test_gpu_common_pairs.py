@@ -135,20 +135,44 @@ def test_anchored_neighbour_lists_follow_the_candidates(pkg, synth, abi, scene_s
     assert h1.anchor_builds == 1 and h0.anchor_builds == 0
     same(synth.perturb(x1, rng, n=9))                            # near the anchor: certified picks
     same(synth.perturb(x1, rng, rot=3e-3, trans=3e-2, scale_rel=6e-3, n=9))   # a spread of ~20 cm: some certify, some search
-    assert h1.anchor_builds == 1
-    same(synth.perturb(x2, rng, n=5))                            # far away: no certificate holds (and no rebuild yet: hysteresis)
-    assert h1.anchor_builds == 1
+    assert h1.anchor_builds <= 2                                 # (its central candidate may sit outside the first anchor's reach: the free second set is built at once then)
+    for _ in range(5):
+        same(synth.perturb(x2, rng, n=5))                        # far away: no certificate of the first anchor holds; a free set, or the older one after four calls, follows
+    assert 2 <= h1.anchor_builds <= 3
+    tight = dict(rot=1e-4, trans=1e-3, scale_rel=1e-4)           # polls well inside an anchor's reach (6 cm of query motion)
+    for _ in range(8):                                           # the two centres in turn: the sets settle on them
+        same(synth.perturb(x2, rng, n=5, **tight))
+        same(synth.perturb(x1, rng, n=5, **tight))
+    nb = h1.anchor_builds
+    assert nb <= 5
     for _ in range(4):
-        same(synth.perturb(x2, rng, n=5))
-    assert h1.anchor_builds == 2                                 # the anchor has followed the candidates
-    same(synth.perturb(x2, rng, n=40))
+        same(synth.perturb(x2, rng, n=5, **tight))               # an optimiser's two incumbents: each keeps its lists
+        same(synth.perturb(x1, rng, n=5, **tight))
+    assert h1.anchor_builds == nb
+    same(np.concatenate([synth.perturb(x1, rng, n=4, **tight), synth.perturb(x2, rng, n=4, **tight)]))   # both in one batch: every candidate reads the set nearest to it
+    assert h1.anchor_builds == nb
+    # both sets taken: a third centre replaces the least recently used one — a set is replaced at most every fourth call since ITS build
+    x3 = x1 - np.array([0.004, -0.003, 0.002, 0.05, -0.04, 0.03, 0.3])
+    x4 = x1 + np.array([-0.004, 0.003, 0.002, -0.05, 0.04, 0.03, -0.2])
+    x5 = x1 + np.array([0.003, 0.004, -0.002, 0.04, 0.05, -0.03, 0.2])
+    same(synth.perturb(x3, rng, n=5))
+    assert h1.anchor_builds == nb + 1
+    same(synth.perturb(x4, rng, n=5))
+    assert h1.anchor_builds == nb + 2
+    same(synth.perturb(x5, rng, n=5))                            # both sets are younger than four calls: no rebuild, every lane searches the tree
+    assert h1.anchor_builds == nb + 2
+    for _ in range(4):
+        same(synth.perturb(x2, rng, n=5, **tight))
+    assert h1.anchor_builds == nb + 3                            # the anchors have followed the candidates
+    same(synth.perturb(x2, rng, n=40, **tight))
+    assert h1.anchor_builds == nb + 3
     q = abi.reference_yaml_params()
     q.norm_reg_threshold *= 0.5                                  # the lists carry the planes' verdicts: a parameter change rebuilds them
     q.local_norm_reg_threshold *= 2.0
     h0.set_params(q)
     h1.set_params(q)
     same(synth.perturb(x2, rng, n=6))
-    assert h1.anchor_builds == 3
+    assert h1.anchor_builds == nb + 4
     h0.close()
     h1.close()
 

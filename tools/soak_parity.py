@@ -2,7 +2,7 @@
 Counters must be equal, cost floats (f1, f2, C) within 1e-10. H and b: every entry within 1e-10 of itself (entries below 1e-6 of the
 largest: of the largest) — OR the candidate's deviation must be EXPLAINED (tests/parity_explain.py, round 4): confined to residual
 blocks that the oracle's conditioning measure flags (a plane factor whose viewing ray lies almost in its plane: Z0 = num / den with a
-cancelling den), within eps / cond^2 of the block's scale, and gone when those blocks are removed from both sides (the remaining
+cancelling den), within a small multiple of the oracle's own measured double-vs-long-double error of that block, and gone when those blocks are removed from both sides (the remaining
 entries within 1e-10 of themselves or within 1e-12 of the sum of the absolute values of their terms: cancelling off-diagonal sums). A deviation that is
 not explained fails the scene. The summary line says how many candidates were above the gate and how many blocks explained them.
 Not part of the test suite (minutes); tests/test_gpu_conditioning.py runs the same check on 30 scenes.
@@ -41,6 +41,8 @@ INT = ("valid_cnt_3d_2d", "cnt_3d_2d", "cnt_3d_3d", "valid_cnt_3d_3d", "valid_pl
 bad = 0
 above_gate = explained_blocks = cancelling = 0   # candidates whose H / b missed the 1e-10 gate; ill-conditioned blocks that explained them
 worst_cond = 1.0
+worst_ratio = 0.0   # a flagged block's deviation over the oracle's own forward error of it
+worst_normal = 0.0  # device vs oracle plane normal of a block that needed the device's normal substituted
 worst_h = 0.0
 worst_entry = 0.0   # per-entry relative deviation over the entries above 1e-6 of the largest
 worst_c = 0.0       # hand-eye term C: device acos / tan through a cancelling log difference vs glibc
@@ -89,7 +91,7 @@ for sc in range(n_scenes):
                 try:
                     res = pe.explain(h, o, p, xs[b])
                     if res["status"] == "explained":
-                        explained_blocks += res["flagged"]; worst_cond = min(worst_cond, res["min_cond"]); cancelling += bool(res["cancelling_entries"])
+                        explained_blocks += res["flagged"]; worst_cond = min(worst_cond, res["min_cond"]); cancelling += bool(res["cancelling_entries"]); worst_ratio = max(worst_ratio, res["worst_dev_over_forward_error"]); worst_normal = max(worst_normal, res["worst_normal_difference"])
                 except AssertionError as ex:
                     msgs.append((b, "H/b not explained", e_dev, str(ex)[:200]))
     # the candidates drift a little between calls (the anchored neighbour lists of the first call serve the next ones)
@@ -127,6 +129,6 @@ for sc in range(n_scenes):
     tag = "ok " if not msgs else "BAD"
     bad += bool(msgs)
     print(f"{tag} seed {seed}: F={nf} P={pts} K={kp} B={len(xs)} pert={scale:g} plane={p.use_plane} w1={p.err_weight[1]:g} cache={p.plane_cache} n_corr={[c.n_corr for c in oc][:3]}", msgs[:3], flush=True)
-print(f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the 1e-10 per-entry gate, all explained: {explained_blocks} ill-conditioned block(s) (smallest conditioning measure {worst_cond:.1e}), {cancelling} candidate(s) by cancelling sums alone" if not bad else f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the gate, NOT all explained")
+print(f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the 1e-10 per-entry gate, all explained: {explained_blocks} ill-conditioned block(s) (smallest conditioning measure {worst_cond:.1e}; largest deviation {worst_ratio:.1f} x the oracle's own long-double-measured error, bound {pe.C_FWD:.0f} x; largest device-vs-oracle plane normal difference among them {worst_normal:.1e}), {cancelling} candidate(s) by cancelling sums alone" if not bad else f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the gate, NOT all explained")
 print(f"worst deviation of H relative to its largest entry {worst_h:.2e}, per entry (re-associated evaluations) {worst_entry:.2e}, worst relative deviation of C {worst_c:.2e}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

@@ -10,7 +10,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 wide = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0   # multiplier on the candidate spread
 KP = int(os.environ.get("PROBE_KEYPOINTS", "2000"))
-prob, meta = synth.make_scene(n_frames=F, pts_per_frame=P, n_keypoints=KP, seed=0)
+prob, meta = synth.make_scene(n_frames=F, pts_per_frame=P, n_keypoints=KP, seed=0, n_covis=int(os.environ.get("PROBE_COVIS", "3")))
 h = pkg.IbaHandle(prob, abi.reference_yaml_params())
 h.set_timing(True)
 L = pkg.load_library()
