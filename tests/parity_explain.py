@@ -2,25 +2,28 @@
 1e-10 of itself". Over thousands of random scenes some candidates miss it, for two reasons that round 3 only asserted in prose:
   (a) CONDITIONING OF A BLOCK. An IBA_PlaneFactor is two nested quotients (IBACalib2.hpp:163-183): Z0 = (n_c . p_c) / den with
       den = Cxz n_cx + Cyz n_cy + n_cz, then u = fx P1x / P1z + cx. When the viewing ray lies almost in the plane, den is a
-      difference of nearly equal terms; the device's analytic chain rule and the oracle's Dual<7> arithmetic are two different double
-      expressions of the same quotients. How far two correct double evaluations of such a block may be apart is MEASURED, not
-      assumed: the oracle evaluates every block a second time in long double (64-bit mantissa, oracle_block_forward_error) and the
-      difference to its own double result — the forward error of a double evaluation of that block, relative to the block's
-      scale — is one half of the yardstick E; the other half is the block's SENSITIVITY, measured too: how far its long-double
-      rows move when x moves by one unit in the last place (oracle_block_sensitivity). The device derives R, t and their
-      derivatives from x with Jet<6> arithmetic, the oracle with Dual<7>: each is exact for an x a few ulps away, and the
-      forward error of one evaluation is a single draw that can come out small by luck (seed 41059, r04: 34 x its own forward
-      error, 2 x its sensitivity). E = the larger of the two. And the two sides do not see the same INPUT: the plane normal n0 comes from the closed-form 3x3
-      eigen-solver (acos / cos), which the device evaluates with its own libm; the normals differ in the last bits (measured
-      below) and an ill-conditioned block amplifies exactly that. So a deviating block is re-evaluated by the oracle WITH THE
-      DEVICE'S NORMAL (iba_debug_plane -> oracle_block_rows_with_normal): same inputs on both sides, and only then compared.
+      difference of nearly equal terms and the block amplifies the last bits of everything it is given. What round 4 measured
+      (tools/device_vs_simulation.py, tools/three_ways_probe.py):
+        * the device kernel and a CPU evaluation of the SAME formulas in the SAME order (oracle_block_three_ways) agree BIT FOR BIT
+          on a block when their inputs are equal — the kernel computes what it says;
+        * the inputs are not always equal: the plane normal n0 comes from the closed-form 3x3 eigen-solver (acos / cos), which the
+          device evaluates with its own libm — the two normals differ by up to 1e-12 — and on some candidates the derivatives of
+          R, t (Jet<6> on the device's host side, Dual<7> in the oracle) differ in the last bit;
+        * the forward error of the analytic chain rule against long double is that of the oracle's duals (ratio 0.997 .. 1.19).
+      So a deviating block is first re-evaluated by the oracle WITH THE DEVICE'S NORMAL (iba_debug_plane ->
+      oracle_block_rows_with_normal), and what is left is held against a yardstick E that is MEASURED per block, the largest of
+        - the forward error of the oracle's own double evaluation against long double (oracle_block_forward_error),
+        - the block's sensitivity to one unit in the last place of x (oracle_block_sensitivity, long double),
+        - its sensitivity to one unit in the last place of every derived input R, t, dR, dt, n0, signs at random, in the kernel's
+          operation order (oracle_block_input_sensitivity):
+      two correct double evaluations of the block cannot be expected to agree better than a small multiple of E.
   (b) CONDITIONING OF A SUM. An entry of H or b is a sum over 10^3..10^5 blocks; off-diagonal entries cancel. Two summation orders of
       the same terms differ by about eps sqrt(n) of the sum of the ABSOLUTE values of the terms, which for a cancelling entry is far
       more than 1e-10 of the entry.
 explain() turns both into tests. Whenever a candidate misses the plain gate:
-  (i)   every residual block's rows (r, J) must agree within max(ROW_FLOOR, C_FWD * E) of the block's scale, E measured; a block
-        beyond that must (a) carry a plane normal, (b) whose device and oracle versions agree to NORMAL_TOL (the eigen-solver's
-        own agreement), and (c) agree within max(ROW_FLOOR, C_FWD * E') once the oracle evaluates it with the device's normal;
+  (i)   every residual block's rows (r, J) must agree within ROW_FLOOR of the block's scale; a block beyond that must, once the
+        oracle evaluates it with the device's plane normal (which may differ from the oracle's by at most NORMAL_TOL), agree within
+        ROW_FLOOR or within C_FWD * E, E the block's measured yardstick — a block without a plane normal gets no such help;
   (ii)  with the deviating blocks removed from BOTH sides, every entry of the rebuilt H and b must be within 1e-10 of itself OR
         within SUM_TOL of the sum of the absolute values of its terms;
   (iii) the candidate's own miss must be accounted for by (i) and (ii): either some block deviates, or the missed entries pass the
@@ -35,7 +38,7 @@ EPS = 2.220446049250313e-16
 GATE = 1e-10          # per entry, relative to the entry itself
 ENTRY_FLOOR = 1e-6    # entries below this fraction of the largest are compared against the largest instead
 ROW_FLOOR = 1e-12     # rows of a well-conditioned block agree to this (of the block's scale)
-C_FWD = 32.0          # rows of any block: within max(ROW_FLOOR, C_FWD * E), E = the oracle's own double-vs-long-double error of that block
+C_FWD = 4.0           # rows of a deviating block, inputs equalised: within C_FWD * E, E = the block's measured yardstick (forward error, sensitivities)
 NORMAL_TOL = 1e-11    # device vs oracle plane normal (unit vectors, sign-aligned), absolute: two libm evaluations of the closed-form eigenvector
 SUM_TOL = 1e-12       # an entry of H / b: within this of the sum of the absolute values of its terms (two summation orders)
 
@@ -104,17 +107,20 @@ def explain(h, o, p, x, nthreads=1):
     fwd = np.maximum(np.maximum(o.block_forward_error(x), o.block_sensitivity(x)), o.block_input_sensitivity(x))   # the yardstick E of a block: see (a)
     starts = np.concatenate([[0], np.where(np.diff(bo) != 0)[0] + 1, [len(bo)]])
     assert len(cond) == len(starts) - 1 == len(fwd)
-    flagged, min_cond, worst_ratio, worst_normal = [], 1.0, 0.0, 0.0
+    flagged, min_cond, worst_ratio, worst_normal, n_by_normal = [], 1.0, 0.0, 0.0, 0
     pts_of = {}
     for i in range(len(starts) - 1):
         lo, hi = starts[i], starts[i + 1]
         scale = max(float(np.max(np.abs(Jo[lo:hi]))), float(np.max(np.abs(ro[lo:hi]))), 1.0)
         dev = max(float(np.max(np.abs(Jg[lo:hi] - Jo[lo:hi]))), float(np.max(np.abs(rg[lo:hi] - ro[lo:hi])))) / scale
-        bound = max(ROW_FLOOR, C_FWD * float(fwd[i]))
-        if dev > bound:
-            # same formula, different INPUT? the device's own plane normal substituted into the oracle's block
-            got = o.block_normal(int(bo[lo]))
-            assert got is not None, "block %d (kind %d, no plane normal) deviates by %.2e of its scale; the oracle's double evaluation is accurate to %.2e: not explained" % (i, ko[lo], dev, fwd[i])
+        if dev <= ROW_FLOOR:
+            continue
+        flagged.append(int(bo[lo]))
+        min_cond = min(min_cond, float(cond[i]))
+        # a deviating block: first give both sides the same INPUT — the device's own plane normal substituted into the oracle's block
+        dev2, e2, dn = dev, float(fwd[i]), 0.0
+        got = o.block_normal(int(bo[lo]))
+        if got is not None:
             n_o, q, frame = got
             if frame not in pts_of:
                 pts_of[frame] = h.problem.frame_points(frame).astype(np.float64)
@@ -131,22 +137,19 @@ def explain(h, o, p, x, nthreads=1):
                 r2, J2 = -r2, -J2                                     # a flipped normal flips the 1-d point-to-plane residual: harmless for H, b
             scale2 = max(float(np.max(np.abs(J2))), float(np.max(np.abs(r2))), 1.0)
             dev2 = max(float(np.max(np.abs(Jg[lo:hi] - J2))), float(np.max(np.abs(rg[lo:hi] - r2)))) / scale2
-            bound2 = max(ROW_FLOOR, C_FWD * e2)
-            if dev2 > bound2 and os.environ.get("IBA_EXPLAIN_DEBUG"):
-                tw = o.block_three_ways(int(bo[lo]), x, hi - lo)
-                if tw is not None:
-                    dvc = np.concatenate([rg[lo:hi, None], Jg[lo:hi]], 1)
-                    print("block %d debug: |device - long double| %.3e, |oracle - long double| %.3e, |device-order simulation - long double| %.3e, |device - its simulation| %.3e (of scale %.3e)"
-                          % (i, np.max(np.abs(dvc - tw[1])), np.max(np.abs(tw[0] - tw[1])), np.max(np.abs(tw[2] - tw[1])), np.max(np.abs(dvc - tw[2])), scale2), flush=True)
-                    print("  device row 0", dvc[0], "\n  simulation  ", tw[2][0], "\n  oracle      ", tw[0][0], "\n  long double ", tw[1][0], flush=True)
-            assert dev2 <= bound2, ("block %d (kind %d) deviates by %.2e of its scale; with the device's own plane normal (|dn| = %.1e) in the oracle's block still %.2e, "
-                                    "beyond %.0f x the oracle's measured forward error %.2e (conditioning %.2e): not explained" % (i, ko[lo], dev, dn, dev2, C_FWD, e2, cond[i]))
-            worst_ratio = max(worst_ratio, dev2 / max(e2, 1e-300))
-        if dev > ROW_FLOOR:
-            flagged.append(int(bo[lo]))
-            min_cond = min(min_cond, float(cond[i]))
-            if dev <= bound:
-                worst_ratio = max(worst_ratio, dev / max(float(fwd[i]), 1e-300))
+        if dev2 <= ROW_FLOOR:
+            n_by_normal += 1                                          # the normal's last bits were all of it
+            continue
+        bound2 = C_FWD * e2
+        if dev2 > bound2 and os.environ.get("IBA_EXPLAIN_DEBUG"):
+            tw = o.block_three_ways(int(bo[lo]), x, hi - lo)
+            if tw is not None:
+                dvc = np.concatenate([rg[lo:hi, None], Jg[lo:hi]], 1)
+                print("block %d debug: |device - long double| %.3e, |oracle - long double| %.3e, |device-order simulation - long double| %.3e, |device - its simulation| %.3e (of scale %.3e)"
+                      % (i, np.max(np.abs(dvc - tw[1])), np.max(np.abs(tw[0] - tw[1])), np.max(np.abs(tw[2] - tw[1])), np.max(np.abs(dvc - tw[2])), scale), flush=True)
+        assert dev2 <= bound2, ("block %d (kind %d) deviates by %.2e of its scale; with the device's own plane normal (|dn| = %.1e) in the oracle's block still %.2e, "
+                                "beyond %.0f x the block's measured yardstick %.2e (conditioning %.2e): not explained" % (i, ko[lo], dev, dn, dev2, C_FWD, e2, cond[i]))
+        worst_ratio = max(worst_ratio, dev2 / max(e2, 1e-300))
     # with the deviating blocks removed: 1e-10 per entry, or the accuracy of a sum of that many cancelling terms
     Hg, bgv = normal_from_rows(rg, Jg, bg, kg, p, skip=flagged)
     Ho, bov = normal_from_rows(ro, Jo, bo, ko, p, skip=flagged)
@@ -164,4 +167,4 @@ def explain(h, o, p, x, nthreads=1):
     # (the rows are the same numbers the device summed: its own H rebuilt from its rows)
     Hfull, _ = normal_from_rows(rg, Jg, bg, kg, p)
     assert np.max(np.abs(Hfull - g.H_np())) <= 1e-9 * np.max(np.abs(g.H_np())), "iba_eval_residuals and iba_eval_normal disagree"
-    return {"status": "explained", "flagged": len(flagged), "min_cond": min_cond, "worst_entry": worst, "cancelling_entries": cancelling, "worst_dev_over_forward_error": worst_ratio, "worst_normal_difference": worst_normal}
+    return {"status": "explained", "flagged": len(flagged), "min_cond": min_cond, "worst_entry": worst, "cancelling_entries": cancelling, "worst_dev_over_forward_error": worst_ratio, "worst_normal_difference": worst_normal, "settled_by_the_normal": n_by_normal}

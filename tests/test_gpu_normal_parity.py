@@ -115,6 +115,39 @@ def test_per_residual_rows_match_oracle(pkg, synth, abi, ob, scene_small):
     h.close()
 
 
+def test_plane_blocks_as_the_g2o_edge_sees_them(pkg, synth, abi, ob, scene_small):
+    """IBAPlaneEdge (IBACalib.hpp:103-140), the per-keypoint g2o twin of IBA_PlaneFactor: a 20-dimensional error — the block's 2 NConv
+    residuals, zero-padded — and its 20 x 7 Jacobian. The rows iba_eval_residuals hands out for a plane-factor block, padded the same
+    way, against the oracle's edge (oracle_eval_plane_edge20): what a g2o user of the per-edge form would bind to."""
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(prob, p)
+    o = ob.Oracle(prob)
+    rng = np.random.default_rng(57)
+    x0 = synth.perturb(meta["x_gt"], rng, n=1)[0]
+    h.build_problem(x0)
+    o.build_problem(p, x0)
+    x = synth.perturb(x0, rng, rot=1e-3, trans=1e-2, scale_rel=2e-3, n=1)[0]
+    rg, Jg, bg, kg = h.eval_residuals(x)
+    starts = np.concatenate([[0], np.where(np.diff(bg) != 0)[0] + 1, [len(bg)]])
+    cond = o.block_conditioning(x)
+    seen = 0
+    for i in range(len(starts) - 1):
+        lo, hi = starts[i], starts[i + 1]
+        if kg[lo] != 0 or cond[i] < 1e-2:      # (ill-conditioned blocks have their own test: tests/test_gpu_conditioning.py)
+            continue
+        edge = o.plane_edge20(int(bg[lo]), x)
+        assert edge is not None and hi - lo <= 20 and (hi - lo) % 2 == 0
+        e20, J20 = np.zeros(20), np.zeros((20, 7))
+        e20[: hi - lo] = rg[lo:hi]; J20[: hi - lo] = Jg[lo:hi]
+        scale = max(np.abs(edge[1]).max(), np.abs(edge[0]).max(), 1.0)
+        assert np.max(np.abs(e20 - edge[0])) <= 1e-10 * scale and np.max(np.abs(J20 - edge[1])) <= 1e-10 * scale
+        assert not edge[0][hi - lo:].any() and not edge[1][hi - lo:].any()
+        seen += 1
+    assert seen > 200
+    h.close()
+
+
 def test_mfma_factor_kernel_matches_oracle(pkg, synth, abi, ob, scene_small, monkeypatch):
     """IBA_FACTOR_MFMA=1: the normal equations accumulated on v_mfma_f64_16x16x4_f64 (rank-1 rows through LDS) instead of the
     VALU: same bars as the default kernel, and equal to it to summation order."""
