@@ -444,6 +444,12 @@ __device__ __forceinline__ double wave_sum_f64(double x) {   // fixed associatio
     x += dpp_f64<0x143, 0xc>(x);   // row_bcast:31 -> rows 2,3
     return x;
 }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {   // inclusive prefix over the lanes of the wave (the total in lane 63)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x) {
     x += dpp_u64<0x111, 0xf>(x); x += dpp_u64<0x112, 0xf>(x); x += dpp_u64<0x114, 0xf>(x); x += dpp_u64<0x118, 0xf>(x);
     x += dpp_u64<0x142, 0xa>(x); x += dpp_u64<0x143, 0xc>(x);

@@ -113,45 +113,57 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     const uint32_t q = ((K + (uint32_t)kThreads * 4u - 1u) / ((uint32_t)kThreads * 4u)) * 4u;   // keypoints per thread: a multiple of 4
     const uint32_t k0 = (uint32_t)tid * q;
     uint32_t n_corr = 0u;
-    unsigned long long mine = 0ull;   // valid | cost-list << 16 | association-list << 32 of this thread's run (K < 65535: each fits 16 bits, so do the block totals)
+    // counts of this thread's run: cost-list | association-list << 16 entries (K < 65 535: each fits 16 bits, so do the block totals); the valid
+    // keypoints are counted per wave with ballots (scalar unit). (Round 3 carried the three counts in one 64-bit word: its adds,
+    // its DPP prefix and the re-derivation of the flags in the list pass were 26 M of the kernel's 79 M vector instructions.)
+    uint32_t mine = 0u, wave_valid = 0u;
     uint4 bi_keep = make_uint4(kNone, kNone, kNone, kNone);
-    for (uint32_t g = 0; g < q && k0 + g < K; g += 4u) {
-        const uint4 bi = *(const uint4*)(s_best_idx + k0 + g), fl4 = FLREG ? rf : *(const uint4*)(s_kfl + k0 + g);
+    uint32_t mC_keep = 0u, mA_keep = 0u;   // FLREG: which of the run's four keypoints go to the cost / the association list
+    for (uint32_t g = 0; g < q; g += 4u) {   // (block-uniform trip count: the ballots below need every lane)
+        uint4 bi = make_uint4(kNone, kNone, kNone, kNone), fl4 = make_uint4(0u, 0u, 0u, 0u);
+        if (k0 + g < K) { bi = *(const uint4*)(s_best_idx + k0 + g); fl4 = FLREG ? rf : *(const uint4*)(s_kfl + k0 + g); }
         if (FLREG) bi_keep = bi;
         const uint32_t bv[4] = {bi.x, bi.y, bi.z, bi.w}, fv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+        uint32_t mC = 0u, mA = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
+            wave_valid += (uint32_t)__popcll(__ballot(valid));
             const uint32_t w = valid ? fv[j] : 0u;
-            mine += (valid ? 1ull : 0ull) | (w != 0u ? 1ull << 16 : 0ull) | ((w & 3u) == 3u ? 1ull << 32 : 0ull);
+            mC |= (w != 0u ? 1u : 0u) << j; mA |= ((w & 3u) == 3u ? 1u : 0u) << j;
         }
+        mine += (uint32_t)__popc(mC) | ((uint32_t)__popc(mA) << 16);
+        if (FLREG) { mC_keep = mC; mA_keep = mA; }
     }
-    const unsigned long long incl = wave_sum_u64(mine);   // inclusive prefix over the lanes of the wave (the total in lane 63)
-    unsigned long long* s_cnt = (unsigned long long*)s_red;   // one total per wave (the reduction slab is not in use yet)
-    if (lane == 63) s_cnt[wave] = incl;
+    const uint32_t incl = wave_sum_u32(mine);   // inclusive prefix over the lanes of the wave (the total in lane 63)
+    uint2* s_cnt = (uint2*)s_red;   // (list counts, valid keypoints) of every wave (the reduction slab is not in use yet)
+    if (lane == 63) s_cnt[wave] = make_uint2(incl, wave_valid);
     __syncthreads();
-    unsigned long long before = 0ull, total = 0ull;
-    for (int w = 0; w < kWaves; ++w) { const unsigned long long t = s_cnt[w]; total += t; if (w < wave) before += t; }
-    n_corr = (uint32_t)(total & 0xffffull);
+    uint32_t before = 0u, total = 0u;
+    for (int w = 0; w < kWaves; ++w) { const uint2 t = s_cnt[w]; total += t.x; n_corr += t.y; if (w < wave) before += t.x; }
     const bool usedA = (want & 1) && !((int)n_corr < prm.num_min_corr);        // iba_local.cpp:192
     const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
     uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
     uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
     uint32_t* s_msk = s_best_idx;        // FLREG: per list item its covisible-slot mask (the winners were read before the barrier above)
     {
-        const int sh = usedC ? 16 : 32;   // which of the two lists this evaluation builds
-        n3 = (usedC || usedA) ? (uint32_t)((total >> sh) & 0xffffull) : 0u;
-        uint32_t at = (uint32_t)(((before + (incl - mine)) >> sh) & 0xffffull);   // entries of the threads before this one
+        const int sh = usedC ? 0 : 16;   // which of the two lists this evaluation builds
+        n3 = (usedC || usedA) ? ((total >> sh) & 0xffffu) : 0u;
+        uint32_t at = ((before + (incl - mine)) >> sh) & 0xffffu;   // entries of the threads before this one
         if (usedC || usedA)
             for (uint32_t g = 0; g < q && k0 + g < K; g += 4u) {
                 const uint4 bi = FLREG ? bi_keep : *(const uint4*)(s_best_idx + k0 + g), fl4 = FLREG ? rf : *(const uint4*)(s_kfl + k0 + g);
                 const uint32_t bv[4] = {bi.x, bi.y, bi.z, bi.w}, fv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+                const uint32_t keep = usedC ? mC_keep : mA_keep;
                 uint32_t ip[4]; bool wk[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {   // the four gathers are in flight together
-                    const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
-                    const uint32_t w = valid ? fv[j] : 0u;
-                    wk[j] = usedC ? w != 0u : (w & 3u) == 3u;
+                    if (FLREG) wk[j] = ((keep >> j) & 1u) != 0u;
+                    else {
+                        const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
+                        const uint32_t w = valid ? fv[j] : 0u;
+                        wk[j] = usedC ? w != 0u : (w & 3u) == 3u;
+                    }
                     ip[j] = wk[j] ? inv_perm[bv[j]] : 0u;
                 }
 #pragma unroll
