@@ -1612,14 +1612,12 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
 
     // ---- a slice beyond every list of the group has nothing to search or sum: zero record, done (the lists hold ~575 of
     //      up to 7 x 128 positions at the bench shape: two blocks in seven) ----
-    {
-        uint32_t nmax_u = 0u;
-        for (int cc = 0; cc < cands_here; ++cc) nmax_u = max(nmax_u, lcount[(size_t)(g * CG + cc) * nf + f]);   // uniform addresses: scalar loads
-        if ((uint32_t)sl * kSliceW >= nmax_u) {
-            const int cc = tid >> 5, q = tid & 31;
-            if (cc < cands_here && q < kNNPartial) nn_partials[((size_t)(g * CG + cc) * nn_nrec + (size_t)f * NS + sl) * kNNPartial + q] = 0.0;
-            return;
-        }
+    uint32_t nmax_u = 0u;
+    for (int cc = 0; cc < cands_here; ++cc) nmax_u = max(nmax_u, lcount[(size_t)(g * CG + cc) * nf + f]);   // uniform addresses: scalar loads
+    if ((uint32_t)sl * kSliceW >= nmax_u) {
+        const int cc = tid >> 5, q = tid & 31;
+        if (cc < cands_here && q < kNNPartial) nn_partials[((size_t)(g * CG + cc) * nn_nrec + (size_t)f * NS + sl) * kNNPartial + q] = 0.0;
+        return;
     }
     // ---- kd nodes -> LDS; list lengths of the group's candidates ----
     const uint32_t nnodes = (1u << D) - 1u;
@@ -1630,6 +1628,13 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
     uint32_t* s_sel = s_ctr + 4;                             // [kMaxGroup] anchor set of each candidate of the group (255: none)
     if (SETS && tid < kMaxGroup) s_sel[tid] = tid < cands_here ? (uint32_t)ka->anchor_sel[g * CG + tid] : 255u;
     if (tid < cands_here * kCdDoubles) s_cd[tid] = ((const double*)&cands[g * CG + tid / kCdDoubles])[12 + tid % kCdDoubles];
+    // (r04: the counters and the result slots are cleared HERE, before the block's first barrier — the slice's extent follows from the
+    //  list lengths every thread has just read — instead of behind two more barriers of their own)
+    if (tid == 0) { s_ctr[0] = 0u; s_ctr[1] = 0u; }
+    if ((WHICH & 2) && refit != kRefitSums) {
+        const uint32_t lo_u = min(nmax_u, (uint32_t)sl * kSliceW), hi_u = min(nmax_u, lo_u + kSliceW);
+        for (uint32_t i = tid; i < ((hi_u - lo_u) << cg_shift); i += T) s_res[i] = NAN;   // entries that turn out to want no cost search
+    }
     __syncthreads();
     if (dbg == 1) return;
     // Work entry w of the block = (candidate w % CG, list position i_lo + w / CG): the candidates' lists interleaved, so that the
@@ -1653,16 +1658,15 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
 
     {
         const uint32_t c0 = 0u, c1 = W;
-        if (tid == 0) *s_ctr = c0;
-        if (WHICH & 2) for (uint32_t i = tid; i < c1 - c0; i += T) {
-            double r = NAN;   // entries that turn out to want no cost search
-            if (refit == kRefitSums) {
+        if (refit == kRefitSums) {
+            if (WHICH & 2) for (uint32_t i = tid; i < c1 - c0; i += T) {
+                double r = NAN;
                 const uint32_t cc = i & ((1u << cg_shift) - 1u), il = i_lo + (i >> cg_shift);
                 if (il < s_n[cc]) r = frefit[((size_t)(g * CG + (int)cc) * nf + f) * (size_t)flist_stride + il].x;
+                s_res[i] = r;
             }
-            s_res[i] = r;
+            __syncthreads();
         }
-        __syncthreads();
         if (dbg == 2) return;
 
         // ---- the searches ----
@@ -1748,8 +1752,6 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                 // ---- the anchored neighbour lists of the MapPoint keypoints are there (iba_anchor_kernel).
                 //      One pass, no claiming: thread t takes the entries t, t + T, ...; per entry one dependent chain of three loads
                 //      (entry -> set -> plane records), the next entry's first load in flight meanwhile ----
-                if (tid == 0) s_ctr[1] = 0u;
-                __syncthreads();
                 // two entries per step: their loads are issued stage by stage (entries, then list rows), so a thread's four entries
                 // cost four dependent round trips instead of eight
                 auto fetch = [&](uint32_t wn, uint4& e, float4& mp) {
