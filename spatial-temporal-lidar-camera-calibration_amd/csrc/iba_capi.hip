@@ -476,7 +476,9 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
         const Cand* src = h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH;
         h->he_staged = with_he && h->n_frames > 0;
         h->head_slot = -1; h->head_deferred = false; h->side_in_use = false;
-        if (h->he_staged && h->side_on && h->side) {   // launched by run_split, on the side stream, right behind the pair search (launch_head)
+        // the side stream pays when there is a pair search to run beside (44 us against this launch's 9); a call whose groups all reuse
+        // earlier lists has nothing to hide the staging behind, and the two event hops cost it ~10 us (tools/chain_gaps.sh, B = 1)
+        if (h->he_staged && h->side_on && h->side && h->cref_ok && h->n_build > 0) {   // launched by run_split, on the side stream, right behind the pair search (launch_head)
             h->head_deferred = true; h->head_slot = slot; h->head_B = B; h->side_in_use = true;
         } else {
             if (h->he_staged) {   // K7 rides in the same launch (one kernel less at the head of every cost evaluation)
