@@ -375,12 +375,13 @@ def main():
             for _ in range(3):
                 step(0, [xb])
             sync()
-            t0 = time.perf_counter()
-            nrep = 20
-            for _ in range(nrep):
+            ts = []
+            for _ in range(50):   # (median of the calls' own wall times: a mean over 20 calls = 4 ms was at the mercy of one hiccup)
+                t0 = time.perf_counter()
                 step(0, [xb])
+                ts.append(time.perf_counter() - t0)
             sync()
-            wall = (time.perf_counter() - t0) / nrep
+            wall = float(np.median(ts))
             a, n, r = phases()
             sweep[str(b)] = {"wall_ms": wall * 1e3, "assoc_ms": a, "nn_ms": n, "factor_sums_ms": r, "evals_per_s": units * b / wall}
         extras["batch_sweep"] = sweep
