@@ -242,6 +242,13 @@ class Oracle:
         return k.value, far.value, nrm, reg.value
 
 
+    def plane_normal_sensitivity(self, frame, pt_idx, radius, max_pts):
+        """how far the plane normal at a scan point moves when its covariance entries move by one ulp (8 random sign draws)"""
+        sn = C.c_double(0)
+        lib().oracle_plane_normal_sensitivity(C.c_void_p(self.h), C.c_int(frame), C.c_uint32(pt_idx), C.c_double(radius), C.c_int(max_pts), C.byref(sn))
+        return sn.value
+
+
 # ---- unit-level helpers for the known-answer tests ----
 def sim3exp(x):
     x = np.ascontiguousarray(x, np.float64)

@@ -842,6 +842,51 @@ int oracle_plane_at(void* h, int frame, uint32_t pt_idx, double radius, int max_
     normal3[0] = n.x; normal3[1] = n.y; normal3[2] = n.z; *reg_err_sum = re;
     return 0;
 }
+// How far the plane normal at a scan point moves when the entries of its covariance matrix move by their own measured accuracy (the
+// double evaluation against the same formula in long double, at least one unit in the last place; signs drawn at random, eight
+// draws; the largest component difference, sign-aligned). The closed-form eigen-solver (FastEigen3x3_EV:
+// acos / cos of a ratio of nearly equal quantities) amplifies the last bits of what it is given — and of its own libm calls, which
+// the device evaluates with another libm: two correct evaluations of it may differ by a small multiple of this
+// (tests/parity_explain.py bounds the device-vs-oracle normal difference by it instead of by a fixed tolerance).
+int oracle_plane_normal_sensitivity(void* h, int frame, uint32_t pt_idx, double radius, int max_pts, double* sens) {
+    Oracle& O = *(Oracle*)h; const Frame& f = O.frames[frame];
+    std::vector<uint32_t> idx; std::vector<double> sq; size_t k;
+    const double* c = &f.pts[3 * (size_t)pt_idx];
+    knn_clip(f, c, max_pts, radius, idx, sq, k);
+    const M3d cov = ComputeCovariance(f.pts.data(), idx.data(), idx.size());
+    // the accuracy of the covariance itself: one-pass raw moments E[x x^T] - E[x] E[x]^T cancel (a neighbourhood 30 m from the sensor with
+    // a spread of decimetres loses four to five digits), and two summation orders of the same neighbours — the device sums them in
+    // its list order — differ by about that much: the same formula in long double is the measure
+    long double cl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t j : idx) {
+        const long double x = f.pts[3 * (size_t)j], y = f.pts[3 * (size_t)j + 1], z = f.pts[3 * (size_t)j + 2];
+        cl[0] += x; cl[1] += y; cl[2] += z; cl[3] += x * x; cl[4] += x * y; cl[5] += x * z; cl[6] += y * y; cl[7] += y * z; cl[8] += z * z;
+    }
+    const long double nn = idx.empty() ? 1.0L : (long double)idx.size();
+    for (long double& v : cl) v /= nn;
+    const long double covl[6] = {cl[3] - cl[0] * cl[0], cl[6] - cl[1] * cl[1], cl[8] - cl[2] * cl[2], cl[4] - cl[0] * cl[1], cl[5] - cl[0] * cl[2], cl[7] - cl[1] * cl[2]};
+    const double covd[6] = {cov(0, 0), cov(1, 1), cov(2, 2), cov(0, 1), cov(0, 2), cov(1, 2)};
+    double err[6];
+    for (int i = 0; i < 6; ++i) err[i] = (double)fabsl((long double)covd[i] - covl[i]) + std::fabs(covd[i]) * 0x1p-52;
+    double ev[3];
+    const V3d n0 = normalized(FastEigen3x3_EV(cov, ev));
+    uint64_t st = 0x2545F4914F6CDD1Dull ^ ((uint64_t)pt_idx << 20) ^ (uint64_t)frame;
+    int at = 0;
+    auto flip = [&](double v) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; const double e = err[at++ % 6]; return v + ((st >> 33) & 1ull ? e : -e); };
+    double worst = 0.0;
+    for (int draw = 0; draw < 8; ++draw) {
+        M3d cp = cov;
+        at = 0;
+        cp(0, 0) = flip(cov(0, 0)); cp(1, 1) = flip(cov(1, 1)); cp(2, 2) = flip(cov(2, 2));
+        cp(0, 1) = flip(cov(0, 1)); cp(1, 0) = cp(0, 1); cp(0, 2) = flip(cov(0, 2)); cp(2, 0) = cp(0, 2); cp(1, 2) = flip(cov(1, 2)); cp(2, 1) = cp(1, 2);
+        V3d n = normalized(FastEigen3x3_EV(cp, ev));
+        if (dot(n, n0) < 0) n = V3d{-n.x, -n.y, -n.z};
+        const double d = std::max(std::max(std::fabs(n.x - n0.x), std::fabs(n.y - n0.y)), std::fabs(n.z - n0.z));
+        worst = (d == d) ? std::max(worst, d) : 1.0;
+    }
+    *sens = worst;
+    return 0;
+}
 int oracle_num_factors(void* h) { return (int)((Oracle*)h)->factors.size(); }
 
 // ---- unit-level exports for the known-answer tests ----

@@ -39,7 +39,8 @@ GATE = 1e-10          # per entry, relative to the entry itself
 ENTRY_FLOOR = 1e-6    # entries below this fraction of the largest are compared against the largest instead
 ROW_FLOOR = 1e-12     # rows of a well-conditioned block agree to this (of the block's scale)
 C_FWD = 4.0           # rows of a deviating block, inputs equalised: within C_FWD * E, E = the block's measured yardstick (forward error, sensitivities)
-NORMAL_TOL = 1e-11    # device vs oracle plane normal (unit vectors, sign-aligned), absolute: two libm evaluations of the closed-form eigenvector
+NORMAL_TOL = 1e-11    # device vs oracle plane normal (unit vectors, sign-aligned), absolute: two libm evaluations of the closed-form eigenvector ...
+C_NORMAL = 16.0       # ... or within this multiple of what the covariance's own accuracy (double vs long double, one-pass raw moments) does to the normal at that point (oracle_plane_normal_sensitivity)
 SUM_TOL = 1e-12       # an entry of H / b: within this of the sum of the absolute values of its terms (two summation orders)
 
 
@@ -131,7 +132,9 @@ def explain(h, o, p, x, nthreads=1):
                 n_d = -n_d                                            # the sign of an eigenvector is arbitrary
             dn = float(np.max(np.abs(n_d - n_o)))
             worst_normal = max(worst_normal, dn)
-            assert dn <= NORMAL_TOL, "block %d: the device's plane normal differs from the oracle's by %.2e" % (i, dn)
+            if dn > NORMAL_TOL:   # beyond the usual agreement: the eigen-solver itself must be that sensitive at this point, measured
+                sn = o.plane_normal_sensitivity(frame, int(hit[0]), p.neigh_radius, p.neigh_max_pts)
+                assert dn <= C_NORMAL * sn, "block %d: the device's plane normal differs from the oracle's by %.2e; the covariance's own accuracy moves it by %.2e only" % (i, dn, sn)
             r2, J2, e2 = o.block_rows_with_normal(int(bo[lo]), x, n_d, hi - lo)
             if ko[lo] == 1 and np.max(np.abs(r2 + rg[lo:hi])) < np.max(np.abs(r2 - rg[lo:hi])):
                 r2, J2 = -r2, -J2                                     # a flipped normal flips the 1-d point-to-plane residual: harmless for H, b

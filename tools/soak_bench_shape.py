@@ -12,7 +12,7 @@ from oracle import binding as ob
 ob.lib()
 INT = ("valid_cnt_3d_2d", "cnt_3d_2d", "cnt_3d_3d", "valid_cnt_3d_3d", "valid_pl_3d_3d", "valid_pt_3d_3d", "frames_used", "n_corr")
 bad = 0; worst = 0.0; t0 = time.time()
-for sc in range(int(sys.argv[1])):
+for sc in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
     seed = 70000 + sc
     rng = np.random.default_rng(seed)
     prob, meta = synth.make_scene(n_frames=int(rng.integers(6, 13)), pts_per_frame=10000, n_keypoints=2000, seed=seed)
