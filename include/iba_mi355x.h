@@ -71,7 +71,8 @@ typedef struct iba_problem_desc {
     const float* Tcw; /* [F*12] */
 
     /* pKF->GetBestCovisibilityKeyFramesSafe(num_best_covis) (or ByWeight), iba_global.cpp:254-258.
-     * One "slot" per (reference KF, covisible KF) pair; at most 30 per reference KF. */
+     * One "slot" per (reference KF, covisible KF) pair; at most 62 per reference KF (30 match bits in the keypoint's flag word, a
+     * second word for the slots beyond them; more: IBA_ERR_UNSUPPORTED). */
     const uint64_t* covis_offset; /* [F+1] slots of frame f are covis_offset[f]..covis_offset[f+1] */
     const int32_t* covis_frame;   /* [S] frame index of the covisible KF */
     /* pKFConv->GetPose() * InvRefCVPose evaluated in CV_32F (iba_global.cpp:280), top 3 rows

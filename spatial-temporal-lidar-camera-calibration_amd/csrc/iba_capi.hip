@@ -123,7 +123,7 @@ struct iba_handle {
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
     DevBuf<float> xs, ys, zs, chunk_box; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
     DevBuf<float4> pts4;   // the same scan points as (x, y, z, original index bits): one 16 B gather per point where lanes diverge
-    DevBuf<float2> kp_uv; DevBuf<float4> kp_mp; DevBuf<uint32_t> kp_fl;
+    DevBuf<float2> kp_uv; DevBuf<float4> kp_mp; DevBuf<uint32_t> kp_fl, kp_fl2;   // kp_fl2: match bits of the covisible slots 30..61 (allocated only when a frame has that many)
     DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
     DevBuf<PlaneRec> plane_cost, plane_local;
@@ -169,7 +169,7 @@ struct iba_handle {
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.plane_ok = plane_ok.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
-        dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u);
+        dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u); dp.kp_fl2 = kp_fl2.p;
         return dp;
     }
 };
@@ -569,7 +569,8 @@ iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, do
     // which is what the sums over the records expect)
     const dim3 grid(h->n_frames, B);
     const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
-    if (h->factor_valu) hipLaunchKernelGGL(iba_factor_kernel, grid, dim3(kFactorThreads), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+    if (h->factor_valu && h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL(iba_factor_kernel<true>, grid, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+    else if (h->factor_valu) hipLaunchKernelGGL(iba_factor_kernel<false>, grid, dim3(kFactorThreads), 96u * std::max<uint32_t>(h->max_slots, 1u), st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
     else hipLaunchKernelGGL(iba_factor_mfma_kernel, grid, dim3(64), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;
@@ -820,7 +821,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->d_anchor.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->kp_fl2.release(); h->d_anchor.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -879,12 +880,14 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     h->device = device; h->params = *params; to_dev_params(*params, h->dprm);
     h->global_frames = F; h->frame_begin = frame_begin; h->n_frames = frame_end - frame_begin;
     const int nf = h->n_frames;
+    bool many_slots = false;   // some frame has more covisible keyframes than the flag word has match bits
 
     for (int f = frame_begin; f < frame_end; ++f) {
         const uint64_t P = d->pt_offset[f + 1] - d->pt_offset[f], K = d->kp_offset[f + 1] - d->kp_offset[f];
         if (P >= (1ull << 22) || K >= 65535ull) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "scan (>= 2^22 points) or keypoint count (>= 65535) too large"); }
         const uint64_t ns = d->covis_offset[f + 1] - d->covis_offset[f];
-        if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 30 covisible keyframes per frame"); }
+        if (ns > (uint64_t)kMaxCovis) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "more than 62 covisible keyframes per frame"); }
+        if (ns > (uint64_t)kCovisWord) many_slots = true;
         h->max_slots = std::max<uint32_t>(h->max_slots, (uint32_t)ns);
     }
 
@@ -964,6 +967,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     std::vector<float2> match_uv(match_base, float2{qnan, qnan});
     std::vector<SlotHdr> slots(slot_base);
     std::vector<uint32_t> kp_fl(kp_base, 0u);   // flag word of every keypoint (see the match loop)
+    std::vector<uint32_t> kp_fl2(many_slots ? (size_t)kp_base : 0, 0u);
     std::atomic<bool> bad_match(false);
     parallel_for(nf, [&](int lf) {
         const int f = frame_begin + lf; const FrameHdr& x = hdr[lf]; const FrameBuild& b = fb[lf];
@@ -1010,7 +1014,8 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
                 if (kr < 0 || (uint32_t)kr >= x.K || kc < 0 || (uint64_t)kc >= cK) { bad_match = true; continue; }
                 match_uv[x.match_base + (uint64_t)sl * x.K + b.kp_inv[kr]] = float2{d->kp_uv[2 * (ck0 + kc)], d->kp_uv[2 * (ck0 + kc) + 1]};
                 // flag word = 1 (owns a MapPoint) | 2 (matched in >= 1 covisible KF) | per-slot match bits << 2 (up to 30 slots)
-                kp_fl[x.kp_base + b.kp_inv[kr]] |= 2u | (4u << sl);
+                if (sl < (uint32_t)kCovisWord) kp_fl[x.kp_base + b.kp_inv[kr]] |= 2u | (4u << sl);
+                else { kp_fl[x.kp_base + b.kp_inv[kr]] |= 2u; kp_fl2[x.kp_base + b.kp_inv[kr]] |= 1u << (sl - (uint32_t)kCovisWord); }
             }
         }
     });
@@ -1069,6 +1074,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     h->h_kp_uv.resize(2 * (size_t)kp_base);
     for (size_t k = 0; k < (size_t)kp_base; ++k) { h->h_kp_uv[2 * k] = kp_uv[k].x; h->h_kp_uv[2 * k + 1] = kp_uv[k].y; }
     UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(kp_fl, kp_fl); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv); UP(mpk, mpk);
+    if (many_slots) UP(kp_fl2, kp_fl2);
 #undef UP
     hipError_t er;
     if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);

@@ -49,6 +49,7 @@ struct DevProblem {
     int64_t n_pt_total;
     int32_t scratch_slot_base;
     const uint32_t* mpk;       // per frame: the keypoints that own a MapPoint (FrameHdr::mpk_base, n_mpk)
+    const uint32_t* kp_fl2;    // match bits of the covisible slots 30..61 per keypoint (nullptr: no frame has more than 30 slots)
     uint32_t max_k;            // largest keypoint count of a frame: row pitch of the per-(frame, keypoint) tables
 };
 
@@ -653,7 +654,10 @@ __device__ __forceinline__ int hidx(int i, int j) { return i * 7 - (i * (i - 1))
 
 // IBA_PlaneFactor core: calls slot(ru, rv, gu, gv, hu, hv) per matched covisible KF, where the two residual rows are
 // (ru, rv) and their Jacobian rows are [gu * z6, hu], [gv * z6, hv] (z6 = dZ0/dx[0:6], last column d/ds).
-template <class SlotFn>
+// MANY: the frame may have more covisible keyframes than the flag word has match bits (a second pass over kp_fl2); the instantiation
+// without it is the loop of rounds 1-3 (the two-word loop cost iba_factor_kernel 3 % at three covisible keyframes: handles whose
+// frames all have at most 30 launch the <false> kernel)
+template <bool MANY = true, class SlotFn>
 __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K,
                                                  double u0, double v0, const double* p0, const double* n0, double* z6, SlotFn slot, const double* rel_lds = nullptr) {
     IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
@@ -684,37 +688,45 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
     int nconv = 0;
     // only the covisible slots whose match bit is set in the keypoint flags (kp_fl >> 2), in slot order; the next
     // match is in flight during the arithmetic of the current one
-    uint32_t mask = (dp.kp_fl[h.kp_base + k] >> 2) & ((1u << kMaxCovis) - 1u);
     const float2* mrow = dp.match_uv + h.match_base + k;
-    float2 mnext = mask ? mrow[(size_t)(__ffs((int)mask) - 1) * K] : make_float2(0.f, 0.f);
-    while (mask) {
-        const uint32_t sl = (uint32_t)__ffs((int)mask) - 1u;
-        mask &= mask - 1u;
-        const float2 m = mnext;
-        if (mask) mnext = mrow[(size_t)(__ffs((int)mask) - 1) * K];
-        const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel;   // the frame's relative poses: the caller's LDS copy, or global memory
-        const double tx = rel[3] * c.s, ty = rel[7] * c.s, tz = rel[11] * c.s;   // _t *= _s (IBACalib2.hpp:175)
-        const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx;
-        const double P1y = ((rel[4] * P0x + rel[5] * P0y) + rel[6] * P0z) + ty;
-        const double P1z = ((rel[8] * P0x + rel[9] * P0y) + rel[10] * P0z) + tz;
-        const double ru = (h.fx * P1x / P1z + h.cx) - (double)m.x;
-        const double rv = (h.fy * P1y / P1z + h.cy) - (double)m.y;
-        const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[4] * Cxz + rel[5] * Cyz) + rel[6], az = (rel[8] * Cxz + rel[9] * Cyz) + rel[10];
-        const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
-        const double gu = h.fx * iz * (ax - xz * az), gv = h.fy * iz * (ay - yz * az);
-        const double hu = h.fx * iz * (rel[3] - xz * rel[11]), hv = h.fy * iz * (rel[7] - yz * rel[11]);
-        slot(ru, rv, gu, gv, hu, hv);
-        ++nconv;
+    // one pass per flag word: the slots 0..29 of the keypoint's flag word, then — frames with more covisible keyframes only, a
+    // block-uniform branch — the slots 30..61 of its second word (kp_fl2)
+    const int n_words = (MANY && h.n_slots > (uint32_t)kCovisWord) ? 2 : 1;   // (block-uniform)
+#pragma unroll 1
+    for (int wi = 0; wi < n_words; ++wi) {   // ONE copy of the loop body for both words (two inlined copies cost the kernel 3 %: code size)
+        uint32_t mask = (!MANY || wi == 0) ? dp.kp_fl[h.kp_base + k] >> 2 : dp.kp_fl2[h.kp_base + k];
+        const uint32_t base = (!MANY || wi == 0) ? 0u : (uint32_t)kCovisWord;
+        float2 mnext = mask ? mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K] : make_float2(0.f, 0.f);
+        while (mask) {
+            const uint32_t sl = base + (uint32_t)__ffs((int)mask) - 1u;
+            mask &= mask - 1u;
+            const float2 m = mnext;
+            if (mask) mnext = mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K];
+            const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel;   // the frame's relative poses: the caller's LDS copy, or global memory
+            const double tx = rel[3] * c.s, ty = rel[7] * c.s, tz = rel[11] * c.s;   // _t *= _s (IBACalib2.hpp:175)
+            const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx;
+            const double P1y = ((rel[4] * P0x + rel[5] * P0y) + rel[6] * P0z) + ty;
+            const double P1z = ((rel[8] * P0x + rel[9] * P0y) + rel[10] * P0z) + tz;
+            const double ru = (h.fx * P1x / P1z + h.cx) - (double)m.x;
+            const double rv = (h.fy * P1y / P1z + h.cy) - (double)m.y;
+            const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[4] * Cxz + rel[5] * Cyz) + rel[6], az = (rel[8] * Cxz + rel[9] * Cyz) + rel[10];
+            const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
+            const double gu = h.fx * iz * (ax - xz * az), gv = h.fy * iz * (ay - yz * az);
+            const double hu = h.fx * iz * (rel[3] - xz * rel[11]), hv = h.fy * iz * (rel[7] - yz * rel[11]);
+            slot(ru, rv, gu, gv, hu, hv);
+            ++nconv;
+        }
     }
     return nconv;
 }
 
+template <bool MANY>
 __device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
                                           double u0, double v0, const double* p0, const double* n0, NAcc& A, const double* rel_lds = nullptr) {
     IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
     double z6[6];
     double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0;
-    const int nconv = plane_factor_core(c, h, dp, k, K, u0, v0, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
+    const int nconv = plane_factor_core<MANY>(c, h, dp, k, K, u0, v0, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
 IBA_ACC_CONTRACT
         ssq += ru * ru + rv * rv;
         G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
@@ -787,12 +799,13 @@ constexpr int kFactorThreads = IBA_FACTOR_THREADS;
 // grid: (n_frames, B), kFactorThreads threads (one wave). Works through the dense residual-block list the association pass left for this
 // (candidate, frame): every lane owns a keypoint that has at least one block. list row = (per_cand ? b : 0).
 // record (b, rec_base + frame) of `partials` receives this block's sums.
+template <bool MANY>
 __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(IBA_FACTOR_WAVES, IBA_FACTOR_WAVES))) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist,
                                                                     const uint32_t* __restrict__ fcount, int flist_stride, int per_cand,
                                                                     double* __restrict__ partials, int nrec, int rec_base) {
     __shared__ double s_part[kFactorThreads / 64][48];
     __shared__ double s_tr[kFactorThreads / 64][21][65];   // [sum][lane], rows padded against bank conflicts
-    __shared__ double s_rel[kMaxCovis * 12];               // relative poses of the frame's covisible slots
+    extern __shared__ __align__(16) double s_rel[];        // relative poses of the frame's covisible slots: 12 doubles each, sized by the launch for the handle's largest slot count (r04: 62 slots as a static array cost every block 3 KB and the kernel 2 %)
     const int f = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameHdr& h = dp.frames[f];
@@ -825,7 +838,7 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
             const float4 pt = p4[q.y];
             const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, n0[3] = {rec.nx, rec.ny, rec.nz};
             const float2 uv = dp.kp_uv[h.kp_base + q.x];
-            plane_factor_accum(c, h, dp, prm, q.x, h.K, (double)uv.x, (double)uv.y, p0, n0, A, s_rel);
+            plane_factor_accum<MANY>(c, h, dp, prm, q.x, h.K, (double)uv.x, (double)uv.y, p0, n0, A, s_rel);
         }
         ha += min(cnt, 64u);
     };

@@ -200,31 +200,38 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     if (usedC) {
         for (uint32_t i = tid; i < n3; i += kThreads) {
             const uint32_t k = s_list[i] & 0xffffu, pos = s_pos[i];
-            uint32_t mask = FLREG ? s_msk[i] : s_kfl[k] >> 2;
-            if (!mask) continue;
+            const uint32_t mask_lo = FLREG ? s_msk[i] : s_kfl[k] >> 2;
+            const uint32_t mask_hi = h.n_slots > (uint32_t)kCovisWord ? dp.kp_fl2[h.kp_base + k] : 0u;   // (block-uniform: a frame with more than 30 covisible keyframes)
+            if (!(mask_lo | mask_hi)) continue;
             float xf_, yf_, zf_; load_pt<true>(c, pos, xf_, yf_, zf_);
             const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
             const double p0x = ((c.R[0] * x + c.R[1] * y) + c.R[2] * z) + c.t[0];
             const double p0y = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
             const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
             const float2* mrow = dp.match_uv + h.match_base + k;
-            float2 mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];
-            while (mask) {
-                const uint32_t sl = (uint32_t)__ffs((int)mask) - 1u;
-                mask &= mask - 1u;
-                const float2 cur = mm;
-                if (mask) mm = mrow[(size_t)(__ffs((int)mask) - 1) * K];   // next match is in flight during the arithmetic
-                const double* rel = s_rel + sl * 12;
-                const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
-                const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
-                const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
-                const double ou = h.fx * p1x / p1z + h.cx;
-                const double ov = h.fy * p1y / p1z + h.cy;
-                if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
-                const double eu = ou - (double)cur.x, ev = ov - (double)cur.y;
-                const double dist = sqrt(eu * eu + ev * ev);
-                if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
-                ++c2;
+#pragma unroll 1
+            for (int wi = 0; wi < (mask_hi ? 2 : 1); ++wi) {   // the slots of one flag word after the other, in slot order (one copy of the loop body)
+                uint32_t mask = wi == 0 ? mask_lo : mask_hi;
+                const uint32_t base = wi == 0 ? 0u : (uint32_t)kCovisWord;
+                if (!mask) continue;
+                float2 mm = mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K];
+                while (mask) {
+                    const uint32_t sl = base + (uint32_t)__ffs((int)mask) - 1u;
+                    mask &= mask - 1u;
+                    const float2 cur = mm;
+                    if (mask) mm = mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K];   // next match is in flight during the arithmetic
+                    const double* rel = s_rel + sl * 12;
+                    const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
+                    const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
+                    const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
+                    const double ou = h.fx * p1x / p1z + h.cx;
+                    const double ov = h.fy * p1y / p1z + h.cy;
+                    if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
+                    const double eu = ou - (double)cur.x, ev = ov - (double)cur.y;
+                    const double dist = sqrt(eu * eu + ev * ev);
+                    if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
+                    ++c2;
+                }
             }
         }
     }

@@ -14,7 +14,8 @@ namespace iba {
 #define IBA_CHUNK 64
 #endif
 constexpr int kChunk = IBA_CHUNK;           // points per culling chunk (~3 kd leaves): static AABB, frustum-tested per candidate
-constexpr int kMaxCovis = 30;        // covisible KFs per frame: one match bit each beside the two flag bits of the 32-bit flag word (kp_fl)
+constexpr int kCovisWord = 30;       // covisible KFs whose match bits sit beside the two flag bits of the 32-bit flag word (kp_fl) ...
+constexpr int kMaxCovis = 62;        // ... and with a second word per keypoint (kp_fl2: slots 30..61, read from global memory only by frames that have them; r04) the limit per frame
 constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum block
 #ifndef IBA_GRID_CELL
 #define IBA_GRID_CELL 2

@@ -88,7 +88,7 @@ def test_more_than_sixty_four_candidates_per_call(pkg, synth, abi, scene_small):
 
 def test_twenty_eight_covisible_keyframes(pkg, synth, abi, ob):
     """GetCovisiblesByWeightSafe (iba_global.cpp:259) is unbounded; the flag word holds one match bit per covisible keyframe:
-    30 of them since round 3 (22 before)."""
+    30 of them since round 3 (22 before); a second word carries the slots 30..61 since round 4 (test_forty_covisible_keyframes)."""
     prob, meta = synth.make_scene(n_frames=32, pts_per_frame=2500, n_keypoints=700, seed=43, n_covis=28, new_mappoints=120, scan_kp=160)
     assert int(np.diff(prob.arrays["covis_offset"].astype(np.int64)).max()) == 28
     p = abi.reference_yaml_params()
@@ -97,6 +97,36 @@ def test_twenty_eight_covisible_keyframes(pkg, synth, abi, ob):
     cost, nrm = _check(h, o, p, xs)
     assert cost[0].cnt_3d_2d > 3 * cost[0].n_corr
     h.close()
+
+
+def test_forty_covisible_keyframes(pkg, synth, abi, ob):
+    """Beyond the 30 match bits of the flag word (r04): the covisible slots 30..61 of a keypoint sit in a second word that only frames
+    with that many covisible keyframes read. 40 of them, against the oracle — cost path (3d-2d terms of every slot), normal equations
+    (IBA_PlaneFactor blocks of up to 80 rows), residual rows, the refit mode; 63 are refused."""
+    prob, meta = synth.make_scene(n_frames=44, pts_per_frame=2500, n_keypoints=700, seed=45, n_covis=40, new_mappoints=120, scan_kp=160)
+    assert int(np.diff(prob.arrays["covis_offset"].astype(np.int64)).max()) == 40
+    p = abi.reference_yaml_params()
+    h, o = pkg.IbaHandle(prob, p), ob.Oracle(prob)
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(45), n=4)])
+    cost, nrm = _check(h, o, p, xs)
+    assert cost[0].cnt_3d_2d > 4 * cost[0].n_corr
+    h.build_problem(xs[1])
+    o.build_problem(p, xs[1])
+    rg, Jg, bg, kg = h.eval_residuals(xs[2])
+    ro, Jo, bo, ko, _ = o.eval_residuals(xs[2])
+    assert np.array_equal(kg, ko) and np.array_equal(bg, bo) and np.allclose(rg, ro, rtol=1e-9, atol=1e-9) and np.allclose(Jg, Jo, rtol=1e-8, atol=1e-8 * np.abs(Jo).max())
+    co, mo = prob.arrays["covis_offset"].astype(np.int64), prob.arrays["match_offset"].astype(np.int64)
+    beyond = sum(int(mo[gs + 1] - mo[gs]) for f in range(44) for gs in range(co[f] + 30, co[f + 1]))
+    assert beyond > 1000 and np.bincount(bo[ko == 0]).max() > 40   # matches in the slots the second word carries; blocks of more than 20 covisible matches
+    h.close()
+    hr = pkg.IbaHandle(prob, abi.reference_yaml_params(plane_cache=0))
+    cr, nr = hr.eval_full(xs[:2])
+    for a, b in zip(cost, cr):
+        assert all(x == y or (x != x and y != y) for x, y in zip(a.as_dict().values(), b.as_dict().values()))
+    hr.close()
+    prob63, _ = synth.make_scene(n_frames=66, pts_per_frame=600, n_keypoints=200, seed=46, n_covis=63, new_mappoints=40, scan_kp=60)
+    with pytest.raises(pkg.IbaError):
+        pkg.IbaHandle(prob63, p)
 
 
 def test_max_pixel_dist_changes_on_a_live_handle(pkg, synth, abi, ob):
