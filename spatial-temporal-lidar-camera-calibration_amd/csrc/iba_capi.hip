@@ -227,7 +227,7 @@ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 // of half of the LDS (two blocks per CU) is split between queue and pair list; a full queue or list only costs speed (inline
 // exact tests + a rescan), never correctness.
 bool layout_assoc(iba_handle* h, LdsLayout& L) {
-    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;
+    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u + 4u * (uint32_t)kHardLds;   // (+ the undecidable-depth points of a block)
     L = LdsLayout{};
     uint32_t off = 0;
     const uint32_t Kp = (std::max(h->maxK, 1u) + 3u) & ~3u;   // per-keypoint tables hold a multiple of 4 entries: the tail reads them 16 bytes at a time

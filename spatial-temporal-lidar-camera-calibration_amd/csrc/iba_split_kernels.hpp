@@ -60,6 +60,7 @@ struct NNArgs {
 // list entry flags (uint4.w) written by iba_assoc_kernel
 constexpr uint32_t kFlagC = 1u;   // cost-path 1-NN wanted (keypoint owns a MapPoint, frame counts for BAError, 3d-3d enabled)
 constexpr int kRefitSearch = 1, kRefitSums = 2;
+constexpr int kHardLds = 256;   // iba_assoc_kernel: scan points within 0.1 m of the camera plane that a block notes for its tie pass (more: the full rescan)
 constexpr uint32_t kFlagA = 2u;   // association-path 1-NN wanted (ComputeLocalNeighbor at the matched point is valid)
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     double* s_rel = s_red + kWaves * 4;
     uint32_t* s_wcnt = (uint32_t*)(s_rel + kMaxCovis * 12);
     uint32_t* s_misc = s_wcnt + kWaves;
+    uint32_t* s_hard = s_misc + 4;                            // [kHardLds] tree positions of the points the float pass could not decide (s_misc[3] of them)
     uint32_t* s_cand = (uint32_t*)(smem + lay.off_cand);
     uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 after phase 2
     float2* s_kuv = (float2*)(smem + lay.off_kuv);            // (u, v) of every keypoint; keypoint ids are in grid-record order
@@ -522,10 +524,14 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
             if (i + kThreads < ncand) { pos_n = s_cand[i + kThreads]; pv_n = c.p4[pos_n]; }
             if (i < ncand) {
                 const float zc = fmaf(r6, pv.x, fmaf(r7, pv.y, fmaf(r8, pv.z, t2)));
-                if (!(zc > 0.1f)) {   // undecidable in f32 (queued by phase 1a for that reason): exact path inline, ties by the full rescan
+                if (!(zc > 0.1f)) {   // undecidable in f32 (queued by phase 1a for that reason): exact path inline; the point is noted for the tie pass
                     double u, v;
                     if (project_uv(c, pv.x, pv.y, pv.z, u, v)) grid_match<1>(c, u, v, pos);
-                    s_misc[1] = 1u;
+                    // (Rounds 2-3 raised the overflow flag here, and with it a rescan of EVERY scan point in f64 for the ties: a 360-degree
+                    //  scan always has a few dozen points within 0.1 m of the camera plane, so every block rescanned — 255 of the kernel's
+                    //  716 us on a box-wide batch, tools/wide_cuts.sh. Now only these points are walked again.)
+                    const uint32_t hs = atomicAdd(&s_misc[3], 1u);
+                    if (hs < (uint32_t)kHardLds) s_hard[hs] = pos; else s_misc[1] = 1u;
                 } else {
                     const float xc = fmaf(r0, pv.x, fmaf(r1, pv.y, fmaf(r2, pv.z, t0)));
                     const float yc = fmaf(r3, pv.x, fmaf(r4, pv.y, fmaf(r5, pv.z, t1)));
@@ -595,7 +601,15 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
         const uint4 pr = s_pair[i];
         if (pr.y != kNone && s_best_d2[pr.y] == ((unsigned long long)pr.z | ((unsigned long long)pr.w << 32))) atomicMin(&s_best_idx[pr.y], pr.x);
     }
-    if (overflow) {   // some exact tests ran inline: every point again, for the ties
+    {   // the points whose depth the float pass could not decide: their exact walk again, for the ties
+        const uint32_t nhard = min(s_misc[3], (uint32_t)kHardLds);
+        for (uint32_t i = tid; i < nhard; i += kThreads) {
+            const uint32_t pos = s_hard[i];
+            double u, v;
+            if (project_pos<true>(c, pos, u, v)) grid_match<2>(c, u, v, pos);
+        }
+    }
+    if (overflow) {   // some other exact tests ran inline (a full queue or pair list, a fifth hit of one point, more undecidable points than the list holds): every point again, for the ties
         for (uint32_t pos = tid; pos < P; pos += kThreads) {
             double u, v;
             if (project_pos<true>(c, pos, u, v)) grid_match<2>(c, u, v, pos);
