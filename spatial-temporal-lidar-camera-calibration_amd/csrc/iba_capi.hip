@@ -227,8 +227,10 @@ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 // of half of the LDS (two blocks per CU) is split between queue and pair list; a full queue or list only costs speed (inline
 // exact tests + a rescan), never correctness.
 bool layout_assoc(iba_handle* h, LdsLayout& L) {
-    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u + 4u * (uint32_t)kHardLds;   // (+ the undecidable-depth points of a block)
+    const uint32_t rel_slots = std::max<uint32_t>(h->max_slots, 1u);   // (62 slots' worth for every handle took 3 KB from the queue and the pair list of handles with 3)
+    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * rel_slots * 12u + 4u * kWaves + 16u + 4u * (uint32_t)kHardLds;   // (+ the undecidable-depth points of a block)
     L = LdsLayout{};
+    L.rel_slots = rel_slots;
     uint32_t off = 0;
     const uint32_t Kp = (std::max(h->maxK, 1u) + 3u) & ~3u;   // per-keypoint tables hold a multiple of 4 entries: the tail reads them 16 bytes at a time
     L.off_best_d2 = off; off += 8u * Kp;
@@ -280,8 +282,10 @@ bool layout_nn(const iba_handle* h, NNLayout& L) {
 bool assoc2_flreg(const iba_handle* h) { return h->assoc2_flreg_on && h->maxK <= 4u * (uint32_t)kThreads; }
 // LDS plan of iba_assoc2_kernel: best d^2, best index and flag word per keypoint, the reduction slab
 bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
-    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * kMaxCovis * 12u + 4u * kWaves + 16u;
+    const uint32_t rel_slots = std::max<uint32_t>(h->max_slots, 1u);
+    const uint32_t red_bytes = 8u * kWaves * 4u + 8u * rel_slots * 12u + 4u * kWaves + 16u;
     L = LdsLayout{};
+    L.rel_slots = rel_slots;
     uint32_t off = 0;
     const uint32_t Kp = (std::max(h->maxK, 1u) + 3u) & ~3u;
     L.off_best_d2 = off; off += 8u * Kp;

@@ -58,6 +58,7 @@ struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from
     uint32_t off_best_d2, off_best_idx, off_nodes, off_bitmap, off_cstart, off_red, off_vis, vis_words, off_cand, cand_cap, total;
     uint32_t off_pair, pair_cap;   // iba_assoc_kernel only: (point, keypoint) pairs, 16 B each
     uint32_t off_kuv, off_kfl;     // iba_assoc_kernel only: (u, v) and flag word of every keypoint
+    uint32_t rel_slots;            // covisible slots the relative-pose slab behind the reduction slab is sized for (the handle's busiest frame)
 };
 struct KArgs { DevProblem dp; DevParams prm; LdsLayout lay; };   // the frame kernel's parameter blocks, first kernel argument
 

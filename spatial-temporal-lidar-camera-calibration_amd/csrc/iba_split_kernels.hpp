@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     uint16_t* s_cstart = (uint16_t*)(smem + lay.off_cstart);
     double* s_red = (double*)(smem + lay.off_red);
     double* s_rel = s_red + kWaves * 4;
-    uint32_t* s_wcnt = (uint32_t*)(s_rel + kMaxCovis * 12);
+    uint32_t* s_wcnt = (uint32_t*)(s_rel + lay.rel_slots * 12u);
     uint32_t* s_misc = s_wcnt + kWaves;
     uint32_t* s_hard = s_misc + 4;                            // [kHardLds] tree positions of the points the float pass could not decide (s_misc[3] of them)
     uint32_t* s_cand = (uint32_t*)(smem + lay.off_cand);
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
     double* s_red = (double*)(smem + lay.off_red);
     double* s_rel = s_red + kWaves * 4;
     uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 once the winners are known
-    uint32_t* s_qn = (uint32_t*)(s_rel + kMaxCovis * 12) + kWaves;   // [0]: pairs noted for the tie pass
+    uint32_t* s_qn = (uint32_t*)(s_rel + lay.rel_slots * 12u) + kWaves;   // [0]: pairs noted for the tie pass
     uint16_t* s_q = (uint16_t*)(smem + lay.off_pair);                // their numbers (pair lists hold at most 65 536 records)
     const uint32_t K = h.K, P = h.P;
     const uint32_t ut = (uint32_t)tid;
