@@ -315,6 +315,8 @@ int32_t iba_debug_pairs_builds(const iba_handle* h);
 double iba_debug_nn_left_to_tree(iba_handle* h);
 /* diagnostic: mean number of (scan point, keypoint) pairs per keyframe that the last shared pair search listed; -1: none ran */
 double iba_debug_mean_pairs(iba_handle* h);
+/* debug: {pair lists of the last call that had overflowed (their blocks rescan every point: speed only), lists read, longest list} */
+iba_status iba_debug_pair_lists(iba_handle* h, int32_t out3[3]);
 /* debug: exact 1-NN (nanoflann semantics with the lowest-index tie rule, iba_global.cpp:116-122) of n LiDAR-frame query
  * points in the scan of local frame `frame`, run through the search kernel's own kd search, one lane per query: original point
  * index and exact squared distance. mode 1: as the association path's query alone; 2: as the cost path's alone; 3 / 4: both paths

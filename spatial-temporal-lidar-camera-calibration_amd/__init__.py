@@ -301,6 +301,14 @@ class IbaHandle:
         return int(self.lib.iba_debug_pairs_builds(self.h))
 
     @property
+    def pair_lists(self):
+        """(overflowed pair lists, pair lists read, longest list) of the last call"""
+        out = (C.c_int32 * 3)()
+        self.lib.iba_debug_pair_lists.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self._chk(self.lib.iba_debug_pair_lists(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    @property
     def mean_pairs(self):
         self.lib.iba_debug_mean_pairs.restype = C.c_double
         self.lib.iba_debug_mean_pairs.argtypes = [C.c_void_p]

@@ -1333,6 +1333,23 @@ double iba_debug_mean_pairs(iba_handle* h) {
     double t = 0; for (int f = 0; f < h->n_frames; ++f) t += v[(size_t)f * kCountStride];
     return t / h->n_frames;
 }
+// debug: of the (list slot, frame) pair lists the last call's candidates read, how many had overflowed (a list or a hard list that did not
+// hold everything: its blocks rescan every scan point exactly — speed only) and the largest list; out3 = {overflowed lists, lists, longest list}
+iba_status iba_debug_pair_lists(iba_handle* h, int32_t out3[3]) {
+    if (!h || !out3) return IBA_ERR_INVALID_ARG;
+    out3[0] = out3[1] = out3[2] = 0;
+    if (!h->d_pcounts.p || h->n_frames == 0 || h->last_path == 0) return IBA_OK;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, IBA_ERR_HIP, "sync");
+    bool used[kMaxPairGroups] = {false, false, false, false};
+    for (int b = 0; b < IBA_MAX_BATCH; ++b) if (h->amap.slot[b] < kMaxPairGroups) used[h->amap.slot[b]] = true;   // (stale entries beyond the last batch only add slots)
+    std::vector<uint32_t> v((size_t)h->n_frames * kCountStride);
+    for (int sl = 0; sl < kMaxPairGroups; ++sl) {
+        if (!used[sl]) continue;
+        if (hipMemcpy(v.data(), h->d_pcounts.p + h->amap.cnt_off[sl], v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return fail(h, IBA_ERR_HIP, "copy");
+        for (int f = 0; f < h->n_frames; ++f) { out3[0] += v[(size_t)f * kCountStride + 2] != 0u; ++out3[1]; out3[2] = std::max<int32_t>(out3[2], (int32_t)v[(size_t)f * kCountStride]); }
+    }
+    return IBA_OK;
+}
 int32_t iba_debug_pairs_builds(const iba_handle* h) { return h ? h->pairs_builds : -1; }
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }
 
