@@ -315,6 +315,10 @@ int32_t iba_debug_pairs_builds(const iba_handle* h);
 double iba_debug_nn_left_to_tree(iba_handle* h);
 /* diagnostic: mean number of (scan point, keypoint) pairs per keyframe that the last shared pair search listed; -1: none ran */
 double iba_debug_mean_pairs(iba_handle* h);
+/* debug: association blocks since the last reset that rescanned every scan point (a speed-only fallback: full queue / pair list) */
+int64_t iba_debug_rescans(iba_handle* h, int32_t reset);
+/* debug: out4 = {those rescans, iba_assoc2_kernel blocks whose note list of possible winners overflowed (speed only), 0, 0} since the last reset */
+iba_status iba_debug_counters(iba_handle* h, uint32_t out4[4], int32_t reset);
 /* debug: {pair lists of the last call that had overflowed (their blocks rescan every point: speed only), lists read, longest list} */
 iba_status iba_debug_pair_lists(iba_handle* h, int32_t out3[3]);
 /* debug: exact 1-NN (nanoflann semantics with the lowest-index tie rule, iba_global.cpp:116-122) of n LiDAR-frame query

@@ -300,6 +300,19 @@ class IbaHandle:
         self.lib.iba_debug_pairs_builds.argtypes = [C.c_void_p]
         return int(self.lib.iba_debug_pairs_builds(self.h))
 
+    def rescans(self, reset=True):
+        """association blocks since the last reset that took the rescan-every-point fallback (speed only)"""
+        self.lib.iba_debug_rescans.restype = C.c_int64
+        self.lib.iba_debug_rescans.argtypes = [C.c_void_p, C.c_int32]
+        return int(self.lib.iba_debug_rescans(self.h, 1 if reset else 0))
+
+    def counters(self, reset=True):
+        """(association blocks that rescanned every point, assoc2 blocks whose winner note list overflowed, 0, 0) since the last reset"""
+        out = (C.c_uint32 * 4)()
+        self.lib.iba_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int32]
+        self._chk(self.lib.iba_debug_counters(self.h, out, 1 if reset else 0))
+        return tuple(int(v) for v in out)
+
     @property
     def pair_lists(self):
         """(overflowed pair lists, pair lists read, longest list) of the last call"""

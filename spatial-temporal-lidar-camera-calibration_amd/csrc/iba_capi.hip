@@ -123,6 +123,7 @@ struct iba_handle {
     DevBuf<FrameHdr> frames; DevBuf<SlotHdr> slots;
     DevBuf<float> xs, ys, zs, chunk_box; DevBuf<uint32_t> perm, inv_perm; DevBuf<TreeNode> nodes;
     DevBuf<float4> pts4;   // the same scan points as (x, y, z, original index bits): one 16 B gather per point where lanes diverge
+    DevBuf<uint32_t> d_diag;              // diagnostic counters (DevProblem::diag)
     DevBuf<float2> kp_uv; DevBuf<float4> kp_mp; DevBuf<uint32_t> kp_fl, kp_fl2;   // kp_fl2: match bits of the covisible slots 30..61 (allocated only when a frame has that many)
     DevBuf<uint32_t> coarse_start, bitmap; DevBuf<float4> crec;
     DevBuf<float2> match_uv;
@@ -169,7 +170,7 @@ struct iba_handle {
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.plane_ok = plane_ok.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
-        dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u); dp.kp_fl2 = kp_fl2.p;
+        dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u); dp.kp_fl2 = kp_fl2.p; dp.diag = d_diag.p;
         return dp;
     }
 };
@@ -825,7 +826,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->kp_fl2.release(); h->d_anchor.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->kp_fl2.release(); h->d_diag.release(); h->d_anchor.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -1087,6 +1088,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(h->nrec, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
     if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
     if ((er = h->d_flist_frozen.alloc((size_t)std::max(nf, 1) * h->lstride)) != hipSuccess) return bail("alloc flist", er);
+    if ((er = h->d_diag.alloc(4)) != hipSuccess || (er = hipMemset(h->d_diag.p, 0, 16)) != hipSuccess) return bail("alloc diag", er);
     if ((er = h->d_fcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc fcount", er);
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
     if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
@@ -1348,6 +1350,20 @@ iba_status iba_debug_pair_lists(iba_handle* h, int32_t out3[3]) {
         if (hipMemcpy(v.data(), h->d_pcounts.p + h->amap.cnt_off[sl], v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return fail(h, IBA_ERR_HIP, "copy");
         for (int f = 0; f < h->n_frames; ++f) { out3[0] += v[(size_t)f * kCountStride + 2] != 0u; ++out3[1]; out3[2] = std::max<int32_t>(out3[2], (int32_t)v[(size_t)f * kCountStride]); }
     }
+    return IBA_OK;
+}
+// debug: (candidate, keyframe) association blocks, since the last reset, that took a speed-only fallback — a full candidate queue or pair
+// list, a fifth hit of one point, an overflowed common list: every scan point again, exactly (results unaffected). reset != 0 clears it.
+int64_t iba_debug_rescans(iba_handle* h, int32_t reset) {
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (iba_debug_counters(h, v, reset) != IBA_OK) return -1;
+    return (int64_t)v[0];
+}
+iba_status iba_debug_counters(iba_handle* h, uint32_t out4[4], int32_t reset) {
+    if (!h || !h->d_diag.p || !out4) return IBA_ERR_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, IBA_ERR_HIP, "sync");
+    if (hipMemcpy(out4, h->d_diag.p, 16, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, IBA_ERR_HIP, "copy");
+    if (reset && hipMemset(h->d_diag.p, 0, 16) != hipSuccess) return fail(h, IBA_ERR_HIP, "memset");
     return IBA_OK;
 }
 int32_t iba_debug_pairs_builds(const iba_handle* h) { return h ? h->pairs_builds : -1; }

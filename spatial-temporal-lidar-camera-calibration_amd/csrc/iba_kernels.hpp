@@ -50,6 +50,8 @@ struct DevProblem {
     int32_t scratch_slot_base;
     const uint32_t* mpk;       // per frame: the keypoints that own a MapPoint (FrameHdr::mpk_base, n_mpk)
     const uint32_t* kp_fl2;    // match bits of the covisible slots 30..61 per keypoint (nullptr: no frame has more than 30 slots)
+    uint32_t* diag;            // diagnostic counters: [0] association blocks that took a speed-only fallback (a full queue or list: every scan point again),
+                               // [1] iba_assoc2_kernel blocks whose note list of possible winners overflowed (every pair beyond the register window again)
     uint32_t max_k;            // largest keypoint count of a frame: row pitch of the per-(frame, keypoint) tables
 };
 

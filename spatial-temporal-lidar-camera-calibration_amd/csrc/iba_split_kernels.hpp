@@ -609,6 +609,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
             if (project_pos<true>(c, pos, u, v)) grid_match<2>(c, u, v, pos);
         }
     }
+    if (overflow && tid == 0) atomicAdd(dp.diag, 1u);   // (iba_debug_rescans: how often the fallback below runs)
     if (overflow) {   // some other exact tests ran inline (a full queue or pair list, a fifth hit of one point, more undecidable points than the list holds): every point again, for the ties
         for (uint32_t pos = tid; pos < P; pos += kThreads) {
             double u, v;
@@ -1072,6 +1073,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         double u, v;
         if (project_pos<true>(c, pos, u, v)) grid_match_g<1>(c, gcs, u, v, pos);
     }
+    if (overflow && tid == 0) atomicAdd(dp.diag, 1u);   // (iba_debug_rescans)
     if (overflow)
         for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<1>(c, gcs, u, v, pos); }
     __syncthreads();
@@ -1089,6 +1091,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
                 if (k != kNone && s_best_d2[k] == bits) atomicMin(&s_best_idx[k], idx);
             }
         } else {   // more than the note list holds: every pair beyond the window again
+            if (tid == 0) atomicAdd(dp.diag + 1, 1u);   // (iba_debug_counters)
             for (uint32_t i = ut + (uint32_t)kPairRegs * kThreads; i < npair; i += kThreads) {
                 uint32_t k, idx;
                 const unsigned long long bits = eval_pair(i, k, idx);

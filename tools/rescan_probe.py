@@ -1,0 +1,23 @@
+"""GPU box. How often do the association kernels fall back to rescanning every scan point (a full candidate queue or pair list, a fifth
+keypoint hit of one point, an overflowed common list)? Counts (candidate, keyframe) blocks per workload (iba_debug_rescans)."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd"); synth = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.synth"); abi = importlib.import_module("spatial-temporal-lidar-camera-calibration_amd.abi")
+def run(name, F, P, xs_fn, calls=3):
+    prob, meta = synth.make_scene(n_frames=F, pts_per_frame=P, seed=0)
+    h = pkg.IbaHandle(prob, abi.reference_yaml_params())
+    h.counters()
+    n = 0
+    for i in range(calls):
+        xs = xs_fn(meta, i); h.eval_cost(xs); n += len(xs) * F
+    c = h.counters()
+    print("%-55s %7d of %8d blocks rescanned, %6d note-list overflows (path %d)" % (name, c[0], n, c[1], h.last_path), flush=True)
+    h.close()
+rng = np.random.default_rng(0)
+run("bench shape, 64 nearby candidates", 200, 10000, lambda m, i: synth.perturb(m["x_gt"], rng, n=64))
+run("bench shape, 64 box-wide candidates", 200, 10000, lambda m, i: m["x_gt"][None, :] + rng.uniform(-1, 1, (64, 7)) * np.array([0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0]))
+run("bench shape, 64 candidates 20 x the bench spread", 200, 10000, lambda m, i: synth.perturb(m["x_gt"], rng, rot=1e-2, trans=1e-1, scale_rel=2e-2, n=64))
+run("40 KF x 120 k points, 64 nearby candidates", 40, 120000, lambda m, i: synth.perturb(m["x_gt"], rng, n=64))
+run("40 KF x 120 k points, 8 box-wide candidates", 40, 120000, lambda m, i: m["x_gt"][None, :] + rng.uniform(-1, 1, (8, 7)) * np.array([0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0]), calls=1)
