@@ -60,6 +60,13 @@ struct NNArgs {
 // list entry flags (uint4.w) written by iba_assoc_kernel
 constexpr uint32_t kFlagC = 1u;   // cost-path 1-NN wanted (keypoint owns a MapPoint, frame counts for BAError, 3d-3d enabled)
 constexpr int kRefitSearch = 1, kRefitSums = 2;
+// Diagnostic counters (iba_debug_counters; tools/rescan_probe.py) are compiled in by `make diag` only (-DIBA_DIAG_COUNTERS ->
+// libiba_diag.so): three cold atomics in iba_assoc2_kernel moved its code generation enough to cost 8 us of 171 (profiles r04e vs r04f).
+#ifdef IBA_DIAG_COUNTERS
+#define IBA_DIAG_COUNT(cond, slot) do { if (cond) atomicAdd(dp.diag + (slot), 1u); } while (0)
+#else
+#define IBA_DIAG_COUNT(cond, slot) do { } while (0)
+#endif
 constexpr int kHardLds = 256;   // iba_assoc_kernel: scan points within 0.1 m of the camera plane that a block notes for its tie pass (more: the full rescan)
 constexpr uint32_t kFlagA = 2u;   // association-path 1-NN wanted (ComputeLocalNeighbor at the matched point is valid)
 
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
             if (project_pos<true>(c, pos, u, v)) grid_match<2>(c, u, v, pos);
         }
     }
-    if (overflow && tid == 0) atomicAdd(dp.diag, 1u);   // (iba_debug_rescans: how often the fallback below runs)
+    IBA_DIAG_COUNT(overflow && tid == 0, 0);   // (iba_debug_counters: how often the fallback below runs)
     if (overflow) {   // some other exact tests ran inline (a full queue or pair list, a fifth hit of one point, more undecidable points than the list holds): every point again, for the ties
         for (uint32_t pos = tid; pos < P; pos += kThreads) {
             double u, v;
@@ -1073,7 +1080,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         double u, v;
         if (project_pos<true>(c, pos, u, v)) grid_match_g<1>(c, gcs, u, v, pos);
     }
-    if (overflow && tid == 0) atomicAdd(dp.diag, 1u);   // (iba_debug_rescans)
+    IBA_DIAG_COUNT(overflow && tid == 0, 0);
     if (overflow)
         for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<1>(c, gcs, u, v, pos); }
     __syncthreads();
@@ -1091,7 +1098,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
                 if (k != kNone && s_best_d2[k] == bits) atomicMin(&s_best_idx[k], idx);
             }
         } else {   // more than the note list holds: every pair beyond the window again
-            if (tid == 0) atomicAdd(dp.diag + 1, 1u);   // (iba_debug_counters)
+            IBA_DIAG_COUNT(tid == 0, 1);
             for (uint32_t i = ut + (uint32_t)kPairRegs * kThreads; i < npair; i += kThreads) {
                 uint32_t k, idx;
                 const unsigned long long bits = eval_pair(i, k, idx);

@@ -1,5 +1,6 @@
 """GPU box. How often do the association kernels fall back to rescanning every scan point (a full candidate queue or pair list, a fifth
-keypoint hit of one point, an overflowed common list)? Counts (candidate, keyframe) blocks per workload (iba_debug_rescans)."""
+keypoint hit of one point, an overflowed common list)? Counts (candidate, keyframe) blocks per workload (iba_debug_counters). The counters are compiled in by `make -C csrc diag` only:
+run with IBA_LIB=<package dir>/libiba_diag.so (the default library reports zeros)."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
