@@ -745,12 +745,17 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     }
     if (common) {
         { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }   // the candidates and the hand-eye terms: first read here
+        // (four instantiations: flags in registers or LDS x at most 30 covisible keyframes or more; the common one is round 3's code)
+        auto launch_assoc2 = [&](auto flreg) {
+            constexpr bool FL = decltype(flreg)::value;
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                                                          h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap); };
+            if (h->max_slots > (uint32_t)kCovisWord) go(iba_assoc2_kernel<FL, true>); else go(iba_assoc2_kernel<FL, false>);
+        };
         if (assoc2_flreg(h))
-            hipLaunchKernelGGL(iba_assoc2_kernel<true>, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                               h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
+            launch_assoc2(std::true_type{});
         else
-            hipLaunchKernelGGL(iba_assoc2_kernel<false>, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                               h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
+            launch_assoc2(std::false_type{});
     } else {
     { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }
     hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
@@ -1127,8 +1132,10 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     // > 64 KB of dynamic LDS must be opted into per kernel
     if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
-    if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
-    if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_assoc2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    {
+        const void* a2[4] = {(const void*)iba_assoc2_kernel<true, false>, (const void*)iba_assoc2_kernel<true, true>, (const void*)iba_assoc2_kernel<false, false>, (const void*)iba_assoc2_kernel<false, true>};
+        for (const void* fn : a2) if (h->common_mode > 0 && (er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    }
     if ((er = hipFuncSetAttribute((const void*)iba_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     const void* nfns[15] = {(const void*)iba_nn_kernel<1, 0, 0>, (const void*)iba_nn_kernel<2, 0, 0>, (const void*)iba_nn_kernel<3, 0, 0>, (const void*)iba_nn_kernel<1, 1, 0>, (const void*)iba_nn_kernel<2, 1, 0>,
                             (const void*)iba_nn_kernel<3, 1, 0>, (const void*)iba_nn_kernel<1, 2, 0>, (const void*)iba_nn_kernel<2, 2, 0>, (const void*)iba_nn_kernel<3, 2, 0>,

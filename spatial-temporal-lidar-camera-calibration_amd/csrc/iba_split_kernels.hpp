@@ -98,7 +98,7 @@ typedef __attribute__((address_space(4))) const KArgs KArgsC;
 // FLREG (at most 2048 keypoints per frame: four per thread): the thread's four flag words arrive in registers (rf, loaded from global
 // memory at the start of the kernel) instead of through an LDS copy of the frame's flags, the winners read in the counting pass stay
 // in registers for the list pass, and the covisible-slot mask of a list entry is parked next to it (s_msk, over the winners' array).
-template <bool FLREG>
+template <bool FLREG, bool MANY = true>   // MANY: a frame may have more covisible keyframes than the flag word has match bits (the second word, kp_fl2)
 __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, uint32_t* s_best_idx, const uint32_t* s_kfl, const uint4 rf, uint32_t* s_list,
                                            double* s_red, const double* s_rel, const uint32_t K, const int want, const int dbg, const bool refit, const int b, const int f, const int nf,
                                            double* __restrict__ part, const double* __restrict__ he, uint4* __restrict__ flist,
@@ -209,7 +209,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
         for (uint32_t i = tid; i < n3; i += kThreads) {
             const uint32_t k = s_list[i] & 0xffffu, pos = s_pos[i];
             const uint32_t mask_lo = FLREG ? s_msk[i] : s_kfl[k] >> 2;
-            const uint32_t mask_hi = h.n_slots > (uint32_t)kCovisWord ? dp.kp_fl2[h.kp_base + k] : 0u;   // (block-uniform: a frame with more than 30 covisible keyframes)
+            const uint32_t mask_hi = (MANY && h.n_slots > (uint32_t)kCovisWord) ? dp.kp_fl2[h.kp_base + k] : 0u;   // (block-uniform: a frame with more than 30 covisible keyframes)
             if (!(mask_lo | mask_hi)) continue;
             float xf_, yf_, zf_; load_pt<true>(c, pos, xf_, yf_, zf_);
             const double x = (double)xf_, y = (double)yf_, z = (double)zf_;
@@ -218,9 +218,9 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
             const double p0z = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
             const float2* mrow = dp.match_uv + h.match_base + k;
 #pragma unroll 1
-            for (int wi = 0; wi < (mask_hi ? 2 : 1); ++wi) {   // the slots of one flag word after the other, in slot order (one copy of the loop body)
-                uint32_t mask = wi == 0 ? mask_lo : mask_hi;
-                const uint32_t base = wi == 0 ? 0u : (uint32_t)kCovisWord;
+            for (int wi = 0; wi < ((MANY && mask_hi) ? 2 : 1); ++wi) {   // the slots of one flag word after the other, in slot order (one copy of the loop body)
+                uint32_t mask = (!MANY || wi == 0) ? mask_lo : mask_hi;
+                const uint32_t base = (!MANY || wi == 0) ? 0u : (uint32_t)kCovisWord;
                 if (!mask) continue;
                 float2 mm = mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K];
                 while (mask) {
@@ -958,7 +958,7 @@ __device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* 
 // LDS: 16 B per keypoint (best d^2, best index, flags) + the relative poses: ~33 KB at 2000 keypoints.
 constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
 constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
-template <bool FLREG>   // FLREG: the frame's keypoint flags never go through LDS (at most 2048 keypoints per frame; see assoc_tail)
+template <bool FLREG, bool MANY>   // FLREG: the frame's keypoint flags never go through LDS (at most 2048 keypoints per frame; see assoc_tail); MANY: more than 30 covisible keyframes possible
 __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
                                                               const double* __restrict__ he, uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
                                                               uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs_all, const uint32_t* __restrict__ hard_all,
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<2>(c, gcs, u, v, pos); }
     __syncthreads();
     if (dbg == 5) return;
-    assoc_tail<FLREG>(ka, h, cd, c, s_best_idx, s_kfl, rf, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
+    assoc_tail<FLREG, MANY>(ka, h, cd, c, s_best_idx, s_kfl, rf, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
 #undef dp
 #undef prm
 #undef lay
