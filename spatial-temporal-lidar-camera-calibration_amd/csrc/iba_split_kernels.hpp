@@ -1035,8 +1035,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
     if (dbg == 1) return;
 
     // ---- pass 1: exact f64 projection + FOV test and exact d^2 of every common pair, ds_min_u64 on the keypoint's best ----
-    auto eval_pair = [&](uint32_t i, uint32_t& k, uint32_t& idx) -> unsigned long long {
-        const float4 a = prq[2 * (size_t)i], q = prq[2 * (size_t)i + 1];
+    auto eval_loaded = [&](const float4& a, const float4& q, uint32_t& k, uint32_t& idx) -> unsigned long long {
         double u, v;
         k = kNone; idx = __float_as_uint(a.w);
         if (project_uv(c, a.x, a.y, a.z, u, v)) {
@@ -1046,12 +1045,24 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         }
         return 0ull;
     };
+    auto eval_pair = [&](uint32_t i, uint32_t& k, uint32_t& idx) -> unsigned long long {
+        const float4 a = prq[2 * (size_t)i], q = prq[2 * (size_t)i + 1];
+        return eval_loaded(a, q, k, idx);
+    };
+    // The pairs are streamed ONE AHEAD (r04): the record of the thread's next pair is in flight while this one is evaluated. (As written
+    // in round 3 the compiler issued load, wait, evaluate, load, wait, ... per pair — and, beyond the register window, the record's
+    // second half only after the projection had passed: three exposed round trips per block at the bench shape, two per pair and
+    // nineteen pairs per thread at 120 k points.)
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nq = na;
+    if (ut < npair) { na = prq[2 * (size_t)ut]; nq = prq[2 * (size_t)ut + 1]; }
     uint32_t rk[kPairRegs], ri[kPairRegs]; unsigned long long rb[kPairRegs];
 #pragma unroll
     for (int j = 0; j < kPairRegs; ++j) {
         rk[j] = kNone; ri[j] = 0u; rb[j] = 0ull;
         const uint32_t i = ut + (uint32_t)j * kThreads;
-        if (i < npair) { rb[j] = eval_pair(i, rk[j], ri[j]); if (rk[j] != kNone) atomicMin(&s_best_d2[rk[j]], rb[j]); }
+        const float4 a = na, q = nq;
+        if (i + (uint32_t)kThreads < npair) { na = prq[2 * (size_t)(i + kThreads)]; nq = prq[2 * (size_t)(i + kThreads) + 1]; }
+        if (i < npair) { rb[j] = eval_loaded(a, q, rk[j], ri[j]); if (rk[j] != kNone) atomicMin(&s_best_d2[rk[j]], rb[j]); }
     }
     // pairs beyond the register window (a dense scan: 9 k pairs per keyframe at 120 k points): one that is at most the keypoint's best
     // so far MAY be the winner and is noted for the tie pass (a keypoint sees ~1.3 such pairs); the others cannot win any more
@@ -1059,10 +1070,12 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
         for (uint32_t i0 = (uint32_t)kPairRegs * kThreads; i0 < npair; i0 += kThreads) {   // block-uniform trip count
             const uint32_t i = i0 + ut;
+            const float4 a = na, q = nq;
+            if (i + (uint32_t)kThreads < npair) { na = prq[2 * (size_t)(i + kThreads)]; nq = prq[2 * (size_t)(i + kThreads) + 1]; }
             bool note = false;
             if (i < npair) {
                 uint32_t k, idx;
-                const unsigned long long bits = eval_pair(i, k, idx);
+                const unsigned long long bits = eval_loaded(a, q, k, idx);
                 if (k != kNone) note = bits <= atomicMin(&s_best_d2[k], bits);
             }
             const unsigned long long bal = __ballot(note);
