@@ -1153,6 +1153,28 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
     float& o0, float& o1, float& o2, float& delc, float& e_lin, float& e_const, float (&pd2)[kPathMax], uint32_t& side, uint32_t& done, uint32_t& node, int& go, \
     bool& actA, bool& actC
 #define IBA_LANE_NN_PASS ax, ay, az, qx, qy, qz, bestA, bestC, bposA, bposC, o0, o1, o2, delc, e_lin, e_const, pd2, side, done, node, go, actA, actC
+// The next level whose far child a search enters (-1: the search has ended). The cell of the far child at level L lies beyond the
+// splitting plane of L AND beyond the planes of every level above it at which the current path has already turned to the far side:
+// per coordinate the largest of those plane distances, summed over the coordinates, is a lower bound of the squared distance from the
+// query to the cell (nanoflann's `dists` vector, nanoflann.hpp searchLevel). Rounds 2-3 tested the plane of L alone — correct, but a
+// query far from the scan (a MapPoint 2 m in front of a wall, a candidate far from the truth) then opens every cell within reach of
+// ONE plane at a time: 24 leaves and more. pd2[] are float lower bounds of the plane distances; their sum keeps a margin of 1e-6.
+__device__ __forceinline__ int nn_next_level(const float (&pd2)[kPathMax], const uint32_t side, uint32_t& done, const uint32_t node, const uint32_t D, const float bestf, const TreeNode* s_nodes) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;   // per coordinate: the largest plane distance^2 among the far turns of the path so far
+    uint32_t cnd = 0u;
+#pragma unroll
+    for (int L = 0; L < kPathMax; ++L) {
+        if (L >= (int)D) break;
+        const uint32_t dm = s_nodes[((node + 1u) >> (D - (uint32_t)L)) - 1u].dim;
+        const float p = pd2[L];
+        const float w0 = dm == 0u ? fmaxf(a0, p) : a0, w1 = dm == 1u ? fmaxf(a1, p) : a1, w2 = dm == 2u ? fmaxf(a2, p) : a2;
+        cnd |= (((w0 + w1) + w2) * 0.999999f <= bestf ? 1u : 0u) << L;
+        if ((side >> (16 + L)) & 1u) { a0 = w0; a1 = w1; a2 = w2; }
+    }
+    cnd &= ~done & ((1u << D) - 1u);
+    done |= ~cnd;
+    return cnd ? 31 - __clz((int)cnd) : -1;
+}
 __device__ __forceinline__ void lane_nn_begin(IBA_LANE_NN_PARAMS) {
     // float steering point o and the radius del >= |q - o| per axis of both queries
     o0 = (float)(actC ? qx : ax); o1 = (float)(actC ? qy : ay); o2 = (float)(actC ? qz : az);
@@ -1173,13 +1195,13 @@ __device__ __forceinline__ void lane_nn_visit(IBA_LANE_NN_PARAMS, const TreeNode
     int start = 0;
     if (go >= 0) {   // enter the far child at level go
         const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
-        done |= 1u << go; side ^= 1u << go;
+        done |= 1u << go; side ^= 1u << go; side |= 0x10000u << go;   // (bits 16..: the levels at which the current path has turned to the FAR side)
         node = 2u * anc + 1u + ((side >> go) & 1u);
         start = go + 1;
     }
     {
         const uint32_t keep = (1u << start) - 1u;
-        side &= keep; done &= keep;
+        side &= keep | (keep << 16); done &= keep;
         uint32_t n1 = node + 1u;
 #pragma unroll
         for (int L = 0; L < kPathMax; ++L) {
@@ -1256,12 +1278,7 @@ __device__ __forceinline__ void lane_nn_visit(IBA_LANE_NN_PARAMS, const TreeNode
     }
     {   // deepest level whose far side may still be within reach of either query
         const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
-        uint32_t cnd = 0u;
-#pragma unroll
-        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= bestf ? 1u : 0u) << L;
-        cnd &= ~done & ((1u << D) - 1u);
-        done |= ~cnd;
-        go = cnd ? 31 - __clz((int)cnd) : -1;
+        go = nn_next_level(pd2, side, done, node, D, bestf, s_nodes);
     }
 }
 
@@ -1294,13 +1311,13 @@ __device__ __forceinline__ void wave_nn_visit(IBA_LANE_NN_PARAMS, const int lane
     int start = 0;
     if (go >= 0) {   // enter the far child at level go
         const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
-        done |= 1u << go; side ^= 1u << go;
+        done |= 1u << go; side ^= 1u << go; side |= 0x10000u << go;   // (bits 16..: the levels at which the current path has turned to the FAR side)
         node = 2u * anc + 1u + ((side >> go) & 1u);
         start = go + 1;
     }
     {
         const uint32_t keep = (1u << start) - 1u;
-        side &= keep; done &= keep;
+        side &= keep | (keep << 16); done &= keep;
         uint32_t n1 = node + 1u;
 #pragma unroll
         for (int L = 0; L < kPathMax; ++L) {
@@ -1391,12 +1408,7 @@ __device__ __forceinline__ void wave_nn_visit(IBA_LANE_NN_PARAMS, const int lane
     }
     {   // deepest level whose far side may still be within reach of either query
         const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
-        uint32_t cnd = 0u;
-#pragma unroll
-        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= bestf ? 1u : 0u) << L;
-        cnd &= ~done & ((1u << D) - 1u);
-        done |= ~cnd;
-        go = cnd ? 31 - __clz((int)cnd) : -1;
+        go = nn_next_level(pd2, side, done, node, D, bestf, s_nodes);
     }
 }
 
