@@ -315,6 +315,8 @@ int32_t iba_debug_pairs_builds(const iba_handle* h);
 double iba_debug_nn_left_to_tree(iba_handle* h);
 /* diagnostic: mean number of (scan point, keypoint) pairs per keyframe that the last shared pair search listed; -1: none ran */
 double iba_debug_mean_pairs(iba_handle* h);
+/* debug (host only): R[9], t[3], dR/d omega_k [3][9], dt/dx_k [6][3], s of a candidate as the factor kernel reads them (58 doubles) */
+iba_status iba_debug_cand(const double x[7], double out58[58]);
 /* debug: association blocks since the last reset that rescanned every scan point (a speed-only fallback: full queue / pair list) */
 int64_t iba_debug_rescans(iba_handle* h, int32_t reset);
 /* debug: out4 = {those rescans, iba_assoc2_kernel blocks whose note list of possible winners overflowed (speed only), 0, 0} since the last reset */

@@ -201,6 +201,14 @@ class Oracle:
             lib().oracle_block_input_sensitivity(C.c_void_p(self.h), _p(x), _p(e), C.byref(n))
         return e[: n.value]
 
+    def block_kernel_order(self, block, cand58, normal, rows):
+        """rows x 8 (r, J) of a plane-factor block in the device kernel's operation order from the DEVICE's inputs (iba_debug_cand, its plane normal); None for other kinds"""
+        c = np.ascontiguousarray(cand58, np.float64); n = np.ascontiguousarray(normal, np.float64)
+        out = np.zeros((rows, 8))
+        if lib().oracle_block_kernel_order(C.c_void_p(self.h), C.c_int64(block), _p(c), _p(n), _p(out)) != 0:
+            return None
+        return out
+
     def block_three_ways(self, block, x, rows, variant=0):
         """(Dual<7> double, long double rounded, the device kernel's operation order in double) rows x 8 (r, J) of a plane-factor block; None for other kinds"""
         x = np.ascontiguousarray(x, np.float64)

@@ -756,6 +756,17 @@ int oracle_block_three_ways(void* h, int64_t block, const double* x, int variant
     plane_block_kernel_order(f, c.R, c.t, c.dR, c.dt, x[6], n0, variant, out2);
     return 0;
 }
+// A plane-factor block in the kernel's operation order from inputs GIVEN by the caller (the device's own: iba_debug_cand, iba_debug_plane):
+// cand58 = R[9], t[3], dR[3][9], dt[6][3], s. out: rows x 8 (r, J[7]). The device's rows must equal this bit for bit.
+int oracle_block_kernel_order(void* h, int64_t block, const double* cand58, const double n0[3], double* out) {
+    Oracle& O = *(Oracle*)h;
+    if (block < 0 || block >= (int64_t)O.factors.size() || O.factors[block].kind != 0) return 1;
+    const Factor& f = O.factors[block];
+    double dR[6][9] = {{0}}, dt[6][3];
+    std::memcpy(dR, cand58 + 12, 216); std::memcpy(dt, cand58 + 39, 144);
+    plane_block_kernel_order(f, cand58, cand58 + 9, dR, dt, cand58[57], n0, 0, out);
+    return 0;
+}
 // INPUT SENSITIVITY of a plane-factor block: the device and this file each derive R, t and their derivatives from x with their own
 // dual arithmetic (Jet<6> / Dual<7>: tools/device_vs_simulation.py finds the two bit-identical on some candidates and a last bit apart
 // on others) and each fit the plane with their own libm; both then run the SAME formulas (device == plane_block_kernel_order bit for
@@ -867,7 +878,10 @@ int oracle_plane_normal_sensitivity(void* h, int frame, uint32_t pt_idx, double 
     const long double covl[6] = {cl[3] - cl[0] * cl[0], cl[6] - cl[1] * cl[1], cl[8] - cl[2] * cl[2], cl[4] - cl[0] * cl[1], cl[5] - cl[0] * cl[2], cl[7] - cl[1] * cl[2]};
     const double covd[6] = {cov(0, 0), cov(1, 1), cov(2, 2), cov(0, 1), cov(0, 2), cov(1, 2)};
     double err[6];
-    for (int i = 0; i < 6; ++i) err[i] = (double)fabsl((long double)covd[i] - covl[i]) + std::fabs(covd[i]) * 0x1p-52;
+    // (the measured difference is ONE draw and can come out small by luck — seed 90431, r04: 2.8e-13 against a device normal 8.4e-11 away;
+    //  no double evaluation of E[ab] - E[a] E[b] is better than a few units in the last place of the two terms it subtracts)
+    const long double raw[6][2] = {{cl[3], cl[0] * cl[0]}, {cl[6], cl[1] * cl[1]}, {cl[8], cl[2] * cl[2]}, {cl[4], cl[0] * cl[1]}, {cl[5], cl[0] * cl[2]}, {cl[7], cl[1] * cl[2]}};
+    for (int i = 0; i < 6; ++i) err[i] = std::max((double)fabsl((long double)covd[i] - covl[i]), 8.0 * 0x1p-52 * (double)(fabsl(raw[i][0]) + fabsl(raw[i][1]))) + std::fabs(covd[i]) * 0x1p-52;
     double ev[3];
     const V3d n0 = normalized(FastEigen3x3_EV(cov, ev));
     uint64_t st = 0x2545F4914F6CDD1Dull ^ ((uint64_t)pt_idx << 20) ^ (uint64_t)frame;

@@ -488,6 +488,18 @@ def mads_options(x0, **opts):
     return o
 
 
+def debug_cand(x):
+    """(host only) R[9], t[3], dR[3][9], dt[6][3], s of a candidate exactly as the factor kernel reads them: 58 doubles"""
+    L = load_library()
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.zeros(58)
+    L.iba_debug_cand.argtypes = [C.c_void_p, C.c_void_p]
+    st = L.iba_debug_cand(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    if st != 0:
+        raise IbaError(st, "iba_debug_cand")
+    return out
+
+
 def mads_selftest(problem, x0, trace=False, **opts):
     """The MADS driver on a built-in analytic black box (host only, no GPU). trace=True also returns the evaluated points."""
     L = load_library()

@@ -19,6 +19,17 @@ using namespace iba;
 
 extern "C" {
 
+// debug (host only): what the library derives from a candidate x before any kernel runs — Sim3Exp(x) and its forward-mode derivatives,
+// exactly the numbers the factor kernel reads (csrc/iba_host_math.hpp). out66 = R[9], t[3], dR[3][9], dt[6][3], s. The parity tests hand
+// them to the oracle's restatement of the kernel's formulas: the device must then equal that CPU evaluation bit for bit.
+iba_status iba_debug_cand(const double x[7], double out66[58]) {
+    if (!x || !out66) return IBA_ERR_INVALID_ARG;
+    static thread_local Cand c;
+    make_cand(x, c);
+    std::memcpy(out66, c.R, 72); std::memcpy(out66 + 9, c.t, 24); std::memcpy(out66 + 12, c.dR, 216); std::memcpy(out66 + 39, c.dt, 144); out66[57] = c.s;
+    return IBA_OK;
+}
+
 iba_status iba_default_create_options(iba_create_options* o) {
     if (!o) return IBA_ERR_INVALID_ARG;
     std::memset(o, 0, sizeof(*o));

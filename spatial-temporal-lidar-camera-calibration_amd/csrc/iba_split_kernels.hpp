@@ -1525,13 +1525,13 @@ __global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, Se
         int start = 0;
         if (go >= 0) {
             const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
-            done |= 1u << go; side ^= 1u << go;
+            done |= 1u << go; side ^= 1u << go; side |= 0x10000u << go;   // (bits 16..: far turns of the path, see nn_next_level)
             node = 2u * anc + 1u + ((side >> go) & 1u);
             start = go + 1;
         }
         {
             const uint32_t keep = (1u << start) - 1u;
-            side &= keep; done &= keep;
+            side &= keep | (keep << 16); done &= keep;
             uint32_t n1 = node + 1u;
 #pragma unroll
             for (int L = 0; L < kPathMax; ++L) {
@@ -1572,12 +1572,7 @@ __global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, Se
             }
         }
         const float bound = bd[kSetM - 1] < INFINITY ? (float)bd[kSetM - 1] * 1.000001f + 1e-30f : INFINITY;
-        uint32_t cnd = 0u;
-#pragma unroll
-        for (int L = 0; L < kPathMax; ++L) cnd |= (pd2[L] <= bound ? 1u : 0u) << L;
-        cnd &= ~done & ((1u << D) - 1u);
-        done |= ~cnd;
-        go = cnd ? 31 - __clz((int)cnd) : -1;
+        go = nn_next_level(pd2, side, done, node, D, bound, s_nodes);
     } while (go >= 0);
     const PlaneRec* planes_cost = dp.plane_cost + h.pt_base;
     const PlaneRec* planes_local = dp.plane_local + h.pt_base;

@@ -44,6 +44,8 @@ worst_cond = 1.0
 worst_ratio = 0.0   # a flagged block's deviation over the oracle's own forward error of it
 worst_normal = 0.0  # device vs oracle plane normal of a block that needed the device's normal substituted
 by_normal = 0       # flagged blocks that agree to ROW_FLOOR once the oracle uses the device's normal
+bitwise = 0         # flagged plane-factor blocks that equal the CPU evaluation of the kernel's formulas from the device's own inputs, bit for bit
+worst_bitwise = 0.0 # ... and how far those are from the oracle, in yardsticks
 worst_h = 0.0
 worst_entry = 0.0   # per-entry relative deviation over the entries above 1e-6 of the largest
 worst_c = 0.0       # hand-eye term C: device acos / tan through a cancelling log difference vs glibc
@@ -92,7 +94,7 @@ for sc in range(n_scenes):
                 try:
                     res = pe.explain(h, o, p, xs[b])
                     if res["status"] == "explained":
-                        explained_blocks += res["flagged"]; worst_cond = min(worst_cond, res["min_cond"]); cancelling += bool(res["cancelling_entries"]); worst_ratio = max(worst_ratio, res["worst_dev_over_forward_error"]); worst_normal = max(worst_normal, res["worst_normal_difference"]); by_normal += res["settled_by_the_normal"]
+                        explained_blocks += res["flagged"]; worst_cond = min(worst_cond, res["min_cond"]); cancelling += bool(res["cancelling_entries"]); worst_ratio = max(worst_ratio, res["worst_dev_over_forward_error"]); worst_normal = max(worst_normal, res["worst_normal_difference"]); by_normal += res["settled_by_the_normal"]; bitwise += res["bit_identical_to_the_cpu_evaluation_of_the_kernel"]; worst_bitwise = max(worst_bitwise, res["their_worst_deviation_over_yardstick"])
                 except AssertionError as ex:
                     msgs.append((b, "H/b not explained", e_dev, str(ex)[:200]))
     # the candidates drift a little between calls (the anchored neighbour lists of the first call serve the next ones)
@@ -130,6 +132,6 @@ for sc in range(n_scenes):
     tag = "ok " if not msgs else "BAD"
     bad += bool(msgs)
     print(f"{tag} seed {seed}: F={nf} P={pts} K={kp} B={len(xs)} pert={scale:g} plane={p.use_plane} w1={p.err_weight[1]:g} cache={p.plane_cache} n_corr={[c.n_corr for c in oc][:3]}", msgs[:3], flush=True)
-print(f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the 1e-10 per-entry gate, all explained: {explained_blocks} ill-conditioned block(s) (smallest conditioning measure {worst_cond:.1e}; {by_normal} of them settled by giving the oracle the device's plane normal — largest normal difference {worst_normal:.1e}; the others deviate by at most {worst_ratio:.1f} x their measured yardstick, bound {pe.C_FWD:.0f} x), {cancelling} candidate(s) by cancelling sums alone" if not bad else f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the gate, NOT all explained")
+print(f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the 1e-10 per-entry gate, all explained: {explained_blocks} ill-conditioned block(s) (smallest conditioning measure {worst_cond:.1e}; {by_normal} of them settled by giving the oracle the device's plane normal — largest normal difference {worst_normal:.1e}; {bitwise} equal the CPU evaluation of the kernel's own formulas from the device's inputs bit for bit (up to {worst_bitwise:.1f} yardsticks from the oracle); the others deviate by at most {worst_ratio:.1f} x their measured yardstick, bound {pe.C_FWD:.0f} x), {cancelling} candidate(s) by cancelling sums alone" if not bad else f"{n_scenes - bad}/{n_scenes} scenes in parity; {above_gate} candidate(s) above the gate, NOT all explained")
 print(f"worst deviation of H relative to its largest entry {worst_h:.2e}, per entry (re-associated evaluations) {worst_entry:.2e}, worst relative deviation of C {worst_c:.2e}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
