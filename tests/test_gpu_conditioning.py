@@ -20,6 +20,9 @@ def test_the_known_ill_conditioned_candidate_is_explained(pkg, synth, abi, ob):
     res = pe.explain(h, o, p, x, nthreads=min(os.cpu_count() or 1, 64))
     assert res["status"] == "explained" and res["flagged"] >= 1 and res["min_cond"] < 1e-4, res
     assert res["worst_entry"] > 1e-10
+    # every deviating block is settled by the device's plane normal alone or equals the CPU evaluation of the kernel's own formulas from
+    # the device's own inputs bit for bit: nothing is left to a tolerance
+    assert res["settled_by_the_normal"] + res["bit_identical_to_the_cpu_evaluation_of_the_kernel"] == res["flagged"], res
     h.close()
 
 
