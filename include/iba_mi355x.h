@@ -282,61 +282,8 @@ iba_status iba_eval_factors_partial(iba_handle* h, const double* x, int32_t B, v
  * is ordered behind everything `stream` held when the call was made and `stream` waits for it before the first kernel that reads
  * its results, so a caller sees one stream's ordering (IBA_SIDE_STREAM=0 in the environment: everything on `stream`). */
 
-/* Introspection for benchmarks: device-side duration of the last evaluation's dominant kernel
- * measured with HIP events on the launch stream (ms), and the frame-kernel launch shape. */
-iba_status iba_last_kernel_ms(iba_handle* h, float* frame_kernel_ms, float* total_ms);
-iba_status iba_set_timing(iba_handle* h, int32_t enable);
-/* the same split by kernel: association kernel (projection, 2d-3d association, 3d-2d residuals), grouped 1-NN search kernel
- * (3d-3d terms), and everything after them (factor kernel, sums) */
-iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_kernel_ms, float* rest_ms);
-/* debug: host copy of the summed partial blocks of the last iba_eval_* call */
-iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
-/* debug: which 2d-3d association ran in the last evaluation chain: 1 = the batch shared one pair search per keyframe
- * (any batch, a single candidate included, whose nominal projection spread stays under IBA_COMMON_MAX_PX = 20 px), 0 = every
- * candidate searched for itself. The results are the same bits either way.
- * Environment (read at iba_create): IBA_COMMON_PAIRS=0 never share, 2 share whenever the bound allows; IBA_COMMON_MAX_PX;
- * IBA_PAIR_MEMO=0 no reuse of pair lists across calls, IBA_PAIR_MEMO_MAX_B (40) the largest batch that reuses, IBA_PAIR_INFL (1.25)
- * the inflation of a reusable list's bound; IBA_SIDE_STREAM=0 one stream only; IBA_SPIN_WAIT=0 blocking waits. */
-int32_t iba_debug_last_path(const iba_handle* h);   /* 2: the batch was clustered into several tight groups with one pair search each */
-/* The planner behind that decision on B <= IBA_MAX_BATCH candidates, host only (no GPU): a batch whose nominal projection spread
- * (at a point 12 m out, 10 m deep, focal length max_fx) exceeds max_px is clustered into at most max_groups (<= 4) groups, accepted
- * when every group is within max_px. group_of[B] (may be NULL) receives each candidate's group, group_px[4] (may be NULL) the
- * groups' nominal spreads, *n_groups 1 (one shared search), 2..4 (clustered) or 0 (wide everywhere: every candidate for itself). */
-iba_status iba_debug_plan_groups(const double* x, int32_t B, double max_fx, double max_px, int32_t max_groups, int32_t* group_of, double* group_px, int32_t* n_groups);
-/* debug: how often the anchored neighbour lists (the 1-NN search memoised around an anchor extrinsic that follows the
- * optimiser's candidates; IBA_NN_SETS=0 disables them, IBA_ANCHOR_REACH sets the drift in metres that moves the anchor) have
- * been built on this handle. Results do not depend on the anchor: every lane certifies its pick or searches the tree. */
-int32_t iba_debug_anchor_builds(const iba_handle* h);
-/* diagnostic: how many times the shared pair search has run on this handle (an evaluation whose batch stays inside the bound of
- * the lists an earlier call built reuses them: IBA_PAIR_MEMO, default on) */
-int32_t iba_debug_pairs_builds(const iba_handle* h);
-/* diagnostic: list entries of the last evaluation (all candidates) that the anchored neighbour lists could not settle and the
- * tree search took over; -1 when no search ran */
-double iba_debug_nn_left_to_tree(iba_handle* h);
-/* diagnostic: mean number of (scan point, keypoint) pairs per keyframe that the last shared pair search listed; -1: none ran */
-double iba_debug_mean_pairs(iba_handle* h);
-/* debug (host only): R[9], t[3], dR/d omega_k [3][9], dt/dx_k [6][3], s of a candidate as the factor kernel reads them (58 doubles) */
-iba_status iba_debug_cand(const double x[7], double out58[58]);
-/* debug: association blocks since the last reset that rescanned every scan point (a speed-only fallback: full queue / pair list) */
-int64_t iba_debug_rescans(iba_handle* h, int32_t reset);
-/* debug: out4 = {those rescans, iba_assoc2_kernel blocks whose note list of possible winners overflowed (speed only), 0, 0} since the last reset */
-iba_status iba_debug_counters(iba_handle* h, uint32_t out4[4], int32_t reset);
-/* debug: {pair lists of the last call that had overflowed (their blocks rescan every point: speed only), lists read, longest list} */
-iba_status iba_debug_pair_lists(iba_handle* h, int32_t out3[3]);
-/* debug: exact 1-NN (nanoflann semantics with the lowest-index tie rule, iba_global.cpp:116-122) of n LiDAR-frame query
- * points in the scan of local frame `frame`, run through the search kernel's own kd search, one lane per query: original point
- * index and exact squared distance. mode 1: as the association path's query alone; 2: as the cost path's alone; 3 / 4: both paths
- * searched together as the kernel does, the query as the first (3) or the second (4) with its partner 1e-7 beside it.
- * For parity tests of the search itself. */
-iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q_xyz, int32_t n, int32_t mode, uint32_t* out_idx, double* out_d2);
-/* debug: the memoised local plane (plane_cache = 1) at scan point `point` (ORIGINAL index) of owned frame `frame`: which = 0 the cost
- * path's planes (norm_radius / norm_max_pts), 1 the association / Jacobian path's (neigh_radius / neigh_max_pts). With plane_cache = 0
- * only which = 1 after iba_build_problem: the plane the frozen problem's residual blocks read (fitted where a block needed one; other
- * points hold stale records). out5 = unit normal
- * (3), sum of |(p_i - c) . n|, squared distance of the farthest kept neighbour; *k = kept neighbours. The parity tests substitute this
- * normal into the oracle's residual block: the device fits planes with its own libm, and an ill-conditioned block amplifies the
- * last-bit difference of the two normals (tests/parity_explain.py). */
-iba_status iba_debug_plane(iba_handle* h, int32_t frame, uint32_t point, int32_t which, double out5[5], int32_t* k);
+/* Diagnostics, timing probes and self-tests (iba_debug_*, iba_last_*_ms, iba_set_timing, iba_*_selftest*) are declared in
+ * iba_mi355x_debug.h: test and benchmark tooling, not part of the drop-in surface. */
 int64_t iba_num_points(const iba_handle* h);
 int64_t iba_num_keypoints(const iba_handle* h);
 
@@ -368,20 +315,6 @@ typedef struct iba_mads_result {
 /* defaults of config/calib/00/iba_calib_global.yml:21-47 around x0 (lb/ub = x0 -/+ (0.1,0.1,0.1,0.3,0.3,0.3,1.0)) */
 iba_status iba_default_mads_options(const double* x0, iba_mads_options* o);
 iba_status iba_calibrate_mads(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res);
-/* the same driver on built-in analytic black boxes (host only; for tests of the search logic without a GPU):
- * 0 smooth bowl, 1 bowl with an active constraint and an infeasible start, 2 nonsmooth with two constraints,
- * 3 shallow bowl covered with narrow local basins (for the variable-neighbourhood restarts) */
-iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res);
-/* the same two calls with the sequence of black-box evaluations recorded: `trace` receives up to `cap` rows of 8 doubles
- * (x[7], f) in evaluation order, *n_trace the number of evaluations (tests diff the sequence against oracle/mads.py) */
-iba_status iba_calibrate_mads_trace(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace);
-/* ... and with the black-box CALLS recorded as well: batch_sizes receives up to cap_batches call sizes in order (they split the
- * rows of `trace` into the batches iba_eval_bbo was given), *n_batches their number. bench.py replays such a record through
- * iba_eval_bbo (extras.mads_trace_replay). */
-iba_status iba_calibrate_mads_record(iba_handle* h, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace,
-                                     int32_t* batch_sizes, int32_t cap_batches, int32_t* n_batches);
-iba_status iba_mads_selftest_trace(int32_t problem, const double* x0, const iba_mads_options* opt, iba_mads_result* res, double* trace, int32_t cap, int32_t* n_trace);
-
 /*
  * Multi-GPU inside one process: the keyframes sharded over n devices of a node (contiguous ranges balanced by points), one
  * handle, one issuing thread and one RCCL communicator per device (ncclCommInitAll). The reference's one parallel strategy is the

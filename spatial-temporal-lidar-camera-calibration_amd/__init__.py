@@ -20,6 +20,8 @@ from .abi import (IBA_MAX_BATCH, IbaCreateOptions, IbaLmOptions, IbaLmResult, Ib
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IBA_LIB", os.path.join(_HERE, "libiba_mi355x.so"))  # IBA_LIB: diagnostic builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "iba_mi355x.h")
+# every header of the boundary: the product surface and the diagnostics (tests check that the library exports all they declare)
+HEADER_PATHS = [HEADER_PATH, os.path.join(os.path.dirname(_HERE), "include", "iba_mi355x_debug.h")]
 
 STATUS = {0: "IBA_OK", 1: "IBA_ERR_INVALID_ARG", 2: "IBA_ERR_NO_DEVICE", 3: "IBA_ERR_HIP", 4: "IBA_ERR_UNSUPPORTED", 5: "IBA_ERR_STATE", 6: "IBA_ERR_IO"}
 
@@ -264,6 +266,18 @@ class IbaHandle:
         self._chk(self.lib.iba_debug_nn(self.h, C.c_int32(frame), _p(q), C.c_int32(len(q)), C.c_int32(mode),
                                         idx.ctypes.data_as(C.POINTER(C.c_uint32)), _p(d2)))
         return idx, d2
+
+    def debug_knn(self, frame, points, k=30, r2=np.inf):
+        """The sorted neighbour lists the plane fits build (iba_plane_kernel's list builder) around scan points given by ORIGINAL
+        index: (idx [n, k], d2 [n, k], cnt [n])."""
+        pts = np.ascontiguousarray(points, np.uint32).reshape(-1)
+        n = len(pts)
+        idx = np.zeros((n, k), np.uint32)
+        d2 = np.zeros((n, k), np.float64)
+        cnt = np.zeros(n, np.int32)
+        self.lib.iba_debug_knn.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.iba_debug_knn(self.h, C.c_int32(frame), _p(pts), C.c_int32(n), C.c_int32(k), C.c_double(r2), _p(idx), _p(d2), _p(cnt)))
+        return idx, d2, cnt
 
     def debug_plane(self, frame, point, which=1):
         """(normal[3], reg_sum, far_d2, k) of the memoised local plane at ORIGINAL scan point index `point` of `frame` (which: 0 cost path, 1 local)"""

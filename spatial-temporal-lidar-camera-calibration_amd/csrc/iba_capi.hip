@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/iba_mi355x.h"
+#include "../../include/iba_mi355x_debug.h"
 #include "iba_build.hpp"
 #include "iba_host_math.hpp"
 #include "iba_internal.hpp"
@@ -802,6 +803,14 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     return IBA_OK;
 }
 
+// plan_pairs commits a list slot (reference, bound, valid, epoch) when the candidates are staged — before iba_pairs_kernel has been
+// enqueued. A chain that fails between the two (staging launch, event, pair search) would leave slots valid for lists that were never
+// built, and a later call inside their bound would associate on stale or empty lists: a failed chain invalidates every slot.
+iba_status chain_status(iba_handle* h, iba_status s) {
+    if (s != IBA_OK && h) for (auto& ps : h->pslot) ps.valid = false;
+    return s;
+}
+
 // batches larger than IBA_MAX_BATCH (the candidates one launch chain takes) run as consecutive chunks
 template <class F>
 iba_status chunked(int B, F f) {
@@ -813,8 +822,8 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
     if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0, nullptr, true, true); if (s != IBA_OK) return s;   // the cost tuple never reads the derivatives
-    return run_split(h, dc, B, 2, false, false, d_partials, st);
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0, nullptr, true, true); if (s != IBA_OK) return chain_status(h, s);   // the cost tuple never reads the derivatives
+    return chain_status(h, run_split(h, dc, B, 2, false, false, d_partials, st));
 }
 
 }  // namespace
@@ -1398,13 +1407,53 @@ iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n
     return IBA_OK;
 }
 
+// debug: the kNN lists of the plane fits (fit_list_rows, the list builder of iba_plane_kernel / iba_fit_kernel) around n scan points
+// (ORIGINAL indices) of a local frame: up to k neighbours with d^2 < r2 each, nearest first (the point itself first, at 0)
+iba_status iba_debug_knn(iba_handle* h, int32_t frame, const uint32_t* points, int32_t n, int32_t k, double r2, uint32_t* out_idx, double* out_d2, int32_t* out_cnt) {
+    if (!h || !points || !out_idx || !out_d2 || !out_cnt || n < 1 || frame < 0 || frame >= h->n_frames) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    if (k < 1 || k > 64 || !(r2 > 0)) return fail(h, IBA_ERR_INVALID_ARG, "k must be in [1, 64] and r2 > 0 (INFINITY: no radius clip)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const FrameHdr& fh = h->h_frames[frame];
+    const uint32_t P = fh.P;
+    for (int i = 0; i < n; ++i) if (points[i] >= P) return fail(h, IBA_ERR_INVALID_ARG, "point index out of range");
+    DevBuf<uint32_t> di; DevBuf<double> dd; DevBuf<int32_t> dc;
+    hipError_t er = di.alloc((size_t)P * k);
+    if (er == hipSuccess) er = dd.alloc((size_t)P * k);
+    if (er == hipSuccess) er = dc.alloc((size_t)P);
+    std::vector<uint32_t> inv(P), hi((size_t)P * k); std::vector<double> hd((size_t)P * k); std::vector<int32_t> hc(P);
+    if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+    if (er == hipSuccess) {
+        const dim3 grid((P + 63) / 64);
+        if (k <= 32) hipLaunchKernelGGL(iba_knn_dump_kernel<2>, grid, dim3(64), 0, h->stream, h->dev_problem(), frame, r2, k, di.p, dd.p, dc.p);
+        else hipLaunchKernelGGL(iba_knn_dump_kernel<4>, grid, dim3(64), 0, h->stream, h->dev_problem(), frame, r2, k, di.p, dd.p, dc.p);
+        er = hipGetLastError();
+    }
+    if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+    if (er == hipSuccess) er = hipMemcpy(inv.data(), h->inv_perm.p + fh.pt_base, sizeof(uint32_t) * P, hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(hi.data(), di.p, sizeof(uint32_t) * hi.size(), hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(hd.data(), dd.p, sizeof(double) * hd.size(), hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(hc.data(), dc.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost);
+    di.release(); dd.release(); dc.release();
+    if (er != hipSuccess) return fail(h, IBA_ERR_HIP, hipGetErrorString(er));
+    for (int i = 0; i < n; ++i) {
+        const uint32_t pos = inv[points[i]];
+        out_cnt[i] = hc[pos];
+        for (int j = 0; j < k; ++j) {
+            const bool have = j < hc[pos];
+            out_idx[(size_t)i * k + j] = have ? hi[(size_t)pos * k + j] : kNone;
+            out_d2[(size_t)i * k + j] = have ? hd[(size_t)pos * k + j] : -1.0;
+        }
+    }
+    return IBA_OK;
+}
+
 static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr, const std::atomic<int>* pre_flag = nullptr) {
     if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, false, true); if (s != IBA_OK) return s;
-    return run_split(h, dc, B, 1, false, true, d_partials, st);
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, false, true); if (s != IBA_OK) return chain_status(h, s);
+    return chain_status(h, run_split(h, dc, B, 1, false, true, d_partials, st));
 }
 
 iba_status iba_eval_normal_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
@@ -1429,8 +1478,8 @@ static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, 
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, true, true); if (s != IBA_OK) return s;
-    return run_split(h, dc, B, 3, false, true, d_partials, st);
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, true, true); if (s != IBA_OK) return chain_status(h, s);
+    return chain_status(h, run_split(h, dc, B, 3, false, true, d_partials, st));
 }
 
 iba_status iba_eval_full_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {

@@ -220,7 +220,16 @@ iba_status iba_run_config_paths(iba_run_config* c, int32_t local_stage, iba_data
     bool ok = get_str(c, "io.BaseDir", base, err) && get_str(c, "io.VOIdFile", vo_id, err) && get_str(c, "io.LOFile", lo, err)
               && get_str(c, "io.PointCloudDir", c->pointcloud_dir, err) && get_str(c, "orb.KeyFrameDir", c->keyframe_dir, err) && get_str(c, "orb.MapFile", c->map_file, err);
     int32_t skip = 1, posx = 0, nbest = 0, minw = 0;
-    ok = ok && get_int(c, "io.PointCloudskip", skip, err) && get_bool(c, "io.PointCloudOnlyPositiveX", posx, err)
+    // the key's spelling differs between the stages: iba_global / iba_func read io["PointCloudskip"] (iba_global.cpp:456), iba_local
+    // io["PointCloudSkip"] (iba_local.cpp:372). Each stage asks for its own spelling first and accepts the other (the reference ships
+    // only the global stage's yml)
+    {
+        std::string e1;
+        const char* first = local_stage ? "io.PointCloudSkip" : "io.PointCloudskip";
+        const char* second = local_stage ? "io.PointCloudskip" : "io.PointCloudSkip";
+        if (ok && !get_int(c, first, skip, e1) && !get_int(c, second, skip, err)) { ok = false; err = e1; }
+    }
+    ok = ok && get_bool(c, "io.PointCloudOnlyPositiveX", posx, err)
          && get_int(c, "runtime.num_best_covis", nbest, err) && get_int(c, "runtime.min_covis_weight", minw, err);
     if (!ok) return cfail(IBA_ERR_IO, err);
     if (!base.empty() && base.back() != '/') base += '/';              // checkpath(base_dir) (kitti_tools.h:18-21; iba_global.cpp:421)

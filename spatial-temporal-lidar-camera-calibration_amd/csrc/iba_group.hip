@@ -111,7 +111,11 @@ struct iba_group {
     // ran out) raises the pool's abort flag: every worker abandons its wait, aborts its communicator and the group is `broken`
     // (every later call fails at once with IBA_ERR_STATE; destroy does not wait for the streams).
     std::atomic<bool> broken{false};
-    double wait_timeout_ms = 20000.0;     // IBA_GROUP_TIMEOUT_MS: bound of a worker's wait for its stream (a collective that never completes)
+    // IBA_GROUP_TIMEOUT_MS (default 20 s): bound of a worker's wait for its stream (a collective that never completes). A group that exceeds
+    // it is marked broken for good, so the bound must sit far above a healthy call: an evaluation takes 0.1 .. 10 ms; the FIRST call of a
+    // group (cold device, RCCL's lazy channel set-up, a profiler attached) may take seconds and gets four times the bound.
+    double wait_timeout_ms = 20000.0;
+    std::atomic<bool> warm{false};        // a call has completed on this group
     int debug_fail_rank = -1, debug_fail_phase = 1; bool debug_fail_armed = false;   // IBA_DEBUG_FAIL_RANK / _PHASE: one injected failure (tests)
 };
 
@@ -142,7 +146,7 @@ int poll_stream(iba_group* g, hipStream_t st, hipError_t* err) {
         if ((++polls & 15) == 0) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (g->pool.aborted()) return 0;
-            if (ms > g->wait_timeout_ms) { g->pool.raise_abort(); return 0; }
+            if (ms > g->wait_timeout_ms * (g->warm.load(std::memory_order_relaxed) ? 1.0 : 4.0)) { g->pool.raise_abort(); return 0; }
             if (ms > 2.0) std::this_thread::yield();
         }
     }
@@ -226,6 +230,7 @@ iba_status eval_chunk(iba_group* g, const double* x, int Bc, EvalKind kind) {
         g->h_part = g->h_sum.data();
     } else g->h_part = g->h_parts[0];
     g->last_issue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    g->warm.store(true, std::memory_order_relaxed);
     return IBA_OK;
 }
 
@@ -250,11 +255,26 @@ void iba_group_destroy(iba_group* g) {
         (void)run_all(g, [g](int i) -> iba_status {
             const bool broken = g->broken.load(std::memory_order_acquire);   // a stream of a broken group may hold a collective that never completes
             if (g->st[i] && !broken) (void)hipStreamSynchronize(g->st[i]);
-            if (g->comm[i]) { if (broken && rccl().CommAbort) (void)rccl().CommAbort(g->comm[i]); else (void)rccl().CommDestroy(g->comm[i]); }
+            if (g->comm[i]) { if (broken && rccl().CommAbort) (void)rccl().CommAbort(g->comm[i]); else if (!broken) (void)rccl().CommDestroy(g->comm[i]); }
+            // A broken group's stream may still hold the abandoned chain: iba_destroy, hipFree and hipHostFree synchronise with the device
+            // and would block for ever behind a collective that never completes (ncclCommAbort is optional — dlsym may not find it — and
+            // need not retire the kernel), and the chain may still be reading the buffers. Wait a bounded time for the stream to drain;
+            // if it does not, LEAK the handle and the buffers of this device and say so.
+            bool retired = true;
+            if (broken && g->st[i]) {
+                const auto t0 = std::chrono::steady_clock::now();
+                hipError_t q;
+                while ((q = hipStreamQuery(g->st[i])) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2000)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                retired = q == hipSuccess;
+            }
+            if (!retired) {
+                std::fprintf(stderr, "[iba] iba_group_destroy: device %d still runs an abandoned collective; its handle and buffers are leaked (not freed) so that teardown cannot hang\n", g->dev[i]);
+                return IBA_OK;
+            }
             if (g->h[i]) iba_destroy(g->h[i]);
             if (g->d_part[i]) (void)hipFree(g->d_part[i]);
             if (g->h_parts[i]) (void)hipHostFree(g->h_parts[i]);
-            if (g->st[i] && !broken) (void)hipStreamDestroy(g->st[i]);
+            if (g->st[i]) (void)hipStreamDestroy(g->st[i]);
             return IBA_OK;
         });
         stop_workers(g);

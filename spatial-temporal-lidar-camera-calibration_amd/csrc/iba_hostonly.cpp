@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/iba_mi355x.h"
+#include "../../include/iba_mi355x_debug.h"
 #include "iba_lm.hpp"
 #include "iba_mads.hpp"
 #include "iba_host_math.hpp"

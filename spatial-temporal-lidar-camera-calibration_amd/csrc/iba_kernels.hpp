@@ -432,6 +432,40 @@ __global__ __launch_bounds__(64) void iba_plane_kernel(DevProblem dp, double r2,
     if (pos < h.P) out[h.pt_base + pos] = fit_finish_lane(p4, pos, s_fit.list[lane], s_fit.count[lane], s_fit.far_d2[lane]);
 }
 
+// debug (iba_debug_knn): the sorted neighbour lists iba_plane_kernel builds around the scan points of ONE frame, dumped instead of fitted:
+// per tree position the kept neighbours nearest first — original point index and exact squared distance, the expression of the list
+// builder itself — and their number. Same grid as iba_plane_kernel for that frame, same fit_list_rows. The parity tests lay these
+// lists beside the reference's own nanoflann kNN(30) (tests/golden/knn_nanoflann_v150.npz: iba_global.cpp:125-133).
+template <int SLOTS>
+__global__ __launch_bounds__(64) void iba_knn_dump_kernel(DevProblem dp, int frame, double r2, int max_pts, uint32_t* __restrict__ out_idx, double* __restrict__ out_d2, int32_t* __restrict__ out_cnt) {
+    __shared__ FitLds<SLOTS> s_fit;
+    const FrameHdr& h = dp.frames[frame];
+    const uint32_t pos0 = blockIdx.x * 64u;
+    if (pos0 >= h.P) return;
+    const float4* p4 = dp.pts4 + h.pt_base;
+    const uint32_t* perm = dp.perm + h.pt_base;
+    const int lane = threadIdx.x;
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t pos = pos0 + 4u * (uint32_t)r + (uint32_t)(lane >> 4);
+        if (pos0 + 4u * (uint32_t)r >= h.P) break;
+        fit_list_rows<SLOTS>(p4, dp.nodes + h.node_base, h.P, h.depth, pos < h.P ? pos : kNone, r2, max_pts, s_fit, 4 * r);
+    }
+    __syncthreads();
+    const uint32_t pos = pos0 + (uint32_t)lane;
+    if (pos >= h.P) return;
+    const int count = s_fit.count[lane];
+    out_cnt[pos] = count;
+    const float4 cq = p4[pos];
+    const double qx = (double)cq.x, qy = (double)cq.y, qz = (double)cq.z;
+    for (int j = 0; j < count; ++j) {
+        const uint32_t pj = s_fit.list[lane][j];
+        const float4 v = p4[pj];
+        const double dx = qx - (double)v.x, dy = qy - (double)v.y, dz = qz - (double)v.z;
+        out_idx[(size_t)pos * max_pts + j] = perm[pj];
+        out_d2[(size_t)pos * max_pts + j] = (dx * dx + dy * dy) + dz * dz;
+    }
+}
+
 // ---- wave64 sum on the VALU (DPP row shifts + row broadcasts, no LDS traffic); total lands in lane 63 ----
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long b) {

@@ -37,6 +37,7 @@ constexpr int kNNWaves = kNNThreads / 64;
 constexpr uint32_t kSliceW = IBA_NN_SLICE;   // list positions per search block: a constant, so that the order of every sum is the same whatever the batch
 constexpr int kNNPartial = 8;   // doubles per (candidate, nn record): sum3d, cnt, valid, valid_pl, valid_pt, 3 spare
 constexpr int kMaxGroup = kNNThreads / 32 < 16 ? kNNThreads / 32 : 16;   // candidates per block (32 threads each in the final sums)
+static_assert(4 * (2 * kMaxGroup + 4) <= 128, "iba_nn_kernel's misc slab (layout_nn: 128 bytes) holds s_n[kMaxGroup], s_ctr[4] and s_sel[kMaxGroup]");
 
 struct NNLayout {   // byte offsets into the dynamic LDS of iba_nn_kernel
     uint32_t off_nodes, off_res, off_misc, off_cd, off_ovf, total;
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
         for (uint32_t i = ut + 4u * kThreads; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = guv[i]; s_kfl[i] = gfl[i]; }
     }
     if (ut < h.n_slots * 12u) s_rel[ut] = rv;
+    for (uint32_t i = ut + kThreads; i < h.n_slots * 12u; i += kThreads) s_rel[i] = dp.slots[h.slot_base + i / 12u].rel[i % 12u];   // more than 42 covisible keyframes: beyond one store per thread
     if (tid < 4) s_misc[tid] = 0u;
     __syncthreads();
 
@@ -1014,6 +1016,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         } else
         for (uint32_t i = ut; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kfl[i] = gfl[i]; }
         if (ut < h.n_slots * 12u) s_rel[ut] = rv;
+        for (uint32_t i = ut + kThreads; i < h.n_slots * 12u; i += kThreads) s_rel[i] = dp.slots[h.slot_base + i / 12u].rel[i % 12u];   // more than 42 covisible keyframes: beyond one store per thread
         if (tid == 0) s_qn[0] = 0u;
     }
     const int dbg = want >> 8;

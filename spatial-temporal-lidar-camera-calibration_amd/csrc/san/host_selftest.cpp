@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../../include/iba_mi355x.h"
+#include "../../../include/iba_mi355x_debug.h"
 
 static int failures = 0;
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "host_selftest: %s failed at line %d\n", #c, __LINE__); ++failures; } } while (0)

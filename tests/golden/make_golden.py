@@ -43,6 +43,47 @@ def knn_fixtures():
     print("wrote knn_nanoflann_v150.npz", len(out), "arrays")
 
 
+def knn_gpu_fixtures():
+    """Reference-held outputs laid out so that the HIP searches THEMSELVES can be replayed against them:
+      3d_self: kNN(30) of the reference's nanoflann (leaf 30) around EVERY point of a float32 scan — what ComputeAlignmentDist asks
+               around nn_pt (iba_global.cpp:125-133) and what iba_plane_kernel's list builder computes (iba_debug_knn);
+      2d_f32:  the 2-D leaf-10 tree of FindProjectCorrespondences (iba_global.cpp:84-95) over float32-exact pixels: scan points
+               (u, v, +-1) under the identity extrinsic with fx = 1, cx = cy = 0 project to (u, v) exactly, so the reference's tree
+               input IS the stored points; queries = float32 keypoints; 1-NN index (into the ORIGINAL scan, through ProjectIndex
+               :69-81) and squared distance. Replayed through iba_get_correspondences."""
+    from oracle import binding as ob
+    assert ob.ref_lib() is not None, "oracle/_ref not built (needs /root/reference)"
+    rng = np.random.default_rng(20251003)
+    out = {}
+    n = 2500
+    pts = (rng.normal(size=(n, 3)) * [20, 8, 1.5]).astype(np.float32)
+    assert len(np.unique(pts, axis=0)) == n
+    idx, d2, cnt = ob.knn("ref", 3, pts.astype(np.float64), 30, pts.astype(np.float64), 30)
+    out["3d_self_pts"] = pts
+    out["3d_self_k30_idx"], out["3d_self_k30_d2"], out["3d_self_k30_cnt"] = idx, d2, cnt
+    # 2-D: 6000 scan points, of which some lie behind the camera (z = -1) or outside the 1241 x 376 image
+    W, H, n2, nk = 1241.0, 376.0, 6000, 2000
+    uv = np.stack([rng.uniform(-60, W + 60, n2), rng.uniform(-40, H + 40, n2)], 1).astype(np.float32)
+    z = np.where(rng.uniform(size=n2) < 0.1, -1.0, 1.0).astype(np.float32)
+    scan = np.concatenate([uv * z[:, None], z[:, None]], 1).astype(np.float32)   # (x, y, z) with x / z = u, y / z = v exactly
+    assert np.array_equal((scan[:, 0].astype(np.float64) + 0.0 * scan[:, 2]) / scan[:, 2].astype(np.float64), uv[:, 0].astype(np.float64))
+    vis = (z > 0) & (uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H)   # iba_global.cpp:71-74
+    proj_index = np.flatnonzero(vis)
+    proj = uv[vis].astype(np.float64)
+    assert len(np.unique(proj, axis=0)) == len(proj)
+    sel = rng.choice(proj_index, 1500, replace=False)
+    kp = np.concatenate([uv[sel] + rng.normal(0, 0.6, (1500, 2)).astype(np.float32), np.stack([rng.uniform(0, W, nk - 1500), rng.uniform(0, H, nk - 1500)], 1).astype(np.float32)]).astype(np.float32)
+    kp = np.clip(kp, [0, 0], [W - 1, H - 1]).astype(np.float32)
+    idx2, d22, cnt2 = ob.knn("ref", 2, proj, 10, kp.astype(np.float64), 1)
+    out["2d_f32_scan"] = scan
+    out["2d_f32_kp"] = kp
+    out["2d_f32_k1_idx"] = proj_index[idx2[:, 0]].astype(np.uint32)     # ProjectIndex[indices[0]] (:93)
+    out["2d_f32_k1_d2"] = d22[:, 0]
+    out["2d_f32_WH"] = np.array([W, H])
+    np.savez_compressed(os.path.join(HERE, "knn_nanoflann_v150_gpu.npz"), **out)
+    print("wrote knn_nanoflann_v150_gpu.npz;", int((d22[:, 0] <= 2.25).sum()), "of", nk, "keypoints within max_pixel_dist")
+
+
 def path_fixtures():
     """Small scene + the oracle's outputs on it (regression pin of the restated path)."""
     synth = importlib.import_module(PKG + ".synth")
@@ -70,5 +111,9 @@ def path_fixtures():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gpu":   # only the fixtures added in round 5 (the others are not regenerated)
+        knn_gpu_fixtures()
+        sys.exit(0)
     knn_fixtures()
+    knn_gpu_fixtures()
     path_fixtures()

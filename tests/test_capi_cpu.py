@@ -1,4 +1,5 @@
-"""CPU-side checks of the product library: it loads, exports every symbol include/iba_mi355x.h declares,
+"""CPU-side checks of the product library: it loads, exports every symbol include/*.h declares (the product surface iba_mi355x.h
+and the diagnostics iba_mi355x_debug.h),
 fails loudly without a GPU (no CPU fallback), and its host-only logic (finalisation, sharding) is right."""
 import ctypes as C
 import re
@@ -18,8 +19,14 @@ def _has_gpu():
 def test_library_exports_every_declared_symbol(pkg):
     pkg.build_extension()
     lib = pkg.load_library()
-    names = sorted(set(re.findall(r"\b(iba_[a-z_0-9]+)\s*\(", open(pkg.HEADER_PATH).read())))
-    assert len(names) >= 20
+    import glob, os
+    headers = sorted(glob.glob(os.path.join(os.path.dirname(pkg.HEADER_PATH), "*.h")))
+    assert [os.path.basename(h) for h in headers] == ["iba_mi355x.h", "iba_mi355x_debug.h"] and sorted(pkg.HEADER_PATHS) == headers
+    names = sorted(set(re.findall(r"\b(iba_[a-z_0-9]+)\s*\(", "".join(open(h).read() for h in headers))))
+    assert len(names) >= 90
+    # header hygiene: nothing diagnostic is declared in the product header
+    product = set(re.findall(r"\b(iba_[a-z_0-9]+)\s*\(", open(pkg.HEADER_PATH).read()))
+    assert not [n for n in product if n.startswith("iba_debug_") or "selftest" in n or n in ("iba_last_phase_ms", "iba_last_kernel_ms", "iba_set_timing")]
     for n in names:
         assert getattr(lib, n) is not None, n
     assert lib.iba_partial_stride() == 64

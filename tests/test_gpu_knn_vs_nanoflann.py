@@ -1,0 +1,142 @@
+"""The HIP searches against REFERENCE-HELD outputs. tests/golden/knn_nanoflann_v150*.npz came out of the reference's own
+vendored nanoflann v1.5.0 compiled where it lies (oracle/_ref, tests/golden/make_golden.py) — the only data in this repository
+that reference code produced. Until round 5 only the CPU oracle was laid beside them (tests/test_oracle_kdtree.py); here the
+device kernels' own searches are:
+
+  * k = 1   the search kernel's kd search (lane_nn_visit through iba_debug_nn, all four query modes) on the 3-D leaf-30 fixtures
+            (`3d_leaf30`, `3d_leaf30_small`: float32 scans, arbitrary double queries)                nanoflann.hpp:1735-1811, iba_global.cpp:116-122
+  * k = 30  the list builder of the plane fits (fit_list_rows through iba_debug_knn) around EVERY point of a float32 scan
+            (`3d_self`), unclipped and clipped to norm_radius^2 (the strict d^2 < r^2 count)          nanoflann.hpp:201-234, iba_global.cpp:125-133
+  * 2-D     the leaf-10 tree FindProjectCorrespondences rebuilds per evaluation, replayed through iba_get_correspondences: float32-exact
+            pixels under the identity extrinsic, fx = 1 (`2d_f32`)                                    iba_global.cpp:55-96
+
+Bar: index AND squared distance bit-equal to nanoflann's. The one documented deviation is the tie rule (nanoflann: first visited
+in ITS tree; here: lowest original index) — it can only show on exact distance ties, so every fixture is searched for exact ties
+by brute force and the affected queries are LISTED (expected: none but the `dups` case, which is asserted separately), not waived."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "knn_nanoflann_v150.npz")
+GOLD_GPU = os.path.join(HERE, "golden", "knn_nanoflann_v150_gpu.npz")
+
+
+def _one_frame_problem(abi, scan, kp=None, intr=(718.856, 718.856, 607.1928, 185.2157, 1241.0, 376.0)):
+    """A one-keyframe problem around a given float32 scan (and keypoints): no MapPoints, no covisibility."""
+    scan = np.ascontiguousarray(scan, np.float32).reshape(-1, 3)
+    kp = np.zeros((1, 2), np.float32) if kp is None else np.ascontiguousarray(kp, np.float32).reshape(-1, 2)
+    K = len(kp)
+    eye = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    return abi.Problem(pt_offset=[0, len(scan)], pts_xyz=scan.reshape(-1), intrinsics=np.array(intr, np.float64), kp_offset=[0, K], kp_uv=kp.reshape(-1),
+                       kp_has_mappoint=np.zeros(K, np.uint8), kp_mappoint_w=np.zeros(3 * K, np.float32), Tcw=eye.astype(np.float32), covis_offset=[0, 0],
+                       covis_frame=np.zeros(0, np.int32), covis_relpose=np.zeros(0, np.float32), match_offset=[0], match_kp_ref=np.zeros(0, np.int32),
+                       match_kp_covis=np.zeros(0, np.int32), Tc_next=eye.astype(np.float32), Tl_next=eye)
+
+
+def _exact_ties_at_rank(pts64, q, k):
+    """queries whose k-th and (k+1)-th smallest squared distances (the reference's expression order) are EQUAL, or that hold an exact tie
+    anywhere inside their first k: only there may two correct kNN lists differ"""
+    out = []
+    for i in range(len(q)):
+        d = q[i][None, :] - pts64
+        d2 = np.zeros(len(pts64))
+        for c in range(pts64.shape[1]):
+            d2 = d2 + d[:, c] * d[:, c]
+        s = np.sort(d2)[: k + 1]
+        if np.any(s[1:] == s[:-1]):
+            out.append(i)
+    return out
+
+
+@pytest.mark.parametrize("name", ["3d_leaf30", "3d_leaf30_small"])
+def test_kd_search_k1_equals_nanoflann(pkg, abi, name):
+    z = np.load(GOLD)
+    pts, q = z[f"{name}_pts"], z[f"{name}_q"]
+    assert np.array_equal(pts, pts.astype(np.float32).astype(np.float64))       # a float32 scan widened, as VecVector3d from a KITTI .bin
+    h = pkg.IbaHandle(_one_frame_problem(abi, pts), abi.reference_yaml_params())
+    ref_i, ref_d = z[f"{name}_k1_idx"][:, 0], z[f"{name}_k1_d2"][:, 0]
+    assert _exact_ties_at_rank(pts, q, 1) == []                                  # no query of the fixture sits on an exact tie
+    for mode in (1, 2):                                                          # the query on the association path's slot / the cost path's
+        gi, gd = h.debug_nn(0, q, mode)
+        assert np.array_equal(gi, ref_i), (mode, np.flatnonzero(gi != ref_i)[:5])
+        assert np.array_equal(gd, ref_d), (mode, np.flatnonzero(gd != ref_d)[:5])
+    for mode in (3, 4):                                                          # both paths searched together (a partner query 1e-7 beside it)
+        gi, gd = h.debug_nn(0, q, mode)
+        assert np.array_equal(gi, ref_i) and np.array_equal(gd, ref_d), mode
+    h.close()
+
+
+def test_plane_fit_neighbour_lists_equal_nanoflann_knn30(pkg, abi):
+    z = np.load(GOLD_GPU)
+    pts = z["3d_self_pts"]
+    n = len(pts)
+    ref_i, ref_d, ref_c = z["3d_self_k30_idx"], z["3d_self_k30_d2"], z["3d_self_k30_cnt"]
+    assert np.all(ref_c == 30) and np.array_equal(ref_i[:, 0], np.arange(n)) and np.all(ref_d[:, 0] == 0)   # nn_pt itself comes first (iba_global.cpp:129)
+    ties = [i for i in range(n) if np.any(ref_d[i, 1:] == ref_d[i, :-1])]
+    assert ties == []                                                            # exact ties inside a reference list: listed, none in this fixture
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(_one_frame_problem(abi, pts), p)
+    gi, gd, gc = h.debug_knn(0, np.arange(n), k=30)
+    assert np.array_equal(gc, ref_c)
+    assert np.array_equal(gi, ref_i), np.flatnonzero(np.any(gi != ref_i, axis=1))[:5]
+    assert np.array_equal(gd, ref_d)
+    # the radius clip of ComputeAlignmentDist: k = #{d^2 < norm_radius^2}, strict (iba_global.cpp:131-133); wider, so that lists get cut and kept
+    for r2 in (p.norm_radius ** 2, 4.0, 25.0):
+        ci, cd, cc = h.debug_knn(0, np.arange(n), k=30, r2=r2)
+        want = (ref_d < r2).sum(1)
+        assert np.array_equal(cc, want)
+        keep = np.arange(30)[None, :] < want[:, None]
+        assert np.array_equal(ci[keep], ref_i[keep]) and np.array_equal(cd[keep], ref_d[keep])
+        assert 0 < (want < 30).sum() and (r2 < 20 or (want == 30).sum() > 0)
+    # a shorter list is the head of the longer one (norm_max_pts < 30)
+    si, sd, sc = h.debug_knn(0, np.arange(n), k=12)
+    assert np.array_equal(si, ref_i[:, :12]) and np.array_equal(sd, ref_d[:, :12]) and np.all(sc == 12)
+    h.close()
+
+
+def test_projected_correspondences_equal_nanoflann_2d_leaf10(pkg, abi):
+    z = np.load(GOLD_GPU)
+    scan, kp, (W, H) = z["2d_f32_scan"], z["2d_f32_kp"], z["2d_f32_WH"]
+    ref_i, ref_d = z["2d_f32_k1_idx"], z["2d_f32_k1_d2"]
+    # identity extrinsic, fx = fy = 1, cx = cy = 0: u = (fx x + cx z) / z = x / z exactly (iba_global.cpp:72-73)
+    prob = _one_frame_problem(abi, scan, kp, intr=(1.0, 1.0, 0.0, 0.0, W, H))
+    p = abi.reference_yaml_params()
+    h = pkg.IbaHandle(prob, p)
+    x = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    gk, gp = h.correspondences(x, 0)
+    want = ref_d <= p.max_pixel_dist ** 2                                        # inclusive gate (:93)
+    assert np.array_equal(gk, np.flatnonzero(want).astype(np.uint32))            # corrset is ordered by keypoint id
+    assert np.array_equal(gp, ref_i[want])
+    assert want.sum() > 1000 and (~want).sum() > 300
+    # exact ties among the projected points of a matched keypoint would be the tie rule's business: none in this fixture
+    uv = (scan[:, :2].astype(np.float64) / scan[:, 2:3].astype(np.float64))
+    vis = (scan[:, 2] > 0) & (uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H)
+    assert _exact_ties_at_rank(uv[vis], kp.astype(np.float64)[want], 1) == []
+    # a wider gate takes the keypoints whose reference 1-NN is further away: the same lists, cut elsewhere
+    for mpd in (0.6, 6.0):
+        q = abi.reference_yaml_params()
+        q.max_pixel_dist = mpd
+        h.set_params(q)
+        gk, gp = h.correspondences(x, 0)
+        w2 = ref_d <= mpd * mpd
+        assert np.array_equal(gk, np.flatnonzero(w2).astype(np.uint32)) and np.array_equal(gp, ref_i[w2])
+    h.close()
+
+
+def test_duplicate_points_are_the_only_deviation(pkg, abi):
+    """`2d_leaf10_dups`-style: exact duplicates in a 3-D scan. nanoflann keeps the duplicate it visits first, the kernels the lowest
+    original index: d^2 is still bit-equal, the index is one of the duplicates of the reference's."""
+    z = np.load(GOLD)
+    pts = z["3d_leaf30_pts"].copy()
+    pts[100:150] = pts[50:100]
+    h = pkg.IbaHandle(_one_frame_problem(abi, pts), abi.reference_yaml_params())
+    q = np.vstack([pts[50:100], pts[100:150] + 1e-9])
+    gi, gd = h.debug_nn(0, q, 1)
+    d2 = ((q[:, None, :] - pts[None, :, :]) ** 2)
+    d2 = (d2[:, :, 0] + d2[:, :, 1]) + d2[:, :, 2]
+    assert np.array_equal(gd, d2.min(1))
+    assert np.array_equal(gi, np.argmin(d2, axis=1).astype(np.uint32)) and np.all(gi < 100)   # the LOWER of the two duplicates
+    h.close()

@@ -129,6 +129,31 @@ def test_forty_covisible_keyframes(pkg, synth, abi, ob):
         pkg.IbaHandle(prob63, p)
 
 
+@pytest.mark.parametrize("n_covis", [43, 62])
+def test_more_than_forty_two_covisible_keyframes(pkg, synth, abi, ob, n_covis):
+    """the association kernels staged the relative poses with ONE store per thread — 512 of the up to 744
+    doubles — so the slots 42.. of a frame with 43..62 covisible keyframes were read from uninitialised LDS by the 3d-2d phase.
+    43 (the first slot beyond one store per thread) and 62 (the limit), on BOTH association kernels (shared pair search: a tight
+    batch; per-candidate: a batch as wide as the search box), against the oracle."""
+    prob, meta = synth.make_scene(n_frames=n_covis + 4, pts_per_frame=2000, n_keypoints=600, seed=47, n_covis=n_covis, new_mappoints=100, scan_kp=140)
+    assert int(np.diff(prob.arrays["covis_offset"].astype(np.int64)).max()) == n_covis
+    p = abi.reference_yaml_params()
+    h, o = pkg.IbaHandle(prob, p), ob.Oracle(prob)
+    xs = np.vstack([meta["x_gt"][None], synth.perturb(meta["x_gt"], np.random.default_rng(47), n=3)])
+    cost, _ = _check(h, o, p, xs)
+    assert h.last_path == 1
+    co, mo = prob.arrays["covis_offset"].astype(np.int64), prob.arrays["match_offset"].astype(np.int64)
+    beyond = sum(int(mo[gs + 1] - mo[gs]) for f in range(prob.n_frames) for gs in range(co[f] + 42, co[f + 1]))
+    assert beyond > 50 and cost[0].cnt_3d_2d > 4 * cost[0].n_corr   # matches in the slots beyond the 42nd
+    xw = meta["x_gt"][None, :] + np.random.default_rng(48).uniform(-1, 1, (4, 7)) * np.array([0.03, 0.03, 0.03, 0.1, 0.1, 0.1, 0.2])
+    _check(h, o, p, xw)
+    assert h.last_path == 0
+    cc = h.eval_cost(xs)   # the cost-only chain
+    for a, b in zip(cc, cost):
+        assert all(getattr(a, k) == getattr(b, k) for k in INT) and abs(a.f1 - b.f1) <= 1e-13 * b.f1
+    h.close()
+
+
 def test_max_pixel_dist_changes_on_a_live_handle(pkg, synth, abi, ob):
     """max_pixel_dist used to be baked into the handle (the reject bitmap of the association is the keypoints dilated by it);
     iba_set_params now rebuilds the bitmap. Both association kernels, against the oracle, for a tighter and a wider gate."""

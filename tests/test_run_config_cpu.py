@@ -139,6 +139,37 @@ def test_missing_and_malformed_entries_fail_loudly(tmp_path):
         fmt.RunConfig(str(tmp_path / "missing.yml"))
 
 
+def test_local_stage_reads_the_reference_s_own_key_spelling(tmp_path):
+    """iba_local.cpp:372 reads io["PointCloudSkip"] (capital S); iba_global.cpp:456 io["PointCloudskip"]. A config file
+    written for the reference's iba_local (the keys IBALocalParams needs, iba_local.cpp:358-377, with ITS spelling) must load for the
+    local stage; the global spelling is accepted as a fallback; neither present is an error that names the stage's own key."""
+    tree = json.loads(json.dumps(GOLD["calib"]["00"]["values"]))
+    del tree["io"]["PointCloudskip"]
+    tree["io"]["PointCloudSkip"] = 3
+    tree["io"]["PointCloudOnlyPositiveX"] = True
+    tree["runtime"].update({"neigh_radius": 0.55, "neigh_max_pts": 28, "robust_kernel_delta": 2.5})
+    p = str(tmp_path / "iba_calib_local.yml")
+    _emit_run_config(tree, p)
+    cfg = fmt.RunConfig(p)
+    dl = cfg.paths(local_stage=True)
+    assert (dl["pointcloud_skip"], dl["only_positive_x"]) == (3, 1)
+    dg = cfg.paths(local_stage=False)                      # the global stage ignores both flags whichever spelling the file has
+    assert (dg["pointcloud_skip"], dg["only_positive_x"]) == (1, 0)
+    lp = cfg.params(local_stage=True)
+    assert (lp.neigh_radius, lp.neigh_max_pts, lp.robust_kernel_delta) == (0.55, 28, 2.5)
+    cfg.close()
+    del tree["io"]["PointCloudSkip"]
+    _emit_run_config(tree, p)
+    cfg = fmt.RunConfig(p)
+    with pytest.raises(pkg.IbaError) as ei:
+        cfg.paths(local_stage=True)
+    assert "PointCloudSkip" in str(ei.value)
+    with pytest.raises(pkg.IbaError) as ei:
+        cfg.paths(local_stage=False)
+    assert "PointCloudskip" in str(ei.value)
+    cfg.close()
+
+
 @pytest.mark.parametrize("name", sorted(GOLD["orb"]))
 def test_cv_yaml_reader_on_the_orb_settings_files(name, tmp_path):
     """The cv::FileStorage reader behind iba_dataset_load (KeyFrames/NNNNNN.yml are written in this dialect) on the ORB-SLAM2
