@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define IBA_ABI_VERSION 1
+#define IBA_ABI_VERSION 2 /* 2: iba_params.factor_3d2d_kind */
 #define IBA_MAX_BATCH 64 /* candidates per launch chain; a call with more runs as consecutive chunks of this many */
 
 typedef enum iba_status {
@@ -126,6 +126,18 @@ typedef struct iba_params {
     /* engine knob (no reference counterpart): 1 = memoise the x-independent local-plane fit per
      * scan point (bit-identical results); 0 = refit inside every evaluation as the reference does. */
     int32_t plane_cache;
+
+    /* Which 3d-2d residual the Jacobian path builds (ABI version 2):
+     *   0  IBA_PlaneFactor (IBACalib2.hpp:152-184; g2o twin IBAPlaneEdge, IBACalib.hpp:103-140): the keypoint's ray intersected with the
+     *      local plane at its scan point, reprojected into every covisible keyframe — one block of 2 NConv rows per keypoint [default];
+     *   1  IBATestEdge (IBACalib.hpp:14-71, functor :40-58): the DIRECT point-to-pixel term — the matched scan point itself,
+     *      p1 = R_i (R_cl p0 + t_cl) + s t_i, one 2-row block per (correspondence, matched covisible keyframe), Huber(robust_kernel_delta)
+     *      each. The reference declares the edge and instantiates it nowhere; the edge set here is that of BAError's 3d-2d loop
+     *      (iba_global.cpp:291-328: every correspondence of a used frame x every covisible keyframe that matches its keypoint; no plane, no
+     *      MapPoint, no neighbourhood test), whose cost these are the normal equations of. The 3d-3d blocks are built as in mode 0 when
+     *      err_weight[1] > 1e-10 and not at all otherwise (BAError's switch, :214-220): err_weight = {1, 0} is BASELINE's
+     *      "point-to-pixel only" configuration on the Jacobian path. */
+    int32_t factor_3d2d_kind;
 } iba_params;
 
 /* Output of one BAError() call. The first five fields are the reference's returned tuple
@@ -152,7 +164,7 @@ typedef struct iba_normal_out {
     double b[7];
     double cost;          /* Ceres convention: 1/2 sum rho(s) */
     double chi2;          /* sum |r|^2 (un-robustified) */
-    int32_t n_factor_3d2d; /* IBA_PlaneFactor blocks */
+    int32_t n_factor_3d2d; /* IBA_PlaneFactor blocks (factor_3d2d_kind = 1: IBATestEdge blocks) */
     int32_t n_factor_p2pl; /* Point2Plane_Factor blocks */
     int32_t n_factor_p2pt; /* Point2Point_Factor blocks */
     int32_t n_residuals;   /* total scalar residuals */
@@ -247,7 +259,7 @@ iba_status iba_calibrate_lm(iba_handle* h, const double* x0, const iba_lm_option
 
 /* Per-residual values and Jacobians of the frozen problem (for Ceres / g2o adaptors and tests).
  * Call with r == NULL to query *n_rows. J is n_rows x 7 row-major, block_id[n_rows] identifies the
- * residual block, block_kind: 0 = IBA_PlaneFactor, 1 = Point2Plane, 2 = Point2Point. */
+ * residual block, block_kind: 0 = IBA_PlaneFactor, 1 = Point2Plane, 2 = Point2Point, 3 = IBATestEdge (factor_3d2d_kind = 1). */
 iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double* J, int32_t* block_id,
                               int32_t* block_kind, int64_t* n_rows);
 

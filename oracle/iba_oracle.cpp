@@ -62,7 +62,7 @@ struct Frame {
 };
 
 struct Factor {
-    int kind;  // 0 IBA_PlaneFactor, 1 Point2Plane_Factor, 2 Point2Point_Factor
+    int kind;  // 0 IBA_PlaneFactor, 1 Point2Plane_Factor, 2 Point2Point_Factor, 3 IBATestEdge (iba_params.factor_3d2d_kind = 1: one covisible keyframe, p0 = the matched scan point)
     int frame, kp;
     double fx, fy, cx, cy, u0, v0;
     std::vector<double> u1, v1;
@@ -70,7 +70,7 @@ struct Factor {
     std::vector<V3d> t;
     V3d p0, n0;          // plane factor
     V3d MapPoint, Q, n;  // 3d-3d factors
-    int rows() const { return kind == 0 ? 2 * (int)u1.size() : (kind == 1 ? 1 : 3); }
+    int rows() const { return (kind == 0 || kind == 3) ? 2 * (int)u1.size() : (kind == 1 ? 1 : 3); }
 };
 
 struct Oracle {
@@ -303,6 +303,27 @@ void eval_plane_factor(const Factor& f, const T* x, T* error) {  // IBACalib2.hp
         error[2 * i + 1] = v1_obs - v1;
     }
 }
+// IBATestEdge::operator() (IBACalib.hpp:40-58): the direct point-to-pixel term. _p0c = _Rcl _p0 + _tcl (:49), _p1c = _R _p0c + _t with
+// _t = t * _s (:48, :50), projection with fx, fy (:52-53), error = observation - keypoint (:54-55). u0, v0 are members the functor never reads.
+template <class T>
+void eval_test_edge(const Factor& f, const T* x, T* error) {
+    M3<T> Rcl; V3<T> tcl; T s;
+    Sim3Exp<T>(x, Rcl, tcl, s);
+    T fx(f.fx), fy(f.fy), cx(f.cx), cy(f.cy);
+    V3<T> p0 = castv<T>(f.p0);
+    V3<T> p0c = mul(Rcl, p0) + tcl;
+    for (size_t i = 0; i < f.u1.size(); ++i) {   // (one covisible keyframe per edge: size 1)
+        M3<T> R = castm<T>(f.R[i]);
+        V3<T> t = castv<T>(f.t[i]);
+        t = t * s;
+        T u1(f.u1[i]), v1(f.v1[i]);
+        V3<T> p1c = mul(R, p0c) + t;
+        T u1_obs = fx * p1c.x / p1c.z + cx;
+        T v1_obs = fy * p1c.y / p1c.z + cy;
+        error[2 * i] = u1_obs - u1;
+        error[2 * i + 1] = v1_obs - v1;
+    }
+}
 template <class T>
 void eval_p2x_factor(const Factor& f, const T* x, T* error) {  // IBACalib2.hpp:570-584, 611-625
     T inv[6] = {-x[0], -x[1], -x[2], -x[3], -x[4], -x[5]};
@@ -313,16 +334,20 @@ void eval_p2x_factor(const Factor& f, const T* x, T* error) {  // IBACalib2.hpp:
     if (f.kind == 2) { error[0] = M.x - Q.x; error[1] = M.y - Q.y; error[2] = M.z - Q.z; }
     else { error[0] = dot(M - Q, castv<T>(f.n)); }
 }
+template <class T>
+void eval_any_factor(const Factor& f, const T* x, T* error) {
+    if (f.kind == 0) eval_plane_factor<T>(f, x, error); else if (f.kind == 3) eval_test_edge<T>(f, x, error); else eval_p2x_factor<T>(f, x, error);
+}
 void eval_factor(const Factor& f, const double* x, double* r, double* J /*rows x 7, may be null*/) {
     using D7 = Dual<7>;
     const int rows = f.rows();
     if (!J) {
-        if (f.kind == 0) eval_plane_factor<double>(f, x, r); else eval_p2x_factor<double>(f, x, r);
+        eval_any_factor<double>(f, x, r);
         return;
     }
     D7 xd[7]; for (int i = 0; i < 7; ++i) xd[i] = D7(x[i], i);
     std::vector<D7> e(rows);
-    if (f.kind == 0) eval_plane_factor<D7>(f, xd, e.data()); else eval_p2x_factor<D7>(f, xd, e.data());
+    eval_any_factor<D7>(f, xd, e.data());
     for (int i = 0; i < rows; ++i) { r[i] = e[i].a; for (int c = 0; c < 7; ++c) J[i * 7 + c] = e[i].v[c]; }
 }
 
@@ -351,9 +376,26 @@ void BuildProblem(Oracle& O, const iba_params& prm, const double* params, bool m
         { frames_used++; n_corr += (int)pt2d3d_map.size(); }
         for (size_t ci = 0; ci < pt2d3d_map.size(); ++ci) {
             const uint32_t point2d_idx = pt2d3d_map[ci].first, point3d_idx = pt2d3d_map[ci].second;
+            const double* c = &kf.pts[3 * (size_t)point3d_idx];
+            const bool test_edges = prm.factor_3d2d_kind == 1;
+            if (test_edges) {
+                // IBATestEdge (IBACalib.hpp:14-71) over the edge set of BAError's 3d-2d loop (iba_global.cpp:291-328): this correspondence x every
+                // covisible keyframe that matches its keypoint, the scan point itself as _p0 — before any of BuildProblem's own tests
+                for (auto const& cv : kf.covis) {
+                    auto it = cv.kptmap.find((int)point2d_idx);
+                    if (it == cv.kptmap.end()) continue;
+                    const Frame& ckf = O.frames[cv.frame];
+                    Factor te; te.kind = 3; te.frame = (int)Fi; te.kp = (int)point2d_idx;
+                    te.fx = kf.fx; te.fy = kf.fy; te.cx = kf.cx; te.cy = kf.cy; te.u0 = kf.kp_uv[2 * point2d_idx]; te.v0 = kf.kp_uv[2 * point2d_idx + 1];
+                    te.p0 = V3d{c[0], c[1], c[2]}; te.n0 = {0, 0, 0}; te.MapPoint = {0, 0, 0}; te.Q = {0, 0, 0}; te.n = {0, 0, 0};
+                    te.u1.push_back(ckf.kp_uv[2 * it->second]); te.v1.push_back(ckf.kp_uv[2 * it->second + 1]);
+                    te.R.push_back(cv.rel.R); te.t.push_back(cv.rel.t);
+                    out_factors.push_back(te);
+                }
+                if (!(prm.err_weight[1] > 1e-10)) continue;   // no 3d-3d blocks (BAError's switch, iba_global.cpp:214-220)
+            }
             // ComputeLocalNeighbor (pointcloud.h:733-760)
             std::vector<uint32_t> neigh_idx; std::vector<double> sq_dist; size_t k;
-            const double* c = &kf.pts[3 * (size_t)point3d_idx];
             knn_clip(kf, c, prm.neigh_max_pts, prm.neigh_radius, neigh_idx, sq_dist, k);
             if ((int)k < prm.neigh_min_pts || sq_dist[k - 1] < prm.local_min_diff_dist * prm.local_min_diff_dist) continue;
             if (!kf.has_mp[point2d_idx]) continue;
@@ -374,7 +416,7 @@ void BuildProblem(Oracle& O, const iba_params& prm, const double* params, bool m
                 pf.R.push_back(cv.rel.R); pf.t.push_back(cv.rel.t);  // translation unscaled: iba_local.cpp:184-188
             }
             if (pf.u1.empty()) continue;
-            if (bvalid_plane) out_factors.push_back(pf);
+            if (bvalid_plane && !test_edges) out_factors.push_back(pf);
             V3d MapPointInLidar = apply(initSE3inv, MapPoint * init_scale);
             uint32_t mp_idx; double mp_sq;
             KNNResultSet rs(1); rs.init(&mp_idx, &mp_sq);
@@ -427,7 +469,7 @@ void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_no
             if (rows > 64) continue;
             eval_factor(f, x, r, J);
             double s = 0; for (int i = 0; i < rows; ++i) s += r[i] * r[i];
-            double rho0, rho1; huber(f.kind == 0 ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, s, rho0, rho1);
+            double rho0, rho1; huber((f.kind == 0 || f.kind == 3) ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, s, rho0, rho1);
             Lcost += 0.5 * rho0; Lchi2 += s;
             for (int i = 0; i < rows; ++i)
                 for (int a = 0; a < 7; ++a) {
@@ -435,7 +477,7 @@ void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_no
                     for (int c = 0; c < 7; ++c) LH[a * 7 + c] += rho1 * J[i * 7 + a] * J[i * 7 + c];
                 }
             out.n_residuals += rows;
-            if (f.kind == 0) out.n_factor_3d2d++; else if (f.kind == 1) out.n_factor_p2pl++; else out.n_factor_p2pt++;
+            if (f.kind == 0 || f.kind == 3) out.n_factor_3d2d++; else if (f.kind == 1) out.n_factor_p2pl++; else out.n_factor_p2pt++;
         }
         for (int i = 0; i < 49; ++i) out.H[i] = (double)LH[i];
         for (int i = 0; i < 7; ++i) out.b[i] = (double)Lb[i];
@@ -454,7 +496,7 @@ void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_no
             if (rows > 64) continue;
             eval_factor(f, x, r, J);
             double s = 0; for (int i = 0; i < rows; ++i) s += r[i] * r[i];
-            double rho0, rho1; huber(f.kind == 0 ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, s, rho0, rho1);
+            double rho0, rho1; huber((f.kind == 0 || f.kind == 3) ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, s, rho0, rho1);
             loc.cost += 0.5 * rho0; loc.chi2 += s;
             for (int i = 0; i < rows; ++i)
                 for (int a = 0; a < 7; ++a) {
@@ -462,7 +504,7 @@ void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_no
                     for (int c = 0; c < 7; ++c) loc.H[a * 7 + c] += rho1 * J[i * 7 + a] * J[i * 7 + c];
                 }
             loc.n_residuals += rows;
-            if (f.kind == 0) loc.n_factor_3d2d++; else if (f.kind == 1) loc.n_factor_p2pl++; else loc.n_factor_p2pt++;
+            if (f.kind == 0 || f.kind == 3) loc.n_factor_3d2d++; else if (f.kind == 1) loc.n_factor_p2pl++; else loc.n_factor_p2pt++;
         }
 #pragma omp critical
         {
@@ -634,7 +676,7 @@ static double block_sensitivity(const Factor& f, const double* x) {
     const int rows = f.rows();
     std::vector<L7> e0(rows), e1(rows);
     L7 xl[7]; for (int i = 0; i < 7; ++i) xl[i] = L7(x[i], i);
-    if (f.kind == 0) eval_plane_factor<L7>(f, xl, e0.data()); else eval_p2x_factor<L7>(f, xl, e0.data());
+    eval_any_factor<L7>(f, xl, e0.data());
     long double scale = 1.0L;
     for (int i = 0; i < rows; ++i) { scale = std::max(scale, fabsl(e0[i].a)); for (int c = 0; c < 7; ++c) scale = std::max(scale, fabsl(e0[i].v[c])); }
     long double worst = 0.0L;
@@ -643,7 +685,7 @@ static double block_sensitivity(const Factor& f, const double* x) {
             const int sgn = ((pat == 0) || (pat == 1 && (i & 1)) || (pat == 2 && (i % 3 == 0)) || (pat == 3 && i < 3)) ? 1 : -1;
             xl[i] = L7(x[i], i); xl[i].a = (long double)x[i] * (1.0L + (long double)sgn * 0x1p-52L);
         }
-        if (f.kind == 0) eval_plane_factor<L7>(f, xl, e1.data()); else eval_p2x_factor<L7>(f, xl, e1.data());
+        eval_any_factor<L7>(f, xl, e1.data());
         for (int i = 0; i < rows; ++i) {
             worst = std::max(worst, fabsl(e1[i].a - e0[i].a));
             for (int c = 0; c < 7; ++c) worst = std::max(worst, fabsl(e1[i].v[c] - e0[i].v[c]));
@@ -671,8 +713,7 @@ int oracle_block_forward_error(void* h, const double* x, double* err, int64_t* n
     for (auto const& f : O.factors) {
         const int rows = f.rows();
         std::vector<D7> ed(rows); std::vector<L7> el(rows);
-        if (f.kind == 0) { eval_plane_factor<D7>(f, xd, ed.data()); eval_plane_factor<L7>(f, xl, el.data()); }
-        else { eval_p2x_factor<D7>(f, xd, ed.data()); eval_p2x_factor<L7>(f, xl, el.data()); }
+        eval_any_factor<D7>(f, xd, ed.data()); eval_any_factor<L7>(f, xl, el.data());
         long double scale = 1.0L, dev = 0.0L;
         for (int i = 0; i < rows; ++i) {
             scale = std::max(scale, fabsl(el[i].a)); dev = std::max(dev, fabsl((long double)ed[i].a - el[i].a));
@@ -812,7 +853,7 @@ int oracle_block_normal(void* h, int64_t block, double n[3], double point[3], in
     Oracle& O = *(Oracle*)h;
     if (block < 0 || block >= (int64_t)O.factors.size()) return 1;
     const Factor& f = O.factors[block];
-    if (f.kind == 2) return 1;
+    if (f.kind == 2 || f.kind == 3) return 1;   // (no normal in a point-to-point block or an IBATestEdge)
     const V3d& v = f.kind == 0 ? f.n0 : f.n;
     const V3d& q = f.kind == 0 ? f.p0 : f.Q;
     n[0] = v.x; n[1] = v.y; n[2] = v.z;
@@ -824,7 +865,7 @@ int oracle_block_rows_with_normal(void* h, int64_t block, const double* x, const
     Oracle& O = *(Oracle*)h;
     if (block < 0 || block >= (int64_t)O.factors.size()) return 1;
     Factor f = O.factors[block];
-    if (f.kind == 2) return 1;
+    if (f.kind == 2 || f.kind == 3) return 1;   // (no normal in a point-to-point block or an IBATestEdge)
     (f.kind == 0 ? f.n0 : f.n) = V3d{n[0], n[1], n[2]};
     eval_factor(f, x, r, J);
     if (fwd_err) {   // the forward error of THIS evaluation (double against long double), relative to the block's scale
@@ -832,7 +873,7 @@ int oracle_block_rows_with_normal(void* h, int64_t block, const double* x, const
         L7 xl[7]; for (int i = 0; i < 7; ++i) xl[i] = L7(x[i], i);
         const int rows = f.rows();
         std::vector<L7> el(rows);
-        if (f.kind == 0) eval_plane_factor<L7>(f, xl, el.data()); else eval_p2x_factor<L7>(f, xl, el.data());
+        eval_any_factor<L7>(f, xl, el.data());
         long double scale = 1.0L, dev = 0.0L;
         for (int i = 0; i < rows; ++i) {
             scale = std::max(scale, fabsl(el[i].a)); dev = std::max(dev, fabsl((long double)r[i] - el[i].a));

@@ -54,6 +54,7 @@ class IbaParams(C.Structure):
         ("robust_kernel_delta", C.c_double),
         ("robust_kernel_3ddelta", C.c_double),
         ("plane_cache", C.c_int32),
+        ("factor_3d2d_kind", C.c_int32),
     ]
 
 

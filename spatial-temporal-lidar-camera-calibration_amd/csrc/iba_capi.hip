@@ -202,6 +202,7 @@ void to_dev_params(const iba_params& p, DevParams& d) {
     d.neigh_max_pts = p.neigh_max_pts; d.neigh_min_pts = p.neigh_min_pts;
     d.local_min_diff_dist2 = p.local_min_diff_dist * p.local_min_diff_dist; d.local_norm_reg_threshold = p.local_norm_reg_threshold;
     d.robust_kernel_delta = p.robust_kernel_delta; d.robust_kernel_3ddelta = p.robust_kernel_3ddelta; d.plane_cache = p.plane_cache;
+    d.p2pix = p.factor_3d2d_kind == 1 ? 1 : 0;
 }
 
 iba_status check_params(iba_handle* h, const iba_params& p) {
@@ -209,6 +210,7 @@ iba_status check_params(iba_handle* h, const iba_params& p) {
         return fail(h, IBA_ERR_UNSUPPORTED, "max_pixel_dist must be in (0, 64] px");
     if (p.norm_max_pts < 1 || p.norm_max_pts > 64 || p.neigh_max_pts < 1 || p.neigh_max_pts > 64)
         return fail(h, IBA_ERR_UNSUPPORTED, "norm_max_pts / neigh_max_pts must be in [1, 64] (the neighbour list lives one entry per lane of a wave)");
+    if (p.factor_3d2d_kind != 0 && p.factor_3d2d_kind != 1) return fail(h, IBA_ERR_INVALID_ARG, "factor_3d2d_kind must be 0 (IBA_PlaneFactor) or 1 (IBATestEdge)");
     return IBA_OK;
 }
 
@@ -575,7 +577,11 @@ iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, do
     // which is what the sums over the records expect)
     const dim3 grid(h->n_frames, B);
     const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
-    if (h->factor_valu && h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL(iba_factor_kernel<true>, grid, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+    if (h->dprm.p2pix) {   // IBATestEdge edges (factor_3d2d_kind = 1): an instantiation of its own (the matrix-core variant has none)
+        if (h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL((iba_factor_kernel<true, true>), grid, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+        else hipLaunchKernelGGL((iba_factor_kernel<false, true>), grid, dim3(kFactorThreads), 96u * std::max<uint32_t>(h->max_slots, 1u), st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+    }
+    else if (h->factor_valu && h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL(iba_factor_kernel<true>, grid, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
     else if (h->factor_valu) hipLaunchKernelGGL(iba_factor_kernel<false>, grid, dim3(kFactorThreads), 96u * std::max<uint32_t>(h->max_slots, 1u), st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
     else hipLaunchKernelGGL(iba_factor_mfma_kernel, grid, dim3(64), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
     HIP_TRY(h, hipGetLastError());
@@ -1650,7 +1656,8 @@ iba_status iba_eval_residuals(iba_handle* h, const double* x, double* r, double*
             const size_t g = fh.kp_base + inv[e];
             if (a[g].x == kNone && a[g].y == kNone) continue;
             row_off[g] = rows;
-            if (a[g].x != kNone) { const int nr = 2 * nconv[g]; for (int i = 0; i < nr; ++i) { bid.push_back(blk); bkind.push_back(0); } rows += nr; ++blk; }
+            if (a[g].x != kNone && h->dprm.p2pix) { for (int i = 0; i < nconv[g]; ++i) { bid.push_back(blk); bid.push_back(blk); bkind.push_back(3); bkind.push_back(3); rows += 2; ++blk; } }   // one IBATestEdge per matched covisible keyframe
+            else if (a[g].x != kNone) { const int nr = 2 * nconv[g]; for (int i = 0; i < nr; ++i) { bid.push_back(blk); bkind.push_back(0); } rows += nr; ++blk; }
             if (a[g].y != kNone) { const bool pl = (a[g].y >> 31) != 0; const int nr = pl ? 1 : 3; for (int i = 0; i < nr; ++i) { bid.push_back(blk); bkind.push_back(pl ? 1 : 2); } rows += nr; ++blk; }
         }
     }

@@ -49,6 +49,7 @@ iba_status iba_default_params(iba_params* p) {
     p->num_min_corr = 30; p->max_3d_dist = 1.0; p->neigh_radius = 0.6; p->neigh_max_pts = 30; p->neigh_min_pts = 5;
     p->local_min_diff_dist = 0.2; p->local_norm_reg_threshold = 0.001; p->robust_kernel_delta = 2.98; p->robust_kernel_3ddelta = 1.0;
     p->plane_cache = 1;
+    p->factor_3d2d_kind = 0;
     return IBA_OK;
 }
 

@@ -784,6 +784,76 @@ IBA_ACC_CONTRACT
     }
 }
 
+// IBATestEdge core (IBACalib.hpp:40-58; factor_3d2d_kind = 1): the matched scan point p0 reprojected DIRECTLY into every covisible keyframe
+// that matches the keypoint — p0c = R p0 + t (:49), p1c = R_i p0c + s t_i (:48, :50), (fx p1x / p1z + cx, fy p1y / p1z + cy) - (u1, v1) (:52-55).
+// One 2-row edge per matched slot, in slot order: calls edge(ru, rv, Ju[7], Jv[7]). Analytic chain rule through the same expressions the
+// reference's auto-diff differentiates: d p0c / dx_k = dt_k (+ dR_k p0 for k < 3), d p1c / dx_k = R_i d p0c / dx_k, d p1c / ds = t_i.
+template <bool MANY = true, class EdgeFn>
+__device__ __forceinline__ int test_edge_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K, const double* p0, EdgeFn edge, const double* rel_lds = nullptr) {
+    IBA_JAC_CONTRACT
+    double p0c[3], dq[6][3];
+    for (int r = 0; r < 3; ++r) {
+        p0c[r] = ((c.R[r * 3] * p0[0] + c.R[r * 3 + 1] * p0[1]) + c.R[r * 3 + 2] * p0[2]) + c.t[r];
+        for (int kk = 0; kk < 6; ++kk) {
+            double v = c.dt[kk][r];
+            if (kk < 3) v += (c.dR[kk][r * 3] * p0[0] + c.dR[kk][r * 3 + 1] * p0[1]) + c.dR[kk][r * 3 + 2] * p0[2];
+            dq[kk][r] = v;
+        }
+    }
+    int nconv = 0;
+    const float2* mrow = dp.match_uv + h.match_base + k;
+    const int n_words = (MANY && h.n_slots > (uint32_t)kCovisWord) ? 2 : 1;   // (block-uniform; see plane_factor_core)
+#pragma unroll 1
+    for (int wi = 0; wi < n_words; ++wi) {
+        uint32_t mask = (!MANY || wi == 0) ? dp.kp_fl[h.kp_base + k] >> 2 : dp.kp_fl2[h.kp_base + k];
+        const uint32_t base = (!MANY || wi == 0) ? 0u : (uint32_t)kCovisWord;
+        float2 mnext = mask ? mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K] : make_float2(0.f, 0.f);
+        while (mask) {
+            const uint32_t sl = base + (uint32_t)__ffs((int)mask) - 1u;
+            mask &= mask - 1u;
+            const float2 m = mnext;
+            if (mask) mnext = mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K];
+            const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel;
+            const double tx = rel[3] * c.s, ty = rel[7] * c.s, tz = rel[11] * c.s;   // _t = t * _s (IBACalib.hpp:48)
+            const double P1x = ((rel[0] * p0c[0] + rel[1] * p0c[1]) + rel[2] * p0c[2]) + tx;
+            const double P1y = ((rel[4] * p0c[0] + rel[5] * p0c[1]) + rel[6] * p0c[2]) + ty;
+            const double P1z = ((rel[8] * p0c[0] + rel[9] * p0c[1]) + rel[10] * p0c[2]) + tz;
+            const double ru = (h.fx * P1x / P1z + h.cx) - (double)m.x;
+            const double rv = (h.fy * P1y / P1z + h.cy) - (double)m.y;
+            const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
+            double Ju[7], Jv[7];
+            for (int kk = 0; kk < 6; ++kk) {
+                const double qx = (rel[0] * dq[kk][0] + rel[1] * dq[kk][1]) + rel[2] * dq[kk][2];
+                const double qy = (rel[4] * dq[kk][0] + rel[5] * dq[kk][1]) + rel[6] * dq[kk][2];
+                const double qz = (rel[8] * dq[kk][0] + rel[9] * dq[kk][1]) + rel[10] * dq[kk][2];
+                Ju[kk] = h.fx * iz * (qx - xz * qz); Jv[kk] = h.fy * iz * (qy - yz * qz);
+            }
+            Ju[6] = h.fx * iz * (rel[3] - xz * rel[11]); Jv[6] = h.fy * iz * (rel[7] - yz * rel[11]);
+            edge(ru, rv, Ju, Jv);
+            ++nconv;
+        }
+    }
+    return nconv;
+}
+// every edge is a residual block of its own: its own Huber weight (g2o: RobustKernelHuber per edge; delta = robust_kernel_delta)
+template <bool MANY>
+__device__ inline void test_edge_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K, const double* p0, NAcc& A, const double* rel_lds = nullptr) {
+    IBA_JAC_CONTRACT
+    test_edge_core<MANY>(c, h, dp, k, K, p0, [&](double ru, double rv, const double* Ju, const double* Jv) {
+        const double ssq = ru * ru + rv * rv;
+        double rho0, w; huber_w(prm.robust_kernel_delta, ssq, rho0, w);
+        A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0;
+        {
+            IBA_ACC_CONTRACT
+            for (int i = 0; i < 7; ++i) {
+                const double wu = w * Ju[i], wv = w * Jv[i];
+                for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wu * Ju[j] + wv * Jv[j];
+                A.b[i] += wu * ru + wv * rv;
+            }
+        }
+    }, rel_lds);
+}
+
 // M = Rlc (s m) + tlc and dM/dx for the 3d-3d factors (IBACalib2.hpp:570-584, 611-625)
 __device__ __forceinline__ void p2x_core(const Cand& c, const FrameHdr& h, const float4 mp, double* M, double dM[7][3]) {
     IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
@@ -836,7 +906,7 @@ constexpr int kFactorThreads = IBA_FACTOR_THREADS;
 // grid: (n_frames, B), kFactorThreads threads (one wave). Works through the dense residual-block list the association pass left for this
 // (candidate, frame): every lane owns a keypoint that has at least one block. list row = (per_cand ? b : 0).
 // record (b, rec_base + frame) of `partials` receives this block's sums.
-template <bool MANY>
+template <bool MANY, bool P2PIX = false>   // P2PIX: the 3d-2d blocks are IBATestEdge edges (factor_3d2d_kind = 1) — an instantiation of its own: the default kernel's code is untouched
 __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(IBA_FACTOR_WAVES, IBA_FACTOR_WAVES))) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist,
                                                                     const uint32_t* __restrict__ fcount, int flist_stride, int per_cand,
                                                                     double* __restrict__ partials, int nrec, int rec_base) {
@@ -871,11 +941,15 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
     auto plane_batch = [&](uint32_t cnt) {   // the first min(cnt, 64) plane factors of the queue
         if ((uint32_t)lane < cnt) {
             const uint2 q = qa[(ha + (uint32_t)lane) & (kQ - 1u)];
-            const PlaneRec& rec = planes[q.y];
             const float4 pt = p4[q.y];
-            const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z}, n0[3] = {rec.nx, rec.ny, rec.nz};
-            const float2 uv = dp.kp_uv[h.kp_base + q.x];
-            plane_factor_accum<MANY>(c, h, dp, prm, q.x, h.K, (double)uv.x, (double)uv.y, p0, n0, A, s_rel);
+            const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z};
+            if (P2PIX) test_edge_accum<MANY>(c, h, dp, prm, q.x, h.K, p0, A, s_rel);
+            else {
+                const PlaneRec& rec = planes[q.y];
+                const double n0[3] = {rec.nx, rec.ny, rec.nz};
+                const float2 uv = dp.kp_uv[h.kp_base + q.x];
+                plane_factor_accum<MANY>(c, h, dp, prm, q.x, h.K, (double)uv.x, (double)uv.y, p0, n0, A, s_rel);
+            }
         }
         ha += min(cnt, 64u);
     };
@@ -1151,6 +1225,14 @@ __global__ __launch_bounds__(64) void iba_residual_kernel(DevProblem dp, DevPara
     const Cand& c = cands[0];
     const float* xs = dp.xs + h.pt_base; const float* ys = dp.ys + h.pt_base; const float* zs = dp.zs + h.pt_base;
     const PlaneRec* planes = prm.plane_cache ? dp.plane_local + h.pt_base : dp.scratch_local + h.pt_base;   // slot 0 = frozen problem
+    if (a.x != kNone && prm.p2pix) {   // IBATestEdge rows: one 2-row edge per matched covisible keyframe
+        const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]};
+        test_edge_core(c, h, dp, k, h.K, p0, [&](double ru, double rv, const double* Ju, const double* Jv) {
+            r_out[row] = ru; r_out[row + 1] = rv;
+            for (int i = 0; i < 7; ++i) { J_out[row * 7 + i] = Ju[i]; J_out[(row + 1) * 7 + i] = Jv[i]; }
+            row += 2;
+        });
+    } else
     if (a.x != kNone) {
         const PlaneRec rec = planes[a.x];
         const double p0[3] = {(double)xs[a.x], (double)ys[a.x], (double)zs[a.x]}, n0[3] = {rec.nx, rec.ny, rec.nz};

@@ -125,6 +125,9 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     // counts of this thread's run: cost-list | association-list << 16 entries (K < 65 535: each fits 16 bits, so do the block totals); the valid
     // keypoints are counted per wave with ballots (scalar unit). (Round 3 carried the three counts in one 64-bit word: its adds,
     // its DPP prefix and the re-derivation of the flags in the list pass were 26 M of the kernel's 79 M vector instructions.)
+    // which keypoints the association list holds: a MapPoint AND a covisible match for BuildProblem's blocks (iba_local.cpp:213, 259-260); a
+    // covisible match alone when the 3d-2d residual is IBATestEdge (factor_3d2d_kind = 1: the edge set of BAError's 3d-2d loop, iba_global.cpp:295-300)
+    const uint32_t amask = prm.p2pix ? 2u : 3u;
     uint32_t mine = 0u, wave_valid = 0u;
     uint4 bi_keep = make_uint4(kNone, kNone, kNone, kNone);
     uint32_t mC_keep = 0u, mA_keep = 0u;   // FLREG: which of the run's four keypoints go to the cost / the association list
@@ -139,7 +142,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
             const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
             wave_valid += (uint32_t)__popcll(__ballot(valid));
             const uint32_t w = valid ? fv[j] : 0u;
-            mC |= (w != 0u ? 1u : 0u) << j; mA |= ((w & 3u) == 3u ? 1u : 0u) << j;
+            mC |= (w != 0u ? 1u : 0u) << j; mA |= ((w & amask) == amask ? 1u : 0u) << j;
         }
         mine += (uint32_t)__popc(mC) | ((uint32_t)__popc(mA) << 16);
         if (FLREG) { mC_keep = mC; mA_keep = mA; }
@@ -171,7 +174,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
                     else {
                         const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
                         const uint32_t w = valid ? fv[j] : 0u;
-                        wk[j] = usedC ? w != 0u : (w & 3u) == 3u;
+                        wk[j] = usedC ? w != 0u : (w & amask) == amask;
                     }
                     ip[j] = wk[j] ? inv_perm[bv[j]] : 0u;
                 }
@@ -188,9 +191,13 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     for (uint32_t i = tid; i < n3; i += kThreads) {
         const uint32_t e = s_list[i], k = e & 0xffffu;
         uint32_t ax_ = kNone, flags = 0u;
-        if (usedA && ((e >> 16) & 3u) == 3u) {
+        if (usedA && ((e >> 16) & amask) == amask) {
             const uint32_t pos = s_pos[i];
-            if (refit) { ax_ = pos; flags |= kFlagA; }
+            // IBATestEdge mode: the 3d-2d edges need no plane (.y = the matched point, always); the 3d-3d block keeps BuildProblem's
+            // conditions (MapPoint, valid neighbourhood) and exists only when the 3d-3d term is on (err_weight[1], iba_global.cpp:214-220)
+            const bool want3 = !prm.p2pix || (prm.use_3d3d && ((e >> 16) & 1u));
+            if (refit) { ax_ = pos; if (want3) flags |= kFlagA; }
+            else if (prm.p2pix) { ax_ = pos; if (want3 && (dp.plane_ok[h.pt_base + pos] & 1u)) flags |= kFlagA; }
             else {   // the two verdicts of the memoised local plane at the matched point: one byte instead of the 48-byte record
                 const uint32_t v = dp.plane_ok[h.pt_base + pos];
                 if ((v & 3u) == 3u) ax_ = pos;      // ComputeLocalNeighbor valid (pointcloud.h:752) and bvalid_plane (iba_local.cpp:231)
@@ -2041,7 +2048,7 @@ __global__ __launch_bounds__(64) void iba_fit_kernel(DevProblem dp, DevParams pr
         if (needA) {
             const bool neigh_ok = local_neigh_ok(prm, rec0);                           // pointcloud.h:752
             const bool plane_ok = neigh_ok && local_plane_ok(prm, rec0);              // bvalid_plane (iba_local.cpp:231)
-            e.y = plane_ok ? posA : kNone;
+            e.y = (plane_ok || prm.p2pix) ? posA : kNone;   // (IBATestEdge mode: the edge needs no plane)
             if (!neigh_ok) e.w &= ~kFlagA;   // no 3d-3d block either (the `continue` at iba_local.cpp:209-211)
             flist[at] = e;
             if (plane_ok) scratch[posA] = rec0;

@@ -125,6 +125,7 @@ struct DevParams {
     double local_min_diff_dist2, local_norm_reg_threshold;
     double robust_kernel_delta, robust_kernel_3ddelta;
     int32_t plane_cache;
+    int32_t p2pix;                // iba_params.factor_3d2d_kind == 1: the 3d-2d residual is IBATestEdge (the matched scan point reprojected directly) instead of IBA_PlaneFactor
 };
 
 // frozen residual block of the Jacobian path (what BuildProblem hands to Ceres)

@@ -154,3 +154,97 @@ def test_plane_edge_twin_and_block_conditioning(synth, abi, ob):
         elif kind[lo] != 0:
             assert cond[i] == 1.0 and o.plane_edge20(int(bid[lo]), x) is None
     assert seen > 20
+
+
+def test_test_edge_against_torch_autograd_and_the_cost_loop(ob, abi, synth, gold):
+    """IBATestEdge (IBACalib.hpp:14-71, functor :40-58) as factor kind 3 (iba_params.factor_3d2d_kind = 1). The reference declares the
+    edge and constructs it nowhere, so it is pinned three ways: (1) its rows and Jacobians against an independent torch.float64
+    autograd evaluation of p1 = R_i (R_cl p0 + t_cl) + s t_i through scipy-checked Sim3Exp formulas; (2) central differences;
+    (3) its EDGE SET against BAError's own 3d-2d loop (iba_global.cpp:291-328): exactly cnt_3d_2d of them lie inside the image, and
+    the mean of |r| over those below corr_3d_2d_threshold is the cost tuple's f1."""
+    torch = pytest.importorskip("torch")
+    z, prob = gold
+    p = abi.reference_yaml_params()
+    p.factor_3d2d_kind = 1
+    o = ob.Oracle(prob)
+    x = z["xs"][1]
+    n_blocks = o.build_problem(p, x)
+    r, J, bid, kind, fk = o.eval_residuals(x)
+    assert set(np.unique(kind)) == {1, 2, 3} and n_blocks == len(np.unique(bid))
+    m3 = kind == 3
+    assert m3.sum() % 2 == 0 and np.all(np.bincount(bid[m3])[np.unique(bid[m3])] == 2)    # 2-row blocks, one per (correspondence, covisible keyframe)
+    # (3) the edge set is the 3d-2d loop's: every in-image edge is one of cnt_3d_2d, the gated mean of the distances is f1
+    c = o.eval_cost(p, x[None])[0]
+    a = prob.arrays
+    W, H = a["intrinsics"][4], a["intrinsics"][5]
+    ru, rv = r[m3][0::2], r[m3][1::2]
+    # observation = residual + matched keypoint; the matched keypoint of an edge is not returned: recover it from the problem arrays
+    kp_off, co, mo = a["kp_offset"].astype(np.int64), a["covis_offset"].astype(np.int64), a["match_offset"].astype(np.int64)
+    uv1 = []
+    edge_fk = fk[m3][0::2]
+    seen = {}
+    for f, k in edge_fk:
+        i = seen.get((f, k), 0)
+        seen[(f, k)] = i + 1
+        hits = []
+        for gs in range(co[f], co[f + 1]):
+            mm = np.flatnonzero(a["match_kp_ref"][mo[gs]:mo[gs + 1]] == k)
+            if len(mm):
+                kc = a["match_kp_covis"][mo[gs] + mm[0]]
+                hits.append(a["kp_uv"].reshape(-1, 2)[kp_off[a["covis_frame"][gs]] + kc])
+        uv1.append(hits[i])
+    uv1 = np.array(uv1, np.float64)
+    ou, ov = ru + uv1[:, 0], rv + uv1[:, 1]
+    inside = (ou >= 0) & (ou < W) & (ov >= 0) & (ov < H)
+    dist = np.sqrt(ru * ru + rv * rv)
+    assert inside.sum() == c.cnt_3d_2d and (inside & (dist < p.corr_3d_2d_threshold)).sum() == c.valid_cnt_3d_2d
+    assert np.isclose(dist[inside & (dist < p.corr_3d_2d_threshold)].mean(), c.f1, rtol=1e-12)
+    # with err_weight[1] = 0 no 3d-3d block is built: the point-to-pixel-only problem (BASELINE configs[0])
+    p0 = abi.reference_yaml_params()
+    p0.factor_3d2d_kind = 1
+    p0.err_weight[1] = 0.0
+    o.build_problem(p0, x)
+    r0, J0, _, kind0, _ = o.eval_residuals(x)
+    assert set(np.unique(kind0)) == {3} and np.array_equal(r0, r[m3]) and np.array_equal(J0, J[m3])
+    no = o.eval_factors(p0, x)[0]
+    assert no.n_factor_3d2d == m3.sum() // 2 and no.n_factor_p2pl == 0 and no.n_factor_p2pt == 0 and no.n_residuals == m3.sum()
+    # (1) torch autograd on 40 edges
+    def sim3(xt):
+        w, u, s = xt[:3], xt[3:6], xt[6]
+        th = torch.sqrt((w * w).sum())
+        Om = torch.zeros(3, 3, dtype=torch.float64)
+        Om[0, 1], Om[0, 2], Om[1, 0], Om[1, 2], Om[2, 0], Om[2, 1] = -w[2], w[1], w[2], -w[0], -w[1], w[0]
+        I = torch.eye(3, dtype=torch.float64)
+        R = I + torch.sin(th) / th * Om + (1 - torch.cos(th)) / th ** 2 * Om @ Om
+        V = I + (1 - torch.cos(th)) / th ** 2 * Om + (th - torch.sin(th)) / th ** 3 * Om @ Om
+        return R, V @ u, s
+    fx, fy, cx, cy = (float(v) for v in a["intrinsics"][:4])
+    rows = np.flatnonzero(m3)[0::2][:40]
+    o.build_problem(p, x)
+    pt_off = a["pt_offset"].astype(np.int64)
+    for e, row in enumerate(rows):
+        f, k = fk[row]
+        kp_, pt_ = o.correspondences(p, x, int(f))
+        p0v = torch.tensor(prob.frame_points(int(f))[pt_[list(kp_).index(k)]].astype(np.float64))
+        # which covisible keyframe: the i-th matching slot of this keypoint, in slot order
+        i = int((edge_fk[:list(np.flatnonzero(m3)[0::2]).index(row)] == [f, k]).all(1).sum())
+        slots = [gs for gs in range(co[f], co[f + 1]) if k in a["match_kp_ref"][mo[gs]:mo[gs + 1]]]
+        gs = slots[i]
+        rel = torch.tensor(a["covis_relpose"].reshape(-1, 12)[gs].astype(np.float64)).reshape(3, 4)
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        def fun(xt):
+            R, t, s = sim3(xt)
+            p1 = rel[:, :3] @ (R @ p0v + t) + s * rel[:, 3]
+            return torch.stack([fx * p1[0] / p1[2] + cx, fy * p1[1] / p1[2] + cy]) - torch.tensor(uv1[e])
+        val = fun(xt).detach().numpy()
+        Jt = torch.autograd.functional.jacobian(fun, xt).numpy()
+        assert np.allclose(val, r[row:row + 2], rtol=1e-11, atol=1e-9) and np.allclose(Jt, J[row:row + 2], rtol=1e-9, atol=1e-9 * np.abs(Jt).max())
+    # (2) central differences over every row
+    Jn = np.zeros_like(J)
+    for kk in range(7):
+        hh = 1e-6 * max(1.0, abs(x[kk]))
+        xp, xm = x.copy(), x.copy()
+        xp[kk] += hh
+        xm[kk] -= hh
+        Jn[:, kk] = (o.eval_residuals(xp)[0] - o.eval_residuals(xm)[0]) / (2 * hh)
+    assert np.allclose(J[m3], Jn[m3], rtol=2e-5, atol=2e-5 * np.abs(J[m3]).max())
