@@ -145,7 +145,7 @@ def test_more_than_forty_two_covisible_keyframes(pkg, synth, abi, ob, n_covis):
     co, mo = prob.arrays["covis_offset"].astype(np.int64), prob.arrays["match_offset"].astype(np.int64)
     beyond = sum(int(mo[gs + 1] - mo[gs]) for f in range(prob.n_frames) for gs in range(co[f] + 42, co[f + 1]))
     assert beyond > 50 and cost[0].cnt_3d_2d > 4 * cost[0].n_corr   # matches in the slots beyond the 42nd
-    xw = meta["x_gt"][None, :] + np.random.default_rng(48).uniform(-1, 1, (4, 7)) * np.array([0.03, 0.03, 0.03, 0.1, 0.1, 0.1, 0.2])
+    xw = meta["x_gt"][None, :] + np.random.default_rng(48).uniform(-1, 1, (7, 7)) * np.array([0.03, 0.03, 0.03, 0.1, 0.1, 0.1, 0.2])   # seven candidates far from each other: more than four groups
     _check(h, o, p, xw)
     assert h.last_path == 0
     cc = h.eval_cost(xs)   # the cost-only chain
