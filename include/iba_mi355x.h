@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 #define IBA_ABI_VERSION 2 /* 2: iba_params.factor_3d2d_kind */
-#define IBA_MAX_BATCH 64 /* candidates per launch chain; a call with more runs as consecutive chunks of this many */
+#define IBA_MAX_BATCH 64 /* the batch unit of the callers in this library (one MADS poll block, the planner's diagnostics); NOT a limit of the evaluators */
+#define IBA_MAX_CHAIN 512 /* most candidates ONE launch chain takes (iba_create_options.max_chain_batch <= this); a call with more runs as consecutive chains */
 
 typedef enum iba_status {
     IBA_OK = 0,
@@ -201,10 +202,16 @@ typedef struct iba_create_options {
     double pair_inflation;        /* inflation of a reusable list's bound [1.25] */
     int32_t anchored_lists;       /* 3-D 1-NN memoised around an anchor extrinsic that follows the candidates [1] */
     double anchor_reach;          /* drift (m) of a MapPoint query 30 m out that moves the anchor [0.06] */
-    int32_t side_stream;          /* staging launch / derivative copy on a second stream of the handle [1] */
+    int32_t side_stream;          /* (round 3-4: staging launch on a second stream of the handle) no effect since round 5: the chain has no staging launch [1] */
     int32_t spin_wait;            /* the host polls the stream at the end of a call instead of blocking [1] */
     int32_t factor_mfma;          /* normal-equation sums on the matrix cores (v_mfma_f64_16x16x4; measured slower) [0] */
     int32_t pair_list_capacity;   /* entries per keyframe of a pair list; 0 = automatic. A full list only costs speed [0] */
+    int32_t max_chain_batch;      /* candidates one launch chain takes, 1..IBA_MAX_CHAIN [512]: a shard of few keyframes (one rank of an 8-GPU job) fills the
+                                     device only with many candidates per chain. Work lists are allocated for the largest batch a call has passed so far
+                                     (16 B x keypoints x keyframes per candidate); with plane_cache = 0 a chain takes at most IBA_MAX_BATCH */
+    int32_t chain_fold;           /* 1: the candidate block reaches the device through spare blocks of the first kernel of the chain and the hand-eye terms
+                                     are evaluated inside the summing kernel (no staging launch, no second stream, no event between kernels) [1];
+                                     0: a staging launch of its own at the head of every chain */
 } iba_create_options;
 iba_status iba_default_create_options(iba_create_options* o);
 iba_status iba_create_ex(const iba_problem_desc* desc, const iba_params* params, int device,

@@ -7,6 +7,7 @@ import ctypes as C
 import numpy as np
 
 IBA_MAX_BATCH = 64
+IBA_MAX_CHAIN = 512
 
 
 class IbaProblemDesc(C.Structure):
@@ -61,7 +62,7 @@ class IbaParams(C.Structure):
 class IbaCreateOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("common_pairs", C.c_int32), ("common_max_px", C.c_double), ("max_pair_groups", C.c_int32), ("pair_memo", C.c_int32),
                 ("pair_memo_max_batch", C.c_int32), ("pair_inflation", C.c_double), ("anchored_lists", C.c_int32), ("anchor_reach", C.c_double), ("side_stream", C.c_int32),
-                ("spin_wait", C.c_int32), ("factor_mfma", C.c_int32), ("pair_list_capacity", C.c_int32)]
+                ("spin_wait", C.c_int32), ("factor_mfma", C.c_int32), ("pair_list_capacity", C.c_int32), ("max_chain_batch", C.c_int32), ("chain_fold", C.c_int32)]
 
 
 class IbaCostOut(C.Structure):

@@ -76,7 +76,7 @@ struct iba_handle {
     uint32_t max_slots = 0;               // covisible keyframes of the busiest frame
     uint32_t lstride = 1;                 // entries per (candidate, frame) row of the lists: no list is longer than maxKw
     int nn_ns = 1;                        // search blocks per (frame, candidate group): ceil(maxKw / kSliceW)
-    DevBuf<double> d_nn_partials;         // IBA_MAX_BATCH * n_frames * kMaxSlices * kNNPartial
+    DevBuf<double> d_nn_partials;         // part_cap * n_frames * nn_ns * kNNPartial (ensure_lists)
     hipEvent_t ev_mid = nullptr;
     float last_assoc_ms = 0.f, last_nn_ms = 0.f;
     // common pairs of a batch of nearby candidates (iba_pairs_kernel + iba_assoc2_kernel)
@@ -90,7 +90,7 @@ struct iba_handle {
     // up to kAnchorSets anchors (an optimiser polls around two incumbents, the feasible and the infeasible one): each with its own set of lists
     bool anchor_valid[kAnchorSets] = {false, false}; AnchorRef anchor_ref[kAnchorSets]{}; int calls_since_anchor[kAnchorSets] = {0, 0}; unsigned long long anchor_used[kAnchorSets] = {0, 0};
     unsigned long long anchor_clock = 0; size_t anchor_set_elems = 0;
-    uint8_t anchor_sel[IBA_MAX_BATCH] = {0};   // this call: the set each candidate reads (255: none)
+    uint8_t anchor_sel[kMaxChain] = {0};       // this call: the set each candidate reads (255: none)
     double anchor_reach = 0.06;           // IBA_ANCHOR_REACH (m): a batch whose reference candidate moves a nominal MapPoint further than this from the anchor's query gets a new anchor
     int anchor_builds = 0;
     // list slots of the common pairs: each holds the pair lists of ONE group of candidates (reference + bound) and may outlive the call
@@ -117,7 +117,6 @@ struct iba_handle {
     int pairs_builds = 0; int pair_memo_max_b = 40; double pair_memo_max_px = 8.0;   // IBA_PAIR_MEMO_MAX_B
     const double* jets_x = nullptr; int jets_B = 0, jets_slot = 0;   // candidates whose derivative half is still to be computed (finish_jets)
     int last_nn_nrec = 0, last_nn_B = 0;   // shape of the search kernel's records of the last evaluation (iba_debug_nn_left_to_tree)
-    bool he_staged = false;               // the hand-eye terms of the staged candidates were computed by the staging launch
     const Cand* jets_src = nullptr; const std::atomic<int>* jets_flag = nullptr;   // ... or is being computed by the group's calling thread: the block to copy once *jets_flag is set
     int last_path = 0;                    // 1: the last evaluation chain used the common pairs
 
@@ -135,11 +134,11 @@ struct iba_handle {
     int scratch_cap = -1; bool scratch_local_aliases = false; int64_t n_pt_total = 0;
     bool plane_local_aliases_cost = false;
     double plane_cost_r2 = -1, plane_local_r2 = -1; int plane_cost_max = -1, plane_local_max = -1;
-    DevBuf<Cand> d_cands;                 // kRing * IBA_MAX_BATCH
-    DevBuf<double> d_frame_partials;      // IBA_MAX_BATCH * n_frames * kPartialStride
-    DevBuf<double> d_partials;            // IBA_MAX_BATCH * kPartialStride
+    DevBuf<Cand> d_cands;                 // kRing * chain_cap
+    DevBuf<double> d_frame_partials;      // part_cap * nrec * kPartialStride (ensure_lists)
+    DevBuf<double> d_partials;            // chain_cap * kPartialStride
     DevBuf<uint32_t> d_corr;              // n_keypoints
-    DevBuf<double> d_he;                  // IBA_MAX_BATCH * n_frames hand-eye values
+    DevBuf<double> d_he;                  // part_cap * n_frames: hand-eye terms of handles with more than kHeLds frames (iba_reduce2_kernel)
     int assoc_cap = 0;
     DevBuf<uint2> d_assoc_frozen;         // n_keypoints (iba_build_problem)
     DevBuf<uint4> d_flist, d_flist_frozen;       // dense residual-block lists: [cand][frame][maxK] / [frame][maxK]
@@ -147,16 +146,19 @@ struct iba_handle {
     bool frozen_valid = false; int32_t frozen_frames = 0, frozen_ncorr = 0;
     int nfb = 0;                          // factor-kernel records per candidate (= n_frames)
     int nrec = 0;                         // partial records per candidate = n_frames + nfb
-    Cand* h_cands = nullptr;              // pinned, kRing * IBA_MAX_BATCH
+    Cand* h_cands = nullptr;              // pinned, kRing * chain_cap
     double* h_partials = nullptr;         // pinned
     double* h_partials_dev = nullptr;     // the same buffer as the kernels see it: the last kernel of a chain writes the sums there (no D2H copy)
     Cand* h_cands_dev = nullptr;          // the pinned candidate ring as the fetch kernel sees it
     hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
-    // The staging launch of a cost evaluation (candidates -> device, hand-eye terms) runs on a stream of its own beside the pair search,
-    // which needs neither: ev_entry orders it behind the caller's stream, the slot's ring event brings the caller's stream back
-    // before the first kernel that reads the candidates (IBA_SIDE_STREAM=0: one stream, staging first).
-    hipStream_t side = nullptr; hipEvent_t ev_entry = nullptr; int side_on = 1; int head_slot = -1; bool head_deferred = false; int head_B = 0;
-    bool side_in_use = false;             // this call's staging launch ran on the side stream (which is therefore ordered behind the caller's earlier work)
+    // The head of a chain (round 5): the candidate block reaches the device through spare blocks of the chain's FIRST kernel (the pair
+    // search when one runs, else the association kernel, whose own blocks then read their candidate from the pinned ring), the hand-eye
+    // terms are evaluated by the summing kernel: no staging launch, no second stream, no event between kernels. chain_fold = 0: a
+    // staging launch (iba_fetch_kernel) at the head of every chain.
+    int chain_fold = 1;                   // iba_create_options.chain_fold / IBA_CHAIN_FOLD
+    int chain_cap = kMaxChain;            // candidates one launch chain takes (iba_create_options.max_chain_batch / IBA_MAX_CHAIN)
+    bool head_pending = false; int head_slot = -1, head_B = 0;   // this call's candidate block still waits in the pinned ring for the first kernel of run_split
+    int part_cap = 0;                     // candidates the per-candidate record buffers hold (ensure_lists)
     bool ring_used[kRing] = {false, false, false, false};
     int ring_next = 0;
     std::vector<FrameHdr> h_frames;
@@ -316,13 +318,11 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
 // stays valid for later calls. Sets h->pplan / h->n_build (the pair search of this call), h->amap, h->n_groups.
 // is every member of the group inside the bound of a valid slot? (-1: no)
 static int covering_slot(const iba_handle* h, const Cand* hc, const GroupPick& g) {
-    Cand tmp[IBA_MAX_BATCH];
-    for (int j = 0; j < g.n; ++j) { std::memcpy(tmp[j].R, hc[g.idx[j]].R, sizeof(tmp[j].R)); std::memcpy(tmp[j].t, hc[g.idx[j]].t, sizeof(tmp[j].t)); }
     for (int sl = 0; sl < kMaxPairGroups; ++sl) {
         const iba_handle::PairSlot& ps = h->pslot[sl];
         if (!ps.valid) continue;
         double rho[9], tau[3];
-        if (!batch_spread(tmp, g.n, ps.ref.R, ps.ref.t, rho, tau, nullptr)) continue;
+        if (!batch_spread(hc, g.n, ps.ref.R, ps.ref.t, rho, tau, nullptr, g.idx)) continue;
         bool fits = true;
         for (int i = 0; i < 9; ++i) fits = fits && rho[i] <= ps.ref.rho[i];
         for (int i = 0; i < 3; ++i) fits = fits && tau[i] <= ps.ref.tau[i];
@@ -387,9 +387,10 @@ inline bool plan_pairs(iba_handle* h, const Cand* hc, int B) {
             pl.cnt_off[k] = cnt_off(sl, ps.epoch); pl.next_off[k] = cnt_off(sl, ps.epoch + 1u);
             ++ps.epoch;
             // (lists that later calls may reuse are bounded entrywise only: the candidates' own per-block bound is this batch's)
-            const bool own = h->pair_bound && gp[g].n > 1 && !memo;
+            const bool own = h->pair_bound && gp[g].n > 1 && gp[g].n <= kOwnBoundMax && !memo;   // (a larger group: entrywise only — the candidates' own motions take a lane each in the pair search)
             pl.first[k] = (uint8_t)rel_at; pl.count[k] = (uint8_t)(own ? gp[g].n : 0);
-            if (own) { std::memcpy(pl.rel[rel_at], gp[g].rel, sizeof(float) * 12 * (size_t)gp[g].n); rel_at += gp[g].n; }
+            if (own && rel_at + gp[g].n > kOwnBoundMax) { pl.count[k] = 0; }   // (the rows of this launch's groups share PairsPlan::rel)
+            else if (own) { std::memcpy(pl.rel[rel_at], gp[g].rel, sizeof(float) * 12 * (size_t)gp[g].n); rel_at += gp[g].n; }
             ps.ref = gp[g].gr; ps.valid = memo;
         }
         h->pslot[sl].last_use = ++h->pair_clock;
@@ -450,23 +451,25 @@ iba_status ensure_scratch(iba_handle* h) {
     return IBA_OK;
 }
 
-// stages B candidates into a pinned ring slot and enqueues the H2D copy; returns the device pointer. The block is computed
-// from x here, or copied from `pre` when the caller (iba_group) has already computed it for all its devices. jets = 0: the
-// values only (cost evaluations never read the derivatives); jets = 2: the values now, the derivatives later (finish_jets:
-// the host differentiates the exponentials while the GPU runs the association and search kernels on the values).
-iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1, const std::atomic<int>* pre_flag = nullptr, bool with_he = false, bool plan = false) {
+// Stages B candidates into a slot of the pinned ring. The block is computed from x here, or copied from `pre` when the caller
+// (iba_group) has already computed it for all its devices. jets = 0: the values only (cost evaluations never read the derivatives);
+// jets = 2: the values now, the derivatives later (finish_jets: the host differentiates the exponentials while the GPU runs the
+// association and search kernels on the values) — a small batch computes them at once (0.6 us each: less than a second copy).
+// plan: the chain goes through run_split, which carries the block to the device in spare blocks of its first kernel (chain_fold);
+// otherwise — and for the callers outside run_split — a staging launch copies it here. *d_out = where the device copy will be.
+iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Cand** d_out, const Cand* pre = nullptr, int jets = 1, const std::atomic<int>* pre_flag = nullptr, bool plan = false) {
     const int slot = h->ring_next; h->ring_next = (h->ring_next + 1) % kRing;
     if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
-    Cand* hc = h->h_cands + (size_t)slot * IBA_MAX_BATCH;
-    Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
+    Cand* hc = h->h_cands + (size_t)slot * h->chain_cap;
+    Cand* dc = h->d_cands.p + (size_t)slot * h->chain_cap;
     h->last_hc = hc;
     h->jets_x = nullptr; h->jets_src = nullptr; h->jets_flag = nullptr;
-    if (!pre && jets == 2 && B <= 4) jets = 1;   // a few candidates: their derivatives cost the host less (0.6 us each) than the second fetch of the block
+    if (!pre && jets == 2 && B <= 16) jets = 1;   // a small batch: its derivatives cost the host less (0.6 us each) than the second copy of the block
     if (pre) {   // the group's block: complete, or (pre_flag) with the derivative half still being computed by the calling thread
         if (pre_flag && jets == 2) {
             // the calling thread is writing the derivative half of `pre` right now: only the value half is read here (the other is
-            // copied by finish_jets once *pre_flag is set). The stale derivative words of the ring slot that the staging fetch carries
-            // along are overwritten on the device by finish_jets' own fetch, stream-ordered before the factor kernel.
+            // copied by finish_jets once *pre_flag is set). The stale derivative words of the ring slot that the head's copy carries
+            // along are overwritten on the device by finish_jets' own copy, stream-ordered before the factor kernel.
             for (int b = 0; b < B; ++b) std::memcpy((void*)&hc[b], (const void*)&pre[b], offsetof(Cand, dR));
             h->jets_src = pre; h->jets_flag = pre_flag; h->jets_B = B; h->jets_slot = slot;
         } else std::memcpy(hc, pre, sizeof(Cand) * (size_t)B);
@@ -477,36 +480,26 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
     const bool planned = plan && h->common_mode > 0 && B >= h->common_min_batch && h->d_pairs.p;
     h->cref_ok = planned && plan_pairs(h, hc, B);
     h->plan_wide = planned && !h->cref_ok;   // the planner looked at this batch and found it wide everywhere
-    // the block crosses PCIe by a kernel that reads the pinned ring (a copy-engine transfer of these 70 KB costs ~15 us of latency
-    // at the head of every evaluation; a strided copy of the value halves alone was slower still)
-    {
+    h->head_pending = false; h->head_slot = slot; h->head_B = B;
+    if (plan && h->chain_fold) h->head_pending = true;   // run_split's first kernel carries the block (and records the slot's event at the end of the chain)
+    else {
+        // the block crosses PCIe by a kernel that reads the pinned ring (a copy-engine transfer of these 70 KB costs ~15 us of latency)
         const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)B / 16);
-        const Cand* src = h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH;
-        h->he_staged = with_he && h->n_frames > 0;
-        h->head_slot = -1; h->head_deferred = false; h->side_in_use = false;
-        // the side stream pays when there is a pair search to run beside (44 us against this launch's 9); a call whose groups all reuse
-        // earlier lists has nothing to hide the staging behind, and the two event hops cost it ~10 us (tools/chain_gaps.sh, B = 1)
-        if (h->he_staged && h->side_on && h->side && h->cref_ok && h->n_build > 0) {   // launched by run_split, on the side stream, right behind the pair search (launch_head)
-            h->head_deferred = true; h->head_slot = slot; h->head_B = B; h->side_in_use = true;
-        } else {
-            if (h->he_staged) {   // K7 rides in the same launch (one kernel less at the head of every cost evaluation)
-                const uint32_t n_fetch = (n16 + 255) / 256;
-                hipLaunchKernelGGL(iba_fetch_he_kernel, dim3(n_fetch + (uint32_t)((B * h->n_frames + 31) / 32)), dim3(64), 0, st, (const uint4*)src, (uint4*)dc, n16, n_fetch, h->dev_problem(), src, B, h->d_he.p);
-            } else hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)src, (uint4*)dc, n16);
-            HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, hipEventRecord(h->ring_ev[slot], st));
-        }
+        hipLaunchKernelGGL(iba_fetch_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)(h->h_cands_dev + (size_t)slot * h->chain_cap), (uint4*)dc, n16);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ring_ev[slot], st));
     }
     if (jets == 2) { h->jets_x = x; h->jets_B = B; h->jets_slot = slot; }
     h->ring_used[slot] = true;
     *d_out = dc;
     return IBA_OK;
 }
-// the derivative half of the staged candidates: computed and uploaded now (before the factor kernel is enqueued)
+// the derivative half of the staged candidates: computed (or taken over from the group's calling thread) and copied now, in stream
+// order, before the factor kernel is enqueued
 iba_status finish_jets(iba_handle* h, hipStream_t st) {
     if (!h->jets_x && !h->jets_src) return IBA_OK;
-    Cand* hc = h->h_cands + (size_t)h->jets_slot * IBA_MAX_BATCH;
-    Cand* dc = h->d_cands.p + (size_t)h->jets_slot * IBA_MAX_BATCH;
+    Cand* hc = h->h_cands + (size_t)h->jets_slot * h->chain_cap;
+    Cand* dc = h->d_cands.p + (size_t)h->jets_slot * h->chain_cap;
     if (h->jets_src) {   // the group's calling thread has been differentiating while this device's kernels ran on the values
         while (h->jets_flag->load(std::memory_order_acquire) == 0) { /* microseconds */ }
         for (int b = 0; b < h->jets_B; ++b)   // the derivative half alone: the values stay as staged
@@ -514,16 +507,12 @@ iba_status finish_jets(iba_handle* h, hipStream_t st) {
         h->jets_src = nullptr; h->jets_flag = nullptr;
     } else
     for (int b = 0; b < h->jets_B; ++b) make_cand_jets(h->jets_x + 7 * b, hc[b]);
-    {   // the derivative half alone (the kernels in flight read the value half). When this call's staging launch went to the side
-        // stream, so does this copy — it then runs beside the search kernel instead of between it and the factor kernel — and the
-        // caller's stream waits for it; otherwise it is stream-ordered where it stands.
+    {   // the derivative half alone (the kernels in flight read the value half), on the chain's own stream: a second stream would hide
+        // these 4 us beside the search kernel at the price of two event hops (~6 us each, tools/chain_gaps.sh)
         static_assert(offsetof(Cand, dR) % 16 == 0 && sizeof(Cand) % 16 == 0, "the halves of a Cand are copied as 16-byte words");
         const uint32_t w0 = (uint32_t)(offsetof(Cand, dR) / 16), w1 = (uint32_t)(sizeof(Cand) / 16), n = (uint32_t)h->jets_B * (w1 - w0);
-        hipStream_t cs = h->side_in_use ? h->side : st;
-        hipLaunchKernelGGL(iba_fetch_jets_kernel, dim3((n + 255) / 256), dim3(256), 0, cs, (const uint4*)(h->h_cands_dev + (size_t)h->jets_slot * IBA_MAX_BATCH), (uint4*)dc, (uint32_t)h->jets_B, w0, w1, w1);
+        hipLaunchKernelGGL(iba_fetch_jets_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4*)(h->h_cands_dev + (size_t)h->jets_slot * h->chain_cap), (uint4*)dc, (uint32_t)h->jets_B, w0, w1, w1);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(h->ring_ev[h->jets_slot], cs));   // the slot is busy until this copy has been read
-        if (h->side_in_use) HIP_TRY(h, hipStreamWaitEvent(st, h->ring_ev[h->jets_slot], 0));
     }
     h->jets_x = nullptr;
     return IBA_OK;
@@ -545,32 +534,6 @@ hipError_t wait_stream(iba_handle* h, hipStream_t st) {
     return hipStreamSynchronize(st);
 }
 
-// The staging launch of a cost evaluation on the side stream. mark_entry() is called BEFORE the pair search is enqueued on the
-// caller's stream (the side stream is ordered behind what the caller's stream held at that moment, not behind the pair search),
-// launch_head() right after it, join_head() before the first kernel that reads the candidates or the hand-eye terms.
-iba_status mark_entry(iba_handle* h, hipStream_t st) {
-    if (h->head_deferred) HIP_TRY(h, hipEventRecord(h->ev_entry, st));
-    return IBA_OK;
-}
-iba_status launch_head(iba_handle* h) {
-    if (!h->head_deferred) return IBA_OK;
-    h->head_deferred = false;
-    const int slot = h->head_slot, B = h->head_B;
-    const Cand* src = h->h_cands_dev + (size_t)slot * IBA_MAX_BATCH;
-    Cand* dc = h->d_cands.p + (size_t)slot * IBA_MAX_BATCH;
-    const uint32_t n16 = (uint32_t)(sizeof(Cand) * (size_t)B / 16), n_fetch = (n16 + 255) / 256;
-    HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_entry, 0));
-    hipLaunchKernelGGL(iba_fetch_he_kernel, dim3(n_fetch + (uint32_t)((B * h->n_frames + 31) / 32)), dim3(64), 0, h->side, (const uint4*)src, (uint4*)dc, n16, n_fetch, h->dev_problem(), src, B, h->d_he.p);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->side));
-    return IBA_OK;
-}
-iba_status join_head(iba_handle* h, hipStream_t st) {
-    if (h->head_deferred) { iba_status s = mark_entry(h, st); if (s != IBA_OK) return s; s = launch_head(h); if (s != IBA_OK) return s; }
-    if (h->head_slot >= 0) { HIP_TRY(h, hipStreamWaitEvent(st, h->ring_ev[h->head_slot], 0)); h->head_slot = -1; }
-    return IBA_OK;
-}
-
 iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
     if (h->n_frames == 0) return IBA_OK;
     // (a handle whose frames hold no keypoint at all still launches: every list is empty and the kernel writes zero records,
@@ -589,20 +552,33 @@ iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, do
 }
 
 
-// work lists of B candidates (the lists also carry the residual blocks to the factor kernel)
+// per-candidate buffers of a chain — work lists (they also carry the residual blocks to the factor kernel), list lengths, partial
+// records, hand-eye scratch — sized for the largest batch a call has passed so far (a chain takes up to chain_cap candidates: 16 B x
+// keypoints x keyframes each for the lists alone, which a handle that is only ever asked for 64 never pays)
 iba_status ensure_lists(iba_handle* h, int B, hipStream_t st) {
     if (h->assoc_cap >= B && (h->params.plane_cache || h->d_frefit.p)) return IBA_OK;
     B = std::max(B, h->assoc_cap);
     HIP_TRY(h, hipStreamSynchronize(st)); HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t nf1 = (size_t)std::max(h->n_frames, 1);
     h->d_flist.release(); h->d_fcount.release(); h->d_lcount.release();
-    HIP_TRY(h, h->d_flist.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
-    HIP_TRY(h, h->d_fcount.alloc((size_t)B * std::max(h->n_frames, 1)));
-    HIP_TRY(h, h->d_lcount.alloc((size_t)B * std::max(h->n_frames, 1)));
+    HIP_TRY(h, h->d_flist.alloc((size_t)B * nf1 * h->lstride));
+    HIP_TRY(h, h->d_fcount.alloc((size_t)B * nf1));
+    HIP_TRY(h, h->d_lcount.alloc((size_t)B * nf1));
     h->d_frefit.release();
-    if (!h->params.plane_cache) HIP_TRY(h, h->d_frefit.alloc((size_t)B * std::max(h->n_frames, 1) * h->lstride));
+    if (!h->params.plane_cache) HIP_TRY(h, h->d_frefit.alloc((size_t)std::min(B, (int)IBA_MAX_BATCH) * nf1 * h->lstride));   // (a chain of refitted planes takes at most IBA_MAX_BATCH candidates)
+    if (h->part_cap < B) {
+        h->d_frame_partials.release(); h->d_nn_partials.release(); h->d_he.release();
+        HIP_TRY(h, h->d_frame_partials.alloc((size_t)B * std::max(h->nrec, 1) * kPartialStride));
+        HIP_TRY(h, h->d_nn_partials.alloc((size_t)B * nf1 * h->nn_ns * kNNPartial));
+        HIP_TRY(h, h->d_he.alloc((size_t)B * nf1));
+        h->part_cap = B;
+    }
     h->assoc_cap = B;
     return IBA_OK;
 }
+// candidates one chain takes on this handle right now: with the planes refitted per evaluation every candidate of a chain owns a
+// private set of plane records (48 B x scan points), allocated for IBA_MAX_BATCH of them
+inline int chain_limit(const iba_handle* h) { return h->params.plane_cache ? h->chain_cap : std::min(h->chain_cap, (int)IBA_MAX_BATCH); }
 
 
 // Two-kernel evaluation chain (plane_cache = 1) on stream st: [hand-eye] -> association -> grouped 1-NN -> [factors] -> sums.
@@ -627,15 +603,19 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     const int NS = h->nn_ns;
     NNLayout nl;
     if (!layout_nn(h, nl)) return fail(h, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel");
+    if (h->part_cap < B) { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }   // (the frozen problem's chain: one candidate)
+    // the candidate block of this chain: still in the pinned ring (the first kernel below carries it to the device: chain_fold) or copied already
+    const bool head = h->head_pending; h->head_pending = false;
+    const uint4* head_src = head ? (const uint4*)(h->h_cands_dev + (size_t)h->head_slot * h->chain_cap) : nullptr;
+    const uint32_t head_n16 = head ? (uint32_t)(sizeof(Cand) * (size_t)B / 16) : 0u;
+    auto chain_done = [&]() -> iba_status {   // the ring slot is free again once everything enqueued so far has run (the head's copy, finish_jets' copy)
+        if (head) HIP_TRY(h, hipEventRecord(h->ring_ev[h->head_slot], st));
+        return IBA_OK;
+    };
     if (nf == 0) {
-        { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }
         HIP_TRY(h, hipMemsetAsync(d_partials, 0, sizeof(double) * (size_t)B * kPartialStride, st));
         if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev0, st)); HIP_TRY(h, hipEventRecord(h->ev_mid, st)); HIP_TRY(h, hipEventRecord(h->ev1, st)); HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
-        return IBA_OK;
-    }
-    if ((want & 2) && !h->he_staged) {   // K7 in its own tiny kernel: one lane per (candidate, frame)
-        hipLaunchKernelGGL(iba_he_kernel, dim3((B * nf + 31) / 32), dim3(64), 0, st, dp, dc, B, h->d_he.p);
-        HIP_TRY(h, hipGetLastError());
+        return chain_done();
     }
     const int per_xcd = (nf + 7) / 8;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
@@ -658,19 +638,19 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     // wide batch searches per candidate (iba_assoc_kernel). Same results either way, bit for bit.
     const bool common = !frozen && h->last_hc && h->cref_ok;
     h->last_path = common ? (h->n_groups > 1 ? 2 : 1) : 0;
-    // the pair search reads nothing the staging launch produces: it goes first, the staging launch runs beside it on the side stream
-    { iba_status ms = mark_entry(h, st); if (ms != IBA_OK) return ms; }
+    bool head_open = head;   // the first kernel launched below takes the head along
     if (common && h->n_build > 0) {   // (n_build == 0: the lists of earlier calls cover every group of this batch)
         // LDS of the pairs kernel: hit stage, coarse CSR (u16), the keypoints' (u, v)
         const uint32_t kuv_off = align_up(8u * (uint32_t)kPairStage + 128u + 2u * std::max(h->maxCoarse, 1u), 16u);
         const uint32_t lds = kuv_off + 8u * std::max(h->maxK, 1u);
         const PairsProblem pp{dp.frames, dp.pts4, dp.chunk_box, dp.kp_uv, dp.coarse_start};
-        hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf, h->n_build), dim3(kPairsThreads), lds, st, PairsArgs{pp, h->pplan}, h->params.max_pixel_dist, kuv_off,
-                           nf, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap);
+        // the pair search needs nothing but its arguments: it goes first and, in one more z-plane of its grid, carries the candidates to the device
+        hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf, h->n_build + (head_open ? 1 : 0)), dim3(kPairsThreads), lds, st, PairsArgs{pp, h->pplan}, h->params.max_pixel_dist, kuv_off,
+                           nf, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap, head_open ? head_src : nullptr, (uint4*)dc, head_open ? head_n16 : 0u);
         HIP_TRY(h, hipGetLastError());
         h->pairs_builds += h->n_build;
+        head_open = false;
     }
-    { iba_status ls = launch_head(h); if (ls != IBA_OK) return ls; }
     // Anchored neighbour lists (iba_anchor_kernel): the scan points nearest to every MapPoint's query under an ANCHOR extrinsic,
     // built once and reused by every evaluation whose candidates stay near the anchor (each lane certifies its own pick, or
     // searches the tree). The anchor follows the optimiser: when the candidate of this call that is nearest the batch mean has
@@ -692,7 +672,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         };
         // the poll centres of this batch: the groups of the pair-search plan (one per incumbent) — or the whole batch; of each, the member
         // nearest the group's mean query transform
-        int grp_of[IBA_MAX_BATCH], n_grp = 1;
+        static thread_local int grp_of[kMaxChain]; int n_grp = 1;
         for (int b = 0; b < B; ++b) grp_of[b] = 0;
         if (common && h->n_groups > 1) {
             int slot_grp[kMaxPairGroups] = {-1, -1, -1, -1}; n_grp = 0;
@@ -750,13 +730,17 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
             if (h->anchor_sel[b] != 255) { sets = true; h->anchor_used[na] = ++h->anchor_clock; }
         }
     }
+    // an association kernel that is the first of its chain carries the head in kHeadBlocks spare blocks, and its own blocks read their
+    // candidate (R, t, s: 13 doubles) where it lies in the pinned ring
+    const uint32_t head_blocks = head_open ? std::min<uint32_t>(kHeadBlocks, (head_n16 + (uint32_t)kThreads - 1u) / (uint32_t)kThreads) : 0u;
+    const Cand* assoc_cands = head_open ? (const Cand*)head_src : dc;
+    const uint4* a_src = head_open ? head_src : nullptr; const uint32_t a_n16 = head_open ? head_n16 : 0u;
     if (common) {
-        { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }   // the candidates and the hand-eye terms: first read here
         // (four instantiations: flags in registers or LDS x at most 30 covisible keyframes or more; the common one is round 3's code)
         auto launch_assoc2 = [&](auto flreg) {
             constexpr bool FL = decltype(flreg)::value;
-            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                                                          h->d_frame_partials.p, nrec, h->d_he.p, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap); };
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B + head_blocks), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                                                          h->d_frame_partials.p, nrec, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap, a_src, (uint4*)dc, a_n16); };
             if (h->max_slots > (uint32_t)kCovisWord) go(iba_assoc2_kernel<FL, true>); else go(iba_assoc2_kernel<FL, false>);
         };
         if (assoc2_flreg(h))
@@ -764,10 +748,10 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         else
             launch_assoc2(std::false_type{});
     } else {
-    { iba_status js = join_head(h, st); if (js != IBA_OK) return js; }
-    hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, dc, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                       h->d_frame_partials.p, nrec, (uint32_t*)nullptr, h->d_he.p, fl, fc, lc, (int)h->lstride);
+    hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B + head_blocks), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                       h->d_frame_partials.p, nrec, (uint32_t*)nullptr, fl, fc, lc, (int)h->lstride, a_src, (uint4*)dc, a_n16);
     }
+    head_open = false;
     HIP_TRY(h, hipGetLastError());
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_mid, st));
     if (refit && (want & 1)) {
@@ -803,10 +787,12 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         iba_status s = finish_jets(h, st); if (s != IBA_OK) return s;   // the GPU has been busy with the values since stage_cands
         s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, nf, st); if (s != IBA_OK) return s;
     }
-    hipLaunchKernelGGL(iba_reduce2_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, search ? h->d_nn_partials.p : (const double*)nullptr, nn_nrec, d_partials);
+    // the sums — and, for a cost evaluation, K7: the hand-eye term of every counted (candidate, frame), evaluated where it is summed
+    hipLaunchKernelGGL(iba_reduce2_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, search ? h->d_nn_partials.p : (const double*)nullptr, nn_nrec, d_partials,
+                       (want & 2) ? dp.frames : (const FrameHdr*)nullptr, dc, h->d_he.p);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
-    return IBA_OK;
+    return chain_done();
 }
 
 // plan_pairs commits a list slot (reference, bound, valid, epoch) when the candidates are staged — before iba_pairs_kernel has been
@@ -817,18 +803,19 @@ iba_status chain_status(iba_handle* h, iba_status s) {
     return s;
 }
 
-// batches larger than IBA_MAX_BATCH (the candidates one launch chain takes) run as consecutive chunks
+// batches larger than one launch chain takes (chain_limit) run as consecutive chains
 template <class F>
-iba_status chunked(int B, F f) {
-    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) { const iba_status s = f(b0, std::min(IBA_MAX_BATCH, B - b0)); if (s != IBA_OK) return s; }
+iba_status chunked(const iba_handle* h, int B, F f) {
+    const int cap = chain_limit(h);
+    for (int b0 = 0; b0 < B; b0 += cap) { const iba_status s = f(b0, std::min(cap, B - b0)); if (s != IBA_OK) return s; }
     return IBA_OK;
 }
 
 iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr) {
-    if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+    if (!h || (!x && !pre) || B < 1 || B > chain_limit(h)) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (a chain takes 1 .. max_chain_batch candidates)");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0, nullptr, true, true); if (s != IBA_OK) return chain_status(h, s);   // the cost tuple never reads the derivatives
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 0, nullptr, true); if (s != IBA_OK) return chain_status(h, s);   // the cost tuple never reads the derivatives
     return chain_status(h, run_split(h, dc, B, 2, false, false, d_partials, st));
 }
 
@@ -851,8 +838,6 @@ void iba_destroy(iba_handle* h) {
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
-    if (h->ev_entry) (void)hipEventDestroy(h->ev_entry);
-    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -873,7 +858,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
         std::memcpy(&opt, user_opt, (size_t)user_opt->struct_size);
         opt.struct_size = (int32_t)sizeof(opt);
         if (opt.common_pairs < 0 || opt.common_pairs > 2 || opt.max_pair_groups < 1 || opt.max_pair_groups > kMaxPairGroups || !(opt.common_max_px >= 0) || !(opt.pair_inflation >= 1.0) ||
-            !(opt.anchor_reach >= 0) || opt.pair_list_capacity < 0 || opt.pair_memo_max_batch < 0)
+            !(opt.anchor_reach >= 0) || opt.pair_list_capacity < 0 || opt.pair_memo_max_batch < 0 || opt.max_chain_batch < 1 || opt.max_chain_batch > IBA_MAX_CHAIN)
             return fail(nullptr, IBA_ERR_INVALID_ARG, "iba_create_options: a field is out of range");
     }
     if (!d || !params || !out) return fail(nullptr, IBA_ERR_INVALID_ARG, "null argument");
@@ -1067,7 +1052,8 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     // the options struct first, then the environment as a debug override (process-global: for A/B runs of an unmodified caller)
     h->common_mode = opt.common_pairs; h->common_max_px = opt.common_max_px; h->max_groups = opt.max_pair_groups; h->pair_memo = opt.pair_memo;
     h->pair_memo_max_b = opt.pair_memo_max_batch; h->pair_infl = opt.pair_inflation; h->nn_sets = opt.anchored_lists != 0; h->anchor_reach = opt.anchor_reach;
-    h->side_on = opt.side_stream; h->spin_wait = opt.spin_wait != 0; h->factor_valu = opt.factor_mfma == 0;
+    h->spin_wait = opt.spin_wait != 0; h->factor_valu = opt.factor_mfma == 0;
+    h->chain_fold = opt.chain_fold != 0; h->chain_cap = opt.max_chain_batch;
     if (const char* e = std::getenv("IBA_NN_CG")) { h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e))); h->nn_cg_fixed = true; }
     if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
@@ -1085,7 +1071,9 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_PAIR_GROUPS")) h->max_groups = std::max(1, std::min(kMaxPairGroups, std::atoi(e)));
-    if (const char* e = std::getenv("IBA_SIDE_STREAM")) h->side_on = std::atoi(e);
+    if (const char* e = std::getenv("IBA_CHAIN_FOLD")) h->chain_fold = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IBA_MAX_CHAIN")) h->chain_cap = std::atoi(e);
+    h->chain_cap = std::max(1, std::min(h->chain_cap, (int)kMaxChain));
     if (!layout_assoc(h, h->alay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
     if (!layout_assoc2(h, h->alay2) || 8u * (uint32_t)kPairStage + 160u + 2u * std::max(h->maxCoarse, 1u) + 8u * std::max(h->maxK, 1u) > kLdsBytes) h->common_mode = 0;
     if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
@@ -1103,15 +1091,13 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
 #undef UP
     hipError_t er;
     if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);
-    if ((er = h->d_cands.alloc((size_t)kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("alloc cands", er);
+    if ((er = h->d_cands.alloc((size_t)kRing * h->chain_cap)) != hipSuccess) return bail("alloc cands", er);
     h->nfb = nf; h->nrec = nf + h->nfb;   // one factor-kernel record per frame
-    if ((er = h->d_frame_partials.alloc((size_t)IBA_MAX_BATCH * std::max(h->nrec, 1) * kPartialStride)) != hipSuccess) return bail("alloc frame partials", er);
     if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
     if ((er = h->d_flist_frozen.alloc((size_t)std::max(nf, 1) * h->lstride)) != hipSuccess) return bail("alloc flist", er);
     if ((er = h->d_diag.alloc(4)) != hipSuccess || (er = hipMemset(h->d_diag.p, 0, 16)) != hipSuccess) return bail("alloc diag", er);
     if ((er = h->d_fcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc fcount", er);
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
-    if ((er = h->d_nn_partials.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1) * h->nn_ns * kNNPartial)) != hipSuccess) return bail("alloc nn partials", er);
     if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
     if (h->nn_sets && h->max_mpk > 0) {
         // 512 B per (frame, keypoint): 205 MB at 200 x 2000 keypoints, linear in the keyframes. The lists are an
@@ -1133,15 +1119,12 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
         if ((er = h->d_pcounts.alloc(2 * (size_t)kMaxPairGroups * std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("alloc pair counts", er);
         if ((er = hipMemset(h->d_pcounts.p, 0, sizeof(uint32_t) * 2 * (size_t)kMaxPairGroups * std::max(nf, 1) * kCountStride)) != hipSuccess) return bail("clear pair counts", er);
     }
-    if ((er = h->d_partials.alloc((size_t)IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
-    if ((er = h->d_he.alloc((size_t)IBA_MAX_BATCH * std::max(nf, 1))) != hipSuccess) return bail("alloc he", er);
+    if ((er = h->d_partials.alloc((size_t)h->chain_cap * kPartialStride)) != hipSuccess) return bail("alloc partials", er);
     if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
-    if ((er = hipHostMalloc((void**)&h->h_cands, sizeof(Cand) * kRing * IBA_MAX_BATCH)) != hipSuccess) return bail("hipHostMalloc", er);
-    if ((er = hipHostMalloc((void**)&h->h_partials, sizeof(double) * IBA_MAX_BATCH * kPartialStride)) != hipSuccess) return bail("hipHostMalloc", er);
+    if ((er = hipHostMalloc((void**)&h->h_cands, sizeof(Cand) * kRing * h->chain_cap)) != hipSuccess) return bail("hipHostMalloc", er);
+    if ((er = hipHostMalloc((void**)&h->h_partials, sizeof(double) * h->chain_cap * kPartialStride)) != hipSuccess) return bail("hipHostMalloc", er);
     if ((er = hipHostGetDevicePointer((void**)&h->h_partials_dev, h->h_partials, 0)) != hipSuccess || (er = hipHostGetDevicePointer((void**)&h->h_cands_dev, h->h_cands, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", er);
     if ((er = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
-    if ((er = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
-    if ((er = hipEventCreateWithFlags(&h->ev_entry, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel
@@ -1231,12 +1214,12 @@ iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_ke
 
 iba_status iba_eval_cost_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
     if (!h || !d_partials || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return chunked(B, [&](int b0, int Bc) { return eval_cost_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
+    return chunked(h, B, [&](int b0, int Bc) { return eval_cost_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
 }
 
 iba_status iba_eval_cost(iba_handle* h, const double* x, int32_t B, iba_cost_out* out) {
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return chunked(B, [&](int b0, int Bc) {
+    return chunked(h, B, [&](int b0, int Bc) {
         iba_status s = eval_cost_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;   // the sums land in pinned host memory: no copy behind the last kernel
         HIP_TRY(h, wait_stream(h, h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
@@ -1246,8 +1229,8 @@ iba_status iba_eval_cost(iba_handle* h, const double* x, int32_t B, iba_cost_out
 
 iba_status iba_eval_bbo(iba_handle* h, const double* x, int32_t B, double he_threshold, double valid_rate, iba_bbo* out) {
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
-    return chunked(B, [&](int b0, int Bc) {
-        iba_cost_out c[IBA_MAX_BATCH];
+    return chunked(h, B, [&](int b0, int Bc) {
+        std::vector<iba_cost_out> cv((size_t)Bc); iba_cost_out* c = cv.data();
         iba_status s = iba_eval_cost(h, x + 7 * b0, Bc, c); if (s != IBA_OK) return s;
         for (int b = 0; b < Bc; ++b) {   // iba_global.cpp:386-392
             out[b0 + b].f = c[b].f1 * h->params.err_weight[0] + c[b].f2 * h->params.err_weight[1];
@@ -1264,10 +1247,11 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     if (lf < 0 || lf >= h->n_frames) return fail(h, IBA_ERR_INVALID_ARG, "frame not owned by this handle");
     HIP_TRY(h, hipSetDevice(h->device));
     Cand* dc = nullptr;
+    { iba_status es = ensure_lists(h, 1, h->stream); if (es != IBA_OK) return es; }
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
     {
         hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * ((h->n_frames + 7) / 8)), dim3(kThreads), h->alay.total, h->stream, KArgs{h->dev_problem(), h->dprm, h->alay}, dc, 1, 0,
-                           h->d_frame_partials.p, h->n_frames, h->d_corr.p, h->d_he.p, h->d_flist_frozen.p, h->d_fcount_frozen.p, h->d_lcount_frozen.p, (int)h->lstride);
+                           h->d_frame_partials.p, h->n_frames, h->d_corr.p, h->d_flist_frozen.p, h->d_fcount_frozen.p, h->d_lcount_frozen.p, (int)h->lstride, (const uint4*)nullptr, (uint4*)nullptr, 0u);
         HIP_TRY(h, hipGetLastError());
     }
     const uint64_t k0 = h->h_kp_off[lf], K = h->h_kp_off[lf + 1] - k0;
@@ -1324,7 +1308,7 @@ iba_status iba_x_to_sim3(const double x[7], double rigid12[12], double* scale) {
 
 // debug: host copy of the last summed partial blocks (B x iba_partial_stride() doubles)
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B) {
-    if (!h || !out || B < 1 || B > IBA_MAX_BATCH) return IBA_ERR_INVALID_ARG;   // the last launch chain's block: at most IBA_MAX_BATCH candidates
+    if (!h || !out || B < 1 || B > h->chain_cap) return IBA_ERR_INVALID_ARG;   // the last launch chain's block
     std::memcpy(out, h->h_partials, sizeof(double) * B * kPartialStride);
     return IBA_OK;
 }
@@ -1365,7 +1349,7 @@ iba_status iba_debug_pair_lists(iba_handle* h, int32_t out3[3]) {
     if (!h->d_pcounts.p || h->n_frames == 0 || h->last_path == 0) return IBA_OK;
     if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, IBA_ERR_HIP, "sync");
     bool used[kMaxPairGroups] = {false, false, false, false};
-    for (int b = 0; b < IBA_MAX_BATCH; ++b) if (h->amap.slot[b] < kMaxPairGroups) used[h->amap.slot[b]] = true;   // (stale entries beyond the last batch only add slots)
+    for (int b = 0; b < kMaxChain; ++b) if (h->amap.slot[b] < kMaxPairGroups) used[h->amap.slot[b]] = true;   // (stale entries beyond the last batch only add slots)
     std::vector<uint32_t> v((size_t)h->n_frames * kCountStride);
     for (int sl = 0; sl < kMaxPairGroups; ++sl) {
         if (!used[sl]) continue;
@@ -1454,22 +1438,22 @@ iba_status iba_debug_knn(iba_handle* h, int32_t frame, const uint32_t* points, i
 }
 
 static iba_status eval_normal_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr, const std::atomic<int>* pre_flag = nullptr) {
-    if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+    if (!h || (!x && !pre) || B < 1 || B > chain_limit(h)) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (a chain takes 1 .. max_chain_batch candidates)");
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, false, true); if (s != IBA_OK) return chain_status(h, s);
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, true); if (s != IBA_OK) return chain_status(h, s);
     return chain_status(h, run_split(h, dc, B, 1, false, true, d_partials, st));
 }
 
 iba_status iba_eval_normal_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
     if (!h || !d_partials || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return chunked(B, [&](int b0, int Bc) { return eval_normal_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
+    return chunked(h, B, [&](int b0, int Bc) { return eval_normal_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
 }
 
 iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return chunked(B, [&](int b0, int Bc) {
+    return chunked(h, B, [&](int b0, int Bc) {
         iba_status s = eval_normal_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
         HIP_TRY(h, wait_stream(h, h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
@@ -1480,22 +1464,22 @@ iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal
 // BAError tuple AND re-associated normal equations of the same candidates from ONE pass over the scans:
 // the two paths share projection + 2d-3d association (iba_global.cpp:55-96 = iba_local.cpp:17-58).
 static iba_status eval_full_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr, const std::atomic<int>* pre_flag = nullptr) {
-    if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (B must be in [1, IBA_MAX_BATCH])");
+    if (!h || (!x && !pre) || B < 1 || B > chain_limit(h)) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments (a chain takes 1 .. max_chain_batch candidates)");
     HIP_TRY(h, hipSetDevice(h->device));
     { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
-    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, true, true); if (s != IBA_OK) return chain_status(h, s);
+    iba_status s = stage_cands(h, x, B, st, &dc, pre, 2, pre_flag, true); if (s != IBA_OK) return chain_status(h, s);
     return chain_status(h, run_split(h, dc, B, 3, false, true, d_partials, st));
 }
 
 iba_status iba_eval_full_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
     if (!h || !d_partials || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return chunked(B, [&](int b0, int Bc) { return eval_full_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
+    return chunked(h, B, [&](int b0, int Bc) { return eval_full_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
 }
 
 iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal) {
     if (!h || !cost || !normal || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return chunked(B, [&](int b0, int Bc) {
+    return chunked(h, B, [&](int b0, int Bc) {
         iba_status s = eval_full_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
         HIP_TRY(h, wait_stream(h, h->stream));
         s = iba_finalize_cost(&h->params, h->h_partials, Bc, cost + b0); if (s != IBA_OK) return s;
@@ -1516,9 +1500,10 @@ static iba_status build_problem_impl(iba_handle* h, const double* x, const Cand*
 iba_status iba_build_problem(iba_handle* h, const double* x) { return build_problem_impl(h, x, nullptr); }
 
 static iba_status eval_factors_partial_impl(iba_handle* h, const double* x, int B, double* d_partials, hipStream_t st, const Cand* pre = nullptr) {
-    if (!h || (!x && !pre) || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    if (!h || (!x && !pre) || B < 1 || B > chain_limit(h)) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
     if (!h->frozen_valid) return fail(h, IBA_ERR_STATE, "iba_eval_factors called before iba_build_problem");
     HIP_TRY(h, hipSetDevice(h->device));
+    { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
@@ -1535,12 +1520,12 @@ static iba_status eval_factors_partial_impl(iba_handle* h, const double* x, int 
 
 iba_status iba_eval_factors_partial(iba_handle* h, const double* x, int32_t B, void* d_partials, void* stream) {
     if (!h || !d_partials || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return chunked(B, [&](int b0, int Bc) { return eval_factors_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
+    return chunked(h, B, [&](int b0, int Bc) { return eval_factors_partial_impl(h, x + 7 * b0, Bc, (double*)d_partials + (size_t)b0 * kPartialStride, stream ? (hipStream_t)stream : h->stream); });
 }
 
 iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_normal_out* out) {
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
-    return chunked(B, [&](int b0, int Bc) {
+    return chunked(h, B, [&](int b0, int Bc) {
         iba_status s = eval_factors_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
         HIP_TRY(h, wait_stream(h, h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
@@ -1698,8 +1683,9 @@ iba_status eval_partial_cands(iba_handle* h, const Cand* hc, int B, EvalKind kin
     return fail(h, IBA_ERR_INVALID_ARG, "bad evaluation kind");
 }
 iba_status build_problem_cands(iba_handle* h, const Cand* hc) { return build_problem_impl(h, nullptr, hc); }
+int chain_capacity(const iba_handle* h) { return h ? chain_limit(h) : 0; }
 iba_status reserve_batch(iba_handle* h, int B) {
-    if (!h || B < 1 || B > IBA_MAX_BATCH) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    if (!h || B < 1 || B > h->chain_cap) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
     HIP_TRY(h, hipSetDevice(h->device));
     return ensure_lists(h, B, h->stream);
 }

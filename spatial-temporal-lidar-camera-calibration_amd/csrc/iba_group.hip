@@ -89,7 +89,7 @@ struct iba_group {
     std::vector<iba_handle*> h;
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> st;
-    std::vector<double*> d_part;          // per device: IBA_MAX_BATCH x stride doubles
+    std::vector<double*> d_part;          // per device: kMaxChain x stride doubles
     std::vector<double*> h_parts;         // per device, pinned (host reduction); h_part = h_parts[0] otherwise
     std::vector<double*> h_parts_dev;     // the same blocks as the devices address them: with the host reduction the last kernel of a
                                           // device's chain writes its sums there (no copy behind it)
@@ -116,6 +116,7 @@ struct iba_group {
     // group (cold device, RCCL's lazy channel set-up, a profiler attached) may take seconds and gets four times the bound.
     double wait_timeout_ms = 20000.0;
     std::atomic<bool> warm{false};        // a call has completed on this group
+    int reserved_batch = IBA_MAX_BATCH;   // the handles' work buffers hold this many candidates (grown, on every device's own thread, before a larger chain is issued)
     int debug_fail_rank = -1, debug_fail_phase = 1; bool debug_fail_armed = false;   // IBA_DEBUG_FAIL_RANK / _PHASE: one injected failure (tests)
 };
 
@@ -173,13 +174,18 @@ void shard(const iba_problem_desc* d, int n, std::vector<int32_t>& b, std::vecto
     b.assign(cuts.begin(), cuts.begin() + n); e.assign(cuts.begin() + 1, cuts.end());
 }
 
-// One chunk (Bc <= IBA_MAX_BATCH candidates) on every device: launch chain -> sum over the devices -> the summed block in
+// One chunk (Bc <= group_chain(g) candidates) on every device: launch chain -> sum over the devices -> the summed block in
 // g->h_part. Per device, on its own thread: pinned copy of the candidate block, kernels, ONE collective, stream drained.
 iba_status eval_chunk(iba_group* g, const double* x, int Bc, EvalKind kind) {
     const auto t0 = std::chrono::steady_clock::now();
     // the values first (6 us for 64 candidates): the devices start on them; the derivatives (38 us, read by the factor kernel alone)
     // are computed on this thread while the workers issue and the kernels run
     const bool late_jets = kind == kEvalNormal || kind == kEvalFull;
+    if (Bc > g->reserved_batch) {   // a larger chain than any before: the work buffers grow now, not inside the concurrent launch chains
+        const iba_status rs = run_all(g, [g, Bc](int i) -> iba_status { W_IBA(g, i, reserve_batch(g->h[i], Bc)); return IBA_OK; });
+        if (rs != IBA_OK) return rs;
+        g->reserved_batch = Bc;
+    }
     make_cands_host(x, Bc, g->cands.data(), kind == kEvalFactors);
     g->jets_ready.store(0, std::memory_order_release);
     const size_t bytes = sizeof(double) * (size_t)Bc * g->stride;
@@ -235,6 +241,8 @@ iba_status eval_chunk(iba_group* g, const double* x, int Bc, EvalKind kind) {
 }
 
 void stop_workers(iba_group* g) { g->pool.stop(); }
+// candidates one chain of the group takes: the smallest of its handles' (all equal: same options, same parameters)
+int group_chain(const iba_group* g) { int c = kMaxChain; for (iba_handle* h : g->h) if (h) c = std::min(c, chain_capacity(h)); return std::max(1, c); }
 }  // namespace
 
 extern "C" {
@@ -301,7 +309,7 @@ iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* p
     g->enq_us.assign(n_devices, 0.0);
     if (const char* e = std::getenv("IBA_GROUP_TIMEOUT_MS")) g->wait_timeout_ms = std::max(1.0, std::atof(e));
     if (const char* e = std::getenv("IBA_DEBUG_FAIL_RANK")) { g->debug_fail_rank = std::atoi(e); g->debug_fail_armed = true; if (const char* ph = std::getenv("IBA_DEBUG_FAIL_PHASE")) g->debug_fail_phase = std::atoi(ph); }
-    g->cands.resize(IBA_MAX_BATCH); g->h_sum.resize((size_t)IBA_MAX_BATCH * g->stride);
+    g->cands.resize(kMaxChain); g->h_sum.resize((size_t)kMaxChain * g->stride);
     shard(desc, n_devices, g->f_begin, g->f_end);
     g->pool.start(n_devices, [g](int i) { (void)hipSetDevice(g->dev[i]); });   // once: every HIP call of a worker targets its device
     // the handles (static index builds, uploads, plane memo) are created concurrently, one per worker
@@ -310,8 +318,8 @@ iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* p
         if (cs != IBA_OK) return wfail(g, i, cs, std::string("iba_create: ") + iba_last_error(nullptr));
         W_HIP(g, i, hipSetDevice(g->dev[i]));
         W_HIP(g, i, hipStreamCreateWithFlags(&g->st[i], hipStreamNonBlocking));
-        W_HIP(g, i, hipMalloc((void**)&g->d_part[i], sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride));
-        W_HIP(g, i, hipHostMalloc((void**)&g->h_parts[i], sizeof(double) * (size_t)IBA_MAX_BATCH * g->stride, hipHostMallocMapped));
+        W_HIP(g, i, hipMalloc((void**)&g->d_part[i], sizeof(double) * (size_t)kMaxChain * g->stride));
+        W_HIP(g, i, hipHostMalloc((void**)&g->h_parts[i], sizeof(double) * (size_t)kMaxChain * g->stride, hipHostMallocMapped));
         W_HIP(g, i, hipHostGetDevicePointer((void**)&g->h_parts_dev[i], g->h_parts[i], 0));
         W_IBA(g, i, reserve_batch(g->h[i], IBA_MAX_BATCH));   // no allocation inside an evaluation (several threads are inside HIP then)
         return IBA_OK;
@@ -342,7 +350,7 @@ double iba_group_last_enqueue_us(const iba_group* g) { return g ? g->last_enqueu
 
 iba_status iba_group_set_params(iba_group* g, const iba_params* p) {
     if (!g || !p) return IBA_ERR_INVALID_ARG;
-    const iba_status s = run_all(g, [g, p](int i) -> iba_status { W_IBA(g, i, iba_set_params(g->h[i], p)); W_IBA(g, i, reserve_batch(g->h[i], IBA_MAX_BATCH)); return IBA_OK; });
+    const iba_status s = run_all(g, [g, p](int i) -> iba_status { W_IBA(g, i, iba_set_params(g->h[i], p)); W_IBA(g, i, reserve_batch(g->h[i], std::min(g->reserved_batch, chain_capacity(g->h[i])))); return IBA_OK; });
     if (s != IBA_OK) return s;
     g->params = *p;
     return IBA_OK;
@@ -350,8 +358,9 @@ iba_status iba_group_set_params(iba_group* g, const iba_params* p) {
 
 iba_status iba_group_eval_cost(iba_group* g, const double* x, int32_t B, iba_cost_out* out) {
     if (!g || !x || !out || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {   // larger batches run as consecutive chunks
-        const int Bc = std::min(IBA_MAX_BATCH, B - b0);
+    const int cap = group_chain(g);
+    for (int b0 = 0; b0 < B; b0 += cap) {   // larger batches run as consecutive chains
+        const int Bc = std::min(cap, B - b0);
         iba_status s = eval_chunk(g, x + 7 * b0, Bc, kEvalCost); if (s != IBA_OK) return s;
         s = iba_finalize_cost(&g->params, g->h_part, Bc, out + b0); if (s != IBA_OK) return s;
     }
@@ -372,8 +381,9 @@ iba_status iba_group_eval_bbo(iba_group* g, const double* x, int32_t B, double h
 
 iba_status iba_group_eval_full(iba_group* g, const double* x, int32_t B, iba_cost_out* cost, iba_normal_out* normal) {
     if (!g || !x || !cost || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
-        const int Bc = std::min(IBA_MAX_BATCH, B - b0);
+    const int cap = group_chain(g);
+    for (int b0 = 0; b0 < B; b0 += cap) {
+        const int Bc = std::min(cap, B - b0);
         iba_status s = eval_chunk(g, x + 7 * b0, Bc, kEvalFull); if (s != IBA_OK) return s;
         s = iba_finalize_cost(&g->params, g->h_part, Bc, cost + b0); if (s != IBA_OK) return s;
         s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
@@ -383,8 +393,9 @@ iba_status iba_group_eval_full(iba_group* g, const double* x, int32_t B, iba_cos
 
 iba_status iba_group_eval_normal(iba_group* g, const double* x, int32_t B, iba_normal_out* normal) {
     if (!g || !x || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
-        const int Bc = std::min(IBA_MAX_BATCH, B - b0);
+    const int cap = group_chain(g);
+    for (int b0 = 0; b0 < B; b0 += cap) {
+        const int Bc = std::min(cap, B - b0);
         iba_status s = eval_chunk(g, x + 7 * b0, Bc, kEvalNormal); if (s != IBA_OK) return s;
         s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
     }
@@ -399,8 +410,9 @@ iba_status iba_group_build_problem(iba_group* g, const double* x_assoc) {
 
 iba_status iba_group_eval_factors(iba_group* g, const double* x, int32_t B, iba_normal_out* normal) {
     if (!g || !x || !normal || B < 1) return gfail(g, IBA_ERR_INVALID_ARG, "bad arguments");
-    for (int b0 = 0; b0 < B; b0 += IBA_MAX_BATCH) {
-        const int Bc = std::min(IBA_MAX_BATCH, B - b0);
+    const int cap = group_chain(g);
+    for (int b0 = 0; b0 < B; b0 += cap) {
+        const int Bc = std::min(cap, B - b0);
         iba_status s = eval_chunk(g, x + 7 * b0, Bc, kEvalFactors); if (s != IBA_OK) return s;
         s = iba_finalize_normal(&g->params, g->h_part, Bc, normal + b0); if (s != IBA_OK) return s;
     }

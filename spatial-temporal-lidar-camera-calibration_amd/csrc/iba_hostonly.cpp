@@ -37,6 +37,7 @@ iba_status iba_default_create_options(iba_create_options* o) {
     o->struct_size = (int32_t)sizeof(*o);
     o->common_pairs = 1; o->common_max_px = 20.0; o->max_pair_groups = 4; o->pair_memo = 1; o->pair_memo_max_batch = 40; o->pair_inflation = 1.25;
     o->anchored_lists = 1; o->anchor_reach = 0.06; o->side_stream = 1; o->spin_wait = 1; o->factor_mfma = 0; o->pair_list_capacity = 0;
+    o->max_chain_batch = IBA_MAX_CHAIN; o->chain_fold = 1;
     return IBA_OK;
 }
 
@@ -180,8 +181,8 @@ iba_status iba_mads_selftest(int32_t problem, const double* x0, const iba_mads_o
 // focal length is max_fx — group index per candidate, nominal projection spread per group, number of groups (1: the whole batch
 // shares one search; 0: wide everywhere, every candidate searches for itself).
 iba_status iba_debug_plan_groups(const double* x, int32_t B, double max_fx, double max_px, int32_t max_groups, int32_t* group_of, double* group_px, int32_t* n_groups) {
-    if (!x || B < 1 || B > IBA_MAX_BATCH || !n_groups) return IBA_ERR_INVALID_ARG;
-    static thread_local Cand hc[IBA_MAX_BATCH];
+    if (!x || B < 1 || B > kMaxChain || !n_groups) return IBA_ERR_INVALID_ARG;
+    static thread_local Cand hc[kMaxChain];
     static thread_local GroupPick gp[kMaxPairGroups];
     for (int b = 0; b < B; ++b) make_cand_values(x + 7 * b, hc[b]);
     gp[0].n = B; for (int b = 0; b < B; ++b) gp[0].idx[b] = b;

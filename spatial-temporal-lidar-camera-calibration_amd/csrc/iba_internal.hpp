@@ -15,7 +15,7 @@ enum EvalKind { kEvalCost = 0, kEvalNormal = 1, kEvalFull = 2, kEvalFactors = 3 
 
 // Cand block of B candidates x (7 doubles each): g2o_tools.h:105-140, 149-183 on the host
 void make_cands_host(const double* x, int B, Cand* out, bool jets = true);   // jets = false: the values only (cost evaluations)
-// launch chain of one chunk (B <= IBA_MAX_BATCH) on `st` from a ready candidate block (host memory, copied into the handle's
+// launch chain of one chunk (B <= chain_capacity(h)) on `st` from a ready candidate block (host memory, copied into the handle's
 // pinned ring before the call returns); no synchronisation
 // jets_ready != nullptr (kEvalNormal / kEvalFull): the derivative half of host_cands is still being computed by the caller; the chain
 // starts on the values and copies the block again, before the factor kernel, once *jets_ready is set
@@ -25,5 +25,7 @@ void make_cands_jets_host(const double* x, int B, Cand* out);   // the derivativ
 iba_status build_problem_cands(iba_handle* h, const Cand* host_cand);
 // work buffers for batches of up to B candidates, so that no evaluation allocates
 iba_status reserve_batch(iba_handle* h, int B);
+// candidates one launch chain takes on this handle (iba_create_options.max_chain_batch; IBA_MAX_BATCH while the planes are refitted per evaluation)
+int chain_capacity(const iba_handle* h);
 
 }  // namespace iba

@@ -21,15 +21,17 @@ struct GroupRef { double R[9], t[3], rho[9], tau[3]; };   // reference candidate
 // point 12 m out, 10 m deep), in which case every candidate searches for itself (iba_assoc_kernel).
 // rho_ij = max_b |R_b R_0^T - I|_ij, tau_i = max_b |t_b - R_b R_0^T t_0|_i of a batch around a reference (R_0, t_0), inflated for their own
 // rounding; rel (optional): the candidates' own (M_b, a_b) as floats. false: a NaN / absurd candidate, no bound.
-inline bool batch_spread(const Cand* hc, int B, const double* R0, const double* t0, double* rho, double* tau, float (*rel)[12]) {
+// (idx: the members of the group among hc[], nullptr = hc[0 .. B))
+inline bool batch_spread(const Cand* hc_all, int B, const double* R0, const double* t0, double* rho, double* tau, float (*rel)[12], const int* idx = nullptr) {
     for (int i = 0; i < 9; ++i) rho[i] = 0;
     for (int i = 0; i < 3; ++i) tau[i] = 0;
     for (int b = 0; b < B; ++b) {
+        const Cand& c = hc_all[idx ? idx[b] : b];
         double A[9];
         for (int r = 0; r < 3; ++r)
-            for (int q = 0; q < 3; ++q) A[r * 3 + q] = (hc[b].R[r * 3] * R0[q * 3] + hc[b].R[r * 3 + 1] * R0[q * 3 + 1]) + hc[b].R[r * 3 + 2] * R0[q * 3 + 2];   // R_b R_0^T
+            for (int q = 0; q < 3; ++q) A[r * 3 + q] = (c.R[r * 3] * R0[q * 3] + c.R[r * 3 + 1] * R0[q * 3 + 1]) + c.R[r * 3 + 2] * R0[q * 3 + 2];   // R_b R_0^T
         for (int r = 0; r < 3; ++r) {
-            const double a = hc[b].t[r] - ((A[r * 3] * t0[0] + A[r * 3 + 1] * t0[1]) + A[r * 3 + 2] * t0[2]);
+            const double a = c.t[r] - ((A[r * 3] * t0[0] + A[r * 3 + 1] * t0[1]) + A[r * 3 + 2] * t0[2]);
             if (!(std::fabs(a) <= 1e30)) return false;
             tau[r] = std::max(tau[r], std::fabs(a));
             if (rel) rel[b][9 + r] = (float)a;
@@ -41,7 +43,8 @@ inline bool batch_spread(const Cand* hc, int B, const double* R0, const double* 
     return true;
 }
 
-struct GroupPick { int n = 0; int idx[IBA_MAX_BATCH]; int ref = 0; GroupRef gr; float rel[IBA_MAX_BATCH][12]; double px = 0; bool ok = false; };
+constexpr int kOwnBoundMax = 64;     // a group of at most this many candidates may hand its members' own motions to the pair search (one lane each; PairsPlan::rel)
+struct GroupPick { int n = 0; int idx[kMaxChain]; int ref = 0; GroupRef gr; float rel[kOwnBoundMax][12]; double px = 0; bool ok = false; };
 inline double nominal_px_of(double max_fx, const double* rho, const double* tau) {
     double rho_row = 0, tau_max = 0;
     for (int r = 0; r < 3; ++r) { rho_row = std::max(rho_row, rho[r * 3] + rho[r * 3 + 1] + rho[r * 3 + 2]); tau_max = std::max(tau_max, tau[r]); }
@@ -62,9 +65,7 @@ inline bool pick_group(double max_fx, const Cand* hc, GroupPick& g) {
     }
     if (!(best < INFINITY)) return false;   // a NaN candidate: no bound
     std::memcpy(g.gr.R, hc[g.ref].R, sizeof(g.gr.R)); std::memcpy(g.gr.t, hc[g.ref].t, sizeof(g.gr.t));
-    Cand tmp[IBA_MAX_BATCH];   // (batch_spread walks consecutive candidates)
-    for (int j = 0; j < g.n; ++j) { std::memcpy(tmp[j].R, hc[g.idx[j]].R, sizeof(tmp[j].R)); std::memcpy(tmp[j].t, hc[g.idx[j]].t, sizeof(tmp[j].t)); }
-    if (!batch_spread(tmp, g.n, g.gr.R, g.gr.t, g.gr.rho, g.gr.tau, g.rel)) return false;
+    if (!batch_spread(hc, g.n, g.gr.R, g.gr.t, g.gr.rho, g.gr.tau, g.n <= kOwnBoundMax ? g.rel : nullptr, g.idx)) return false;
     g.px = nominal_px_of(max_fx, g.gr.rho, g.gr.tau);
     return true;
 }
@@ -82,7 +83,7 @@ inline int cluster_batch(double max_fx, const Cand* hc, int B, double max_px, in
     if (max_groups < 2 || B < 2) return 0;
     max_groups = std::min(max_groups, kMaxPairGroups);
     int seeds[kMaxPairGroups]; seeds[0] = gp[0].ref;
-    static thread_local double dist[kMaxPairGroups][IBA_MAX_BATCH];
+    static thread_local double dist[kMaxPairGroups][kMaxChain];
     for (int b = 0; b < B; ++b) dist[0][b] = cand_px(max_fx, hc[b], hc[seeds[0]]);
     for (int ng = 1;;) {
         // the candidate farthest from its nearest seed becomes the next seed

@@ -55,7 +55,7 @@ struct NNArgs {
     // which set of anchored neighbour lists each candidate of the batch reads (255: none — its lanes search the tree), and the
     // distance in bytes between two sets
     unsigned long long anchor_set_bytes;
-    uint8_t anchor_sel[IBA_MAX_BATCH];
+    uint8_t anchor_sel[kMaxChain];
 };
 
 // list entry flags (uint4.w) written by iba_assoc_kernel
@@ -102,7 +102,7 @@ typedef __attribute__((address_space(4))) const KArgs KArgsC;
 template <bool FLREG, bool MANY = true>   // MANY: a frame may have more covisible keyframes than the flag word has match bits (the second word, kp_fl2)
 __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, uint32_t* s_best_idx, const uint32_t* s_kfl, const uint4 rf, uint32_t* s_list,
                                            double* s_red, const double* s_rel, const uint32_t K, const int want, const int dbg, const bool refit, const int b, const int f, const int nf,
-                                           double* __restrict__ part, const double* __restrict__ he, uint4* __restrict__ flist,
+                                           double* __restrict__ part, uint4* __restrict__ flist,
                                            uint32_t* __restrict__ fcount, uint32_t* __restrict__ lcount, const int flist_stride) {
 #define dp (ka->dp)
 #define prm (ka->prm)
@@ -272,7 +272,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
                 else if ((tid == P_CNT_3D3D || tid == P_VALID_3D3D) && !prm.use_3d3d) out = 1.0;   // iba_global.cpp:214-220
                 else if (tid == P_FRAMES) out = 1.0;
                 else if (tid == P_NCORR) out = (double)n_corr;
-                else if (tid == P_HE_SUM) out = h.he_valid ? he[(size_t)b * nf + f] : 0.0;
+                // (the hand-eye VALUE of a counted (candidate, frame) is evaluated by the summing kernel, iba_reduce2_kernel: K7 left the head of the chain in round 5)
                 else if (tid == P_HE_CNT) out = h.he_valid ? 1.0 : 0.0;
             }
             if (tid == P_FRAMES_N) out = usedA ? 1.0 : 0.0;
@@ -283,6 +283,16 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
 #undef dp
 #undef prm
 }
+
+// THE HEAD OF A CHAIN (round 5). Every kernel of a chain but the first reads the candidates from device memory; rounds 1-4 copied them
+// there with a staging launch of their own (12 us of latency at the head of every evaluation, or a second stream and two event hops to
+// hide it). Now the FIRST kernel of the chain carries the copy in a few spare workgroups: `head_n16` 16-byte words from the pinned ring
+// (`head_src`, as the device sees it) to `head_dst`. When that kernel is an association kernel its own blocks read their candidate (13
+// doubles) from the pinned ring directly; when the pair search runs first it carries the copy and the association reads the device copy.
+__device__ __forceinline__ void chain_head_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, uint32_t block, uint32_t n_blocks, uint32_t threads) {
+    for (uint32_t i = block * threads + threadIdx.x; i < n16; i += n_blocks * threads) dst[i] = src[i];
+}
+constexpr uint32_t kHeadBlocks = 16;   // spare workgroups appended to an association kernel's grid for the copy (64 candidates = 4096 words: half a pass)
 
 // iba_assoc_kernel. want: bit 0 = BuildProblem association wanted, bit 1 = BAError cost wanted, bit 2 = planes are refitted (plane_cache = 0). corr_out != nullptr: dump
 // the correspondences and return (iba_get_correspondences).
@@ -295,11 +305,15 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
 #endif
 __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want,
                                                              double* __restrict__ frame_partials, int nrec, uint32_t* __restrict__ corr_out,
-                                                             const double* __restrict__ he, uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
-                                                             uint32_t* __restrict__ lcount, int flist_stride) {
+                                                             uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
+                                                             uint32_t* __restrict__ lcount, int flist_stride, const uint4* __restrict__ head_src, uint4* __restrict__ head_dst, uint32_t head_n16) {
     extern __shared__ __align__(16) unsigned char smem[];
     KArgsC* ka = (KArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // see iba_frame_kernel: parameter blocks are read where they are used
     (void)ka_by_value;
+    {   // the chain's head rides in the blocks behind the (frame, candidate) grid
+        const uint32_t main_blocks = 8u * (uint32_t)((ka->dp.n_frames + 7) / 8) * (uint32_t)B;
+        if (blockIdx.x >= main_blocks) { chain_head_copy(head_src, head_dst, head_n16, blockIdx.x - main_blocks, gridDim.x - main_blocks, (uint32_t)kThreads); return; }
+    }
 #define dp (ka->dp)
 #define prm (ka->prm)
 #define lay (ka->lay)
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 
     if (dbg == 5) return;
     IBA_RELOAD();
-    assoc_tail<false>(ka, h, cd, c, s_best_idx, s_kfl, make_uint4(0u, 0u, 0u, 0u), s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
+    assoc_tail<false>(ka, h, cd, c, s_best_idx, s_kfl, make_uint4(0u, 0u, 0u, 0u), s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride);
 #undef dp
 #undef prm
 #undef lay
@@ -686,7 +700,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 struct PairsProblem { const FrameHdr* frames; const float4* pts4; const float* chunk_box; const float2* kp_uv; const uint32_t* coarse_start; };
 struct PairsPlan {
     GroupRef g[kMaxPairGroups];                  // the groups whose lists this launch builds (blockIdx.z)
-    float rel[IBA_MAX_BATCH][12];                // the candidates' own motions relative to their group's reference, the rows of a group consecutive
+    float rel[kOwnBoundMax][12];                 // the candidates' own motions relative to their group's reference, the rows of a group consecutive (groups of at most kOwnBoundMax candidates: a larger group is bounded entrywise only)
     uint32_t cnt_off[kMaxPairGroups];            // per built group: offset (u32) of the counter set its lists use ...
     uint32_t next_off[kMaxPairGroups];           // ... and of the set cleared for the slot's next build
     uint8_t first[kMaxPairGroups], count[kMaxPairGroups];   // rows of rel[] of the group; count 0: entrywise bound only (a lone candidate, a reusable list)
@@ -696,7 +710,7 @@ struct PairsPlan {
 struct PairsArgs { PairsProblem dp; PairsPlan pl; };
 static_assert(sizeof(PairsArgs) + 96 <= 4096, "the pair search's arguments must fit the 4 KB kernel argument segment");
 // which list slot a candidate's association block reads, and where the slots' current counters are
-struct Assoc2Map { uint32_t cnt_off[kMaxPairGroups]; uint8_t slot[IBA_MAX_BATCH]; };
+struct Assoc2Map { uint32_t cnt_off[kMaxPairGroups]; uint8_t slot[kMaxChain]; };
 struct K2Args { KArgs k; Assoc2Map m; };   // first argument of iba_assoc2_kernel: read in place through the kernarg segment pointer
 struct PairRec { float x, y, z; uint32_t idx; float u, v; uint32_t k, pad; };   // scan point (+ original index), keypoint (+ id): 32 B, streamed
 constexpr int kPairsThreads = 512;    // measured at the bench shape: 1024 threads 50 us, 512 threads 39 us, 256 threads 58 us per batch
@@ -708,8 +722,13 @@ constexpr int kPairStage = 2048;   // (point, keypoint) hits a block parks in LD
 // and written out behind one atomic reservation per block.
 __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_by_value, double max_pixel_dist, uint32_t lds_kuv_off, int n_frames,
                                                                   PairRec* __restrict__ pairs_all, uint32_t* __restrict__ hard_all,
-                                                                  uint32_t* __restrict__ counts_all, int pair_cap, int hard_cap) {
+                                                                  uint32_t* __restrict__ counts_all, int pair_cap, int hard_cap,
+                                                                  const uint4* __restrict__ head_src, uint4* __restrict__ head_dst, uint32_t head_n16) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (head_n16 != 0u && blockIdx.z + 1u == gridDim.z) {   // the chain's head: one more z-plane of the grid carries the candidates to the device (see chain_head_copy)
+        chain_head_copy(head_src, head_dst, head_n16, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, (uint32_t)kPairsThreads);
+        return;
+    }
     typedef __attribute__((address_space(4))) const PairsArgs PairsArgsC;
     PairsArgsC* pa = (PairsArgsC*)__builtin_amdgcn_kernarg_segment_ptr();   // (the argument block is read in place: the group is indexed per block, rel[] per lane)
     (void)pa_by_value;
@@ -969,14 +988,19 @@ constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers 
 constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
 template <bool FLREG, bool MANY>   // FLREG: the frame's keypoint flags never go through LDS (at most 2048 keypoints per frame; see assoc_tail); MANY: more than 30 covisible keyframes possible
 __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
-                                                              const double* __restrict__ he, uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
+                                                              uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
                                                               uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs_all, const uint32_t* __restrict__ hard_all,
-                                                              const uint32_t* __restrict__ counts_all, int pair_cap, int hard_cap) {
+                                                              const uint32_t* __restrict__ counts_all, int pair_cap, int hard_cap,
+                                                              const uint4* __restrict__ head_src, uint4* __restrict__ head_dst, uint32_t head_n16) {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef __attribute__((address_space(4))) const K2Args K2ArgsC;
     K2ArgsC* ka2 = (K2ArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
     KArgsC* ka = &ka2->k;
     (void)ka_by_value;
+    {   // the chain's head rides in the blocks behind the (frame, candidate) grid (a call that reuses earlier pair lists has no pair search to carry it)
+        const uint32_t main_blocks = 8u * (uint32_t)((ka->dp.n_frames + 7) / 8) * (uint32_t)B;
+        if (blockIdx.x >= main_blocks) { chain_head_copy(head_src, head_dst, head_n16, blockIdx.x - main_blocks, gridDim.x - main_blocks, (uint32_t)kThreads); return; }
+    }
 #define dp (ka->dp)
 #define prm (ka->prm)
 #define lay (ka->lay)
@@ -1138,7 +1162,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<2>(c, gcs, u, v, pos); }
     __syncthreads();
     if (dbg == 5) return;
-    assoc_tail<FLREG, MANY>(ka, h, cd, c, s_best_idx, s_kfl, rf, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, he, flist, fcount, lcount, flist_stride);
+    assoc_tail<FLREG, MANY>(ka, h, cd, c, s_best_idx, s_kfl, rf, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride);
 #undef dp
 #undef prm
 #undef lay
@@ -2086,31 +2110,52 @@ __global__ __launch_bounds__(256) void iba_verdict_kernel(const PlaneRec* __rest
     out[i] = (uint8_t)((neigh_ok ? 1u : 0u) | (neigh_ok && local_plane_ok(prm, rec) ? 2u : 0u));
 }
 
+// K7 rides here (round 5): the hand-eye term of every counted (candidate, frame) — iba_global.cpp:264-276, two lanes per term as in
+// rounds 3-4's staging launch — is evaluated by this block right before it is summed, from the device copy of the candidates. The
+// sum over the frames keeps its place and its order in the record sums (slot P_HE_SUM of the association's records, which now hold
+// the COUNT alone): the same numbers added in the same order as when the association kernel wrote them into its records.
+constexpr int kHeLds = 2048;   // frames whose terms wait in LDS (more: through `he_scratch`, read back past the L1)
 __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, int nfr, const double* __restrict__ nn_partials, int nn_nrec,
-                                                                     double* __restrict__ out) {
+                                                                     double* __restrict__ out, const FrameHdr* __restrict__ frames, const Cand* __restrict__ cands, double* __restrict__ he_scratch) {
     constexpr int NG = kReduceThreads / kPartialStride;
     constexpr int NL = kReduceThreads / kNNPartial;
     __shared__ double s[NG][kPartialStride];
     __shared__ double s2[NL][kNNPartial];
+    __shared__ double s_he[kHeLds];
     const int b = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
     const double* src = frame_partials + (size_t)b * nrec * kPartialStride;
+    const bool he_on = frames != nullptr;   // (nullptr: an evaluation without the cost tuple)
+    const bool he_lds = nfr <= kHeLds;
+    double* he_g = he_scratch + (size_t)b * (size_t)nfr;
+    if (he_on) {
+        const Cand& cd = cands[b];
+        for (int t0 = 0; t0 < 2 * nfr; t0 += kReduceThreads) {   // (block-uniform trip count: he_term pairs lanes)
+            const int t = t0 + (int)threadIdx.x, f = t >> 1;
+            const bool live = f < nfr && src[(size_t)(f < nfr ? f : 0) * kPartialStride + P_HE_CNT] != 0.0;   // the frame counts for this candidate (corrset test passed) and has a next keyframe
+            const double v = he_term(frames[f < nfr ? f : 0], cd, t & 1, live);
+            if (f < nfr && !(t & 1)) { if (he_lds) s_he[f] = v; else __hip_atomic_store(he_g + f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        __syncthreads();
+    }
+    auto he_at = [&](int f) { return he_lds ? s_he[f] : __hip_atomic_load(he_g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // the first nfr records are the association's (one per frame), the others — when the evaluation has them — the factor kernel's:
     // a group sums the same frame range of either half, so that a slot only one half fills (every cost slot, every H / b slot) gets
     // the same bits whether or not the other half exists (iba_eval_cost = the cost tuple of iba_eval_full, bit for bit)
     const int per = (nfr + NG - 1) / NG, f0 = g * per, f1 = min(nfr, f0 + per);
-    auto range_sum = [&](const double* base, int lo, int hi) {
+    const bool he_lane = he_on && i == P_HE_SUM;
+    auto range_sum = [&](const double* base, int lo, int hi, bool he_here) {
+        auto val = [&](int f) { return he_here ? (base[(size_t)f * kPartialStride + P_HE_CNT] != 0.0 ? he_at(f) : 0.0) : base[(size_t)f * kPartialStride + i]; };
         double x = 0;
         int f = lo;
         for (; f + 4 <= hi; f += 4) {
-            const double v0 = base[(size_t)f * kPartialStride + i], v1 = base[(size_t)(f + 1) * kPartialStride + i];
-            const double v2 = base[(size_t)(f + 2) * kPartialStride + i], v3 = base[(size_t)(f + 3) * kPartialStride + i];
+            const double v0 = val(f), v1 = val(f + 1), v2 = val(f + 2), v3 = val(f + 3);
             x = (((x + v0) + v1) + v2) + v3;
         }
-        for (; f < hi; ++f) x += base[(size_t)f * kPartialStride + i];
+        for (; f < hi; ++f) x += val(f);
         return x;
     };
-    double x = range_sum(src, f0, f1);
-    if (nrec > nfr) x += range_sum(src + (size_t)nfr * kPartialStride, f0, min(f1, nrec - nfr));
+    double x = range_sum(src, f0, f1, he_lane);
+    if (nrec > nfr) x += range_sum(src + (size_t)nfr * kPartialStride, f0, min(f1, nrec - nfr), false);
     s[g][i] = x;
     if (nn_partials) {   // record lane rl sums the records rl, rl + NL, ... of slot q
         const int q = threadIdx.x & (kNNPartial - 1), rl = threadIdx.x / kNNPartial;

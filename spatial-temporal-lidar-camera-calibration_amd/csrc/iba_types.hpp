@@ -17,6 +17,7 @@ constexpr int kChunk = IBA_CHUNK;           // points per culling chunk (~3 kd l
 constexpr int kCovisWord = 30;       // covisible KFs whose match bits sit beside the two flag bits of the 32-bit flag word (kp_fl) ...
 constexpr int kMaxCovis = 62;        // ... and with a second word per keypoint (kp_fl2: slots 30..61, read from global memory only by frames that have them; r04) the limit per frame
 constexpr int kPartialStride = 64;   // doubles per candidate in the partial-sum block
+constexpr int kMaxChain = 512;       // most candidates one launch chain takes (= IBA_MAX_CHAIN): sizes the per-candidate tables in kernel arguments (one byte each)
 #ifndef IBA_GRID_CELL
 #define IBA_GRID_CELL 2
 #endif
