@@ -759,8 +759,12 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         else hipLaunchKernelGGL((iba_fit_kernel<2, 1>), fit_grid, dim3(64), 0, st, dp, h->dprm, fl, h->d_frefit.p, lc, (int)h->lstride, slot_base, want);
         HIP_TRY(h, hipGetLastError());
     }
+    bool he_in_search = false;
     if (search) {
-        const dim3 grid(8 * per_xcd * ngroups * NS), block(kNNThreads);
+        // the hand-eye terms of a cost evaluation ride in front of the search's grid (two lanes per term), padded to a multiple of 8 blocks
+        const int he_blocks = (want & 2) ? (B * nf + kNNThreads / 2 - 1) / (kNNThreads / 2) : 0;
+        he_in_search = he_blocks > 0;
+        const dim3 grid(8 * per_xcd * ngroups * NS + ((he_blocks + 7) & ~7)), block(kNNThreads);
         NNArgs na{dp, h->dprm, nl, (unsigned long long)(h->anchor_set_elems * sizeof(SetPt)), {0}};
         std::memcpy(na.anchor_sel, h->anchor_sel, sizeof(na.anchor_sel));
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
@@ -768,7 +772,9 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         auto launch_nn = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             h->last_nn_nrec = nn_nrec; h->last_nn_B = B;
-            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, anchor); };
+            const int heb = MODE == kRefitSums ? 0 : he_blocks;   // (the second launch of a refit chain only sums)
+            const dim3 grid_m(MODE == kRefitSums ? 8 * per_xcd * ngroups * NS : grid.x);
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid_m, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, anchor, h->d_he.p, heb); };
             if (sets && MODE != kRefitSums) { if (wA && wC) go(iba_nn_kernel<3, MODE, 1>); else if (wA) go(iba_nn_kernel<1, MODE, 1>); else go(iba_nn_kernel<2, MODE, 1>); }
             else { if (wA && wC) go(iba_nn_kernel<3, MODE, 0>); else if (wA) go(iba_nn_kernel<1, MODE, 0>); else go(iba_nn_kernel<2, MODE, 0>); }
         };
@@ -789,7 +795,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     }
     // the sums — and, for a cost evaluation, K7: the hand-eye term of every counted (candidate, frame), evaluated where it is summed
     hipLaunchKernelGGL(iba_reduce2_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, search ? h->d_nn_partials.p : (const double*)nullptr, nn_nrec, d_partials,
-                       (want & 2) ? dp.frames : (const FrameHdr*)nullptr, dc, h->d_he.p);
+                       dp.frames, dc, h->d_he.p, (want & 2) ? (he_in_search ? 2 : 1) : 0);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
     return chain_done();

@@ -1660,8 +1660,21 @@ template <int WHICH, int REFIT, int SETS>   // REFIT: 0 = planes memoised; plane
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS ? 4 : IBA_NN_WAVES, SETS ? 4 : IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
                                                                                                   double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist,
                                                                                                   const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit,
-                                                                                                  const SetPt* __restrict__ anchor) {
+                                                                                                  const SetPt* __restrict__ anchor, double* __restrict__ he_out, int he_blocks) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // K7 rides in front (round 5): the first he_blocks workgroups evaluate the hand-eye term of every (candidate, frame) — two lanes per
+    // term, iba_global.cpp:264-276 — into he_out[b][f] for the summing kernel, beside the searches instead of in a launch of their own at
+    // the head of the chain (rounds 3-4) or inside the summing kernel's single block per candidate (13 us of dependent f64 there).
+    if ((int)blockIdx.x < he_blocks) {
+        const int nfh = ka_by_value.dp.n_frames;
+        const int i = (int)blockIdx.x * (kNNThreads / 2) + (int)(threadIdx.x >> 1);
+        const bool live = i < B * nfh;
+        const int ii = live ? i : 0;
+        const double v = he_term(ka_by_value.dp.frames[ii % nfh], cands[ii / nfh], threadIdx.x & 1, live);
+        if (live && !(threadIdx.x & 1)) he_out[i] = v;
+        return;
+    }
+    const uint32_t bid = blockIdx.x - (uint32_t)((he_blocks + 7) & ~7);   // (the hand-eye blocks are padded to a multiple of 8: block i of the search still runs on XCD i % 8)
     // SETS: the anchored neighbour lists (iba_anchor_kernel): a lane whose certificate holds picks its nearest points from its
     // keypoint's list instead of searching the tree.
     // kRefitSearch = the searches only (neighbour and query offset of every entry -> flist.z / frefit), kRefitSums = the fixed-order
@@ -1679,7 +1692,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
     const int per_xcd = (nf + 7) / 8;
     const int NG = (B + CG - 1) / CG;
     const int per_frame = NG * NS;
-    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    if (blockIdx.x < (uint32_t)((he_blocks + 7) & ~7)) return;   // (padding)
+    const int xcd = bid & 7, jj = bid >> 3;
     const int f = xcd + 8 * (jj / per_frame);
     if (f >= nf || jj / per_frame >= per_xcd) return;
     const int g = (jj % per_frame) / NS, sl = (jj % per_frame) % NS;
@@ -2116,7 +2130,7 @@ __global__ __launch_bounds__(256) void iba_verdict_kernel(const PlaneRec* __rest
 // the COUNT alone): the same numbers added in the same order as when the association kernel wrote them into its records.
 constexpr int kHeLds = 2048;   // frames whose terms wait in LDS (more: through `he_scratch`, read back past the L1)
 __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, int nfr, const double* __restrict__ nn_partials, int nn_nrec,
-                                                                     double* __restrict__ out, const FrameHdr* __restrict__ frames, const Cand* __restrict__ cands, double* __restrict__ he_scratch) {
+                                                                     double* __restrict__ out, const FrameHdr* __restrict__ frames, const Cand* __restrict__ cands, double* __restrict__ he_scratch, int he_mode) {
     constexpr int NG = kReduceThreads / kPartialStride;
     constexpr int NL = kReduceThreads / kNNPartial;
     __shared__ double s[NG][kPartialStride];
@@ -2124,10 +2138,12 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
     __shared__ double s_he[kHeLds];
     const int b = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
     const double* src = frame_partials + (size_t)b * nrec * kPartialStride;
-    const bool he_on = frames != nullptr;   // (nullptr: an evaluation without the cost tuple)
-    const bool he_lds = nfr <= kHeLds;
+    // he_mode 0: an evaluation without the cost tuple; 2: the search kernel's spare blocks have left the terms in he_scratch[b][f] (the
+    // usual chain); 1: no search kernel ran in this chain — the terms are evaluated here
+    const bool he_on = he_mode != 0;
+    const bool he_lds = he_mode == 1 && nfr <= kHeLds;
     double* he_g = he_scratch + (size_t)b * (size_t)nfr;
-    if (he_on) {
+    if (he_mode == 1) {
         const Cand& cd = cands[b];
         for (int t0 = 0; t0 < 2 * nfr; t0 += kReduceThreads) {   // (block-uniform trip count: he_term pairs lanes)
             const int t = t0 + (int)threadIdx.x, f = t >> 1;
@@ -2137,7 +2153,7 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
         }
         __syncthreads();
     }
-    auto he_at = [&](int f) { return he_lds ? s_he[f] : __hip_atomic_load(he_g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto he_at = [&](int f) { return he_lds ? s_he[f] : (he_mode == 2 ? he_g[f] : __hip_atomic_load(he_g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
     // the first nfr records are the association's (one per frame), the others — when the evaluation has them — the factor kernel's:
     // a group sums the same frame range of either half, so that a slot only one half fills (every cost slot, every H / b slot) gets
     // the same bits whether or not the other half exists (iba_eval_cost = the cost tuple of iba_eval_full, bit for bit)
