@@ -794,8 +794,13 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, nf, st); if (s != IBA_OK) return s;
     }
     // the sums — and, for a cost evaluation, K7: the hand-eye term of every counted (candidate, frame), evaluated where it is summed
-    hipLaunchKernelGGL(iba_reduce2_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, search ? h->d_nn_partials.p : (const double*)nullptr, nn_nrec, d_partials,
-                       dp.frames, dc, h->d_he.p, (want & 2) ? (he_in_search ? 2 : 1) : 0);
+    {
+        const double* nnp = search ? h->d_nn_partials.p : (const double*)nullptr;
+        const int he_mode = (want & 2) ? (he_in_search ? 2 : 1) : 0;
+        if (he_mode == 2) hipLaunchKernelGGL(iba_reduce2_kernel<2>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p);
+        else if (he_mode == 1) hipLaunchKernelGGL(iba_reduce2_kernel<1>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p);
+        else hipLaunchKernelGGL(iba_reduce2_kernel<0>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p);
+    }
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
     return chain_done();

@@ -2128,22 +2128,22 @@ __global__ __launch_bounds__(256) void iba_verdict_kernel(const PlaneRec* __rest
 // rounds 3-4's staging launch — is evaluated by this block right before it is summed, from the device copy of the candidates. The
 // sum over the frames keeps its place and its order in the record sums (slot P_HE_SUM of the association's records, which now hold
 // the COUNT alone): the same numbers added in the same order as when the association kernel wrote them into its records.
-constexpr int kHeLds = 2048;   // frames whose terms wait in LDS (more: through `he_scratch`, read back past the L1)
+constexpr int kHeLds = 2048;   // HE_MODE 1: frames whose terms wait in LDS (more: through `he_scratch`, read back past the L1)
+// HE_MODE 0: an evaluation without the cost tuple; 2: the search kernel's spare blocks have left the terms in he_scratch[b][f] (the usual
+// chain); 1: no search kernel ran in this chain — the terms are evaluated here, two lanes each
+template <int HE_MODE>
 __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, int nfr, const double* __restrict__ nn_partials, int nn_nrec,
-                                                                     double* __restrict__ out, const FrameHdr* __restrict__ frames, const Cand* __restrict__ cands, double* __restrict__ he_scratch, int he_mode) {
+                                                                     double* __restrict__ out, const FrameHdr* __restrict__ frames, const Cand* __restrict__ cands, double* __restrict__ he_scratch) {
     constexpr int NG = kReduceThreads / kPartialStride;
     constexpr int NL = kReduceThreads / kNNPartial;
     __shared__ double s[NG][kPartialStride];
     __shared__ double s2[NL][kNNPartial];
-    __shared__ double s_he[kHeLds];
+    __shared__ double s_he[HE_MODE == 1 ? kHeLds : 1];
     const int b = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
     const double* src = frame_partials + (size_t)b * nrec * kPartialStride;
-    // he_mode 0: an evaluation without the cost tuple; 2: the search kernel's spare blocks have left the terms in he_scratch[b][f] (the
-    // usual chain); 1: no search kernel ran in this chain — the terms are evaluated here
-    const bool he_on = he_mode != 0;
-    const bool he_lds = he_mode == 1 && nfr <= kHeLds;
+    const bool he_lds = HE_MODE == 1 && nfr <= kHeLds;
     double* he_g = he_scratch + (size_t)b * (size_t)nfr;
-    if (he_mode == 1) {
+    if (HE_MODE == 1) {
         const Cand& cd = cands[b];
         for (int t0 = 0; t0 < 2 * nfr; t0 += kReduceThreads) {   // (block-uniform trip count: he_term pairs lanes)
             const int t = t0 + (int)threadIdx.x, f = t >> 1;
@@ -2153,24 +2153,39 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
         }
         __syncthreads();
     }
-    auto he_at = [&](int f) { return he_lds ? s_he[f] : (he_mode == 2 ? he_g[f] : __hip_atomic_load(he_g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
     // the first nfr records are the association's (one per frame), the others — when the evaluation has them — the factor kernel's:
     // a group sums the same frame range of either half, so that a slot only one half fills (every cost slot, every H / b slot) gets
     // the same bits whether or not the other half exists (iba_eval_cost = the cost tuple of iba_eval_full, bit for bit)
     const int per = (nfr + NG - 1) / NG, f0 = g * per, f1 = min(nfr, f0 + per);
-    const bool he_lane = he_on && i == P_HE_SUM;
-    auto range_sum = [&](const double* base, int lo, int hi, bool he_here) {
-        auto val = [&](int f) { return he_here ? (base[(size_t)f * kPartialStride + P_HE_CNT] != 0.0 ? he_at(f) : 0.0) : base[(size_t)f * kPartialStride + i]; };
+    // slot P_HE_SUM of an association record is empty; its lane sums the hand-eye terms of the counted frames instead (the count is the
+    // neighbouring lane's own value: one shuffle; the term one more load of that lane alone — straight-line code, no divergent loop)
+    const bool he_lane = HE_MODE != 0 && i == P_HE_SUM;
+    auto he_of = [&](int f) -> double {
+        if (HE_MODE == 0 || !he_lane) return 0.0;
+        if (HE_MODE == 2) return he_g[f];
+        return he_lds ? s_he[f] : __hip_atomic_load(he_g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto range_sum = [&](const double* base, int lo, int hi, const bool he_half) {
         double x = 0;
         int f = lo;
         for (; f + 4 <= hi; f += 4) {
-            const double v0 = val(f), v1 = val(f + 1), v2 = val(f + 2), v3 = val(f + 3);
+            double v0 = base[(size_t)f * kPartialStride + i], v1 = base[(size_t)(f + 1) * kPartialStride + i];
+            double v2 = base[(size_t)(f + 2) * kPartialStride + i], v3 = base[(size_t)(f + 3) * kPartialStride + i];
+            if (HE_MODE != 0 && he_half) {
+                const double h0 = he_of(f), h1 = he_of(f + 1), h2 = he_of(f + 2), h3 = he_of(f + 3);
+                const double c0 = __shfl(v0, P_HE_CNT), c1 = __shfl(v1, P_HE_CNT), c2 = __shfl(v2, P_HE_CNT), c3 = __shfl(v3, P_HE_CNT);
+                if (he_lane) { v0 = c0 != 0.0 ? h0 : 0.0; v1 = c1 != 0.0 ? h1 : 0.0; v2 = c2 != 0.0 ? h2 : 0.0; v3 = c3 != 0.0 ? h3 : 0.0; }
+            }
             x = (((x + v0) + v1) + v2) + v3;
         }
-        for (; f < hi; ++f) x += val(f);
+        for (; f < hi; ++f) {
+            double v = base[(size_t)f * kPartialStride + i];
+            if (HE_MODE != 0 && he_half) { const double hv = he_of(f), c = __shfl(v, P_HE_CNT); if (he_lane) v = c != 0.0 ? hv : 0.0; }
+            x += v;
+        }
         return x;
     };
-    double x = range_sum(src, f0, f1, he_lane);
+    double x = range_sum(src, f0, f1, true);
     if (nrec > nfr) x += range_sum(src + (size_t)nfr * kPartialStride, f0, min(f1, nrec - nfr), false);
     s[g][i] = x;
     if (nn_partials) {   // record lane rl sums the records rl, rl + NL, ... of slot q

@@ -1,8 +1,8 @@
 # kernel timeline of one small-batch evaluation chain: durations and the gaps between consecutive kernels
-# usage (GPU box): bash tools/chain_gaps.sh <B> <cost|full|factors>
+# usage (GPU box): bash tools/chain_gaps.sh <B> <cost|full|factors> [frames of the shard, default 200]
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-B=${1:-1}; M=${2:-cost}
+B=${1:-1}; M=${2:-cost}; FR=${3:-200}
 mkdir -p gpurun_out/gaps
 cat > /tmp/gaps_run.py <<PY
 import importlib, os, sys
@@ -12,7 +12,7 @@ import torch
 PKG = "spatial-temporal-lidar-camera-calibration_amd"
 pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synth"); abi = importlib.import_module(PKG + ".abi")
 prob, meta = synth.make_scene(n_frames=200, pts_per_frame=10000, seed=0)
-h = pkg.IbaHandle(prob, abi.reference_yaml_params())
+h = pkg.IbaHandle(prob, abi.reference_yaml_params(), frame_begin=0, frame_end=$FR)
 h.build_problem(meta["x_gt"])
 xs = synth.perturb(meta["x_gt"], np.random.default_rng(0), n=$B)
 fn = {"cost": h.eval_cost, "full": h.eval_full, "factors": h.eval_factors}["$M"]
