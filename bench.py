@@ -56,7 +56,7 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--settle", type=int, default=150, help="untimed steps BEFORE the warmup steps: a 10 ms timed region on a GPU that has only just left idle measures the clock ramp (config.untimed_steps_before_warmup)")
+    ap.add_argument("--settle", type=int, default=2500, help="untimed steps BEFORE the warmup steps: a 10 ms timed region on a GPU that has only just left idle measures the clock ramp (config.untimed_steps_before_warmup)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--pts", type=int, default=PTS_PER_FRAME)
