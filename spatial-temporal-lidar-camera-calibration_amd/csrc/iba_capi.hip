@@ -608,8 +608,9 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     const bool head = h->head_pending; h->head_pending = false;
     const uint4* head_src = head ? (const uint4*)(h->h_cands_dev + (size_t)h->head_slot * h->chain_cap) : nullptr;
     const uint32_t head_n16 = head ? (uint32_t)(sizeof(Cand) * (size_t)B / 16) : 0u;
-    auto chain_done = [&]() -> iba_status {   // the ring slot is free again once everything enqueued so far has run (the head's copy, finish_jets' copy)
-        if (head) HIP_TRY(h, hipEventRecord(h->ring_ev[h->head_slot], st));
+    auto chain_done = [&]() -> iba_status {   // the ring slot is free again once everything enqueued so far has run: the head's copy AND finish_jets' copy,
+        // which reads the slot long after a staging launch (chain_fold = 0) has recorded its own event
+        if (!frozen && h->head_slot >= 0) HIP_TRY(h, hipEventRecord(h->ring_ev[h->head_slot], st));
         return IBA_OK;
     };
     if (nf == 0) {
