@@ -89,6 +89,6 @@ def test_group_of_shards_takes_long_chains(pkg, synth, abi, scene_small):
         assert abs(a.f1 - b.f1) <= 1e-12 * a.f1 and abs(a.f2 - b.f2) <= 1e-12 * a.f2 and abs(a.C - b.C) <= 1e-12 * abs(a.C)
     for a, b in zip(n0, n1):
         assert a.counts() == b.counts() and np.max(np.abs(a.H_np() - b.H_np())) <= 1e-12 * np.abs(a.H_np()).max()
-    bb = g.eval_bbo(xs, 0.094, 0.95)
-    assert len(bb) == 200
+    cc = g.eval_cost(xs)   # the cost-only chain of the group
+    assert len(cc) == 200 and all(a.cnt_3d_2d == b.cnt_3d_2d and abs(a.f1 - b.f1) <= 1e-12 * a.f1 for a, b in zip(c0, cc))
     g.close()
