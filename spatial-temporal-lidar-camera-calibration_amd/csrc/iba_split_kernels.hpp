@@ -796,18 +796,25 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
             chunk_vis = !(behind || right || left || below || above);   // a NaN box (empty chunk) compares false everywhere: kept, harmless
         }
     }
+    // A DENSE scan (the reference's own: 120 k points, 235 blocks per keyframe, three in four of them behind or beside every candidate's
+    // camera) decides first and loads afterwards: the point and the keypoint grid of a block that returns below were 20 KB of traffic per
+    // block — 0.9 GB per pair search at 200 keyframes x 120 k points (r05: 356 -> 325 us per search there). A sparse scan keeps round 3's order: everything in
+    // flight before the first barrier (one exposed round trip less for the blocks that stay, and few blocks to spare).
+    const bool dense = P >= 32768u;   // (block-uniform: a property of the keyframe)
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pos < P) pv = p4[pos];
+    if (!dense && pos < P) pv = p4[pos];
     // the frame's keypoint grid is fetched into registers now and parked in LDS only if some point of the block needs it: a block
     // of consecutive tree positions is a compact piece of the scene, and most pieces lie outside every candidate's image
     const uint32_t* gcs = dp.coarse_start + h.coarse_base;
     const uint32_t ncs = h.gwc * h.ghc + 1u;
-    uint32_t cs_r[2]; float2 uv_r[2];
+    uint32_t cs_r[2] = {0u, 0u}; float2 uv_r[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    if (!dense) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint32_t i = threadIdx.x + (uint32_t)j * kPairsThreads;
-        cs_r[j] = i < ncs ? gcs[i] : 0u;
-        uv_r[j] = i < K ? guv[i] : make_float2(0.f, 0.f);
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t i = threadIdx.x + (uint32_t)j * kPairsThreads;
+            cs_r[j] = i < ncs ? gcs[i] : 0u;
+            uv_r[j] = i < K ? guv[i] : make_float2(0.f, 0.f);
+        }
     }
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0u;
     if (threadIdx.x < 64) {   // wave 0 holds the chunk tests
@@ -816,6 +823,7 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
     }
     __syncthreads();
     if (!s_n[3]) return;   // no candidate sees any point of this block
+    if (dense && pos < P) pv = p4[pos];
     // ---- how far the candidates move the points of THIS block (512 consecutive tree positions: a box with centre c and half extent
     //      e in the LiDAR frame, qc = R_0 c + t_0, ex = |R_0| e under the reference): candidate b moves q_0 by M_b q_0 + a_b
     //      (Cand::rel), so |q_b - q_0|_i <= |(M_b qc + a_b)_i| + sum_j |M_b|_ij ex_j for every point of the box. Wave 0: lane b
@@ -908,6 +916,14 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
 #pragma unroll
         for (int w = 0; w < kPairsThreads / 64; ++w) walk |= s_n[4 + w];
         if (!walk) return;   // no point of this block can meet a keypoint under any candidate
+    }
+    if (dense) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // (the loads of the two passes in flight together)
+            const uint32_t i = threadIdx.x + (uint32_t)j * kPairsThreads;
+            cs_r[j] = i < ncs ? gcs[i] : 0u;
+            uv_r[j] = i < K ? guv[i] : make_float2(0.f, 0.f);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

@@ -8,6 +8,10 @@ PKG = "spatial-temporal-lidar-camera-calibration_amd"
 pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synth"); abi = importlib.import_module(PKG + ".abi")
 kf = int(os.environ.get("KITTI_KF", "40"))
 prob, meta = synth.make_scene(n_frames=kf, pts_per_frame=int(os.environ.get("KITTI_PTS", "120000")), seed=0)
+tile = int(os.environ.get("KITTI_TILE", "1"))   # KITTI_TILE=5: the whole 200 keyframes on the device (the 40 ray-cast ones five times)
+if tile > 1:
+    prob = synth.tile_scene(prob, meta, tile)[0]
+    kf *= tile
 h = pkg.IbaHandle(prob, abi.reference_yaml_params())
 xs = synth.perturb(meta["x_gt"], np.random.default_rng(0), n=int(os.environ.get("KITTI_B", "64")))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
