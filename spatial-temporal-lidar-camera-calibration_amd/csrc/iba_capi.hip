@@ -102,7 +102,8 @@ struct iba_handle {
     int n_groups = 0;                     // groups of this call's batch (1: the whole batch shares one search)
     int max_groups = kMaxPairGroups;      // IBA_PAIR_GROUPS: 1 = no clustering of wide batches (round 3's behaviour)
     int last_mean_pairs_slot = -1;
-    int pair_cap = 0, hard_cap = 0, pairs_slices = 1;   // pairs_slices: scan points per thread of iba_pairs_kernel (IBA_PAIRS_SLICES)
+    int pair_cap = 0, hard_cap = 0;
+    uint32_t pairs_dense_min = 32768u;    // scans of at least this many points: the pair search tests a block's boxes before it loads the block's points and the keypoint grid (IBA_PAIRS_DENSE_MIN)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
     bool spin_wait = true;                // IBA_SPIN_WAIT=0: blocking waits only
     bool nn_sets = true;                  // IBA_NN_SETS=0: no anchored neighbour lists, every lane searches the tree (diagnostic)
@@ -647,7 +648,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         const PairsProblem pp{dp.frames, dp.pts4, dp.chunk_box, dp.kp_uv, dp.coarse_start};
         // the pair search needs nothing but its arguments: it goes first and, in one more z-plane of its grid, carries the candidates to the device
         hipLaunchKernelGGL(iba_pairs_kernel, dim3(std::max(1u, (h->maxP + (uint32_t)kPairsThreads - 1u) / (uint32_t)kPairsThreads), nf, h->n_build + (head_open ? 1 : 0)), dim3(kPairsThreads), lds, st, PairsArgs{pp, h->pplan}, h->params.max_pixel_dist, kuv_off,
-                           nf, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap, head_open ? head_src : nullptr, (uint4*)dc, head_open ? head_n16 : 0u);
+                           nf, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap, head_open ? head_src : nullptr, (uint4*)dc, head_open ? head_n16 : 0u, h->pairs_dense_min);
         HIP_TRY(h, hipGetLastError());
         h->pairs_builds += h->n_build;
         head_open = false;
@@ -1081,7 +1082,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (const char* e = std::getenv("IBA_PAIR_MEMO_MAX_B")) h->pair_memo_max_b = std::atoi(e);
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
-    if (const char* e = std::getenv("IBA_PAIRS_SLICES")) h->pairs_slices = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IBA_PAIRS_DENSE_MIN")) h->pairs_dense_min = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("IBA_PAIR_GROUPS")) h->max_groups = std::max(1, std::min(kMaxPairGroups, std::atoi(e)));
     if (const char* e = std::getenv("IBA_CHAIN_FOLD")) h->chain_fold = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_MAX_CHAIN")) h->chain_cap = std::atoi(e);

@@ -49,6 +49,9 @@ constexpr int kCdDoubles = 14;   // per candidate in LDS: s, Ri[9], ti[3], (s32,
 #ifndef IBA_NN_LEAF_BATCH
 #define IBA_NN_LEAF_BATCH 4   /* points of a leaf scan whose loads are in flight together */
 #endif
+#ifndef IBA_NN_SETS_WAVES
+#define IBA_NN_SETS_WAVES 4   /* waves per SIMD the search kernel with the anchored lists is compiled for (4: 128 VGPRs, what its LDS allows) */
+#endif
 constexpr int kAnchorSets = 2;      // anchored neighbour lists are kept around up to this many anchor extrinsics (an optimiser polls around two incumbents)
 struct NNArgs {
     DevProblem dp; DevParams prm; NNLayout lay;
@@ -723,7 +726,7 @@ constexpr int kPairStage = 2048;   // (point, keypoint) hits a block parks in LD
 __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_by_value, double max_pixel_dist, uint32_t lds_kuv_off, int n_frames,
                                                                   PairRec* __restrict__ pairs_all, uint32_t* __restrict__ hard_all,
                                                                   uint32_t* __restrict__ counts_all, int pair_cap, int hard_cap,
-                                                                  const uint4* __restrict__ head_src, uint4* __restrict__ head_dst, uint32_t head_n16) {
+                                                                  const uint4* __restrict__ head_src, uint4* __restrict__ head_dst, uint32_t head_n16, uint32_t dense_min_pts) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (head_n16 != 0u && blockIdx.z + 1u == gridDim.z) {   // the chain's head: one more z-plane of the grid carries the candidates to the device (see chain_head_copy)
         chain_head_copy(head_src, head_dst, head_n16, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, (uint32_t)kPairsThreads);
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
     // camera) decides first and loads afterwards: the point and the keypoint grid of a block that returns below were 20 KB of traffic per
     // block — 0.9 GB per pair search at 200 keyframes x 120 k points (r05: 356 -> 325 us per search there). A sparse scan keeps round 3's order: everything in
     // flight before the first barrier (one exposed round trip less for the blocks that stay, and few blocks to spare).
-    const bool dense = P >= 32768u;   // (block-uniform: a property of the keyframe)
+    const bool dense = P >= dense_min_pts;   // (block-uniform: a property of the keyframe; 32768 points by default)
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!dense && pos < P) pv = p4[pos];
     // the frame's keypoint grid is fetched into registers now and parked in LDS only if some point of the block needs it: a block
@@ -1673,7 +1676,7 @@ __global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, Se
 // SETS 1: the anchored neighbour lists are in use (anchor != nullptr); compiled for 4 waves per SIMD — what its LDS allows anyway — so that the
 // direct pass keeps two entries' loads in registers
 template <int WHICH, int REFIT, int SETS>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS ? 4 : IBA_NN_WAVES, SETS ? 4 : IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS ? IBA_NN_SETS_WAVES : IBA_NN_WAVES, SETS ? IBA_NN_SETS_WAVES : IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
                                                                                                   double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist,
                                                                                                   const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit,
                                                                                                   const SetPt* __restrict__ anchor, double* __restrict__ he_out, int he_blocks) {
