@@ -56,7 +56,7 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--settle", type=int, default=2500, help="untimed steps BEFORE the warmup steps: a 10 ms timed region on a GPU that has only just left idle measures the clock ramp (config.untimed_steps_before_warmup)")
+    ap.add_argument("--settle", type=int, default=300, help="untimed steps BEFORE the warmup steps: a 10 ms timed region on a GPU that has only just left idle measures the clock ramp (config.untimed_steps_before_warmup)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--pts", type=int, default=PTS_PER_FRAME)
@@ -404,38 +404,45 @@ def main():
                 row[name + "_evals_per_s"] = units * b / float(np.median(ts))
             sweep2[str(b)] = row
         extras["batch_sweep_cost_and_factors"] = sweep2
-        # (1c) a SUSTAINED, DRIFTING region next to the headline: >= 2 s of back-to-back steps whose 64 candidates are drawn
-        # afresh every step around a centre that drifts (a random walk of 0.15 mrad / 1.5 mm per step, reflected at 6 mrad / 6 cm from the
-        # planted extrinsic): every step runs its own pair search, the anchored lists are rebuilt as the centre leaves them, nothing is
-        # reused from a fixed set. evaluations/s over the whole region and min / median / max over windows of 100 steps.
-        rs = np.random.default_rng(99)
-        centre = meta["x_gt"].copy()
-        sus_sigma = np.array([1.5e-4] * 3 + [1.5e-3] * 3 + [2e-4 * abs(meta["x_gt"][6])])
-        sus_box = np.array([6e-3] * 3 + [6e-2] * 3 + [0.02 * abs(meta["x_gt"][6])])
-        n_sus, t_windows, ab0 = 0, [], h.anchor_builds
-        pb0 = h.pairs_builds
-        sync()
-        t_sus0 = time.perf_counter()
-        tw0 = t_sus0
-        while True:
-            centre = centre + rs.normal(size=7) * sus_sigma
-            off = centre - meta["x_gt"]
-            centre = meta["x_gt"] + np.where(np.abs(off) > sus_box, np.sign(off) * (2 * sus_box - np.abs(off)), off)
-            xs_s = synth.perturb(centre, rs, n=B)
-            step(0, [xs_s])
-            n_sus += 1
-            if n_sus % 100 == 0:
-                tnow = time.perf_counter()
-                t_windows.append(100 * B / (tnow - tw0))
-                tw0 = tnow
-                if tnow - t_sus0 > 2.0 and n_sus >= 400:
-                    break
-        sync()
-        t_sus = time.perf_counter() - t_sus0
-        extras["sustained"] = {"seconds": t_sus, "steps": n_sus, "evals_per_s": n_sus * B / t_sus, "window_steps": 100,
-                               "window_evals_per_s": {"min": float(np.min(t_windows)), "median": float(np.median(t_windows)), "max": float(np.max(t_windows))},
-                               "anchor_builds": h.anchor_builds - ab0, "pair_searches": h.pairs_builds - pb0,
-                               "what": "64 fresh candidates (0.5 mrad / 5 mm / 0.1 %) per step around a drifting centre; candidate generation (numpy, ~60 us per step) is inside the clock"}
+        # (1c) SUSTAINED regions next to the headline: >= 1.5 s each of back-to-back steps whose 64 candidates are drawn afresh
+        # every step — (a) around the planted extrinsic (the headline's own workload without its four fixed candidate sets: every step
+        # runs its own pair search on candidates it has never seen), (b) around a centre that DRIFTS (a random walk of 0.15 mrad / 1.5 mm
+        # per step, reflected at 6 mrad / 6 cm from the planted extrinsic): the anchored lists are rebuilt as the centre leaves them.
+        # A drifted centre is a LIGHTER workload, not a faster machine — away from the planted extrinsic fewer scan points meet a keypoint
+        # within max_pixel_dist, so every later stage has less to do: the mean correspondence count is reported beside each rate, and only
+        # (a) compares with the headline. evaluations/s over the whole region and min / median / max over windows of 100 steps.
+        def sustained(drift):
+            rs = np.random.default_rng(99)
+            centre = meta["x_gt"].copy()
+            sig = np.array([1.5e-4] * 3 + [1.5e-3] * 3 + [2e-4 * abs(meta["x_gt"][6])])
+            box = np.array([6e-3] * 3 + [6e-2] * 3 + [0.02 * abs(meta["x_gt"][6])])
+            n_s, wins, ncs, ab0, pb0 = 0, [], [], h.anchor_builds, h.pairs_builds
+            sync()
+            t00 = time.perf_counter()
+            tw0 = t00
+            while True:
+                if drift:
+                    centre = centre + rs.normal(size=7) * sig
+                    off = centre - meta["x_gt"]
+                    centre = meta["x_gt"] + np.where(np.abs(off) > box, np.sign(off) * (2 * box - np.abs(off)), off)
+                o_ = step(0, [synth.perturb(centre, rs, n=B)])
+                n_s += 1
+                if n_s % 100 == 0:
+                    tnow = time.perf_counter()
+                    wins.append(100 * B / (tnow - tw0))
+                    ncs.append(float(np.mean([c.n_corr for c in o_[0]])))
+                    tw0 = time.perf_counter()
+                    if tnow - t00 > 1.5 and n_s >= 300:
+                        break
+            sync()
+            t_s = time.perf_counter() - t00
+            return {"seconds": t_s, "steps": n_s, "evals_per_s": n_s * B / t_s, "window_steps": 100,
+                    "window_evals_per_s": {"min": float(np.min(wins)), "median": float(np.median(wins)), "max": float(np.max(wins))},
+                    "mean_n_corr_sampled_every_100_steps": float(np.mean(ncs)), "anchor_builds": h.anchor_builds - ab0, "pair_searches": h.pairs_builds - pb0}
+        extras["sustained"] = {"fresh_candidates_fixed_centre": sustained(False), "fresh_candidates_drifting_centre": sustained(True),
+                               "headline_mean_n_corr": float(np.mean([c.n_corr for c in out[0]])),
+                               "what": "64 fresh candidates (0.5 mrad / 5 mm / 0.1 %) per step; candidate generation (numpy, ~60 us per step) is inside the clock. The drifting "
+                                       "centre wanders up to 6 mrad / 6 cm from the planted extrinsic: fewer correspondences, less work per evaluation (see mean_n_corr) - only the fixed centre compares with the headline"}
         # (2) a batch as wide as the reference's search box (iba_calib_global.yml:39-40: +-0.1 rad, +-0.3 m, +-1 on the scale)
         xw = meta["x_gt"][None, :] + np.random.default_rng(7).uniform(-1, 1, (B, 7)) * np.array([0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0])
         for _ in range(2):

@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 T=${1:-r03}
 mkdir -p gpurun_out/$T
-BENCH="python3 bench.py --steps 15 --warmup 2 --no-cpu-baseline --no-extras"
+BENCH="python3 bench.py --steps 15 --warmup 2 --settle 100 --no-cpu-baseline --no-extras"   # (--settle 100: the profiler does not need the clocks at their sustained state, and 2500 untimed steps x 6 passes are 100 MB of traces)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/stats -o stats -- $BENCH > gpurun_out/$T/bench_under_rocprof.json 2> gpurun_out/$T/rocprof_stats.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$T/fetch -o pmc -- $BENCH > /dev/null 2> gpurun_out/$T/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$T/write -o pmc -- $BENCH > /dev/null 2> gpurun_out/$T/pmc_write.log
