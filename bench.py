@@ -466,7 +466,7 @@ def main():
                     "window_evals_per_s": {"min": float(np.min(wins)), "median": float(np.median(wins)), "max": float(np.max(wins))},
                     "mean_n_corr_sampled_every_100_steps": float(np.mean(ncs)), "anchor_builds": h.anchor_builds - ab0, "pair_searches": h.pairs_builds - pb0}
         extras["sustained"] = {"fresh_candidates_fixed_centre": sustained(False), "fresh_candidates_drifting_centre": sustained(True),
-                               "headline_mean_n_corr": float(np.mean([c.n_corr for c in out[0]])),
+                               "headline_mean_n_corr": res["config"]["mean_n_corr"],
                                "what": "64 fresh candidates (0.5 mrad / 5 mm / 0.1 %) per step, every set generated before the clock starts and used once. The drifting "
                                        "centre wanders up to 6 mrad / 6 cm from the planted extrinsic: fewer correspondences, less work per evaluation (see mean_n_corr) - only the fixed centre compares with the headline"}
         # (2) a batch as wide as the reference's search box (iba_calib_global.yml:39-40: +-0.1 rad, +-0.3 m, +-1 on the scale)
