@@ -14,7 +14,7 @@ pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synt
 def handle(prob, p, plain):
     """plain: every cross-call / cross-candidate mechanism off (iba_create_options)"""
     if plain:
-        return pkg.IbaHandle(prob, p, options=dict(common_pairs=0, anchored_lists=0, side_stream=0, pair_memo=0, max_pair_groups=1))
+        return pkg.IbaHandle(prob, p, options=dict(common_pairs=0, anchored_lists=0, side_stream=0, pair_memo=0, max_pair_groups=1, chain_fold=0, max_chain_batch=64))   # (r05: the chain of rounds 1-4 too)
     return pkg.IbaHandle(prob, p)
 
 
@@ -39,6 +39,8 @@ for sq in range(n_seq):
     prob, meta = synth.make_scene(n_frames=nf, pts_per_frame=pts, n_keypoints=kp, seed=seed0 + sq)
     p = abi.reference_yaml_params()
     if rng.random() < 0.2: p.plane_cache = 0
+    if rng.random() < 0.25: p.factor_3d2d_kind = 1   # (r05: IBATestEdge blocks)
+    if rng.random() < 0.15: p.err_weight[1] = 0.0    # (no search kernel in a cost chain: the hand-eye terms inside the summing kernel)
     h, r = handle(prob, p, False), handle(prob, p, True)
     centre = meta["x_gt"].copy()
     # a second and a third poll centre tens of pixels away (an optimiser's infeasible incumbent): batches of several tight groups
@@ -48,7 +50,7 @@ for sq in range(n_seq):
     for step in range(int(rng.integers(15, 40))):
         op = rng.choice(["cost", "full", "normal", "frozen", "params", "corr", "bbo"], p=[0.3, 0.3, 0.1, 0.12, 0.06, 0.04, 0.08])
         scale = float(rng.choice([1e-5, 1e-4, 5e-4, 2e-3, 2e-2]))
-        n = int(rng.choice([1, 2, 5, 14, 33, 64, 70]))
+        n = int(rng.choice([1, 2, 5, 14, 17, 33, 64, 70, 130, 300], p=[0.14, 0.1, 0.1, 0.14, 0.08, 0.12, 0.12, 0.08, 0.07, 0.05]))   # (r05: chains of more than 64 candidates)
         xs = synth.perturb(centre, rng, rot=scale, trans=8 * scale, scale_rel=2 * scale, n=n)
         if n >= 2 and rng.random() < 0.35:   # several centres in one batch, interleaved
             k = int(rng.choice([1, 2]))
@@ -70,7 +72,7 @@ for sq in range(n_seq):
             h.build_problem(xs[0]); r.build_problem(xs[0])
             ok = same_normal(h.eval_factors(xs), r.eval_factors(xs))
         elif op == "params":
-            p2 = abi.reference_yaml_params(); p2.plane_cache = p.plane_cache
+            p2 = abi.reference_yaml_params(); p2.plane_cache = p.plane_cache; p2.factor_3d2d_kind = p.factor_3d2d_kind; p2.err_weight[1] = p.err_weight[1]
             p2.max_pixel_dist = float(rng.choice([1.0, 1.5, 2.5])); p2.corr_3d_3d_threshold = float(rng.choice([2.0, 5.0])); p2.neigh_radius = float(rng.choice([0.6, 0.9]))
             h.set_params(p2); r.set_params(p2)
         elif op == "corr":
