@@ -16,14 +16,13 @@
  *   IBA_PAIR_INFL           pair_inflation                inflation of a reusable list's bound
  *   IBA_NN_SETS             anchored_lists                anchored neighbour lists on / off
  *   IBA_ANCHOR_REACH        anchor_reach                  drift (m) that moves an anchor
- *   IBA_SIDE_STREAM         side_stream                   staging launch beside the pair search on a second stream
  *   IBA_SPIN_WAIT           spin_wait                     polling wait at the end of a call
  *   IBA_FACTOR_MFMA         factor_mfma                   normal-equation sums on the matrix cores
  *   IBA_DEBUG_PAIR_CAP      pair_list_capacity            entries per pair list (tests force the overflow path)
  *   IBA_CHAIN_FOLD          chain_fold                    staging / reduction launches folded into their neighbours
  *   IBA_MAX_CHAIN           max_chain_batch               candidates one launch chain takes
  *   -- no field: pure diagnostics, results unaffected unless stated --
- *   IBA_NN_CG, IBA_PAIRS_SLICES, IBA_COMMON_MIN_BATCH, IBA_PAIR_BOUND, IBA_ASSOC2_FLREG, IBA_ASSOC_BLOCKS, IBA_CAND_BYTES,
+ *   IBA_NN_CG, IBA_PAIRS_DENSE_MIN, IBA_COMMON_MIN_BATCH, IBA_PAIR_BOUND, IBA_ASSOC2_FLREG, IBA_ASSOC_BLOCKS, IBA_CAND_BYTES,
  *   IBA_PAIR_BYTES                                        launch-shape / LDS-plan knobs of single kernels (A/B timing)
  *   IBA_NN_DBG, IBA_ASSOC_DBG                             cut a kernel short after a phase (timing attribution; RESULTS ARE GARBAGE)
  *   IBA_LAYOUT_DEBUG, IBA_DEBUG_LEFT_HIST                 print the LDS plan / a histogram of left-over searches to stderr
