@@ -1525,7 +1525,7 @@ static iba_status eval_factors_partial_impl(iba_handle* h, const double* x, int 
     hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->nfb, d_partials);
     HIP_TRY(h, hipGetLastError());
     // the frozen problem's frame / correspondence counts (iba_build_problem) ride in their slots of the block
-    hipLaunchKernelGGL(iba_set_slots_kernel, dim3(1), dim3(64), 0, st, d_partials, B, (int)P_FRAMES_N, (double)h->frozen_frames, (int)P_NCORR_N, (double)h->frozen_ncorr);
+    hipLaunchKernelGGL(iba_set_slots_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_partials, B, (int)P_FRAMES_N, (double)h->frozen_frames, (int)P_NCORR_N, (double)h->frozen_ncorr);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = false; }
     return IBA_OK;

@@ -1306,7 +1306,7 @@ __global__ void iba_fetch_jets_kernel(const uint4* __restrict__ src, uint4* __re
 
 // writes two host-known values into their slots of B partial blocks (frozen-problem counts)
 __global__ void iba_set_slots_kernel(double* __restrict__ partials, int B, int slot_a, double va, int slot_b, double vb) {
-    const int b = threadIdx.x;
+    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (one thread per candidate: a chain takes up to 512 since round 5)
     if (b < B) { partials[(size_t)b * kPartialStride + slot_a] = va; partials[(size_t)b * kPartialStride + slot_b] = vb; }
 }
 

@@ -45,6 +45,13 @@ def test_one_chain_of_many_equals_chains_of_64(pkg, synth, abi, ob, scene_small)
         # the mixed batch above is too wide to share one pair search (the per-candidate kernel carried the head); a tight one shares it
         a, b = _blocks(big, xs[:300], "full"), _blocks(old, xs[:300], "full")
         assert big.last_path == 1 and np.array_equal(a, b, equal_nan=True)
+        # the frozen problem's residual blocks at 337 other x in one chain (tools/sequence_fuzz.py caught the frozen counts reaching only the
+        # first 64 candidates of a longer chain)
+        for hh in (big, old):
+            hh.build_problem(xs[3])
+        fa, fb = big.eval_factors(xs), old.eval_factors(xs)
+        assert all(a.counts() == b.counts() and np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.cost == b.cost for a, b in zip(fa, fb))
+        assert fa[336].frames_used == fa[0].frames_used > 0 and fa[336].n_corr == fa[0].n_corr > 0
         big.close(); old.close(); mid.close()
     with pytest.raises(pkg.IbaError):
         pkg.IbaHandle(prob, p, options={"max_chain_batch": 513})
