@@ -85,6 +85,7 @@ struct iba_handle {
     DevBuf<PairRec> d_pairs;              // n_frames x pair_cap
     DevBuf<uint32_t> d_hard, d_pcounts;   // n_frames x hard_cap; n_frames x kCountStride
     DevBuf<uint32_t> mpk;                 // per frame: keypoints that own a MapPoint
+    DevBuf<uint2> fkp;                    // per frame: (keypoint, flag word) of the keypoints that can own a term (FrameHdr::fk_base, n_fk)
     uint32_t max_mpk = 0;
     DevBuf<SetPt> d_anchor;               // anchored neighbour lists: n_frames x maxK rows of kAnchorRowBytes (512) bytes
     // up to kAnchorSets anchors (an optimiser polls around two incumbents, the feasible and the infeasible one): each with its own set of lists
@@ -174,7 +175,7 @@ struct iba_handle {
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.plane_ok = plane_ok.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
-        dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u); dp.kp_fl2 = kp_fl2.p; dp.diag = d_diag.p;
+        dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u); dp.kp_fl2 = kp_fl2.p; dp.diag = d_diag.p; dp.fkp = fkp.p;
         return dp;
     }
 };
@@ -248,7 +249,7 @@ bool layout_assoc(iba_handle* h, LdsLayout& L) {
     off += 4u * L.vis_words + 2u * (h->maxPpad / (uint32_t)kChunk + 2u);
     off = align_up(off, 4); L.off_cstart = off; off += 2u * std::max(h->maxCoarse, 1u);
     off = align_up(off, 16); L.off_kuv = off; off += 8u * Kp;
-    L.off_kfl = off; off += 4u * Kp;
+    L.off_kfl = off;   // (no LDS copy of the flags since round 5: the tail reads the flagged-keypoint list)
     off = align_up(off, 16);
     const uint32_t bm_bytes = align_up(4u * std::max(h->maxBitmapWords, 1u), 16u);
     if (off + bm_bytes + 4u * 512u > kLdsBytes) return false;
@@ -285,8 +286,9 @@ bool layout_nn(const iba_handle* h, NNLayout& L) {
     return L.total <= kLdsBytes;
 }
 
-// iba_assoc2_kernel<true>: at most four keypoints per thread, their flags in registers (IBA_ASSOC2_FLREG=0: always through LDS)
-bool assoc2_flreg(const iba_handle* h) { return h->assoc2_flreg_on && h->maxK <= 4u * (uint32_t)kThreads; }
+// iba_assoc2_kernel<Q>: flagged keypoints per thread that the tail keeps in registers — 2 (at most 1024 flagged keypoints per frame), 4 (at most
+// 2048), 0 = any number, read from the list where needed (IBA_ASSOC2_FLREG=0: always 0)
+int assoc2_q(const iba_handle* h) { return !h->assoc2_flreg_on ? 0 : (h->maxKw <= 2u * (uint32_t)kThreads ? 2 : (h->maxKw <= 4u * (uint32_t)kThreads ? 4 : 0)); }
 // LDS plan of iba_assoc2_kernel: best d^2, best index and flag word per keypoint, the reduction slab
 bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     const uint32_t rel_slots = std::max<uint32_t>(h->max_slots, 1u);
@@ -297,7 +299,7 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     const uint32_t Kp = (std::max(h->maxK, 1u) + 3u) & ~3u;
     L.off_best_d2 = off; off += 8u * Kp;
     L.off_best_idx = off; off += 4u * Kp;
-    L.off_kfl = off; if (!assoc2_flreg(h)) off += 4u * Kp;   // (the register variant keeps no LDS copy of the flags)
+    L.off_kfl = off;   // (no LDS copy of the flags since round 5: the tail reads the flagged-keypoint list)
     off = align_up(off, 16); L.off_red = off; off += red_bytes;
     off = align_up(off, 16); L.off_pair = off; off += 2u * (uint32_t)kPairNote;   // possible winners beyond the register window
     L.total = align_up(off, 16);
@@ -738,17 +740,17 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     const Cand* assoc_cands = head_open ? (const Cand*)head_src : dc;
     const uint4* a_src = head_open ? head_src : nullptr; const uint32_t a_n16 = head_open ? head_n16 : 0u;
     if (common) {
-        // (four instantiations: flags in registers or LDS x at most 30 covisible keyframes or more; the common one is round 3's code)
-        auto launch_assoc2 = [&](auto flreg) {
-            constexpr bool FL = decltype(flreg)::value;
+        // (six instantiations: two / four / any number of flagged keypoints per thread x at most 30 covisible keyframes or more)
+        auto launch_assoc2 = [&](auto qtag) {
+            constexpr int QQ = decltype(qtag)::value;
             auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B + head_blocks), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                                                           h->d_frame_partials.p, nrec, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap, a_src, (uint4*)dc, a_n16); };
-            if (h->max_slots > (uint32_t)kCovisWord) go(iba_assoc2_kernel<FL, true>); else go(iba_assoc2_kernel<FL, false>);
+            if (h->max_slots > (uint32_t)kCovisWord) go(iba_assoc2_kernel<QQ, true>); else go(iba_assoc2_kernel<QQ, false>);
         };
-        if (assoc2_flreg(h))
-            launch_assoc2(std::true_type{});
-        else
-            launch_assoc2(std::false_type{});
+        const int aq = assoc2_q(h);
+        if (aq == 2) launch_assoc2(std::integral_constant<int, 2>{});
+        else if (aq == 4) launch_assoc2(std::integral_constant<int, 4>{});
+        else launch_assoc2(std::integral_constant<int, 0>{});
     } else {
     hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B + head_blocks), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                        h->d_frame_partials.p, nrec, (uint32_t*)nullptr, fl, fc, lc, (int)h->lstride, a_src, (uint4*)dc, a_n16);
@@ -846,7 +848,7 @@ void iba_destroy(iba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
-    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->kp_fl2.release(); h->d_diag.release(); h->d_anchor.release();
+    h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->fkp.release(); h->kp_fl2.release(); h->d_diag.release(); h->d_anchor.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -1051,12 +1053,17 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
         hdr[lf].n_mpk = (uint32_t)(mpk.size() - hdr[lf].mpk_base);
         h->max_mpk = std::max(h->max_mpk, hdr[lf].n_mpk);
     }
+    std::vector<uint2> fkp;   // per frame: the keypoints whose flag word is not zero, ascending (the association tail's walk)
     for (int lf = 0; lf < nf; ++lf) {
         uint32_t cnt = 0;
         for (uint32_t k = 0; k < hdr[lf].K; ++k) { uint32_t idb; std::memcpy(&idb, &crec[hdr[lf].kp_base + k].z, 4); crec_ok = crec_ok && idb == k; }
-        for (uint32_t k = 0; k < hdr[lf].K; ++k) cnt += kp_fl[hdr[lf].kp_base + k] != 0u ? 1u : 0u;
+        hdr[lf].fk_base = fkp.size();
+        for (uint32_t k = 0; k < hdr[lf].K; ++k) if (kp_fl[hdr[lf].kp_base + k] != 0u) { fkp.push_back(make_uint2(k, kp_fl[hdr[lf].kp_base + k])); ++cnt; }
+        hdr[lf].n_fk = cnt;
+        while (fkp.size() & 3u) fkp.push_back(make_uint2(kNone, 0u));   // (every frame's list starts 32-byte aligned and is read two or four entries at a time)
         h->maxKw = std::max(h->maxKw, cnt);
     }
+    fkp.resize(fkp.size() + 4, make_uint2(kNone, 0u));
     fb.clear(); fb.shrink_to_fit();
     if (bad_match) { delete h; return fail(nullptr, IBA_ERR_INVALID_ARG, "covisibility / match index out of range"); }
     if (!crec_ok) { delete h; return fail(nullptr, IBA_ERR_STATE, "internal: keypoint grid records are not in keypoint order"); }
@@ -1099,7 +1106,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     UP(frames, hdr); UP(slots, slots); UP(xs, xs); UP(ys, ys); UP(zs, zs); UP(perm, perm); UP(inv_perm, inv_perm); UP(nodes, nodes); UP(chunk_box, chunk_box); UP(pts4, pts4);
     h->h_kp_uv.resize(2 * (size_t)kp_base);
     for (size_t k = 0; k < (size_t)kp_base; ++k) { h->h_kp_uv[2 * k] = kp_uv[k].x; h->h_kp_uv[2 * k + 1] = kp_uv[k].y; }
-    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(kp_fl, kp_fl); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv); UP(mpk, mpk);
+    UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(kp_fl, kp_fl); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv); UP(mpk, mpk); UP(fkp, fkp);
     if (many_slots) UP(kp_fl2, kp_fl2);
 #undef UP
     hipError_t er;
@@ -1144,7 +1151,8 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     {
-        const void* a2[4] = {(const void*)iba_assoc2_kernel<true, false>, (const void*)iba_assoc2_kernel<true, true>, (const void*)iba_assoc2_kernel<false, false>, (const void*)iba_assoc2_kernel<false, true>};
+        const void* a2[6] = {(const void*)iba_assoc2_kernel<2, false>, (const void*)iba_assoc2_kernel<2, true>, (const void*)iba_assoc2_kernel<4, false>, (const void*)iba_assoc2_kernel<4, true>,
+                             (const void*)iba_assoc2_kernel<0, false>, (const void*)iba_assoc2_kernel<0, true>};
         for (const void* fn : a2) if (h->common_mode > 0 && (er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     }
     if ((er = hipFuncSetAttribute((const void*)iba_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);

@@ -53,6 +53,8 @@ struct DevProblem {
     uint32_t* diag;            // diagnostic counters: [0] association blocks that took a speed-only fallback (a full queue or list: every scan point again),
                                // [1] iba_assoc2_kernel blocks whose note list of possible winners overflowed (every pair beyond the register window again)
     uint32_t max_k;            // largest keypoint count of a frame: row pitch of the per-(frame, keypoint) tables
+    const uint2* fkp;          // per frame (FrameHdr::fk_base, n_fk): (keypoint id, flag word) of the keypoints that can own a term — a MapPoint and/or a covisible match —
+                               // in ascending id order: the association tail walks these (~40 % of the keypoints), not every keypoint (r05)
 };
 
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
@@ -567,11 +569,13 @@ __device__ __forceinline__ bool near_keypoint(const FrameCtx& c, double u, doubl
 // keypoints of the <= 2x2 grid cells around it. PASS 1: ds_min_u64 on the keypoint's best d^2.
 // PASS 2: resolve exact ties by the lowest original point index.
 template <int PASS>
-__device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v, uint32_t pos) {
+// returns (PASS 1) how many keypoints this point was the FIRST to reach: ds_min_u64 hands back the keypoint's previous best, and exactly one
+// caller per keypoint sees the initial ~0 — the sum over a block is corrset.size() (r05: the tail no longer walks every keypoint to count them)
+__device__ __forceinline__ uint32_t grid_match(const FrameCtx& c, double u, double v, uint32_t pos) {
     const float uf = (float)u, vf = (float)v;
     const int x0 = grid_cell(uf - c.margin, c.gw) >> kCoarseShift, x1 = grid_cell(uf + c.margin, c.gw) >> kCoarseShift;
     const int y0 = grid_cell(vf - c.margin, c.gh) >> kCoarseShift, y1 = grid_cell(vf + c.margin, c.gh) >> kCoarseShift;
-    bool hit = false;
+    uint32_t hit = 0u;
     for (int yy = y0; yy <= y1; ++yy) {
         const uint32_t e0 = c.cstart[yy * c.gwc + x0], e1 = c.cstart[yy * c.gwc + x1 + 1];
         for (uint32_t e = e0; e < e1; ++e) {
@@ -581,7 +585,7 @@ __device__ __forceinline__ bool grid_match(const FrameCtx& c, double u, double v
             const double d2 = du * du + dv * dv;
             if (d2 <= c.gate2) {
                 const uint32_t k = __float_as_uint(rec.z);
-                if (PASS == 1) { atomicMin(&c.best_d2[k], d2bits(d2)); hit = true; }
+                if (PASS == 1) hit += atomicMin(&c.best_d2[k], d2bits(d2)) == ~0ull ? 1u : 0u;
                 else if (c.best_d2[k] == d2bits(d2)) atomicMin(&c.best_idx[k], c.perm[pos]);
             }
         }

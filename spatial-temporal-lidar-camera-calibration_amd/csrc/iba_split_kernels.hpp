@@ -99,60 +99,69 @@ template <class PRM> __device__ __forceinline__ double cost_res(const PRM& prm, 
 // One function, one order of every sum: which kernel ran the first half cannot be told from the results.
 // ------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(4))) const KArgs KArgsC;
-// FLREG (at most 2048 keypoints per frame: four per thread): the thread's four flag words arrive in registers (rf, loaded from global
-// memory at the start of the kernel) instead of through an LDS copy of the frame's flags, the winners read in the counting pass stay
-// in registers for the list pass, and the covisible-slot mask of a list entry is parked next to it (s_msk, over the winners' array).
-template <bool FLREG, bool MANY = true>   // MANY: a frame may have more covisible keyframes than the flag word has match bits (the second word, kp_fl2)
-__device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, uint32_t* s_best_idx, const uint32_t* s_kfl, const uint4 rf, uint32_t* s_list,
+// The tail walks the frame's FLAGGED keypoints — the ones that own a MapPoint or have a covisible match (DevProblem::fkp: ~40 % of the
+// keypoints of a frame, ascending ids) — not every keypoint (round 5): a keypoint without either can own no term, and corrset.size(), the
+// one thing that needed all of them, is counted where the winners are made (`first_hits`: the number of keypoints this thread was the first
+// to reach; see grid_match). Q > 0 (at most Q x 512 flagged keypoints per frame): the thread's Q list entries (keypoint, flag word) arrive in
+// registers (rfa, rfb: loaded at the start of the kernel), their winners are gathered once and stay in registers for the list pass, and the
+// covisible-slot mask of a list entry is parked next to it (s_msk, over the winners' array). Q = 0: any number, read from the list where needed.
+template <int Q, bool MANY = true>   // MANY: a frame may have more covisible keyframes than the flag word has match bits (the second word, kp_fl2)
+__device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, uint32_t* s_best_idx, const uint4 rfa, const uint4 rfb, uint32_t* s_list,
                                            double* s_red, const double* s_rel, const uint32_t K, const int want, const int dbg, const bool refit, const int b, const int f, const int nf,
                                            double* __restrict__ part, uint4* __restrict__ flist,
-                                           uint32_t* __restrict__ fcount, uint32_t* __restrict__ lcount, const int flist_stride) {
+                                           uint32_t* __restrict__ fcount, uint32_t* __restrict__ lcount, const int flist_stride, const uint32_t first_hits) {
 #define dp (ka->dp)
 #define prm (ka->prm)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
+    const uint2* fk = dp.fkp + h.fk_base;
+    const uint32_t Kw = h.n_fk;
 
     const double s = cd.s;
     uint32_t n3 = 0;
-    // ---- phase 3: corrset.size() and the work list in keypoint order, in one pass: every thread owns a run of q consecutive
-    //      keypoints (q = 4 up to 2048 keypoints: one 16-byte LDS read each of the winners and of the flag words), counts its
-    //      valid / cost-list / association-list keypoints, an inclusive DPP scan of the packed counts gives its place in the
-    //      wave, the waves' totals go through LDS (the one barrier), and the entries are written. Work list = keypoints with a
-    //      correspondence that can own a term: a MapPoint and/or a covisible match for the cost (iba_global.cpp:225, 295-300),
-    //      both for a residual block (iba_local.cpp:213, 259-260); entry = k | w << 16 (bits 16,17: MapPoint / covisible-match
-    //      flags). (Round 2 counted with three ballots per 64 keypoints and walked the keypoints a second time for the entries:
-    //      2.3e7 of the kernel's 8.1e7 vector instructions at the bench shape, and as many scalar ones.) ----
-    const uint32_t q = ((K + (uint32_t)kThreads * 4u - 1u) / ((uint32_t)kThreads * 4u)) * 4u;   // keypoints per thread: a multiple of 4
-    const uint32_t k0 = (uint32_t)tid * q;
-    uint32_t n_corr = 0u;
-    // counts of this thread's run: cost-list | association-list << 16 entries (K < 65 535: each fits 16 bits, so do the block totals); the valid
-    // keypoints are counted per wave with ballots (scalar unit). (Round 3 carried the three counts in one 64-bit word: its adds,
-    // its DPP prefix and the re-derivation of the flags in the list pass were 26 M of the kernel's 79 M vector instructions.)
+    // ---- phase 3: the work list in keypoint order, in one pass over the flagged keypoints: every thread owns a run of q consecutive list
+    //      entries, counts the ones that go to the cost list / the association list, an inclusive DPP scan of the packed counts gives its
+    //      place in the wave, the waves' totals go through LDS (the one barrier), and the entries are written. Work list = keypoints with a
+    //      correspondence that can own a term: a MapPoint and/or a covisible match for the cost (iba_global.cpp:225, 295-300), both for a
+    //      residual block (iba_local.cpp:213, 259-260); entry = k | w << 16 (bits 16,17: MapPoint / covisible-match flags). ----
     // which keypoints the association list holds: a MapPoint AND a covisible match for BuildProblem's blocks (iba_local.cpp:213, 259-260); a
     // covisible match alone when the 3d-2d residual is IBATestEdge (factor_3d2d_kind = 1: the edge set of BAError's 3d-2d loop, iba_global.cpp:295-300)
     const uint32_t amask = prm.p2pix ? 2u : 3u;
-    uint32_t mine = 0u, wave_valid = 0u;
-    uint4 bi_keep = make_uint4(kNone, kNone, kNone, kNone);
-    uint32_t mC_keep = 0u, mA_keep = 0u;   // FLREG: which of the run's four keypoints go to the cost / the association list
-    for (uint32_t g = 0; g < q; g += 4u) {   // (block-uniform trip count: the ballots below need every lane)
-        uint4 bi = make_uint4(kNone, kNone, kNone, kNone), fl4 = make_uint4(0u, 0u, 0u, 0u);
-        if (k0 + g < K) { bi = *(const uint4*)(s_best_idx + k0 + g); fl4 = FLREG ? rf : *(const uint4*)(s_kfl + k0 + g); }
-        if (FLREG) bi_keep = bi;
-        const uint32_t bv[4] = {bi.x, bi.y, bi.z, bi.w}, fv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
-        uint32_t mC = 0u, mA = 0u;
+    constexpr int QR = Q > 0 ? Q : 1;
+    const uint32_t q = Q > 0 ? (uint32_t)Q : ((Kw + (uint32_t)kThreads * 2u - 1u) / ((uint32_t)kThreads * 2u)) * 2u;   // list entries per thread (even: read two at a time)
+    const uint32_t e0 = (uint32_t)tid * q;
+    uint32_t n_corr = 0u;
+    // counts of this thread's run: cost-list | association-list << 16 entries (K < 65 535: each fits 16 bits, so do the block totals)
+    uint32_t mine = 0u;
+    uint32_t kk[QR], ff[QR], bw[QR];      // Q > 0: keypoint, flag word and winner of the thread's entries
+    uint32_t mC_keep = 0u, mA_keep = 0u;  // ... and which of them go to the cost / the association list
+    if (Q > 0) {
+        const uint32_t rk4[4] = {rfa.x, rfa.z, rfb.x, rfb.z}, rf4[4] = {rfa.y, rfa.w, rfb.y, rfb.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
-            wave_valid += (uint32_t)__popcll(__ballot(valid));
-            const uint32_t w = valid ? fv[j] : 0u;
-            mC |= (w != 0u ? 1u : 0u) << j; mA |= ((w & amask) == amask ? 1u : 0u) << j;
+        for (int j = 0; j < QR; ++j) {
+            kk[j] = rk4[j]; ff[j] = rf4[j];
+            bw[j] = e0 + (uint32_t)j < Kw ? s_best_idx[kk[j]] : kNone;
+            const uint32_t w = bw[j] != kNone ? ff[j] : 0u;
+            mC_keep |= (w != 0u ? 1u : 0u) << j; mA_keep |= ((w & amask) == amask ? 1u : 0u) << j;
         }
-        mine += (uint32_t)__popc(mC) | ((uint32_t)__popc(mA) << 16);
-        if (FLREG) { mC_keep = mC; mA_keep = mA; }
+        mine = (uint32_t)__popc(mC_keep) | ((uint32_t)__popc(mA_keep) << 16);
+    } else {
+        for (uint32_t g = 0; g < q; g += 2u) {   // (block-uniform trip count)
+            uint4 two = make_uint4(kNone, 0u, kNone, 0u);
+            if (e0 + g < Kw) two = *(const uint4*)(fk + e0 + g);
+            const uint32_t k2[2] = {two.x, two.z}, f2[2] = {two.y, two.w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t bwv = e0 + g + (uint32_t)j < Kw ? s_best_idx[k2[j]] : kNone;
+                const uint32_t w = bwv != kNone ? f2[j] : 0u;
+                mine += (w != 0u ? 1u : 0u) | (((w & amask) == amask ? 1u : 0u) << 16);
+            }
+        }
     }
-    const uint32_t incl = wave_sum_u32(mine);   // inclusive prefix over the lanes of the wave (the total in lane 63)
-    uint2* s_cnt = (uint2*)s_red;   // (list counts, valid keypoints) of every wave (the reduction slab is not in use yet)
-    if (lane == 63) s_cnt[wave] = make_uint2(incl, wave_valid);
+    const uint32_t incl = wave_sum_u32(mine);         // inclusive prefix over the lanes of the wave (the total in lane 63)
+    const uint32_t fhw = wave_sum_u32(first_hits);    // keypoints this wave was the first to reach
+    uint2* s_cnt = (uint2*)s_red;   // (list counts, first hits) of every wave (the reduction slab is not in use yet)
+    if (lane == 63) s_cnt[wave] = make_uint2(incl, fhw);
     __syncthreads();
     uint32_t before = 0u, total = 0u;
     for (int w = 0; w < kWaves; ++w) { const uint2 t = s_cnt[w]; total += t.x; n_corr += t.y; if (w < wave) before += t.x; }
@@ -160,31 +169,36 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     const bool usedC = (want & 2) && !((int)n_corr < prm.num_min_corr_cost);   // iba_global.cpp:203
     uint4* fl = flist + ((size_t)b * nf + f) * (size_t)flist_stride;
     uint32_t* s_pos = s_list + K;        // per list item: matched scan point (tree position); aliases the 2nd half of best_d2
-    uint32_t* s_msk = s_best_idx;        // FLREG: per list item its covisible-slot mask (the winners were read before the barrier above)
+    uint32_t* s_msk = s_best_idx;        // Q > 0: per list item its covisible-slot mask (every winner was read before the barrier above)
     {
         const int sh = usedC ? 0 : 16;   // which of the two lists this evaluation builds
         n3 = (usedC || usedA) ? ((total >> sh) & 0xffffu) : 0u;
         uint32_t at = ((before + (incl - mine)) >> sh) & 0xffffu;   // entries of the threads before this one
-        if (usedC || usedA)
-            for (uint32_t g = 0; g < q && k0 + g < K; g += 4u) {
-                const uint4 bi = FLREG ? bi_keep : *(const uint4*)(s_best_idx + k0 + g), fl4 = FLREG ? rf : *(const uint4*)(s_kfl + k0 + g);
-                const uint32_t bv[4] = {bi.x, bi.y, bi.z, bi.w}, fv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
-                const uint32_t keep = usedC ? mC_keep : mA_keep;
-                uint32_t ip[4]; bool wk[4];
+        if ((usedC || usedA) && Q > 0) {
+            const uint32_t keep = usedC ? mC_keep : mA_keep;
+            uint32_t ip[QR];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {   // the four gathers are in flight together
-                    if (FLREG) wk[j] = ((keep >> j) & 1u) != 0u;
-                    else {
-                        const bool valid = k0 + g + (uint32_t)j < K && bv[j] != kNone;
-                        const uint32_t w = valid ? fv[j] : 0u;
-                        wk[j] = usedC ? w != 0u : (w & amask) == amask;
-                    }
-                    ip[j] = wk[j] ? inv_perm[bv[j]] : 0u;
+            for (int j = 0; j < QR; ++j) ip[j] = ((keep >> j) & 1u) ? inv_perm[bw[j]] : 0u;   // the gathers are in flight together
+#pragma unroll
+            for (int j = 0; j < QR; ++j)
+                if ((keep >> j) & 1u) { s_list[at] = kk[j] | ((ff[j] & 3u) << 16); s_pos[at] = ip[j]; s_msk[at] = ff[j] >> 2; ++at; }
+        } else if (usedC || usedA) {
+            for (uint32_t g = 0; g < q && e0 + g < Kw; g += 2u) {
+                const uint4 two = *(const uint4*)(fk + e0 + g);
+                const uint32_t k2[2] = {two.x, two.z}, f2[2] = {two.y, two.w};
+                uint32_t ip[2], bv2[2]; bool wk[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bv2[j] = e0 + g + (uint32_t)j < Kw ? s_best_idx[k2[j]] : kNone;
+                    const uint32_t w = bv2[j] != kNone ? f2[j] : 0u;
+                    wk[j] = usedC ? w != 0u : (w & amask) == amask;
+                    ip[j] = wk[j] ? inv_perm[bv2[j]] : 0u;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (wk[j]) { s_list[at] = (k0 + g + (uint32_t)j) | ((fv[j] & 3u) << 16); s_pos[at] = ip[j]; if (FLREG) s_msk[at] = fv[j] >> 2; ++at; }   // (not FLREG: the slot mask is read from s_kfl where it is needed)
+                for (int j = 0; j < 2; ++j)
+                    if (wk[j]) { s_list[at] = k2[j] | ((f2[j] & 3u) << 16); s_pos[at] = ip[j]; ++at; }   // (the slot mask is read from kp_fl where it is needed)
             }
+        }
     }
     __syncthreads();
     if (dbg == 6) return;
@@ -219,7 +233,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     if (usedC) {
         for (uint32_t i = tid; i < n3; i += kThreads) {
             const uint32_t k = s_list[i] & 0xffffu, pos = s_pos[i];
-            const uint32_t mask_lo = FLREG ? s_msk[i] : s_kfl[k] >> 2;
+            const uint32_t mask_lo = Q > 0 ? s_msk[i] : dp.kp_fl[h.kp_base + k] >> 2;
             const uint32_t mask_hi = (MANY && h.n_slots > (uint32_t)kCovisWord) ? dp.kp_fl2[h.kp_base + k] : 0u;   // (block-uniform: a frame with more than 30 covisible keyframes)
             if (!(mask_lo | mask_hi)) continue;
             float xf_, yf_, zf_; load_pt<true>(c, pos, xf_, yf_, zf_);
@@ -343,7 +357,6 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     uint32_t* s_cand = (uint32_t*)(smem + lay.off_cand);
     uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 after phase 2
     float2* s_kuv = (float2*)(smem + lay.off_kuv);            // (u, v) of every keypoint; keypoint ids are in grid-record order
-    uint32_t* s_kfl = (uint32_t*)(smem + lay.off_kfl);        // flag word of every keypoint: bit 0 MapPoint, bit 1 any covisible match, bits 2.. one per covisible slot
 
     const uint32_t P = h.P, Ppad = h.Ppad, K = h.K;
     const float* gxs = dp.xs + h.pt_base; const float* gys = dp.ys + h.pt_base; const float* gzs = dp.zs + h.pt_base;
@@ -361,24 +374,24 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     if (ut < nchunks) { blo_n = boxes[2 * (size_t)ut]; bhi_n = boxes[2 * (size_t)ut + 1]; }
     {
         const uint32_t* gbm = dp.bitmap + h.bitmap_base; const uint32_t* gcs = dp.coarse_start + h.coarse_base;
-        const float2* guv = dp.kp_uv + h.kp_base; const uint32_t* gfl = dp.kp_fl + h.kp_base;
-        uint32_t bw[8], cw[4], fw[4]; float2 uv[4];
+        const float2* guv = dp.kp_uv + h.kp_base;
+        uint32_t bw[8], cw[4]; float2 uv[4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; bw[j] = i < nbw ? gbm[i] : 0u; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; cw[j] = i < ncs ? gcs[i] : 0u; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; uv[j] = make_float2(0.f, 0.f); fw[j] = 0u; if (i < K) { uv[j] = guv[i]; fw[j] = gfl[i]; } }
+        for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; uv[j] = make_float2(0.f, 0.f); if (i < K) uv[j] = guv[i]; }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; if (i < nbw) s_bitmap[i] = bw[j]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; if (i < ncs) s_cstart[i] = (uint16_t)cw[j]; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; if (i < K) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = uv[j]; s_kfl[i] = fw[j]; } }
+        for (int j = 0; j < 4; ++j) { const uint32_t i = ut + (uint32_t)j * kThreads; if (i < K) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = uv[j]; } }
         // what the first batch did not cover (more than 2048 keypoints, a larger image)
         for (uint32_t i = ut + 8u * kThreads; i < nbw; i += kThreads) s_bitmap[i] = gbm[i];
         for (uint32_t i = ut + 4u * kThreads; i < ncs; i += kThreads) s_cstart[i] = (uint16_t)gcs[i];
-        for (uint32_t i = ut + 4u * kThreads; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = guv[i]; s_kfl[i] = gfl[i]; }
+        for (uint32_t i = ut + 4u * kThreads; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kuv[i] = guv[i]; }
     }
     if (ut < h.n_slots * 12u) s_rel[ut] = rv;
     for (uint32_t i = ut + kThreads; i < h.n_slots * 12u; i += kThreads) s_rel[i] = dp.slots[h.slot_base + i / 12u].rel[i % 12u];   // more than 42 covisible keyframes: beyond one store per thread
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     const int dbg = want >> 8;   // diagnostic: cut the kernel short after a phase (timing attribution; results are garbage)
     const bool refit = (want & 4) != 0;   // plane_cache = 0: the local planes are fitted after this kernel (iba_fit_kernel<.., 1>), which then settles .y and kFlagA
     if (dbg == 1) return;
+    uint32_t first = 0u;   // keypoints this thread was the first to reach with a point inside max_pixel_dist: their block sum is corrset.size() (see grid_match)
     FrameCtx c;
     c.xs = gxs; c.ys = gys; c.zs = gzs;
     c.nodes = nullptr; c.bitmap = s_bitmap; c.best_d2 = s_best_d2; c.best_idx = s_best_idx;
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
                     if (off[j] < cand_cap) s_cand[off[j]] = base + j;
                     else {   // queue full: exact path inline, full rescan in phase 2 (speed only)
                         double u, v;
-                        if (project_uv(c, px[j], py[j], pz[j], u, v)) grid_match<1>(c, u, v, base + j);
+                        if (project_uv(c, px[j], py[j], pz[j], u, v)) first += grid_match<1>(c, u, v, base + j);
                         s_misc[1] = 1u;
                     }
                 }
@@ -543,7 +557,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
             if (project_uv(c, pv.x, pv.y, pv.z, u, v)) {
                 const double du_ = (double)rec.x - u, dv_ = (double)rec.y - v;
                 const double d2 = du_ * du_ + dv_ * dv_;
-                if (d2 <= c.gate2) atomicMin(&s_best_d2[e], d2bits(d2));
+                if (d2 <= c.gate2) first += atomicMin(&s_best_d2[e], d2bits(d2)) == ~0ull ? 1u : 0u;
             }
             s_misc[1] = 1u;
         };
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
                 const float zc = fmaf(r6, pv.x, fmaf(r7, pv.y, fmaf(r8, pv.z, t2)));
                 if (!(zc > 0.1f)) {   // undecidable in f32 (queued by phase 1a for that reason): exact path inline; the point is noted for the tie pass
                     double u, v;
-                    if (project_uv(c, pv.x, pv.y, pv.z, u, v)) grid_match<1>(c, u, v, pos);
+                    if (project_uv(c, pv.x, pv.y, pv.z, u, v)) first += grid_match<1>(c, u, v, pos);
                     // (Rounds 2-3 raised the overflow flag here, and with it a rescan of EVERY scan point in f64 for the ties: a 360-degree
                     //  scan always has a few dozen points within 0.1 m of the camera plane, so every block rescanned — 255 of the kernel's
                     //  716 us on a box-wide batch, tools/wide_cuts.sh. Now only these points are walked again.)
@@ -624,7 +638,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
         if (project_uv(c, pv.x, pv.y, pv.z, u, v)) {
             const double du = (double)rec.x - u, dv = (double)rec.y - v;
             const double d2 = du * du + dv * dv;
-            if (d2 <= c.gate2) { k = pr.y; bits = d2bits(d2); atomicMin(&s_best_d2[k], bits); }
+            if (d2 <= c.gate2) { k = pr.y; bits = d2bits(d2); first += atomicMin(&s_best_d2[k], bits) == ~0ull ? 1u : 0u; }
         }
         s_pair[i] = make_uint4(__float_as_uint(pv.w), k, (uint32_t)bits, (uint32_t)(bits >> 32));
     }
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 
     if (dbg == 5) return;
     IBA_RELOAD();
-    assoc_tail<false>(ka, h, cd, c, s_best_idx, s_kfl, make_uint4(0u, 0u, 0u, 0u), s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride);
+    assoc_tail<0>(ka, h, cd, c, s_best_idx, make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride, first);
 #undef dp
 #undef prm
 #undef lay
@@ -979,7 +993,8 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
 // exact association of one scan point against the keypoint grid in GLOBAL memory (hard points, overflow rescans): grid_match
 // with the coarse CSR read through L2. PASS 1: ds_min_u64 on the keypoint's best d^2; PASS 2: ties -> lowest original index.
 template <int PASS>
-__device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* __restrict__ gcs, double u, double v, uint32_t pos) {
+__device__ __forceinline__ uint32_t grid_match_g(const FrameCtx& c, const uint32_t* __restrict__ gcs, double u, double v, uint32_t pos) {
+    uint32_t hit = 0u;   // (PASS 1) keypoints this point was the first to reach: see grid_match
     const float uf = (float)u, vf = (float)v;
     const int x0 = grid_cell(uf - c.margin, c.gw) >> kCoarseShift, x1 = grid_cell(uf + c.margin, c.gw) >> kCoarseShift;
     const int y0 = grid_cell(vf - c.margin, c.gh) >> kCoarseShift, y1 = grid_cell(vf + c.margin, c.gh) >> kCoarseShift;
@@ -992,11 +1007,12 @@ __device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* 
             const double d2 = du * du + dv * dv;
             if (d2 <= c.gate2) {
                 const uint32_t k = __float_as_uint(rec.z);
-                if (PASS == 1) atomicMin(&c.best_d2[k], d2bits(d2));
+                if (PASS == 1) hit += atomicMin(&c.best_d2[k], d2bits(d2)) == ~0ull ? 1u : 0u;
                 else if (c.best_d2[k] == d2bits(d2)) atomicMin(&c.best_idx[k], c.perm[pos]);
             }
         }
     }
+    return hit;
 }
 
 // iba_assoc2_kernel: one workgroup per (keyframe, candidate), as iba_assoc_kernel, with the first half replaced by the exact
@@ -1005,7 +1021,7 @@ __device__ __forceinline__ void grid_match_g(const FrameCtx& c, const uint32_t* 
 // LDS: 16 B per keypoint (best d^2, best index, flags) + the relative poses: ~33 KB at 2000 keypoints.
 constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
 constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
-template <bool FLREG, bool MANY>   // FLREG: the frame's keypoint flags never go through LDS (at most 2048 keypoints per frame; see assoc_tail); MANY: more than 30 covisible keyframes possible
+template <int Q, bool MANY>   // Q: flagged keypoints per thread that the tail keeps in registers (2: at most 1024 per frame, 4: at most 2048; 0: any number, read where needed; see assoc_tail); MANY: more than 30 covisible keyframes possible
 __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
                                                               uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
                                                               uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs_all, const uint32_t* __restrict__ hard_all,
@@ -1040,7 +1056,6 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
 
     unsigned long long* s_best_d2 = (unsigned long long*)(smem + lay.off_best_d2);
     uint32_t* s_best_idx = (uint32_t*)(smem + lay.off_best_idx);
-    uint32_t* s_kfl = (uint32_t*)(smem + lay.off_kfl);
     double* s_red = (double*)(smem + lay.off_red);
     double* s_rel = s_red + kWaves * 4;
     uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 once the winners are known
@@ -1051,20 +1066,21 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
 
     // ---- the counts of this frame's common lists, the first pairs of this thread, the tables ----
     const uint32_t* cnt = counts + (size_t)f * kCountStride;
-    uint4 rf = make_uint4(0u, 0u, 0u, 0u);
+    uint4 rfa = make_uint4(kNone, 0u, kNone, 0u), rfb = rfa;   // Q > 0: this thread's Q entries of the frame's flagged-keypoint list (keypoint, flag word)
+    uint32_t first = 0u;   // keypoints this thread is the first to reach (their block sum is corrset.size(): see grid_match)
     const bool overflow = cnt[2] != 0u;   // a list did not hold everything: every point again, exactly (speed only)
     const uint32_t npair = overflow ? 0u : min(cnt[0], (uint32_t)pair_cap), nhard = overflow ? 0u : min(cnt[1], (uint32_t)hard_cap);
     const float4* prq = (const float4*)(pairs + (size_t)f * (size_t)pair_cap);   // two 16-byte halves per record
     {
-        const uint32_t* gfl = dp.kp_fl + h.kp_base;
         double rv = 0.0;
         if (ut < h.n_slots * 12u) rv = dp.slots[h.slot_base + ut / 12].rel[ut % 12];
-        if (FLREG) {   // this thread's four flag words: in flight until the tail
-            const uint32_t k4 = ut * 4u;
-            rf.x = k4 < K ? gfl[k4] : 0u; rf.y = k4 + 1u < K ? gfl[k4 + 1u] : 0u; rf.z = k4 + 2u < K ? gfl[k4 + 2u] : 0u; rf.w = k4 + 3u < K ? gfl[k4 + 3u] : 0u;
-            for (uint32_t i = ut; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; }
-        } else
-        for (uint32_t i = ut; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; s_kfl[i] = gfl[i]; }
+        if (Q > 0) {   // this thread's list entries: in flight until the tail
+            const uint2* fk = dp.fkp + h.fk_base;
+            const uint32_t e0 = ut * (uint32_t)Q;
+            if (e0 < h.n_fk) rfa = *(const uint4*)(fk + e0);                    // (the lists are padded to four entries)
+            if (Q > 2 && e0 + 2u < h.n_fk) rfb = *(const uint4*)(fk + e0 + 2u);
+        }
+        for (uint32_t i = ut; i < K; i += kThreads) { s_best_d2[i] = ~0ull; s_best_idx[i] = kNone; }
         if (ut < h.n_slots * 12u) s_rel[ut] = rv;
         for (uint32_t i = ut + kThreads; i < h.n_slots * 12u; i += kThreads) s_rel[i] = dp.slots[h.slot_base + i / 12u].rel[i % 12u];   // more than 42 covisible keyframes: beyond one store per thread
         if (tid == 0) s_qn[0] = 0u;
@@ -1115,7 +1131,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         const uint32_t i = ut + (uint32_t)j * kThreads;
         const float4 a = na, q = nq;
         if (i + (uint32_t)kThreads < npair) { na = prq[2 * (size_t)(i + kThreads)]; nq = prq[2 * (size_t)(i + kThreads) + 1]; }
-        if (i < npair) { rb[j] = eval_loaded(a, q, rk[j], ri[j]); if (rk[j] != kNone) atomicMin(&s_best_d2[rk[j]], rb[j]); }
+        if (i < npair) { rb[j] = eval_loaded(a, q, rk[j], ri[j]); if (rk[j] != kNone) first += atomicMin(&s_best_d2[rk[j]], rb[j]) == ~0ull ? 1u : 0u; }
     }
     // pairs beyond the register window (a dense scan: 9 k pairs per keyframe at 120 k points): one that is at most the keypoint's best
     // so far MAY be the winner and is noted for the tie pass (a keypoint sees ~1.3 such pairs); the others cannot win any more
@@ -1129,7 +1145,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
             if (i < npair) {
                 uint32_t k, idx;
                 const unsigned long long bits = eval_loaded(a, q, k, idx);
-                if (k != kNone) note = bits <= atomicMin(&s_best_d2[k], bits);
+                if (k != kNone) { const unsigned long long was = atomicMin(&s_best_d2[k], bits); note = bits <= was; first += was == ~0ull ? 1u : 0u; }
             }
             const unsigned long long bal = __ballot(note);
             if (bal != 0ull) {
@@ -1144,11 +1160,11 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
     for (uint32_t i = ut; i < nhard; i += kThreads) {
         const uint32_t pos = hard[(size_t)f * (size_t)hard_cap + i];
         double u, v;
-        if (project_pos<true>(c, pos, u, v)) grid_match_g<1>(c, gcs, u, v, pos);
+        if (project_pos<true>(c, pos, u, v)) first += grid_match_g<1>(c, gcs, u, v, pos);
     }
     IBA_DIAG_COUNT(overflow && tid == 0, 0);
     if (overflow)
-        for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<1>(c, gcs, u, v, pos); }
+        for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) first += grid_match_g<1>(c, gcs, u, v, pos); }
     __syncthreads();
     if (dbg == 4) return;
     // ---- pass 2: the winner of each keypoint records its original index; exact ties -> lowest index ----
@@ -1181,7 +1197,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<2>(c, gcs, u, v, pos); }
     __syncthreads();
     if (dbg == 5) return;
-    assoc_tail<FLREG, MANY>(ka, h, cd, c, s_best_idx, s_kfl, rf, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride);
+    assoc_tail<Q, MANY>(ka, h, cd, c, s_best_idx, rfa, rfb, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride, first);
 #undef dp
 #undef prm
 #undef lay

@@ -80,7 +80,8 @@ struct FrameHdr {
     int32_t he_valid;     // global frame index < F-1
     int32_t global_frame;
     uint64_t mpk_base;    // offset into mpk[]: the keypoints of this frame that own a MapPoint (internal ids, ascending)
-    uint32_t n_mpk, pad_mpk;
+    uint32_t n_mpk, n_fk;  // n_fk: entries of the frame's flagged-keypoint list (r05)
+    uint64_t fk_base;     // offset into fkp[]: (keypoint id, flag word) of every keypoint that owns a MapPoint or has a covisible match, ascending ids (even offset: read two at a time)
 };
 
 struct SlotHdr {
