@@ -225,10 +225,10 @@ def main():
 
     for i in range(args.settle):
         out = step(i)
+    stage("settled")   # (no print, no allocation between the warm-up steps and the timed region: a write() to the log pipe right before t0 showed as a slow first region)
     for i in range(args.warmup):
         out = step(i)
     sync()
-    stage("warmup done")
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
@@ -258,22 +258,24 @@ def main():
     # ---- the same step with 512 candidates per call: ONE launch chain (one pair search, one anchor plan, one set of launches), every rank
     #      on its shard, one all-reduce of 512 x 64 doubles. Not the headline (an optimiser's poll is tens of candidates); what the path
     #      gives a caller that has that many — and what keeps a small shard's GPU full in a multi-GPU job. Same bracket as the headline. ----
-    xs_big = [np.vstack([xs_all[(k + j) % len(xs_all)] for j in range(BIG // B)]) for k in range(2)]
-    for i in range(3):
-        step(i, xs_big)
-    sync()
-    t0b = time.perf_counter()
-    n_big = max(4, args.steps // 2)
-    for i in range(n_big):
-        step(i, xs_big)
-    sync()
-    dt_big = time.perf_counter() - t0b
-    if use_dist:
-        tb_ = torch.tensor([dt_big], dtype=torch.float64, device=dev)
-        dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
-        dt_big = float(tb_.item())
-    for i in range(2):   # (the record's counts below come from the headline's candidates)
-        out = step(i)
+    #      (Skipped with --no-extras: a profiling run then sees launches of ONE shape.)
+    dt_big, n_big = None, max(4, args.steps // 2)
+    if not args.no_extras:
+        xs_big = [np.vstack([xs_all[(k + j) % len(xs_all)] for j in range(BIG // B)]) for k in range(2)]
+        for i in range(3):
+            step(i, xs_big)
+        sync()
+        t0b = time.perf_counter()
+        for i in range(n_big):
+            step(i, xs_big)
+        sync()
+        dt_big = time.perf_counter() - t0b
+        if use_dist:
+            tb_ = torch.tensor([dt_big], dtype=torch.float64, device=dev)
+            dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
+            dt_big = float(tb_.item())
+        for i in range(2):   # (the record's counts below come from the headline's candidates)
+            out = step(i)
 
     # ---- dominant kernels, timed with HIP events on their launch stream ----
     L = pkg.load_library()
@@ -380,8 +382,9 @@ def main():
         except Exception:
             pass
 
-    res["large_batch"] = {"candidates_per_step": BIG, "steps": n_big, "ms_per_step": dt_big / n_big * 1e3, "evals_per_s": BIG * n_big / dt_big,
-                          "note": "512 candidates per call = one launch chain; same scene, same candidate spread, same bracket (barrier + synchronize on both sides, max over ranks) as the headline, which stays at 64 per step"}
+    if dt_big is not None:
+        res["large_batch"] = {"candidates_per_step": BIG, "steps": n_big, "ms_per_step": dt_big / n_big * 1e3, "evals_per_s": BIG * n_big / dt_big,
+                              "note": "512 candidates per call = one launch chain; same scene, same candidate spread, same bracket (barrier + synchronize on both sides, max over ranks) as the headline, which stays at 64 per step"}
     if group_mode:
         res["config"]["group_issue_us_last_call"] = grp.last_issue_us
     if not args.no_extras and group_mode:
