@@ -752,8 +752,10 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         else if (aq == 4) launch_assoc2(std::integral_constant<int, 4>{});
         else launch_assoc2(std::integral_constant<int, 0>{});
     } else {
-    hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * per_xcd * B + head_blocks), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
-                       h->d_frame_partials.p, nrec, (uint32_t*)nullptr, fl, fc, lc, (int)h->lstride, a_src, (uint4*)dc, a_n16);
+    auto go1 = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B + head_blocks), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+                       h->d_frame_partials.p, nrec, (uint32_t*)nullptr, fl, fc, lc, (int)h->lstride, a_src, (uint4*)dc, a_n16); };
+    const int aq1 = assoc2_q(h);
+    if (aq1 == 2) go1(iba_assoc_kernel<2>); else if (aq1 == 4) go1(iba_assoc_kernel<4>); else go1(iba_assoc_kernel<0>);
     }
     head_open = false;
     HIP_TRY(h, hipGetLastError());
@@ -1148,7 +1150,8 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
     for (int i = 0; i < kRing; ++i) if ((er = hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", er);
     // > 64 KB of dynamic LDS must be opted into per kernel
-    if ((er = hipFuncSetAttribute((const void*)iba_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    for (const void* fn : {(const void*)iba_assoc_kernel<0>, (const void*)iba_assoc_kernel<2>, (const void*)iba_assoc_kernel<4>})
+        if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     {
         const void* a2[6] = {(const void*)iba_assoc2_kernel<2, false>, (const void*)iba_assoc2_kernel<2, true>, (const void*)iba_assoc2_kernel<4, false>, (const void*)iba_assoc2_kernel<4, true>,
@@ -1271,7 +1274,7 @@ iba_status iba_get_correspondences(iba_handle* h, const double* x, int32_t frame
     { iba_status es = ensure_lists(h, 1, h->stream); if (es != IBA_OK) return es; }
     iba_status s = stage_cands(h, x, 1, h->stream, &dc); if (s != IBA_OK) return s;
     {
-        hipLaunchKernelGGL(iba_assoc_kernel, dim3(8 * ((h->n_frames + 7) / 8)), dim3(kThreads), h->alay.total, h->stream, KArgs{h->dev_problem(), h->dprm, h->alay}, dc, 1, 0,
+        hipLaunchKernelGGL(iba_assoc_kernel<0>, dim3(8 * ((h->n_frames + 7) / 8)), dim3(kThreads), h->alay.total, h->stream, KArgs{h->dev_problem(), h->dprm, h->alay}, dc, 1, 0,
                            h->d_frame_partials.p, h->n_frames, h->d_corr.p, h->d_flist_frozen.p, h->d_fcount_frozen.p, h->d_lcount_frozen.p, (int)h->lstride, (const uint4*)nullptr, (uint4*)nullptr, 0u);
         HIP_TRY(h, hipGetLastError());
     }

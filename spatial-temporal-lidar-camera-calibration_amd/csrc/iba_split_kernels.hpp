@@ -320,6 +320,7 @@ constexpr uint32_t kHeadBlocks = 16;   // spare workgroups appended to an associ
 #else
 #define IBA_ASSOC_ATTR
 #endif
+template <int Q>   // flagged keypoints per thread that the tail keeps in registers (2, 4; 0: any number): see assoc_tail
 __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArgs ka_by_value, const Cand* __restrict__ cands, int B, int want,
                                                              double* __restrict__ frame_partials, int nrec, uint32_t* __restrict__ corr_out,
                                                              uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
@@ -402,6 +403,13 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
     const bool refit = (want & 4) != 0;   // plane_cache = 0: the local planes are fitted after this kernel (iba_fit_kernel<.., 1>), which then settles .y and kFlagA
     if (dbg == 1) return;
     uint32_t first = 0u;   // keypoints this thread was the first to reach with a point inside max_pixel_dist: their block sum is corrset.size() (see grid_match)
+    uint4 rfa = make_uint4(kNone, 0u, kNone, 0u), rfb = rfa;   // Q > 0: this thread's Q entries of the frame's flagged-keypoint list, in flight until the tail
+    if (Q > 0) {
+        const uint2* fk = dp.fkp + h.fk_base;
+        const uint32_t e0 = ut * (uint32_t)Q;
+        if (e0 < h.n_fk) rfa = *(const uint4*)(fk + e0);
+        if (Q > 2 && e0 + 2u < h.n_fk) rfb = *(const uint4*)(fk + e0 + 2u);
+    }
     FrameCtx c;
     c.xs = gxs; c.ys = gys; c.zs = gzs;
     c.nodes = nullptr; c.bitmap = s_bitmap; c.best_d2 = s_best_d2; c.best_idx = s_best_idx;
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(kThreads) IBA_ASSOC_ATTR void iba_assoc_kernel(KArg
 
     if (dbg == 5) return;
     IBA_RELOAD();
-    assoc_tail<0>(ka, h, cd, c, s_best_idx, make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride, first);
+    assoc_tail<Q>(ka, h, cd, c, s_best_idx, rfa, rfb, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride, first);
 #undef dp
 #undef prm
 #undef lay
