@@ -84,6 +84,39 @@ def knn_gpu_fixtures():
     print("wrote knn_nanoflann_v150_gpu.npz;", int((d22[:, 0] <= 2.25).sum()), "of", nk, "keypoints within max_pixel_dist")
 
 
+def knn_big_fixture():
+    """A KITTI-sized scan for the device searches (deep tree, leaves of the size the real scans give): 40 000 float32 points of the
+    synthetic street scene — REGENERATED from its seed by the test (numpy is deterministic: the points are not stored, only a hash of
+    them) — and, from the reference's nanoflann (leaf 30): kNN(30) around 1000 of its points and the 1-NN of 3000 arbitrary queries.
+    Only the INDICES are stored (u16): every squared distance is re-derived from them with the reference's expression, after this
+    script has checked that doing so reproduces nanoflann's own d^2 bit for bit."""
+    import hashlib
+    from oracle import binding as ob
+    synth = importlib.import_module(PKG + ".synth")
+    assert ob.ref_lib() is not None
+    prob, _ = synth.make_scene(n_frames=1, pts_per_frame=40000, n_keypoints=200, seed=11, new_mappoints=10, scan_kp=20)
+    pts = prob.frame_points(0).astype(np.float32)
+    n = len(pts)
+    assert n < 65536 and len(np.unique(pts, axis=0)) == n
+    p64 = pts.astype(np.float64)
+    rng = np.random.default_rng(20251004)
+    sel = np.sort(rng.choice(n, 1000, replace=False))
+    idx, d2, cnt = ob.knn("ref", 3, p64, 30, p64[sel], 30)
+    assert np.all(cnt == 30)
+    dd = p64[sel][:, None, :] - p64[idx.astype(np.int64)]
+    assert np.array_equal((dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2], d2)       # d^2 follows from the indices, bit for bit
+    assert not np.any(d2[:, 1:] == d2[:, :-1])                                                                    # no exact tie inside a list
+    lo, hi = p64.min(0), p64.max(0)
+    q = np.vstack([p64[rng.choice(n, 1500)] + rng.normal(0, 0.05, (1500, 3)), rng.uniform(lo - 2, hi + 2, (1500, 3))])
+    i1, d1, _ = ob.knn("ref", 3, p64, 30, q, 1)
+    d1b = q - p64[i1[:, 0].astype(np.int64)]
+    assert np.array_equal((d1b[:, 0] * d1b[:, 0] + d1b[:, 1] * d1b[:, 1]) + d1b[:, 2] * d1b[:, 2], d1[:, 0])
+    out = {"scene": np.array([1, 40000, 200, 11, 10, 20]), "pts_sha256": np.frombuffer(hashlib.sha256(pts.tobytes()).digest(), np.uint8),
+           "self_sel": sel.astype(np.uint16), "self_k30_idx": idx.astype(np.uint16), "q_seed": np.array([20251004]), "q": q.astype(np.float64), "q_k1_idx": i1[:, 0].astype(np.uint16)}
+    np.savez_compressed(os.path.join(HERE, "knn_nanoflann_v150_big.npz"), **out)
+    print("wrote knn_nanoflann_v150_big.npz: %d points, %d x 30 + %d x 1 indices" % (n, len(sel), len(q)))
+
+
 def path_fixtures():
     """Small scene + the oracle's outputs on it (regression pin of the restated path)."""
     synth = importlib.import_module(PKG + ".synth")
@@ -114,6 +147,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "gpu":   # only the fixtures added in round 5 (the others are not regenerated)
         knn_gpu_fixtures()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        knn_big_fixture()
+        sys.exit(0)
     knn_fixtures()
     knn_gpu_fixtures()
+    knn_big_fixture()
     path_fixtures()

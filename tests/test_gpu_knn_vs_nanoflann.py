@@ -140,3 +140,36 @@ def test_duplicate_points_are_the_only_deviation(pkg, abi):
     assert np.array_equal(gd, d2.min(1))
     assert np.array_equal(gi, np.argmin(d2, axis=1).astype(np.uint32)) and np.all(gi < 100)   # the LOWER of the two duplicates
     h.close()
+
+
+def _big_fixture(synth):
+    import hashlib
+    z = np.load(os.path.join(HERE, "golden", "knn_nanoflann_v150_big.npz"))
+    nf, ppf, nk, seed, nm, sk = (int(v) for v in z["scene"])
+    prob, _ = synth.make_scene(n_frames=nf, pts_per_frame=ppf, n_keypoints=nk, seed=seed, new_mappoints=nm, scan_kp=sk)
+    pts = prob.frame_points(0).astype(np.float32)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(pts.tobytes()).digest(), np.uint8), z["pts_sha256"]), "the scene generator no longer reproduces the fixture's scan"
+    return z, pts
+
+
+def test_device_searches_on_a_kitti_sized_scan_equal_nanoflann(pkg, synth, abi):
+    """A scan of KITTI's size class (40 000 points: the deepest tree the builder makes, leaves of 19-20 points) — regenerated from its seed,
+    hashed against the fixture — under the device's kd search (k = 1, 3000 arbitrary queries) and the plane fits' list builder (kNN(30)
+    around 1000 of its points) against the reference's nanoflann: indices bit-equal; every d^2 equals the one re-derived from nanoflann's
+    indices with the reference's expression (tests/golden/make_golden.py checked that this reproduces nanoflann's own d^2 bit for bit)."""
+    z, pts = _big_fixture(synth)
+    p64 = pts.astype(np.float64)
+    h = pkg.IbaHandle(_one_frame_problem(abi, pts), abi.reference_yaml_params())
+    q, ref_i = z["q"], z["q_k1_idx"].astype(np.uint32)
+    d = q - p64[ref_i.astype(np.int64)]
+    ref_d = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    for mode in (1, 2, 3, 4):
+        gi, gd = h.debug_nn(0, q, mode)
+        assert np.array_equal(gi, ref_i), (mode, np.flatnonzero(gi != ref_i)[:5])
+        assert np.array_equal(gd, ref_d), mode
+    sel, ref_l = z["self_sel"].astype(np.uint32), z["self_k30_idx"].astype(np.uint32)
+    gi, gd, gc = h.debug_knn(0, sel, k=30)
+    assert np.all(gc == 30) and np.array_equal(gi, ref_l), np.flatnonzero(np.any(gi != ref_l, axis=1))[:5]
+    dd = p64[sel.astype(np.int64)][:, None, :] - p64[ref_l.astype(np.int64)]
+    assert np.array_equal(gd, (dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2])
+    h.close()

@@ -55,3 +55,19 @@ def test_knn_empty_and_tiny(ob):
     assert np.all(cnt == 0)
     idx, d2, cnt = ob.knn("oracle", 2, np.array([[1.0, 2.0], [3.0, 4.0]]), 10, np.array([[0.0, 0.0]]), 5)
     assert cnt[0] == 2 and list(idx[0][:2]) == [0, 1] and d2[0][0] == 5.0
+
+
+def test_oracle_knn_on_the_kitti_sized_fixture(ob, synth):
+    """tests/golden/knn_nanoflann_v150_big.npz (round 5): nanoflann's kNN(30) / 1-NN INDICES on a 40 000-point scan that is regenerated from its
+    seed (hash-checked). The restated tree must return the same indices; the GPU tier runs the device searches against the same file."""
+    import hashlib
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_nanoflann_v150_big.npz"))
+    nf, ppf, nk, seed, nm, sk = (int(v) for v in z["scene"])
+    prob, _ = synth.make_scene(n_frames=nf, pts_per_frame=ppf, n_keypoints=nk, seed=seed, new_mappoints=nm, scan_kp=sk)
+    pts = prob.frame_points(0).astype(np.float32)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(pts.tobytes()).digest(), np.uint8), z["pts_sha256"])
+    p64 = pts.astype(np.float64)
+    idx, d2, cnt = ob.knn("oracle", 3, p64, 30, p64[z["self_sel"].astype(np.int64)], 30)
+    assert np.all(cnt == 30) and np.array_equal(idx, z["self_k30_idx"].astype(np.uint32))
+    i1, d1, _ = ob.knn("oracle", 3, p64, 30, z["q"], 1)
+    assert np.array_equal(i1[:, 0], z["q_k1_idx"].astype(np.uint32))
