@@ -118,6 +118,12 @@ iba_status iba_mads_selftest_trace(int32_t problem, const double* x0, const iba_
  * library's tree (nanoflann keeps its own tree's): only exact ties can differ from the reference's lists. */
 iba_status iba_debug_knn(iba_handle* h, int32_t frame, const uint32_t* points, int32_t n, int32_t k, double r2, uint32_t* out_idx, double* out_d2, int32_t* out_cnt);
 
+/* debug: the kernels' shared-reciprocal division (two quotients by one depth: csrc/iba_kernels.hpp, div2) beside the compiler's IEEE f64
+ * division, on n operand triples from the caller, on `device`. q0/q1 = num0/den, num1/den as the projections compute them, ref0/ref1 = as
+ * the plain division does; *n_fast = triples that took the shared-reciprocal path (the others fall back to the plain division inside). The
+ * two must agree bit for bit on every operand (tests/test_gpu_division.py; iba_global.cpp:70-75, :308-313 are the divisions they stand for). */
+iba_status iba_debug_div2_selftest(int32_t device, const double* num0, const double* num1, const double* den, int64_t n, double* q0, double* q1, double* ref0, double* ref1, int64_t* n_fast);
+
 #ifdef __cplusplus
 }
 #endif

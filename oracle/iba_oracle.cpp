@@ -753,9 +753,9 @@ static void plane_block_kernel_order(const Factor& f, const double* R, const dou
         const double t3[3] = {f.t[i].x, f.t[i].y, f.t[i].z};
         const double tx = t3[0] * s, ty = t3[1] * s, tz = t3[2] * s;
         const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx, P1y = ((rel[3] * P0x + rel[4] * P0y) + rel[5] * P0z) + ty, P1z = ((rel[6] * P0x + rel[7] * P0y) + rel[8] * P0z) + tz;
-        const double ru = (f.fx * P1x / P1z + f.cx) - f.u1[i], rv = (f.fy * P1y / P1z + f.cy) - f.v1[i];
+        const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;   // (round 5: the kernel forms the residual from the same reciprocal as its derivatives)
+        const double ru = (f.fx * xz + f.cx) - f.u1[i], rv = (f.fy * yz + f.cy) - f.v1[i];
         const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[3] * Cxz + rel[4] * Cyz) + rel[5], az = (rel[6] * Cxz + rel[7] * Cyz) + rel[8];
-        const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
         double cu, cv;
         if (variant == 0) { cu = ax - xz * az; cv = ay - yz * az; }
         else { cu = (ax * tz - az * tx) * iz; cv = (ay * tz - az * ty) * iz; }   // P1 = Z0 a + s t  =>  ax - (P1x / P1z) az = (ax tz - az tx) / P1z exactly

@@ -514,6 +514,21 @@ def debug_cand(x):
     return out
 
 
+def debug_div2_selftest(num0, num1, den, device=0):
+    """(q0, q1, ref0, ref1, n_fast): num0 / den and num1 / den as the kernels' shared-reciprocal division computes them, as the compiler's
+    f64 division does, and how many triples took the shared-reciprocal path (include/iba_mi355x_debug.h)."""
+    L = load_library()
+    a, b, d = (np.ascontiguousarray(v, np.float64).reshape(-1) for v in (num0, num1, den))
+    assert len(a) == len(b) == len(d)
+    out = [np.zeros(len(a)) for _ in range(4)]
+    nf = C.c_int64(0)
+    L.iba_debug_div2_selftest.argtypes = [C.c_int32] + [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 4 + [C.POINTER(C.c_int64)]
+    st = L.iba_debug_div2_selftest(C.c_int32(device), _p(a), _p(b), _p(d), C.c_int64(len(a)), *[_p(o) for o in out], C.byref(nf))
+    if st != 0:
+        raise IbaError(st, "iba_debug_div2_selftest")
+    return out[0], out[1], out[2], out[3], nf.value
+
+
 def mads_selftest(problem, x0, trace=False, **opts):
     """The MADS driver on a built-in analytic black box (host only, no GPU). trace=True also returns the evaluated points."""
     L = load_library()

@@ -1421,6 +1421,33 @@ iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n
     return IBA_OK;
 }
 
+// debug: div2 (the projections' two quotients by one depth, iba_kernels.hpp) beside the compiler's f64 division, on the caller's operands
+iba_status iba_debug_div2_selftest(int32_t device, const double* num0, const double* num1, const double* den, int64_t n, double* q0, double* q1, double* ref0, double* ref1, int64_t* n_fast) {
+    if (!num0 || !num1 || !den || !q0 || !q1 || !ref0 || !ref1 || !n_fast || n < 1 || n > (1ll << 28)) return fail(nullptr, IBA_ERR_INVALID_ARG, "bad arguments");
+    hipError_t er = hipSetDevice(device);
+    if (er != hipSuccess) return fail(nullptr, IBA_ERR_HIP, hipGetErrorString(er));
+    DevBuf<double> d[7]; DevBuf<unsigned long long> dn;
+    for (auto& b : d) if (er == hipSuccess) er = b.alloc((size_t)n);
+    if (er == hipSuccess) er = dn.alloc(1);
+    const double* src[3] = {num0, num1, den};
+    for (int i = 0; i < 3 && er == hipSuccess; ++i) er = hipMemcpy(d[i].p, src[i], sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemset(dn.p, 0, sizeof(unsigned long long));
+    if (er == hipSuccess) {
+        hipLaunchKernelGGL(iba_div2_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d[0].p, d[1].p, d[2].p, (long long)n, d[3].p, d[4].p, d[5].p, d[6].p, dn.p);
+        er = hipGetLastError();
+    }
+    if (er == hipSuccess) er = hipDeviceSynchronize();
+    double* dst[4] = {q0, q1, ref0, ref1};
+    for (int i = 0; i < 4 && er == hipSuccess; ++i) er = hipMemcpy(dst[i], d[3 + i].p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+    unsigned long long nf = 0;
+    if (er == hipSuccess) er = hipMemcpy(&nf, dn.p, sizeof(nf), hipMemcpyDeviceToHost);
+    for (auto& b : d) b.release();
+    dn.release();
+    if (er != hipSuccess) return fail(nullptr, IBA_ERR_HIP, hipGetErrorString(er));
+    *n_fast = (int64_t)nf;
+    return IBA_OK;
+}
+
 // debug: the kNN lists of the plane fits (fit_list_rows, the list builder of iba_plane_kernel / iba_fit_kernel) around n scan points
 // (ORIGINAL indices) of a local frame: up to k neighbours with d^2 < r2 each, nearest first (the point itself first, at 0)
 iba_status iba_debug_knn(iba_handle* h, int32_t frame, const uint32_t* points, int32_t n, int32_t k, double r2, uint32_t* out_idx, double* out_d2, int32_t* out_cnt) {

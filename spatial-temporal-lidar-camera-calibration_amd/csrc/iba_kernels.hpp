@@ -536,6 +536,48 @@ struct FrameCtx {   // wave-uniform per-block context
     double R[9], t[3];
 };
 
+// ---- two IEEE quotients by ONE denominator (round 5) ----
+// A pinhole projection divides twice by the same depth. The compiler's f64 division (LLVM AMDGPU LowerFDIV64) is, per quotient,
+//   s0 = div_scale(den), s1 = div_scale(num); r = rcp(s0); two Newton steps on r (4 fma); q0 = s1 r; e = fma(-s0, q0, s1);
+//   q = div_fmas(e, r, q0); div_fixup
+// i.e. 11 instructions, one of them (v_rcp_f64) quarter rate, of which everything up to the refined reciprocal depends on the denominator
+// alone. div2 computes that reciprocal once and the last three steps per numerator — the same operations on the same values, so the same,
+// correctly rounded, quotients — WITHOUT the scaling steps, which is exact only while no intermediate leaves the normal range:
+//   2^-100 <= |den| < 2^100 (checked first: the reciprocal and its refinement are then plain normal arithmetic), and
+//   |quotient| >= 2^-700 (checked afterwards: then |num| = |q den| >= 2^-801, and the remainder e ~ 2^-53 num is not denormal);
+//   upwards nothing can go wrong that the true quotient does not share (q0 overflows only if the quotient itself is beyond 2^1023).
+// Anything else — zero, denormal, huge, NaN — takes the compiler's division. tests/test_gpu_division.py (through the debug entry
+// iba_debug_div2_selftest) compares the two bit for bit over random and edge-case operands.
+__device__ __forceinline__ void div2(const double n0, const double n1, const double den, double& q0, double& q1) {
+    const uint32_t hi = (uint32_t)__double2hiint(den) & 0x7fffffffu;
+    bool ok = (hi - 0x39b00000u) < (0x46300000u - 0x39b00000u);   // exponent field in [1023 - 100, 1023 + 100)
+    if (ok) {
+        const double r0 = __builtin_amdgcn_rcp(den);
+        const double e0 = __builtin_fma(-den, r0, 1.0);
+        const double r1 = __builtin_fma(r0, e0, r0);
+        const double e1 = __builtin_fma(-den, r1, 1.0);
+        const double r = __builtin_fma(r1, e1, r1);
+        const double a0 = n0 * r, a1 = n1 * r;
+        q0 = __builtin_fma(__builtin_fma(-den, a0, n0), r, a0);
+        q1 = __builtin_fma(__builtin_fma(-den, a1, n1), r, a1);
+        ok = fabs(q0) >= 0x1p-700 && fabs(q1) >= 0x1p-700;   // (NaN: not ok)
+    }
+    if (!ok) { q0 = n0 / den; q1 = n1 / den; }
+}
+
+// debug (iba_debug_div2_selftest): div2 beside the compiler's division on operands from the host; fast[i] = the denominator passed div2's first test
+__global__ __launch_bounds__(256) void iba_div2_selftest_kernel(const double* __restrict__ n0, const double* __restrict__ n1, const double* __restrict__ den, long long n,
+                                                                double* __restrict__ q0, double* __restrict__ q1, double* __restrict__ r0, double* __restrict__ r1, unsigned long long* __restrict__ n_fast) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a, b;
+    div2(n0[i], n1[i], den[i], a, b);
+    q0[i] = a; q1[i] = b;
+    r0[i] = n0[i] / den[i]; r1[i] = n1[i] / den[i];
+    const uint32_t hi = (uint32_t)__double2hiint(den[i]) & 0x7fffffffu;
+    if ((hi - 0x39b00000u) < (0x46300000u - 0x39b00000u) && fabs(a) >= 0x1p-700 && fabs(b) >= 0x1p-700) atomicAdd(n_fast, 1ull);
+}
+
 // K1+K2: Tcl*p (pointcloud.h:82-86), pinhole projection and FOV cull (iba_global.cpp:68-81) for one scan point
 __device__ __forceinline__ bool project_uv(const FrameCtx& c, float xf, float yf, float zf, double& u, double& v) {
     const double x = (double)xf, y = (double)yf, z = (double)zf;
@@ -543,8 +585,7 @@ __device__ __forceinline__ bool project_uv(const FrameCtx& c, float xf, float yf
     const double pcy = ((c.R[3] * x + c.R[4] * y) + c.R[5] * z) + c.t[1];
     const double pcz = ((c.R[6] * x + c.R[7] * y) + c.R[8] * z) + c.t[2];
     if (!(pcz > 0)) return false;
-    u = (c.fx * pcx + c.cx * pcz) / pcz;
-    v = (c.fx * pcy + c.cy * pcz) / pcz;   // fx on purpose: iba_global.cpp:73
+    div2(c.fx * pcx + c.cx * pcz, c.fx * pcy + c.cy * pcz, pcz, u, v);   // (K p) / z; fx for both on purpose: iba_global.cpp:73
     return 0 <= u && u < c.W && 0 <= v && v < c.H;
 }
 // one scan point by tree position, where the lanes of a wave ask for unrelated positions: one 16 B gather instead of three
@@ -748,10 +789,12 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
             const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx;
             const double P1y = ((rel[4] * P0x + rel[5] * P0y) + rel[6] * P0z) + ty;
             const double P1z = ((rel[8] * P0x + rel[9] * P0y) + rel[10] * P0z) + tz;
-            const double ru = (h.fx * P1x / P1z + h.cx) - (double)m.x;
-            const double rv = (h.fy * P1y / P1z + h.cy) - (double)m.y;
-            const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[4] * Cxz + rel[5] * Cyz) + rel[6], az = (rel[8] * Cxz + rel[9] * Cyz) + rel[10];
+            // (one reciprocal for the residual and its derivatives: the Jacobian path carries a relative budget, not bit parity — round 5: the
+            //  two quotients fx P1x / P1z, fy P1y / P1z were divisions of their own, 11 instructions each)
             const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
+            const double ru = (h.fx * xz + h.cx) - (double)m.x;
+            const double rv = (h.fy * yz + h.cy) - (double)m.y;
+            const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[4] * Cxz + rel[5] * Cyz) + rel[6], az = (rel[8] * Cxz + rel[9] * Cyz) + rel[10];
             const double gu = h.fx * iz * (ax - xz * az), gv = h.fy * iz * (ay - yz * az);
             const double hu = h.fx * iz * (rel[3] - xz * rel[11]), hv = h.fy * iz * (rel[7] - yz * rel[11]);
             slot(ru, rv, gu, gv, hu, hv);
@@ -822,9 +865,9 @@ __device__ __forceinline__ int test_edge_core(const Cand& c, const FrameHdr& h, 
             const double P1x = ((rel[0] * p0c[0] + rel[1] * p0c[1]) + rel[2] * p0c[2]) + tx;
             const double P1y = ((rel[4] * p0c[0] + rel[5] * p0c[1]) + rel[6] * p0c[2]) + ty;
             const double P1z = ((rel[8] * p0c[0] + rel[9] * p0c[1]) + rel[10] * p0c[2]) + tz;
-            const double ru = (h.fx * P1x / P1z + h.cx) - (double)m.x;
-            const double rv = (h.fy * P1y / P1z + h.cy) - (double)m.y;
-            const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
+            const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;   // (one reciprocal: see plane_factor_core)
+            const double ru = (h.fx * xz + h.cx) - (double)m.x;
+            const double rv = (h.fy * yz + h.cy) - (double)m.y;
             double Ju[7], Jv[7];
             for (int kk = 0; kk < 6; ++kk) {
                 const double qx = (rel[0] * dq[kk][0] + rel[1] * dq[kk][1]) + rel[2] * dq[kk][2];

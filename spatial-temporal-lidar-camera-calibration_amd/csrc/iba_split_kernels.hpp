@@ -257,8 +257,9 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
                     const double p1x = ((rel[0] * p0x + rel[1] * p0y) + rel[2] * p0z) + rel[3] * s;
                     const double p1y = ((rel[4] * p0x + rel[5] * p0y) + rel[6] * p0z) + rel[7] * s;
                     const double p1z = ((rel[8] * p0x + rel[9] * p0y) + rel[10] * p0z) + rel[11] * s;
-                    const double ou = h.fx * p1x / p1z + h.cx;
-                    const double ov = h.fy * p1y / p1z + h.cy;
+                    double qu, qv;
+                    div2(h.fx * p1x, h.fy * p1y, p1z, qu, qv);
+                    const double ou = qu + h.cx, ov = qv + h.cy;
                     if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
                     const double eu = ou - (double)cur.x, ev = ov - (double)cur.y;
                     const double dist = sqrt(eu * eu + ev * ev);
