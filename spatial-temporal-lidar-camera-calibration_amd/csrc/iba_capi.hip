@@ -72,6 +72,7 @@ struct iba_handle {
     int nn_dbg = 0;                       // IBA_NN_DBG: cut the search kernel short (timing attribution; results are garbage)
     int nn_cg_max = 8;                    // candidates per search block (power of two <= kMaxGroup)
     bool nn_cg_fixed = false;             // IBA_NN_CG given: no adaptation to the batch size
+    bool nn_rounds = true;                // IBA_NN_ROUNDS=0: the entries the anchored lists leave over are searched leaf by leaf (rounds 3-4) instead of in rounds of leaves
     DevBuf<uint32_t> d_lcount, d_lcount_frozen;   // work-list length per (candidate, frame)
     uint32_t max_slots = 0;               // covisible keyframes of the busiest frame
     uint32_t lstride = 1;                 // entries per (candidate, frame) row of the lists: no list is longer than maxKw
@@ -771,7 +772,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         const int he_blocks = (want & 2) ? (B * nf + kNNThreads / 2 - 1) / (kNNThreads / 2) : 0;
         he_in_search = he_blocks > 0;
         const dim3 grid(8 * per_xcd * ngroups * NS + ((he_blocks + 7) & ~7)), block(kNNThreads);
-        NNArgs na{dp, h->dprm, nl, (unsigned long long)(h->anchor_set_elems * sizeof(SetPt)), {0}};
+        NNArgs na{dp, h->dprm, nl, (unsigned long long)(h->anchor_set_elems * sizeof(SetPt)), h->nn_rounds ? 1u : 0u, {0}};
         std::memcpy(na.anchor_sel, h->anchor_sel, sizeof(na.anchor_sel));
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
         const SetPt* anchor = sets ? h->d_anchor.p : nullptr;
@@ -1076,6 +1077,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     h->pair_memo_max_b = opt.pair_memo_max_batch; h->pair_infl = opt.pair_inflation; h->nn_sets = opt.anchored_lists != 0; h->anchor_reach = opt.anchor_reach;
     h->spin_wait = opt.spin_wait != 0; h->factor_valu = opt.factor_mfma == 0;
     h->chain_fold = opt.chain_fold != 0; h->chain_cap = opt.max_chain_batch;
+    if (const char* e = std::getenv("IBA_NN_ROUNDS")) h->nn_rounds = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_NN_CG")) { h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e))); h->nn_cg_fixed = true; }
     if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);

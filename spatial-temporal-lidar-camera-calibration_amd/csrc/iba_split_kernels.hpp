@@ -46,6 +46,9 @@ constexpr int kCdDoubles = 14;   // per candidate in LDS: s, Ri[9], ti[3], (s32,
 #ifndef IBA_NN_WAVES
 #define IBA_NN_WAVES 5   /* waves per SIMD the search kernel is compiled for (<= 96 VGPRs) */
 #endif
+#ifndef IBA_NN_ROUND_LEAVES
+#define IBA_NN_ROUND_LEAVES 8   /* leaves a group of lanes walks to before it scans them together (wave_nn_round) */
+#endif
 #ifndef IBA_NN_LEAF_BATCH
 #define IBA_NN_LEAF_BATCH 4   /* points of a leaf scan whose loads are in flight together */
 #endif
@@ -58,6 +61,7 @@ struct NNArgs {
     // which set of anchored neighbour lists each candidate of the batch reads (255: none — its lanes search the tree), and the
     // distance in bytes between two sets
     unsigned long long anchor_set_bytes;
+    uint32_t nn_rounds;   // the entries the lists leave over are searched in rounds of leaves (wave_nn_round; 0: leaf by leaf, wave_nn_visit)
     uint8_t anchor_sel[kMaxChain];
 };
 
@@ -1490,6 +1494,148 @@ __device__ __forceinline__ void wave_nn_visit(IBA_LANE_NN_PARAMS, const int lane
     }
 }
 
+// ---- ROUNDS of leaves (round 5). A left-over entry starts from a good bound (the nearest LISTED point: seed), so its search seldom
+//      improves the bound — it has to LOOK into every leaf the ball of that radius reaches (24 and more for a MapPoint 2 m in front
+//      of a wall at 120 k points per scan), and wave_nn_visit pays three dependent round trips per leaf (the leaf's points, the exact
+//      confirmation, the walk to the next leaf). Here the group first walks on, WITHOUT looking, to the next leaves the current bound
+//      reaches (LDS only: the nodes), then scans them together — the loads of two leaves in flight at a time — and confirms once. A
+//      stale bound can only add leaves; the result (least d^2, ties to the lowest original index) does not depend on the leaves'
+//      order or on looking into one too many. s_leaf: round_cap <= kRoundLeaves words of LDS of this group. ----
+constexpr int kRoundLeaves = IBA_NN_ROUND_LEAVES;
+template <int WHICH>
+__device__ __forceinline__ void wave_nn_round(IBA_LANE_NN_PARAMS, const int lane, const int G, const TreeNode* s_nodes, const float4* __restrict__ p4, const uint32_t* __restrict__ perm_g, uint32_t P, uint32_t D,
+                                              uint32_t* s_leaf, const int round_cap) {
+    const uint32_t first_leaf = (1u << D) - 1u;
+    auto lower_bound = [delc](float d) { const float a = fmaxf(fmaf(fabsf(d), 0.999999f, -delc), 0.f); return a * a; };
+    int nl = 0;
+    {
+        const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+        do {
+            int start = 0;
+            if (go >= 0) {   // enter the far child at level go
+                const uint32_t anc = ((node + 1u) >> (D - (uint32_t)go)) - 1u;
+                done |= 1u << go; side ^= 1u << go; side |= 0x10000u << go;
+                node = 2u * anc + 1u + ((side >> go) & 1u);
+                start = go + 1;
+            }
+            const uint32_t keep = (1u << start) - 1u;
+            side &= keep | (keep << 16); done &= keep;
+            uint32_t n1 = node + 1u;
+#pragma unroll
+            for (int L = 0; L < kPathMax; ++L) {
+                if (L >= (int)D) break;
+                if (L >= start) {
+                    const TreeNode n = s_nodes[n1 - 1u];
+                    const float d = (n.dim == 0 ? o0 : (n.dim == 1 ? o1 : o2)) - n.split;
+                    const uint32_t r = (~__float_as_uint(d)) >> 31;
+                    pd2[L] = lower_bound(d);
+                    side |= r << L;
+                    n1 = (n1 << 1) | r;
+                }
+            }
+            node = n1 - 1u;
+            s_leaf[nl++] = node - first_leaf;   // (every lane of the group writes the same word)
+            go = nn_next_level(pd2, side, done, node, D, bestf, s_nodes);
+        } while (go >= 0 && nl < round_cap);
+    }
+    auto err_of = [e_lin, e_const](float u) { return fmaf(1.001f * e_lin, __builtin_amdgcn_sqrtf(3.f * u), fmaf(1.5e-6f, u, e_const)); };
+    auto range_of = [P, D](uint32_t j, uint32_t& lo, uint32_t& hi) { lo = (uint32_t)(((uint64_t)j * P) >> D); hi = (uint32_t)(((uint64_t)(j + 1) * P) >> D); };
+    // this lane's share of the round's leaves, two leaves at a time, then the group's (m1, m2, mi) of all of them
+    float l1 = INFINITY, l2 = INFINITY; uint32_t li = kNone;
+    for (int m = 0; m < nl; m += 2) {
+        uint32_t loa, hia, lob, hib;
+        range_of(s_leaf[m], loa, hia);
+        range_of(s_leaf[m + 1 < nl ? m + 1 : m], lob, hib);
+        if (m + 1 >= nl) hib = lob;   // an odd last leaf: no partner
+        const uint32_t len = max(hia - loa, hib - lob);
+        for (uint32_t k0 = (uint32_t)lane; k0 < len; k0 += 4u * (uint32_t)G) {
+            float4 va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = k0 + (uint32_t)u * (uint32_t)G;
+                va[u] = p4[loa + k < hia ? loa + k : hia - 1u];
+                vb[u] = p4[lob + k < hib ? lob + k : lob];   // (an absent partner reads the leaf's own first point and is masked)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = k0 + (uint32_t)u * (uint32_t)G;
+                {
+                    const float dx = o0 - va[u].x, dy = o1 - va[u].y, dz = o2 - va[u].z;
+                    float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    uu = loa + k < hia ? uu : INFINITY;
+                    li = uu < l1 ? loa + k : li;
+                    l2 = __builtin_amdgcn_fmed3f(l1, l2, uu);
+                    l1 = vmin(l1, uu);
+                }
+                {
+                    const float dx = o0 - vb[u].x, dy = o1 - vb[u].y, dz = o2 - vb[u].z;
+                    float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    uu = lob + k < hib ? uu : INFINITY;
+                    li = uu < l1 ? lob + k : li;
+                    l2 = __builtin_amdgcn_fmed3f(l1, l2, uu);
+                    l1 = vmin(l1, uu);
+                }
+            }
+        }
+    }
+    const float m1 = group_min_f32(l1, G);
+    const uint32_t mi = group_min_u32(l1 == m1 ? li : kNone, G);
+    const float m2 = group_min_f32((li == mi && mi != kNone) ? l2 : l1, G);
+    const float mono = 4.f * e_lin * e_lin;
+    const float thi = m1 + err_of(m1);
+    const bool single = m2 >= mono && m2 - err_of(m2) > thi;
+    const float bnear = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+    const float bmax = fmaf(fabsf(bnear), 1.2e-7f, bnear);
+    const bool skip = m1 >= mono && m1 - err_of(m1) > bmax;
+    if (mi != kNone && !skip) {
+        if (single) {
+            const float4 pv = p4[mi];
+            const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+            if (WHICH & 1) { const double dx = ax - x, dy = ay - y, dz = az - z; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, mi, perm_g); }
+            if (WHICH & 2) { const double dx = qx - x, dy = qy - y, dz = qz - z; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, mi, perm_g); }
+        } else {   // several points within the float scan's error of the least: each of them exactly (rare: one leaf at a time)
+            double lbA = INFINITY, lbC = INFINITY; uint32_t lpA = kNone, lpC = kNone;
+            for (int m = 0; m < nl; ++m) {
+                uint32_t lo, hi;
+                range_of(s_leaf[m], lo, hi);
+                for (uint32_t i0 = lo + (uint32_t)lane; i0 < hi; i0 += 4u * (uint32_t)G) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const uint32_t iu = i0 + (uint32_t)u * (uint32_t)G; v[u] = p4[iu < hi ? iu : hi - 1u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t i = i0 + (uint32_t)u * (uint32_t)G;
+                        const float4 pv = v[u];
+                        const float dx = o0 - pv.x, dy = o1 - pv.y, dz = o2 - pv.z;
+                        const float uu = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        if (i < hi && uu - err_of(uu) <= thi) {
+                            const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+                            if (WHICH & 1) { const double ex = ax - x, ey = ay - y, ez = az - z; nn_merge(lbA, lpA, (ex * ex + ey * ey) + ez * ez, i, perm_g); }
+                            if (WHICH & 2) { const double ex = qx - x, ey = qy - y, ez = qz - z; nn_merge(lbC, lpC, (ex * ex + ey * ey) + ez * ez, i, perm_g); }
+                        }
+                    }
+                }
+            }
+            if (WHICH & 1) {
+                const double g = group_min_f64(lbA, G);
+                const uint32_t key = group_min_u32((lbA == g && lpA != kNone) ? perm_g[lpA] : kNone, G);
+                const uint32_t pw = group_min_u32((lbA == g && lpA != kNone && perm_g[lpA] == key) ? lpA : kNone, G);
+                if (pw != kNone) nn_merge(bestA, bposA, g, pw, perm_g);
+            }
+            if (WHICH & 2) {
+                const double g = group_min_f64(lbC, G);
+                const uint32_t key = group_min_u32((lbC == g && lpC != kNone) ? perm_g[lpC] : kNone, G);
+                const uint32_t pw = group_min_u32((lbC == g && lpC != kNone && perm_g[lpC] == key) ? lpC : kNone, G);
+                if (pw != kNone) nn_merge(bestC, bposC, g, pw, perm_g);
+            }
+        }
+    }
+    if (go >= 0) {   // the walk stopped at a full round: which far side comes next, under the bound as it is NOW (the level picked above has not been entered)
+        const float bestf = (float)fmax(actA ? bestA : -INFINITY, actC ? bestC : -INFINITY);
+        go = nn_next_level(pd2, side, done, node, D, bestf, s_nodes);
+    }
+}
+
 // diagnostic (iba_debug_nn): the search of iba_nn_kernel on caller-supplied LiDAR-frame queries, one lane per query, run to its
 // end. mode 1: the query is the association path's (a) alone; 2: the cost path's (c) alone; 3 / 4: both paths are searched
 // together, the query as a (3) or as c (4), its partner 1e-7 beside it as the reference's two float/double islands are.
@@ -1541,6 +1687,8 @@ __global__ __launch_bounds__(256) void iba_nn_probe_kernel(DevProblem dp, int fr
 // d_M ~ 30 cm: one or two entries qualify, and no lane searches the tree.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kCoopMax = kNNThreads / 2; // entries the lists left over that a block searches with a group of 2 .. 64 lanes each (more: one lane each)
+constexpr int kCoopLimit = kCoopMax;     // (r05: up to four passes of two-lane groups instead of one lane each beyond kCoopMax, i.e. 4 * kCoopMax here — measured 0.147 -> 0.152 ms at 40 KF x 120 k points: 52 of 2240 blocks take that path and their time is the same either way)
+static_assert((int)(kSliceW * (uint32_t)kMaxGroup) - kCoopLimit >= kNNThreads / 2 * 4, "the rounds of leaves of a cooperative block (wave_nn_round: at least four per two-lane group) live behind its queue");
 constexpr int kSetM = 8;              // neighbours a list holds
 // a listed neighbour: the scan point, a float lower bound of its distance to the anchor query, and (plane_cache = 1) what the
 // memoised planes at it say: flags bit 0 = the local plane is valid (pointcloud.h:699-717), bit 1 = the cost term is
@@ -1963,9 +2111,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
             }
             // ---- a few entries left over by the lists: a group of lanes each — a whole wave when there are at most 8, 8 lanes when
             //      there are 64, 2 when there are 256 (their searches would otherwise run one lane each while 500 lanes of the block wait for the slowest) ----
-            const bool coop = SETS && c_end != 0u && c_end <= (uint32_t)kCoopMax;
+            const bool coop = SETS && c_end != 0u && c_end <= (uint32_t)kCoopLimit;
             if (coop && dbg != 4) {
-                int G = 64; while ((uint32_t)(T / G) < c_end) G >>= 1;   // the largest group that takes all of them in one round
+                int G = 64; while ((uint32_t)(T / G) < c_end && G > 2) G >>= 1;   // the largest group that takes all of them in one pass
                 for (uint32_t q = (uint32_t)tid / (uint32_t)G; q < c_end; q += (uint32_t)(T / G)) {
                     const uint32_t wn = s_ovf[q];
                     const uint32_t cc = wn & ((1u << cg_shift) - 1u);
@@ -1974,7 +2122,13 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     make_queries(cc, e, mp);
                     lane_nn_begin(IBA_LANE_NN_PASS);
                     seed(wn);
-                    do wave_nn_visit<WHICH>(IBA_LANE_NN_PASS, tid & (G - 1), G, s_nodes, p4, perm_g, P, D); while (go >= 0);
+                    // this group's leaves of a round: in the queue's own array, behind the at most kCoopLimit entries of a cooperative block
+                    const int round_cap = min(kRoundLeaves, (int)((kSliceW * (uint32_t)kMaxGroup - (uint32_t)kCoopLimit) / (uint32_t)(T / G)));
+                    uint32_t* s_leaf = s_ovf + kCoopLimit + ((uint32_t)tid / (uint32_t)G) * (uint32_t)round_cap;
+                    // (IBA_NN_DBG 6: no search at all, 7: one round / leaf — timing cuts, the results are garbage)
+                    if (dbg == 6) {}
+                    else if (ka->nn_rounds) do wave_nn_round<WHICH>(IBA_LANE_NN_PASS, tid & (G - 1), G, s_nodes, p4, perm_g, P, D, s_leaf, round_cap); while (go >= 0 && dbg != 7);
+                    else do wave_nn_visit<WHICH>(IBA_LANE_NN_PASS, tid & (G - 1), G, s_nodes, p4, perm_g, P, D); while (go >= 0 && dbg != 7);
                     if (dbg != 5) finish(wn, nullptr, nullptr);   // every lane of the group writes the same values
                 }
             }

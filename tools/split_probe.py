@@ -29,3 +29,5 @@ for B in (1, 8, 14, 64):
             ts.append(phases())
         t = np.median(np.array(ts[1:]), axis=0)
         print("%s B=%2d %s: assoc %.3f ms  nn %.3f ms  rest %.3f ms  sum %.3f ms" % (tag, B, mode, t[0], t[1], t[2], t.sum()), flush=True)
+        if os.environ.get("IBA_DEBUG_LEFT_HIST") and B == 64:
+            print("   entries left to the tree search (all candidates): %.0f" % h.nn_left_to_tree, flush=True)   # (+ the library's histogram per block on stderr)
