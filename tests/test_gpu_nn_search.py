@@ -61,3 +61,37 @@ def test_kd_search_is_exact_where_float_is_blind(pkg, synth, abi, mode):
         assert np.array_equal(gd, bd), (f, np.flatnonzero(gd != bd)[:5])
         assert np.array_equal(gi.astype(np.int64), bi), (f, np.flatnonzero(gi != bi)[:5])
     h.close()
+
+
+def test_left_over_entries_in_rounds_of_leaves_equal_leaf_by_leaf(pkg, synth, abi, ob, monkeypatch):
+    """Dense scans (120 k points: 59-point leaves) leave entries to the tree search that the anchored lists cannot certify; round 5
+    searches them in ROUNDS of leaves (walk to the next leaves first, scan them together, confirm once: wave_nn_round) instead of leaf by
+    leaf (IBA_NN_ROUNDS=0, rounds 3-4). The visited set may only grow, the nearest neighbour may not change: the partial blocks of 24
+    candidates — a tight poll, a wide one, and both kinds of evaluation — bit for bit, the neighbours against the oracle's counters."""
+    import torch
+    prob, meta = synth.make_scene(n_frames=3, pts_per_frame=120000, seed=11)
+    p = abi.reference_yaml_params()
+    rng = np.random.default_rng(11)
+    xs = np.vstack([synth.perturb(meta["x_gt"], rng, n=16), synth.perturb(meta["x_gt"], rng, rot=3e-3, trans=0.03, scale_rel=4e-3, n=8)])
+    blocks = {}
+    for rounds in ("1", "0"):
+        monkeypatch.setenv("IBA_NN_ROUNDS", rounds)
+        h = pkg.IbaHandle(prob, p)
+        out = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            st = torch.cuda.current_stream().cuda_stream
+            for fn in (h.eval_full_partial, h.eval_cost_partial):
+                d = torch.zeros(len(xs) * 64, dtype=torch.float64, device="cuda")
+                fn(xs, d.data_ptr(), st)
+                torch.cuda.synchronize()
+                out.append(d.cpu().numpy().copy())
+        left = h.nn_left_to_tree
+        assert left > 0, "the scene must leave entries to the tree search"
+        if rounds == "1":
+            cost = h.eval_cost(xs[:3])
+            for g, r in zip(cost, ob.Oracle(prob).eval_cost(p, xs[:3], nthreads=8)):
+                assert (g.cnt_3d_3d, g.valid_cnt_3d_3d, g.n_corr) == (r.cnt_3d_3d, r.valid_cnt_3d_3d, r.n_corr) and abs(g.f2 - r.f2) <= 1e-10 * r.f2
+        h.close()
+        blocks[rounds] = out
+    for a, b in zip(blocks["1"], blocks["0"]):
+        assert np.array_equal(a, b, equal_nan=True), np.argwhere(a != b)[:5]
