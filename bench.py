@@ -429,6 +429,8 @@ def main():
                     ts.append(time.perf_counter() - t0)
                 row[name + "_wall_ms"] = float(np.median(ts)) * 1e3
                 row[name + "_evals_per_s"] = units * b / float(np.median(ts))
+                # the same calls in a C loop (iba_debug_call_latency): what the reference's own caller — C++, one candidate per call — sees
+                row[name + "_wall_ms_c_caller"] = h.call_latency(xb, "cost" if name == "cost" else "factors", 100)[0]
             sweep2[str(b)] = row
         extras["batch_sweep_cost_and_factors"] = sweep2
         # (1c) SUSTAINED regions next to the headline: >= 1.5 s each of back-to-back steps whose 64 candidates are drawn afresh

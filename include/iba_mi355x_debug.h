@@ -120,6 +120,12 @@ iba_status iba_mads_selftest_trace(int32_t problem, const double* x0, const iba_
  * library's tree (nanoflann keeps its own tree's): only exact ties can differ from the reference's lists. */
 iba_status iba_debug_knn(iba_handle* h, int32_t frame, const uint32_t* points, int32_t n, int32_t k, double r2, uint32_t* out_idx, double* out_d2, int32_t* out_cnt);
 
+/* debug: what a blocking entry point costs a C caller (no language binding in the clock): `iters` back-to-back calls — after three that do not
+ * count — of iba_eval_cost (kind 0), iba_eval_full (kind 1) or iba_eval_factors (kind 2; needs iba_build_problem) on the same B candidates, each
+ * timed here with the steady clock. *median_ms, *min_ms (may be NULL) per call. The unmodified caller of the reference is such a loop
+ * (BALoss::eval_x, iba_global.cpp:385: one candidate per call). */
+iba_status iba_debug_call_latency(iba_handle* h, const double* x, int32_t B, int32_t kind, int32_t iters, double* median_ms, double* min_ms);
+
 /* debug: the kernels' shared-reciprocal division (two quotients by one depth: csrc/iba_kernels.hpp, div2) beside the compiler's IEEE f64
  * division, on n operand triples from the caller, on `device`. q0/q1 = num0/den, num1/den as the projections compute them, ref0/ref1 = as
  * the plain division does; *n_fast = triples that took the shared-reciprocal path (the others fall back to the plain division inside). The

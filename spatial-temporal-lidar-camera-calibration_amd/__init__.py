@@ -267,6 +267,15 @@ class IbaHandle:
                                         idx.ctypes.data_as(C.POINTER(C.c_uint32)), _p(d2)))
         return idx, d2
 
+    def call_latency(self, xs, kind="cost", iters=200):
+        """(median_ms, min_ms) of a blocking entry point called `iters` times back to back from C (iba_debug_call_latency): kind = "cost"
+        (iba_eval_cost), "full" (iba_eval_full) or "factors" (iba_eval_factors)"""
+        xs = np.ascontiguousarray(xs, np.float64).reshape(-1, 7)
+        med, mn = C.c_double(0), C.c_double(0)
+        self.lib.iba_debug_call_latency.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        self._chk(self.lib.iba_debug_call_latency(self.h, _p(xs), C.c_int32(len(xs)), C.c_int32({"cost": 0, "full": 1, "factors": 2}[kind]), C.c_int32(iters), C.byref(med), C.byref(mn)))
+        return med.value, mn.value
+
     def debug_knn(self, frame, points, k=30, r2=np.inf):
         """The sorted neighbour lists the plane fits build (iba_plane_kernel's list builder) around scan points given by ORIGINAL
         index: (idx [n, k], d2 [n, k], cnt [n])."""

@@ -1423,6 +1423,23 @@ iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n
     return IBA_OK;
 }
 
+// debug: the wall time of a blocking entry point as a C caller sees it — `iters` back-to-back calls of iba_eval_cost (kind 0), iba_eval_full (1) or
+// iba_eval_factors (2) on the same candidates, timed around each call with the steady clock here, no language binding in the clock
+iba_status iba_debug_call_latency(iba_handle* h, const double* x, int32_t B, int32_t kind, int32_t iters, double* median_ms, double* min_ms) {
+    if (!h || !x || !median_ms || B < 1 || iters < 1 || iters > 100000 || kind < 0 || kind > 2) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    std::vector<iba_cost_out> c((size_t)B); std::vector<iba_normal_out> n((size_t)B); std::vector<double> t((size_t)iters);
+    for (int i = -3; i < iters; ++i) {   // three calls that do not count
+        const auto t0 = std::chrono::steady_clock::now();
+        const iba_status s = kind == 0 ? iba_eval_cost(h, x, B, c.data()) : (kind == 1 ? iba_eval_full(h, x, B, c.data(), n.data()) : iba_eval_factors(h, x, B, n.data()));
+        if (s != IBA_OK) return s;
+        if (i >= 0) t[(size_t)i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    std::sort(t.begin(), t.end());
+    *median_ms = t[t.size() / 2];
+    if (min_ms) *min_ms = t[0];
+    return IBA_OK;
+}
+
 // debug: div2 (the projections' two quotients by one depth, iba_kernels.hpp) beside the compiler's f64 division, on the caller's operands
 iba_status iba_debug_div2_selftest(int32_t device, const double* num0, const double* num1, const double* den, int64_t n, double* q0, double* q1, double* ref0, double* ref1, int64_t* n_fast) {
     if (!num0 || !num1 || !den || !q0 || !q1 || !ref0 || !ref1 || !n_fast || n < 1 || n > (1ll << 28)) return fail(nullptr, IBA_ERR_INVALID_ARG, "bad arguments");

@@ -17,4 +17,5 @@ for B in (1, 8, 14, 64):
         ts = []
         for _ in range(200):
             t0 = time.perf_counter(); fn(xs); ts.append(time.perf_counter() - t0)
-        print("B=%2d %-8s median %.3f ms  (%.0f evals/s)" % (B, name, np.median(ts) * 1e3, B / np.median(ts)), flush=True)
+        med_c, min_c = h.call_latency(xs, name, 200)   # the same calls in a C loop (iba_debug_call_latency): no Python in the clock
+        print("B=%2d %-8s median %.3f ms  (%.0f evals/s)   from C: median %.3f ms, min %.3f ms (%.0f evals/s)" % (B, name, np.median(ts) * 1e3, B / np.median(ts), med_c, min_c, B / (med_c * 1e-3)), flush=True)
