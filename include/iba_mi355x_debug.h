@@ -26,6 +26,8 @@
  *   IBA_PAIR_BYTES                                        launch-shape / LDS-plan knobs of single kernels (A/B timing)
  *   IBA_NN_ROUNDS                                         0: the entries the anchored lists leave over are searched leaf by leaf (rounds 3-4) instead of
  *                                                         in rounds of leaves (same results; A/B timing)
+ *   IBA_DONE_FLAG                                         0: a blocking call polls its stream (rounds 3-4) instead of the sequence number the summing
+ *                                                         kernel's last block publishes in pinned memory (same results; A/B timing)
  *   IBA_NN_DBG, IBA_ASSOC_DBG                             cut a kernel short after a phase (timing attribution; RESULTS ARE GARBAGE)
  *   IBA_LAYOUT_DEBUG, IBA_DEBUG_LEFT_HIST                 print the LDS plan / a histogram of left-over searches to stderr
  *   IBA_GROUP_TIMEOUT_MS                                  bound (ms, default 20 000; x4 for a group's first call) of a device thread's

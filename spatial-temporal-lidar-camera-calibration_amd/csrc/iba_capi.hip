@@ -152,6 +152,10 @@ struct iba_handle {
     Cand* h_cands = nullptr;              // pinned, kRing * chain_cap
     double* h_partials = nullptr;         // pinned
     double* h_partials_dev = nullptr;     // the same buffer as the kernels see it: the last kernel of a chain writes the sums there (no D2H copy)
+    unsigned long long* h_done = nullptr; unsigned long long* h_done_dev = nullptr;   // pinned: the sequence number of the last blocking call whose sums have landed (iba_reduce2_kernel)
+    DevBuf<uint32_t> d_done_ctr;          // blocks of the summing kernel that have finished (reset by the last one)
+    unsigned long long done_seq = 0; bool done_armed = false;   // the call in flight publishes done_seq; done_flag (IBA_DONE_FLAG=0: poll the stream as rounds 3-4 did)
+    bool done_flag_on = true;
     Cand* h_cands_dev = nullptr;          // the pinned candidate ring as the fetch kernel sees it
     hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
     // The head of a chain (round 5): the candidate block reaches the device through spare blocks of the chain's FIRST kernel (the pair
@@ -538,6 +542,22 @@ hipError_t wait_stream(iba_handle* h, hipStream_t st) {
     return hipStreamSynchronize(st);
 }
 
+// End of a BLOCKING evaluation whose sums land in the handle's pinned block: the host polls the sequence number the summing kernel's last
+// block publishes there (iba_reduce2_kernel), not the stream — whose completion reaches the host 3-4 us later. Falls back to the stream
+// after 2 ms, and whenever the chain did not arm the flag (event timing on, an empty handle, IBA_DONE_FLAG=0).
+hipError_t wait_done(iba_handle* h, hipStream_t st) {
+    if (h->done_armed) {
+        h->done_armed = false;
+        const volatile unsigned long long* f = h->h_done;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int polls = 1;; ++polls) {
+            if (*f == h->done_seq) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+            if ((polls & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    return wait_stream(h, st);
+}
+
 iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
     if (h->n_frames == 0) return IBA_OK;
     // (a handle whose frames hold no keypoint at all still launches: every list is empty and the kernel writes zero records,
@@ -804,9 +824,14 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     {
         const double* nnp = search ? h->d_nn_partials.p : (const double*)nullptr;
         const int he_mode = (want & 2) ? (he_in_search ? 2 : 1) : 0;
-        if (he_mode == 2) hipLaunchKernelGGL(iba_reduce2_kernel<2>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p);
-        else if (he_mode == 1) hipLaunchKernelGGL(iba_reduce2_kernel<1>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p);
-        else hipLaunchKernelGGL(iba_reduce2_kernel<0>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p);
+        // a blocking entry point's sums go to pinned memory and its caller polls the flag the last block publishes (wait_done)
+        const bool flag = h->done_flag_on && d_partials == h->h_partials_dev && !h->timing;
+        unsigned long long* df = flag ? h->h_done_dev : nullptr;
+        if (flag) ++h->done_seq;
+        h->done_armed = flag;
+        if (he_mode == 2) hipLaunchKernelGGL(iba_reduce2_kernel<2>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
+        else if (he_mode == 1) hipLaunchKernelGGL(iba_reduce2_kernel<1>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
+        else hipLaunchKernelGGL(iba_reduce2_kernel<0>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
     }
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
@@ -855,6 +880,7 @@ void iba_destroy(iba_handle* h) {
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->h_cands) (void)hipHostFree(h->h_cands);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
+    if (h->h_done) (void)hipHostFree(h->h_done);
     for (int i = 0; i < kRing; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1078,6 +1104,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     h->spin_wait = opt.spin_wait != 0; h->factor_valu = opt.factor_mfma == 0;
     h->chain_fold = opt.chain_fold != 0; h->chain_cap = opt.max_chain_batch;
     if (const char* e = std::getenv("IBA_NN_ROUNDS")) h->nn_rounds = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IBA_DONE_FLAG")) h->done_flag_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_NN_CG")) { h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e))); h->nn_cg_fixed = true; }
     if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
@@ -1147,6 +1174,10 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if ((er = h->d_corr.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc corr", er);
     if ((er = hipHostMalloc((void**)&h->h_cands, sizeof(Cand) * kRing * h->chain_cap)) != hipSuccess) return bail("hipHostMalloc", er);
     if ((er = hipHostMalloc((void**)&h->h_partials, sizeof(double) * h->chain_cap * kPartialStride)) != hipSuccess) return bail("hipHostMalloc", er);
+    if ((er = hipHostMalloc((void**)&h->h_done, 64)) != hipSuccess) return bail("hipHostMalloc", er);
+    *h->h_done = 0ull;
+    if ((er = hipHostGetDevicePointer((void**)&h->h_done_dev, h->h_done, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", er);
+    if ((er = h->d_done_ctr.alloc(1)) != hipSuccess || (er = hipMemset(h->d_done_ctr.p, 0, sizeof(uint32_t))) != hipSuccess) return bail("done counter", er);
     if ((er = hipHostGetDevicePointer((void**)&h->h_partials_dev, h->h_partials, 0)) != hipSuccess || (er = hipHostGetDevicePointer((void**)&h->h_cands_dev, h->h_cands, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", er);
     if ((er = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", er);
     if ((er = hipEventCreate(&h->ev0)) != hipSuccess || (er = hipEventCreate(&h->ev1)) != hipSuccess || (er = hipEventCreate(&h->ev2)) != hipSuccess) return bail("hipEventCreate", er);
@@ -1247,7 +1278,7 @@ iba_status iba_eval_cost(iba_handle* h, const double* x, int32_t B, iba_cost_out
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(h, B, [&](int b0, int Bc) {
         iba_status s = eval_cost_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;   // the sums land in pinned host memory: no copy behind the last kernel
-        HIP_TRY(h, wait_stream(h, h->stream));
+        HIP_TRY(h, wait_done(h, h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_cost(&h->params, h->h_partials, Bc, out + b0);
     });
@@ -1525,7 +1556,7 @@ iba_status iba_eval_normal(iba_handle* h, const double* x, int32_t B, iba_normal
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(h, B, [&](int b0, int Bc) {
         iba_status s = eval_normal_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, wait_stream(h, h->stream));
+        HIP_TRY(h, wait_done(h, h->stream));
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_normal(&h->params, h->h_partials, Bc, out + b0);
     });
@@ -1551,7 +1582,7 @@ iba_status iba_eval_full(iba_handle* h, const double* x, int32_t B, iba_cost_out
     if (!h || !cost || !normal || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(h, B, [&](int b0, int Bc) {
         iba_status s = eval_full_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, wait_stream(h, h->stream));
+        HIP_TRY(h, wait_done(h, h->stream));
         s = iba_finalize_cost(&h->params, h->h_partials, Bc, cost + b0); if (s != IBA_OK) return s;
         return iba_finalize_normal(&h->params, h->h_partials, Bc, normal + b0);
     });
@@ -1563,6 +1594,7 @@ static iba_status build_problem_impl(iba_handle* h, const double* x, const Cand*
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, 1, h->stream, &dc, pre); if (s != IBA_OK) return s;
     s = run_split(h, dc, 1, 1, true, false, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
+    h->done_armed = false;   // (waited for on the stream: the flag this chain publishes is nobody's to poll)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->frozen_frames = (int32_t)h->h_partials[P_FRAMES_N]; h->frozen_ncorr = (int32_t)h->h_partials[P_NCORR_N]; h->frozen_valid = true;
     return IBA_OK;
@@ -1597,7 +1629,7 @@ iba_status iba_eval_factors(iba_handle* h, const double* x, int32_t B, iba_norma
     if (!h || !out || !x || B < 1) return fail(h, IBA_ERR_INVALID_ARG, "null argument");
     return chunked(h, B, [&](int b0, int Bc) {
         iba_status s = eval_factors_partial_impl(h, x + 7 * b0, Bc, h->h_partials_dev, h->stream); if (s != IBA_OK) return s;
-        HIP_TRY(h, wait_stream(h, h->stream));
+        HIP_TRY(h, wait_stream(h, h->stream));   // (this chain ends in iba_set_slots_kernel, not in the summing kernel that publishes the flag of wait_done)
         if (h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->last_frame_ms, h->ev0, h->ev1)); HIP_TRY(h, hipEventElapsedTime(&h->last_total_ms, h->ev0, h->ev2)); }
         return iba_finalize_normal(&h->params, h->h_partials, Bc, out + b0);
     });

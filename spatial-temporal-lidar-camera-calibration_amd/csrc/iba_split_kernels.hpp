@@ -2331,7 +2331,8 @@ constexpr int kHeLds = 2048;   // HE_MODE 1: frames whose terms wait in LDS (mor
 // chain); 1: no search kernel ran in this chain — the terms are evaluated here, two lanes each
 template <int HE_MODE>
 __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, int nfr, const double* __restrict__ nn_partials, int nn_nrec,
-                                                                     double* __restrict__ out, const FrameHdr* __restrict__ frames, const Cand* __restrict__ cands, double* __restrict__ he_scratch) {
+                                                                     double* __restrict__ out, const FrameHdr* __restrict__ frames, const Cand* __restrict__ cands, double* __restrict__ he_scratch,
+                                                                     unsigned long long* __restrict__ done_flag, uint32_t* __restrict__ done_ctr, unsigned long long done_seq) {
     constexpr int NG = kReduceThreads / kPartialStride;
     constexpr int NL = kReduceThreads / kNNPartial;
     __shared__ double s[NG][kPartialStride];
@@ -2407,6 +2408,21 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
             t += y;
         }
         out[(size_t)b * kPartialStride + i] = t;
+        if (done_flag) __threadfence_system();   // (see below)
+    }
+    // END OF A BLOCKING CALL (round 5): `out` is pinned host memory and the caller polls `done_flag` (pinned, too) instead of the stream — the
+    // stream's own completion signal reaches the host 3-4 us after the last wave has retired, a tenth of a one-candidate call. Every writer
+    // fences its sums to system scope, the block's thread 0 counts the block in, and the last block of the grid publishes the call's sequence number.
+    if (done_flag) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev + 1u == gridDim.x) {
+                __hip_atomic_store(done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next chain's sums run behind this kernel in stream order)
+                __threadfence_system();
+                __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
