@@ -22,7 +22,8 @@
  *   IBA_CHAIN_FOLD          chain_fold                    staging / reduction launches folded into their neighbours
  *   IBA_MAX_CHAIN           max_chain_batch               candidates one launch chain takes
  *   -- no field: pure diagnostics, results unaffected unless stated --
- *   IBA_NN_CG, IBA_PAIRS_DENSE_MIN, IBA_COMMON_MIN_BATCH, IBA_PAIR_BOUND, IBA_ASSOC2_FLREG, IBA_ASSOC_BLOCKS, IBA_CAND_BYTES,
+ *   IBA_NN_CG, IBA_PAIRS_DENSE_MIN, IBA_COMMON_MIN_BATCH, IBA_PAIR_BOUND, IBA_ASSOC2_FLREG, IBA_ASSOC2_THREADS (256 / 512 threads per
+ *   block of the shared-pair association, else chosen per launch), IBA_ASSOC2_SMALL_MIN, IBA_ASSOC_BLOCKS, IBA_CAND_BYTES,
  *   IBA_PAIR_BYTES                                        launch-shape / LDS-plan knobs of single kernels (A/B timing)
  *   IBA_NN_ROUNDS                                         0: the entries the anchored lists leave over are searched leaf by leaf (rounds 3-4) instead of
  *                                                         in rounds of leaves (same results; A/B timing)

@@ -105,6 +105,8 @@ struct iba_handle {
     int max_groups = kMaxPairGroups;      // IBA_PAIR_GROUPS: 1 = no clustering of wide batches (round 3's behaviour)
     int last_mean_pairs_slot = -1;
     int pair_cap = 0, hard_cap = 0;
+    int assoc2_threads_forced = 0;        // IBA_ASSOC2_THREADS: 256 / 512 (0: chosen per launch, assoc2_threads)
+    int assoc2_small_min_blocks = 1024;   // launches of at least this many (candidate, keyframe) blocks run iba_assoc2_kernel with 256 threads per block (IBA_ASSOC2_SMALL_MIN)
     uint32_t pairs_dense_min = 32768u;    // scans of at least this many points: the pair search tests a block's boxes before it loads the block's points and the keypoint grid (IBA_PAIRS_DENSE_MIN)
     int common_mode = 1;                  // IBA_COMMON_PAIRS: 0 = never, 1 = when the batch is tight (default), 2 = whenever the bound allows
     bool spin_wait = true;                // IBA_SPIN_WAIT=0: blocking waits only
@@ -293,7 +295,15 @@ bool layout_nn(const iba_handle* h, NNLayout& L) {
 
 // iba_assoc2_kernel<Q>: flagged keypoints per thread that the tail keeps in registers — 2 (at most 1024 flagged keypoints per frame), 4 (at most
 // 2048), 0 = any number, read from the list where needed (IBA_ASSOC2_FLREG=0: always 0)
-int assoc2_q(const iba_handle* h) { return !h->assoc2_flreg_on ? 0 : (h->maxKw <= 2u * (uint32_t)kThreads ? 2 : (h->maxKw <= 4u * (uint32_t)kThreads ? 4 : 0)); }
+int assoc2_q(const iba_handle* h, int threads = kThreads) { return !h->assoc2_flreg_on ? 0 : (h->maxKw <= 2u * (uint32_t)threads ? 2 : (h->maxKw <= 4u * (uint32_t)threads ? 4 : 0)); }
+// threads per block of iba_assoc2_kernel for a launch of `blocks` (candidate, keyframe) blocks: 256 once the launch fills the machine more than
+// twice over (see the kernel), 512 below that (a one-candidate call's 200 blocks are latency, not throughput) and whenever 256 threads would
+// push the tail off its register path. IBA_ASSOC2_THREADS=256 / 512 forces one.
+int assoc2_threads(const iba_handle* h, int blocks) {
+    if (h->assoc2_threads_forced) return h->assoc2_threads_forced;
+    if (blocks < h->assoc2_small_min_blocks) return kThreads;
+    return assoc2_q(h, 256) != 0 || assoc2_q(h, kThreads) == 0 ? 256 : kThreads;
+}
 // LDS plan of iba_assoc2_kernel: best d^2, best index and flag word per keypoint, the reduction slab
 bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     const uint32_t rel_slots = std::max<uint32_t>(h->max_slots, 1u);
@@ -761,17 +771,21 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     const Cand* assoc_cands = head_open ? (const Cand*)head_src : dc;
     const uint4* a_src = head_open ? head_src : nullptr; const uint32_t a_n16 = head_open ? head_n16 : 0u;
     if (common) {
-        // (six instantiations: two / four / any number of flagged keypoints per thread x at most 30 covisible keyframes or more)
-        auto launch_assoc2 = [&](auto qtag) {
-            constexpr int QQ = decltype(qtag)::value;
-            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B + head_blocks), dim3(kThreads), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
+        // (twelve instantiations: two / four / any number of flagged keypoints per thread x at most 30 covisible keyframes or more x 256 / 512 threads)
+        const int at = assoc2_threads(h, 8 * per_xcd * B);
+        auto launch_assoc2 = [&](auto qtag, auto ttag) {
+            constexpr int QQ = decltype(qtag)::value, TT = decltype(ttag)::value;
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B + head_blocks), dim3(TT), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                                                           h->d_frame_partials.p, nrec, fl, fc, lc, (int)h->lstride, h->d_pairs.p, h->d_hard.p, h->d_pcounts.p, h->pair_cap, h->hard_cap, a_src, (uint4*)dc, a_n16); };
-            if (h->max_slots > (uint32_t)kCovisWord) go(iba_assoc2_kernel<QQ, true>); else go(iba_assoc2_kernel<QQ, false>);
+            if (h->max_slots > (uint32_t)kCovisWord) go(iba_assoc2_kernel<QQ, true, TT>); else go(iba_assoc2_kernel<QQ, false, TT>);
         };
-        const int aq = assoc2_q(h);
-        if (aq == 2) launch_assoc2(std::integral_constant<int, 2>{});
-        else if (aq == 4) launch_assoc2(std::integral_constant<int, 4>{});
-        else launch_assoc2(std::integral_constant<int, 0>{});
+        auto launch_t = [&](auto ttag) {
+            const int aq = assoc2_q(h, decltype(ttag)::value);
+            if (aq == 2) launch_assoc2(std::integral_constant<int, 2>{}, ttag);
+            else if (aq == 4) launch_assoc2(std::integral_constant<int, 4>{}, ttag);
+            else launch_assoc2(std::integral_constant<int, 0>{}, ttag);
+        };
+        if (at == 256) launch_t(std::integral_constant<int, 256>{}); else launch_t(std::integral_constant<int, kThreads>{});
     } else {
     auto go1 = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B + head_blocks), dim3(kThreads), h->alay.total, st, KArgs{dp, h->dprm, h->alay}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
                        h->d_frame_partials.p, nrec, (uint32_t*)nullptr, fl, fc, lc, (int)h->lstride, a_src, (uint4*)dc, a_n16); };
@@ -1121,6 +1135,8 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
     if (const char* e = std::getenv("IBA_PAIRS_DENSE_MIN")) h->pairs_dense_min = (uint32_t)std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("IBA_ASSOC2_THREADS")) { const int v = std::atoi(e); h->assoc2_threads_forced = (v == 256 || v == kThreads) ? v : 0; }
+    if (const char* e = std::getenv("IBA_ASSOC2_SMALL_MIN")) h->assoc2_small_min_blocks = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("IBA_PAIR_GROUPS")) h->max_groups = std::max(1, std::min(kMaxPairGroups, std::atoi(e)));
     if (const char* e = std::getenv("IBA_CHAIN_FOLD")) h->chain_fold = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_MAX_CHAIN")) h->chain_cap = std::atoi(e);
@@ -1187,8 +1203,10 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     if (h->common_mode > 0 && (er = hipFuncSetAttribute((const void*)iba_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     {
-        const void* a2[6] = {(const void*)iba_assoc2_kernel<2, false>, (const void*)iba_assoc2_kernel<2, true>, (const void*)iba_assoc2_kernel<4, false>, (const void*)iba_assoc2_kernel<4, true>,
-                             (const void*)iba_assoc2_kernel<0, false>, (const void*)iba_assoc2_kernel<0, true>};
+        const void* a2[12] = {(const void*)iba_assoc2_kernel<2, false, kThreads>, (const void*)iba_assoc2_kernel<2, true, kThreads>, (const void*)iba_assoc2_kernel<4, false, kThreads>, (const void*)iba_assoc2_kernel<4, true, kThreads>,
+                              (const void*)iba_assoc2_kernel<0, false, kThreads>, (const void*)iba_assoc2_kernel<0, true, kThreads>,
+                              (const void*)iba_assoc2_kernel<2, false, 256>, (const void*)iba_assoc2_kernel<2, true, 256>, (const void*)iba_assoc2_kernel<4, false, 256>, (const void*)iba_assoc2_kernel<4, true, 256>,
+                              (const void*)iba_assoc2_kernel<0, false, 256>, (const void*)iba_assoc2_kernel<0, true, 256>};
         for (const void* fn : a2) if (h->common_mode > 0 && (er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->alay2.total)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     }
     if ((er = hipFuncSetAttribute((const void*)iba_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);

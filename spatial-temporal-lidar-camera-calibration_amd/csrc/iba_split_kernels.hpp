@@ -109,13 +109,14 @@ typedef __attribute__((address_space(4))) const KArgs KArgsC;
 // to reach; see grid_match). Q > 0 (at most Q x 512 flagged keypoints per frame): the thread's Q list entries (keypoint, flag word) arrive in
 // registers (rfa, rfb: loaded at the start of the kernel), their winners are gathered once and stay in registers for the list pass, and the
 // covisible-slot mask of a list entry is parked next to it (s_msk, over the winners' array). Q = 0: any number, read from the list where needed.
-template <int Q, bool MANY = true>   // MANY: a frame may have more covisible keyframes than the flag word has match bits (the second word, kp_fl2)
+template <int Q, bool MANY = true, int T = IBA_THREADS>   // MANY: a frame may have more covisible keyframes than the flag word has match bits (the second word, kp_fl2); T: threads of the block
 __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const Cand& cd, const FrameCtx& c, uint32_t* s_best_idx, const uint4 rfa, const uint4 rfb, uint32_t* s_list,
                                            double* s_red, const double* s_rel, const uint32_t K, const int want, const int dbg, const bool refit, const int b, const int f, const int nf,
                                            double* __restrict__ part, uint4* __restrict__ flist,
                                            uint32_t* __restrict__ fcount, uint32_t* __restrict__ lcount, const int flist_stride, const uint32_t first_hits) {
 #define dp (ka->dp)
 #define prm (ka->prm)
+    constexpr int kThreads = T, kWaves = T / 64;   // (of THIS block: iba_assoc2_kernel runs blocks of 256 or of 512 threads)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t* inv_perm = dp.inv_perm + h.pt_base;
     const uint2* fk = dp.fkp + h.fk_base;
@@ -206,7 +207,12 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     }
     __syncthreads();
     if (dbg == 6) return;
-    double sum2d = 0.0;
+    // The 3d-2d sum keeps the order of a block of IBA_THREADS threads whatever T is (a candidate's bits may not depend on the block size its
+    // launch was given): a thread of a smaller block stands for V = IBA_THREADS / T threads of the big one — entry i belongs to thread
+    // i % IBA_THREADS there — with an accumulator for each, and their wave sums go to the slots those threads' waves would have filled.
+    constexpr int V = IBA_THREADS / T;
+    static_assert(V == 1 || V == 2, "assoc_tail: blocks of IBA_THREADS or IBA_THREADS / 2 threads");
+    double sum2d = 0.0, sum2d_hi = 0.0;
     uint32_t c2 = 0, v2 = 0;
     // association: local plane at the matched point (iba_local.cpp:207-231); list entry for the search / factor kernels
     for (uint32_t i = tid; i < n3; i += kThreads) {
@@ -267,7 +273,7 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
                     if (!(ou >= 0 && ou < h.W && ov >= 0 && ov < h.H)) continue;
                     const double eu = ou - (double)cur.x, ev = ov - (double)cur.y;
                     const double dist = sqrt(eu * eu + ev * ev);
-                    if (dist < prm.corr_3d_2d_threshold) { sum2d += dist; ++v2; }
+                    if (dist < prm.corr_3d_2d_threshold) { if (V == 2 && ((i / (uint32_t)kThreads) & 1u)) sum2d_hi += dist; else sum2d += dist; ++v2; }
                     ++c2;
                 }
             }
@@ -277,15 +283,16 @@ __device__ __forceinline__ void assoc_tail(KArgsC* ka, const FrameHdr& h, const 
     // K8: reduction -> record. The 3d-3d sums of this (candidate, frame) come from iba_nn_kernel's own records.
     {
         const double w2d = wave_sum_f64(sum2d);
+        const double w2d_hi = V == 2 ? wave_sum_f64(sum2d_hi) : 0.0;
         const unsigned long long wa = wave_sum_u64((unsigned long long)c2 | ((unsigned long long)v2 << 32));
         unsigned long long* s_redu = (unsigned long long*)s_red;
         __syncthreads();
-        if (lane == 63) { s_red[wave * 4 + 0] = w2d; s_redu[wave * 4 + 2] = wa; }
+        if (lane == 63) { s_red[wave * 4 + 0] = w2d; s_redu[wave * 4 + 2] = wa; if (V == 2) { s_red[(wave + kWaves) * 4 + 0] = w2d_hi; s_redu[(wave + kWaves) * 4 + 2] = 0ull; } }
         __syncthreads();
         if (tid < kPartialStride) {
             double out = 0.0;
             if (usedC) {
-                if (tid == P_SUM_3D2D) { for (int w = 0; w < kWaves; ++w) out += s_red[w * 4 + 0]; }
+                if (tid == P_SUM_3D2D) { for (int w = 0; w < kWaves * V; ++w) out += s_red[w * 4 + 0]; }
                 else if (tid == P_CNT_3D2D || tid == P_VALID_3D2D) {
                     unsigned long long a = 0;
                     for (int w = 0; w < kWaves; ++w) a += s_redu[w * 4 + 2];
@@ -1032,15 +1039,27 @@ __device__ __forceinline__ uint32_t grid_match_g(const FrameCtx& c, const uint32
 // f64 test of the batch's common pairs (K1 + K2 + K3 of the reference: TransformPointCloud pointcloud.h:82-86, the projection
 // and FOV test iba_global.cpp:68-81, the 1-NN within max_pixel_dist :86-95) streamed from the list iba_pairs_kernel left.
 // LDS: 16 B per keypoint (best d^2, best index, flags) + the relative poses: ~33 KB at 2000 keypoints.
-constexpr int kPairRegs = 4;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
+#ifndef IBA_PAIR_REGS
+#define IBA_PAIR_REGS 4
+#endif
+#ifndef IBA_PAIR_REGS_256
+#define IBA_PAIR_REGS_256 6   /* ... of a block of 256 threads (6 x 256 = 1536 pairs) */
+#endif
+constexpr int kPairRegs = IBA_PAIR_REGS;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
 constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
-template <int Q, bool MANY>   // Q: flagged keypoints per thread that the tail keeps in registers (2: at most 1024 per frame, 4: at most 2048; 0: any number, read where needed; see assoc_tail); MANY: more than 30 covisible keyframes possible
-__global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
+// BLOCK SIZE (round 5). T = 512 threads was round 1's choice for the per-candidate kernel (two blocks of 80 KB LDS per CU) and this kernel
+// inherited it. With a keyframe's ~1.2 k common pairs and ~800 flagged keypoints a block of 256 threads (four waves behind every barrier
+// instead of eight, six pairs per thread in registers) takes the association of 64 candidates x 200 keyframes from 0.219 to 0.183 ms; a
+// block of 128 falls off the register path of the tail (0.274 ms), 384 is no power of two (0.234 ms). Few blocks (one candidate: 200) are
+// faster with 512 threads each, and dense scans (9.8 k pairs per keyframe) do not care: the host picks per launch (assoc2_threads).
+template <int Q, bool MANY, int T>   // Q: flagged keypoints per thread that the tail keeps in registers (2: at most 2 T per frame, 4: at most 4 T; 0: any number, read where needed; see assoc_tail); MANY: more than 30 covisible keyframes possible; T: threads per block
+__global__ __launch_bounds__(T) void iba_assoc2_kernel(K2Args ka_by_value, const Cand* __restrict__ cands, int B, int want, double* __restrict__ frame_partials, int nrec,
                                                               uint4* __restrict__ flist, uint32_t* __restrict__ fcount,
                                                               uint32_t* __restrict__ lcount, int flist_stride, const PairRec* __restrict__ pairs_all, const uint32_t* __restrict__ hard_all,
                                                               const uint32_t* __restrict__ counts_all, int pair_cap, int hard_cap,
                                                               const uint4* __restrict__ head_src, uint4* __restrict__ head_dst, uint32_t head_n16) {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int kThreads = T, kPairRegs = T <= 256 ? IBA_PAIR_REGS_256 : IBA_PAIR_REGS;   // (of THIS block)
     typedef __attribute__((address_space(4))) const K2Args K2ArgsC;
     K2ArgsC* ka2 = (K2ArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
     KArgsC* ka = &ka2->k;
@@ -1070,9 +1089,9 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
     unsigned long long* s_best_d2 = (unsigned long long*)(smem + lay.off_best_d2);
     uint32_t* s_best_idx = (uint32_t*)(smem + lay.off_best_idx);
     double* s_red = (double*)(smem + lay.off_red);
-    double* s_rel = s_red + kWaves * 4;
+    double* s_rel = s_red + (IBA_THREADS / 64) * 4;   // (the reduction slab is laid out for the largest block: layout_assoc2)
     uint32_t* s_list = (uint32_t*)(smem + lay.off_best_d2);   // aliases best_d2 once the winners are known
-    uint32_t* s_qn = (uint32_t*)(s_rel + lay.rel_slots * 12u) + kWaves;   // [0]: pairs noted for the tie pass
+    uint32_t* s_qn = (uint32_t*)(s_rel + lay.rel_slots * 12u) + IBA_THREADS / 64;   // [0]: pairs noted for the tie pass
     uint16_t* s_q = (uint16_t*)(smem + lay.off_pair);                // their numbers (pair lists hold at most 65 536 records)
     const uint32_t K = h.K, P = h.P;
     const uint32_t ut = (uint32_t)tid;
@@ -1210,7 +1229,7 @@ __global__ __launch_bounds__(kThreads) void iba_assoc2_kernel(K2Args ka_by_value
         for (uint32_t pos = ut; pos < P; pos += kThreads) { double u, v; if (project_pos<true>(c, pos, u, v)) grid_match_g<2>(c, gcs, u, v, pos); }
     __syncthreads();
     if (dbg == 5) return;
-    assoc_tail<Q, MANY>(ka, h, cd, c, s_best_idx, rfa, rfb, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride, first);
+    assoc_tail<Q, MANY, T>(ka, h, cd, c, s_best_idx, rfa, rfb, s_list, s_red, s_rel, K, want, dbg, refit, b, f, nf, part, flist, fcount, lcount, flist_stride, first);
 #undef dp
 #undef prm
 #undef lay
