@@ -316,7 +316,10 @@ bool layout_assoc2(const iba_handle* h, LdsLayout& L) {
     L.off_best_idx = off; off += 4u * Kp;
     L.off_kfl = off;   // (no LDS copy of the flags since round 5: the tail reads the flagged-keypoint list)
     off = align_up(off, 16); L.off_red = off; off += red_bytes;
-    off = align_up(off, 16); L.off_pair = off; off += 2u * (uint32_t)kPairNote;   // possible winners beyond the register window
+    // possible winners beyond the register window (1536 / 2048 pairs): a sparse scan's ~1.2 k pairs per keyframe never get there, and at 2000
+    // keypoints the 3 KB decide whether a CU holds five or six blocks of 256 threads
+    L.pair_cap = h->maxP >= 32768u ? (uint32_t)kPairNote : 512u;
+    off = align_up(off, 16); L.off_pair = off; off += 2u * L.pair_cap;
     L.total = align_up(off, 16);
     return L.total <= kLdsBytes;
 }

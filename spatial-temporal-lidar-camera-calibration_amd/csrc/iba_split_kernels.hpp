@@ -1046,7 +1046,7 @@ __device__ __forceinline__ uint32_t grid_match_g(const FrameCtx& c, const uint32
 #define IBA_PAIR_REGS_256 6   /* ... of a block of 256 threads (6 x 256 = 1536 pairs) */
 #endif
 constexpr int kPairRegs = IBA_PAIR_REGS;   // pairs per thread whose d^2 waits in registers for the tie pass (4 x 512 = 2048 pairs; of the others, the possible winners are re-evaluated)
-constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS)
+constexpr int kPairNote = 2048;  // possible winners beyond the register window a block can note (u16 pair numbers, 4 KB of LDS) when the scans are dense; 512 otherwise (layout_assoc2)
 // BLOCK SIZE (round 5). T = 512 threads was round 1's choice for the per-candidate kernel (two blocks of 80 KB LDS per CU) and this kernel
 // inherited it. With a keyframe's ~1.2 k common pairs and ~800 flagged keypoints a block of 256 threads (four waves behind every barrier
 // instead of eight, six pairs per thread in registers) takes the association of 64 candidates x 200 keyframes from 0.219 to 0.183 ms; a
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(T) void iba_assoc2_kernel(K2Args ka_by_value, const
                 if ((tid & 63) == 0) base = atomicAdd(&s_qn[0], (uint32_t)__popcll(bal));
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 const uint32_t slot = base + (uint32_t)__popcll(bal & lt);
-                if (note && slot < (uint32_t)kPairNote) s_q[slot] = (uint16_t)i;
+                if (note && slot < lay.pair_cap) s_q[slot] = (uint16_t)i;
             }
         }
     }
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(T) void iba_assoc2_kernel(K2Args ka_by_value, const
         if (rk[j] != kNone && s_best_d2[rk[j]] == rb[j]) atomicMin(&s_best_idx[rk[j]], ri[j]);
     {
         const uint32_t nq = s_qn[0];
-        if (nq <= (uint32_t)kPairNote) {   // the noted pairs alone
+        if (nq <= lay.pair_cap) {   // the noted pairs alone (lay.pair_cap: the note list's capacity, layout_assoc2)
             for (uint32_t t = ut; t < nq; t += kThreads) {
                 uint32_t k, idx;
                 const unsigned long long bits = eval_pair((uint32_t)s_q[t], k, idx);
