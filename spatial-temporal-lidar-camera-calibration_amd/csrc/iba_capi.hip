@@ -576,13 +576,17 @@ iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, do
     // (a handle whose frames hold no keypoint at all still launches: every list is empty and the kernel writes zero records,
     // which is what the sums over the records expect)
     const dim3 grid(h->n_frames, B);
+    // iba_factor_kernel with a keyframe count that is no multiple of 8: the XCD-aware mapping of the association kernels (see the kernel)
+    const bool xmap = (h->n_frames % 8) != 0;
+    const dim3 grid1 = xmap ? dim3(8 * ((h->n_frames + 7) / 8) * B) : grid;
+    const int Bx = xmap ? B : 0;
     const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
     if (h->dprm.p2pix) {   // IBATestEdge edges (factor_3d2d_kind = 1): an instantiation of its own (the matrix-core variant has none)
-        if (h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL((iba_factor_kernel<true, true>), grid, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
-        else hipLaunchKernelGGL((iba_factor_kernel<false, true>), grid, dim3(kFactorThreads), 96u * std::max<uint32_t>(h->max_slots, 1u), st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+        if (h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL((iba_factor_kernel<true, true>), grid1, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base, Bx);
+        else hipLaunchKernelGGL((iba_factor_kernel<false, true>), grid1, dim3(kFactorThreads), 96u * std::max<uint32_t>(h->max_slots, 1u), st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base, Bx);
     }
-    else if (h->factor_valu && h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL(iba_factor_kernel<true>, grid, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
-    else if (h->factor_valu) hipLaunchKernelGGL(iba_factor_kernel<false>, grid, dim3(kFactorThreads), 96u * std::max<uint32_t>(h->max_slots, 1u), st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
+    else if (h->factor_valu && h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL(iba_factor_kernel<true>, grid1, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base, Bx);
+    else if (h->factor_valu) hipLaunchKernelGGL(iba_factor_kernel<false>, grid1, dim3(kFactorThreads), 96u * std::max<uint32_t>(h->max_slots, 1u), st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base, Bx);
     else hipLaunchKernelGGL(iba_factor_mfma_kernel, grid, dim3(64), 0, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base);
     HIP_TRY(h, hipGetLastError());
     return IBA_OK;

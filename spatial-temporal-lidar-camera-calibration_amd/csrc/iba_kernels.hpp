@@ -956,11 +956,20 @@ constexpr int kFactorThreads = IBA_FACTOR_THREADS;
 template <bool MANY, bool P2PIX = false>   // P2PIX: the 3d-2d blocks are IBATestEdge edges (factor_3d2d_kind = 1) — an instantiation of its own: the default kernel's code is untouched
 __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(IBA_FACTOR_WAVES, IBA_FACTOR_WAVES))) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist,
                                                                     const uint32_t* __restrict__ fcount, int flist_stride, int per_cand,
-                                                                    double* __restrict__ partials, int nrec, int rec_base) {
+                                                                    double* __restrict__ partials, int nrec, int rec_base, int B) {
     __shared__ double s_part[kFactorThreads / 64][48];
     __shared__ double s_tr[kFactorThreads / 64][21][65];   // [sum][lane], rows padded against bank conflicts
     extern __shared__ __align__(16) double s_rel[];        // relative poses of the frame's covisible slots: 12 doubles each, sized by the launch for the handle's largest slot count (r04: 62 slots as a static array cost every block 3 KB and the kernel 2 %)
-    const int f = blockIdx.x, b = blockIdx.y;
+    // block -> (keyframe, candidate). B = 0: a (keyframe, candidate) grid — block i runs on XCD i % 8, so with a keyframe count that is a multiple
+    // of 8 a keyframe's candidates share one XCD's L2 and a candidate's keyframes follow each other (its list rows are contiguous). B > 0 (r05, any
+    // other keyframe count: a rank's shard of 25): the association kernels' mapping — keyframe f on XCD f % 8 by construction, its candidates side by
+    // side (a 25-keyframe shard, 64 candidates: 0.146 -> 0.136 ms per call; at 200 keyframes the plain grid is 4 us better and stays).
+    int f = (int)blockIdx.x, b = (int)blockIdx.y;
+    if (B > 0) {
+        const int per_xcd = (dp.n_frames + 7) / 8;
+        f = (int)(blockIdx.x & 7u) + 8 * (int)((blockIdx.x >> 3) / (uint32_t)B); b = (int)((blockIdx.x >> 3) % (uint32_t)B);
+        if (f >= dp.n_frames || (int)((blockIdx.x >> 3) / (uint32_t)B) >= per_xcd) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameHdr& h = dp.frames[f];
     const Cand& c = cands[b];
