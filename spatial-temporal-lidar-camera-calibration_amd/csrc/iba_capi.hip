@@ -1153,7 +1153,11 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
     { NNLayout probe; if (!layout_nn(h, probe)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel"); } }
     h->lstride = std::max(1u, std::min(h->maxK, h->maxKw));
-    h->nn_ns = (int)((h->lstride + kSliceW - 1u) / kSliceW);
+    // ... rounded up to an ODD count (r05): with 8 candidates per block a keyframe has 8 x NS search blocks, and a power of two of them per keyframe
+    // is a pathology of the block -> XCD / memory-channel pattern — measured at 200 x 10 k points with the count forced: 4 slices 0.177 ms, 5: 0.118,
+    // 6: 0.129, 7 (what this shape needs): 0.120, 8: 0.184, 9: 0.126; at 40 x 120 k points (needs 8) 0.169 -> 0.161 ms with 9. The extra slice's
+    // blocks return at once.
+    h->nn_ns = (int)((h->lstride + kSliceW - 1u) / kSliceW) | 1;
 
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
 #define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
