@@ -137,9 +137,16 @@ typedef struct iba_params {
      *      (iba_global.cpp:291-328: every correspondence of a used frame x every covisible keyframe that matches its keypoint; no plane, no
      *      MapPoint, no neighbourhood test), whose cost these are the normal equations of. The 3d-3d blocks are built as in mode 0 when
      *      err_weight[1] > 1e-10 and not at all otherwise (BAError's switch, :214-220): err_weight = {1, 0} is BASELINE's
-     *      "point-to-pixel only" configuration on the Jacobian path. */
+     *      "point-to-pixel only" configuration on the Jacobian path. Mode 1 is an EXTENSION without a reference-run counterpart: the
+     *      reference never constructs the edge, so there is no reference output to validate against (it is checked against the oracle's
+     *      restatement of the functor and an independent autograd evaluation only), and its cost follows this library's Ceres convention
+     *      (0.5 rho) although the edge's reference twin is a g2o edge. */
     int32_t factor_3d2d_kind;
 } iba_params;
+
+/* The ABI version the LIBRARY was built with (IBA_ABI_VERSION of its header). iba_params carries no struct_size: a caller compiled against
+ * an older header would pass a shorter struct. Callers compare iba_abi_version() with their own IBA_ABI_VERSION before iba_create(). */
+int32_t iba_abi_version(void);
 
 /* Output of one BAError() call. The first five fields are the reference's returned tuple
  * (iba_global.cpp:343); the rest are the counters it prints with verborse (:341-342). */

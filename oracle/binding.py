@@ -134,7 +134,16 @@ class Oracle:
     @staticmethod
     def set_exact_sums(on):
         """test aid: add the per-block contributions of the normal equations in long double (see iba_oracle.cpp)"""
-        lib().oracle_set_exact_sums(C.c_int(1 if on else 0))
+        lib().oracle_set_exact_sums(C.c_int(int(on)))   # True / 1: long-double SUMS of the double rows; 2: rows and sums in long double ("the truth")
+
+    def eval_normal_truth(self, params, x):
+        """the normal equations with rows, weights and sums in long double (x87 80-bit), rounded to double at the end: what the reference's formulas are
+        worth at x. Single-threaded (one candidate: ~1 s per 50 k blocks)."""
+        Oracle.set_exact_sums(2)
+        try:
+            return self.eval_normal(params, x, nthreads=1)
+        finally:
+            Oracle.set_exact_sums(0)
 
     def eval_normal(self, params, x, nthreads=1):
         x = np.ascontiguousarray(np.atleast_2d(x), np.float64)

@@ -454,12 +454,45 @@ inline void huber(double a, double s, double& rho0, double& rho1) {
 // doubles as otherwise — are ADDED in long double (x87 80-bit), i.e. the sums are taken (nearly) exactly instead of in the
 // order-dependent double arithmetic of a sequential loop. Used to separate "the device differs from the reference's terms"
 // from "two double summations of 10^5 cancelling terms differ from each other" (tests/test_gpu_golden_and_shapes.py).
-static bool g_exact_sums = false;
+// Mode 2 (round 6) goes one step further: the ROWS themselves are evaluated in long double (DualL<7>: the same expressions as the Dual<7> rows, 64-bit
+// mantissa), the Huber weight and the products in long double too — "the value the reference's formulas have", against which BOTH double evaluations
+// (this file's duals and the device's fused chain) are measured: tests/test_gpu_golden_and_shapes.py holds the device to the truth, not to this
+// file's own rounding.
+static int g_exact_sums = 0;
 
 void EvalFactors(const Oracle& O, const iba_params& prm, const double* x, iba_normal_out& out, bool multithread = false) {
     std::memset(&out, 0, sizeof(out));
     const long n = (long)O.factors.size();
     (void)multithread;
+    if (g_exact_sums == 2) {
+        using L7 = DualL<7>;
+        long double LH[49] = {0}, Lb[7] = {0}, Lcost = 0, Lchi2 = 0;
+        L7 xl[7]; for (int i = 0; i < 7; ++i) xl[i] = L7(x[i], i);
+        std::vector<L7> e(64);
+        for (long fi = 0; fi < n; ++fi) {
+            const Factor& f = O.factors[fi];
+            const int rows = f.rows();
+            if (rows > 64) continue;
+            eval_any_factor<L7>(f, xl, e.data());
+            long double s = 0; for (int i = 0; i < rows; ++i) s += e[i].a * e[i].a;
+            const long double a = (f.kind == 0 || f.kind == 3) ? prm.robust_kernel_delta : prm.robust_kernel_3ddelta, bb = a * a;
+            long double rho0 = s, rho1 = 1.0L;
+            if (s > bb) { const long double rr = sqrtl(s); rho0 = 2.0L * a * rr - bb; rho1 = a / rr; }
+            Lcost += 0.5L * rho0; Lchi2 += s;
+            for (int i = 0; i < rows; ++i)
+                for (int q = 0; q < 7; ++q) {
+                    Lb[q] += rho1 * e[i].v[q] * e[i].a;
+                    for (int c = 0; c < 7; ++c) LH[q * 7 + c] += rho1 * e[i].v[q] * e[i].v[c];
+                }
+            out.n_residuals += rows;
+            if (f.kind == 0 || f.kind == 3) out.n_factor_3d2d++; else if (f.kind == 1) out.n_factor_p2pl++; else out.n_factor_p2pt++;
+        }
+        for (int i = 0; i < 49; ++i) out.H[i] = (double)LH[i];
+        for (int i = 0; i < 7; ++i) out.b[i] = (double)Lb[i];
+        out.cost = (double)Lcost; out.chi2 = (double)Lchi2;
+        out.frames_used = O.bp_frames_used; out.n_corr = O.bp_n_corr;
+        return;
+    }
     if (g_exact_sums) {
         long double LH[49] = {0}, Lb[7] = {0}, Lcost = 0, Lchi2 = 0;
         double r[64], J[64 * 7];
@@ -590,7 +623,7 @@ int oracle_eval_factors(void* h, const iba_params* p, const double* x, int B, ib
     for (int b = 0; b < B; ++b) EvalFactors(*(Oracle*)h, *p, x + 7 * b, out[b]);
     return 0;
 }
-void oracle_set_exact_sums(int on) { g_exact_sums = on != 0; }
+void oracle_set_exact_sums(int on) { g_exact_sums = on; }   // 0 off, 1 long-double sums of the double rows, 2 long-double rows and sums
 void oracle_set_frame_range(void* h, int f_begin, int f_end) { ((Oracle*)h)->bp_f_begin = f_begin; ((Oracle*)h)->bp_f_end = f_end; }
 int oracle_eval_normal(void* h, const iba_params* p, const double* x, int B, iba_normal_out* out, int nthreads) {
 #ifdef _OPENMP
@@ -728,39 +761,45 @@ int oracle_block_forward_error(void* h, const double* x, double* err, int64_t* n
 // in double, from explicit inputs: R, t and their derivatives (dR[k] for k < 3, dt[k] for k < 6), the scale s, the plane normal n0.
 // variant: how the cancelling factor (ax - xz az) is formed: 0 as the kernel does, 1 from the exact identity (ax tz - az tx) / P1z.
 // out: rows x 8 doubles (r, J[7]).
+static inline double kfdot3(double a0, double b0, double a1, double b1, double a2, double b2) { return std::fma(a2, b2, std::fma(a1, b1, a0 * b0)); }
+static inline double kfdot3c(double a0, double b0, double a1, double b1, double a2, double b2, double c) { return std::fma(a2, b2, std::fma(a1, b1, std::fma(a0, b0, c))); }
 static void plane_block_kernel_order(const Factor& f, const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], double s, const double* n0, int variant, double* out) {
+    // round 6: the kernel's chain is a fixed sequence of IEEE operations with EXPLICIT fused multiply-adds (csrc/iba_kernels.hpp, plane_core:
+    // fdot3 / fdot3c); std::fma is the same correctly rounded operation, so this function reproduces the device's rows bit for bit
     const double p0[3] = {f.p0.x, f.p0.y, f.p0.z};
     double p0c[3], n0c[3];
-    for (int r = 0; r < 3; ++r) { p0c[r] = ((R[r * 3] * p0[0] + R[r * 3 + 1] * p0[1]) + R[r * 3 + 2] * p0[2]) + t[r]; n0c[r] = (R[r * 3] * n0[0] + R[r * 3 + 1] * n0[1]) + R[r * 3 + 2] * n0[2]; }
+    for (int r = 0; r < 3; ++r) { p0c[r] = kfdot3c(R[r * 3], p0[0], R[r * 3 + 1], p0[1], R[r * 3 + 2], p0[2], t[r]); n0c[r] = kfdot3(R[r * 3], n0[0], R[r * 3 + 1], n0[1], R[r * 3 + 2], n0[2]); }
     const double Cxz = (f.u0 - f.cx) / f.fx, Cyz = (f.v0 - f.cy) / f.fy;
-    const double num = (n0c[0] * p0c[0] + n0c[1] * p0c[1]) + n0c[2] * p0c[2];
-    const double den = (Cxz * n0c[0] + Cyz * n0c[1]) + n0c[2];
-    const double Z0 = num / den, iden = 1.0 / den;
+    const double num = kfdot3(n0c[0], p0c[0], n0c[1], p0c[1], n0c[2], p0c[2]);
+    const double den = std::fma(Cyz, n0c[1], std::fma(Cxz, n0c[0], n0c[2]));
+    const double iden = 1.0 / den, Z0 = num * iden;
     double z6[6];
-    for (int kk = 0; kk < 6; ++kk) {
-        double dpv[3], dnv[3] = {0, 0, 0};
+    for (int kk = 0; kk < 3; ++kk) {
+        double dn[3], dq[3];
         for (int r = 0; r < 3; ++r) {
-            dpv[r] = dt[kk][r];
-            if (kk < 3) { dpv[r] += (dR[kk][r * 3] * p0[0] + dR[kk][r * 3 + 1] * p0[1]) + dR[kk][r * 3 + 2] * p0[2]; dnv[r] = (dR[kk][r * 3] * n0[0] + dR[kk][r * 3 + 1] * n0[1]) + dR[kk][r * 3 + 2] * n0[2]; }
+            dn[r] = kfdot3(dR[kk][r * 3], n0[0], dR[kk][r * 3 + 1], n0[1], dR[kk][r * 3 + 2], n0[2]);
+            dq[r] = kfdot3c(dR[kk][r * 3], p0[0], dR[kk][r * 3 + 1], p0[1], dR[kk][r * 3 + 2], p0[2], dt[kk][r]);
         }
-        const double dnum = ((dnv[0] * p0c[0] + dnv[1] * p0c[1]) + dnv[2] * p0c[2]) + ((n0c[0] * dpv[0] + n0c[1] * dpv[1]) + n0c[2] * dpv[2]);
-        const double dden = (Cxz * dnv[0] + Cyz * dnv[1]) + dnv[2];
-        z6[kk] = (dnum - Z0 * dden) * iden;
+        const double dnum = kfdot3c(n0c[0], dq[0], n0c[1], dq[1], n0c[2], dq[2], kfdot3(dn[0], p0c[0], dn[1], p0c[1], dn[2], p0c[2]));
+        const double dden = std::fma(Cyz, dn[1], std::fma(Cxz, dn[0], dn[2]));
+        z6[kk] = std::fma(-Z0, dden, dnum) * iden;
     }
+    for (int kk = 3; kk < 6; ++kk) z6[kk] = kfdot3(n0c[0], dt[kk][0], n0c[1], dt[kk][1], n0c[2], dt[kk][2]) * iden;
     const double P0x = Cxz * Z0, P0y = Cyz * Z0, P0z = Z0;
     for (size_t i = 0; i < f.u1.size(); ++i) {
         const double* rel = f.R[i].m;
         const double t3[3] = {f.t[i].x, f.t[i].y, f.t[i].z};
         const double tx = t3[0] * s, ty = t3[1] * s, tz = t3[2] * s;
-        const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx, P1y = ((rel[3] * P0x + rel[4] * P0y) + rel[5] * P0z) + ty, P1z = ((rel[6] * P0x + rel[7] * P0y) + rel[8] * P0z) + tz;
-        const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;   // (round 5: the kernel forms the residual from the same reciprocal as its derivatives)
-        const double ru = (f.fx * xz + f.cx) - f.u1[i], rv = (f.fy * yz + f.cy) - f.v1[i];
-        const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[3] * Cxz + rel[4] * Cyz) + rel[5], az = (rel[6] * Cxz + rel[7] * Cyz) + rel[8];
+        const double P1x = kfdot3c(rel[0], P0x, rel[1], P0y, rel[2], P0z, tx), P1y = kfdot3c(rel[3], P0x, rel[4], P0y, rel[5], P0z, ty), P1z = kfdot3c(rel[6], P0x, rel[7], P0y, rel[8], P0z, tz);
+        const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;   // (the kernel forms the residual from the same reciprocal as its derivatives)
+        const double ru = std::fma(f.fx, xz, f.cx) - f.u1[i], rv = std::fma(f.fy, yz, f.cy) - f.v1[i];
+        const double ax = std::fma(rel[1], Cyz, std::fma(rel[0], Cxz, rel[2])), ay = std::fma(rel[4], Cyz, std::fma(rel[3], Cxz, rel[5])), az = std::fma(rel[7], Cyz, std::fma(rel[6], Cxz, rel[8]));
         double cu, cv;
-        if (variant == 0) { cu = ax - xz * az; cv = ay - yz * az; }
+        if (variant == 0) { cu = std::fma(-xz, az, ax); cv = std::fma(-yz, az, ay); }
         else { cu = (ax * tz - az * tx) * iz; cv = (ay * tz - az * ty) * iz; }   // P1 = Z0 a + s t  =>  ax - (P1x / P1z) az = (ax tz - az tx) / P1z exactly
-        const double gu = f.fx * iz * cu, gv = f.fy * iz * cv;
-        const double hu = f.fx * iz * (t3[0] - xz * t3[2]), hv = f.fy * iz * (t3[1] - yz * t3[2]);
+        const double fxiz = f.fx * iz, fyiz = f.fy * iz;
+        const double gu = fxiz * cu, gv = fyiz * cv;
+        const double hu = fxiz * std::fma(-xz, t3[2], t3[0]), hv = fyiz * std::fma(-yz, t3[2], t3[1]);
         double* o0 = out + 8 * (2 * i); double* o1 = out + 8 * (2 * i + 1);
         o0[0] = ru; o1[0] = rv;
         for (int k = 0; k < 6; ++k) { o0[1 + k] = gu * z6[k]; o1[1 + k] = gv * z6[k]; }

@@ -44,6 +44,7 @@ def build_extension(force=False):
 
 
 _lib = None
+ABI_VERSION = 2   # IBA_ABI_VERSION of include/iba_mi355x.h these ctypes structs mirror
 
 
 def load_library():
@@ -52,6 +53,9 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise IbaError(2, f"{LIB_PATH} is not built (run __graft_entry__.build()); there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
+        L.iba_abi_version.restype = C.c_int32
+        if L.iba_abi_version() != ABI_VERSION:   # iba_params has no struct_size: a stale library would read past (or short of) the struct
+            raise IbaError(1, f"{LIB_PATH} speaks ABI {L.iba_abi_version()}, these bindings ABI {ABI_VERSION}: rebuild the library")
         L.iba_last_error.restype = C.c_char_p
         L.iba_last_error.argtypes = [C.c_void_p]
         L.iba_create.argtypes = [C.POINTER(IbaProblemDesc), C.POINTER(IbaParams), C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]

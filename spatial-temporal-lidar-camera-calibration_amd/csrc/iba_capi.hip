@@ -25,6 +25,7 @@
 #include "iba_mads.hpp"
 #include "iba_mads_glue.hpp"
 #include "iba_split_kernels.hpp"
+#include "iba_factor2_kernel.hpp"
 #include "iba_types.hpp"
 
 using namespace iba;
@@ -69,6 +70,13 @@ struct iba_handle {
     uint32_t maxKw = 0;                   // max over frames of the keypoints that can own a term (MapPoint or covisible match)
     int assoc_dbg = 0;
     bool factor_valu = true;              // IBA_FACTOR_MFMA=1 selects the matrix-core variant of the factor kernel (slower on gfx950: see iba_kernels.hpp)
+    // iba_factor2_kernel (r06): one wave per equal share of a candidate's whole work list (iba_factor2_kernel.hpp)
+    bool factor_v2 = true;                // IBA_FACTOR_V1=1 (debug): the one-wave-per-(keyframe, candidate) kernel of rounds 2-5
+    int factor_slots = 2048;              // wave slots of the device at two waves per SIMD: CUs x 8
+    int factor_waves_forced = 0;          // IBA_FACTOR_WAVES_PER_CAND (debug): ranges per candidate instead of the rule in factor_waves()
+    F2Layout f2lay{};
+    DevBuf<double> d_ffr;                 // per keyframe: camera, pose, table offsets, relative poses of its covisible slots — one contiguous record (kFfrHead + 12 max_slots doubles)
+    DevBuf<double2> d_kp_c;               // ((u - cx) / fx, (v - cy) / fy) of every keypoint: IBA_PlaneFactor's ray (IBACalib2.hpp:165), divided once here instead of per residual block
     int nn_dbg = 0;                       // IBA_NN_DBG: cut the search kernel short (timing attribution; results are garbage)
     int nn_cg_max = 8;                    // candidates per search block (power of two <= kMaxGroup)
     bool nn_cg_fixed = false;             // IBA_NN_CG given: no adaptation to the batch size
@@ -559,8 +567,9 @@ hipError_t wait_stream(iba_handle* h, hipStream_t st) {
 // block publishes there (iba_reduce2_kernel), not the stream — whose completion reaches the host 3-4 us later. Falls back to the stream
 // after 2 ms, and whenever the chain did not arm the flag (event timing on, an empty handle, IBA_DONE_FLAG=0).
 hipError_t wait_done(iba_handle* h, hipStream_t st) {
-    if (h->done_armed) {
-        h->done_armed = false;
+    const bool armed = h->done_armed;
+    h->done_armed = false;
+    if (armed && h->spin_wait) {   // (a caller that asked for blocking waits only — spin_wait = 0 — never polls: not the stream, not this word)
         const volatile unsigned long long* f = h->h_done;
         const auto t0 = std::chrono::steady_clock::now();
         for (int polls = 1;; ++polls) {
@@ -571,8 +580,29 @@ hipError_t wait_done(iba_handle* h, hipStream_t st) {
     return wait_stream(h, st);
 }
 
+// ranges (= waves = records) per candidate of iba_factor2_kernel for a batch of B: the device's wave slots shared out, at most one per keyframe
+// (a range of less than a keyframe's list is mostly start-up), at least one. 0: the batch runs on the kernels that write one record per keyframe.
+int factor_waves(const iba_handle* h, int B) {
+    if (!h->factor_v2 || !h->factor_valu || h->n_frames == 0 || h->n_frames > kF2MaxFrames || !h->d_ffr.p || h->f2lay.total == 0) return 0;
+    if (h->factor_waves_forced > 0) return std::min(h->factor_waves_forced, h->n_frames);
+    return std::max(1, std::min(h->n_frames, h->factor_slots / std::max(B, 1)));
+}
+// records per candidate the factor kernel of this launch writes
+int factor_records(const iba_handle* h, int B) { const int w = factor_waves(h, B); return w > 0 ? w : h->n_frames; }
+
 iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, double* partials, int nrec, int rec_base, hipStream_t st) {
     if (h->n_frames == 0) return IBA_OK;
+    if (const int W = factor_waves(h, B)) {
+        const uint4* fl2 = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc2 = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
+        const dim3 grid2(8u * (uint32_t)((W + 7) / 8) * (uint32_t)B);
+        const bool many = h->max_slots > (uint32_t)kCovisWord;
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid2, dim3(64), h->f2lay.total, st, h->dev_problem(), h->dprm, dc, fl2, fc2, (int)h->lstride, per_cand, partials, nrec, rec_base, B, W,
+                                                      (const double*)h->d_ffr.p, (const double2*)h->d_kp_c.p, h->f2lay); };
+        if (h->dprm.p2pix) { if (many) go(iba_factor2_kernel<true, true>); else go(iba_factor2_kernel<false, true>); }
+        else { if (many) go(iba_factor2_kernel<true, false>); else go(iba_factor2_kernel<false, false>); }
+        HIP_TRY(h, hipGetLastError());
+        return IBA_OK;
+    }
     // (a handle whose frames hold no keypoint at all still launches: every list is empty and the kernel writes zero records,
     // which is what the sums over the records expect)
     const dim3 grid(h->n_frames, B);
@@ -601,13 +631,18 @@ iba_status ensure_lists(iba_handle* h, int B, hipStream_t st) {
     B = std::max(B, h->assoc_cap);
     HIP_TRY(h, hipStreamSynchronize(st)); HIP_TRY(h, hipStreamSynchronize(h->stream));
     const size_t nf1 = (size_t)std::max(h->n_frames, 1);
+    // a growth that fails half-way must not leave the old capacities standing over released buffers (the next call of at most the old size
+    // would launch on null pointers): the handle forgets its capacities first and learns the new ones only when every buffer exists
+    const int old_part_cap = h->part_cap;
+    h->assoc_cap = 0;
+    if (old_part_cap < B) h->part_cap = 0;
     h->d_flist.release(); h->d_fcount.release(); h->d_lcount.release();
     HIP_TRY(h, h->d_flist.alloc((size_t)B * nf1 * h->lstride));
     HIP_TRY(h, h->d_fcount.alloc((size_t)B * nf1));
     HIP_TRY(h, h->d_lcount.alloc((size_t)B * nf1));
     h->d_frefit.release();
     if (!h->params.plane_cache) HIP_TRY(h, h->d_frefit.alloc((size_t)std::min(B, (int)IBA_MAX_BATCH) * nf1 * h->lstride));   // (a chain of refitted planes takes at most IBA_MAX_BATCH candidates)
-    if (h->part_cap < B) {
+    if (old_part_cap < B) {
         h->d_frame_partials.release(); h->d_nn_partials.release(); h->d_he.release();
         HIP_TRY(h, h->d_frame_partials.alloc((size_t)B * std::max(h->nrec, 1) * kPartialStride));
         HIP_TRY(h, h->d_nn_partials.alloc((size_t)B * nf1 * h->nn_ns * kNNPartial));
@@ -841,6 +876,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         iba_status s = finish_jets(h, st); if (s != IBA_OK) return s;   // the GPU has been busy with the values since stage_cands
         s = launch_factors(h, dc, B, 1, h->d_frame_partials.p, h->nrec, nf, st); if (s != IBA_OK) return s;
     }
+    const int n_fact = factors ? factor_records(h, B) : 0;   // records the factor kernel wrote behind the association's nf (iba_factor2_kernel: one per range)
     // the sums — and, for a cost evaluation, K7: the hand-eye term of every counted (candidate, frame), evaluated where it is summed
     {
         const double* nnp = search ? h->d_nn_partials.p : (const double*)nullptr;
@@ -850,9 +886,9 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
         unsigned long long* df = flag ? h->h_done_dev : nullptr;
         if (flag) ++h->done_seq;
         h->done_armed = flag;
-        if (he_mode == 2) hipLaunchKernelGGL(iba_reduce2_kernel<2>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
-        else if (he_mode == 1) hipLaunchKernelGGL(iba_reduce2_kernel<1>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
-        else hipLaunchKernelGGL(iba_reduce2_kernel<0>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
+        if (he_mode == 2) hipLaunchKernelGGL(iba_reduce2_kernel<2>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, n_fact, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
+        else if (he_mode == 1) hipLaunchKernelGGL(iba_reduce2_kernel<1>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, n_fact, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
+        else hipLaunchKernelGGL(iba_reduce2_kernel<0>, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nrec, nf, n_fact, nnp, nn_nrec, d_partials, dp.frames, dc, h->d_he.p, df, h->d_done_ctr.p, h->done_seq);
     }
     HIP_TRY(h, hipGetLastError());
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev2, st)); h->timing_recorded = true; h->timing_split = true; }
@@ -863,7 +899,12 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
 // enqueued. A chain that fails between the two (staging launch, event, pair search) would leave slots valid for lists that were never
 // built, and a later call inside their bound would associate on stale or empty lists: a failed chain invalidates every slot.
 iba_status chain_status(iba_handle* h, iba_status s) {
-    if (s != IBA_OK && h) for (auto& ps : h->pslot) ps.valid = false;
+    if (s != IBA_OK && h) {
+        for (auto& ps : h->pslot) ps.valid = false;
+        // a chain that failed after its first launch never recorded its ring slot's event (chain_done runs at the successful end), but a kernel
+        // that reads the pinned candidates may be in flight: drain the device before the slot can be staged again (error path only)
+        (void)hipDeviceSynchronize();
+    }
     return s;
 }
 
@@ -887,6 +928,7 @@ iba_status eval_cost_partial_impl(iba_handle* h, const double* x, int B, double*
 
 extern "C" {
 
+int32_t iba_abi_version(void) { return IBA_ABI_VERSION; }
 const char* iba_last_error(const iba_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 int64_t iba_num_points(const iba_handle* h) { return h ? h->n_points : 0; }
 int64_t iba_num_keypoints(const iba_handle* h) { return h ? h->n_keypoints : 0; }
@@ -896,6 +938,7 @@ void iba_destroy(iba_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
+    h->d_ffr.release(); h->d_kp_c.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
     h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->fkp.release(); h->kp_fl2.release(); h->d_diag.release(); h->d_anchor.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
@@ -1130,6 +1173,8 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
     if (const char* e = std::getenv("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
+    if (const char* e = std::getenv("IBA_FACTOR_V1")) h->factor_v2 = std::atoi(e) == 0;
+    if (const char* e = std::getenv("IBA_FACTOR_WAVES_PER_CAND")) h->factor_waves_forced = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("IBA_COMMON_PAIRS")) h->common_mode = std::atoi(e);
     if (const char* e = std::getenv("IBA_NN_SETS")) h->nn_sets = std::atoi(e) != 0;
     if (const char* e = std::getenv("IBA_SPIN_WAIT")) h->spin_wait = std::atoi(e) != 0;
@@ -1166,6 +1211,37 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     for (size_t k = 0; k < (size_t)kp_base; ++k) { h->h_kp_uv[2 * k] = kp_uv[k].x; h->h_kp_uv[2 * k + 1] = kp_uv[k].y; }
     UP(kp_uv, kp_uv); UP(kp_mp, kp_mp); UP(kp_fl, kp_fl); UP(coarse_start, coarse_start); UP(crec, crec); UP(bitmap, bitmap); UP(match_uv, match_uv); UP(mpk, mpk); UP(fkp, fkp);
     if (many_slots) UP(kp_fl2, kp_fl2);
+    {   // iba_factor2_kernel's per-keyframe records and per-keypoint rays (iba_factor2_kernel.hpp)
+        const uint32_t gstride = (uint32_t)kFfrHead + 12u * h->max_slots;
+        std::vector<double> ffr((size_t)std::max(nf, 1) * gstride, 0.0);
+        std::vector<double2> kp_c(kp_base);
+        parallel_for(nf, [&](int lf) {
+            const FrameHdr& x = hdr[lf];
+            double* r = ffr.data() + (size_t)lf * gstride;
+            r[0] = x.fx; r[1] = x.fy; r[2] = x.cx; r[3] = x.cy;
+            for (int i = 0; i < 12; ++i) r[4 + i] = x.Tcw[i];
+            const uint64_t u64s[3] = {x.kp_base, x.pt_base, x.match_base};
+            std::memcpy(&r[16], u64s, 24);
+            const uint32_t u32s[2] = {x.K, x.n_slots};
+            std::memcpy(&r[19], u32s, 8);
+            for (uint32_t sl = 0; sl < x.n_slots; ++sl) for (int i = 0; i < 12; ++i) r[kFfrHead + 12 * sl + i] = slots[x.slot_base + sl].rel[i];
+            for (uint32_t k = 0; k < x.K; ++k) {   // (u0 - cx) / fx with u0 the float pixel widened: the quotient IBA_PlaneFactor forms (IBACalib2.hpp:165-166)
+                const float2 uv = kp_uv[x.kp_base + k];
+                kp_c[x.kp_base + k] = double2{((double)uv.x - x.cx) / x.fx, ((double)uv.y - x.cy) / x.fy};
+            }
+        });
+        UP(d_ffr, ffr); UP(d_kp_c, kp_c);
+        // LDS plan of one wave: prefix sums | derivative halves of the candidate | three block queues | keyframe ring ; the final reduction (21 x 65 doubles) over queues + ring
+        F2Layout& L = h->f2lay;
+        L.ffr_stride = gstride; L.ring_stride = (uint32_t)kFfrHead + (uint32_t)kFfrSlotRing * h->max_slots;
+        L.ring_slots = 8u; while (L.ring_slots > 2u && L.ring_slots * L.ring_stride * 8u > 8192u) L.ring_slots >>= 1;
+        L.off_pre = 0u; L.off_cand = align_up(4u * ((uint32_t)nf + 1u), 16u); L.off_q = L.off_cand + 90u * 8u;
+        L.off_ring = L.off_q + 3u * kF2Queue * 8u; L.off_tr = L.off_q;
+        L.total = std::max(L.off_ring + L.ring_slots * L.ring_stride * 8u, L.off_tr + 21u * 65u * 8u);
+        if (L.total > 64u * 1024u) L.total = 0u;   // (a handle with that many keyframes or covisible slots keeps the one-record-per-keyframe kernel)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->factor_slots = cus * 8;
+    }
 #undef UP
     hipError_t er;
     if ((er = h->plane_cost.alloc(pt_base)) != hipSuccess) return bail("alloc plane_cost", er);
@@ -1638,9 +1714,10 @@ static iba_status eval_factors_partial_impl(iba_handle* h, const double* x, int 
     Cand* dc = nullptr;
     iba_status s = stage_cands(h, x, B, st, &dc, pre); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    s = launch_factors(h, dc, B, 0, h->d_frame_partials.p, h->nfb, 0, st); if (s != IBA_OK) return s;
+    const int nfr = factor_records(h, B);   // (records per candidate: the stride of this launch's records and the count of its sums)
+    s = launch_factors(h, dc, B, 0, h->d_frame_partials.p, nfr, 0, st); if (s != IBA_OK) return s;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, h->nfb, d_partials);
+    hipLaunchKernelGGL(iba_reduce_kernel, dim3(B), dim3(kReduceThreads), 0, st, h->d_frame_partials.p, nfr, d_partials);
     HIP_TRY(h, hipGetLastError());
     // the frozen problem's frame / correspondence counts (iba_build_problem) ride in their slots of the block
     hipLaunchKernelGGL(iba_set_slots_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_partials, B, (int)P_FRAMES_N, (double)h->frozen_frames, (int)P_NCORR_N, (double)h->frozen_ncorr);
@@ -1816,7 +1893,7 @@ iba_status eval_partial_cands(iba_handle* h, const Cand* hc, int B, EvalKind kin
 iba_status build_problem_cands(iba_handle* h, const Cand* hc) { return build_problem_impl(h, nullptr, hc); }
 int chain_capacity(const iba_handle* h) { return h ? chain_limit(h) : 0; }
 iba_status reserve_batch(iba_handle* h, int B) {
-    if (!h || B < 1 || B > h->chain_cap) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    if (!h || B < 1 || B > chain_limit(h)) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");   // (the evaluators' own limit: chain_limit)
     HIP_TRY(h, hipSetDevice(h->device));
     return ensure_lists(h, B, h->stream);
 }

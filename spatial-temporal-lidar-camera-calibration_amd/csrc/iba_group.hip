@@ -321,7 +321,7 @@ iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* p
         W_HIP(g, i, hipMalloc((void**)&g->d_part[i], sizeof(double) * (size_t)kMaxChain * g->stride));
         W_HIP(g, i, hipHostMalloc((void**)&g->h_parts[i], sizeof(double) * (size_t)kMaxChain * g->stride, hipHostMallocMapped));
         W_HIP(g, i, hipHostGetDevicePointer((void**)&g->h_parts_dev[i], g->h_parts[i], 0));
-        W_IBA(g, i, reserve_batch(g->h[i], IBA_MAX_BATCH));   // no allocation inside an evaluation (several threads are inside HIP then)
+        W_IBA(g, i, reserve_batch(g->h[i], std::min((int)IBA_MAX_BATCH, chain_capacity(g->h[i]))));   // no allocation inside an evaluation (several threads are inside HIP then)
         return IBA_OK;
     });
     if (s == IBA_OK && !host_reduce) {

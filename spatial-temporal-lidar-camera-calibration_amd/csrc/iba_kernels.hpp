@@ -709,22 +709,24 @@ __global__ void iba_kernarg_probe_kernel(KArgs ka_by_value, int32_t* ok) {
 // IRLS weights as Ceres' Corrector applies them (rho'' <= 0), accumulated as the upper triangle of
 // H = sum w J^T J, b = sum w J^T r. Derivatives are analytic: the chain rule through the same
 // expressions the reference's Jets differentiate, with dR/dx, dt/dx from the host duals (Cand).
-// The Jacobian path is compiled WITHOUT FMA contraction, like the cost path: measured on the C2 / C3 scenes
-// (tools/entry_parity_c2.py, r02), every entry of H and b above 1e-6 of the largest then agrees with the oracle's forward-mode
-// duals to 6e-14 .. 2e-13 of ITSELF (cost 2e-12); with contraction the same figures are 5e-11 .. 1.2e-10 — inside BASELINE.md's
-// 1e-10 gate only just, for 0.05 ms per 64 candidates (0.17 -> 0.22 ms). -DIBA_JAC_FMA builds the contracted variant.
-// (What neither build can remove: a plane factor whose viewing ray lies almost in its plane — Z0 = num / den with a
-// cancelling den, residuals of 10^4 px, Jacobian entries of 10^9 — carries a relative uncertainty of ~1e-10 in the
-// reference's own double arithmetic; one such block shifts entries of b by up to 1e-7 of themselves in either build.)
-#ifdef IBA_JAC_FMA
-#define IBA_JAC_CONTRACT _Pragma("clang fp contract(fast)")
-#else
+// Round 6: the chain is written with EXPLICIT fused multiply-adds (fma()). The library is still compiled with -ffp-contract=off, so
+// exactly the products written as fma() fuse and nothing else: the arithmetic is a fixed sequence of IEEE operations that the oracle's
+// kernel-order mirror (oracle/iba_oracle.cpp, plane_block_kernel_order) repeats with std::fma bit for bit. A fused chain rounds once
+// where the unfused one rounds twice: per entry it is as close to the exact value as the reference's own double arithmetic or closer
+// (measured against a long-double evaluation: tests/test_gpu_conditioning.py), and it is a third fewer f64 instructions
+// in a kernel that is bound by f64 issue. (Rounds 2-5 kept the chain unfused and offered the compiler's contraction as a build switch,
+// -DIBA_JAC_FMA: faster, but which products fuse was then the compiler's choice and could not be mirrored on the CPU.)
+// What no build can remove: a plane factor whose viewing ray lies almost in its plane — Z0 = num / den with a cancelling den,
+// residuals of 10^4 px, Jacobian entries of 10^9 — carries a relative uncertainty of ~1e-10 in the reference's own double
+// arithmetic; one such block shifts entries of b by up to 1e-7 of themselves.
 #define IBA_JAC_CONTRACT _Pragma("clang fp contract(off)")
-#endif
 // the accumulation H += (w J_i) J_j of terms that are already formed may fuse its multiply-add: that changes the sums by parts in
 // 1e-16 of a term, not by the cancellation the Jacobian chain is sensitive to (measured: per-entry agreement unchanged)
 #define IBA_ACC_CONTRACT _Pragma("clang fp contract(fast)")
 struct NAcc { double H[28], b[7], chi2, cost, nf2d, nfpl, nfpt, nres; };
+
+__device__ __forceinline__ double fdot3(double a0, double b0, double a1, double b1, double a2, double b2) { return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0)); }
+__device__ __forceinline__ double fdot3c(double a0, double b0, double a1, double b1, double a2, double b2, double c) { return __builtin_fma(a2, b2, __builtin_fma(a1, b1, __builtin_fma(a0, b0, c))); }
 
 __device__ __forceinline__ void huber_w(double a, double s, double& rho0, double& w) {
     const double bb = a * a;
@@ -734,69 +736,82 @@ __device__ __forceinline__ void huber_w(double a, double s, double& rho0, double
 // H (upper, row-major i<=j) index
 __device__ __forceinline__ int hidx(int i, int j) { return i * 7 - (i * (i - 1)) / 2 + (j - i); }
 
+struct Cam4 { double fx, fy, cx, cy; };
+
 // IBA_PlaneFactor core: calls slot(ru, rv, gu, gv, hu, hv) per matched covisible KF, where the two residual rows are
 // (ru, rv) and their Jacobian rows are [gu * z6, hu], [gv * z6, hv] (z6 = dZ0/dx[0:6], last column d/ds).
-// MANY: the frame may have more covisible keyframes than the flag word has match bits (a second pass over kp_fl2); the instantiation
-// without it is the loop of rounds 1-3 (the two-word loop cost iba_factor_kernel 3 % at three covisible keyframes: handles whose
-// frames all have at most 30 launch the <false> kernel)
-template <bool MANY = true, class SlotFn>
-__device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K,
-                                                 double u0, double v0, const double* p0, const double* n0, double* z6, SlotFn slot, const double* rel_lds = nullptr) {
-    IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
+// Inputs: R, t and their derivatives (dR[k] for k < 3, dt[k] for k < 6) — pointers, so that a kernel may keep them where it likes (scalar
+// registers, LDS) —, the camera of the keypoint's keyframe, (Cxz, Cyz) = ((u0 - cx) / fx, (v0 - cy) / fy) (the host divides once per keypoint:
+// DevProblem::kp_c; the same IEEE quotient a kernel would form), the match words of the keypoint (m0: slots 0..29, m1: slots 30..61, MANY
+// only) and its row of the match table, and rel_of(slot, ts) -> the 12 doubles [R_i | t_i] of a covisible slot, ts = s t_i (IBACalib2.hpp:175).
+// The keypoint's matches in its first kMatchPre covisible slots, loaded UNCONDITIONALLY (a slot without a match holds NaN and its bit is clear): the
+// loads need neither the flag word nor each other — a kernel issues them with its other gathers instead of one dependent round trip per matched slot
+// (r06; the slots beyond, if a keyframe has them, are still fetched as the loop reaches them)
+constexpr int kMatchPre = 4;
+struct MatchPre { float u0, v0, u1, v1, u2, v2, u3, v3; };   // (plain floats: a struct of float2 was kept in scratch memory by the selects below)
+__device__ __forceinline__ MatchPre load_match_pre(const float2* mrow, size_t K, uint32_t n_slots) {
+    const float2 z = make_float2(0.f, 0.f);
+    const float2 a = 0u < n_slots ? mrow[0] : z, b = 1u < n_slots ? mrow[K] : z, c = 2u < n_slots ? mrow[2 * K] : z, d = 3u < n_slots ? mrow[3 * K] : z;
+    return MatchPre{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+}
+template <bool MANY, class RelFn, class SlotFn>
+__device__ __forceinline__ int plane_core(const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], const Cam4& cam, double Cxz, double Cyz,
+                                          const double* p0, const double* n0, double* z6, uint32_t m0, uint32_t m1, const float2* mrow, size_t K, const MatchPre mp, RelFn rel_of, SlotFn slot) {
+    IBA_JAC_CONTRACT
     double p0c[3], n0c[3];
     for (int r = 0; r < 3; ++r) {
-        p0c[r] = ((c.R[r * 3] * p0[0] + c.R[r * 3 + 1] * p0[1]) + c.R[r * 3 + 2] * p0[2]) + c.t[r];
-        n0c[r] = (c.R[r * 3] * n0[0] + c.R[r * 3 + 1] * n0[1]) + c.R[r * 3 + 2] * n0[2];
+        p0c[r] = fdot3c(R[r * 3], p0[0], R[r * 3 + 1], p0[1], R[r * 3 + 2], p0[2], t[r]);
+        n0c[r] = fdot3(R[r * 3], n0[0], R[r * 3 + 1], n0[1], R[r * 3 + 2], n0[2]);
     }
-    const double Cxz = (u0 - h.cx) / h.fx, Cyz = (v0 - h.cy) / h.fy;
-    const double num = (n0c[0] * p0c[0] + n0c[1] * p0c[1]) + n0c[2] * p0c[2];
-    const double den = (Cxz * n0c[0] + Cyz * n0c[1]) + n0c[2];
-    const double Z0 = num / den;
-    const double iden = 1.0 / den;   // derivative rows only: 1 ulp-level differences are inside the 1e-10 budget of H, b
-    for (int kk = 0; kk < 6; ++kk) {
-        double dpv[3], dnv[3] = {0, 0, 0};
+    const double num = fdot3(n0c[0], p0c[0], n0c[1], p0c[1], n0c[2], p0c[2]);
+    const double den = __builtin_fma(Cyz, n0c[1], __builtin_fma(Cxz, n0c[0], n0c[2]));
+    const double iden = 1.0 / den;
+    const double Z0 = num * iden;   // (one division for the depth and its derivatives)
+    // a ROLLED loop over the three rotation parameters: 12 derivative constants are live at a time, not 45 (a kernel that keeps them in LDS would
+    // otherwise hold them all in vector registers beside its 41 sums); the result lands in its register through selects
+    double zr0 = 0, zr1 = 0, zr2 = 0;
+#pragma unroll 1
+    for (int kk = 0; kk < 3; ++kk) {
+        const double* A = dR[kk]; const double* tk = dt[kk];
+        double dn[3], dq[3];
         for (int r = 0; r < 3; ++r) {
-            dpv[r] = c.dt[kk][r];
-            if (kk < 3) {
-                dpv[r] += (c.dR[kk][r * 3] * p0[0] + c.dR[kk][r * 3 + 1] * p0[1]) + c.dR[kk][r * 3 + 2] * p0[2];
-                dnv[r] = (c.dR[kk][r * 3] * n0[0] + c.dR[kk][r * 3 + 1] * n0[1]) + c.dR[kk][r * 3 + 2] * n0[2];
-            }
+            dn[r] = fdot3(A[r * 3], n0[0], A[r * 3 + 1], n0[1], A[r * 3 + 2], n0[2]);
+            dq[r] = fdot3c(A[r * 3], p0[0], A[r * 3 + 1], p0[1], A[r * 3 + 2], p0[2], tk[r]);
         }
-        const double dnum = ((dnv[0] * p0c[0] + dnv[1] * p0c[1]) + dnv[2] * p0c[2]) + ((n0c[0] * dpv[0] + n0c[1] * dpv[1]) + n0c[2] * dpv[2]);
-        const double dden = (Cxz * dnv[0] + Cyz * dnv[1]) + dnv[2];
-        z6[kk] = (dnum - Z0 * dden) * iden;
+        const double dnum = fdot3c(n0c[0], dq[0], n0c[1], dq[1], n0c[2], dq[2], fdot3(dn[0], p0c[0], dn[1], p0c[1], dn[2], p0c[2]));
+        const double dden = __builtin_fma(Cyz, dn[1], __builtin_fma(Cxz, dn[0], dn[2]));
+        const double z = __builtin_fma(-Z0, dden, dnum) * iden;
+        zr0 = kk == 0 ? z : zr0; zr1 = kk == 1 ? z : zr1; zr2 = kk == 2 ? z : zr2;
     }
+    z6[0] = zr0; z6[1] = zr1; z6[2] = zr2;
+    for (int kk = 3; kk < 6; ++kk) z6[kk] = fdot3(n0c[0], dt[kk][0], n0c[1], dt[kk][1], n0c[2], dt[kk][2]) * iden;   // (the plane normal does not move with the translation)
     const double P0x = Cxz * Z0, P0y = Cyz * Z0, P0z = Z0;
     int nconv = 0;
-    // only the covisible slots whose match bit is set in the keypoint flags (kp_fl >> 2), in slot order; the next
-    // match is in flight during the arithmetic of the current one
-    const float2* mrow = dp.match_uv + h.match_base + k;
-    // one pass per flag word: the slots 0..29 of the keypoint's flag word, then — frames with more covisible keyframes only, a
-    // block-uniform branch — the slots 30..61 of its second word (kp_fl2)
-    const int n_words = (MANY && h.n_slots > (uint32_t)kCovisWord) ? 2 : 1;   // (block-uniform)
+    // only the covisible slots whose match bit is set, in slot order; the next match is in flight during the arithmetic of the current one.
+    // One pass per flag word: the slots 0..29, then — frames with more covisible keyframes only — the slots 30..61
+    const int n_words = (MANY && m1 != 0u) ? 2 : 1;
 #pragma unroll 1
     for (int wi = 0; wi < n_words; ++wi) {   // ONE copy of the loop body for both words (two inlined copies cost the kernel 3 %: code size)
-        uint32_t mask = (!MANY || wi == 0) ? dp.kp_fl[h.kp_base + k] >> 2 : dp.kp_fl2[h.kp_base + k];
+        uint32_t mask = (!MANY || wi == 0) ? m0 : m1;
         const uint32_t base = (!MANY || wi == 0) ? 0u : (uint32_t)kCovisWord;
-        float2 mnext = mask ? mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K] : make_float2(0.f, 0.f);
         while (mask) {
             const uint32_t sl = base + (uint32_t)__ffs((int)mask) - 1u;
             mask &= mask - 1u;
-            const float2 m = mnext;
-            if (mask) mnext = mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K];
-            const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel;   // the frame's relative poses: the caller's LDS copy, or global memory
-            const double tx = rel[3] * c.s, ty = rel[7] * c.s, tz = rel[11] * c.s;   // _t *= _s (IBACalib2.hpp:175)
-            const double P1x = ((rel[0] * P0x + rel[1] * P0y) + rel[2] * P0z) + tx;
-            const double P1y = ((rel[4] * P0x + rel[5] * P0y) + rel[6] * P0z) + ty;
-            const double P1z = ((rel[8] * P0x + rel[9] * P0y) + rel[10] * P0z) + tz;
-            // (one reciprocal for the residual and its derivatives: the Jacobian path carries a relative budget, not bit parity — round 5: the
-            //  two quotients fx P1x / P1z, fy P1y / P1z were divisions of their own, 11 instructions each)
-            const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;
-            const double ru = (h.fx * xz + h.cx) - (double)m.x;
-            const double rv = (h.fy * yz + h.cy) - (double)m.y;
-            const double ax = (rel[0] * Cxz + rel[1] * Cyz) + rel[2], ay = (rel[4] * Cxz + rel[5] * Cyz) + rel[6], az = (rel[8] * Cxz + rel[9] * Cyz) + rel[10];
-            const double gu = h.fx * iz * (ax - xz * az), gv = h.fy * iz * (ay - yz * az);
-            const double hu = h.fx * iz * (rel[3] - xz * rel[11]), hv = h.fy * iz * (rel[7] - yz * rel[11]);
+            float2 m = make_float2(sl == 0u ? mp.u0 : (sl == 1u ? mp.u1 : (sl == 2u ? mp.u2 : mp.u3)), sl == 0u ? mp.v0 : (sl == 1u ? mp.v1 : (sl == 2u ? mp.v2 : mp.v3)));
+            if (sl >= (uint32_t)kMatchPre) m = mrow[(size_t)sl * K];
+            double ts[3];
+            const double* rel = rel_of(sl, ts);
+            const double P1x = fdot3c(rel[0], P0x, rel[1], P0y, rel[2], P0z, ts[0]);
+            const double P1y = fdot3c(rel[4], P0x, rel[5], P0y, rel[6], P0z, ts[1]);
+            const double P1z = fdot3c(rel[8], P0x, rel[9], P0y, rel[10], P0z, ts[2]);
+            const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;   // (one reciprocal for the residual and its derivatives)
+            const double ru = __builtin_fma(cam.fx, xz, cam.cx) - (double)m.x;
+            const double rv = __builtin_fma(cam.fy, yz, cam.cy) - (double)m.y;
+            const double ax = __builtin_fma(rel[1], Cyz, __builtin_fma(rel[0], Cxz, rel[2])), ay = __builtin_fma(rel[5], Cyz, __builtin_fma(rel[4], Cxz, rel[6])),
+                         az = __builtin_fma(rel[9], Cyz, __builtin_fma(rel[8], Cxz, rel[10]));
+            const double fxiz = cam.fx * iz, fyiz = cam.fy * iz;
+            const double gu = fxiz * __builtin_fma(-xz, az, ax), gv = fyiz * __builtin_fma(-yz, az, ay);
+            const double hu = fxiz * __builtin_fma(-xz, rel[11], rel[3]), hv = fyiz * __builtin_fma(-yz, rel[11], rel[7]);
             slot(ru, rv, gu, gv, hu, hv);
             ++nconv;
         }
@@ -804,20 +819,21 @@ __device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& 
     return nconv;
 }
 
-template <bool MANY>
-__device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
-                                          double u0, double v0, const double* p0, const double* n0, NAcc& A, const double* rel_lds = nullptr) {
-    IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
+// the sums of one IBA_PlaneFactor block into the lane's accumulators
+template <bool MANY, class RelFn>
+__device__ __forceinline__ void plane_accum(const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], const Cam4& cam, double Cxz, double Cyz, const double* p0, const double* n0,
+                                            uint32_t m0, uint32_t m1, const float2* mrow, size_t K, const MatchPre mp, RelFn rel_of, double delta, NAcc& A) {
+    IBA_JAC_CONTRACT
     double z6[6];
     double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0;
-    const int nconv = plane_factor_core<MANY>(c, h, dp, k, K, u0, v0, p0, n0, z6, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
+    const int nconv = plane_core<MANY>(R, t, dR, dt, cam, Cxz, Cyz, p0, n0, z6, m0, m1, mrow, K, mp, rel_of, [&](double ru, double rv, double gu, double gv, double hu, double hv) {
 IBA_ACC_CONTRACT
         ssq += ru * ru + rv * rv;
         G += gu * gu + gv * gv; GH += gu * hu + gv * hv; HH += hu * hu + hv * hv;
         Gr += gu * ru + gv * rv; Hr += hu * ru + hv * rv;
-    }, rel_lds);
+    });
     if (nconv == 0) return;
-    double rho0, w; huber_w(prm.robust_kernel_delta, ssq, rho0, w);
+    double rho0, w; huber_w(delta, ssq, rho0, w);
     A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0 * nconv;
     {
         IBA_ACC_CONTRACT
@@ -835,47 +851,44 @@ IBA_ACC_CONTRACT
 // that matches the keypoint — p0c = R p0 + t (:49), p1c = R_i p0c + s t_i (:48, :50), (fx p1x / p1z + cx, fy p1y / p1z + cy) - (u1, v1) (:52-55).
 // One 2-row edge per matched slot, in slot order: calls edge(ru, rv, Ju[7], Jv[7]). Analytic chain rule through the same expressions the
 // reference's auto-diff differentiates: d p0c / dx_k = dt_k (+ dR_k p0 for k < 3), d p1c / dx_k = R_i d p0c / dx_k, d p1c / ds = t_i.
-template <bool MANY = true, class EdgeFn>
-__device__ __forceinline__ int test_edge_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K, const double* p0, EdgeFn edge, const double* rel_lds = nullptr) {
+template <bool MANY, class RelFn, class EdgeFn>
+__device__ __forceinline__ int edge_core(const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], const Cam4& cam, const double* p0,
+                                         uint32_t m0, uint32_t m1, const float2* mrow, size_t K, const MatchPre mp, RelFn rel_of, EdgeFn edge) {
     IBA_JAC_CONTRACT
     double p0c[3], dq[6][3];
     for (int r = 0; r < 3; ++r) {
-        p0c[r] = ((c.R[r * 3] * p0[0] + c.R[r * 3 + 1] * p0[1]) + c.R[r * 3 + 2] * p0[2]) + c.t[r];
-        for (int kk = 0; kk < 6; ++kk) {
-            double v = c.dt[kk][r];
-            if (kk < 3) v += (c.dR[kk][r * 3] * p0[0] + c.dR[kk][r * 3 + 1] * p0[1]) + c.dR[kk][r * 3 + 2] * p0[2];
-            dq[kk][r] = v;
-        }
+        p0c[r] = fdot3c(R[r * 3], p0[0], R[r * 3 + 1], p0[1], R[r * 3 + 2], p0[2], t[r]);
+        for (int kk = 0; kk < 3; ++kk) dq[kk][r] = fdot3c(dR[kk][r * 3], p0[0], dR[kk][r * 3 + 1], p0[1], dR[kk][r * 3 + 2], p0[2], dt[kk][r]);
+        for (int kk = 3; kk < 6; ++kk) dq[kk][r] = dt[kk][r];
     }
     int nconv = 0;
-    const float2* mrow = dp.match_uv + h.match_base + k;
-    const int n_words = (MANY && h.n_slots > (uint32_t)kCovisWord) ? 2 : 1;   // (block-uniform; see plane_factor_core)
+    const int n_words = (MANY && m1 != 0u) ? 2 : 1;
 #pragma unroll 1
     for (int wi = 0; wi < n_words; ++wi) {
-        uint32_t mask = (!MANY || wi == 0) ? dp.kp_fl[h.kp_base + k] >> 2 : dp.kp_fl2[h.kp_base + k];
+        uint32_t mask = (!MANY || wi == 0) ? m0 : m1;
         const uint32_t base = (!MANY || wi == 0) ? 0u : (uint32_t)kCovisWord;
-        float2 mnext = mask ? mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K] : make_float2(0.f, 0.f);
         while (mask) {
             const uint32_t sl = base + (uint32_t)__ffs((int)mask) - 1u;
             mask &= mask - 1u;
-            const float2 m = mnext;
-            if (mask) mnext = mrow[(size_t)(base + (uint32_t)__ffs((int)mask) - 1u) * K];
-            const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel;
-            const double tx = rel[3] * c.s, ty = rel[7] * c.s, tz = rel[11] * c.s;   // _t = t * _s (IBACalib.hpp:48)
-            const double P1x = ((rel[0] * p0c[0] + rel[1] * p0c[1]) + rel[2] * p0c[2]) + tx;
-            const double P1y = ((rel[4] * p0c[0] + rel[5] * p0c[1]) + rel[6] * p0c[2]) + ty;
-            const double P1z = ((rel[8] * p0c[0] + rel[9] * p0c[1]) + rel[10] * p0c[2]) + tz;
-            const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;   // (one reciprocal: see plane_factor_core)
-            const double ru = (h.fx * xz + h.cx) - (double)m.x;
-            const double rv = (h.fy * yz + h.cy) - (double)m.y;
+            float2 m = make_float2(sl == 0u ? mp.u0 : (sl == 1u ? mp.u1 : (sl == 2u ? mp.u2 : mp.u3)), sl == 0u ? mp.v0 : (sl == 1u ? mp.v1 : (sl == 2u ? mp.v2 : mp.v3)));
+            if (sl >= (uint32_t)kMatchPre) m = mrow[(size_t)sl * K];
+            double ts[3];
+            const double* rel = rel_of(sl, ts);   // ts = t_i * _s (IBACalib.hpp:48)
+            const double P1x = fdot3c(rel[0], p0c[0], rel[1], p0c[1], rel[2], p0c[2], ts[0]);
+            const double P1y = fdot3c(rel[4], p0c[0], rel[5], p0c[1], rel[6], p0c[2], ts[1]);
+            const double P1z = fdot3c(rel[8], p0c[0], rel[9], p0c[1], rel[10], p0c[2], ts[2]);
+            const double iz = 1.0 / P1z, xz = P1x * iz, yz = P1y * iz;   // (one reciprocal: see plane_core)
+            const double ru = __builtin_fma(cam.fx, xz, cam.cx) - (double)m.x;
+            const double rv = __builtin_fma(cam.fy, yz, cam.cy) - (double)m.y;
+            const double fxiz = cam.fx * iz, fyiz = cam.fy * iz;
             double Ju[7], Jv[7];
             for (int kk = 0; kk < 6; ++kk) {
-                const double qx = (rel[0] * dq[kk][0] + rel[1] * dq[kk][1]) + rel[2] * dq[kk][2];
-                const double qy = (rel[4] * dq[kk][0] + rel[5] * dq[kk][1]) + rel[6] * dq[kk][2];
-                const double qz = (rel[8] * dq[kk][0] + rel[9] * dq[kk][1]) + rel[10] * dq[kk][2];
-                Ju[kk] = h.fx * iz * (qx - xz * qz); Jv[kk] = h.fy * iz * (qy - yz * qz);
+                const double qx = fdot3(rel[0], dq[kk][0], rel[1], dq[kk][1], rel[2], dq[kk][2]);
+                const double qy = fdot3(rel[4], dq[kk][0], rel[5], dq[kk][1], rel[6], dq[kk][2]);
+                const double qz = fdot3(rel[8], dq[kk][0], rel[9], dq[kk][1], rel[10], dq[kk][2]);
+                Ju[kk] = fxiz * __builtin_fma(-xz, qz, qx); Jv[kk] = fyiz * __builtin_fma(-yz, qz, qy);
             }
-            Ju[6] = h.fx * iz * (rel[3] - xz * rel[11]); Jv[6] = h.fy * iz * (rel[7] - yz * rel[11]);
+            Ju[6] = fxiz * __builtin_fma(-xz, rel[11], rel[3]); Jv[6] = fyiz * __builtin_fma(-yz, rel[11], rel[7]);
             edge(ru, rv, Ju, Jv);
             ++nconv;
         }
@@ -883,12 +896,13 @@ __device__ __forceinline__ int test_edge_core(const Cand& c, const FrameHdr& h, 
     return nconv;
 }
 // every edge is a residual block of its own: its own Huber weight (g2o: RobustKernelHuber per edge; delta = robust_kernel_delta)
-template <bool MANY>
-__device__ inline void test_edge_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K, const double* p0, NAcc& A, const double* rel_lds = nullptr) {
+template <bool MANY, class RelFn>
+__device__ __forceinline__ void edge_accum(const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], const Cam4& cam, const double* p0,
+                                           uint32_t m0, uint32_t m1, const float2* mrow, size_t K, const MatchPre mp, RelFn rel_of, double delta, NAcc& A) {
     IBA_JAC_CONTRACT
-    test_edge_core<MANY>(c, h, dp, k, K, p0, [&](double ru, double rv, const double* Ju, const double* Jv) {
+    edge_core<MANY>(R, t, dR, dt, cam, p0, m0, m1, mrow, K, mp, rel_of, [&](double ru, double rv, const double* Ju, const double* Jv) {
         const double ssq = ru * ru + rv * rv;
-        double rho0, w; huber_w(prm.robust_kernel_delta, ssq, rho0, w);
+        double rho0, w; huber_w(delta, ssq, rho0, w);
         A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0;
         {
             IBA_ACC_CONTRACT
@@ -898,47 +912,146 @@ __device__ inline void test_edge_accum(const Cand& c, const FrameHdr& h, const D
                 A.b[i] += wu * ru + wv * rv;
             }
         }
-    }, rel_lds);
+    });
 }
 
-// M = Rlc (s m) + tlc and dM/dx for the 3d-3d factors (IBACalib2.hpp:570-584, 611-625)
-__device__ __forceinline__ void p2x_core(const Cand& c, const FrameHdr& h, const float4 mp, double* M, double dM[7][3]) {
-    IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
+// M = Rlc (s m) + tlc and dM/dx for the 3d-3d factors (IBACalib2.hpp:570-584, 611-625); Tcw: the keyframe's pose (3 x 4, row-major)
+__device__ __forceinline__ void p2x_core(const double* Rlc, const double* tlc, const double (*dRlc)[9], const double (*dtlc)[3], double s, const double* Tcw, const float4 mp, double* M, double dM[7][3]) {
+    IBA_JAC_CONTRACT
     const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
-    const double m[3] = {((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3], ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7],
-                         ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11]};
-    const double sm[3] = {m[0] * c.s, m[1] * c.s, m[2] * c.s};
+    const double m[3] = {fdot3c(Tcw[0], w0, Tcw[1], w1, Tcw[2], w2, Tcw[3]), fdot3c(Tcw[4], w0, Tcw[5], w1, Tcw[6], w2, Tcw[7]), fdot3c(Tcw[8], w0, Tcw[9], w1, Tcw[10], w2, Tcw[11])};
+    const double sm[3] = {m[0] * s, m[1] * s, m[2] * s};
     for (int r = 0; r < 3; ++r) {
-        M[r] = ((c.Rlc[r * 3] * sm[0] + c.Rlc[r * 3 + 1] * sm[1]) + c.Rlc[r * 3 + 2] * sm[2]) + c.tlc[r];
-        for (int kk = 0; kk < 6; ++kk) {
-            double v = c.dtlc[kk][r];
-            if (kk < 3) v += (c.dRlc[kk][r * 3] * sm[0] + c.dRlc[kk][r * 3 + 1] * sm[1]) + c.dRlc[kk][r * 3 + 2] * sm[2];
-            dM[kk][r] = v;
-        }
-        dM[6][r] = (c.Rlc[r * 3] * m[0] + c.Rlc[r * 3 + 1] * m[1]) + c.Rlc[r * 3 + 2] * m[2];
+        M[r] = fdot3c(Rlc[r * 3], sm[0], Rlc[r * 3 + 1], sm[1], Rlc[r * 3 + 2], sm[2], tlc[r]);
+        for (int kk = 0; kk < 3; ++kk) dM[kk][r] = fdot3c(dRlc[kk][r * 3], sm[0], dRlc[kk][r * 3 + 1], sm[1], dRlc[kk][r * 3 + 2], sm[2], dtlc[kk][r]);
+        for (int kk = 3; kk < 6; ++kk) dM[kk][r] = dtlc[kk][r];
+        dM[6][r] = fdot3(Rlc[r * 3], m[0], Rlc[r * 3 + 1], m[1], Rlc[r * 3 + 2], m[2]);
     }
 }
 
-__device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const DevParams& prm, const float4 mp, const double* Q, const double* n, bool is_plane, NAcc& A) {
-    IBA_JAC_CONTRACT   // Jacobian path: H, b carry a relative budget, not bit parity
+__device__ __forceinline__ void p2x_accum(const double* Rlc, const double* tlc, const double (*dRlc)[9], const double (*dtlc)[3], double s, const double* Tcw, double delta3, const float4 mp, const double* Q, const double* n, bool is_plane, NAcc& A) {
+    IBA_JAC_CONTRACT
     double M[3], dM[7][3];
-    p2x_core(c, h, mp, M, dM);
+    p2x_core(Rlc, tlc, dRlc, dtlc, s, Tcw, mp, M, dM);
     const double e[3] = {M[0] - Q[0], M[1] - Q[1], M[2] - Q[2]};
     if (is_plane) {
-        const double r = (e[0] * n[0] + e[1] * n[1]) + e[2] * n[2];
+        const double r = fdot3(e[0], n[0], e[1], n[1], e[2], n[2]);
         double J[7];
-        for (int kk = 0; kk < 7; ++kk) J[kk] = (dM[kk][0] * n[0] + dM[kk][1] * n[1]) + dM[kk][2] * n[2];
-        double rho0, w; huber_w(prm.robust_kernel_3ddelta, r * r, rho0, w);
+        for (int kk = 0; kk < 7; ++kk) J[kk] = fdot3(dM[kk][0], n[0], dM[kk][1], n[1], dM[kk][2], n[2]);
+        double rho0, w; huber_w(delta3, r * r, rho0, w);
         A.cost += 0.5 * rho0; A.chi2 += r * r; A.nfpl += 1.0; A.nres += 1.0;
         { IBA_ACC_CONTRACT for (int i = 0; i < 7; ++i) { const double wj = w * J[i]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * J[j]; A.b[i] += wj * r; } }
     } else {
-        const double ssq = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
-        double rho0, w; huber_w(prm.robust_kernel_3ddelta, ssq, rho0, w);
+        const double ssq = fdot3(e[0], e[0], e[1], e[1], e[2], e[2]);
+        double rho0, w; huber_w(delta3, ssq, rho0, w);
         A.cost += 0.5 * rho0; A.chi2 += ssq; A.nfpt += 1.0; A.nres += 3.0;
         { IBA_ACC_CONTRACT for (int r = 0; r < 3; ++r)
             for (int i = 0; i < 7; ++i) { const double wj = w * dM[i][r]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * dM[j][r]; A.b[i] += wj * e[r]; } }
     }
 }
+
+// The 3d-3d blocks again for the factor kernels, with the derivative constants consumed in ROLLED loops (12 resp. 15 live at a time, see plane_core):
+// the same fused chains as p2x_core / p2x_accum, term for term — the same bits.
+__device__ __forceinline__ void p2x_head(const double* Rlc, const double* tlc, double s, const double* Tcw, const float4 mp, const double* Q, double* m, double* sm, double* e) {
+    IBA_JAC_CONTRACT
+    const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
+    m[0] = fdot3c(Tcw[0], w0, Tcw[1], w1, Tcw[2], w2, Tcw[3]); m[1] = fdot3c(Tcw[4], w0, Tcw[5], w1, Tcw[6], w2, Tcw[7]); m[2] = fdot3c(Tcw[8], w0, Tcw[9], w1, Tcw[10], w2, Tcw[11]);
+    for (int r = 0; r < 3; ++r) sm[r] = m[r] * s;
+    for (int r = 0; r < 3; ++r) e[r] = fdot3c(Rlc[r * 3], sm[0], Rlc[r * 3 + 1], sm[1], Rlc[r * 3 + 2], sm[2], tlc[r]) - Q[r];
+}
+// Point2Plane_Factor (IBACalib2.hpp:611-625): one row J = n^T dM/dx
+__device__ __forceinline__ void p2pl_accum(const double* Rlc, const double* tlc, const double (*dRlc)[9], const double (*dtlc)[3], double s, const double* Tcw, double delta3, const float4 mp, const double* Q, const double* n, NAcc& A) {
+    IBA_JAC_CONTRACT
+    double m[3], sm[3], e[3];
+    p2x_head(Rlc, tlc, s, Tcw, mp, Q, m, sm, e);
+    const double r = fdot3(e[0], n[0], e[1], n[1], e[2], n[2]);
+    double J[7];
+    double j0 = 0, j1 = 0, j2 = 0;
+#pragma unroll 1
+    for (int kk = 0; kk < 3; ++kk) {
+        const double* D = dRlc[kk]; const double* tk = dtlc[kk];
+        double dm[3];
+        for (int rr = 0; rr < 3; ++rr) dm[rr] = fdot3c(D[rr * 3], sm[0], D[rr * 3 + 1], sm[1], D[rr * 3 + 2], sm[2], tk[rr]);
+        const double jj = fdot3(dm[0], n[0], dm[1], n[1], dm[2], n[2]);
+        j0 = kk == 0 ? jj : j0; j1 = kk == 1 ? jj : j1; j2 = kk == 2 ? jj : j2;
+    }
+    J[0] = j0; J[1] = j1; J[2] = j2;
+    for (int kk = 3; kk < 6; ++kk) J[kk] = fdot3(dtlc[kk][0], n[0], dtlc[kk][1], n[1], dtlc[kk][2], n[2]);
+    {
+        double d6[3];
+        for (int rr = 0; rr < 3; ++rr) d6[rr] = fdot3(Rlc[rr * 3], m[0], Rlc[rr * 3 + 1], m[1], Rlc[rr * 3 + 2], m[2]);
+        J[6] = fdot3(d6[0], n[0], d6[1], n[1], d6[2], n[2]);
+    }
+    double rho0, w; huber_w(delta3, r * r, rho0, w);
+    A.cost += 0.5 * rho0; A.chi2 += r * r; A.nfpl += 1.0; A.nres += 1.0;
+    { IBA_ACC_CONTRACT for (int i = 0; i < 7; ++i) { const double wj = w * J[i]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * J[j]; A.b[i] += wj * r; } }
+}
+// Point2Point_Factor (IBACalib2.hpp:570-584): three rows, row rr = d M_rr / dx
+__device__ __forceinline__ void p2pt_accum(const double* Rlc, const double* tlc, const double (*dRlc)[9], const double (*dtlc)[3], double s, const double* Tcw, double delta3, const float4 mp, const double* Q, NAcc& A) {
+    IBA_JAC_CONTRACT
+    double m[3], sm[3], e[3];
+    p2x_head(Rlc, tlc, s, Tcw, mp, Q, m, sm, e);
+    const double ssq = fdot3(e[0], e[0], e[1], e[1], e[2], e[2]);
+    double rho0, w; huber_w(delta3, ssq, rho0, w);
+    A.cost += 0.5 * rho0; A.chi2 += ssq; A.nfpt += 1.0; A.nres += 3.0;
+#pragma unroll 1
+    for (int rr = 0; rr < 3; ++rr) {
+        double v[7];
+        for (int kk = 0; kk < 3; ++kk) v[kk] = fdot3c(dRlc[kk][rr * 3], sm[0], dRlc[kk][rr * 3 + 1], sm[1], dRlc[kk][rr * 3 + 2], sm[2], dtlc[kk][rr]);
+        for (int kk = 3; kk < 6; ++kk) v[kk] = dtlc[kk][rr];
+        v[6] = fdot3(Rlc[rr * 3], m[0], Rlc[rr * 3 + 1], m[1], Rlc[rr * 3 + 2], m[2]);
+        const double er = rr == 0 ? e[0] : (rr == 1 ? e[1] : e[2]);
+        { IBA_ACC_CONTRACT for (int i = 0; i < 7; ++i) { const double wj = w * v[i]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * v[j]; A.b[i] += wj * er; } }
+    }
+}
+
+// ---- the same cores behind the signatures of rounds 1-5 (a keyframe header, a Cand and the keypoint's pixel): iba_residual_kernel,
+// iba_factor_mfma_kernel and the one-wave-per-(keyframe, candidate) iba_factor_kernel evaluate the SAME arithmetic as iba_factor2_kernel ----
+template <bool MANY = true, class SlotFn>
+__device__ __forceinline__ int plane_factor_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K,
+                                                 double u0, double v0, const double* p0, const double* n0, double* z6, SlotFn slot, const double* rel_lds = nullptr) {
+    const Cam4 cam{h.fx, h.fy, h.cx, h.cy};
+    const double Cxz = (u0 - h.cx) / h.fx, Cyz = (v0 - h.cy) / h.fy;
+    const uint32_t m0 = dp.kp_fl[h.kp_base + k] >> 2, m1 = (MANY && h.n_slots > (uint32_t)kCovisWord) ? dp.kp_fl2[h.kp_base + k] : 0u;
+    const double s = c.s;
+    const MatchPre mp = load_match_pre(dp.match_uv + h.match_base + k, (size_t)K, h.n_slots);
+    return plane_core<MANY>(c.R, c.t, c.dR, c.dt, cam, Cxz, Cyz, p0, n0, z6, m0, m1, dp.match_uv + h.match_base + k, (size_t)K, mp,
+                            [&](uint32_t sl, double* ts) { const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel; ts[0] = rel[3] * s; ts[1] = rel[7] * s; ts[2] = rel[11] * s; return rel; }, slot);
+}
+template <bool MANY>
+__device__ inline void plane_factor_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K,
+                                          double u0, double v0, const double* p0, const double* n0, NAcc& A, const double* rel_lds = nullptr) {
+    const Cam4 cam{h.fx, h.fy, h.cx, h.cy};
+    const double Cxz = (u0 - h.cx) / h.fx, Cyz = (v0 - h.cy) / h.fy;
+    const uint32_t m0 = dp.kp_fl[h.kp_base + k] >> 2, m1 = (MANY && h.n_slots > (uint32_t)kCovisWord) ? dp.kp_fl2[h.kp_base + k] : 0u;
+    const double s = c.s;
+    const MatchPre mp = load_match_pre(dp.match_uv + h.match_base + k, (size_t)K, h.n_slots);
+    plane_accum<MANY>(c.R, c.t, c.dR, c.dt, cam, Cxz, Cyz, p0, n0, m0, m1, dp.match_uv + h.match_base + k, (size_t)K, mp,
+                      [&](uint32_t sl, double* ts) { const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel; ts[0] = rel[3] * s; ts[1] = rel[7] * s; ts[2] = rel[11] * s; return rel; }, prm.robust_kernel_delta, A);
+}
+template <bool MANY = true, class EdgeFn>
+__device__ __forceinline__ int test_edge_core(const Cand& c, const FrameHdr& h, const DevProblem& dp, uint32_t k, uint32_t K, const double* p0, EdgeFn edge, const double* rel_lds = nullptr) {
+    const Cam4 cam{h.fx, h.fy, h.cx, h.cy};
+    const uint32_t m0 = dp.kp_fl[h.kp_base + k] >> 2, m1 = (MANY && h.n_slots > (uint32_t)kCovisWord) ? dp.kp_fl2[h.kp_base + k] : 0u;
+    const double s = c.s;
+    const MatchPre mp = load_match_pre(dp.match_uv + h.match_base + k, (size_t)K, h.n_slots);
+    return edge_core<MANY>(c.R, c.t, c.dR, c.dt, cam, p0, m0, m1, dp.match_uv + h.match_base + k, (size_t)K, mp,
+                           [&](uint32_t sl, double* ts) { const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel; ts[0] = rel[3] * s; ts[1] = rel[7] * s; ts[2] = rel[11] * s; return rel; }, edge);
+}
+template <bool MANY>
+__device__ inline void test_edge_accum(const Cand& c, const FrameHdr& h, const DevProblem& dp, const DevParams& prm, uint32_t k, uint32_t K, const double* p0, NAcc& A, const double* rel_lds = nullptr) {
+    const Cam4 cam{h.fx, h.fy, h.cx, h.cy};
+    const uint32_t m0 = dp.kp_fl[h.kp_base + k] >> 2, m1 = (MANY && h.n_slots > (uint32_t)kCovisWord) ? dp.kp_fl2[h.kp_base + k] : 0u;
+    const double s = c.s;
+    const MatchPre mp = load_match_pre(dp.match_uv + h.match_base + k, (size_t)K, h.n_slots);
+    edge_accum<MANY>(c.R, c.t, c.dR, c.dt, cam, p0, m0, m1, dp.match_uv + h.match_base + k, (size_t)K, mp,
+                     [&](uint32_t sl, double* ts) { const double* rel = rel_lds ? rel_lds + sl * 12u : dp.slots[h.slot_base + sl].rel; ts[0] = rel[3] * s; ts[1] = rel[7] * s; ts[2] = rel[11] * s; return rel; }, prm.robust_kernel_delta, A);
+}
+__device__ __forceinline__ void p2x_core(const Cand& c, const FrameHdr& h, const float4 mp, double* M, double dM[7][3]) { p2x_core(c.Rlc, c.tlc, c.dRlc, c.dtlc, c.s, h.Tcw, mp, M, dM); }
+__device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const DevParams& prm, const float4 mp, const double* Q, const double* n, bool is_plane, NAcc& A) {
+    p2x_accum(c.Rlc, c.tlc, c.dRlc, c.dtlc, c.s, h.Tcw, prm.robust_kernel_3ddelta, mp, Q, n, is_plane, A);
+}
+
 
 #ifndef IBA_FACTOR_WAVES
 #define IBA_FACTOR_WAVES 2
@@ -1159,16 +1272,16 @@ IBA_JAC_CONTRACT
                 p2x_core(c, h, dp.kp_mp[h.kp_base + k], M, dM);
                 const double ev[3] = {M[0] - (double)pt.x, M[1] - (double)pt.y, M[2] - (double)pt.z};
                 if (is_plane) {
-                    const double r = (ev[0] * rec.nx + ev[1] * rec.ny) + ev[2] * rec.nz;
+                    const double r = fdot3(ev[0], rec.nx, ev[1], rec.ny, ev[2], rec.nz);
                     double J[8];
-                    for (int kk = 0; kk < 7; ++kk) J[kk] = (dM[kk][0] * rec.nx + dM[kk][1] * rec.ny) + dM[kk][2] * rec.nz;
+                    for (int kk = 0; kk < 7; ++kk) J[kk] = fdot3(dM[kk][0], rec.nx, dM[kk][1], rec.ny, dM[kk][2], rec.nz);
                     J[7] = r;
                     double rho0; huber_w(prm.robust_kernel_3ddelta, r * r, rho0, w);
                     cost += 0.5 * rho0; chi2 += r * r; nfpl += 1.0; nres += 1.0;
 #pragma unroll
                     for (int q = 0; q < 8; q += 2) *(double2*)(Q + q) = make_double2(J[q], J[q + 1]);
                 } else {
-                    const double ssq = (ev[0] * ev[0] + ev[1] * ev[1]) + ev[2] * ev[2];
+                    const double ssq = fdot3(ev[0], ev[0], ev[1], ev[1], ev[2], ev[2]);
                     double rho0; huber_w(prm.robust_kernel_3ddelta, ssq, rho0, w);
                     cost += 0.5 * rho0; chi2 += ssq; nfpt += 1.0; nres += 3.0;
                     is_pt = true;
@@ -1310,8 +1423,8 @@ __global__ __launch_bounds__(64) void iba_residual_kernel(DevProblem dp, DevPara
         p2x_core(c, h, dp.kp_mp[h.kp_base + k], M, dM);
         const double e[3] = {M[0] - (double)xs[pos], M[1] - (double)ys[pos], M[2] - (double)zs[pos]};
         if (is_plane) {
-            r_out[row] = (e[0] * rec.nx + e[1] * rec.ny) + e[2] * rec.nz;
-            for (int i = 0; i < 7; ++i) J_out[row * 7 + i] = (dM[i][0] * rec.nx + dM[i][1] * rec.ny) + dM[i][2] * rec.nz;
+            r_out[row] = fdot3(e[0], rec.nx, e[1], rec.ny, e[2], rec.nz);   // (the factor kernels' own expressions: p2x_accum)
+            for (int i = 0; i < 7; ++i) J_out[row * 7 + i] = fdot3(dM[i][0], rec.nx, dM[i][1], rec.ny, dM[i][2], rec.nz);
         } else {
             for (int rr = 0; rr < 3; ++rr) { r_out[row + rr] = e[rr]; for (int i = 0; i < 7; ++i) J_out[(row + rr) * 7 + i] = dM[i][rr]; }
         }

@@ -2349,7 +2349,7 @@ constexpr int kHeLds = 2048;   // HE_MODE 1: frames whose terms wait in LDS (mor
 // HE_MODE 0: an evaluation without the cost tuple; 2: the search kernel's spare blocks have left the terms in he_scratch[b][f] (the usual
 // chain); 1: no search kernel ran in this chain — the terms are evaluated here, two lanes each
 template <int HE_MODE>
-__global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, int nfr, const double* __restrict__ nn_partials, int nn_nrec,
+__global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const double* __restrict__ frame_partials, int nrec, int nfr, int n_fact, const double* __restrict__ nn_partials, int nn_nrec,
                                                                      double* __restrict__ out, const FrameHdr* __restrict__ frames, const Cand* __restrict__ cands, double* __restrict__ he_scratch,
                                                                      unsigned long long* __restrict__ done_flag, uint32_t* __restrict__ done_ctr, unsigned long long done_seq) {
     constexpr int NG = kReduceThreads / kPartialStride;
@@ -2404,7 +2404,7 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
         return x;
     };
     double x = range_sum(src, f0, f1, true);
-    if (nrec > nfr) x += range_sum(src + (size_t)nfr * kPartialStride, f0, min(f1, nrec - nfr), false);
+    if (n_fact > 0) x += range_sum(src + (size_t)nfr * kPartialStride, f0, min(f1, n_fact), false);   // (n_fact <= nfr records of the factor kernel: one per keyframe, or one per range of iba_factor2_kernel)
     s[g][i] = x;
     if (nn_partials) {   // record lane rl sums the records rl, rl + NL, ... of slot q
         const int q = threadIdx.x & (kNNPartial - 1), rl = threadIdx.x / kNNPartial;

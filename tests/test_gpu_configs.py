@@ -9,6 +9,10 @@
 import numpy as np
 import pytest
 
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parity_gate  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -55,11 +59,9 @@ def test_c2_combined_cost_and_normal_vs_oracle(pkg, synth, abi, ob, c2):
     orc = ob.Oracle(prob)
     _cmp_cost(cost[0], orc.eval_cost(p, x)[0])
     on = orc.eval_normal(p, x)[0]
-    gH, oH = nrm[0].H_np(), on.H_np()
-    assert nrm[0].counts() == on.counts()
-    assert np.allclose(gH, oH, rtol=1e-9, atol=1e-9 * np.abs(oH).max())
-    assert np.allclose(nrm[0].b_np(), on.b_np(), rtol=1e-9, atol=1e-9 * np.abs(on.b_np()).max())
-    assert abs(nrm[0].cost - on.cost) <= 1e-10 * on.cost
+    # H, b, cost, chi^2 against the long-double evaluation (tests/parity_gate.py): within 1e-10 of the exact value per entry, or no further from it than
+    # 1.5 x the double oracle's own error (round 6; rounds 1-5 held C2's H, b to 1e-9 of the double oracle)
+    parity_gate.normal_vs_truth(nrm[0], on, orc.eval_normal_truth(p, x)[0])
     h.close()
 
 

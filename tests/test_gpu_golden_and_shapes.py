@@ -21,6 +21,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import lm_ref  # noqa: E402
+import parity_gate  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "path_small_scene.npz")
@@ -48,8 +49,14 @@ def cmp_cost(g, o, rel=1e-10):
     assert (np.isnan(g.C) and np.isnan(o.C)) or abs(g.C - o.C) <= 1e-10 * abs(o.C) + 1e-15   # device acos / tan vs glibc: measured 5e-12 over 1500 random scenes (tools/soak_parity.py, r03)
 
 
-def cmp_normal(g, o):
+def cmp_normal(g, o, t=None):
+    """t: the long-double evaluation (Oracle.eval_normal_truth). With it the device is held to the truth (tests/parity_gate.py: within 1e-10 of the
+    exact value, or no further from it than 1.5 x the double oracle's own error); without it, to 1e-10 of the double oracle's entries."""
     assert g.counts() == o.counts(), (g.counts(), o.counts())
+    if t is not None:
+        parity_gate.normal_vs_truth(g, o, t)
+        per_entry(g.H_np(), o.H_np(), rel=2e-9); per_entry(g.b_np(), o.b_np(), rel=2e-9)   # (and the two double evaluations stay near each other)
+        return
     per_entry(g.H_np(), o.H_np())
     per_entry(g.b_np(), o.b_np())
     assert abs(g.cost - o.cost) <= 1e-10 * abs(o.cost) and abs(g.chi2 - o.chi2) <= 1e-10 * abs(o.chi2)
@@ -114,7 +121,7 @@ def test_c2_per_entry_gate(pkg, synth, abi, ob, c2):
         x = synth.perturb(meta["x_gt"], np.random.default_rng(seed), n=1)
         cost, nrm = h.eval_full(x)
         cmp_cost(cost[0], o.eval_cost(p, x, nthreads=min(NCPU, 64))[0])
-        cmp_normal(nrm[0], o.eval_normal(p, x, nthreads=min(NCPU, 64))[0])
+        cmp_normal(nrm[0], o.eval_normal(p, x, nthreads=min(NCPU, 64))[0], o.eval_normal_truth(p, x)[0])
     h.close()
 
 
@@ -152,7 +159,7 @@ def test_c3_six_million_points_vs_oracle(pkg, synth, abi, ob, c2):
     cost, nrm = h.eval_full(x)
     o = ob.Oracle(prob)
     cmp_cost(cost[0], o.eval_cost(p, x, nthreads=min(NCPU, 64))[0])
-    cmp_normal(nrm[0], o.eval_normal(p, x, nthreads=min(NCPU, 64))[0])
+    cmp_normal(nrm[0], o.eval_normal(p, x, nthreads=min(NCPU, 64))[0], o.eval_normal_truth(p, x)[0])
     h.close()
 
 
