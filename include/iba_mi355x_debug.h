@@ -3,9 +3,9 @@
  * plane fits exposed for parity tests, and the host-only self-tests of the optimiser logic. Test and benchmark tooling; none of
  * it is part of the drop-in surface (iba_mi355x.h), none of it changes a result, and an integrator never needs it.
  *
- * DEBUG-ONLY ENVIRONMENT VARIABLES (read once, at iba_create / iba_group_create; an integrator sets iba_create_options instead —
- * where a variable has a field there, the FIELD is the interface and the variable only overrides it for A/B runs of an unmodified
- * caller):
+ * DEBUG-ONLY ENVIRONMENT VARIABLES (read at iba_create / iba_group_create, AND ONLY WHEN IBA_DEBUG_ENV=1 IS SET AS WELL — round 6: a stray
+ * variable in an integrator's environment changes nothing; an integrator sets iba_create_options instead — where a variable has a field
+ * there, the FIELD is the interface and the variable only overrides it for A/B runs of an unmodified caller):
  *
  *   variable                field of iba_create_options   meaning
  *   IBA_COMMON_PAIRS        common_pairs                  0 never share the 2d-3d pair search, 1 when tight, 2 always
@@ -29,7 +29,10 @@
  *                                                         in rounds of leaves (same results; A/B timing)
  *   IBA_DONE_FLAG                                         0: a blocking call polls its stream (rounds 3-4) instead of the sequence number the summing
  *                                                         kernel's last block publishes in pinned memory (same results; A/B timing)
- *   IBA_NN_DBG, IBA_ASSOC_DBG                             cut a kernel short after a phase (timing attribution; RESULTS ARE GARBAGE)
+ *   IBA_FACTOR_V2                                         1: the normal equations by iba_factor2_kernel — one wave per equal share of a candidate's whole work
+ *                                                         list (csrc/iba_factor2_kernel.hpp) — instead of one wave per (keyframe, candidate); same sums to
+ *                                                         summation order, measured no faster; IBA_FACTOR_WAVES_PER_CAND forces its ranges per candidate
+ *   IBA_NN_DBG, IBA_ASSOC_DBG, IBA_FACTOR_DBG             cut a kernel short after a phase (timing attribution; RESULTS ARE GARBAGE)
  *   IBA_LAYOUT_DEBUG, IBA_DEBUG_LEFT_HIST                 print the LDS plan / a histogram of left-over searches to stderr
  *   IBA_GROUP_TIMEOUT_MS                                  bound (ms, default 20 000; x4 for a group's first call) of a device thread's
  *                                                         wait for its stream before the group is declared broken
@@ -52,6 +55,12 @@ iba_status iba_set_timing(iba_handle* h, int32_t enable);
 /* the same split by kernel: association kernel (projection, 2d-3d association, 3d-2d residuals), grouped 1-NN search kernel
  * (3d-3d terms), and everything after them (factor kernel, sums) */
 iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_kernel_ms, float* rest_ms);
+/* debug: threads per block of the last iba_assoc2_kernel launch on this handle (256 or 512: chosen per launch from the number of (candidate,
+ * keyframe) blocks; 0 = no shared-pair association has run) */
+int32_t iba_debug_last_assoc2_threads(const iba_handle* h);
+/* debug: ranges per candidate iba_factor2_kernel would cut a batch of B into on this handle; 0 = the batch runs on the one-wave-per-(keyframe,
+ * candidate) factor kernel (the default) */
+int32_t iba_debug_factor_ranges(const iba_handle* h, int32_t B);
 /* debug: host copy of the summed partial blocks of the last iba_eval_* call */
 iba_status iba_debug_last_partials(iba_handle* h, double* out, int32_t B);
 /* debug: which 2d-3d association ran in the last evaluation chain: 1 = the batch shared one pair search per keyframe

@@ -307,6 +307,18 @@ class IbaHandle:
         x = self._x(x)
         self._chk(self.lib.iba_eval_normal_partial(self.h, _p(x), C.c_int32(len(x)), C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
 
+    @property
+    def last_assoc2_threads(self):
+        self.lib.iba_debug_last_assoc2_threads.argtypes = [C.c_void_p]
+        self.lib.iba_debug_last_assoc2_threads.restype = C.c_int32
+        return int(self.lib.iba_debug_last_assoc2_threads(self.h))
+
+    def debug_factor_ranges(self, B):
+        """ranges per candidate iba_factor2_kernel would cut a batch of B into; 0 = the default factor kernel runs"""
+        self.lib.iba_debug_factor_ranges.argtypes = [C.c_void_p, C.c_int32]
+        self.lib.iba_debug_factor_ranges.restype = C.c_int32
+        return int(self.lib.iba_debug_factor_ranges(self.h, C.c_int32(B)))
+
     def debug_last_partials(self, B):
         out = np.zeros((B, partial_stride()))
         self._chk(self.lib.iba_debug_last_partials(self.h, _p(out), C.c_int32(B)))

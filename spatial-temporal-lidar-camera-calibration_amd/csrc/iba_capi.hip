@@ -20,6 +20,12 @@
 #include "iba_build.hpp"
 #include "iba_host_math.hpp"
 #include "iba_internal.hpp"
+namespace iba {
+const char* debug_env(const char* name) {   // (read at every handle creation: a test may switch it on after the library was loaded)
+    const char* e = std::getenv("IBA_DEBUG_ENV");
+    return (e && std::atoi(e) != 0) ? std::getenv(name) : nullptr;
+}
+}  // namespace iba
 #include "iba_kernels.hpp"
 #include "iba_lm.hpp"
 #include "iba_mads.hpp"
@@ -31,6 +37,9 @@
 using namespace iba;
 
 namespace {
+// Environment overrides are DEBUG aids (A/B runs of an unmodified caller, timing cuts, fault injection: include/iba_mi355x_debug.h): they are read only
+// when IBA_DEBUG_ENV=1 is set as well, so that a stray variable in an integrator's environment cannot change launch shapes or kernels (round 6)
+const char* dbg_env(const char* name) { return iba::debug_env(name); }
 
 thread_local std::string g_create_error = "";
 
@@ -71,8 +80,9 @@ struct iba_handle {
     int assoc_dbg = 0;
     bool factor_valu = true;              // IBA_FACTOR_MFMA=1 selects the matrix-core variant of the factor kernel (slower on gfx950: see iba_kernels.hpp)
     // iba_factor2_kernel (r06): one wave per equal share of a candidate's whole work list (iba_factor2_kernel.hpp)
-    bool factor_v2 = true;                // IBA_FACTOR_V1=1 (debug): the one-wave-per-(keyframe, candidate) kernel of rounds 2-5
+    bool factor_v2 = false;               // IBA_FACTOR_V2=1 (debug): iba_factor2_kernel instead of the one-wave-per-(keyframe, candidate) kernel (measured: no faster, see the header)
     int factor_slots = 2048;              // wave slots of the device at two waves per SIMD: CUs x 8
+    int factor_dbg = 0;                   // IBA_FACTOR_DBG (debug): timing cuts of iba_factor2_kernel (results invalid)
     int factor_waves_forced = 0;          // IBA_FACTOR_WAVES_PER_CAND (debug): ranges per candidate instead of the rule in factor_waves()
     F2Layout f2lay{};
     DevBuf<double> d_ffr;                 // per keyframe: camera, pose, table offsets, relative poses of its covisible slots — one contiguous record (kFfrHead + 12 max_slots doubles)
@@ -113,6 +123,7 @@ struct iba_handle {
     int max_groups = kMaxPairGroups;      // IBA_PAIR_GROUPS: 1 = no clustering of wide batches (round 3's behaviour)
     int last_mean_pairs_slot = -1;
     int pair_cap = 0, hard_cap = 0;
+    int last_assoc2_threads = 0;          // block size of the last iba_assoc2_kernel launch (iba_debug_last_assoc2_threads)
     int assoc2_threads_forced = 0;        // IBA_ASSOC2_THREADS: 256 / 512 (0: chosen per launch, assoc2_threads)
     int assoc2_small_min_blocks = 1024;   // launches of at least this many (candidate, keyframe) blocks run iba_assoc2_kernel with 256 threads per block (IBA_ASSOC2_SMALL_MIN)
     uint32_t pairs_dense_min = 32768u;    // scans of at least this many points: the pair search tests a block's boxes before it loads the block's points and the keypoint grid (IBA_PAIRS_DENSE_MIN)
@@ -271,7 +282,7 @@ bool layout_assoc(iba_handle* h, LdsLayout& L) {
     const uint32_t want_q = std::max<uint32_t>(h->maxPpad / 2u, 512u) * 4u;      // nothing queues more than half of a scan
     const uint32_t want_p = std::max<uint32_t>(2u * h->maxK, 256u) * 16u;         // ~1 pair per matched keypoint, x 1.7 for the f32 margin
     int nb_max = 2;
-    if (const char* e = std::getenv("IBA_ASSOC_BLOCKS")) nb_max = std::max(1, std::atoi(e));   // diagnostic
+    if (const char* e = dbg_env("IBA_ASSOC_BLOCKS")) nb_max = std::max(1, std::atoi(e));   // diagnostic
     uint32_t room = (kLdsBytes - off - bm_bytes) & ~15u;   // beyond the tables and the bitmap
     for (int nb = nb_max; nb >= 2; --nb) {
         const uint32_t share = (kLdsBytes / (uint32_t)nb) & ~255u;
@@ -280,8 +291,8 @@ bool layout_assoc(iba_handle* h, LdsLayout& L) {
     // the queue first (a scan queues ~8 % of its points at 2000 keypoints), the pair list gets the bitmap and the rest
     uint32_t bytes_q = std::min(want_q, std::max<uint32_t>(std::min<uint32_t>(room, std::max<uint32_t>(h->maxPpad / 8u, 1024u) * 4u), room / 2u) & ~15u);
     uint32_t bytes_p = std::min(want_p, bm_bytes + ((room - bytes_q) & ~15u));
-    if (const char* e = std::getenv("IBA_CAND_BYTES")) bytes_q = std::min<uint32_t>((uint32_t)std::atoi(e) & ~15u, bytes_q);   // diagnostic
-    if (const char* e = std::getenv("IBA_PAIR_BYTES")) bytes_p = std::min<uint32_t>((uint32_t)std::atoi(e) & ~15u, bytes_p);   // diagnostic
+    if (const char* e = dbg_env("IBA_CAND_BYTES")) bytes_q = std::min<uint32_t>((uint32_t)std::atoi(e) & ~15u, bytes_q);   // diagnostic
+    if (const char* e = dbg_env("IBA_PAIR_BYTES")) bytes_p = std::min<uint32_t>((uint32_t)std::atoi(e) & ~15u, bytes_p);   // diagnostic
     L.off_cand = off; L.cand_cap = bytes_q / 4u; off += bytes_q;
     L.off_bitmap = off; L.off_pair = off; L.pair_cap = bytes_p / 16u; off += std::max(bm_bytes, bytes_p);
     L.total = off;
@@ -584,8 +595,10 @@ hipError_t wait_done(iba_handle* h, hipStream_t st) {
 // (a range of less than a keyframe's list is mostly start-up), at least one. 0: the batch runs on the kernels that write one record per keyframe.
 int factor_waves(const iba_handle* h, int B) {
     if (!h->factor_v2 || !h->factor_valu || h->n_frames == 0 || h->n_frames > kF2MaxFrames || !h->d_ffr.p || h->f2lay.total == 0) return 0;
-    if (h->factor_waves_forced > 0) return std::min(h->factor_waves_forced, h->n_frames);
-    return std::max(1, std::min(h->n_frames, h->factor_slots / std::max(B, 1)));
+    // a lane counts the blocks it evaluates in 16 bits (NAccP): a range may hold at most 64 x 60000 list entries
+    const int w_min = (int)std::min<uint64_t>((uint64_t)h->n_frames, ((uint64_t)h->n_frames * h->lstride + 64ull * 60000ull - 1ull) / (64ull * 60000ull));
+    if (h->factor_waves_forced > 0) return std::max(w_min, std::min(h->factor_waves_forced, h->n_frames));
+    return std::max(std::max(1, w_min), std::min(h->n_frames, h->factor_slots / std::max(B, 1)));
 }
 // records per candidate the factor kernel of this launch writes
 int factor_records(const iba_handle* h, int B) { const int w = factor_waves(h, B); return w > 0 ? w : h->n_frames; }
@@ -597,7 +610,7 @@ iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, do
         const dim3 grid2(8u * (uint32_t)((W + 7) / 8) * (uint32_t)B);
         const bool many = h->max_slots > (uint32_t)kCovisWord;
         auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid2, dim3(64), h->f2lay.total, st, h->dev_problem(), h->dprm, dc, fl2, fc2, (int)h->lstride, per_cand, partials, nrec, rec_base, B, W,
-                                                      (const double*)h->d_ffr.p, (const double2*)h->d_kp_c.p, h->f2lay); };
+                                                      (const double*)h->d_ffr.p, (const double2*)h->d_kp_c.p, h->f2lay, h->factor_dbg); };
         if (h->dprm.p2pix) { if (many) go(iba_factor2_kernel<true, true>); else go(iba_factor2_kernel<false, true>); }
         else { if (many) go(iba_factor2_kernel<true, false>); else go(iba_factor2_kernel<false, false>); }
         HIP_TRY(h, hipGetLastError());
@@ -815,6 +828,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     if (common) {
         // (twelve instantiations: two / four / any number of flagged keypoints per thread x at most 30 covisible keyframes or more x 256 / 512 threads)
         const int at = assoc2_threads(h, 8 * per_xcd * B);
+        h->last_assoc2_threads = at;
         auto launch_assoc2 = [&](auto qtag, auto ttag) {
             constexpr int QQ = decltype(qtag)::value, TT = decltype(ttag)::value;
             auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(8 * per_xcd * B + head_blocks), dim3(TT), h->alay2.total, st, K2Args{KArgs{dp, h->dprm, h->alay2}, h->amap}, assoc_cands, B, want | (refit ? 4 : 0) | (h->assoc_dbg << 8),
@@ -1167,35 +1181,36 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     h->pair_memo_max_b = opt.pair_memo_max_batch; h->pair_infl = opt.pair_inflation; h->nn_sets = opt.anchored_lists != 0; h->anchor_reach = opt.anchor_reach;
     h->spin_wait = opt.spin_wait != 0; h->factor_valu = opt.factor_mfma == 0;
     h->chain_fold = opt.chain_fold != 0; h->chain_cap = opt.max_chain_batch;
-    if (const char* e = std::getenv("IBA_NN_ROUNDS")) h->nn_rounds = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IBA_DONE_FLAG")) h->done_flag_on = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IBA_NN_CG")) { h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e))); h->nn_cg_fixed = true; }
-    if (const char* e = std::getenv("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
-    if (const char* e = std::getenv("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
-    if (const char* e = std::getenv("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
-    if (const char* e = std::getenv("IBA_FACTOR_V1")) h->factor_v2 = std::atoi(e) == 0;
-    if (const char* e = std::getenv("IBA_FACTOR_WAVES_PER_CAND")) h->factor_waves_forced = std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("IBA_COMMON_PAIRS")) h->common_mode = std::atoi(e);
-    if (const char* e = std::getenv("IBA_NN_SETS")) h->nn_sets = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IBA_SPIN_WAIT")) h->spin_wait = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IBA_ANCHOR_REACH")) h->anchor_reach = std::atof(e);
-    if (const char* e = std::getenv("IBA_PAIR_BOUND")) h->pair_bound = std::atoi(e);
-    if (const char* e = std::getenv("IBA_ASSOC2_FLREG")) h->assoc2_flreg_on = std::atoi(e);
-    if (const char* e = std::getenv("IBA_PAIR_MEMO")) h->pair_memo = std::atoi(e);
-    if (const char* e = std::getenv("IBA_PAIR_INFL")) h->pair_infl = std::max(1.0, std::atof(e));
-    if (const char* e = std::getenv("IBA_PAIR_MEMO_MAX_B")) h->pair_memo_max_b = std::atoi(e);
-    if (const char* e = std::getenv("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
-    if (const char* e = std::getenv("IBA_PAIRS_DENSE_MIN")) h->pairs_dense_min = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("IBA_ASSOC2_THREADS")) { const int v = std::atoi(e); h->assoc2_threads_forced = (v == 256 || v == kThreads) ? v : 0; }
-    if (const char* e = std::getenv("IBA_ASSOC2_SMALL_MIN")) h->assoc2_small_min_blocks = std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("IBA_PAIR_GROUPS")) h->max_groups = std::max(1, std::min(kMaxPairGroups, std::atoi(e)));
-    if (const char* e = std::getenv("IBA_CHAIN_FOLD")) h->chain_fold = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IBA_MAX_CHAIN")) h->chain_cap = std::atoi(e);
+    if (const char* e = dbg_env("IBA_NN_ROUNDS")) h->nn_rounds = std::atoi(e) != 0;
+    if (const char* e = dbg_env("IBA_DONE_FLAG")) h->done_flag_on = std::atoi(e) != 0;
+    if (const char* e = dbg_env("IBA_NN_CG")) { h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e))); h->nn_cg_fixed = true; }
+    if (const char* e = dbg_env("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
+    if (const char* e = dbg_env("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
+    if (const char* e = dbg_env("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
+    if (const char* e = dbg_env("IBA_FACTOR_V2")) h->factor_v2 = std::atoi(e) != 0;
+    if (const char* e = dbg_env("IBA_FACTOR_DBG")) h->factor_dbg = std::atoi(e);
+    if (const char* e = dbg_env("IBA_FACTOR_WAVES_PER_CAND")) h->factor_waves_forced = std::max(0, std::atoi(e));
+    if (const char* e = dbg_env("IBA_COMMON_PAIRS")) h->common_mode = std::atoi(e);
+    if (const char* e = dbg_env("IBA_NN_SETS")) h->nn_sets = std::atoi(e) != 0;
+    if (const char* e = dbg_env("IBA_SPIN_WAIT")) h->spin_wait = std::atoi(e) != 0;
+    if (const char* e = dbg_env("IBA_ANCHOR_REACH")) h->anchor_reach = std::atof(e);
+    if (const char* e = dbg_env("IBA_PAIR_BOUND")) h->pair_bound = std::atoi(e);
+    if (const char* e = dbg_env("IBA_ASSOC2_FLREG")) h->assoc2_flreg_on = std::atoi(e);
+    if (const char* e = dbg_env("IBA_PAIR_MEMO")) h->pair_memo = std::atoi(e);
+    if (const char* e = dbg_env("IBA_PAIR_INFL")) h->pair_infl = std::max(1.0, std::atof(e));
+    if (const char* e = dbg_env("IBA_PAIR_MEMO_MAX_B")) h->pair_memo_max_b = std::atoi(e);
+    if (const char* e = dbg_env("IBA_COMMON_MIN_BATCH")) h->common_min_batch = std::max(1, std::atoi(e));
+    if (const char* e = dbg_env("IBA_COMMON_MAX_PX")) h->common_max_px = std::atof(e);
+    if (const char* e = dbg_env("IBA_PAIRS_DENSE_MIN")) h->pairs_dense_min = (uint32_t)std::max(0, std::atoi(e));
+    if (const char* e = dbg_env("IBA_ASSOC2_THREADS")) { const int v = std::atoi(e); h->assoc2_threads_forced = (v == 256 || v == kThreads) ? v : 0; }
+    if (const char* e = dbg_env("IBA_ASSOC2_SMALL_MIN")) h->assoc2_small_min_blocks = std::max(0, std::atoi(e));
+    if (const char* e = dbg_env("IBA_PAIR_GROUPS")) h->max_groups = std::max(1, std::min(kMaxPairGroups, std::atoi(e)));
+    if (const char* e = dbg_env("IBA_CHAIN_FOLD")) h->chain_fold = std::atoi(e) != 0;
+    if (const char* e = dbg_env("IBA_MAX_CHAIN")) h->chain_cap = std::atoi(e);
     h->chain_cap = std::max(1, std::min(h->chain_cap, (int)kMaxChain));
     if (!layout_assoc(h, h->alay)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "keypoints per frame exceed the LDS plan"); }
     if (!layout_assoc2(h, h->alay2) || 8u * (uint32_t)kPairStage + 160u + 2u * std::max(h->maxCoarse, 1u) + 8u * std::max(h->maxK, 1u) > kLdsBytes) h->common_mode = 0;
-    if (std::getenv("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
+    if (dbg_env("IBA_LAYOUT_DEBUG")) std::fprintf(stderr, "[iba] assoc LDS: total %u B, queue %u entries, pairs %u, bitmap@%u; maxK %u maxKw %u\n", h->alay.total, h->alay.cand_cap, h->alay.pair_cap, h->alay.off_bitmap, h->maxK, h->maxKw);
     { NNLayout probe; if (!layout_nn(h, probe)) { delete h; return fail(nullptr, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel"); } }
     h->lstride = std::max(1u, std::min(h->maxK, h->maxKw));
     // ... rounded up to an ODD count (r05): with 8 candidates per block a keyframe has 8 x NS search blocks, and a power of two of them per keyframe
@@ -1265,7 +1280,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
         h->pair_cap = (int)std::min<uint32_t>(65536u, std::max<uint32_t>(std::max<uint32_t>(2048u, 4u * h->maxK), h->maxP / 4u));
         h->hard_cap = 1024;
         if (opt.pair_list_capacity > 0) { h->pair_cap = opt.pair_list_capacity; h->hard_cap = std::max(1, opt.pair_list_capacity / 8); }
-        if (const char* e = std::getenv("IBA_DEBUG_PAIR_CAP")) { h->pair_cap = std::max(1, std::atoi(e)); h->hard_cap = std::max(1, std::atoi(e) / 8); }   // tests: force the overflow path
+        if (const char* e = dbg_env("IBA_DEBUG_PAIR_CAP")) { h->pair_cap = std::max(1, std::atoi(e)); h->hard_cap = std::max(1, std::atoi(e) / 8); }   // tests: force the overflow path
         h->pair_cap = std::min(h->pair_cap, 65536);   // (iba_assoc2_kernel notes pair numbers as u16)
         // kMaxPairGroups list slots (one group of candidates each); two counter sets per slot, used in turn (the pair search clears the set of the slot's NEXT build)
         if ((er = h->d_pairs.alloc((size_t)kMaxPairGroups * std::max(nf, 1) * h->pair_cap)) != hipSuccess) return bail("alloc pairs", er);
@@ -1486,7 +1501,7 @@ double iba_debug_nn_left_to_tree(iba_handle* h) {
     if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1.0;
     if (hipMemcpy(v.data(), h->d_nn_partials.p, v.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
     double t = 0; for (size_t i = 5; i < v.size(); i += kNNPartial) t += v[i];
-    if (std::getenv("IBA_DEBUG_LEFT_HIST")) {   // blocks by the number of entries they searched in the tree
+    if (dbg_env("IBA_DEBUG_LEFT_HIST")) {   // blocks by the number of entries they searched in the tree
         const int edges[] = {0, 1, 9, 17, 33, 65, 129, 257, 1 << 30};
         int hist[8] = {0};
         for (size_t i = 5; i < v.size(); i += kNNPartial) for (int k = 0; k < 8; ++k) if (v[i] >= edges[k] && v[i] < edges[k + 1]) ++hist[k];
@@ -1534,6 +1549,8 @@ iba_status iba_debug_counters(iba_handle* h, uint32_t out4[4], int32_t reset) {
     if (reset && hipMemset(h->d_diag.p, 0, 16) != hipSuccess) return fail(h, IBA_ERR_HIP, "memset");
     return IBA_OK;
 }
+int32_t iba_debug_last_assoc2_threads(const iba_handle* h) { return h ? h->last_assoc2_threads : -1; }
+int32_t iba_debug_factor_ranges(const iba_handle* h, int32_t B) { return h ? factor_waves(h, B) : -1; }
 int32_t iba_debug_pairs_builds(const iba_handle* h) { return h ? h->pairs_builds : -1; }
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }
 

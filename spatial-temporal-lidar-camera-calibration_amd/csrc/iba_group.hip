@@ -307,8 +307,8 @@ iba_status iba_group_create_ex(const iba_problem_desc* desc, const iba_params* p
     g->dev.assign(devices, devices + n_devices);
     g->h.assign(n_devices, nullptr); g->comm.assign(n_devices, nullptr); g->st.assign(n_devices, nullptr); g->d_part.assign(n_devices, nullptr); g->h_parts.assign(n_devices, nullptr); g->h_parts_dev.assign(n_devices, nullptr);
     g->enq_us.assign(n_devices, 0.0);
-    if (const char* e = std::getenv("IBA_GROUP_TIMEOUT_MS")) g->wait_timeout_ms = std::max(1.0, std::atof(e));
-    if (const char* e = std::getenv("IBA_DEBUG_FAIL_RANK")) { g->debug_fail_rank = std::atoi(e); g->debug_fail_armed = true; if (const char* ph = std::getenv("IBA_DEBUG_FAIL_PHASE")) g->debug_fail_phase = std::atoi(ph); }
+    if (const char* e = debug_env("IBA_GROUP_TIMEOUT_MS")) g->wait_timeout_ms = std::max(1.0, std::atof(e));
+    if (const char* e = debug_env("IBA_DEBUG_FAIL_RANK")) { g->debug_fail_rank = std::atoi(e); g->debug_fail_armed = true; if (const char* ph = debug_env("IBA_DEBUG_FAIL_PHASE")) g->debug_fail_phase = std::atoi(ph); }
     g->cands.resize(kMaxChain); g->h_sum.resize((size_t)kMaxChain * g->stride);
     shard(desc, n_devices, g->f_begin, g->f_end);
     g->pool.start(n_devices, [g](int i) { (void)hipSetDevice(g->dev[i]); });   // once: every HIP call of a worker targets its device

@@ -25,6 +25,8 @@ void make_cands_jets_host(const double* x, int B, Cand* out);   // the derivativ
 iba_status build_problem_cands(iba_handle* h, const Cand* host_cand);
 // work buffers for batches of up to B candidates, so that no evaluation allocates
 iba_status reserve_batch(iba_handle* h, int B);
+// getenv(name) when IBA_DEBUG_ENV=1 is set, nullptr otherwise: every environment override of the library is a debug aid (include/iba_mi355x_debug.h)
+const char* debug_env(const char* name);
 // candidates one launch chain takes on this handle (iba_create_options.max_chain_batch; IBA_MAX_BATCH while the planes are refitted per evaluation)
 int chain_capacity(const iba_handle* h);
 

@@ -723,7 +723,17 @@ __global__ void iba_kernarg_probe_kernel(KArgs ka_by_value, int32_t* ok) {
 // the accumulation H += (w J_i) J_j of terms that are already formed may fuse its multiply-add: that changes the sums by parts in
 // 1e-16 of a term, not by the cancellation the Jacobian chain is sensitive to (measured: per-entry agreement unchanged)
 #define IBA_ACC_CONTRACT _Pragma("clang fp contract(fast)")
-struct NAcc { double H[28], b[7], chi2, cost, nf2d, nfpl, nfpt, nres; };
+struct NAcc {
+    double H[28], b[7], chi2, cost, nf2d, nfpl, nfpt, nres;
+    __device__ __forceinline__ void count(int f2d, int fpl, int fpt, int rows) { nf2d += (double)f2d; nfpl += (double)fpl; nfpt += (double)fpt; nres += (double)rows; }
+};
+// the same sums with the four block / row counters as integers in three registers instead of four doubles in eight (iba_factor2_kernel holds its
+// accumulators for a whole range of a candidate's list and needs the registers; a lane evaluates < 65536 blocks of a kind: factor_waves() sees to it)
+struct NAccP {
+    double H[28], b[7], chi2, cost;
+    uint32_t c2d_pl, cpt, rows;
+    __device__ __forceinline__ void count(int f2d, int fpl, int fpt, int nr) { c2d_pl += (uint32_t)f2d | ((uint32_t)fpl << 16); cpt += (uint32_t)fpt; rows += (uint32_t)nr; }
+};
 
 __device__ __forceinline__ double fdot3(double a0, double b0, double a1, double b1, double a2, double b2) { return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0)); }
 __device__ __forceinline__ double fdot3c(double a0, double b0, double a1, double b1, double a2, double b2, double c) { return __builtin_fma(a2, b2, __builtin_fma(a1, b1, __builtin_fma(a0, b0, c))); }
@@ -747,12 +757,12 @@ struct Cam4 { double fx, fy, cx, cy; };
 // The keypoint's matches in its first kMatchPre covisible slots, loaded UNCONDITIONALLY (a slot without a match holds NaN and its bit is clear): the
 // loads need neither the flag word nor each other — a kernel issues them with its other gathers instead of one dependent round trip per matched slot
 // (r06; the slots beyond, if a keyframe has them, are still fetched as the loop reaches them)
-constexpr int kMatchPre = 4;
-struct MatchPre { float u0, v0, u1, v1, u2, v2, u3, v3; };   // (plain floats: a struct of float2 was kept in scratch memory by the selects below)
+constexpr int kMatchPre = 3;
+struct MatchPre { float u0, v0, u1, v1, u2, v2; };   // (plain floats: a struct of float2 was kept in scratch memory by the selects below)
 __device__ __forceinline__ MatchPre load_match_pre(const float2* mrow, size_t K, uint32_t n_slots) {
     const float2 z = make_float2(0.f, 0.f);
-    const float2 a = 0u < n_slots ? mrow[0] : z, b = 1u < n_slots ? mrow[K] : z, c = 2u < n_slots ? mrow[2 * K] : z, d = 3u < n_slots ? mrow[3 * K] : z;
-    return MatchPre{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+    const float2 a = 0u < n_slots ? mrow[0] : z, b = 1u < n_slots ? mrow[K] : z, c = 2u < n_slots ? mrow[2 * K] : z;
+    return MatchPre{a.x, a.y, b.x, b.y, c.x, c.y};
 }
 template <bool MANY, class RelFn, class SlotFn>
 __device__ __forceinline__ int plane_core(const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], const Cam4& cam, double Cxz, double Cyz,
@@ -797,7 +807,7 @@ __device__ __forceinline__ int plane_core(const double* R, const double* t, cons
         while (mask) {
             const uint32_t sl = base + (uint32_t)__ffs((int)mask) - 1u;
             mask &= mask - 1u;
-            float2 m = make_float2(sl == 0u ? mp.u0 : (sl == 1u ? mp.u1 : (sl == 2u ? mp.u2 : mp.u3)), sl == 0u ? mp.v0 : (sl == 1u ? mp.v1 : (sl == 2u ? mp.v2 : mp.v3)));
+            float2 m = make_float2(sl == 0u ? mp.u0 : (sl == 1u ? mp.u1 : mp.u2), sl == 0u ? mp.v0 : (sl == 1u ? mp.v1 : mp.v2));
             if (sl >= (uint32_t)kMatchPre) m = mrow[(size_t)sl * K];
             double ts[3];
             const double* rel = rel_of(sl, ts);
@@ -820,9 +830,9 @@ __device__ __forceinline__ int plane_core(const double* R, const double* t, cons
 }
 
 // the sums of one IBA_PlaneFactor block into the lane's accumulators
-template <bool MANY, class RelFn>
+template <bool MANY, class RelFn, class Acc>
 __device__ __forceinline__ void plane_accum(const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], const Cam4& cam, double Cxz, double Cyz, const double* p0, const double* n0,
-                                            uint32_t m0, uint32_t m1, const float2* mrow, size_t K, const MatchPre mp, RelFn rel_of, double delta, NAcc& A) {
+                                            uint32_t m0, uint32_t m1, const float2* mrow, size_t K, const MatchPre mp, RelFn rel_of, double delta, Acc& A) {
     IBA_JAC_CONTRACT
     double z6[6];
     double ssq = 0, G = 0, GH = 0, HH = 0, Gr = 0, Hr = 0;
@@ -834,7 +844,7 @@ IBA_ACC_CONTRACT
     });
     if (nconv == 0) return;
     double rho0, w; huber_w(delta, ssq, rho0, w);
-    A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0 * nconv;
+    A.cost += 0.5 * rho0; A.chi2 += ssq; A.count(1, 0, 0, 2 * nconv);
     {
         IBA_ACC_CONTRACT
         for (int i = 0; i < 6; ++i) {
@@ -870,7 +880,7 @@ __device__ __forceinline__ int edge_core(const double* R, const double* t, const
         while (mask) {
             const uint32_t sl = base + (uint32_t)__ffs((int)mask) - 1u;
             mask &= mask - 1u;
-            float2 m = make_float2(sl == 0u ? mp.u0 : (sl == 1u ? mp.u1 : (sl == 2u ? mp.u2 : mp.u3)), sl == 0u ? mp.v0 : (sl == 1u ? mp.v1 : (sl == 2u ? mp.v2 : mp.v3)));
+            float2 m = make_float2(sl == 0u ? mp.u0 : (sl == 1u ? mp.u1 : mp.u2), sl == 0u ? mp.v0 : (sl == 1u ? mp.v1 : mp.v2));
             if (sl >= (uint32_t)kMatchPre) m = mrow[(size_t)sl * K];
             double ts[3];
             const double* rel = rel_of(sl, ts);   // ts = t_i * _s (IBACalib.hpp:48)
@@ -896,14 +906,14 @@ __device__ __forceinline__ int edge_core(const double* R, const double* t, const
     return nconv;
 }
 // every edge is a residual block of its own: its own Huber weight (g2o: RobustKernelHuber per edge; delta = robust_kernel_delta)
-template <bool MANY, class RelFn>
+template <bool MANY, class RelFn, class Acc>
 __device__ __forceinline__ void edge_accum(const double* R, const double* t, const double (*dR)[9], const double (*dt)[3], const Cam4& cam, const double* p0,
-                                           uint32_t m0, uint32_t m1, const float2* mrow, size_t K, const MatchPre mp, RelFn rel_of, double delta, NAcc& A) {
+                                           uint32_t m0, uint32_t m1, const float2* mrow, size_t K, const MatchPre mp, RelFn rel_of, double delta, Acc& A) {
     IBA_JAC_CONTRACT
     edge_core<MANY>(R, t, dR, dt, cam, p0, m0, m1, mrow, K, mp, rel_of, [&](double ru, double rv, const double* Ju, const double* Jv) {
         const double ssq = ru * ru + rv * rv;
         double rho0, w; huber_w(delta, ssq, rho0, w);
-        A.cost += 0.5 * rho0; A.chi2 += ssq; A.nf2d += 1.0; A.nres += 2.0;
+        A.cost += 0.5 * rho0; A.chi2 += ssq; A.count(1, 0, 0, 2);
         {
             IBA_ACC_CONTRACT
             for (int i = 0; i < 7; ++i) {
@@ -939,12 +949,12 @@ __device__ __forceinline__ void p2x_accum(const double* Rlc, const double* tlc, 
         double J[7];
         for (int kk = 0; kk < 7; ++kk) J[kk] = fdot3(dM[kk][0], n[0], dM[kk][1], n[1], dM[kk][2], n[2]);
         double rho0, w; huber_w(delta3, r * r, rho0, w);
-        A.cost += 0.5 * rho0; A.chi2 += r * r; A.nfpl += 1.0; A.nres += 1.0;
+        A.cost += 0.5 * rho0; A.chi2 += r * r; A.count(0, 1, 0, 1);
         { IBA_ACC_CONTRACT for (int i = 0; i < 7; ++i) { const double wj = w * J[i]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * J[j]; A.b[i] += wj * r; } }
     } else {
         const double ssq = fdot3(e[0], e[0], e[1], e[1], e[2], e[2]);
         double rho0, w; huber_w(delta3, ssq, rho0, w);
-        A.cost += 0.5 * rho0; A.chi2 += ssq; A.nfpt += 1.0; A.nres += 3.0;
+        A.cost += 0.5 * rho0; A.chi2 += ssq; A.count(0, 0, 1, 3);
         { IBA_ACC_CONTRACT for (int r = 0; r < 3; ++r)
             for (int i = 0; i < 7; ++i) { const double wj = w * dM[i][r]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * dM[j][r]; A.b[i] += wj * e[r]; } }
     }
@@ -960,7 +970,8 @@ __device__ __forceinline__ void p2x_head(const double* Rlc, const double* tlc, d
     for (int r = 0; r < 3; ++r) e[r] = fdot3c(Rlc[r * 3], sm[0], Rlc[r * 3 + 1], sm[1], Rlc[r * 3 + 2], sm[2], tlc[r]) - Q[r];
 }
 // Point2Plane_Factor (IBACalib2.hpp:611-625): one row J = n^T dM/dx
-__device__ __forceinline__ void p2pl_accum(const double* Rlc, const double* tlc, const double (*dRlc)[9], const double (*dtlc)[3], double s, const double* Tcw, double delta3, const float4 mp, const double* Q, const double* n, NAcc& A) {
+template <class Acc>
+__device__ __forceinline__ void p2pl_accum(const double* Rlc, const double* tlc, const double (*dRlc)[9], const double (*dtlc)[3], double s, const double* Tcw, double delta3, const float4 mp, const double* Q, const double* n, Acc& A) {
     IBA_JAC_CONTRACT
     double m[3], sm[3], e[3];
     p2x_head(Rlc, tlc, s, Tcw, mp, Q, m, sm, e);
@@ -983,17 +994,18 @@ __device__ __forceinline__ void p2pl_accum(const double* Rlc, const double* tlc,
         J[6] = fdot3(d6[0], n[0], d6[1], n[1], d6[2], n[2]);
     }
     double rho0, w; huber_w(delta3, r * r, rho0, w);
-    A.cost += 0.5 * rho0; A.chi2 += r * r; A.nfpl += 1.0; A.nres += 1.0;
+    A.cost += 0.5 * rho0; A.chi2 += r * r; A.count(0, 1, 0, 1);
     { IBA_ACC_CONTRACT for (int i = 0; i < 7; ++i) { const double wj = w * J[i]; for (int j = i; j < 7; ++j) A.H[hidx(i, j)] += wj * J[j]; A.b[i] += wj * r; } }
 }
 // Point2Point_Factor (IBACalib2.hpp:570-584): three rows, row rr = d M_rr / dx
-__device__ __forceinline__ void p2pt_accum(const double* Rlc, const double* tlc, const double (*dRlc)[9], const double (*dtlc)[3], double s, const double* Tcw, double delta3, const float4 mp, const double* Q, NAcc& A) {
+template <class Acc>
+__device__ __forceinline__ void p2pt_accum(const double* Rlc, const double* tlc, const double (*dRlc)[9], const double (*dtlc)[3], double s, const double* Tcw, double delta3, const float4 mp, const double* Q, Acc& A) {
     IBA_JAC_CONTRACT
     double m[3], sm[3], e[3];
     p2x_head(Rlc, tlc, s, Tcw, mp, Q, m, sm, e);
     const double ssq = fdot3(e[0], e[0], e[1], e[1], e[2], e[2]);
     double rho0, w; huber_w(delta3, ssq, rho0, w);
-    A.cost += 0.5 * rho0; A.chi2 += ssq; A.nfpt += 1.0; A.nres += 3.0;
+    A.cost += 0.5 * rho0; A.chi2 += ssq; A.count(0, 0, 1, 3);
 #pragma unroll 1
     for (int rr = 0; rr < 3; ++rr) {
         double v[7];
@@ -1107,52 +1119,99 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
     __shared__ uint2 s_qa[kFactorThreads / 64][kQ], s_qb[kFactorThreads / 64][kQ];   // (keypoint, scan point) of a plane factor / (keypoint, point | kind) of a 3d-3d factor
     uint2* qa = s_qa[wave]; uint2* qb = s_qb[wave];
     uint32_t ha = 0u, ta = 0u, hb = 0u, tb = 0u;   // ring heads / tails (wave-uniform)
-    auto plane_batch = [&](uint32_t cnt) {   // the first min(cnt, 64) plane factors of the queue
-        if ((uint32_t)lane < cnt) {
-            const uint2 q = qa[(ha + (uint32_t)lane) & (kQ - 1u)];
-            const float4 pt = p4[q.y];
-            const double p0[3] = {(double)pt.x, (double)pt.y, (double)pt.z};
-            if (P2PIX) test_edge_accum<MANY>(c, h, dp, prm, q.x, h.K, p0, A, s_rel);
+    // Round 6: a body is two halves — its GATHERS (unconditional: a lane without a block reads element 0 of every table, so that no load is merged
+    // with a default behind a branch and waited for on the spot) and its ARITHMETIC; the gathers of the plane-factor batch and of the 3d-3d batch
+    // that are due go out together. The hand-over between the lanes of the one wave is a wavefront-scope fence: the LDS executes a wave's
+    // instructions in order, and a workgroup-scope release would wait for every load in flight (vmcnt(0)) — the next round's entries among them.
+    struct PIn { bool on; uint32_t k, m0, m1; float px, py, pz; double n0x, n0y, n0z, u0, v0; MatchPre mp; };
+    struct QIn { bool on, pl; float qx, qy, qz, mx, my, mz; double nx, ny, nz; };
+    const float2* mtab = dp.match_uv + h.match_base;
+    const uint32_t n_sl = h.n_slots, Kf = h.K;
+    auto plane_load = [&](uint32_t cnt) -> PIn {
+        PIn in;
+        in.on = (uint32_t)lane < cnt;
+        uint2 q = make_uint2(0u, 0u);
+        if (in.on) q = qa[(ha + (uint32_t)lane) & (kQ - 1u)];
+        in.k = q.x;
+        const bool has_m = n_sl > 0u;
+        {
+            const float2* mrow = mtab + (has_m ? q.x : 0u);
+            const size_t s1 = has_m ? (size_t)min(1u, n_sl - 1u) * Kf : 0, s2 = has_m ? (size_t)min(2u, n_sl - 1u) * Kf : 0;
+            const float2 a = has_m ? mrow[0] : dp.match_uv[0], bq = has_m ? mrow[s1] : dp.match_uv[0], cq = has_m ? mrow[s2] : dp.match_uv[0];
+            in.mp = MatchPre{a.x, a.y, bq.x, bq.y, cq.x, cq.y};
+        }
+        const float4 pt = p4[q.y];
+        in.px = pt.x; in.py = pt.y; in.pz = pt.z;
+        in.m0 = dp.kp_fl[h.kp_base + q.x] >> 2; in.m1 = (MANY && n_sl > (uint32_t)kCovisWord) ? dp.kp_fl2[h.kp_base + q.x] : 0u;
+        if (!P2PIX) {
+            const PlaneRec& rec = planes[q.y];
+            in.n0x = rec.nx; in.n0y = rec.ny; in.n0z = rec.nz;
+            const float2 uv = dp.kp_uv[h.kp_base + q.x];
+            in.u0 = (double)uv.x; in.v0 = (double)uv.y;
+        } else { in.n0x = in.n0y = in.n0z = in.u0 = in.v0 = 0.0; }
+        ha += min(cnt, 64u);
+        return in;
+    };
+    const double cs = c.s;
+    auto rel_of = [&](uint32_t sl, double* ts) { const double* rel = s_rel + sl * 12u; ts[0] = rel[3] * cs; ts[1] = rel[7] * cs; ts[2] = rel[11] * cs; return (const double*)rel; };
+    const Cam4 cam{h.fx, h.fy, h.cx, h.cy};
+    auto plane_compute = [&](const PIn& in) {
+        if (in.on) {
+            const double p0[3] = {(double)in.px, (double)in.py, (double)in.pz};
+            if (P2PIX) edge_accum<MANY>(c.R, c.t, c.dR, c.dt, cam, p0, in.m0, in.m1, mtab + in.k, (size_t)Kf, in.mp, rel_of, prm.robust_kernel_delta, A);
             else {
-                const PlaneRec& rec = planes[q.y];
-                const double n0[3] = {rec.nx, rec.ny, rec.nz};
-                const float2 uv = dp.kp_uv[h.kp_base + q.x];
-                plane_factor_accum<MANY>(c, h, dp, prm, q.x, h.K, (double)uv.x, (double)uv.y, p0, n0, A, s_rel);
+                const double n0[3] = {in.n0x, in.n0y, in.n0z};
+                const double Cxz = (in.u0 - h.cx) / h.fx, Cyz = (in.v0 - h.cy) / h.fy;
+                plane_accum<MANY>(c.R, c.t, c.dR, c.dt, cam, Cxz, Cyz, p0, n0, in.m0, in.m1, mtab + in.k, (size_t)Kf, in.mp, rel_of, prm.robust_kernel_delta, A);
             }
         }
-        ha += min(cnt, 64u);
     };
-    auto p2x_batch = [&](uint32_t cnt) {
-        if ((uint32_t)lane < cnt) {
-            const uint2 q = qb[(hb + (uint32_t)lane) & (kQ - 1u)];
-            const uint32_t pos3 = q.y & 0x7FFFFFFFu;
-            const float4 pt3 = p4[pos3], mp3 = dp.kp_mp[h.kp_base + q.x];
-            const PlaneRec& r3 = planes[pos3];
-            const double Q[3] = {(double)pt3.x, (double)pt3.y, (double)pt3.z}, nn[3] = {r3.nx, r3.ny, r3.nz};
-            p2x_factor_accum(c, h, prm, mp3, Q, nn, (q.y >> 31) != 0, A);
-        }
+    auto p2x_load = [&](uint32_t cnt) -> QIn {
+        QIn in;
+        in.on = (uint32_t)lane < cnt;
+        uint2 q = make_uint2(0u, 0u);
+        if (in.on) q = qb[(hb + (uint32_t)lane) & (kQ - 1u)];
+        const uint32_t pos3 = q.y & 0x7FFFFFFFu;
+        in.pl = (q.y >> 31) != 0u;
+        const float4 pt3 = p4[pos3], mp3 = dp.kp_mp[h.kp_base + q.x];
+        const PlaneRec& r3 = planes[pos3];
+        in.qx = pt3.x; in.qy = pt3.y; in.qz = pt3.z; in.mx = mp3.x; in.my = mp3.y; in.mz = mp3.z; in.nx = r3.nx; in.ny = r3.ny; in.nz = r3.nz;
         hb += min(cnt, 64u);
+        return in;
     };
-    auto lds_order = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
-    uint4 e_n = make_uint4(0u, kNone, kNone, 0u);
-    if ((uint32_t)tid < n) e_n = fl[tid];
+    auto p2x_compute = [&](const QIn& in) {
+        if (in.on) {
+            const double Q[3] = {(double)in.qx, (double)in.qy, (double)in.qz}, nn[3] = {in.nx, in.ny, in.nz};
+            const float4 mp3 = make_float4(in.mx, in.my, in.mz, 0.f);
+            if (in.pl) p2pl_accum(c.Rlc, c.tlc, c.dRlc, c.dtlc, cs, h.Tcw, prm.robust_kernel_3ddelta, mp3, Q, nn, A);
+            else p2pt_accum(c.Rlc, c.tlc, c.dRlc, c.dtlc, cs, h.Tcw, prm.robust_kernel_3ddelta, mp3, Q, A);
+        }
+    };
+    auto both = [&](uint32_t ca, uint32_t cb) { const PIn ia = plane_load(ca); const QIn ib = p2x_load(cb); p2x_compute(ib); plane_compute(ia); };
+    auto lds_order = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    // (three of an entry's four words, loaded unconditionally — lanes past the end read the last entry again: see iba_factor2_kernel.hpp)
+    auto entry_at = [&](uint32_t i) -> uint4 {
+        typedef uint32_t u3v __attribute__((ext_vector_type(3)));
+        const u3v v = *(const u3v*)(fl + min(i, n - 1u));
+        return make_uint4(v.x, v.y, v.z, 0u);
+    };
+    if (n > 0u) {
+    uint4 e_n = entry_at((uint32_t)tid);
     for (uint32_t i0 = 0; i0 < n; i0 += kFactorThreads) {
         const uint32_t i = i0 + (uint32_t)tid;
         const uint4 e = e_n;
-        e_n = make_uint4(0u, kNone, kNone, 0u);
-        if (i + kFactorThreads < n) e_n = fl[i + kFactorThreads];   // the next entries are in flight during this round's arithmetic
+        e_n = entry_at(i + kFactorThreads);   // the next entries are in flight during this round's arithmetic
         const bool hp = i < n && e.y != kNone, h3 = i < n && e.z != kNone;
         const unsigned long long bp = __ballot(hp), b3 = __ballot(h3), lt = (1ull << lane) - 1ull;
         if (hp) qa[(ta + (uint32_t)__popcll(bp & lt)) & (kQ - 1u)] = make_uint2(e.x, e.y);
         if (h3) qb[(tb + (uint32_t)__popcll(b3 & lt)) & (kQ - 1u)] = make_uint2(e.x, e.z);
         ta += (uint32_t)__popcll(bp); tb += (uint32_t)__popcll(b3);
         lds_order();
-        if (ta - ha >= 64u) plane_batch(64u);
-        if (tb - hb >= 64u) p2x_batch(64u);
+        if (ta - ha >= 64u || tb - hb >= 64u) both(ta - ha >= 64u ? 64u : 0u, tb - hb >= 64u ? 64u : 0u);   // (wave-uniform)
         lds_order();   // the slots just read may be rewritten by the next round
     }
-    if (ta - ha) plane_batch(ta - ha);
-    if (tb - hb) p2x_batch(tb - hb);
+    }
+    if (ta - ha || tb - hb) both(ta - ha, tb - hb);
     // fixed-order reduction through LDS: every lane parks its 41 sums (two halves of <= 21 through an 11 KB transposing
     // buffer), then lane v adds the 64 lanes' values of sum v in lane order. (The DPP butterfly this replaces cost 12 moves
     // and 6 adds per 64-bit sum: 1.5 k instructions per block, a quarter of the kernel.)

@@ -20,6 +20,11 @@ except Exception:   # the CPU tier runs without it too
     torch = None
 
 
+# the library reads its debug environment overrides (IBA_FACTOR_MFMA, IBA_NN_ROUNDS, IBA_FACTOR_V2, ...) only when IBA_DEBUG_ENV=1 is set as well
+# (round 6): the tests are the users of those overrides
+os.environ.setdefault("IBA_DEBUG_ENV", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

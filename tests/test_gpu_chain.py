@@ -1,24 +1,11 @@
 """The launch chain of round 5: up to 512 candidates per chain (iba_create_options.max_chain_batch), the candidate block carried to the
 device by spare blocks of the chain's first kernel and the hand-eye terms evaluated beside the searches (chain_fold), against the
 chain of rounds 1-4 (64 candidates, a staging launch at the head: max_chain_batch = 64, chain_fold = 0). A candidate's result may not
-depend on the chain it rode in: the cost tuple and every counter of the 64-double partial blocks are compared BIT FOR BIT. The sums of
-the Jacobian path (H, b, cost, chi^2: slots 12..48) are bit-identical between chains of the same length; since round 6 the factor kernel cuts a
-candidate's work list into as many ranges as the batch leaves it wave slots (csrc/iba_factor2_kernel.hpp), so between chains of DIFFERENT
-length they agree to summation order — held here to 1e-13 of the largest entry."""
+depend on the chain it rode in: the 64-double partial blocks are compared BIT FOR BIT — cost tuple, normal equations, every counter."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-
-JAC = slice(12, 49)   # P_H0 .. P_COST of the partial block (csrc/iba_types.hpp): sums of the factor kernel
-
-
-def _same_blocks(a, b, what):
-    """cost tuple + counters bit for bit; the factor kernel's sums to summation order"""
-    rest = np.ones(a.shape[1], bool); rest[JAC] = False
-    assert np.array_equal(a[:, rest], b[:, rest], equal_nan=True), (what, np.argwhere(a[:, rest] != b[:, rest])[:5])
-    scale = np.maximum(np.max(np.abs(b[:, JAC]), axis=1, keepdims=True), 1e-300)
-    assert np.max(np.abs(a[:, JAC] - b[:, JAC]) / scale) <= 1e-13, (what, np.max(np.abs(a[:, JAC] - b[:, JAC]) / scale))
 
 
 def _blocks(h, xs, kind):
@@ -43,9 +30,8 @@ def test_one_chain_of_many_equals_chains_of_64(pkg, synth, abi, ob, scene_small)
         mid = pkg.IbaHandle(prob, p, options={"max_chain_batch": 100, "chain_fold": 1})          # four chains, the last one short
         for kind in ("full", "cost", "normal"):
             a, b, c = _blocks(big, xs, kind), _blocks(old, xs, kind), _blocks(mid, xs, kind)
-            _same_blocks(a, b, kind)
-            _same_blocks(a, c, kind)
-            assert np.array_equal(a, _blocks(big, xs, kind), equal_nan=True), kind   # (the same chain again: the same bits)
+            assert np.array_equal(a, b, equal_nan=True), (kind, np.argwhere(a != b)[:5])
+            assert np.array_equal(a, c, equal_nan=True), kind
         # ... and the blocking entry points, against the oracle on a few of them
         cost, nrm = big.eval_full(xs)
         o = ob.Oracle(prob)
@@ -58,18 +44,13 @@ def test_one_chain_of_many_equals_chains_of_64(pkg, synth, abi, ob, scene_small)
             assert nrm[i].counts() == r.counts() and np.max(np.abs(nrm[i].H_np() - r.H_np())) <= 1e-8 * np.abs(r.H_np()).max()
         # the mixed batch above is too wide to share one pair search (the per-candidate kernel carried the head); a tight one shares it
         a, b = _blocks(big, xs[:300], "full"), _blocks(old, xs[:300], "full")
-        assert big.last_path == 1
-        _same_blocks(a, b, "tight")
-        # a candidate's sums do not depend on WHERE in a chain it stands: the same 300 in reverse order, same chain length
-        r = _blocks(big, xs[:300][::-1].copy(), "full")
-        assert np.array_equal(a, r[::-1], equal_nan=True)
+        assert big.last_path == 1 and np.array_equal(a, b, equal_nan=True)
         # the frozen problem's residual blocks at 337 other x in one chain (tools/sequence_fuzz.py caught the frozen counts reaching only the
         # first 64 candidates of a longer chain)
         for hh in (big, old):
             hh.build_problem(xs[3])
         fa, fb = big.eval_factors(xs), old.eval_factors(xs)
-        assert all(a.counts() == b.counts() and np.max(np.abs(a.H_np() - b.H_np())) <= 1e-13 * np.abs(b.H_np()).max() and np.max(np.abs(a.b_np() - b.b_np())) <= 1e-13 * np.abs(b.b_np()).max()
-                   and abs(a.cost - b.cost) <= 1e-13 * b.cost for a, b in zip(fa, fb))
+        assert all(a.counts() == b.counts() and np.array_equal(a.H_np(), b.H_np()) and np.array_equal(a.b_np(), b.b_np()) and a.cost == b.cost for a, b in zip(fa, fb))
         assert fa[336].frames_used == fa[0].frames_used > 0 and fa[336].n_corr == fa[0].n_corr > 0
         big.close(); old.close(); mid.close()
     with pytest.raises(pkg.IbaError):

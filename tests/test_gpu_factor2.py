@@ -1,7 +1,7 @@
-"""iba_factor2_kernel (round 6): the normal equations summed by waves that each take an equal share of a candidate's whole work list
-(csrc/iba_factor2_kernel.hpp) instead of one wave per (keyframe, candidate). The cut of a list into ranges may not change what is
+"""iba_factor2_kernel (round 6, opt-in: IBA_FACTOR_V2=1): the normal equations summed by waves that each take an equal share of a candidate's whole
+work list (csrc/iba_factor2_kernel.hpp) instead of one wave per (keyframe, candidate). The cut of a list into ranges may not change what is
 summed: every way of cutting (1 range, 3, 7, one per keyframe, the default rule) must give the sums of the one-wave-per-keyframe kernel
-of rounds 2-5 (IBA_FACTOR_V1=1) up to summation order, the counts exactly, and the oracle's to the usual bars. Shapes that stress the walk:
+of rounds 2-5 (the default) up to summation order, the counts exactly, and the oracle's to the usual bars. Shapes that stress the walk:
 keyframes with a handful of entries (a round of 64 entries spans more keyframes than the LDS ring holds), empty keyframes, more covisible
 keyframes than one flag word (MANY), the frozen problem's shared list, refitted planes, IBATestEdge."""
 import numpy as np
@@ -11,14 +11,18 @@ pytestmark = pytest.mark.gpu
 
 
 def _handle(pkg, prob, p, monkeypatch, v1=False, waves=0, **kw):
-    if v1:
-        monkeypatch.setenv("IBA_FACTOR_V1", "1")
+    """v1: the default kernel (one wave per (keyframe, candidate)); otherwise iba_factor2_kernel (IBA_FACTOR_V2=1, a debug override: read only with
+    IBA_DEBUG_ENV=1, which tests/conftest.py sets), `waves` ranges per candidate (0: its own rule)"""
+    if not v1:
+        monkeypatch.setenv("IBA_FACTOR_V2", "1")
     if waves:
         monkeypatch.setenv("IBA_FACTOR_WAVES_PER_CAND", str(waves))
     try:
-        return pkg.IbaHandle(prob, p, **kw)
+        h = pkg.IbaHandle(prob, p, **kw)
+        assert (h.debug_factor_ranges(4) == 0) == bool(v1)
+        return h
     finally:
-        monkeypatch.delenv("IBA_FACTOR_V1", raising=False)
+        monkeypatch.delenv("IBA_FACTOR_V2", raising=False)
         monkeypatch.delenv("IBA_FACTOR_WAVES_PER_CAND", raising=False)
 
 
@@ -134,3 +138,18 @@ def test_a_batch_that_fills_the_machine(pkg, synth, abi, ob, monkeypatch):
     for a, c in zip(got[:3], o.eval_normal(p, xs[:3], nthreads=4)):
         assert a.counts() == c.counts() and np.max(np.abs(a.H_np() - c.H_np())) <= 1e-9 * np.abs(c.H_np()).max()
     h.close(); h1.close()
+
+
+def test_environment_overrides_need_the_debug_switch(pkg, synth, abi, scene_small, monkeypatch):
+    """IBA_FACTOR_V2=1 (like every environment override of the library) is read only together with IBA_DEBUG_ENV=1"""
+    prob, meta = scene_small
+    p = abi.reference_yaml_params()
+    monkeypatch.setenv("IBA_FACTOR_V2", "1")
+    monkeypatch.setenv("IBA_DEBUG_ENV", "0")
+    h = pkg.IbaHandle(prob, p)
+    assert h.debug_factor_ranges(64) == 0
+    h.close()
+    monkeypatch.setenv("IBA_DEBUG_ENV", "1")
+    h = pkg.IbaHandle(prob, p)
+    assert h.debug_factor_ranges(64) > 0
+    h.close()

@@ -1,4 +1,5 @@
 # A/B of two builds of the library on the same box: per-kernel averages (30 evaluations each), then the bench line of each
+export IBA_DEBUG_ENV=1   # the library reads its environment overrides only with this set (round 6)
 # usage (GPU box): bash tools/ab_kstats.sh build/lib_base.so
 cd $GRAFT_REPO_ROOT
 for L in "$1" ""; do

@@ -1,6 +1,7 @@
 """GPU box. iba_factor2_kernel's walk at the bench shape: rounds and plane batches per wave (diagnostic counters: `make -C csrc diag`,
 IBA_LIB=<package dir>/libiba_diag.so), list lengths per keyframe. usage: python tools/factor2_probe.py [frames] [B]"""
 import importlib, os, sys
+os.environ["IBA_DEBUG_ENV"] = "1"; os.environ["IBA_FACTOR_V2"] = "1"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,5 +16,11 @@ h.counters()
 n = h.eval_normal(xs)
 c = h.counters()
 W = max(1, min(F, 2048 // B))
-print("B %d F %d: ranges per candidate %d; plane batches %d (%.1f per wave), rounds %d (%.1f per wave); blocks per candidate: 3d2d %d p2pl %d p2pt %d" % (
-    B, F, W, c[2], c[2] / (W * B), c[3], c[3] / (W * B), n[0].n_factor_3d2d, n[0].n_factor_p2pl, n[0].n_factor_p2pt))
+print("B %d F %d: ranges per candidate %d; blocks per candidate: 3d2d %d p2pl %d p2pt %d" % (B, F, W, n[0].n_factor_3d2d, n[0].n_factor_p2pl, n[0].n_factor_p2pt))
+p = h.debug_last_partials(B)
+tot = p.sum(axis=0)
+if tot[63] > 0:
+    names = ["entries landed / next issued", "keyframes staged + blocks queued", "gathers issued", "point-to-plane arithmetic (+ wait for gathers)", "plane-factor arithmetic", "point-to-point batch"]
+    print("cycles per wave (mean over %d waves): whole life %.0f" % (tot[63], tot[62] / tot[63]))
+    for i, nm in enumerate(names):
+        print("   %-48s %8.0f  (%.1f %%)" % (nm, tot[56 + i] / tot[63], 100 * tot[56 + i] / tot[62]))

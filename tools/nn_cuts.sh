@@ -1,4 +1,5 @@
 # cumulative time of the search kernel's phases (IBA_NN_DBG cuts the kernel short; results are garbage, times are not)
+export IBA_DEBUG_ENV=1   # the library reads its environment overrides only with this set (round 6)
 cd $GRAFT_REPO_ROOT
 for k in ${CUTS:-1 2 4 5 3 0}; do
   IBA_NN_DBG=$k python tools/split_probe.py 2>&1 | grep "B=64" | sed "s/^/nn_dbg=$k /"

@@ -1,4 +1,5 @@
 # instruction counts of the association kernel phase by phase: the kernel cut short after each phase (IBA_ASSOC_DBG), one
+export IBA_DEBUG_ENV=1   # the library reads its environment overrides only with this set (round 6)
 # --pmc pass per cut. usage (GPU box): bash tools/pmc_cuts.sh <tag>   -> gpurun_out/<tag>/cuts.txt
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp

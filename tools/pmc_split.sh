@@ -1,4 +1,5 @@
 # per-phase instruction counters of the two-kernel path: one rocprofv3 --pmc pass per cut point (IBA_ASSOC_DBG / IBA_NN_DBG cut the
+export IBA_DEBUG_ENV=1   # the library reads its environment overrides only with this set (round 6)
 # kernels short after a phase; results are garbage, counters are not). usage: bash tools/pmc_split.sh "<counters>" <tag> [mode]
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp

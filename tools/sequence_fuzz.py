@@ -27,15 +27,7 @@ def same_cost(a, b):
 
 
 def same_normal(a, b):
-    """the same bits — for batches that both handles run as ONE chain (up to 64 candidates). A longer batch is one chain on the default handle and
-    chains of 64 on the plain one: the factor kernel (r06, iba_factor2_kernel) cuts a candidate's list into as many ranges as the chain's length leaves
-    it wave slots, so the sums of the Jacobian path agree to summation order there (1e-13 of the largest entry); counters exact either way"""
-    if len(a) <= 64:
-        return all(np.array_equal(x.H_np(), y.H_np(), equal_nan=True) and np.array_equal(x.b_np(), y.b_np(), equal_nan=True) and eq(x.cost, y.cost) and x.counts() == y.counts() for x, y in zip(a, b))
-    def near(u, v):
-        u, v = np.asarray(u, float), np.asarray(v, float)
-        return bool(np.all(np.abs(u - v) <= 1e-13 * max(float(np.max(np.abs(v))), 1e-300)))
-    return all(near(x.H_np(), y.H_np()) and near(x.b_np(), y.b_np()) and near(x.cost, y.cost) and x.counts() == y.counts() for x, y in zip(a, b))
+    return all(np.array_equal(x.H_np(), y.H_np(), equal_nan=True) and np.array_equal(x.b_np(), y.b_np(), equal_nan=True) and eq(x.cost, y.cost) and x.counts() == y.counts() for x, y in zip(a, b))
 
 
 n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 20
