@@ -79,6 +79,9 @@ def job_value(evals, seconds, n_gpus, scaling):
     return evals / seconds
 
 
+SUSTAIN_S = 10.0   # seconds per sustained region of extras.sustained
+
+
 def main():
     args = build_parser().parse_args()
 
@@ -351,7 +354,7 @@ def main():
             #              SIMD cycles that issue a VALU instruction (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)).
             # The old effective figure lives on under effective_vs_reference_formulation (it is not a roofline fraction).
             "bound": "issue", "kernel": "association (iba_pairs_kernel + iba_assoc2_kernel) + search (iba_nn_kernel)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": None, "hbm_frac": None, "traffic": None, "issue_frac": None,
+            "frac": None, "frac_is": "valu_issue_share (4 x SQ_ACTIVE_INST_VALU / SIMD cycles) of the kernels named in `kernel`: NOT bytes / time / peak — that is hbm_frac", "hbm_frac": None, "traffic": None, "issue_frac": None,
             "launch_ms": pair_ms, "evals_per_launch": B, "shared_pair_search": bool(h.last_path),
             "kernel_ms": {"association (pairs + assoc2)": assoc_ms, "iba_nn_kernel": nn_ms, "factor + sums": rest_ms},
             "kernel_ms_how": "HIP events of the library on the launch stream (iba_set_timing), median of 5 launches of the headline's candidates right after the timed regions; the timed regions themselves run with the event timing off, as a caller's do",
@@ -382,6 +385,13 @@ def main():
                     rf["whole_step"] = {"hbm_bytes": pmc["hbm_bytes_per_step"], "hbm_frac": pmc["hbm_bytes_per_step"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                         "issue_frac": pmc.get("valu_issue_frac_step")}
                 rf["pmc_provenance"] = {k: pmc.get(k) for k in ("round", "git_head", "source_stamp", "taken_on", "counters")}
+                # per kernel of one step, from the same counter passes and the committed rocprofv3 summary: duration, share of the HBM peak, VALU-active share
+                pk = pmc.get("per_kernel") or {}
+                step_kernels = {k: v for k, v in pk.items() if not any(t in k for t in ("anchor", "plane_kernel", "verdict"))}
+                if step_kernels:
+                    rf["per_kernel"] = {k: {"avg_us": v.get("avg_us"), "hbm_frac": ((v.get("hbm_read_bytes", 0) + v.get("hbm_write_bytes", 0)) / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if v.get("avg_us") else None,
+                                            "valu_active": v.get("valu_active_share"), "wait_any": v.get("wait_any_share"), "l2_requests": v.get("l2_requests")} for k, v in step_kernels.items()}
+                    rf["longest_kernel"] = max(step_kernels, key=lambda k: step_kernels[k].get("avg_us") or 0.0)
             else:
                 res["roofline"]["pmc_provenance"] = "profiles/pmc_latest.json was taken on another launch shape (%s frames x %s pts x %s candidates): not quoted" % (pmc.get("frames"), pmc.get("pts"), pmc.get("batch"))
         except Exception:
@@ -437,48 +447,6 @@ def main():
                 row[name + "_wall_ms_c_caller"] = h.call_latency(xb, "cost" if name == "cost" else "factors", 100)[0]
             sweep2[str(b)] = row
         extras["batch_sweep_cost_and_factors"] = sweep2
-        # (1c) SUSTAINED regions next to the headline: >= 1.5 s each of back-to-back steps whose 64 candidates are drawn afresh
-        # every step — (a) around the planted extrinsic (the headline's own workload without its four fixed candidate sets: every step
-        # runs its own pair search on candidates it has never seen), (b) around a centre that DRIFTS (a random walk of 0.15 mrad / 1.5 mm
-        # per step, reflected at 6 mrad / 6 cm from the planted extrinsic): the anchored lists are rebuilt as the centre leaves them.
-        # A drifted centre is a LIGHTER workload, not a faster machine — away from the planted extrinsic fewer scan points meet a keypoint
-        # within max_pixel_dist, so every later stage has less to do: the mean correspondence count is reported beside each rate, and only
-        # (a) compares with the headline. evaluations/s over the whole region and min / median / max over windows of 100 steps.
-        def sustained(drift, n_sets=4000):
-            rs = np.random.default_rng(99)
-            centre = meta["x_gt"].copy()
-            sig = np.array([1.5e-4] * 3 + [1.5e-3] * 3 + [2e-4 * abs(meta["x_gt"][6])])
-            box = np.array([6e-3] * 3 + [6e-2] * 3 + [0.02 * abs(meta["x_gt"][6])])
-            sets = []
-            for _ in range(n_sets):   # (generated BEFORE the clock: 60 us of numpy per set are not part of the path)
-                if drift:
-                    centre = centre + rs.normal(size=7) * sig
-                    off = centre - meta["x_gt"]
-                    centre = meta["x_gt"] + np.where(np.abs(off) > box, np.sign(off) * (2 * box - np.abs(off)), off)
-                sets.append(synth.perturb(centre, rs, n=B))
-            n_s, wins, ncs, ab0, pb0 = 0, [], [], h.anchor_builds, h.pairs_builds
-            sync()
-            t00 = time.perf_counter()
-            tw0 = t00
-            while n_s < n_sets:
-                o_ = step(n_s, sets)
-                n_s += 1
-                if n_s % 100 == 0:
-                    tnow = time.perf_counter()
-                    wins.append(100 * B / (tnow - tw0))
-                    ncs.append(float(np.mean([c.n_corr for c in o_[0]])))
-                    tw0 = time.perf_counter()
-                    if tnow - t00 > 1.5 and n_s >= 300:
-                        break
-            sync()
-            t_s = time.perf_counter() - t00
-            return {"seconds": t_s, "steps": n_s, "evals_per_s": n_s * B / t_s, "window_steps": 100,
-                    "window_evals_per_s": {"min": float(np.min(wins)), "median": float(np.median(wins)), "max": float(np.max(wins))},
-                    "mean_n_corr_sampled_every_100_steps": float(np.mean(ncs)), "anchor_builds": h.anchor_builds - ab0, "pair_searches": h.pairs_builds - pb0}
-        extras["sustained"] = {"fresh_candidates_fixed_centre": sustained(False), "fresh_candidates_drifting_centre": sustained(True),
-                               "headline_mean_n_corr": res["config"]["mean_n_corr"],
-                               "what": "64 fresh candidates (0.5 mrad / 5 mm / 0.1 %) per step, every set generated before the clock starts and used once. The drifting "
-                                       "centre wanders up to 6 mrad / 6 cm from the planted extrinsic: fewer correspondences, less work per evaluation (see mean_n_corr) - only the fixed centre compares with the headline"}
         # (2) a batch as wide as the reference's search box (iba_calib_global.yml:39-40: +-0.1 rad, +-0.3 m, +-1 on the scale)
         xw = meta["x_gt"][None, :] + np.random.default_rng(7).uniform(-1, 1, (B, 7)) * np.array([0.1, 0.1, 0.1, 0.3, 0.3, 0.3, 1.0])
         for _ in range(2):
@@ -736,6 +704,48 @@ def main():
                                   "edges_per_s": br.n_edges / t_lin, "optimize_seconds": t_opt, "device_evaluations": int(br.evaluations),
                                   "err_vs_planted": {"rot_rad": float(np.linalg.norm(bx[:3] - bx_gt[:3])), "trans_m": float(np.linalg.norm(bx[3:6] - bx_gt[3:6])), "scale": float(abs(bx[6] - bx_gt[6]))}}
             bh.close()
+        # (1c) SUSTAINED regions next to the headline: >= 10 s each (r06; 1.5 s in r05) of back-to-back steps, run LAST so that an outside sampler of GPU activity lands inside them, whose 64 candidates are drawn afresh
+        # every step — (a) around the planted extrinsic (the headline's own workload without its four fixed candidate sets: every step
+        # runs its own pair search on candidates it has never seen), (b) around a centre that DRIFTS (a random walk of 0.15 mrad / 1.5 mm
+        # per step, reflected at 6 mrad / 6 cm from the planted extrinsic): the anchored lists are rebuilt as the centre leaves them.
+        # A drifted centre is a LIGHTER workload, not a faster machine — away from the planted extrinsic fewer scan points meet a keypoint
+        # within max_pixel_dist, so every later stage has less to do: the mean correspondence count is reported beside each rate, and only
+        # (a) compares with the headline. evaluations/s over the whole region and min / median / max over windows of 100 steps.
+        def sustained(drift, n_sets=40000):
+            rs = np.random.default_rng(99)
+            centre = meta["x_gt"].copy()
+            sig = np.array([1.5e-4] * 3 + [1.5e-3] * 3 + [2e-4 * abs(meta["x_gt"][6])])
+            box = np.array([6e-3] * 3 + [6e-2] * 3 + [0.02 * abs(meta["x_gt"][6])])
+            sets = []
+            for _ in range(n_sets):   # (generated BEFORE the clock: 60 us of numpy per set are not part of the path)
+                if drift:
+                    centre = centre + rs.normal(size=7) * sig
+                    off = centre - meta["x_gt"]
+                    centre = meta["x_gt"] + np.where(np.abs(off) > box, np.sign(off) * (2 * box - np.abs(off)), off)
+                sets.append(synth.perturb(centre, rs, n=B))
+            n_s, wins, ncs, ab0, pb0 = 0, [], [], h.anchor_builds, h.pairs_builds
+            sync()
+            t00 = time.perf_counter()
+            tw0 = t00
+            while n_s < n_sets:
+                o_ = step(n_s, sets)
+                n_s += 1
+                if n_s % 100 == 0:
+                    tnow = time.perf_counter()
+                    wins.append(100 * B / (tnow - tw0))
+                    ncs.append(float(np.mean([c.n_corr for c in o_[0]])))
+                    tw0 = time.perf_counter()
+                    if tnow - t00 > SUSTAIN_S and n_s >= 300:
+                        break
+            sync()
+            t_s = time.perf_counter() - t00
+            return {"seconds": t_s, "steps": n_s, "evals_per_s": n_s * B / t_s, "window_steps": 100,
+                    "window_evals_per_s": {"min": float(np.min(wins)), "median": float(np.median(wins)), "max": float(np.max(wins))},
+                    "mean_n_corr_sampled_every_100_steps": float(np.mean(ncs)), "anchor_builds": h.anchor_builds - ab0, "pair_searches": h.pairs_builds - pb0}
+        extras["sustained"] = {"fresh_candidates_fixed_centre": sustained(False), "fresh_candidates_drifting_centre": sustained(True),
+                               "headline_mean_n_corr": res["config"]["mean_n_corr"],
+                               "what": "64 fresh candidates (0.5 mrad / 5 mm / 0.1 %) per step, every set generated before the clock starts and used once. The drifting "
+                                       "centre wanders up to 6 mrad / 6 cm from the planted extrinsic: fewer correspondences, less work per evaluation (see mean_n_corr) - only the fixed centre compares with the headline"}
         res["extras"] = extras
     stage("extras done")
 
@@ -743,7 +753,7 @@ def main():
         # ---- CPU baseline: the oracle — a port of the reference algorithm, per-evaluation 2-D tree rebuild included — on
         #      this box's host cores: x0 and 16 seeded perturbations, cost tuple + normal equations each; 1 warm-up, then the
         #      median over the 17 candidates on ONE thread (what the reference's NOMAD loop runs, iba_global.cpp:385) and the
-        #      median of 5 passes over them with OpenMP over keyframes (iba_func.cpp:203) ----
+        #      2 passes over them with OpenMP over keyframes (iba_func.cpp:203) at 8 and min(cores, 32) threads ----
         from oracle import binding as ob
         o = ob.Oracle(base)
         ncpu = ob.max_threads()
@@ -760,12 +770,12 @@ def main():
         single = 1.0 / float(np.median(t1))
         by_threads = {"1": single}
         best_nt, best = 1, single
-        for nt in sorted(set([8, min(ncpu, 32), min(ncpu, args.frames)])):
+        for nt in sorted(set([8, min(ncpu, 32)])):   # (r06: bounded to ~30 s — the pass with one thread per keyframe of r05 ran at 0.5 evals/s for three minutes)
             if nt <= 1 or nt > ncpu:
                 continue
             one(cand[0], nt)
             reps = []
-            for _ in range(5 if nt >= 8 else 1):
+            for _ in range(2):
                 t0 = time.perf_counter()
                 for x in cand:
                     one(x, nt)
@@ -782,7 +792,7 @@ def main():
         res["cpu_baseline"] = {
             "value": best, "unit": "evals/s", "cores": best_nt, "kind": "port",
             "sample": "x0 + 16 seeded perturbations (cost tuple + normal equations each), 1 warm-up; one thread: median over the 17 candidates; "
-                      "OpenMP over keyframes with the reference's critical sections (iba_func.cpp:203, iba_global.cpp:239,318; iba_local.cpp:162): median of 5 passes; best thread count reported",
+                      "OpenMP over keyframes with the reference's critical sections (iba_func.cpp:203, iba_global.cpp:239,318; iba_local.cpp:162): median of 2 passes at 8 and at min(host cores, 32) threads; best thread count reported",
             "evals_per_s_by_threads": by_threads, "single_thread_evals_per_s": single,
             "single_thread_note": "1 thread = what the reference's NOMAD loop runs (iba_global.cpp:385)", "host_cores": ncpu,
         }

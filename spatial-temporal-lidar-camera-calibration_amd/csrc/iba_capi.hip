@@ -85,6 +85,10 @@ struct iba_handle {
     int factor_dbg = 0;                   // IBA_FACTOR_DBG (debug): timing cuts of iba_factor2_kernel (results invalid)
     int factor_waves_forced = 0;          // IBA_FACTOR_WAVES_PER_CAND (debug): ranges per candidate instead of the rule in factor_waves()
     F2Layout f2lay{};
+    DevBuf<KpRec> d_kp_rec;               // the factor kernel's keypoint records (r06: one cache line per keypoint)
+    DevBuf<ScanRec> d_scan_rec;           // ... and scan-point records (point + memoised local-plane normal), rebuilt by compute_plane_cache; empty when the allocation failed
+    bool scan_rec_valid = false;          // d_scan_rec holds the normals of the current plane memo (plane_cache = 1)
+    bool factor_rec = true;               // IBA_FACTOR_REC=0 (debug): gather from the separate arrays as rounds 1-5 did
     DevBuf<double> d_ffr;                 // per keyframe: camera, pose, table offsets, relative poses of its covisible slots — one contiguous record (kFfrHead + 12 max_slots doubles)
     DevBuf<double2> d_kp_c;               // ((u - cx) / fx, (v - cy) / fy) of every keypoint: IBA_PlaneFactor's ray (IBACalib2.hpp:165), divided once here instead of per residual block
     int nn_dbg = 0;                       // IBA_NN_DBG: cut the search kernel short (timing attribution; results are garbage)
@@ -199,6 +203,7 @@ struct iba_handle {
         dp.frames = frames.p; dp.slots = slots.p; dp.xs = xs.p; dp.ys = ys.p; dp.zs = zs.p; dp.perm = perm.p; dp.inv_perm = inv_perm.p; dp.chunk_box = chunk_box.p; dp.pts4 = pts4.p;
         dp.nodes = nodes.p; dp.kp_uv = kp_uv.p; dp.kp_mp = kp_mp.p; dp.kp_fl = kp_fl.p; dp.coarse_start = coarse_start.p; dp.crec = crec.p;
         dp.bitmap = bitmap.p; dp.match_uv = match_uv.p; dp.plane_cost = plane_cost.p;
+        dp.kp_rec = d_kp_rec.p; dp.scan_rec = (scan_rec_valid && factor_rec) ? d_scan_rec.p : nullptr;
         dp.plane_local = plane_local_aliases_cost ? plane_cost.p : plane_local.p; dp.plane_ok = plane_ok.p; dp.n_frames = n_frames; dp.n_kp_total = n_keypoints;
         dp.scratch_cost = scratch_cost.p; dp.scratch_local = scratch_local_aliases ? scratch_cost.p : scratch_local.p; dp.n_pt_total = n_pt_total; dp.scratch_slot_base = 1;
         dp.mpk = mpk.p; dp.max_k = std::max(maxK, 1u); dp.kp_fl2 = kp_fl2.p; dp.diag = d_diag.p; dp.fkp = fkp.p;
@@ -444,6 +449,7 @@ inline bool plan_pairs(iba_handle* h, const Cand* hc, int B) {
 iba_status ensure_scratch(iba_handle* h);
 iba_status compute_plane_cache(iba_handle* h) {
     const iba_params& p = h->params;
+    h->scan_rec_valid = false;
     if (!p.plane_cache) return ensure_scratch(h);   // planes are refitted inside every evaluation, into per-candidate scratch
     const DevProblem dp = h->dev_problem();
     auto run = [&](double r2, int max_pts, PlaneRec* out) -> hipError_t {
@@ -470,6 +476,15 @@ iba_status compute_plane_cache(iba_handle* h) {
         hipLaunchKernelGGL(iba_verdict_kernel, dim3((unsigned)((h->plane_cost.n + 255) / 256)), dim3(256), 0, h->stream, h->plane_local_aliases_cost ? h->plane_cost.p : h->plane_local.p, h->dprm, h->plane_ok.p, h->plane_cost.n);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        // the factor kernel's scan-point records: the point and the normal of its memoised LOCAL plane side by side (one cache line). An optional memo:
+        // 64 B per scan point; when the allocation fails the kernel gathers from the separate arrays
+        if (!h->d_scan_rec.p && h->d_scan_rec.alloc(h->plane_cost.n) != hipSuccess) { (void)hipGetLastError(); h->d_scan_rec.p = nullptr; h->d_scan_rec.n = 0; }
+        if (h->d_scan_rec.p) {
+            hipLaunchKernelGGL(iba_scanrec_kernel, dim3((unsigned)((h->plane_cost.n + 255) / 256)), dim3(256), 0, h->stream, h->pts4.p, h->plane_local_aliases_cost ? h->plane_cost.p : h->plane_local.p, h->d_scan_rec.p, h->plane_cost.n);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            h->scan_rec_valid = true;
+        }
     }
     return IBA_OK;
 }
@@ -624,6 +639,15 @@ iba_status launch_factors(iba_handle* h, const Cand* dc, int B, int per_cand, do
     const dim3 grid1 = xmap ? dim3(8 * ((h->n_frames + 7) / 8) * B) : grid;
     const int Bx = xmap ? B : 0;
     const uint4* fl = per_cand ? h->d_flist.p : h->d_flist_frozen.p; const uint32_t* fc = per_cand ? h->d_fcount.p : h->d_fcount_frozen.p;
+    if (h->factor_valu && h->scan_rec_valid && h->factor_rec && h->d_kp_rec.p) {   // the gathers from the one-line records (planes memoised)
+        const uint32_t lds = 96u * std::max<uint32_t>(h->max_slots, 1u);
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid1, dim3(kFactorThreads), lds, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base, Bx); };
+        const bool many = h->max_slots > (uint32_t)kCovisWord;
+        if (h->dprm.p2pix) { if (many) go(iba_factor_kernel<true, true, true>); else go(iba_factor_kernel<false, true, true>); }
+        else { if (many) go(iba_factor_kernel<true, false, true>); else go(iba_factor_kernel<false, false, true>); }
+        HIP_TRY(h, hipGetLastError());
+        return IBA_OK;
+    }
     if (h->dprm.p2pix) {   // IBATestEdge edges (factor_3d2d_kind = 1): an instantiation of its own (the matrix-core variant has none)
         if (h->max_slots > (uint32_t)kCovisWord) hipLaunchKernelGGL((iba_factor_kernel<true, true>), grid1, dim3(kFactorThreads), 96u * h->max_slots, st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base, Bx);
         else hipLaunchKernelGGL((iba_factor_kernel<false, true>), grid1, dim3(kFactorThreads), 96u * std::max<uint32_t>(h->max_slots, 1u), st, h->dev_problem(), h->dprm, dc, fl, fc, (int)h->lstride, per_cand, partials, nrec, rec_base, Bx);
@@ -952,7 +976,7 @@ void iba_destroy(iba_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->frames.release(); h->slots.release(); h->xs.release(); h->ys.release(); h->zs.release(); h->perm.release(); h->inv_perm.release(); h->chunk_box.release(); h->pts4.release();
-    h->d_ffr.release(); h->d_kp_c.release();
+    h->d_ffr.release(); h->d_kp_c.release(); h->d_kp_rec.release(); h->d_scan_rec.release();
     h->nodes.release(); h->kp_uv.release(); h->kp_mp.release(); h->kp_fl.release(); h->coarse_start.release(); h->bitmap.release(); h->crec.release();
     h->match_uv.release(); h->plane_cost.release(); h->plane_local.release(); h->plane_ok.release(); h->scratch_cost.release(); h->scratch_local.release(); h->d_assoc_frozen.release(); h->d_flist.release(); h->d_flist_frozen.release(); h->d_fcount.release(); h->d_fcount_frozen.release(); h->d_cands.release(); h->d_frame_partials.release(); h->d_partials.release(); h->d_corr.release(); h->d_he.release(); h->d_lcount.release(); h->d_lcount_frozen.release(); h->d_nn_partials.release(); h->d_frefit.release(); h->d_pairs.release(); h->d_hard.release(); h->d_pcounts.release(); h->mpk.release(); h->fkp.release(); h->kp_fl2.release(); h->d_diag.release(); h->d_anchor.release();
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
@@ -1187,6 +1211,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (const char* e = dbg_env("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = dbg_env("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
     if (const char* e = dbg_env("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
+    if (const char* e = dbg_env("IBA_FACTOR_REC")) h->factor_rec = std::atoi(e) != 0;
     if (const char* e = dbg_env("IBA_FACTOR_V2")) h->factor_v2 = std::atoi(e) != 0;
     if (const char* e = dbg_env("IBA_FACTOR_DBG")) h->factor_dbg = std::atoi(e);
     if (const char* e = dbg_env("IBA_FACTOR_WAVES_PER_CAND")) h->factor_waves_forced = std::max(0, std::atoi(e));
@@ -1246,6 +1271,22 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
             }
         });
         UP(d_ffr, ffr); UP(d_kp_c, kp_c);
+        {   // the factor kernel's keypoint records: ray, first three matches (as load_match_pre reads them), flag word, MapPoint — one cache line
+            std::vector<KpRec> kr(kp_base);
+            parallel_for(nf, [&](int lf) {
+                const FrameHdr& x = hdr[lf];
+                for (uint32_t k = 0; k < x.K; ++k) {
+                    KpRec& r = kr[x.kp_base + k];
+                    r.cxz = kp_c[x.kp_base + k].x; r.cyz = kp_c[x.kp_base + k].y;
+                    float2 m[3];
+                    for (uint32_t i = 0; i < 3u; ++i) m[i] = x.n_slots ? match_uv[x.match_base + (uint64_t)std::min(i, x.n_slots - 1u) * x.K + k] : float2{qnan, qnan};
+                    r.m0u = m[0].x; r.m0v = m[0].y; r.m1u = m[1].x; r.m1v = m[1].y; r.m2u = m[2].x; r.m2v = m[2].y;
+                    r.fl = kp_fl[x.kp_base + k]; r.pad0 = 0u;
+                    r.mpx = kp_mp[x.kp_base + k].x; r.mpy = kp_mp[x.kp_base + k].y; r.mpz = kp_mp[x.kp_base + k].z; r.pad1 = 0.f;
+                }
+            });
+            UP(d_kp_rec, kr);
+        }
         // LDS plan of one wave: prefix sums | derivative halves of the candidate | three block queues | keyframe ring ; the final reduction (21 x 65 doubles) over queues + ring
         F2Layout& L = h->f2lay;
         L.ffr_stride = gstride; L.ring_stride = (uint32_t)kFfrHead + (uint32_t)kFfrSlotRing * h->max_slots;

@@ -144,8 +144,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const unsigned long long kp_base = (unsigned long long)__double_as_longlong(fr[16]), pt_base = (unsigned long long)__double_as_longlong(fr[17]), match_base = (unsigned long long)__double_as_longlong(fr[18]);
         const unsigned long long kn = (unsigned long long)__double_as_longlong(fr[19]);
         const uint32_t K = (uint32_t)(kn & 0xFFFFFFFFull), n_sl = (uint32_t)(kn >> 32);
-        const size_t kp_i = in.on ? (size_t)(kp_base + k) : 0, pt_i = in.on ? (size_t)(pt_base + q.y) : 0;
-        const bool has_m = in.on && n_sl > 0u;
+        size_t kp_i = in.on ? (size_t)(kp_base + k) : 0, pt_i = in.on ? (size_t)(pt_base + q.y) : 0;
+        if (dbg & 16) { kp_i = (size_t)lane; pt_i = (size_t)lane; }   // (timing cut: every gather of the launch in the same few cache lines — what the kernel costs without its L2 traffic)
+        const bool has_m = in.on && n_sl > 0u && !(dbg & 16);
         in.fro = (uint32_t)(fr - ring); in.K = K; in.mro = has_m ? (uint32_t)(match_base + k) : 0u;
         {   // the matches of the first kMatchPre slots (a keyframe with fewer: its last slot again; the bits of the flag word say which count)
             const float2* mrow = dp.match_uv + in.mro;
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const double* fr = in.on ? frame_rec(q.x) : ring + (size_t)(f_ring_any & rmask) * rstride;
         const uint32_t k = q.x & 0xFFFFFu;
         const unsigned long long kp_base = (unsigned long long)__double_as_longlong(fr[16]), pt_base = (unsigned long long)__double_as_longlong(fr[17]);
-        const size_t kp_i = in.on ? (size_t)(kp_base + k) : 0, pt_i = in.on ? (size_t)(pt_base + q.y) : 0;
+        size_t kp_i = in.on ? (size_t)(kp_base + k) : 0, pt_i = in.on ? (size_t)(pt_base + q.y) : 0;
+        if (dbg & 16) { kp_i = (size_t)lane; pt_i = (size_t)lane; }
         const float4 pt3 = dp.pts4[pt_i], mp3 = dp.kp_mp[kp_i];
         in.fro = (uint32_t)(fr - ring); in.qx = pt3.x; in.qy = pt3.y; in.qz = pt3.z; in.mx = mp3.x; in.my = mp3.y; in.mz = mp3.z;
         if (is_plane) { const PlaneRec& r3 = planes[pt_i]; in.nx = r3.nx; in.ny = r3.ny; in.nz = r3.nz; } else { in.nx = in.ny = in.nz = 0.0; }

@@ -25,6 +25,23 @@
 
 namespace iba {
 
+// ---- the factor kernel's gathers as ONE cache line per keypoint and ONE per scan point (round 6) ----
+// iba_factor_kernel is bound by the L2's request rate (~100 G 64-byte requests/s: profiles/r06*): a plane-factor block gathered from seven arrays
+// (scan point, plane record, pixel, flag word, three match rows), a 3d-3d block from three. The same values side by side:
+struct KpRec {     // 64 B per keypoint, x-independent, built at iba_create
+    double cxz, cyz;          // ((u - cx) / fx, (v - cy) / fy): IBA_PlaneFactor's ray (IBACalib2.hpp:165-166)
+    float m0u, m0v, m1u, m1v; // the keypoint's matches in the covisible slots 0, 1
+    float m2u, m2v;           // ... and 2 (NaN = none; a keyframe with fewer slots: its last slot again, as load_match_pre reads them)
+    uint32_t fl, pad0;        // the flag word (kp_fl)
+    float mpx, mpy, mpz, pad1;// the MapPoint (kp_mp)
+};
+struct ScanRec {   // 64 B per scan point (tree order): the point and the unit normal of its memoised local plane; rebuilt with the plane memo
+    float x, y, z; uint32_t pad0;
+    double nx, ny, nz;
+    double pad1[3];
+};
+static_assert(sizeof(KpRec) == 64 && sizeof(ScanRec) == 64, "one cache line each");
+
 struct DevProblem {
     const FrameHdr* frames;
     const SlotHdr* slots;
@@ -55,6 +72,8 @@ struct DevProblem {
     uint32_t max_k;            // largest keypoint count of a frame: row pitch of the per-(frame, keypoint) tables
     const uint2* fkp;          // per frame (FrameHdr::fk_base, n_fk): (keypoint id, flag word) of the keypoints that can own a term — a MapPoint and/or a covisible match —
                                // in ascending id order: the association tail walks these (~40 % of the keypoints), not every keypoint (r05)
+    const KpRec* kp_rec;       // [n_kp_total] (r06) ...
+    const ScanRec* scan_rec;   // ... [n_pt_total], valid while the planes are memoised (nullptr otherwise: the factor kernel gathers from the separate arrays)
 };
 
 struct LdsLayout {   // byte offsets into dynamic LDS, computed on the host from max P/K/D over frames
@@ -1065,6 +1084,17 @@ __device__ inline void p2x_factor_accum(const Cand& c, const FrameHdr& h, const 
 }
 
 
+// (point, memoised local-plane normal) records of every scan point: one thread each
+__global__ __launch_bounds__(256) void iba_scanrec_kernel(const float4* __restrict__ pts4, const PlaneRec* __restrict__ planes_local, ScanRec* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts4[i];
+    const PlaneRec r = planes_local[i];
+    ScanRec o;
+    o.x = p.x; o.y = p.y; o.z = p.z; o.pad0 = 0u; o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.pad1[0] = o.pad1[1] = o.pad1[2] = 0.0;
+    out[i] = o;
+}
+
 #ifndef IBA_FACTOR_WAVES
 #define IBA_FACTOR_WAVES 2
 #endif
@@ -1078,7 +1108,7 @@ constexpr int kFactorThreads = IBA_FACTOR_THREADS;
 // grid: (n_frames, B), kFactorThreads threads (one wave). Works through the dense residual-block list the association pass left for this
 // (candidate, frame): every lane owns a keypoint that has at least one block. list row = (per_cand ? b : 0).
 // record (b, rec_base + frame) of `partials` receives this block's sums.
-template <bool MANY, bool P2PIX = false>   // P2PIX: the 3d-2d blocks are IBATestEdge edges (factor_3d2d_kind = 1) — an instantiation of its own: the default kernel's code is untouched
+template <bool MANY, bool P2PIX = false, bool REC = false>   // P2PIX: the 3d-2d blocks are IBATestEdge edges (factor_3d2d_kind = 1); REC: the gathers come from the one-line records (DevProblem::kp_rec, scan_rec)
 __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(IBA_FACTOR_WAVES, IBA_FACTOR_WAVES))) void iba_factor_kernel(DevProblem dp, DevParams prm, const Cand* __restrict__ cands, const uint4* __restrict__ flist,
                                                                     const uint32_t* __restrict__ fcount, int flist_stride, int per_cand,
                                                                     double* __restrict__ partials, int nrec, int rec_base, int B) {
@@ -1133,6 +1163,22 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
         uint2 q = make_uint2(0u, 0u);
         if (in.on) q = qa[(ha + (uint32_t)lane) & (kQ - 1u)];
         in.k = q.x;
+        if (REC) {   // one line of the keypoint's record, one of the scan point's
+            const KpRec* kr = dp.kp_rec + h.kp_base + q.x;
+            const ScanRec* sr = dp.scan_rec + h.pt_base + q.y;
+            const double2 cz = *(const double2*)&kr->cxz;
+            const float4 m01 = *(const float4*)&kr->m0u;
+            const uint4 m2f = *(const uint4*)&kr->m2u;
+            const float4 pt = *(const float4*)&sr->x;
+            const double2 nxy = *(const double2*)&sr->nx;
+            const double nz = sr->nz;
+            in.mp = MatchPre{m01.x, m01.y, m01.z, m01.w, __uint_as_float(m2f.x), __uint_as_float(m2f.y)};
+            in.px = pt.x; in.py = pt.y; in.pz = pt.z;
+            in.m0 = m2f.z >> 2; in.m1 = (MANY && n_sl > (uint32_t)kCovisWord) ? dp.kp_fl2[h.kp_base + q.x] : 0u;
+            in.n0x = nxy.x; in.n0y = nxy.y; in.n0z = nz; in.u0 = cz.x; in.v0 = cz.y;   // (u0, v0 carry Cxz, Cyz here)
+            ha += min(cnt, 64u);
+            return in;
+        }
         const bool has_m = n_sl > 0u;
         {
             const float2* mrow = mtab + (has_m ? q.x : 0u);
@@ -1161,7 +1207,7 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
             if (P2PIX) edge_accum<MANY>(c.R, c.t, c.dR, c.dt, cam, p0, in.m0, in.m1, mtab + in.k, (size_t)Kf, in.mp, rel_of, prm.robust_kernel_delta, A);
             else {
                 const double n0[3] = {in.n0x, in.n0y, in.n0z};
-                const double Cxz = (in.u0 - h.cx) / h.fx, Cyz = (in.v0 - h.cy) / h.fy;
+                const double Cxz = REC ? in.u0 : (in.u0 - h.cx) / h.fx, Cyz = REC ? in.v0 : (in.v0 - h.cy) / h.fy;   // (the record holds the quotient the host formed: the same IEEE division)
                 plane_accum<MANY>(c.R, c.t, c.dR, c.dt, cam, Cxz, Cyz, p0, n0, in.m0, in.m1, mtab + in.k, (size_t)Kf, in.mp, rel_of, prm.robust_kernel_delta, A);
             }
         }
@@ -1173,6 +1219,16 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
         if (in.on) q = qb[(hb + (uint32_t)lane) & (kQ - 1u)];
         const uint32_t pos3 = q.y & 0x7FFFFFFFu;
         in.pl = (q.y >> 31) != 0u;
+        if (REC) {
+            const KpRec* kr = dp.kp_rec + h.kp_base + q.x;
+            const ScanRec* sr = dp.scan_rec + h.pt_base + pos3;
+            const float4 mp3 = *(const float4*)&kr->mpx, pt3 = *(const float4*)&sr->x;
+            const double2 nxy = *(const double2*)&sr->nx;
+            const double nz = sr->nz;
+            in.qx = pt3.x; in.qy = pt3.y; in.qz = pt3.z; in.mx = mp3.x; in.my = mp3.y; in.mz = mp3.z; in.nx = nxy.x; in.ny = nxy.y; in.nz = nz;
+            hb += min(cnt, 64u);
+            return in;
+        }
         const float4 pt3 = p4[pos3], mp3 = dp.kp_mp[h.kp_base + q.x];
         const PlaneRec& r3 = planes[pos3];
         in.qx = pt3.x; in.qy = pt3.y; in.qz = pt3.z; in.mx = mp3.x; in.my = mp3.y; in.mz = mp3.z; in.nx = r3.nx; in.ny = r3.ny; in.nz = r3.nz;

@@ -12,6 +12,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$T/fetch -o pmc -- 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$T/write -o pmc -- $BENCH > /dev/null 2> gpurun_out/$T/pmc_write.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES --output-format csv -d gpurun_out/$T/insts -o pmc -- $BENCH > /dev/null 2> gpurun_out/$T/pmc_insts.log
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/$T/cycles -o pmc -- $BENCH > /dev/null 2> gpurun_out/$T/pmc_cycles.log
+rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/$T/l2 -o pmc -- $BENCH > /dev/null 2> gpurun_out/$T/pmc_l2.log   # (r06: the L2 request rate — what bounds the association and factor kernels)
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d gpurun_out/$T/mfma -o pmc -- $BENCH > /dev/null 2> gpurun_out/$T/pmc_mfma.log
 python3 bench.py --steps 20 --warmup 3 > gpurun_out/$T/bench_full.json 2> gpurun_out/$T/bench_full.err
 ls gpurun_out/$T

@@ -34,10 +34,10 @@ avg_us = {}
 for r in rows:
     avg_us[short(r["Name"])] = float(r["AverageNs"]) / 1e3
     lines.append("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-fetch, write, insts, cyc, mfma = counters("fetch"), counters("write"), counters("insts"), counters("cycles"), counters("mfma")
+fetch, write, insts, cyc, mfma, l2 = counters("fetch"), counters("write"), counters("insts"), counters("cycles"), counters("mfma"), counters("l2")
 kernels = [k for k in avg_us if k.startswith(("iba_assoc", "iba_pairs", "iba_nn_kernel", "iba_anchor", "iba_factor", "iba_reduce2", "iba_he_kernel", "iba_fetch"))]
 lines += ["", "## counters per launch (separate --pmc passes on the same command; KiB -> bytes, FETCH_SIZE x2 on gfx950)", "",
-          "| kernel | HBM read MB (x2) | HBM write MB | SQ_INSTS_VALU | SQ_INSTS_SALU | SQ_INSTS_LDS | SQ_INSTS_VMEM | VALU-active share of SIMD cycles | SQ_WAIT_ANY / SQ_WAVE_CYCLES | MFMA F64 insts |", "|---|---|---|---|---|---|---|---|---|---|"]
+          "| kernel | HBM read MB (x2) | HBM write MB | SQ_INSTS_VALU | SQ_INSTS_SALU | SQ_INSTS_LDS | SQ_INSTS_VMEM | VALU-active share of SIMD cycles | SQ_WAIT_ANY / SQ_WAVE_CYCLES | MFMA F64 insts | L2 requests (TCC_REQ) | L2 hit share | L2 requests / s |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 tot_hbm = 0.0; act = 0.0; gui = 0.0
 step_hbm = 0.0; step_act = 0.0; step_gui = 0.0; per_kernel = {}
 for k in kernels:
@@ -45,13 +45,16 @@ for k in kernels:
     i, c, m = insts.get(k, {}), cyc.get(k, {}), mfma.get(k, {})
     share = 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (N_SIMD * c["GRBM_GUI_ACTIVE"] / 8) if c.get("GRBM_GUI_ACTIVE") else float("nan")
     wait = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else float("nan")
-    lines.append("| %s | %.2f | %.2f | %.3g | %.3g | %.3g | %.3g | %.2f | %.2f | %.3g |" % (k, f / 1e6, w / 1e6, i.get("SQ_INSTS_VALU", 0), i.get("SQ_INSTS_SALU", 0), i.get("SQ_INSTS_LDS", 0),
-                                                                                        i.get("SQ_INSTS_VMEM", 0), share, wait, m.get("SQ_INSTS_VALU_MFMA_F64", 0)))
+    q = l2.get(k, {})
+    req, hit = q.get("TCC_REQ_sum", 0.0), q.get("TCC_HIT_sum", 0.0)
+    req_rate = req / (avg_us[k] * 1e-6) if avg_us.get(k) else float("nan")
+    lines.append("| %s | %.2f | %.2f | %.3g | %.3g | %.3g | %.3g | %.2f | %.2f | %.3g | %.3g | %.2f | %.3g |" % (k, f / 1e6, w / 1e6, i.get("SQ_INSTS_VALU", 0), i.get("SQ_INSTS_SALU", 0), i.get("SQ_INSTS_LDS", 0),
+                                                                                        i.get("SQ_INSTS_VMEM", 0), share, wait, m.get("SQ_INSTS_VALU_MFMA_F64", 0), req, hit / req if req else float("nan"), req_rate))
     if k.startswith(("iba_assoc", "iba_pairs", "iba_nn_kernel")):
         tot_hbm += f + w; act += 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0); gui += c.get("GRBM_GUI_ACTIVE", 0.0) / 8
     if not k.startswith("iba_anchor"):   # every kernel of a step (the anchor lists are built once, outside the timed steps)
         step_hbm += f + w; step_act += 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0); step_gui += c.get("GRBM_GUI_ACTIVE", 0.0) / 8
-    per_kernel[k] = {"avg_us": avg_us.get(k), "hbm_read_bytes": f, "hbm_write_bytes": w, "valu_active_share": share, "wait_any_share": wait, "insts_valu": i.get("SQ_INSTS_VALU", 0)}
+    per_kernel[k] = {"avg_us": avg_us.get(k), "hbm_read_bytes": f, "hbm_write_bytes": w, "valu_active_share": share, "wait_any_share": wait, "insts_valu": i.get("SQ_INSTS_VALU", 0), "l2_requests": req, "l2_hit_share": hit / req if req else None, "l2_requests_per_s": req_rate}
 bench_line = None
 try:
     bench_line = json.loads([l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][-1])
@@ -69,7 +72,7 @@ pmc = {"round": tag, "git_head": head + ("+uncommitted kernel changes" if dirty 
        "frames": cfg.get("frames_this_rank"), "pts": cfg.get("points_per_frame"), "batch": cfg.get("candidates_per_step"),
        "kernels": "iba_pairs_kernel + iba_assoc2_kernel + iba_nn_kernel", "hbm_bytes_per_launch": tot_hbm, "valu_issue_frac": act / (N_SIMD * gui) if gui else None,
        "hbm_bytes_per_step": step_hbm, "valu_issue_frac_step": step_act / (N_SIMD * step_gui) if step_gui else None, "per_kernel": per_kernel,
-       "counters": "FETCH_SIZE x2 + WRITE_SIZE (KiB); 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+       "counters": "FETCH_SIZE x2 + WRITE_SIZE (KiB); 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); TCC_REQ_sum / TCC_HIT_sum (64-byte L2 requests)",
        "note": "one rocprofv3 --pmc pass per counter list on `python3 bench.py --steps 15 --warmup 2 --no-cpu-baseline --no-extras`; mean per launch"}
 json.dump(pmc, open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
 lines += ["", "association (pairs + assoc2) + search kernels per launch: HBM %.1f MB, VALU-active share of the SIMD cycles %.2f  (source stamp %s, head %s)" % (tot_hbm / 1e6, pmc["valu_issue_frac"] or float("nan"), pmc["source_stamp"], pmc["git_head"])]
