@@ -144,6 +144,19 @@ typedef struct iba_params {
     int32_t factor_3d2d_kind;
 } iba_params;
 
+/* GeoCalib.h:18-33 computeCorrespondence, the cloud-to-cloud 1-NN correspondence north_star's "GeoCalib call surface" names: for every
+ * source point the nearest target point (nanoflann KDTreeSingleIndexAdaptor, L2_Simple, max_leaf 15: the leaf size does not change a result),
+ * kept when  sq_dist <= max_distance  — the SQUARED distance against the un-squared parameter, exactly as the reference writes it (:29);
+ * pairs (source index, target index) in ascending source order (:30).
+ * The target cloud is the scan of local keyframe `frame` of the handle (the float32 points as loaded, io_tools.h:170-187; indices are the scan's
+ * ORIGINAL order), searched by the kd search of the evaluation path itself (exact f64 distances; a tie between two target points goes to the
+ * lower index, nanoflann keeps the first visited: only duplicate points can tie). src_xyz: n_src points (x, y, z doubles) in that scan's frame —
+ * the caller applies its transform, as computeInitialGeoError does (GeoCalib.h:76-105). out_src / out_tgt: room for n_src entries each.
+ * The header is an orphan of the reference (nothing includes it, and std::vector<Eigen::Vector3d> is no nanoflann dataset: it does not compile
+ * there); this entry point exists so that the one name north_star lists is not missing, and is pinned against the reference's own nanoflann. */
+iba_status iba_geo_correspondences(iba_handle* h, int32_t frame, const double* src_xyz, int32_t n_src, double max_distance,
+                                   uint32_t* out_src, uint32_t* out_tgt, int32_t* n_out);
+
 /* The ABI version the LIBRARY was built with (IBA_ABI_VERSION of its header). iba_params carries no struct_size: a caller compiled against
  * an older header would pass a shorter struct. Callers compare iba_abi_version() with their own IBA_ABI_VERSION before iba_create(). */
 int32_t iba_abi_version(void);

@@ -53,6 +53,18 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def geo_correspondences(which, src, tgt, max_distance):
+    """GeoCalib.h:18-33 computeCorrespondence. which: 'oracle' (this directory's restatement) | 'ref' (the reference's own nanoflann, oracle/_ref).
+    src [n, 3], tgt [m, 3] doubles -> (source indices, target indices) of the kept pairs."""
+    L = lib() if which == "oracle" else ref_lib()
+    fn = L.oracle_geo_correspondences if which == "oracle" else L.ref_geo_correspondences
+    src = np.ascontiguousarray(src, np.float64).reshape(-1, 3); tgt = np.ascontiguousarray(tgt, np.float64).reshape(-1, 3)
+    o_s = np.zeros(max(len(src), 1), np.uint32); o_t = np.zeros(max(len(src), 1), np.uint32); n = C.c_int64(0)
+    rc = fn(_p(src), C.c_uint64(len(src)), _p(tgt), C.c_uint64(len(tgt)), C.c_double(max_distance), _p(o_s), _p(o_t), C.byref(n))
+    assert rc == 0
+    return o_s[: n.value].copy(), o_t[: n.value].copy()
+
+
 def knn(which, dim, pts, leaf, queries, k):
     """which: 'oracle' | 'ref'. Returns (idx[nq,k] u32, d2[nq,k] f64, cnt[nq] i32)."""
     L = lib() if which == "oracle" else ref_lib()

@@ -1010,6 +1010,23 @@ int oracle_knn(int dim, const double* pts, uint64_t n, int leaf, const double* q
     if (dim == 3) { KDTree<3> t(pts, n, (size_t)leaf); run(t, 3); return 0; }
     return 1;
 }
+// GeoCalib.h:18-33 computeCorrespondence restated on this file's kd tree (the restatement of the reference's nanoflann, pinned bit for bit against it:
+// tests/test_oracle_kdtree.py): max_leaf 15 (:23), 1-NN (:25-28), kept when  sq_dist <= maxDistance  — squared against un-squared, as written (:29).
+// nanoflann's knnSearch leaves sq_dist at the caller's initial 1000 and returns 0 only for an empty tree; the initial value is not a search radius.
+int oracle_geo_correspondences(const double* src, uint64_t n_src, const double* tgt, uint64_t n_tgt, double maxDistance, uint32_t* out_src, uint32_t* out_tgt, int64_t* n_out) {
+    *n_out = 0;
+    if (n_tgt == 0) return 0;
+    KDTree<3> tree(tgt, n_tgt, (size_t)15);
+    int64_t n = 0;
+    for (uint64_t i = 0; i < n_src; ++i) {
+        uint32_t idx = 0; double sq = 1000;
+        KNNResultSet rs((size_t)1); rs.init(&idx, &sq);
+        tree.findNeighbors(rs, src + 3 * i);
+        if (rs.size() > 0 && sq <= maxDistance) { out_src[n] = (uint32_t)i; out_tgt[n] = idx; ++n; }
+    }
+    *n_out = n;
+    return 0;
+}
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -53,3 +53,34 @@ extern "C" int ref_nanoflann_knn(int dim, const double* pts, uint64_t n, int lea
 }
 
 extern "C" int ref_nanoflann_version(void) { return NANOFLANN_VERSION; }
+
+// GeoCalib.h:18-33 computeCorrespondence on the reference's nanoflann: the same index type (KDTreeSingleIndexAdaptor, L2_Simple_Adaptor<double, .>,
+// 3, std::uint32_t), max_leaf 15 (:23), knnSearch with num_res = 1 (:25-28) and the test  sq_dist[0] <= maxDistance  as written (:29). The reference
+// hands nanoflann a std::vector<Eigen::Vector3d>, which is no nanoflann dataset (no kdtree_get_pt: the header compiles nowhere); the
+// dataset adaptor below is the minimal one nanoflann's own documentation prescribes — everything that decides a result is the reference's code.
+namespace {
+struct GeoCloud {
+    const double* p; size_t n;
+    inline size_t kdtree_get_point_count() const { return n; }
+    inline double kdtree_get_pt(const size_t idx, const size_t dim) const { return p[3 * idx + dim]; }
+    template <class BBOX> bool kdtree_get_bbox(BBOX&) const { return false; }
+};
+}  // namespace
+extern "C" int ref_geo_correspondences(const double* src, uint64_t n_src, const double* tgt, uint64_t n_tgt, double maxDistance,
+                                       uint32_t* out_src, uint32_t* out_tgt, int64_t* n_out) {
+    typedef nanoflann::KDTreeSingleIndexAdaptor<nanoflann::L2_Simple_Adaptor<double, GeoCloud>, GeoCloud, 3, std::uint32_t> KDTreeType;
+    *n_out = 0;
+    if (n_tgt == 0) return 0;
+    GeoCloud cloud{tgt, (size_t)n_tgt};
+    std::unique_ptr<KDTreeType> kdtree(new KDTreeType(3, cloud, {15}));   // max_leaf_size = 15
+    int64_t n = 0;
+    for (std::uint32_t i = 0; i < (std::uint32_t)n_src; ++i) {
+        std::uint32_t num_res = 1;
+        std::vector<std::uint32_t> query_index(num_res);
+        std::vector<double> sq_dist(num_res, 1000);
+        num_res = kdtree->knnSearch(src + 3 * (size_t)i, num_res, query_index.data(), sq_dist.data());
+        if (num_res > 0 && sq_dist[0] <= maxDistance) { out_src[n] = i; out_tgt[n] = query_index[0]; ++n; }
+    }
+    *n_out = n;
+    return 0;
+}

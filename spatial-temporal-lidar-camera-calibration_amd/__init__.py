@@ -313,6 +313,15 @@ class IbaHandle:
         self.lib.iba_debug_last_assoc2_threads.restype = C.c_int32
         return int(self.lib.iba_debug_last_assoc2_threads(self.h))
 
+    def geo_correspondences(self, frame, src_xyz, max_distance=0.05):
+        """GeoCalib.h:18-33 computeCorrespondence with the scan of local keyframe `frame` as the target cloud -> (source indices, target indices)"""
+        src = np.ascontiguousarray(np.asarray(src_xyz, np.float64).reshape(-1, 3))
+        n = len(src)
+        o_s = np.zeros(max(n, 1), np.uint32); o_t = np.zeros(max(n, 1), np.uint32); cnt = C.c_int32(0)
+        self.lib.iba_geo_correspondences.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        self._chk(self.lib.iba_geo_correspondences(self.h, C.c_int32(frame), _p(src), C.c_int32(n), C.c_double(max_distance), _p(o_s), _p(o_t), C.byref(cnt)))
+        return o_s[: cnt.value].copy(), o_t[: cnt.value].copy()
+
     def debug_factor_ranges(self, B):
         """ranges per candidate iba_factor2_kernel would cut a batch of B into; 0 = the default factor kernel runs"""
         self.lib.iba_debug_factor_ranges.argtypes = [C.c_void_p, C.c_int32]

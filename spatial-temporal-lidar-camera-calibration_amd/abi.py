@@ -244,3 +244,16 @@ class Problem:
     def load(path):
         z = np.load(path)
         return Problem(**{k: z[k] for k in _FIELDS})
+
+    @staticmethod
+    def from_scans(scans, intr=(718.856, 718.856, 607.1928, 185.2157, 1241.0, 376.0)):
+        """A problem that holds scans only (no keypoint, no covisibility): what iba_geo_correspondences and the kd-search probes need.
+        scans: list of [P_f, 3] float32 arrays."""
+        F = len(scans)
+        pt_off = np.concatenate([[0], np.cumsum([len(s) for s in scans])]).astype(np.uint64)
+        eye34 = np.tile(np.eye(3, 4, dtype=np.float32).ravel(), F)
+        return Problem(pt_offset=pt_off, pts_xyz=np.concatenate([np.asarray(s, np.float32).reshape(-1, 3) for s in scans]).ravel() if F else np.zeros(0, np.float32),
+                       intrinsics=np.tile(np.asarray(intr, np.float64), F), kp_offset=np.zeros(F + 1, np.uint64), kp_uv=np.zeros(0, np.float32),
+                       kp_has_mappoint=np.zeros(0, np.uint8), kp_mappoint_w=np.zeros(0, np.float32), Tcw=eye34, covis_offset=np.zeros(F + 1, np.uint64),
+                       covis_frame=np.zeros(0, np.int32), covis_relpose=np.zeros(0, np.float32), match_offset=np.zeros(1, np.uint64),
+                       match_kp_ref=np.zeros(0, np.int32), match_kp_covis=np.zeros(0, np.int32), Tc_next=eye34.copy(), Tl_next=np.tile(np.eye(3, 4).ravel(), F))

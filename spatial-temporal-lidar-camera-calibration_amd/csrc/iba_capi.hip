@@ -1608,12 +1608,28 @@ iba_status iba_debug_nn(iba_handle* h, int32_t frame, const double* q, int32_t n
     if (er != hipSuccess) return fail(h, IBA_ERR_HIP, hipGetErrorString(er));
     const size_t lds = 8u * (size_t)std::max(h->maxNodes, 1u);
     const int blocks = (int)(((size_t)n + 255) / 256);
+    if (er == hipSuccess) er = hipMemsetAsync(di.p, 0xFF, sizeof(uint32_t) * (size_t)n, h->stream);   // (an empty scan: the kernel writes nothing, every query answers "none")
     hipLaunchKernelGGL(iba_nn_probe_kernel, dim3(blocks), dim3(256), lds, h->stream, h->dev_problem(), frame, dq.p, n, mode, di.p, dd.p);
     er = hipStreamSynchronize(h->stream);
     if (er == hipSuccess) er = hipMemcpy(out_idx, di.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
     if (er == hipSuccess) er = hipMemcpy(out_d2, dd.p, sizeof(double) * n, hipMemcpyDeviceToHost);
     dq.release(); dd.release(); di.release();
     if (er != hipSuccess) return fail(h, IBA_ERR_HIP, hipGetErrorString(er));
+    return IBA_OK;
+}
+
+// GeoCalib.h:18-33 on the evaluation path's own kd search (see the header)
+iba_status iba_geo_correspondences(iba_handle* h, int32_t frame, const double* src_xyz, int32_t n_src, double max_distance, uint32_t* out_src, uint32_t* out_tgt, int32_t* n_out) {
+    if (!h || !n_out || n_src < 0 || frame < 0 || frame >= h->n_frames || (n_src > 0 && (!src_xyz || !out_src || !out_tgt))) return fail(h, IBA_ERR_INVALID_ARG, "bad arguments");
+    *n_out = 0;
+    if (n_src == 0) return IBA_OK;
+    std::vector<uint32_t> idx((size_t)n_src); std::vector<double> d2((size_t)n_src);
+    const iba_status s = iba_debug_nn(h, frame, src_xyz, n_src, 1, idx.data(), d2.data());
+    if (s != IBA_OK) return s;
+    int32_t n = 0;
+    for (int32_t i = 0; i < n_src; ++i)   // num_res > 0 && sq_dist[0] <= maxDistance (GeoCalib.h:29; an empty target cloud answers "none")
+        if (idx[(size_t)i] != 0xFFFFFFFFu && d2[(size_t)i] <= max_distance) { out_src[n] = (uint32_t)i; out_tgt[n] = idx[(size_t)i]; ++n; }
+    *n_out = n;
     return IBA_OK;
 }
 

@@ -2064,14 +2064,17 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                 //      (entry -> set -> plane records), the next entry's first load in flight meanwhile ----
                 // two entries per step: their loads are issued stage by stage (entries, then list rows), so a thread's four entries
                 // cost four dependent round trips instead of eight
-                // (round 6) Every load of a step is UNCONDITIONAL, on an address that is valid whatever the lane holds (a lane without an entry reads
-                // entry 0 of the group's first candidate, keypoint 0, row 0), and what it returns is never overwritten with a default: whether the lane's
-                // entry exists / wants a search / has a list is carried in flags of their own. A load under `if (...)` whose result is merged with a default
-                // behind the branch is waited for AT the merge — the ISA of rounds 3-5 had s_waitcnt vmcnt(0) behind each of the six loads of a step: six
-                // dependent round trips where two were meant. Now: both entries -> both MapPoints and both list rows -> the picks.
-                const size_t at_safe = ((size_t)(uint32_t)(g * CG) * nf + f) * (size_t)flist_stride;
-                auto entry_ok = [&](uint32_t wn) -> bool { const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift); return (wn < c1) & (il < s_n[cc]); };   // (& not &&: no branch around the LDS read)
-                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, const AnchorHdr& hd, const SetPt& p0, const unsigned char* row, bool listed) {
+                // (round 6, measured and reverted: the ISA waits behind each conditional load of this step — a load merged with a default behind a branch is
+                //  waited for at the merge —, six dependent round trips where two were meant. With every load unconditional on a safe address, pinned by
+                //  compiler barriers, one entry per step and the next entry's fetch in flight (two round trips per entry, one exposed): 38 % more vector-memory
+                //  instructions — lanes without an entry load too — and the kernel 0.121 -> 0.125 ms on the same box, twice. The pass is not bound by its
+                //  round trips: 2.7e10 L2 requests/s against the ~1e11 the association and factor kernels reach, VALU-active 0.36.)
+                auto fetch = [&](uint32_t wn, uint4& e, float4& mp) {
+                    e = make_uint4(0u, 0u, 0u, 0u); mp = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
+                    if (wn < c1 && il < s_n[cc]) { e = flist[entry_at(wn)]; if (e.w & kWantMask) mp = kmp[e.x]; }
+                };
+                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, const AnchorHdr& hd, const SetPt& p0, const unsigned char* row) {
                     make_queries(wn & ((1u << cg_shift) - 1u), e, mp);
                     // the certificate: this candidate's queries are S from the anchor's; its nearest points lie within d_1 + 2 S of the
                     // anchor query, and the list is complete out to d_M (exclusive)
@@ -2080,14 +2083,14 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     if ((WHICH & 2) && actC) { const double dx = qx - hd.qa[0], dy = qy - hd.qa[1], dz = qz - hd.qa[2]; S2 = fmax(S2, (dx * dx + dy * dy) + dz * dz); }
                     const double S = sqrt(S2);
                     const double radius = (hd.d1 + 2.0 * S) * (1.0 + 1e-12) + 1e-12;
-                    const bool quick = listed && radius < hd.dM;   // (NaN queries fail both tests)
+                    const bool quick = radius < hd.dM;   // (NaN queries fail both tests)
                     // Second chance, from the whole row: with r = the distance to the nearest LISTED point, every point within r of this
                     // query is within r + S of the anchor's; if that is inside d_M they are all listed and the nearest listed point is the
                     // nearest point. (Dense scans: d_M shrinks with the point spacing, S does not.) An entry that fails this too goes to
                     // the tree search WITH its nearest listed points as the first bound: a query far from the scan (a MapPoint 2 m in front
                     // of a wall) otherwise opens every leaf within its first, poor, bound.
                     auto leave = [&](uint32_t pa, uint32_t pc) { ((uint2*)s_res)[wn - c0] = make_uint2(pa, pc); s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; };
-                    if (!listed || hd.count == 0u) { leave(kNone, kNone); return; }   // (no list for this candidate, or an empty one: the tree search, unseeded)
+                    if (hd.count == 0u) { leave(kNone, kNone); return; }
                     bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
                     SetPt abest = p0, cbest = p0;
                     const float rf = quick ? (float)radius * 1.000001f + 1e-30f : INFINITY;   // >= radius
@@ -2107,41 +2110,21 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     }
                     if (dbg != 5) finish(wn, &abest, &cbest);
                 };
-                // One entry per step, two stages deep: while an entry's MapPoint and list row are in flight (stage 2) the thread's NEXT entry is fetched (stage 1),
-                // so a step exposes one round trip. (Two entries per step with both stages paired needs 2 x 96 bytes of list row in registers beside the
-                // search state: 27 spilled registers at the kernel's 128.)
-                {
-                    uint32_t wn = (uint32_t)tid;
-                    bool v = entry_ok(wn);
-                    uint4 e = flist[v ? entry_at(wn) : at_safe];
-                    for (; wn < c1; wn += (uint32_t)T) {
-                        const uint32_t wnn = wn + (uint32_t)T;
-                        const bool vn = entry_ok(wnn);
-                        const size_t atn = vn ? entry_at(wnn) : at_safe;
-                        // (the keypoint of an entry is used UNCONDITIONALLY — clamped to the keyframe's keypoints, a no-op for a real entry —: a use under
-                        //  `wants a search ?` lets the compiler sink the load of the keypoint word behind that test, one more dependent round trip)
-                        const uint32_t k0 = min(e.x, h.K - 1u);
-                        // the lists this lane's candidate reads: the set built around the anchor nearest to it (255: none is near — straight to the tree search)
-                        const uint32_t sel0 = s_sel[wn & ((1u << cg_shift) - 1u)];
-                        const unsigned char* r0 = anchor_row((const unsigned char*)anchor + (size_t)(sel0 != 255u ? sel0 : 0u) * ka->anchor_set_bytes, (size_t)f * dp.max_k + k0);
-                        // (the row's address goes through an opaque statement and comes back as a plain global-memory address: it forgets that it came from a
-                        //  __restrict__ pointer — loads of which the compiler moves across the barrier below, into the branch that first uses them)
-                        unsigned long long r0a = (unsigned long long)r0;
-                        asm volatile("" : "+v"(r0a));
-                        // stage 2: the MapPoint and the first line of the list row (header + nearest neighbour: ONE 128-byte line, all that most lanes need) ...
-                        const float4 mq0 = kmp[k0];
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        const __attribute__((address_space(1))) u32x4* rq = (const __attribute__((address_space(1))) u32x4*)r0a;
-                        const u32x4 rw[6] = {rq[0], rq[1], rq[2], rq[3], rq[4], rq[5]};   // header (48 B) + nearest neighbour (48 B) = anchor_hdr(r0), anchor_pt(r0, 0)
-                        AnchorHdr h0; SetPt a0;
-                        __builtin_memcpy(&h0, &rw[0], sizeof(AnchorHdr)); __builtin_memcpy(&a0, &rw[3], sizeof(SetPt));
-                        // ... and stage 1 of the next step
-                        const uint4 en = flist[atn];
-                        asm volatile("" ::: "memory");   // (a compiler barrier, no instruction: the loads above may not be sunk below it — into the branch that first uses them)
-                        const bool w0 = v & ((e.w & kWantMask) != 0u);
-                        if (w0) pick(wn, e, mq0, h0, a0, r0, sel0 != 255u);
-                        e = en; v = vn;
-                    }
+                for (uint32_t wn = (uint32_t)tid; wn < c1; wn += 2u * (uint32_t)T) {
+                    uint4 e0, e1; float4 mq0, mq1;
+                    fetch(wn, e0, mq0); fetch(wn + (uint32_t)T, e1, mq1);
+                    const bool w0 = (e0.w & kWantMask) != 0u, w1 = (e1.w & kWantMask) != 0u;
+                    // the lists this lane's candidate reads: the set built around the anchor nearest to it (255: none is near — straight to the tree search)
+                    const uint32_t sel0 = s_sel[wn & ((1u << cg_shift) - 1u)], sel1 = s_sel[(wn + (uint32_t)T) & ((1u << cg_shift) - 1u)];
+                    const unsigned char* r0 = anchor_row((const unsigned char*)anchor + (size_t)(sel0 != 255u ? sel0 : 0u) * ka->anchor_set_bytes, (size_t)f * dp.max_k + (w0 ? e0.x : 0u));
+                    const unsigned char* r1 = anchor_row((const unsigned char*)anchor + (size_t)(sel1 != 255u ? sel1 : 0u) * ka->anchor_set_bytes, (size_t)f * dp.max_k + (w1 ? e1.x : 0u));
+                    AnchorHdr h0, h1; SetPt a0, b0;
+                    h0.count = h1.count = 0u; h0.dM = h1.dM = -1.0; h0.d1 = h1.d1 = 0.0; h0.da1_lo = h1.da1_lo = INFINITY;
+                    a0.flags = b0.flags = 0u;
+                    if (w0 && sel0 != 255u) { h0 = *anchor_hdr(r0); a0 = *anchor_pt(r0, 0u); }   // header + nearest neighbour: ONE 128-byte line, all that most lanes need
+                    if (w1 && sel1 != 255u) { h1 = *anchor_hdr(r1); b0 = *anchor_pt(r1, 0u); }
+                    if (w0) pick(wn, e0, mq0, h0, a0, r0);
+                    if (w1) pick(wn + (uint32_t)T, e1, mq1, h1, b0, r1);
                 }
                 __syncthreads();
                 c_end = s_ctr[1];
