@@ -1243,7 +1243,11 @@ __global__ __launch_bounds__(kFactorThreads) __attribute__((amdgpu_waves_per_eu(
             else p2pt_accum(c.Rlc, c.tlc, c.dRlc, c.dtlc, cs, h.Tcw, prm.robust_kernel_3ddelta, mp3, Q, A);
         }
     };
+#if IBA_FACTOR_WAVES >= 3
+    auto both = [&](uint32_t ca, uint32_t cb) { { const QIn ib = p2x_load(cb); p2x_compute(ib); } { const PIn ia = plane_load(ca); plane_compute(ia); } };   // (three waves per SIMD: the two bodies' inputs are not held at once)
+#else
     auto both = [&](uint32_t ca, uint32_t cb) { const PIn ia = plane_load(ca); const QIn ib = p2x_load(cb); p2x_compute(ib); plane_compute(ia); };
+#endif
     auto lds_order = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     // (three of an entry's four words, loaded unconditionally — lanes past the end read the last entry again: see iba_factor2_kernel.hpp)
     auto entry_at = [&](uint32_t i) -> uint4 {
