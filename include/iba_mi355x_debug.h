@@ -55,6 +55,9 @@ iba_status iba_set_timing(iba_handle* h, int32_t enable);
 /* the same split by kernel: association kernel (projection, 2d-3d association, 3d-2d residuals), grouped 1-NN search kernel
  * (3d-3d terms), and everything after them (factor kernel, sums) */
 iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_kernel_ms, float* rest_ms);
+/* debug (library built with -DIBA_DIAG_COUNTERS only, `make -C csrc diag`; zeros otherwise): cycle sums per phase of the search kernel (thread 0 of every block:
+ * start-up, entries + MapPoints, list rows, picks, wait at the end of the list pass, left-over searches, sums) and the number of blocks */
+iba_status iba_debug_phase_cycles(iba_handle* h, uint64_t out8[8], int32_t reset);
 /* debug: threads per block of the last iba_assoc2_kernel launch on this handle (256 or 512: chosen per launch from the number of (candidate,
  * keyframe) blocks; 0 = no shared-pair association has run) */
 int32_t iba_debug_last_assoc2_threads(const iba_handle* h);

@@ -1305,7 +1305,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     h->nfb = nf; h->nrec = nf + h->nfb;   // one factor-kernel record per frame
     if ((er = h->d_assoc_frozen.alloc((size_t)std::max<int64_t>(h->n_keypoints, 1))) != hipSuccess) return bail("alloc assoc", er);
     if ((er = h->d_flist_frozen.alloc((size_t)std::max(nf, 1) * h->lstride)) != hipSuccess) return bail("alloc flist", er);
-    if ((er = h->d_diag.alloc(4)) != hipSuccess || (er = hipMemset(h->d_diag.p, 0, 16)) != hipSuccess) return bail("alloc diag", er);
+    if ((er = h->d_diag.alloc(32)) != hipSuccess || (er = hipMemset(h->d_diag.p, 0, 128)) != hipSuccess) return bail("alloc diag", er);   // [0..3] counters, [8..23] eight 64-bit cycle sums (diag build)
     if ((er = h->d_fcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc fcount", er);
     if ((er = h->d_lcount_frozen.alloc((size_t)std::max(nf, 1))) != hipSuccess) return bail("alloc lcount", er);
     if ((er = hipEventCreate(&h->ev_mid)) != hipSuccess) return bail("hipEventCreate", er);
@@ -1592,6 +1592,14 @@ iba_status iba_debug_counters(iba_handle* h, uint32_t out4[4], int32_t reset) {
 }
 int32_t iba_debug_last_assoc2_threads(const iba_handle* h) { return h ? h->last_assoc2_threads : -1; }
 int32_t iba_debug_factor_ranges(const iba_handle* h, int32_t B) { return h ? factor_waves(h, B) : -1; }
+// debug (diag build only: make -C csrc diag): eight 64-bit sums the search kernel's thread 0 of every block adds up — cycles per phase, blocks
+iba_status iba_debug_phase_cycles(iba_handle* h, uint64_t out8[8], int32_t reset) {
+    if (!h || !h->d_diag.p || !out8) return IBA_ERR_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, IBA_ERR_HIP, "sync");
+    if (hipMemcpy(out8, h->d_diag.p + 8, 64, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, IBA_ERR_HIP, "copy");
+    if (reset && hipMemset(h->d_diag.p + 8, 0, 64) != hipSuccess) return fail(h, IBA_ERR_HIP, "memset");
+    return IBA_OK;
+}
 int32_t iba_debug_pairs_builds(const iba_handle* h) { return h ? h->pairs_builds : -1; }
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }
 

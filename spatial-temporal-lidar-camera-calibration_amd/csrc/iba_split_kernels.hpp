@@ -1899,6 +1899,12 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
 #define lay (ka->lay)
     constexpr int T = kNNThreads;
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef IBA_DIAG_COUNTERS
+    unsigned long long nn_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nn_last = __builtin_readcyclecounter();   // cycles of thread 0 per phase -> dp.diag[8 + 2 i] (64-bit sums)
+#define NN_TICK(i) do { const unsigned long long _t = __builtin_readcyclecounter(); nn_t[i] += _t - nn_last; nn_last = _t; } while (0)
+#else
+#define NN_TICK(i) do { } while (0)
+#endif
     const int nf = dp.n_frames;
     const int per_xcd = (nf + 7) / 8;
     const int NG = (B + CG - 1) / CG;
@@ -1946,6 +1952,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
         for (uint32_t i = tid; i < ((hi_u - lo_u) << cg_shift); i += T) s_res[i] = NAN;   // entries that turn out to want no cost search
     }
     __syncthreads();
+    NN_TICK(0);   // block start-up: list lengths, candidate constants -> LDS, first barrier
     if (dbg == 1) return;
     // Work entry w of the block = (candidate w % CG, list position i_lo + w / CG): the candidates' lists interleaved, so that the
     // lanes of a wave search for (nearly) the same MapPoints under different candidates and walk the same leaves. The slices
@@ -2113,6 +2120,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                 for (uint32_t wn = (uint32_t)tid; wn < c1; wn += 2u * (uint32_t)T) {
                     uint4 e0, e1; float4 mq0, mq1;
                     fetch(wn, e0, mq0); fetch(wn + (uint32_t)T, e1, mq1);
+                    asm volatile("" :: "v"(e0.x), "v"(e1.x), "v"(mq0.x), "v"(mq1.x));
+                    NN_TICK(1);   // entries + MapPoints of the step
                     const bool w0 = (e0.w & kWantMask) != 0u, w1 = (e1.w & kWantMask) != 0u;
                     // the lists this lane's candidate reads: the set built around the anchor nearest to it (255: none is near — straight to the tree search)
                     const uint32_t sel0 = s_sel[wn & ((1u << cg_shift) - 1u)], sel1 = s_sel[(wn + (uint32_t)T) & ((1u << cg_shift) - 1u)];
@@ -2123,10 +2132,14 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     a0.flags = b0.flags = 0u;
                     if (w0 && sel0 != 255u) { h0 = *anchor_hdr(r0); a0 = *anchor_pt(r0, 0u); }   // header + nearest neighbour: ONE 128-byte line, all that most lanes need
                     if (w1 && sel1 != 255u) { h1 = *anchor_hdr(r1); b0 = *anchor_pt(r1, 0u); }
+                    asm volatile("" :: "v"(h0.count), "v"(h1.count), "v"(a0.pos), "v"(b0.pos));
+                    NN_TICK(2);   // list rows of the step
                     if (w0) pick(wn, e0, mq0, h0, a0, r0);
                     if (w1) pick(wn + (uint32_t)T, e1, mq1, h1, b0, r1);
+                    NN_TICK(3);   // the picks (certificate, nearest listed points, results)
                 }
                 __syncthreads();
+                NN_TICK(4);   // waiting for the block's other waves at the end of the list pass
                 c_end = s_ctr[1];
                 left_to_tree = c_end;
                 if (tid == 0) *s_ctr = 0u;
@@ -2193,6 +2206,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
             }
         }
         __syncthreads();
+        NN_TICK(5);   // left-over tree searches (and the barriers around them)
         if (dbg == 3) return;
         // ---- fixed-order sums of the chunk: 32 threads per candidate, each over a strided subset of its entries ----
         if (WHICH & 2) {
@@ -2230,6 +2244,14 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
             nn_partials[((size_t)(g * CG + cc) * nn_nrec + (size_t)f * NS + sl) * kNNPartial + q] = out;
         }
     }
+#ifdef IBA_DIAG_COUNTERS
+    NN_TICK(6);   // sums + records
+    if (tid == 0 && dp.diag) {
+        unsigned long long* d64 = (unsigned long long*)(dp.diag + 8);
+        for (int i = 0; i < 7; ++i) atomicAdd(d64 + i, nn_t[i]);
+        atomicAdd(d64 + 7, 1ull);   // blocks that got here
+    }
+#endif
 #undef dp
 #undef prm
 #undef lay
