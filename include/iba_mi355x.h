@@ -481,6 +481,11 @@ iba_status iba_x_to_sim3(const double x[7], double rigid12[12], double* scale);
  */
 iba_status iba_pose_to_motion(const double* poses12, int64_t n, double* motions12 /* (n-1) x 12 */); /* kitti_tools.h:160-165 */
 iba_status iba_handeye(const double* Ta12, const double* Tb12, int64_t n, double rigid12[12], double* scale); /* HECalib.h:12-57 */
+/* DGHECalib (HECalib.h:66-120), the reference's initialiser for degenerate motion: the rotation as iba_handeye's, translation zero (:109), scale =
+ * sum |ta| |tb| / sum |ta|^2 over the pairs whose camera rotation angle is below dg_threshold (reference default 0.01 rad, :66, :82, :112-119;
+ * NaN when there is none, as in the reference); *n_degenerate (may be NULL): how many pairs that were. iba_handeye returns IBA_ERR_UNSUPPORTED
+ * exactly when its 4 x 4 system is singular — the case this one is for. */
+iba_status iba_handeye_degenerate(const double* Ta12, const double* Tb12, int64_t n, double dg_threshold, double rigid12[12], double* scale, int64_t* n_degenerate);
 /* The cost HECalibRobustKernelg2o minimises (NLHECalib.hpp:121-163): EdgeHE residual (:27-48), Huber(delta) per pair,
  * optional regulariser on upsilon with information n * ratio; Levenberg-Marquardt with a numerical Jacobian instead of
  * g2o's Dogleg on the reference's hand-written one (see csrc/iba_handeye.cpp). he_calib.cpp: 10 iterations. */

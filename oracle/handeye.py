@@ -37,6 +37,25 @@ def handeye(Ta, Tb):
     return np.concatenate([R, x[:3, None]], 1), float(x[3])
 
 
+def handeye_degenerate(Ta, Tb, dg_threshold=0.01):
+    """DGHECalib (HECalib.h:66-120): the rotation as handeye's (:73-107), NO translation (:109), scale = sum |ta| |tb| / sum |ta|^2 over the pairs whose
+    camera rotation angle is below dg_threshold (:82, :112-119). -> (rigid 3x4, scale, number of such pairs)"""
+    Ta, Tb = np.asarray(Ta, np.float64), np.asarray(Tb, np.float64)
+    alpha = np.array([rotvec(T[:3, :3]) for T in Ta])
+    beta = np.array([rotvec(T[:3, :3]) for T in Tb])
+    H = (beta - beta.mean(0)).T @ (alpha - alpha.mean(0))
+    U, _, Vt = np.linalg.svd(H)
+    R = Vt.T @ U.T
+    if np.linalg.det(R) < 0:
+        Vt[2] *= -1
+        R = Vt.T @ U.T
+    dg = np.linalg.norm(alpha, axis=1) < dg_threshold
+    ta, tb = np.linalg.norm(Ta[dg, :3, 3], axis=1), np.linalg.norm(Tb[dg, :3, 3], axis=1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        scale = float(np.float64(np.sum(ta * tb)) / np.float64(np.sum(ta * ta)))
+    return np.concatenate([R, np.zeros((3, 1))], 1), scale, int(dg.sum())
+
+
 def sim3_exp(x):
     w = np.asarray(x[:3], np.float64)
     th = np.linalg.norm(w)

@@ -292,14 +292,16 @@ iba_status iba_pose_to_motion(const double* poses12, int64_t n, double* motions1
     return IBA_OK;
 }
 
-iba_status iba_handeye(const double* Ta12, const double* Tb12, int64_t n, double rigid12[12], double* scale) {   // HECalib.h:12-57
-    if (!Ta12 || !Tb12 || !rigid12 || !scale || n < 2) return IBA_ERR_INVALID_ARG;
+// the rotation part RAB both initialisers share (HECalib.h:16-45 = :73-107): rotation vectors of the paired motions, decentred covariance, SVD, determinant fix;
+// alpha_norm (may be null): |alpha_i| per pair, what DGHECalib's degeneracy test reads (:82)
+static void handeye_rotation(const double* Ta12, const double* Tb12, int64_t n, double R[9], double* alpha_norm) {
     std::vector<double> alpha(3 * (size_t)n), beta(3 * (size_t)n);
     double am[3] = {0, 0, 0}, bm[3] = {0, 0, 0};
     for (int64_t i = 0; i < n; ++i) {
         const Iso A = load(Ta12 + 12 * i), B = load(Tb12 + 12 * i);
         rotvec_of(A.R, &alpha[3 * (size_t)i]); rotvec_of(B.R, &beta[3 * (size_t)i]);
         for (int k = 0; k < 3; ++k) { am[k] += alpha[3 * (size_t)i + k]; bm[k] += beta[3 * (size_t)i + k]; }
+        if (alpha_norm) { const double* a = &alpha[3 * (size_t)i]; alpha_norm[i] = std::sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); }
     }
     for (int k = 0; k < 3; ++k) { am[k] /= (double)n; bm[k] /= (double)n; }
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -307,10 +309,38 @@ iba_status iba_handeye(const double* Ta12, const double* Tb12, int64_t n, double
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += (beta[3 * (size_t)i + r] - bm[r]) * (alpha[3 * (size_t)i + c] - am[c]);
     double U[9], V[9];
     svd3(H, U, V);
-    double Ut[9], R[9];
+    double Ut[9];
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Ut[r * 3 + c] = U[c * 3 + r];
     mat3_mul(V, Ut, R);   // RAB = Vt^T * Ut
     if (det3(R) < 0) { for (int r = 0; r < 3; ++r) V[r * 3 + 2] = -V[r * 3 + 2]; mat3_mul(V, Ut, R); }   // Vt.row(2) *= -1
+}
+
+// DGHECalib (HECalib.h:66-120), the initialiser for degenerate motion (a vehicle that hardly turns): the rotation as HECalib's, NO translation
+// (tAB = 0, :109), the scale from the pairs whose camera rotation is below dg_threshold (|alpha| < dg_threshold, :82): sum |ta| |tb| / sum |ta|^2 (:112-119).
+// n_degenerate (may be null): how many pairs that were (the reference prints it, :118). No such pair: the quotient is 0 / 0 = NaN, as in the reference.
+iba_status iba_handeye_degenerate(const double* Ta12, const double* Tb12, int64_t n, double dg_threshold, double rigid12[12], double* scale, int64_t* n_degenerate) {
+    if (!Ta12 || !Tb12 || !rigid12 || !scale || n < 1) return IBA_ERR_INVALID_ARG;
+    double R[9];
+    std::vector<double> an((size_t)n);
+    handeye_rotation(Ta12, Tb12, n, R, an.data());
+    double num = 0, den = 0;
+    int64_t nd = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!(an[(size_t)i] < dg_threshold)) continue;
+        const Iso A = load(Ta12 + 12 * i), B = load(Tb12 + 12 * i);
+        const double ta = std::sqrt((A.t[0] * A.t[0] + A.t[1] * A.t[1]) + A.t[2] * A.t[2]), tb = std::sqrt((B.t[0] * B.t[0] + B.t[1] * B.t[1]) + B.t[2] * B.t[2]);
+        num += ta * tb; den += ta * ta; ++nd;
+    }
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) rigid12[r * 4 + c] = R[r * 3 + c]; rigid12[r * 4 + 3] = 0.0; }
+    *scale = num / den;
+    if (n_degenerate) *n_degenerate = nd;
+    return IBA_OK;
+}
+
+iba_status iba_handeye(const double* Ta12, const double* Tb12, int64_t n, double rigid12[12], double* scale) {   // HECalib.h:12-57
+    if (!Ta12 || !Tb12 || !rigid12 || !scale || n < 2) return IBA_ERR_INVALID_ARG;
+    double R[9];
+    handeye_rotation(Ta12, Tb12, n, R, nullptr);
     // [Ra - I | ta] [t; s] = R tb, normal equations (:46-52)
     double AtA[16] = {0}, Atb[4] = {0};
     for (int64_t i = 0; i < n; ++i) {
@@ -322,7 +352,7 @@ iba_status iba_handeye(const double* Ta12, const double* Tb12, int64_t n, double
         }
     }
     double x[4];
-    if (!solve_n(4, AtA, Atb, x)) return IBA_ERR_UNSUPPORTED;   // degenerate motion (no rotation about two axes)
+    if (!solve_n(4, AtA, Atb, x)) return IBA_ERR_UNSUPPORTED;   // degenerate motion (no rotation about two axes): iba_handeye_degenerate is the reference's initialiser for it
     for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) rigid12[r * 4 + c] = R[r * 3 + c]; rigid12[r * 4 + 3] = x[r]; }
     *scale = x[3];
     return IBA_OK;

@@ -172,6 +172,21 @@ def handeye(Ta, Tb):
     return r.reshape(3, 4), s.value
 
 
+def handeye_degenerate(Ta, Tb, dg_threshold=0.01):
+    """DGHECalib (HECalib.h:66-120): returns (rigid 3x4 with zero translation, scale, number of degenerate pairs)."""
+    L = _lib()
+    A = np.ascontiguousarray(np.asarray(Ta, np.float64)[:, :3, :4]).reshape(-1, 12)
+    B = np.ascontiguousarray(np.asarray(Tb, np.float64)[:, :3, :4]).reshape(-1, 12)
+    r = np.zeros(12)
+    s = C.c_double(0)
+    nd = C.c_int64(0)
+    L.iba_handeye_degenerate.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    st = L.iba_handeye_degenerate(_dp(A), _dp(B), len(A), float(dg_threshold), _dp(r), C.byref(s), C.byref(nd))
+    if st != 0:
+        raise IbaError(st, "iba_handeye_degenerate")
+    return r.reshape(3, 4), s.value, nd.value
+
+
 def handeye_robust(Ta, Tb, rigid0, scale0, robust_kernel_size=0.1, regulation=True, regulation_ratio=0.005, iterations=10):
     """HECalibRobustKernelg2o (NLHECalib.hpp:121-163) on the device-independent host path."""
     L = _lib()

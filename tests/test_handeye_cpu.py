@@ -135,3 +135,44 @@ def test_lineprocess_refinement_downweights_outliers_like_the_restated_annealing
     r0, s0 = fmt.handeye(Ta, Tb)
     r1, s1 = fmt.handeye_lineprocess(Ta, Tb, r0, s0, regulation=False)
     assert np.allclose(r1, r0, atol=1e-6) and abs(s1 - s0) < 1e-6
+
+
+def _straight_trajectory(n, seed, turn_every=0):
+    """a vehicle that drives (almost) straight: rotation vectors of ~1e-3 rad, so HECalib's translation system is (near-)singular — DGHECalib's case"""
+    rng = np.random.default_rng(seed)
+    X = _T(np.array([1.2, -1.2, 1.2]), np.array([0.05, -0.08, -0.27]))
+    s = 9.0
+    Twl = [np.eye(4)]
+    for i in range(n - 1):
+        rv = rng.normal(0, 1e-3, 3)
+        if turn_every and i % turn_every == turn_every - 1:
+            rv = rv + np.array([0, 0, 0.08])          # an occasional real turn: not a degenerate pair
+        Twl.append(Twl[-1] @ _T(rv, np.array([1.0 + 0.2 * np.sin(i / 3), 0, 0]) + rng.normal(0, 0.02, 3)))
+    Twl = np.array(Twl)
+    Twc = []
+    for T in Twl:
+        Cm = X @ T @ np.linalg.inv(X)
+        Cm[:3, 3] /= s
+        Twc.append(Cm)
+    return np.array(Twc), Twl, X, s
+
+
+def test_degenerate_motion_initialiser_matches_numpy_and_recovers_the_scale():
+    """DGHECalib (HECalib.h:66-120): rotation as HECalib's, zero translation, scale from the translation norms of the hardly-rotating pairs"""
+    Twc, Twl, X, s = _straight_trajectory(80, 3, turn_every=10)
+    Ta, Tb = fmt.pose_to_motion(Twc), fmt.pose_to_motion(Twl)
+    rigid, scale, nd = fmt.handeye_degenerate(Ta, Tb, 0.01)
+    r_np, s_np, nd_np = ohe.handeye_degenerate(Ta, Tb, 0.01)
+    assert nd == nd_np and 50 < nd < len(Ta)                       # the turns are not degenerate pairs, the rest is
+    assert np.allclose(rigid, r_np, rtol=0, atol=1e-9) and abs(scale - s_np) <= 1e-12 * s_np
+    assert not rigid[:, 3].any()                                    # tAB = 0 (:109)
+    assert abs(np.linalg.det(rigid[:, :3]) - 1) < 1e-12
+    # with almost no rotation |ta| = |tb| / s up to the lever arm: the scale comes out within a few per mille
+    assert abs(scale - s) < 0.01 * s
+    # the threshold is a strict '<' on the rotation angle (:82): a threshold of 0 selects no pair and the quotient is 0 / 0, as in the reference
+    _, s0, n0 = fmt.handeye_degenerate(Ta, Tb, 0.0)
+    assert n0 == 0 and np.isnan(s0) and np.isnan(ohe.handeye_degenerate(Ta, Tb, 0.0)[1])
+    # every pair degenerate when the threshold is large
+    assert fmt.handeye_degenerate(Ta, Tb, 10.0)[2] == len(Ta)
+    with pytest.raises(pkg.IbaError):
+        fmt.handeye_degenerate(Ta[:0], Tb[:0])
