@@ -88,6 +88,7 @@ struct iba_handle {
     DevBuf<KpRec> d_kp_rec;               // the factor kernel's keypoint records (r06: one cache line per keypoint)
     DevBuf<ScanRec> d_scan_rec;           // ... and scan-point records (point + memoised local-plane normal), rebuilt by compute_plane_cache; empty when the allocation failed
     bool scan_rec_valid = false;          // d_scan_rec holds the normals of the current plane memo (plane_cache = 1)
+    bool jets_fold = true;                // IBA_JETS_FOLD=0 (debug): the derivative half of a batch always by a copy launch of its own (rounds 3-5)
     bool factor_rec = true;               // IBA_FACTOR_REC=0 (debug): gather from the separate arrays as rounds 1-5 did
     DevBuf<double> d_ffr;                 // per keyframe: camera, pose, table offsets, relative poses of its covisible slots — one contiguous record (kFfrHead + 12 max_slots doubles)
     DevBuf<double2> d_kp_c;               // ((u - cx) / fx, (v - cy) / fy) of every keypoint: IBA_PlaneFactor's ray (IBACalib2.hpp:165), divided once here instead of per residual block
@@ -551,8 +552,11 @@ iba_status stage_cands(iba_handle* h, const double* x, int B, hipStream_t st, Ca
 }
 // the derivative half of the staged candidates: computed (or taken over from the group's calling thread) and copied now, in stream
 // order, before the factor kernel is enqueued
-iba_status finish_jets(iba_handle* h, hipStream_t st) {
-    if (!h->jets_x && !h->jets_src) return IBA_OK;
+// what is left to copy of a staged batch's derivative half (pinned ring -> device), in 16-byte words [w0, w1) of every Cand
+struct JetsCopy { const uint4* src = nullptr; uint4* dst = nullptr; uint32_t B = 0, w0 = 0, w1 = 0; };
+// the host side: the derivatives are computed (or taken over from the group's calling thread) into the pinned slot. false: nothing is pending
+bool prepare_jets(iba_handle* h, JetsCopy& jc) {
+    if (!h->jets_x && !h->jets_src) return false;
     Cand* hc = h->h_cands + (size_t)h->jets_slot * h->chain_cap;
     Cand* dc = h->d_cands.p + (size_t)h->jets_slot * h->chain_cap;
     if (h->jets_src) {   // the group's calling thread has been differentiating while this device's kernels ran on the values
@@ -562,14 +566,21 @@ iba_status finish_jets(iba_handle* h, hipStream_t st) {
         h->jets_src = nullptr; h->jets_flag = nullptr;
     } else
     for (int b = 0; b < h->jets_B; ++b) make_cand_jets(h->jets_x + 7 * b, hc[b]);
-    {   // the derivative half alone (the kernels in flight read the value half), on the chain's own stream: a second stream would hide
-        // these 4 us beside the search kernel at the price of two event hops (~6 us each, tools/chain_gaps.sh)
-        static_assert(offsetof(Cand, dR) % 16 == 0 && sizeof(Cand) % 16 == 0, "the halves of a Cand are copied as 16-byte words");
-        const uint32_t w0 = (uint32_t)(offsetof(Cand, dR) / 16), w1 = (uint32_t)(sizeof(Cand) / 16), n = (uint32_t)h->jets_B * (w1 - w0);
-        hipLaunchKernelGGL(iba_fetch_jets_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4*)(h->h_cands_dev + (size_t)h->jets_slot * h->chain_cap), (uint4*)dc, (uint32_t)h->jets_B, w0, w1, w1);
-        HIP_TRY(h, hipGetLastError());
-    }
+    static_assert(offsetof(Cand, dR) % 16 == 0 && sizeof(Cand) % 16 == 0, "the halves of a Cand are copied as 16-byte words");
+    jc.src = (const uint4*)(h->h_cands_dev + (size_t)h->jets_slot * h->chain_cap); jc.dst = (uint4*)dc;
+    jc.B = (uint32_t)h->jets_B; jc.w0 = (uint32_t)(offsetof(Cand, dR) / 16); jc.w1 = (uint32_t)(sizeof(Cand) / 16);
     h->jets_x = nullptr;
+    return true;
+}
+// the derivative half of the staged candidates: computed and copied now, in stream order, before the factor kernel is enqueued (a chain with a search
+// kernel lets that kernel's spare blocks do the copy instead: run_split)
+iba_status finish_jets(iba_handle* h, hipStream_t st) {
+    JetsCopy jc;
+    if (!prepare_jets(h, jc)) return IBA_OK;
+    // the derivative half alone (the kernels in flight read the value half), on the chain's own stream
+    const uint32_t n = jc.B * (jc.w1 - jc.w0);
+    hipLaunchKernelGGL(iba_fetch_jets_kernel, dim3((n + 255) / 256), dim3(256), 0, st, jc.src, jc.dst, jc.B, jc.w0, jc.w1, jc.w1);
+    HIP_TRY(h, hipGetLastError());
     return IBA_OK;
 }
 
@@ -846,9 +857,19 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     }
     // an association kernel that is the first of its chain carries the head in kHeadBlocks spare blocks, and its own blocks read their
     // candidate (R, t, s: 13 doubles) where it lies in the pinned ring
-    const uint32_t head_blocks = head_open ? std::min<uint32_t>(kHeadBlocks, (head_n16 + (uint32_t)kThreads - 1u) / (uint32_t)kThreads) : 0u;
+    uint32_t head_blocks = head_open ? std::min<uint32_t>(kHeadBlocks, (head_n16 + (uint32_t)kThreads - 1u) / (uint32_t)kThreads) : 0u;
     const Cand* assoc_cands = head_open ? (const Cand*)head_src : dc;
-    const uint4* a_src = head_open ? head_src : nullptr; const uint32_t a_n16 = head_open ? head_n16 : 0u;
+    const uint4* a_src = head_open ? head_src : nullptr; uint32_t a_n16 = head_open ? head_n16 : 0u;
+    // (round 6) the pair search has carried the values: the spare blocks of the shared-pair association are free for the DERIVATIVE half, which the host finishes now — the
+    // GPU is busy with the pair search for 45 us — instead of a copy launch of its own in front of the factor kernel (5 us in stream order). A chain whose association kernel
+    // carries the head itself, or the per-candidate association, keeps the copy launch (finish_jets below).
+    if (common && !head_open && factors && h->chain_fold && h->jets_fold) {
+        JetsCopy jc;
+        if (prepare_jets(h, jc) && jc.B <= 0xFFFFu && jc.w1 < 128u) {
+            a_src = jc.src; a_n16 = 0x80000000u | jc.B | (jc.w0 << 16) | (jc.w1 << 24);
+            head_blocks = std::min<uint32_t>(kHeadBlocks, (jc.B * (jc.w1 - jc.w0) + 255u) / 256u);
+        }
+    }
     if (common) {
         // (twelve instantiations: two / four / any number of flagged keypoints per thread x at most 30 covisible keyframes or more x 256 / 512 threads)
         const int at = assoc2_threads(h, 8 * per_xcd * B);
@@ -1211,6 +1232,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (const char* e = dbg_env("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
     if (const char* e = dbg_env("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
     if (const char* e = dbg_env("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
+    if (const char* e = dbg_env("IBA_JETS_FOLD")) h->jets_fold = std::atoi(e) != 0;
     if (const char* e = dbg_env("IBA_FACTOR_REC")) h->factor_rec = std::atoi(e) != 0;
     if (const char* e = dbg_env("IBA_FACTOR_V2")) h->factor_v2 = std::atoi(e) != 0;
     if (const char* e = dbg_env("IBA_FACTOR_DBG")) h->factor_dbg = std::atoi(e);

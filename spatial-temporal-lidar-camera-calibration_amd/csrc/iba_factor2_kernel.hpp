@@ -285,7 +285,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             { const uint32_t gn = min(g + 64u, e_hi - 1u); locate(gn, f_n); e_n = entry_of(gn, f_n); }   // the next entries are in flight during this round's arithmetic
             // keyframes this round reaches: into the ring (the last live lane holds the highest). A round whose 64 entries span more keyframes than the
             // ring holds (keyframes with a handful of entries each) goes through in windows of keyframes; one window is the rule
+#ifdef IBA_DIAG_COUNTERS
             asm volatile("" :: "v"(e.x));
+#endif
             F2_TICK(0);   // this round's entries have landed, the next round's are issued
             const uint32_t n_live = min(64u, e_hi - cur);
             const uint32_t f_max = (uint32_t)__builtin_amdgcn_readlane((int)f_l, (int)n_live - 1);
@@ -329,10 +331,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     ib = p2x_load(qb, hb, tb - hb >= 64u ? 64u : 0u, true);
                     F2_TICK(2);   // gathers issued
                     p2x_compute(ib, true); ib.on = false;
+#ifdef IBA_DIAG_COUNTERS
                     asm volatile("" :: "v"(A.H[0]));
+#endif
                     F2_TICK(3);   // point-to-plane arithmetic (incl. the wait for its gathers)
                     plane_compute(ia);
+#ifdef IBA_DIAG_COUNTERS
                     asm volatile("" :: "v"(A.H[27]));
+#endif
                     F2_TICK(4);   // plane-factor arithmetic
                 }
                 if (tc - hc >= 64u) p2x_batch(qc, hc, 64u, false);

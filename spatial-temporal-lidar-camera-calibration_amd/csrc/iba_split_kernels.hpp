@@ -1066,7 +1066,19 @@ __global__ __launch_bounds__(T) void iba_assoc2_kernel(K2Args ka_by_value, const
     (void)ka_by_value;
     {   // the chain's head rides in the blocks behind the (frame, candidate) grid (a call that reuses earlier pair lists has no pair search to carry it)
         const uint32_t main_blocks = 8u * (uint32_t)((ka->dp.n_frames + 7) / 8) * (uint32_t)B;
-        if (blockIdx.x >= main_blocks) { chain_head_copy(head_src, head_dst, head_n16, blockIdx.x - main_blocks, gridDim.x - main_blocks, (uint32_t)kThreads); return; }
+        if (blockIdx.x >= main_blocks) {
+            // (round 6) head_n16 with bit 31 set: the spare blocks carry the DERIVATIVE half of the candidates instead — words [w0, w1) of every Cand, B | w0 << 16 | w1 << 24 —
+            // for the factor kernel at the end of this chain (the pair search in front of this kernel has carried the values; rounds 3-5: iba_fetch_jets_kernel, a launch of
+            // its own in stream order, 5 us)
+            if (head_n16 >> 31) {
+                const uint32_t nb = head_n16 & 0xFFFFu, w0 = (head_n16 >> 16) & 0x7Fu, w1 = (head_n16 >> 24) & 0x7Fu, per = w1 - w0, n = nb * per;
+                for (uint32_t i = (blockIdx.x - main_blocks) * (uint32_t)kThreads + threadIdx.x; i < n; i += (gridDim.x - main_blocks) * (uint32_t)kThreads) {
+                    const uint32_t w = (i / per) * w1 + w0 + i % per;
+                    head_dst[w] = head_src[w];
+                }
+            } else chain_head_copy(head_src, head_dst, head_n16, blockIdx.x - main_blocks, gridDim.x - main_blocks, (uint32_t)kThreads);
+            return;
+        }
     }
 #define dp (ka->dp)
 #define prm (ka->prm)
@@ -2120,7 +2132,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                 for (uint32_t wn = (uint32_t)tid; wn < c1; wn += 2u * (uint32_t)T) {
                     uint4 e0, e1; float4 mq0, mq1;
                     fetch(wn, e0, mq0); fetch(wn + (uint32_t)T, e1, mq1);
-                    asm volatile("" :: "v"(e0.x), "v"(e1.x), "v"(mq0.x), "v"(mq1.x));
+#ifdef IBA_DIAG_COUNTERS
+                    asm volatile("" :: "v"(e0.x), "v"(e1.x), "v"(mq0.x), "v"(mq1.x));   // (diag build only: pinning the values here costs the regular build 33 spilled registers)
+#endif
                     NN_TICK(1);   // entries + MapPoints of the step
                     const bool w0 = (e0.w & kWantMask) != 0u, w1 = (e1.w & kWantMask) != 0u;
                     // the lists this lane's candidate reads: the set built around the anchor nearest to it (255: none is near — straight to the tree search)
@@ -2132,7 +2146,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     a0.flags = b0.flags = 0u;
                     if (w0 && sel0 != 255u) { h0 = *anchor_hdr(r0); a0 = *anchor_pt(r0, 0u); }   // header + nearest neighbour: ONE 128-byte line, all that most lanes need
                     if (w1 && sel1 != 255u) { h1 = *anchor_hdr(r1); b0 = *anchor_pt(r1, 0u); }
+#ifdef IBA_DIAG_COUNTERS
                     asm volatile("" :: "v"(h0.count), "v"(h1.count), "v"(a0.pos), "v"(b0.pos));
+#endif
                     NN_TICK(2);   // list rows of the step
                     if (w0) pick(wn, e0, mq0, h0, a0, r0);
                     if (w1) pick(wn + (uint32_t)T, e1, mq1, h1, b0, r1);
@@ -2413,6 +2429,19 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
     auto range_sum = [&](const double* base, int lo, int hi, const bool he_half) {
         double x = 0;
         int f = lo;
+        // (round 6) eight records in flight before the four of the loop below: a group's 13 keyframes (200 keyframes) cost two dependent round trips per half
+        // instead of four; the additions keep their order
+        for (; f + 8 <= hi; f += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = base[(size_t)(f + q) * kPartialStride + i];
+            if (HE_MODE != 0 && he_half) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const double hq = he_of(f + q), cq = __shfl(v[q], P_HE_CNT); if (he_lane) v[q] = cq != 0.0 ? hq : 0.0; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x += v[q];
+        }
         for (; f + 4 <= hi; f += 4) {
             double v0 = base[(size_t)f * kPartialStride + i], v1 = base[(size_t)(f + 1) * kPartialStride + i];
             double v2 = base[(size_t)(f + 2) * kPartialStride + i], v3 = base[(size_t)(f + 3) * kPartialStride + i];
@@ -2437,7 +2466,12 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
         const int q = threadIdx.x & (kNNPartial - 1), rl = threadIdx.x / kNNPartial;
         const double* ns = nn_partials + (size_t)b * nn_nrec * kNNPartial;
         double y = 0;
-        for (int r = rl; r < nn_nrec; r += NL) y += ns[(size_t)r * kNNPartial + q];
+        int r = rl;
+        for (; r + 3 * NL < nn_nrec; r += 4 * NL) {   // (round 6) four records in flight per step (1400 records per candidate at 200 keyframes x 7 slices: eleven per lane, one dependent round trip each before); the additions keep their order
+            const double v0 = ns[(size_t)r * kNNPartial + q], v1 = ns[(size_t)(r + NL) * kNNPartial + q], v2 = ns[(size_t)(r + 2 * NL) * kNNPartial + q], v3 = ns[(size_t)(r + 3 * NL) * kNNPartial + q];
+            y = (((y + v0) + v1) + v2) + v3;
+        }
+        for (; r < nn_nrec; r += NL) y += ns[(size_t)r * kNNPartial + q];
         s2[rl][q] = y;
     }
     __syncthreads();
