@@ -2400,7 +2400,7 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
     __shared__ double s[NG][kPartialStride];
     __shared__ double s2[NL][kNNPartial];
     __shared__ double s_he[HE_MODE == 1 ? kHeLds : 1];
-    const int b = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int b = blockIdx.x, i = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (a wave is one record group: its ranges and base addresses are scalars)
     const double* src = frame_partials + (size_t)b * nrec * kPartialStride;
     const bool he_lds = HE_MODE == 1 && nfr <= kHeLds;
     double* he_g = he_scratch + (size_t)b * (size_t)nfr;
@@ -2421,58 +2421,81 @@ __global__ __launch_bounds__(kReduceThreads) void iba_reduce2_kernel(const doubl
     // slot P_HE_SUM of an association record is empty; its lane sums the hand-eye terms of the counted frames instead (the count is the
     // neighbouring lane's own value: one shuffle; the term one more load of that lane alone — straight-line code, no divergent loop)
     const bool he_lane = HE_MODE != 0 && i == P_HE_SUM;
-    auto he_of = [&](int f) -> double {
-        if (HE_MODE == 0 || !he_lane) return 0.0;
-        if (HE_MODE == 2) return he_g[f];
-        return he_lds ? s_he[f] : __hip_atomic_load(he_g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (round 6) every load of a thread — its share of the search kernel's records, of the association's and of the factor kernel's — is issued before
+    // the first addition: the kernel was a chain of nine dependent round trips to records the previous kernels had just written (13 + 13 keyframes in
+    // steps of four, eleven search records one by one), 15.7 us at 64 x 200 keyframes. Loads past the end of a range re-read its last record
+    // (an unconditional load: one under a condition is waited for where its value merges with the default) and are left out of the sum; the
+    // additions keep the order of rounds 2-5.
+    // A range's last step reads the CH records that END at the range's end (one base address, immediate offsets) and leaves out the ones below
+    // its start; the additions keep the order of rounds 2-5.
+    constexpr int CH = HE_MODE == 1 ? 8 : 16, CN = 12;
+    double vn[CN];
+    const int qn = threadIdx.x & (kNNPartial - 1), rl = threadIdx.x / kNNPartial;
+    const double* ns = nn_partials ? nn_partials + (size_t)b * nn_nrec * kNNPartial : nullptr;
+    const int n_mine = ns && rl < nn_nrec ? (nn_nrec - rl + NL - 1) / NL : 0;   // records rl, rl + NL, ... of slot qn
+    if (n_mine > 0) {
+#pragma unroll
+        for (int k = 0; k < CN; ++k) vn[k] = ns[(size_t)(rl + (k < n_mine ? k : 0) * NL) * kNNPartial + qn];   // (past the lane's last record: its first one again, left out below)
+    }
+    const double* srcB = src + (size_t)nfr * kPartialStride;
+    const int nB = n_fact > 0 ? min(nfr, n_fact) : 0;   // (n_fact <= nfr records of the factor kernel: one per keyframe, or one per range of iba_factor2_kernel)
+    const int hiB = n_fact > 0 ? min(f1, n_fact) : f0;
+    double x = 0, xb = 0;
+    auto he_fix = [&](double v, int f) -> double {   // slot P_HE_SUM of an association record is empty; its lane sums the hand-eye term of every counted frame instead (the count is the neighbouring lane's own value)
+        if (HE_MODE == 0) return v;
+        double hv = 0.0;
+        if (HE_MODE == 2) hv = he_g[f];
+        else if (he_lane) hv = he_lds ? s_he[f] : __hip_atomic_load(he_g + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double c = __shfl(v, P_HE_CNT);
+        return he_lane ? (c != 0.0 ? hv : 0.0) : v;
     };
-    auto range_sum = [&](const double* base, int lo, int hi, const bool he_half) {
-        double x = 0;
-        int f = lo;
-        // (round 6) eight records in flight before the four of the loop below: a group's 13 keyframes (200 keyframes) cost two dependent round trips per half
-        // instead of four; the additions keep their order
-        for (; f + 8 <= hi; f += 8) {
-            double v[8];
+    if (nfr >= CH) {
+        for (int f = f0; f < f1; f += CH) {
+            double va[CH], vb[CH], hv[CH];
+            const int wa = min(f, nfr - CH);
+            const double* pa = src + (size_t)wa * kPartialStride + i;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = base[(size_t)(f + q) * kPartialStride + i];
-            if (HE_MODE != 0 && he_half) {
+            for (int q = 0; q < CH; ++q) va[q] = pa[(size_t)q * kPartialStride];
+            if (HE_MODE == 2) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const double hq = he_of(f + q), cq = __shfl(v[q], P_HE_CNT); if (he_lane) v[q] = cq != 0.0 ? hq : 0.0; }
+                for (int q = 0; q < CH; ++q) hv[q] = he_g[wa + q];   // (left in he_scratch by the search kernel's spare blocks; one address per wave: scalar loads)
+            }
+            const bool any_b = f < hiB && nB >= CH;
+            const int wb = min(f, nB - CH);
+            if (any_b) {
+                const double* pb = srcB + (size_t)wb * kPartialStride + i;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) vb[q] = pb[(size_t)q * kPartialStride];
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) x += v[q];
-        }
-        for (; f + 4 <= hi; f += 4) {
-            double v0 = base[(size_t)f * kPartialStride + i], v1 = base[(size_t)(f + 1) * kPartialStride + i];
-            double v2 = base[(size_t)(f + 2) * kPartialStride + i], v3 = base[(size_t)(f + 3) * kPartialStride + i];
-            if (HE_MODE != 0 && he_half) {
-                const double h0 = he_of(f), h1 = he_of(f + 1), h2 = he_of(f + 2), h3 = he_of(f + 3);
-                const double c0 = __shfl(v0, P_HE_CNT), c1 = __shfl(v1, P_HE_CNT), c2 = __shfl(v2, P_HE_CNT), c3 = __shfl(v3, P_HE_CNT);
-                if (he_lane) { v0 = c0 != 0.0 ? h0 : 0.0; v1 = c1 != 0.0 ? h1 : 0.0; v2 = c2 != 0.0 ? h2 : 0.0; v3 = c3 != 0.0 ? h3 : 0.0; }
+            for (int q = 0; q < CH; ++q) {
+                double v = va[q];
+                if (HE_MODE == 2) { const double c = __shfl(v, P_HE_CNT); if (he_lane) v = c != 0.0 ? hv[q] : 0.0; }
+                else if (HE_MODE == 1) v = he_fix(v, wa + q);
+                if (wa + q >= f && wa + q < f1) x += v;
             }
-            x = (((x + v0) + v1) + v2) + v3;
+            if (any_b) {
+#pragma unroll
+                for (int q = 0; q < CH; ++q) if (wb + q >= f && wb + q < hiB) xb += vb[q];
+            } else {
+                for (int fb = f; fb < min(f + CH, hiB); ++fb) xb += srcB[(size_t)fb * kPartialStride + i];
+            }
         }
-        for (; f < hi; ++f) {
-            double v = base[(size_t)f * kPartialStride + i];
-            if (HE_MODE != 0 && he_half) { const double hv = he_of(f), c = __shfl(v, P_HE_CNT); if (he_lane) v = c != 0.0 ? hv : 0.0; }
-            x += v;
-        }
-        return x;
-    };
-    double x = range_sum(src, f0, f1, true);
-    if (n_fact > 0) x += range_sum(src + (size_t)nfr * kPartialStride, f0, min(f1, n_fact), false);   // (n_fact <= nfr records of the factor kernel: one per keyframe, or one per range of iba_factor2_kernel)
+    } else {
+        for (int f = f0; f < f1; ++f) x += he_fix(src[(size_t)f * kPartialStride + i], f);
+        for (int f = f0; f < hiB; ++f) xb += srcB[(size_t)f * kPartialStride + i];
+    }
+    if (n_fact > 0) x += xb;
     s[g][i] = x;
-    if (nn_partials) {   // record lane rl sums the records rl, rl + NL, ... of slot q
-        const int q = threadIdx.x & (kNNPartial - 1), rl = threadIdx.x / kNNPartial;
-        const double* ns = nn_partials + (size_t)b * nn_nrec * kNNPartial;
+    if (nn_partials) {
         double y = 0;
-        int r = rl;
-        for (; r + 3 * NL < nn_nrec; r += 4 * NL) {   // (round 6) four records in flight per step (1400 records per candidate at 200 keyframes x 7 slices: eleven per lane, one dependent round trip each before); the additions keep their order
-            const double v0 = ns[(size_t)r * kNNPartial + q], v1 = ns[(size_t)(r + NL) * kNNPartial + q], v2 = ns[(size_t)(r + 2 * NL) * kNNPartial + q], v3 = ns[(size_t)(r + 3 * NL) * kNNPartial + q];
-            y = (((y + v0) + v1) + v2) + v3;
+        asm volatile("" : "+v"(y));   // (the first addition, 0 + vn[0], was scheduled right behind its load — a wait before the other loads were issued)
+        if (n_mine > 0) {
+#pragma unroll
+            for (int k = 0; k < CN; ++k) if (k < n_mine) y += vn[k];
+            for (int k = CN; k < n_mine; ++k) y += ns[(size_t)(rl + k * NL) * kNNPartial + qn];
         }
-        for (; r < nn_nrec; r += NL) y += ns[(size_t)r * kNNPartial + q];
-        s2[rl][q] = y;
+        s2[rl][qn] = y;
     }
     __syncthreads();
     if (g == 0) {
