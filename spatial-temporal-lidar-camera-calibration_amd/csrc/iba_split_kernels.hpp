@@ -26,6 +26,9 @@
 
 namespace iba {
 
+#ifndef IBA_NN_EXP
+#define IBA_NN_EXP 0
+#endif
 #ifndef IBA_NN_THREADS
 #define IBA_NN_THREADS 256
 #endif
@@ -2005,7 +2008,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
             IBA_LANE_NN_DECL;
             auto entry_at = [&](uint32_t wn) -> size_t { return ((size_t)((uint32_t)(g * CG) + (wn & ((1u << cg_shift) - 1u))) * nf + f) * (size_t)flist_stride + (i_lo + (wn >> cg_shift)); };
             // the two MapPoint -> LiDAR-frame queries of an entry under candidate cc (iba_local.cpp:238-239,282 and iba_global.cpp:231-234)
-            auto make_queries = [&](uint32_t cc, const uint4& e, const float4& mp) {
+            auto make_queries_to = [&](uint32_t cc, const uint4& e, const float4& mp, bool& actA, bool& actC, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
                 actC = (WHICH & 2) && (e.w & kFlagC);
                 actA = (WHICH & 1) && (e.w & kFlagA);
                 const double* cdl = s_cd + cc * kCdDoubles;
@@ -2040,6 +2043,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
                 }
             };
+            auto make_queries = [&](uint32_t cc, const uint4& e, const float4& mp) { make_queries_to(cc, e, mp, actA, actC, ax, ay, az, qx, qy, qz); };   // into the lane's search state
             // the finished searches of entry wn: the association's neighbour (+ kind), the cost distance. From the tree search
             // the plane records are fetched here; a set lane brings them along (sa / sc: the set entries of its two neighbours)
             auto finish = [&](uint32_t wn, const SetPt* sa, const SetPt* sc) {
@@ -2093,14 +2097,20 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     const uint32_t cc = wn & ((1u << cg_shift) - 1u), il = i_lo + (wn >> cg_shift);
                     if (wn < c1 && il < s_n[cc]) { e = flist[entry_at(wn)]; if (e.w & kWantMask) mp = kmp[e.x]; }
                 };
-                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, const AnchorHdr& hd, const SetPt& p0, const unsigned char* row) {
-                    make_queries(wn & ((1u << cg_shift) - 1u), e, mp);
+                // (round 6: the pick keeps the INDEX of its nearest listed points, not copies of their 48-byte entries — the nearest listed point to the anchor,
+                //  p0, is the answer of nearly every lane and is in registers already; two copies of it per entry were 50 register moves and 24 live registers.
+                //  The certificate's S comes from a float square root rounded UP: a larger S can only send an entry to the second chance or the tree.)
+                auto pick = [&](uint32_t wn, const uint4& e, const float4& mp, const AnchorHdr& hd, SetPt p0, const unsigned char* row) {
+                    // (its own queries and bests, not the lane's search state: that lives across the loop for the left-over searches, and every pick merging into it was a register move per word)
+                    bool actA, actC; double ax, ay, az, qx, qy, qz, bestA, bestC; uint32_t bposA, bposC;
+                    make_queries_to(wn & ((1u << cg_shift) - 1u), e, mp, actA, actC, ax, ay, az, qx, qy, qz);
                     // the certificate: this candidate's queries are S from the anchor's; its nearest points lie within d_1 + 2 S of the
                     // anchor query, and the list is complete out to d_M (exclusive)
                     double S2 = 0.0;
                     if ((WHICH & 1) && actA) { const double dx = ax - hd.qa[0], dy = ay - hd.qa[1], dz = az - hd.qa[2]; S2 = (dx * dx + dy * dy) + dz * dz; }
                     if ((WHICH & 2) && actC) { const double dx = qx - hd.qa[0], dy = qy - hd.qa[1], dz = qz - hd.qa[2]; S2 = fmax(S2, (dx * dx + dy * dy) + dz * dz); }
-                    const double S = sqrt(S2);
+                    auto sqrt_up = [](double v2) -> double { return (double)(__builtin_sqrtf((float)v2) * 1.000001f + 1e-18f); };   // >= sqrt(v2) (float rounding 6e-8, flushed denormals < 1.1e-19); NaN stays NaN
+                    const double S = sqrt_up(S2);
                     const double radius = (hd.d1 + 2.0 * S) * (1.0 + 1e-12) + 1e-12;
                     const bool quick = radius < hd.dM;   // (NaN queries fail both tests)
                     // Second chance, from the whole row: with r = the distance to the nearest LISTED point, every point within r of this
@@ -2111,23 +2121,45 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     auto leave = [&](uint32_t pa, uint32_t pc) { ((uint2*)s_res)[wn - c0] = make_uint2(pa, pc); s_ovf[atomicAdd(&s_ctr[1], 1u)] = wn; };
                     if (hd.count == 0u) { leave(kNone, kNone); return; }
                     bestA = INFINITY; bestC = INFINITY; bposA = kNone; bposC = kNone;
-                    SetPt abest = p0, cbest = p0;
+                    uint32_t ia = 0u, ic = 0u;   // which listed point each search ended on
                     const float rf = quick ? (float)radius * 1.000001f + 1e-30f : INFINITY;   // >= radius
-                    for (uint32_t si = 0; si < hd.count; ++si) {
-                        if (si == 1u && !(hd.da1_lo <= rf)) break;   // the second neighbour cannot qualify: its line is not even fetched (the usual case)
-                        const SetPt pv = si == 0u ? p0 : *anchor_pt(row, si);
-                        if (!(pv.da_lo <= rf)) break;            // the list is sorted by distance to the anchor query: nothing further qualifies
-                        const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
-                        if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; const uint32_t was = bposA; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposA != was) abest = pv; }
-                        if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; const uint32_t was = bposC; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposC != was) cbest = pv; }
+                    {   // the nearest listed point (its own lower bound is <= d_1 <= radius: it always qualifies)
+                        const double x = (double)p0.x, y = (double)p0.y, z = (double)p0.z;
+                        if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, p0.pos, perm_g); }
+                        if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, p0.pos, perm_g); }
+                    }
+                    if (hd.count > 1u && hd.da1_lo <= rf) {   // (the usual case: the second neighbour cannot qualify and its line is not even fetched)
+                        for (uint32_t si = 1u; si < hd.count; ++si) {
+                            const SetPt pv = *anchor_pt(row, si);
+                            if (!(pv.da_lo <= rf)) break;            // the list is sorted by distance to the anchor query: nothing further qualifies
+                            const double x = (double)pv.x, y = (double)pv.y, z = (double)pv.z;
+                            if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; const uint32_t was = bposA; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposA != was) ia = si; }
+                            if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; const uint32_t was = bposC; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, pv.pos, perm_g); if (bposC != was) ic = si; }
+                        }
                     }
                     if (!quick) {
                         double r2 = 0.0;
                         if ((WHICH & 1) && actA) r2 = bestA;
                         if ((WHICH & 2) && actC) r2 = fmax(r2, bestC);
-                        if (!((sqrt(r2) + S) * (1.0 + 1e-12) + 1e-12 < hd.dM)) { leave(bposA, bposC); return; }   // (NaN queries end here, unseeded)
+                        if (!((sqrt_up(r2) + S) * (1.0 + 1e-12) + 1e-12 < hd.dM)) { leave(bposA, bposC); return; }   // (NaN queries end here, unseeded)
                     }
-                    if (dbg != 5) finish(wn, &abest, &cbest);
+                    if (dbg == 5) return;
+                    // ---- the results (finish() with the listed points' own verdicts and normals; p0 is overwritten by the rare other pick) ----
+                    const size_t at = entry_at(wn);
+                    if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2)) {   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
+                        uint32_t fa = p0.flags;
+                        if (ia != 0u) fa = anchor_pt(row, ia)->flags;
+                        flist[at].z = bposA | ((!refit && (fa & 1u)) ? 0x80000000u : 0u);   // (refit: the kind bit is settled by the fit kernel)
+                    }
+                    double res = NAN;
+                    if ((WHICH & 2) && actC) {
+                        if (ic != 0u) p0 = *anchor_pt(row, ic);
+                        const double ex = (double)p0.x - qx, ey = (double)p0.y - qy, ez = (double)p0.z - qz;
+                        if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
+                        else if (p0.flags & 2u) res = fabs(ex * p0.nx + ey * p0.ny + ez * p0.nz);   // cost_res with the plane's verdict already taken (iba_anchor_kernel): the same expressions
+                        else res = -sqrt((ex * ex + ey * ey) + ez * ez);
+                    }
+                    if (WHICH & 2) s_res[wn - c0] = res;   // (NaN when the planes are refitted: the sums come from the fit kernel's distances)
                 };
                 for (uint32_t wn = (uint32_t)tid; wn < c1; wn += 2u * (uint32_t)T) {
                     uint4 e0, e1; float4 mq0, mq1;
@@ -2144,8 +2176,17 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     AnchorHdr h0, h1; SetPt a0, b0;
                     h0.count = h1.count = 0u; h0.dM = h1.dM = -1.0; h0.d1 = h1.d1 = 0.0; h0.da1_lo = h1.da1_lo = INFINITY;
                     a0.flags = b0.flags = 0u;
+#if IBA_NN_EXP == 1   /* timing experiment: the nearest neighbour's 48 bytes are not fetched (results invalid) */
+                    if (w0 && sel0 != 255u) { h0 = *anchor_hdr(r0); }
+                    if (w1 && sel1 != 255u) { h1 = *anchor_hdr(r1); }
+#else
                     if (w0 && sel0 != 255u) { h0 = *anchor_hdr(r0); a0 = *anchor_pt(r0, 0u); }   // header + nearest neighbour: ONE 128-byte line, all that most lanes need
                     if (w1 && sel1 != 255u) { h1 = *anchor_hdr(r1); b0 = *anchor_pt(r1, 0u); }
+#endif
+#if IBA_NN_EXP == 2   /* timing experiment: the loads of the list pass alone, no picks (results invalid) */
+                    asm volatile("" :: "v"(h0.count), "v"(h1.count), "v"(a0.pos), "v"(b0.pos), "v"(h0.dM), "v"(h1.dM), "v"(a0.nz), "v"(b0.nz), "v"(mq0.x), "v"(mq1.x));
+                    continue;
+#endif
 #ifdef IBA_DIAG_COUNTERS
                     asm volatile("" :: "v"(h0.count), "v"(h1.count), "v"(a0.pos), "v"(b0.pos));
 #endif
