@@ -29,6 +29,8 @@
  *                                                         in rounds of leaves (same results; A/B timing)
  *   IBA_DONE_FLAG                                         0: a blocking call polls its stream (rounds 3-4) instead of the sequence number the summing
  *                                                         kernel's last block publishes in pinned memory (same results; A/B timing)
+ *   IBA_NN_LIST                                           1: the anchored lists are walked by iba_nn_list_kernel's persistent grid (measured slower; csrc/iba_nn_list_kernel.hpp);
+ *                                                         IBA_NN_LIST_WORKERS=n: its blocks per CU
  *   IBA_FACTOR_V2                                         1: the normal equations by iba_factor2_kernel — one wave per equal share of a candidate's whole work
  *                                                         list (csrc/iba_factor2_kernel.hpp) — instead of one wave per (keyframe, candidate); same sums to
  *                                                         summation order, measured no faster; IBA_FACTOR_WAVES_PER_CAND forces its ranges per candidate
@@ -58,6 +60,7 @@ iba_status iba_last_phase_ms(iba_handle* h, float* assoc_kernel_ms, float* nn_ke
 /* debug (library built with -DIBA_DIAG_COUNTERS only, `make -C csrc diag`; zeros otherwise): cycle sums per phase of the search kernel (thread 0 of every block:
  * start-up, entries + MapPoints, list rows, picks, wait at the end of the list pass, left-over searches, sums) and the number of blocks */
 iba_status iba_debug_phase_cycles(iba_handle* h, uint64_t out8[8], int32_t reset);
+iba_status iba_debug_phase_cycles12(iba_handle* h, uint64_t out12[12], int32_t reset);   /* the same with iba_nn_list_kernel's four slots inside its picks */
 /* debug: threads per block of the last iba_assoc2_kernel launch on this handle (256 or 512: chosen per launch from the number of (candidate,
  * keyframe) blocks; 0 = no shared-pair association has run) */
 int32_t iba_debug_last_assoc2_threads(const iba_handle* h);
@@ -88,6 +91,7 @@ int32_t iba_debug_pairs_builds(const iba_handle* h);
 /* diagnostic: list entries of the last evaluation (all candidates) that the anchored neighbour lists could not settle and the
  * tree search took over; -1 when no search ran */
 double iba_debug_nn_left_to_tree(iba_handle* h);
+int32_t iba_debug_last_nn_list(const iba_handle* h);   /* > 0: the last search launch was iba_nn_list_kernel (IBA_NN_LIST=1, opt-in) with that many workers per (XCD, group) */
 /* diagnostic: mean number of (scan point, keypoint) pairs per keyframe that the last shared pair search listed; -1: none ran */
 double iba_debug_mean_pairs(iba_handle* h);
 /* debug (host only): R[9], t[3], dR/d omega_k [3][9], dt/dx_k [6][3], s of a candidate as the factor kernel reads them (58 doubles) */

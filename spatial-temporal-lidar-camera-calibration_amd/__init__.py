@@ -328,6 +328,13 @@ class IbaHandle:
         self.lib.iba_debug_factor_ranges.restype = C.c_int32
         return int(self.lib.iba_debug_factor_ranges(self.h, C.c_int32(B)))
 
+    @property
+    def last_nn_list(self):
+        """> 0: the last search launch was iba_nn_list_kernel (opt-in, IBA_NN_LIST=1) with that many workers per (XCD, group of candidates)"""
+        self.lib.iba_debug_last_nn_list.argtypes = [C.c_void_p]
+        self.lib.iba_debug_last_nn_list.restype = C.c_int32
+        return int(self.lib.iba_debug_last_nn_list(self.h))
+
     def debug_last_partials(self, B):
         out = np.zeros((B, partial_stride()))
         self._chk(self.lib.iba_debug_last_partials(self.h, _p(out), C.c_int32(B)))

@@ -32,6 +32,7 @@ const char* debug_env(const char* name) {   // (read at every handle creation: a
 #include "iba_mads_glue.hpp"
 #include "iba_split_kernels.hpp"
 #include "iba_factor2_kernel.hpp"
+#include "iba_nn_list_kernel.hpp"
 #include "iba_types.hpp"
 
 using namespace iba;
@@ -93,6 +94,10 @@ struct iba_handle {
     DevBuf<double> d_ffr;                 // per keyframe: camera, pose, table offsets, relative poses of its covisible slots — one contiguous record (kFfrHead + 12 max_slots doubles)
     DevBuf<double2> d_kp_c;               // ((u - cx) / fx, (v - cy) / fy) of every keypoint: IBA_PlaneFactor's ray (IBACalib2.hpp:165), divided once here instead of per residual block
     int nn_dbg = 0;                       // IBA_NN_DBG: cut the search kernel short (timing attribution; results are garbage)
+    bool nn_list = false;                 // IBA_NN_LIST=1 (opt-in, measured slower: see iba_nn_list_kernel.hpp): the anchored lists are walked by iba_nn_list_kernel's persistent grid instead of iba_nn_kernel's one block per slice
+    int nn_list_workers = 0;              // IBA_NN_LIST_WORKERS: blocks of iba_nn_list_kernel per CU (0: what the LDS and 4 waves per SIMD allow)
+    int n_cus = 256;                      // compute units of the device (MI355X: 256)
+    int last_nn_list = 0;                 // diagnostic: workers per (XCD, group) of the last iba_nn_list_kernel launch (0: iba_nn_kernel ran)
     int nn_cg_max = 8;                    // candidates per search block (power of two <= kMaxGroup)
     bool nn_cg_fixed = false;             // IBA_NN_CG given: no adaptation to the batch size
     bool nn_rounds = true;                // IBA_NN_ROUNDS=0: the entries the anchored lists leave over are searched leaf by leaf (rounds 3-4) instead of in rounds of leaves
@@ -315,6 +320,7 @@ bool layout_nn(const iba_handle* h, NNLayout& L) {
     off = align_up(off, 16); L.off_res = off; off += 8u * kSliceW * (uint32_t)kMaxGroup;
     L.off_ovf = off; off += 4u * kSliceW * (uint32_t)kMaxGroup;   // work entries left to the tree search when the batch's neighbour sets are in use
     L.total = off;
+    off = align_up(off, 16); L.off_res2 = off;   // (iba_nn_list_kernel launches with total + one more result buffer)
     return L.total <= kLdsBytes;
 }
 
@@ -917,7 +923,22 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
             const int heb = MODE == kRefitSums ? 0 : he_blocks;   // (the second launch of a refit chain only sums)
             const dim3 grid_m(MODE == kRefitSums ? 8 * per_xcd * ngroups * NS : grid.x);
             auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid_m, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, anchor, h->d_he.p, heb); };
-            if (sets && MODE != kRefitSums) { if (wA && wC) go(iba_nn_kernel<3, MODE, 1>); else if (wA) go(iba_nn_kernel<1, MODE, 1>); else go(iba_nn_kernel<2, MODE, 1>); }
+            h->last_nn_list = 0;
+            const bool small_bufs = (size_t)B * nf * h->lstride * 16u < 0xFFFFFF00ull && (size_t)kAnchorSets * h->anchor_set_elems * sizeof(SetPt) < 0xFFFFFF00ull && (size_t)dp.n_kp_total * 16u < 0x80000000ull;   // (32-bit buffer offsets)
+            if (sets && MODE == 0 && h->nn_list && small_bufs && CG >= 4 && (kSliceW * (uint32_t)CG) % (2u * (uint32_t)kNNThreads) == 0u && (kSliceW * (uint32_t)CG) / (uint32_t)kNNThreads <= 4u) {
+                // the persistent form (iba_nn_list_kernel): R workers per (XCD, group of candidates), as many blocks as the machine holds at once
+                const uint32_t lds = align_up(nl.off_res2 + 8u * kSliceW * (uint32_t)kMaxGroup, 16);
+                const int per_cu = h->nn_list_workers > 0 ? h->nn_list_workers : std::max(1, std::min(4 * IBA_NN_LIST_WAVES * 64 / kNNThreads, (int)(kLdsBytes / lds)));
+                const int R = std::max(1, std::min(per_xcd * NS, (h->n_cus * per_cu) / (8 * ngroups)));
+                h->last_nn_list = R;
+                const dim3 grid_l(8 * ngroups * R + ((heb + 7) & ~7));
+                auto gol = [&](auto kern) { hipLaunchKernelGGL(kern, grid_l, block, lds, st, na, dc, B, CG, NS, R, h->d_nn_partials.p, nn_nrec, fl, lc, (int)h->lstride, h->nn_dbg, anchor, h->d_he.p, heb); };
+                const bool four = (kSliceW * (uint32_t)CG) / (uint32_t)kNNThreads == 4u;
+                if (wA && wC) { if (four) gol(iba_nn_list_kernel<3, 4>); else gol(iba_nn_list_kernel<3, 2>); }
+                else if (wA) { if (four) gol(iba_nn_list_kernel<1, 4>); else gol(iba_nn_list_kernel<1, 2>); }
+                else { if (four) gol(iba_nn_list_kernel<2, 4>); else gol(iba_nn_list_kernel<2, 2>); }
+            }
+            else if (sets && MODE != kRefitSums) { if (wA && wC) go(iba_nn_kernel<3, MODE, 1>); else if (wA) go(iba_nn_kernel<1, MODE, 1>); else go(iba_nn_kernel<2, MODE, 1>); }
             else { if (wA && wC) go(iba_nn_kernel<3, MODE, 0>); else if (wA) go(iba_nn_kernel<1, MODE, 0>); else go(iba_nn_kernel<2, MODE, 0>); }
         };
         if (refit) launch_nn(std::integral_constant<int, kRefitSearch>{}); else launch_nn(std::integral_constant<int, 0>{});
@@ -1230,6 +1251,8 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     if (const char* e = dbg_env("IBA_DONE_FLAG")) h->done_flag_on = std::atoi(e) != 0;
     if (const char* e = dbg_env("IBA_NN_CG")) { h->nn_cg_max = std::max(1, std::min(kMaxGroup, std::atoi(e))); h->nn_cg_fixed = true; }
     if (const char* e = dbg_env("IBA_NN_DBG")) h->nn_dbg = std::atoi(e);
+    if (const char* e = dbg_env("IBA_NN_LIST")) h->nn_list = std::atoi(e) != 0;
+    if (const char* e = dbg_env("IBA_NN_LIST_WORKERS")) h->nn_list_workers = std::max(0, std::atoi(e));
     if (const char* e = dbg_env("IBA_ASSOC_DBG")) h->assoc_dbg = std::atoi(e);
     if (const char* e = dbg_env("IBA_FACTOR_MFMA")) h->factor_valu = std::atoi(e) == 0;
     if (const char* e = dbg_env("IBA_JETS_FOLD")) h->jets_fold = std::atoi(e) != 0;
@@ -1318,7 +1341,7 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
         L.total = std::max(L.off_ring + L.ring_slots * L.ring_stride * 8u, L.off_tr + 21u * 65u * 8u);
         if (L.total > 64u * 1024u) L.total = 0u;   // (a handle with that many keyframes or covisible slots keeps the one-record-per-keyframe kernel)
         int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->factor_slots = cus * 8;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) { h->factor_slots = cus * 8; h->n_cus = cus; }
     }
 #undef UP
     hipError_t er;
@@ -1380,6 +1403,9 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
                             (const void*)iba_nn_kernel<1, 0, 1>, (const void*)iba_nn_kernel<2, 0, 1>, (const void*)iba_nn_kernel<3, 0, 1>, (const void*)iba_nn_kernel<1, 1, 1>, (const void*)iba_nn_kernel<2, 1, 1>,
                             (const void*)iba_nn_kernel<3, 1, 1>};
     for (const void* fn : nfns)
+        if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    const void* lfns[6] = {(const void*)iba_nn_list_kernel<1, 2>, (const void*)iba_nn_list_kernel<2, 2>, (const void*)iba_nn_list_kernel<3, 2>, (const void*)iba_nn_list_kernel<1, 4>, (const void*)iba_nn_list_kernel<2, 4>, (const void*)iba_nn_list_kernel<3, 4>};
+    for (const void* fn : lfns)
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
 
     {   // the association kernel's view of its kernarg segment (see iba_kernarg_probe_kernel)
@@ -1622,6 +1648,14 @@ iba_status iba_debug_phase_cycles(iba_handle* h, uint64_t out8[8], int32_t reset
     if (reset && hipMemset(h->d_diag.p + 8, 0, 64) != hipSuccess) return fail(h, IBA_ERR_HIP, "memset");
     return IBA_OK;
 }
+iba_status iba_debug_phase_cycles12(iba_handle* h, uint64_t out12[12], int32_t reset) {   // (iba_nn_list_kernel: slots 8-11 split its picks)
+    if (!h || !h->d_diag.p || !out12) return IBA_ERR_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, IBA_ERR_HIP, "sync");
+    if (hipMemcpy(out12, h->d_diag.p + 8, 96, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, IBA_ERR_HIP, "copy");
+    if (reset && hipMemset(h->d_diag.p + 8, 0, 96) != hipSuccess) return fail(h, IBA_ERR_HIP, "memset");
+    return IBA_OK;
+}
+int32_t iba_debug_last_nn_list(const iba_handle* h) { return h ? h->last_nn_list : -1; }   // workers per (XCD, group) of the last search launch if it was iba_nn_list_kernel's (0: iba_nn_kernel)
 int32_t iba_debug_pairs_builds(const iba_handle* h) { return h ? h->pairs_builds : -1; }
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }
 

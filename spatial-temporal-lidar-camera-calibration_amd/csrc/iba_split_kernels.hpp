@@ -44,6 +44,7 @@ static_assert(4 * (2 * kMaxGroup + 4) <= 128, "iba_nn_kernel's misc slab (layout
 
 struct NNLayout {   // byte offsets into the dynamic LDS of iba_nn_kernel
     uint32_t off_nodes, off_res, off_misc, off_cd, off_ovf, total;
+    uint32_t off_res2;   // the second result-slot buffer of iba_nn_list_kernel (items alternate)
 };
 constexpr int kCdDoubles = 14;   // per candidate in LDS: s, Ri[9], ti[3], (s32, pad) = doubles 12..25 of Cand
 #ifndef IBA_NN_WAVES
