@@ -1942,6 +1942,15 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
     double* s_cd = (double*)(smem + lay.off_cd);             // [kMaxGroup][kCdDoubles] candidate constants of the query transform
     int cg_shift = 0; while ((1 << cg_shift) < CG) ++cg_shift;   // CG is a power of two (host)
 
+    // (round 6) what the block stages — its candidates' list lengths, transform constants and anchor sets — is requested BEFORE the list lengths of the
+    // empty-slice test are waited for: the block's start-up was two dependent round trips (the scalar loads of the test, then these), 28 us of the kernel
+    // when it is cut short behind its first barrier (tools/nn_exp.sh)
+    uint32_t my_n = 0u;
+    if (tid < cands_here) my_n = lcount[(size_t)(g * CG + tid) * nf + f];
+    double my_cd = 0.0;
+    if (tid < cands_here * kCdDoubles) my_cd = ((const double*)&cands[g * CG + tid / kCdDoubles])[12 + tid % kCdDoubles];
+    uint32_t my_sel = 255u;
+    if (SETS && tid < cands_here) my_sel = (uint32_t)ka->anchor_sel[g * CG + tid];
     // ---- a slice beyond every list of the group has nothing to search or sum: zero record, done (the lists hold ~575 of
     //      up to 7 x 128 positions at the bench shape: two blocks in seven) ----
     uint32_t nmax_u = 0u;
@@ -1953,13 +1962,11 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
     }
     // ---- kd nodes -> LDS; list lengths of the group's candidates ----
     const uint32_t nnodes = (1u << D) - 1u;
-    uint32_t my_n = 0u;
-    if (tid < cands_here) my_n = lcount[(size_t)(g * CG + tid) * nf + f];
     if (!SETS) for (uint32_t i = tid; i < nnodes; i += T) s_nodes[i] = dp.nodes[h.node_base + i];   // with the batch's neighbour sets the tree is staged only if a lane needs it
     if (tid < kMaxGroup) s_n[tid] = my_n;
     uint32_t* s_sel = s_ctr + 4;                             // [kMaxGroup] anchor set of each candidate of the group (255: none)
-    if (SETS && tid < kMaxGroup) s_sel[tid] = tid < cands_here ? (uint32_t)ka->anchor_sel[g * CG + tid] : 255u;
-    if (tid < cands_here * kCdDoubles) s_cd[tid] = ((const double*)&cands[g * CG + tid / kCdDoubles])[12 + tid % kCdDoubles];
+    if (SETS && tid < kMaxGroup) s_sel[tid] = my_sel;
+    if (tid < cands_here * kCdDoubles) s_cd[tid] = my_cd;
     // (r04: the counters and the result slots are cleared HERE, before the block's first barrier — the slice's extent follows from the
     //  list lengths every thread has just read — instead of behind two more barriers of their own)
     if (tid == 0) { s_ctr[0] = 0u; s_ctr[1] = 0u; }
@@ -2145,22 +2152,27 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                         if (!((sqrt_up(r2) + S) * (1.0 + 1e-12) + 1e-12 < hd.dM)) { leave(bposA, bposC); return; }   // (NaN queries end here, unseeded)
                     }
                     if (dbg == 5) return;
-                    // ---- the results (finish() with the listed points' own verdicts and normals; p0 is overwritten by the rare other pick) ----
+                    // ---- the results (finish() with the listed points' own verdicts and normals). The rare other pick fetches its entry and finishes INSIDE its own
+                    //      branch: a value loaded under a condition and merged behind it is waited for behind it, by every lane (s_waitcnt vmcnt(0)) ----
                     const size_t at = entry_at(wn);
-                    if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2)) {   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
-                        uint32_t fa = p0.flags;
-                        if (ia != 0u) fa = anchor_pt(row, ia)->flags;
-                        flist[at].z = bposA | ((!refit && (fa & 1u)) ? 0x80000000u : 0u);   // (refit: the kind bit is settled by the fit kernel)
+                    auto results = [&](const uint32_t fa, const SetPt& pc) {
+                        if ((WHICH & 1) && actA && !(bestA > prm.max_3d_dist2))   // the association keeps its neighbour only within max_3d_dist (iba_local.cpp:289)
+                            flist[at].z = bposA | ((!refit && (fa & 1u)) ? 0x80000000u : 0u);   // (refit: the kind bit is settled by the fit kernel)
+                        double res = NAN;
+                        if ((WHICH & 2) && actC) {
+                            const double ex = (double)pc.x - qx, ey = (double)pc.y - qy, ez = (double)pc.z - qz;
+                            if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
+                            else if (pc.flags & 2u) res = fabs(ex * pc.nx + ey * pc.ny + ez * pc.nz);   // cost_res with the plane's verdict already taken (iba_anchor_kernel): the same expressions
+                            else res = -sqrt((ex * ex + ey * ey) + ez * ez);
+                        }
+                        if (WHICH & 2) s_res[wn - c0] = res;   // (NaN when the planes are refitted: the sums come from the fit kernel's distances)
+                    };
+                    if ((ia | ic) == 0u) results(p0.flags, p0);
+                    else {
+                        const uint32_t fa = ia != 0u ? anchor_pt(row, ia)->flags : p0.flags;
+                        const SetPt pc = ic != 0u ? *anchor_pt(row, ic) : p0;
+                        results(fa, pc);
                     }
-                    double res = NAN;
-                    if ((WHICH & 2) && actC) {
-                        if (ic != 0u) p0 = *anchor_pt(row, ic);
-                        const double ex = (double)p0.x - qx, ey = (double)p0.y - qy, ez = (double)p0.z - qz;
-                        if (refit) frefit[at] = make_double4(ex, ey, ez, __longlong_as_double((long long)bposC));
-                        else if (p0.flags & 2u) res = fabs(ex * p0.nx + ey * p0.ny + ez * p0.nz);   // cost_res with the plane's verdict already taken (iba_anchor_kernel): the same expressions
-                        else res = -sqrt((ex * ex + ey * ey) + ez * ez);
-                    }
-                    if (WHICH & 2) s_res[wn - c0] = res;   // (NaN when the planes are refitted: the sums come from the fit kernel's distances)
                 };
                 for (uint32_t wn = (uint32_t)tid; wn < c1; wn += 2u * (uint32_t)T) {
                     uint4 e0, e1; float4 mq0, mq1;
