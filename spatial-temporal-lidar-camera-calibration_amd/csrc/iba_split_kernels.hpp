@@ -2019,37 +2019,37 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
             auto make_queries_to = [&](uint32_t cc, const uint4& e, const float4& mp, bool& actA, bool& actC, double& ax, double& ay, double& az, double& qx, double& qy, double& qz) {
                 actC = (WHICH & 2) && (e.w & kFlagC);
                 actA = (WHICH & 1) && (e.w & kFlagA);
+                // (round 6) both queries are computed by every lane and an unwanted one is set to NaN behind it: nearly every entry wants both, and a branch
+                // around each was two exec-mask round trips per pick in a kernel bound by instruction issue; the candidate's rotation row by row (4 of its
+                // 13 constants live at a time)
                 const double* cdl = s_cd + cc * kCdDoubles;
-                struct { double s, Ri[9], ti[3]; float s32; } cd;
-                cd.s = cdl[0];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) cd.Ri[q] = cdl[1 + q];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) cd.ti[q] = cdl[10 + q];
-                cd.s32 = *(const float*)(cdl + 13);
-                const double s = cd.s;
-                ax = NAN; ay = NAN; az = NAN; qx = NAN; qy = NAN; qz = NAN;
-                if (actA) {
+                const double s = cdl[0];
+                const float s32 = *(const float*)(cdl + 13);
+                double sx = 0, sy = 0, sz = 0, cx_ = 0, cy_ = 0, cz_ = 0;
+                if (WHICH & 1) {
                     const double w0 = (double)mp.x, w1 = (double)mp.y, w2 = (double)mp.z;
                     const double mx = ((h.Tcw[0] * w0 + h.Tcw[1] * w1) + h.Tcw[2] * w2) + h.Tcw[3];
                     const double my = ((h.Tcw[4] * w0 + h.Tcw[5] * w1) + h.Tcw[6] * w2) + h.Tcw[7];
                     const double mz = ((h.Tcw[8] * w0 + h.Tcw[9] * w1) + h.Tcw[10] * w2) + h.Tcw[11];
-                    const double sx = mx * s, sy = my * s, sz = mz * s;
-                    ax = ((cd.Ri[0] * sx + cd.Ri[1] * sy) + cd.Ri[2] * sz) + cd.ti[0];
-                    ay = ((cd.Ri[3] * sx + cd.Ri[4] * sy) + cd.Ri[5] * sz) + cd.ti[1];
-                    az = ((cd.Ri[6] * sx + cd.Ri[7] * sy) + cd.Ri[8] * sz) + cd.ti[2];
+                    sx = mx * s; sy = my * s; sz = mz * s;
                 }
-                if (actC) {
+                if (WHICH & 2) {
                     const double ts0 = h.Tcw[3] * s, ts1 = h.Tcw[7] * s, ts2 = h.Tcw[11] * s;   // TcwRS translation *= scale (:208)
-                    const float m0 = mp.x * cd.s32, m1 = mp.y * cd.s32, m2 = mp.z * cd.s32;       // CV_32F product (:232)
+                    const float m0 = mp.x * s32, m1 = mp.y * s32, m2 = mp.z * s32;       // CV_32F product (:232)
                     const double a0 = (double)m0, a1 = (double)m1, a2 = (double)m2;
-                    const double cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
-                    const double cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
-                    const double cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
-                    qx = ((cd.Ri[0] * cx_ + cd.Ri[1] * cy_) + cd.Ri[2] * cz_) + cd.ti[0];
-                    qy = ((cd.Ri[3] * cx_ + cd.Ri[4] * cy_) + cd.Ri[5] * cz_) + cd.ti[1];
-                    qz = ((cd.Ri[6] * cx_ + cd.Ri[7] * cy_) + cd.Ri[8] * cz_) + cd.ti[2];
+                    cx_ = ((h.Tcw[0] * a0 + h.Tcw[1] * a1) + h.Tcw[2] * a2) + ts0;
+                    cy_ = ((h.Tcw[4] * a0 + h.Tcw[5] * a1) + h.Tcw[6] * a2) + ts1;
+                    cz_ = ((h.Tcw[8] * a0 + h.Tcw[9] * a1) + h.Tcw[10] * a2) + ts2;
                 }
+                double oa[3], oc[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double r0 = cdl[1 + 3 * i], r1 = cdl[2 + 3 * i], r2 = cdl[3 + 3 * i], t0 = cdl[10 + i];
+                    oa[i] = ((r0 * sx + r1 * sy) + r2 * sz) + t0;
+                    oc[i] = ((r0 * cx_ + r1 * cy_) + r2 * cz_) + t0;
+                }
+                ax = actA ? oa[0] : NAN; ay = actA ? oa[1] : NAN; az = actA ? oa[2] : NAN;
+                qx = actC ? oc[0] : NAN; qy = actC ? oc[1] : NAN; qz = actC ? oc[2] : NAN;
             };
             auto make_queries = [&](uint32_t cc, const uint4& e, const float4& mp) { make_queries_to(cc, e, mp, actA, actC, ax, ay, az, qx, qy, qz); };   // into the lane's search state
             // the finished searches of entry wn: the association's neighbour (+ kind), the cost distance. From the tree search
@@ -2114,9 +2114,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     make_queries_to(wn & ((1u << cg_shift) - 1u), e, mp, actA, actC, ax, ay, az, qx, qy, qz);
                     // the certificate: this candidate's queries are S from the anchor's; its nearest points lie within d_1 + 2 S of the
                     // anchor query, and the list is complete out to d_M (exclusive)
-                    double S2 = 0.0;
-                    if ((WHICH & 1) && actA) { const double dx = ax - hd.qa[0], dy = ay - hd.qa[1], dz = az - hd.qa[2]; S2 = (dx * dx + dy * dy) + dz * dz; }
-                    if ((WHICH & 2) && actC) { const double dx = qx - hd.qa[0], dy = qy - hd.qa[1], dz = qz - hd.qa[2]; S2 = fmax(S2, (dx * dx + dy * dy) + dz * dz); }
+                    double S2 = 0.0;   // (an unwanted query is NaN: fmax drops it, the select keeps the 0)
+                    if (WHICH & 1) { const double dx = ax - hd.qa[0], dy = ay - hd.qa[1], dz = az - hd.qa[2]; const double dA = (dx * dx + dy * dy) + dz * dz; S2 = actA ? dA : 0.0; }
+                    if (WHICH & 2) { const double dx = qx - hd.qa[0], dy = qy - hd.qa[1], dz = qz - hd.qa[2]; const double dC = (dx * dx + dy * dy) + dz * dz; S2 = actC ? fmax(S2, dC) : S2; }
                     auto sqrt_up = [](double v2) -> double { return (double)(__builtin_sqrtf((float)v2) * 1.000001f + 1e-18f); };   // >= sqrt(v2) (float rounding 6e-8, flushed denormals < 1.1e-19); NaN stays NaN
                     const double S = sqrt_up(S2);
                     const double radius = (hd.d1 + 2.0 * S) * (1.0 + 1e-12) + 1e-12;
@@ -2133,8 +2133,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
                     const float rf = quick ? (float)radius * 1.000001f + 1e-30f : INFINITY;   // >= radius
                     {   // the nearest listed point (its own lower bound is <= d_1 <= radius: it always qualifies)
                         const double x = (double)p0.x, y = (double)p0.y, z = (double)p0.z;
-                        if ((WHICH & 1) && actA) { const double dx = ax - x, dy = ay - y, dz = az - z; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, p0.pos, perm_g); }
-                        if ((WHICH & 2) && actC) { const double dx = qx - x, dy = qy - y, dz = qz - z; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, p0.pos, perm_g); }
+                        // (an unwanted query is NaN: its distance compares false with everything and nn_merge leaves best / bpos alone)
+                        if (WHICH & 1) { const double dx = ax - x, dy = ay - y, dz = az - z; nn_merge(bestA, bposA, (dx * dx + dy * dy) + dz * dz, p0.pos, perm_g); }
+                        if (WHICH & 2) { const double dx = qx - x, dy = qy - y, dz = qz - z; nn_merge(bestC, bposC, (dx * dx + dy * dy) + dz * dz, p0.pos, perm_g); }
                     }
                     if (hd.count > 1u && hd.da1_lo <= rf) {   // (the usual case: the second neighbour cannot qualify and its line is not even fetched)
                         for (uint32_t si = 1u; si < hd.count; ++si) {
