@@ -29,7 +29,7 @@
  *                                                         in rounds of leaves (same results; A/B timing)
  *   IBA_DONE_FLAG                                         0: a blocking call polls its stream (rounds 3-4) instead of the sequence number the summing
  *                                                         kernel's last block publishes in pinned memory (same results; A/B timing)
- *   IBA_NN_LIST                                           1: the anchored lists are walked by iba_nn_list_kernel's persistent grid (measured slower; csrc/iba_nn_list_kernel.hpp);
+ *   IBA_NN_LIST                                           1: the anchored lists are walked by the persistent list kernel, measured slower: csrc/iba_nn_list_kernel.hpp;
  *                                                         IBA_NN_LIST_WORKERS=n: its blocks per CU
  *   IBA_FACTOR_V2                                         1: the normal equations by iba_factor2_kernel — one wave per equal share of a candidate's whole work
  *                                                         list (csrc/iba_factor2_kernel.hpp) — instead of one wave per (keyframe, candidate); same sums to
@@ -91,7 +91,7 @@ int32_t iba_debug_pairs_builds(const iba_handle* h);
 /* diagnostic: list entries of the last evaluation (all candidates) that the anchored neighbour lists could not settle and the
  * tree search took over; -1 when no search ran */
 double iba_debug_nn_left_to_tree(iba_handle* h);
-int32_t iba_debug_last_nn_list(const iba_handle* h);   /* > 0: the last search launch was iba_nn_list_kernel (IBA_NN_LIST=1, opt-in) with that many workers per (XCD, group) */
+int32_t iba_debug_last_nn_list(const iba_handle* h);   /* > 0: the last search launch was the opt-in persistent list kernel, IBA_NN_LIST=1, with that many workers per XCD and group */
 /* diagnostic: mean number of (scan point, keypoint) pairs per keyframe that the last shared pair search listed; -1: none ran */
 double iba_debug_mean_pairs(iba_handle* h);
 /* debug (host only): R[9], t[3], dR/d omega_k [3][9], dt/dx_k [6][3], s of a candidate as the factor kernel reads them (58 doubles) */
