@@ -26,6 +26,9 @@
 
 namespace iba {
 
+#ifndef IBA_PAIRS_CUT
+#define IBA_PAIRS_CUT 0   /* timing experiment (tools/pairs_cuts.sh): iba_pairs_kernel ends behind its k-th phase; results invalid */
+#endif
 #ifndef IBA_NN_EXP
 #define IBA_NN_EXP 0
 #endif
@@ -864,6 +867,9 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
     }
     __syncthreads();
     if (!s_n[3]) return;   // no candidate sees any point of this block
+#if IBA_PAIRS_CUT == 1
+    return;
+#endif
     if (dense && pos < P) pv = p4[pos];
     // ---- how far the candidates move the points of THIS block (512 consecutive tree positions: a box with centre c and half extent
     //      e in the LiDAR frame, qc = R_0 c + t_0, ex = |R_0| e under the reference): candidate b moves q_0 by M_b q_0 + a_b
@@ -915,6 +921,9 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
         __syncthreads();
         wdx = (double)s_delta[0]; wdy = (double)s_delta[1]; wdz = (double)s_delta[2];
     }
+#if IBA_PAIRS_CUT == 2
+    return;
+#endif
     // ---- the point under the reference candidate, the batch's bound on its motion, its search window ----
     int kind = 0;   // 0: nothing to do, 1: walk the grid, 2: hard point
     double u0 = 0, v0 = 0, r = 0;
@@ -958,6 +967,9 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
         for (int w = 0; w < kPairsThreads / 64; ++w) walk |= s_n[4 + w];
         if (!walk) return;   // no point of this block can meet a keypoint under any candidate
     }
+#if IBA_PAIRS_CUT == 3
+    return;
+#endif
     if (dense) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {   // (the loads of the two passes in flight together)
@@ -975,6 +987,9 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
     for (uint32_t i = threadIdx.x + 2u * kPairsThreads; i < ncs; i += kPairsThreads) s_cstart[i] = (uint16_t)gcs[i];
     for (uint32_t i = threadIdx.x + 2u * kPairsThreads; i < K; i += kPairsThreads) s_kuv[i] = guv[i];
     __syncthreads();
+#if IBA_PAIRS_CUT == 4
+    return;
+#endif
     if (kind == 1) {
         // keypoints within r of (u0, v0): the coarse CSR of the keypoint grid (record e of the grid IS keypoint e)
         const int x0c = grid_cell((float)(u0 - r) - 0.01f, gw) >> kCoarseShift, x1c = grid_cell((float)(u0 + r) + 0.01f, gw) >> kCoarseShift;
@@ -998,6 +1013,9 @@ __global__ __launch_bounds__(kPairsThreads) void iba_pairs_kernel(PairsArgs pa_b
         }
     }
     __syncthreads();
+#if IBA_PAIRS_CUT == 5
+    return;
+#endif
     const uint32_t n = min(s_n[0], (uint32_t)kPairStage);
     if (n == 0u) return;
     if (threadIdx.x == 0) s_n[1] = atomicAdd(&cnt[0], n);
