@@ -29,6 +29,7 @@
  *                                                         in rounds of leaves (same results; A/B timing)
  *   IBA_DONE_FLAG                                         0: a blocking call polls its stream (rounds 3-4) instead of the sequence number the summing
  *                                                         kernel's last block publishes in pinned memory (same results; A/B timing)
+ *   IBA_NN_SMALL, IBA_NN_SMALL_MIN_B                      0 / 1: the search kernel in blocks of four waves / of one wave whatever the size of the kd trees; from how many candidates per launch
  *   IBA_NN_LIST                                           1: the anchored lists are walked by the persistent list kernel, measured slower: csrc/iba_nn_list_kernel.hpp;
  *                                                         IBA_NN_LIST_WORKERS=n: its blocks per CU
  *   IBA_FACTOR_V2                                         1: the normal equations by iba_factor2_kernel — one wave per equal share of a candidate's whole work
@@ -91,6 +92,7 @@ int32_t iba_debug_pairs_builds(const iba_handle* h);
 /* diagnostic: list entries of the last evaluation (all candidates) that the anchored neighbour lists could not settle and the
  * tree search took over; -1 when no search ran */
 double iba_debug_nn_left_to_tree(iba_handle* h);
+int32_t iba_debug_last_nn_threads(const iba_handle* h);   /* threads per block of the last search launch: 64 = one-wave blocks (small kd trees, 12 candidates or more), 256 otherwise */
 int32_t iba_debug_last_nn_list(const iba_handle* h);   /* > 0: the last search launch was the opt-in persistent list kernel, IBA_NN_LIST=1, with that many workers per XCD and group */
 /* diagnostic: mean number of (scan point, keypoint) pairs per keyframe that the last shared pair search listed; -1: none ran */
 double iba_debug_mean_pairs(iba_handle* h);

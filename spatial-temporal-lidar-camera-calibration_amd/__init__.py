@@ -329,6 +329,13 @@ class IbaHandle:
         return int(self.lib.iba_debug_factor_ranges(self.h, C.c_int32(B)))
 
     @property
+    def last_nn_threads(self):
+        """threads per block of the last search launch (64: one-wave blocks; 256)"""
+        self.lib.iba_debug_last_nn_threads.argtypes = [C.c_void_p]
+        self.lib.iba_debug_last_nn_threads.restype = C.c_int32
+        return int(self.lib.iba_debug_last_nn_threads(self.h))
+
+    @property
     def last_nn_list(self):
         """> 0: the last search launch was iba_nn_list_kernel (opt-in, IBA_NN_LIST=1) with that many workers per (XCD, group of candidates)"""
         self.lib.iba_debug_last_nn_list.argtypes = [C.c_void_p]

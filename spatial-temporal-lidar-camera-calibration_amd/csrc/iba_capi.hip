@@ -97,8 +97,11 @@ struct iba_handle {
     bool nn_list = false;                 // IBA_NN_LIST=1 (opt-in, measured slower: see iba_nn_list_kernel.hpp): the anchored lists are walked by iba_nn_list_kernel's persistent grid instead of iba_nn_kernel's one block per slice
     int nn_list_workers = 0;              // IBA_NN_LIST_WORKERS: blocks of iba_nn_list_kernel per CU (0: what the LDS and 4 waves per SIMD allow)
     int n_cus = 256;                      // compute units of the device (MI355X: 256)
+    int last_nn_threads = 0;              // diagnostic: threads per block of the last iba_nn_kernel launch
     int last_nn_list = 0;                 // diagnostic: workers per (XCD, group) of the last iba_nn_list_kernel launch (0: iba_nn_kernel ran)
-    int nn_cg_max = 8;                    // candidates per search block (power of two <= kMaxGroup)
+    int nn_cg_max = kMaxGroup < 8 ? kMaxGroup : 8;   // candidates per search block (power of two <= kMaxGroup)
+    int nn_small_min_b = 12;              // ... from this many candidates per launch (IBA_NN_SMALL_MIN_B)
+    bool nn_small = false;                // the search kernel runs one-wave blocks (kNNThreadsSmall): decided at create from the size of the keyframes' kd trees; IBA_NN_SMALL=0 / 1 forces it
     bool nn_cg_fixed = false;             // IBA_NN_CG given: no adaptation to the batch size
     bool nn_rounds = true;                // IBA_NN_ROUNDS=0: the entries the anchored lists leave over are searched leaf by leaf (rounds 3-4) instead of in rounds of leaves
     DevBuf<uint32_t> d_lcount, d_lcount_frozen;   // work-list length per (candidate, frame)
@@ -311,14 +314,14 @@ bool layout_assoc(iba_handle* h, LdsLayout& L) {
 }
 
 // LDS plan of iba_nn_kernel: kd nodes, counters, the candidates' transform constants and one result slot (8 B) per work entry
-bool layout_nn(const iba_handle* h, NNLayout& L) {
+bool layout_nn(const iba_handle* h, NNLayout& L, const int max_group = kMaxGroup) {   // max_group: candidates per block of the block shape (kMaxGroup, or 2 for one-wave blocks)
     L = NNLayout{};
     uint32_t off = 0;
     L.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
     off = align_up(off, 16); L.off_misc = off; off += 128u;
-    off = align_up(off, 16); L.off_cd = off; off += 8u * (uint32_t)kCdDoubles * (uint32_t)kMaxGroup;
-    off = align_up(off, 16); L.off_res = off; off += 8u * kSliceW * (uint32_t)kMaxGroup;
-    L.off_ovf = off; off += 4u * kSliceW * (uint32_t)kMaxGroup;   // work entries left to the tree search when the batch's neighbour sets are in use
+    off = align_up(off, 16); L.off_cd = off; off += 8u * (uint32_t)kCdDoubles * (uint32_t)max_group;
+    off = align_up(off, 16); L.off_res = off; off += 8u * kSliceW * (uint32_t)max_group;
+    L.off_ovf = off; off += 4u * kSliceW * (uint32_t)max_group;   // work entries left to the tree search when the batch's neighbour sets are in use
     L.total = off;
     off = align_up(off, 16); L.off_res2 = off;   // (iba_nn_list_kernel launches with total + one more result buffer)
     return L.total <= kLdsBytes;
@@ -727,12 +730,16 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     // short of blocks and every block waits for its slowest search: fewer per block below 24 candidates (measured at 200 keyframes:
     // 8 candidates 0.122 -> 0.082 ms, 14 candidates 0.112 -> 0.101 ms; the sums do not depend on the grouping)
     // (r04, with the anchored lists' direct pass: 14 candidates 81.4 -> 84.5 k evaluations/s with 8 per block instead of 4, 8 candidates best with 4)
-    const int cg_cap = h->nn_cg_fixed ? h->nn_cg_max : std::min(h->nn_cg_max, B >= 12 ? 8 : (B >= 6 ? 4 : 2));
+    // (round 6) the block shape of the search kernel: one wave and two candidates per block while the keyframes' trees are small (nn_small: see kNNThreadsSmall), else four waves
+    // and up to eight; the refit chain (plane_cache = 0) keeps the four-wave shape
+    const bool nn_small = h->nn_small && h->params.plane_cache && B >= h->nn_small_min_b;   // (a small batch keeps the four-wave blocks: 1 candidate 0.035 vs 0.038 ms, 8: 0.082 vs 0.088, 14: 0.081 vs 0.078, 64: 0.265 vs 0.252 — tools/latency_probe.py, cost tuple)
+    const int nn_threads = nn_small ? kNNThreadsSmall : kNNThreads, nn_mg = nn_threads / 32 < 16 ? nn_threads / 32 : 16;
+    const int cg_cap = std::min(nn_mg, h->nn_cg_fixed ? h->nn_cg_max : std::min(h->nn_cg_max, B >= 12 ? 8 : (B >= 6 ? 4 : 2)));
     int CG = 1; while (CG < std::min(B, cg_cap)) CG <<= 1;
     const int ngroups = (B + CG - 1) / CG;
     const int NS = h->nn_ns;
     NNLayout nl;
-    if (!layout_nn(h, nl)) return fail(h, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel");
+    if (!layout_nn(h, nl, nn_mg)) return fail(h, IBA_ERR_UNSUPPORTED, "kd tree exceeds the LDS plan of the search kernel");
     if (h->part_cap < B) { iba_status es = ensure_lists(h, B, st); if (es != IBA_OK) return es; }   // (the frozen problem's chain: one candidate)
     // the candidate block of this chain: still in the pinned ring (the first kernel below carries it to the device: chain_fold) or copied already
     const bool head = h->head_pending; h->head_pending = false;
@@ -848,7 +855,7 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
                 AnchorRef& ar = h->anchor_ref[slot];
                 for (int i = 0; i < 9; ++i) ar.M[i] = c.s * c.Ri[i];
                 for (int i = 0; i < 3; ++i) ar.t[i] = c.ti[i];
-                hipLaunchKernelGGL(iba_anchor_kernel, dim3((h->max_mpk + kNNThreads - 1) / kNNThreads, nf), dim3(kNNThreads), 8u * std::max(h->maxNodes, 1u), st, AnchorArgs{dp, h->dprm, ar}, h->d_anchor.p + (size_t)slot * h->anchor_set_elems);
+                hipLaunchKernelGGL(iba_anchor_kernel, dim3((h->max_mpk + kAnchorThreads - 1) / kAnchorThreads, nf), dim3(kAnchorThreads), 8u * std::max(h->maxNodes, 1u), st, AnchorArgs{dp, h->dprm, ar}, h->d_anchor.p + (size_t)slot * h->anchor_set_elems);
                 HIP_TRY(h, hipGetLastError());
                 h->anchor_valid[slot] = true; h->calls_since_anchor[slot] = 0; ++h->anchor_builds;
             }
@@ -910,9 +917,9 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
     bool he_in_search = false;
     if (search) {
         // the hand-eye terms of a cost evaluation ride in front of the search's grid (two lanes per term), padded to a multiple of 8 blocks
-        const int he_blocks = (want & 2) ? (B * nf + kNNThreads / 2 - 1) / (kNNThreads / 2) : 0;
+        const int he_blocks = (want & 2) ? (B * nf + nn_threads / 2 - 1) / (nn_threads / 2) : 0;
         he_in_search = he_blocks > 0;
-        const dim3 grid(8 * per_xcd * ngroups * NS + ((he_blocks + 7) & ~7)), block(kNNThreads);
+        const dim3 grid(8 * per_xcd * ngroups * NS + ((he_blocks + 7) & ~7)), block(nn_threads);
         NNArgs na{dp, h->dprm, nl, (unsigned long long)(h->anchor_set_elems * sizeof(SetPt)), h->nn_rounds ? 1u : 0u, {0}};
         std::memcpy(na.anchor_sel, h->anchor_sel, sizeof(na.anchor_sel));
         const bool wA = (want & 1) != 0, wC = (want & 2) && h->dprm.use_3d3d;
@@ -923,20 +930,38 @@ iba_status run_split(iba_handle* h, const Cand* dc, int B, int want, bool frozen
             const int heb = MODE == kRefitSums ? 0 : he_blocks;   // (the second launch of a refit chain only sums)
             const dim3 grid_m(MODE == kRefitSums ? 8 * per_xcd * ngroups * NS : grid.x);
             auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid_m, block, nl.total, st, na, dc, B, CG, NS, h->d_nn_partials.p, nn_nrec, fl, lc, (int)h->lstride, h->nn_dbg, h->d_frefit.p, anchor, h->d_he.p, heb); };
-            h->last_nn_list = 0;
+            h->last_nn_list = 0; h->last_nn_threads = nn_threads;
             const bool small_bufs = (size_t)B * nf * h->lstride * 16u < 0xFFFFFF00ull && (size_t)kAnchorSets * h->anchor_set_elems * sizeof(SetPt) < 0xFFFFFF00ull && (size_t)dp.n_kp_total * 16u < 0x80000000ull;   // (32-bit buffer offsets)
-            if (sets && MODE == 0 && h->nn_list && small_bufs && CG >= 4 && (kSliceW * (uint32_t)CG) % (2u * (uint32_t)kNNThreads) == 0u && (kSliceW * (uint32_t)CG) / (uint32_t)kNNThreads <= 4u) {
-                // the persistent form (iba_nn_list_kernel): R workers per (XCD, group of candidates), as many blocks as the machine holds at once
-                const uint32_t lds = align_up(nl.off_res2 + 8u * kSliceW * (uint32_t)kMaxGroup, 16);
-                const int per_cu = h->nn_list_workers > 0 ? h->nn_list_workers : std::max(1, std::min(4 * IBA_NN_LIST_WAVES * 64 / kNNThreads, (int)(kLdsBytes / lds)));
-                const int R = std::max(1, std::min(per_xcd * NS, (h->n_cus * per_cu) / (8 * ngroups)));
+            // (the opt-in persistent form keeps its own block shape: 256 threads, up to 8 candidates per block; its LDS plan and hand-eye blocks follow that shape)
+            int CGl = 1; { const int capl = B >= 12 ? 8 : (B >= 6 ? 4 : 2); while (CGl < std::min(B, capl)) CGl <<= 1; }
+            if (sets && MODE == 0 && h->nn_list && small_bufs && CGl >= 4 && (kSliceW * (uint32_t)CGl) % (2u * (uint32_t)kNLThreads) == 0u && (kSliceW * (uint32_t)CGl) / (uint32_t)kNLThreads <= 4u) {
+                NNLayout ll{};
+                {
+                    uint32_t off = 0;
+                    ll.off_nodes = off; off += 8u * std::max(h->maxNodes, 1u);
+                    off = align_up(off, 16); ll.off_misc = off; off += 128u;
+                    off = align_up(off, 16); ll.off_cd = off; off += 8u * (uint32_t)kCdDoubles * (uint32_t)kNLMaxGroup;
+                    off = align_up(off, 16); ll.off_res = off; off += 8u * kSliceW * (uint32_t)kNLMaxGroup;
+                    ll.off_ovf = off; off += 4u * kSliceW * (uint32_t)kNLMaxGroup;
+                    ll.total = off; off = align_up(off, 16); ll.off_res2 = off;
+                }
+                const uint32_t lds = align_up(ll.off_res2 + 8u * kSliceW * (uint32_t)kNLMaxGroup, 16);
+                const int ngl = (B + CGl - 1) / CGl;
+                const int hebl = (want & 2) ? (B * nf + kNLThreads / 2 - 1) / (kNLThreads / 2) : 0;
+                const int per_cu = h->nn_list_workers > 0 ? h->nn_list_workers : std::max(1, std::min(4 * IBA_NN_LIST_WAVES * 64 / kNLThreads, (int)(kLdsBytes / lds)));
+                const int R = std::max(1, std::min(per_xcd * NS, (h->n_cus * per_cu) / (8 * ngl)));
                 h->last_nn_list = R;
-                const dim3 grid_l(8 * ngroups * R + ((heb + 7) & ~7));
-                auto gol = [&](auto kern) { hipLaunchKernelGGL(kern, grid_l, block, lds, st, na, dc, B, CG, NS, R, h->d_nn_partials.p, nn_nrec, fl, lc, (int)h->lstride, h->nn_dbg, anchor, h->d_he.p, heb); };
-                const bool four = (kSliceW * (uint32_t)CG) / (uint32_t)kNNThreads == 4u;
+                NNArgs nal = na; nal.lay = ll;
+                const dim3 grid_l(8 * ngl * R + ((hebl + 7) & ~7));
+                auto gol = [&](auto kern) { hipLaunchKernelGGL(kern, grid_l, dim3(kNLThreads), lds, st, nal, dc, B, CGl, NS, R, h->d_nn_partials.p, nn_nrec, fl, lc, (int)h->lstride, h->nn_dbg, anchor, h->d_he.p, hebl); };
+                const bool four = (kSliceW * (uint32_t)CGl) / (uint32_t)kNLThreads == 4u;
                 if (wA && wC) { if (four) gol(iba_nn_list_kernel<3, 4>); else gol(iba_nn_list_kernel<3, 2>); }
                 else if (wA) { if (four) gol(iba_nn_list_kernel<1, 4>); else gol(iba_nn_list_kernel<1, 2>); }
                 else { if (four) gol(iba_nn_list_kernel<2, 4>); else gol(iba_nn_list_kernel<2, 2>); }
+            }
+            else if (MODE == 0 && nn_small) {   // (one-wave blocks: instantiated for the memoised-plane chain only)
+                if (sets) { if (wA && wC) go(iba_nn_kernel<3, 0, 1, kNNThreadsSmall>); else if (wA) go(iba_nn_kernel<1, 0, 1, kNNThreadsSmall>); else go(iba_nn_kernel<2, 0, 1, kNNThreadsSmall>); }
+                else { if (wA && wC) go(iba_nn_kernel<3, 0, 0, kNNThreadsSmall>); else if (wA) go(iba_nn_kernel<1, 0, 0, kNNThreadsSmall>); else go(iba_nn_kernel<2, 0, 0, kNNThreadsSmall>); }
             }
             else if (sets && MODE != kRefitSums) { if (wA && wC) go(iba_nn_kernel<3, MODE, 1>); else if (wA) go(iba_nn_kernel<1, MODE, 1>); else go(iba_nn_kernel<2, MODE, 1>); }
             else { if (wA && wC) go(iba_nn_kernel<3, MODE, 0>); else if (wA) go(iba_nn_kernel<1, MODE, 0>); else go(iba_nn_kernel<2, MODE, 0>); }
@@ -1288,6 +1313,10 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
     // 6: 0.129, 7 (what this shape needs): 0.120, 8: 0.184, 9: 0.126; at 40 x 120 k points (needs 8) 0.169 -> 0.161 ms with 9. The extra slice's
     // blocks return at once.
     h->nn_ns = (int)((h->lstride + kSliceW - 1u) / kSliceW) | 1;
+    // one-wave search blocks while a block's LDS plan (the tree's nodes + ~3 KB) lets a CU hold 16 of them (see kNNThreadsSmall)
+    h->nn_small = 8u * std::max(h->maxNodes, 1u) <= 6144u;
+    if (const char* e = dbg_env("IBA_NN_SMALL")) h->nn_small = std::atoi(e) != 0;
+    if (const char* e = dbg_env("IBA_NN_SMALL_MIN_B")) h->nn_small_min_b = std::max(1, std::atoi(e));
 
     auto bail = [&](const char* what, hipError_t er) { std::string m = std::string(what) + ": " + hipGetErrorString(er); iba_destroy(h); return fail(nullptr, IBA_ERR_HIP, m); };
 #define UP(buf, vec) do { hipError_t _e = h->buf.upload(vec); if (_e != hipSuccess) return bail("upload " #buf, _e); } while (0)
@@ -1403,6 +1432,10 @@ iba_status iba_create_ex(const iba_problem_desc* d, const iba_params* params, in
                             (const void*)iba_nn_kernel<1, 0, 1>, (const void*)iba_nn_kernel<2, 0, 1>, (const void*)iba_nn_kernel<3, 0, 1>, (const void*)iba_nn_kernel<1, 1, 1>, (const void*)iba_nn_kernel<2, 1, 1>,
                             (const void*)iba_nn_kernel<3, 1, 1>};
     for (const void* fn : nfns)
+        if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
+    const void* sfns[6] = {(const void*)iba_nn_kernel<1, 0, 0, kNNThreadsSmall>, (const void*)iba_nn_kernel<2, 0, 0, kNNThreadsSmall>, (const void*)iba_nn_kernel<3, 0, 0, kNNThreadsSmall>,
+                           (const void*)iba_nn_kernel<1, 0, 1, kNNThreadsSmall>, (const void*)iba_nn_kernel<2, 0, 1, kNNThreadsSmall>, (const void*)iba_nn_kernel<3, 0, 1, kNNThreadsSmall>};
+    for (const void* fn : sfns)
         if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes)) != hipSuccess) return bail("hipFuncSetAttribute", er);
     const void* lfns[6] = {(const void*)iba_nn_list_kernel<1, 2>, (const void*)iba_nn_list_kernel<2, 2>, (const void*)iba_nn_list_kernel<3, 2>, (const void*)iba_nn_list_kernel<1, 4>, (const void*)iba_nn_list_kernel<2, 4>, (const void*)iba_nn_list_kernel<3, 4>};
     for (const void* fn : lfns)
@@ -1655,6 +1688,7 @@ iba_status iba_debug_phase_cycles12(iba_handle* h, uint64_t out12[12], int32_t r
     if (reset && hipMemset(h->d_diag.p + 8, 0, 96) != hipSuccess) return fail(h, IBA_ERR_HIP, "memset");
     return IBA_OK;
 }
+int32_t iba_debug_last_nn_threads(const iba_handle* h) { return h ? h->last_nn_threads : -1; }   // threads per block of the last search launch (64: one-wave blocks, 256)
 int32_t iba_debug_last_nn_list(const iba_handle* h) { return h ? h->last_nn_list : -1; }   // workers per (XCD, group) of the last search launch if it was iba_nn_list_kernel's (0: iba_nn_kernel)
 int32_t iba_debug_pairs_builds(const iba_handle* h) { return h ? h->pairs_builds : -1; }
 int32_t iba_debug_anchor_builds(const iba_handle* h) { return h ? h->anchor_builds : -1; }

@@ -29,12 +29,14 @@
 // would pay is the same walk at >= 4 waves / SIMD (rows through LDS instead of registers) or two entries' chains interleaved in one wave.
 //
 // grid: hand-eye blocks (as iba_nn_kernel) + 8 XCDs x NG groups x R workers. Launched only when the anchored lists are there, the planes are
-// memoised, a group holds at least 4 candidates (STEPS = kSliceW * CG / kNNThreads = 2 or 4) and every buffer stays below 4 GB (32-bit offsets).
+// memoised, a group holds at least 4 candidates (STEPS = kSliceW * CG / 256 = 2 or 4) and every buffer stays below 4 GB (32-bit offsets).
 #pragma once
 #include "iba_split_kernels.hpp"
 
 namespace iba {
 
+// the persistent kernel keeps the block shape it was built and measured with (four waves, up to eight candidates), whatever iba_nn_kernel's is
+constexpr int kNLThreads = 256, kNLMaxGroup = 8, kNLCoopLimit = kNLThreads / 2;
 #ifndef IBA_NN_LIST_SEARCH_ATTR
 #define IBA_NN_LIST_SEARCH_ATTR __forceinline__
 #endif
@@ -50,11 +52,11 @@ __device__ IBA_NN_LIST_SEARCH_ATTR void nn_list_search(const int f, const int sl
 #define dp (ka->dp)
 #define prm (ka->prm)
 #define lay (ka->lay)
-    constexpr int T = kNNThreads;
+    constexpr int T = kNLThreads;
     const int tid = tid_in, lane = tid & 63;
     const int nf = dp.n_frames;
     TreeNode* s_nodes = (TreeNode*)(smem + lay.off_nodes);
-    uint32_t* s_ctr = (uint32_t*)(smem + lay.off_misc) + kMaxGroup;
+    uint32_t* s_ctr = (uint32_t*)(smem + lay.off_misc) + kNLMaxGroup;
     double* s_cd = (double*)(smem + lay.off_cd);
     uint32_t* s_ovf = (uint32_t*)(smem + lay.off_ovf);
     typedef __attribute__((address_space(4))) const FrameHdr FrameHdrC;
@@ -130,7 +132,7 @@ __device__ IBA_NN_LIST_SEARCH_ATTR void nn_list_search(const int f, const int sl
         if ((WHICH & 1) && actA && sd.x != kNone) { const float4 pv = p4[sd.x]; const double dx = ax - (double)pv.x, dy = ay - (double)pv.y, dz = az - (double)pv.z; bestA = (dx * dx + dy * dy) + dz * dz; bposA = sd.x; }
         if ((WHICH & 2) && actC && sd.y != kNone) { const float4 pv = p4[sd.y]; const double dx = qx - (double)pv.x, dy = qy - (double)pv.y, dz = qz - (double)pv.z; bestC = (dx * dx + dy * dy) + dz * dz; bposC = sd.y; }
     };
-    const bool coop = c_end <= (uint32_t)kCoopLimit;
+    const bool coop = c_end <= (uint32_t)kNLCoopLimit;
     if (coop && dbg != 4) {   // a few entries: a group of lanes each
         int G = 64; while ((uint32_t)(T / G) < c_end && G > 2) G >>= 1;
         for (uint32_t q = (uint32_t)tid / (uint32_t)G; q < c_end; q += (uint32_t)(T / G)) {
@@ -139,8 +141,8 @@ __device__ IBA_NN_LIST_SEARCH_ATTR void nn_list_search(const int f, const int sl
             make_queries(wn & ((1u << cg_shift) - 1u), e, mp);
             lane_nn_begin(IBA_LANE_NN_PASS);
             seed(wn);
-            const int round_cap = min(kRoundLeaves, (int)((kSliceW * (uint32_t)kMaxGroup - (uint32_t)kCoopLimit) / (uint32_t)(T / G)));
-            uint32_t* s_leaf = s_ovf + kCoopLimit + ((uint32_t)tid / (uint32_t)G) * (uint32_t)round_cap;
+            const int round_cap = min(kRoundLeaves, (int)((kSliceW * (uint32_t)kNLMaxGroup - (uint32_t)kNLCoopLimit) / (uint32_t)(T / G)));
+            uint32_t* s_leaf = s_ovf + kNLCoopLimit + ((uint32_t)tid / (uint32_t)G) * (uint32_t)round_cap;
             if (dbg == 6) {}
             else if (ka->nn_rounds) do wave_nn_round<WHICH>(IBA_LANE_NN_PASS, tid & (G - 1), G, s_nodes, p4, perm_g, P, D, s_leaf, round_cap); while (go >= 0 && dbg != 7);
             else do wave_nn_visit<WHICH>(IBA_LANE_NN_PASS, tid & (G - 1), G, s_nodes, p4, perm_g, P, D); while (go >= 0 && dbg != 7);
@@ -193,13 +195,13 @@ __device__ IBA_NN_LIST_SEARCH_ATTR void nn_list_search(const int f, const int sl
 #define IBA_NN_LIST_WAVES 2   /* waves per SIMD iba_nn_list_kernel is compiled for (256 VGPRs: the rows of a whole item in flight beside a pick; its own loads run ahead of its arithmetic) */
 #endif
 template <int WHICH, int STEPS>
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_NN_LIST_WAVES, IBA_NN_LIST_WAVES))) void iba_nn_list_kernel(
+__global__ __launch_bounds__(kNLThreads) __attribute__((amdgpu_waves_per_eu(IBA_NN_LIST_WAVES, IBA_NN_LIST_WAVES))) void iba_nn_list_kernel(
     NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS, int R, double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist,
     const uint32_t* __restrict__ lcount, int flist_stride, int dbg, const SetPt* __restrict__ anchor, double* __restrict__ he_out, int he_blocks) {
     extern __shared__ __align__(16) unsigned char smem[];
     if ((int)blockIdx.x < he_blocks) {   // K7 rides in front, as in iba_nn_kernel
         const int nfh = ka_by_value.dp.n_frames;
-        const int i = (int)blockIdx.x * (kNNThreads / 2) + (int)(threadIdx.x >> 1);
+        const int i = (int)blockIdx.x * (kNLThreads / 2) + (int)(threadIdx.x >> 1);
         const bool live = i < B * nfh;
         const int ii = live ? i : 0;
         const double v = he_term(ka_by_value.dp.frames[ii % nfh], cands[ii / nfh], threadIdx.x & 1, live);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
 #define dp (ka->dp)
 #define prm (ka->prm)
 #define lay (ka->lay)
-    constexpr int T = kNNThreads;
+    constexpr int T = kNLThreads;
     constexpr uint32_t kWantMask = ((WHICH & 2) ? kFlagC : 0u) | ((WHICH & 1) ? kFlagA : 0u);
     const int tid = threadIdx.x;
 #ifdef IBA_DIAG_COUNTERS
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(IBA_
 
     double* s_res0 = (double*)(smem + lay.off_res);
     double* s_res1 = (double*)(smem + lay.off_res2);
-    uint32_t* s_ctr = (uint32_t*)(smem + lay.off_misc) + kMaxGroup;   // [0]: next unclaimed left-over entry; [1..3]: left-over counts of the items k % 3
+    uint32_t* s_ctr = (uint32_t*)(smem + lay.off_misc) + kNLMaxGroup;   // [0]: next unclaimed left-over entry; [1..3]: left-over counts of the items k % 3
     double* s_cd = (double*)(smem + lay.off_cd);
     uint32_t* s_ovf = (uint32_t*)(smem + lay.off_ovf);
 

@@ -35,6 +35,12 @@ namespace iba {
 #ifndef IBA_NN_THREADS
 #define IBA_NN_THREADS 256
 #endif
+// (round 6) iba_nn_kernel is also built with ONE wave per block and two candidates per block (kNNThreadsSmall), which the host picks while a keyframe's kd tree is small (its
+// LDS copy is reserved per block: 4 KB at 10 k points per scan, 64 KB at 120 k): 0.1058 -> 0.0909 ms at the bench shape (128 threads / 4 candidates: 0.0955; 256 / 8, rounds
+// 2-5: 0.1058; 512 / 16: 0.128 — tools/experiments/README.md). The kernel is bound by instruction issue over dependent chains with the blocks of a CU in step; single-wave
+// blocks come and go one by one, their barriers cost nothing, and 44 800 of them fill the tail of the launch evenly. At 120 k points per scan the same shape is 18 % slower
+// (1.52 -> 1.80 ms per call: two blocks of one wave per CU beside their trees), hence the choice per handle. (The sums use 32 threads per candidate: a wave holds two.)
+constexpr int kNNThreadsSmall = 64;
 constexpr int kNNThreads = IBA_NN_THREADS;
 constexpr int kNNWaves = kNNThreads / 64;
 #ifndef IBA_NN_SLICE
@@ -1759,19 +1765,20 @@ __device__ __forceinline__ const AnchorHdr* anchor_hdr(const unsigned char* r) {
 __device__ __forceinline__ const SetPt* anchor_pt(const unsigned char* r, uint32_t i) { return (const SetPt*)(r + (i == 0u ? 48u : 128u + (i - 1u) * 48u)); }
 struct AnchorRef { double M[9], t[3]; };   // s_a Ri_a, ti_a of the anchor extrinsic: q_a = M m + t
 struct AnchorArgs { DevProblem dp; DevParams prm; AnchorRef ar; };
-// grid: (ceil(max MapPoint keypoints of a frame / kNNThreads), frames); one lane per MapPoint keypoint; dynamic LDS: the tree nodes
-__global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, SetPt* __restrict__ rows) {
+// grid: (ceil(max MapPoint keypoints of a frame / kAnchorThreads), frames); one lane per MapPoint keypoint; dynamic LDS: the tree nodes
+constexpr int kAnchorThreads = 256;
+__global__ __launch_bounds__(kAnchorThreads) void iba_anchor_kernel(AnchorArgs a, SetPt* __restrict__ rows) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevProblem& dp = a.dp;
     const DevParams& prm = a.prm;
     const int f = blockIdx.y;
     const FrameHdr& h = dp.frames[f];
-    if (blockIdx.x * (uint32_t)kNNThreads >= h.n_mpk) return;
+    if (blockIdx.x * (uint32_t)kAnchorThreads >= h.n_mpk) return;
     TreeNode* s_nodes = (TreeNode*)smem;
     const uint32_t P = h.P, D = h.depth;
-    for (uint32_t i = threadIdx.x; i < (1u << D) - 1u; i += kNNThreads) s_nodes[i] = dp.nodes[h.node_base + i];
+    for (uint32_t i = threadIdx.x; i < (1u << D) - 1u; i += kAnchorThreads) s_nodes[i] = dp.nodes[h.node_base + i];
     __syncthreads();
-    const uint32_t j = blockIdx.x * (uint32_t)kNNThreads + threadIdx.x;
+    const uint32_t j = blockIdx.x * (uint32_t)kAnchorThreads + threadIdx.x;
     if (j >= h.n_mpk) return;
     const uint32_t k = dp.mpk[h.mpk_base + j];
     unsigned char* row = (unsigned char*)anchor_row(rows, (size_t)f * dp.max_k + k);
@@ -1901,8 +1908,8 @@ __global__ __launch_bounds__(kNNThreads) void iba_anchor_kernel(AnchorArgs a, Se
 // ------------------------------------------------------------------------------------------------------------------
 // SETS 1: the anchored neighbour lists are in use (anchor != nullptr); compiled for 4 waves per SIMD — what its LDS allows anyway — so that the
 // direct pass keeps two entries' loads in registers
-template <int WHICH, int REFIT, int SETS>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS ? IBA_NN_SETS_WAVES : IBA_NN_WAVES, SETS ? IBA_NN_SETS_WAVES : IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
+template <int WHICH, int REFIT, int SETS, int T = kNNThreads>   // REFIT: 0 = planes memoised; plane_cache = 0 runs the kernel twice around iba_fit_kernel<.., 2>: kRefitSearch, then kRefitSums; T: threads per block (kNNThreads, or kNNThreadsSmall: see there)
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(SETS ? IBA_NN_SETS_WAVES : IBA_NN_WAVES, SETS ? IBA_NN_SETS_WAVES : IBA_NN_WAVES))) void iba_nn_kernel(NNArgs ka_by_value, const Cand* __restrict__ cands, int B, int CG, int NS,
                                                                                                   double* __restrict__ nn_partials, int nn_nrec, uint4* __restrict__ flist,
                                                                                                   const uint32_t* __restrict__ lcount, int flist_stride, int dbg, double4* __restrict__ frefit,
                                                                                                   const SetPt* __restrict__ anchor, double* __restrict__ he_out, int he_blocks) {
@@ -1912,7 +1919,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
     // the head of the chain (rounds 3-4) or inside the summing kernel's single block per candidate (13 us of dependent f64 there).
     if ((int)blockIdx.x < he_blocks) {
         const int nfh = ka_by_value.dp.n_frames;
-        const int i = (int)blockIdx.x * (kNNThreads / 2) + (int)(threadIdx.x >> 1);
+        const int i = (int)blockIdx.x * (T / 2) + (int)(threadIdx.x >> 1);
         const bool live = i < B * nfh;
         const int ii = live ? i : 0;
         const double v = he_term(ka_by_value.dp.frames[ii % nfh], cands[ii / nfh], threadIdx.x & 1, live);
@@ -1931,7 +1938,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SETS
 #define dp (ka->dp)
 #define prm (ka->prm)
 #define lay (ka->lay)
-    constexpr int T = kNNThreads;
+    constexpr int kMaxGroup = T / 32 < 16 ? T / 32 : 16, kCoopLimit = T / 2;   // (of THIS block shape: they shadow the namespace's, which are kNNThreads')
+    static_assert((int)(kSliceW * (uint32_t)kMaxGroup) - kCoopLimit >= T / 2 * 4 && 4 * (2 * kMaxGroup + 4) <= 128, "LDS plan of the block shape");
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef IBA_DIAG_COUNTERS
     unsigned long long nn_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nn_last = __builtin_readcyclecounter();   // cycles of thread 0 per phase -> dp.diag[8 + 2 i] (64-bit sums)

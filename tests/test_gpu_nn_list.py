@@ -70,3 +70,30 @@ def test_a_sparse_scene_and_the_frozen_problem(pkg, synth, abi, monkeypatch):
     for a, b in zip(h1.eval_factors(xs[:8]), h0.eval_factors(xs[:8])):
         _same(a, b)
     h1.close(); h0.close()
+
+
+def test_the_block_shape_of_the_search_kernel_does_not_change_a_bit(pkg, synth, abi, monkeypatch):
+    """iba_nn_kernel runs one-wave blocks of two candidates (small kd trees, 12 candidates or more per launch) or four-wave blocks of up to eight: the same searches, the
+    same result slots, and sums whose order depends on the list positions alone — every number must be identical, here at 64, 13 (one-wave) and 6 (four-wave either way)"""
+    prob, meta = synth.make_scene(n_frames=24, pts_per_frame=5000, seed=12)
+    p = abi.reference_yaml_params()
+    xs = synth.perturb(meta["x_gt"], np.random.default_rng(1), n=64)
+    monkeypatch.setenv("IBA_NN_SMALL", "0")
+    try:
+        h4 = pkg.IbaHandle(prob, p)
+    finally:
+        monkeypatch.delenv("IBA_NN_SMALL", raising=False)
+    h1 = pkg.IbaHandle(prob, p)
+    for n in (64, 13, 6):
+        c1, n1 = h1.eval_full(xs[:n]); c4, n4 = h4.eval_full(xs[:n])
+        assert h1.last_nn_threads == (64 if n >= 12 else 256) and h4.last_nn_threads == 256
+        for a, b in zip(n1, n4):
+            _same(a, b)
+        for a, b in zip(c1, c4):
+            assert _tup(a) == _tup(b)
+        for a, b in zip(h1.eval_cost(xs[:n]), h4.eval_cost(xs[:n])):
+            assert _tup(a) == _tup(b)
+    far = synth.perturb(meta["x_gt"], np.random.default_rng(3), rot=4e-3, trans=4e-2, n=32)   # entries left to the tree search
+    for a, b in zip(h1.eval_normal(far), h4.eval_normal(far)):
+        _same(a, b)
+    h1.close(); h4.close()
